@@ -1,0 +1,53 @@
+"""Builds the in-tree HIP shared library (libagx.so) for gfx950 with hipcc.
+
+The .so is git-ignored but travels to the GPU box with the gpurun snapshot.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libagx.so")
+
+SOURCES = ["agx_api.hip", "nn_forward.hip"]
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    for name in os.listdir(CSRC):
+        if os.path.getmtime(os.path.join(CSRC, name)) > t:
+            return True
+    if os.path.getmtime(os.path.join(HERE, "..", "include", "agx.h")) > t:
+        return True
+    return False
+
+
+def build(force=False, verbose=True):
+    if not force and not needs_build():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    procs = []
+    for src in SOURCES:
+        obj = os.path.join(CSRC, src.rsplit(".", 1)[0] + ".o")
+        objs.append(obj)
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+               "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append(subprocess.Popen(cmd))
+    for p in procs:
+        if p.wait() != 0:
+            raise RuntimeError("hipcc failed")
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

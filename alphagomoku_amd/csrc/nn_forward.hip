@@ -1,0 +1,623 @@
+/*
+ * nn_forward.hip — whole-tower policy/value forward for one board per workgroup, gfx950 (CDNA4).
+ *
+ * Replaces `graph.predict` of the ResnetPV graph (src/networks/networks.cpp:71-93; layers from
+ * src/networks/blocks.cpp:32-38 input block, :45-55 residual block, :99-107 policy head, :108-118 value head)
+ * after optimize(2) folded every BatchNormalization into the preceding layer (AGNetwork.cpp:136-160), plus
+ * `ml::unpackInput` (AGNetwork.cpp:249-258) which expands the bit-packed feature word of each cell
+ * (NNInputFeatures.cpp:59-113) to Cin = 32 channels of {0,1}.
+ *
+ * MI355X-first design (not how MinML runs it):
+ *   - A 15x15 board with F = 128 channels in fp16 is 57.6 KB, so TWO activation planes of a board fit in the
+ *     160 KB LDS of one CU.  One workgroup (4 waves, one per SIMD) therefore carries a board through the
+ *     entire tower — conv5x5, every residual block, both heads — without a single activation byte touching
+ *     HBM.  HBM traffic per position is the algorithmic minimum: 4*HW bytes in, 4*(HW+3) bytes out.
+ *   - Each convolution is an implicit GEMM on the matrix cores: D[out-ch][position] += W[out-ch][k] * X[k][position]
+ *     with v_mfma_f32_16x16x32_f16 (fp16 in, fp32 accumulate).  The WEIGHTS are the A operand and the
+ *     activations the B operand, so an accumulator lane ends up with 4 consecutive output channels of one
+ *     position = one 8-byte LDS store in NHWC order.
+ *   - The board is stored with a row stride of S = cols + 1 positions and one spare row above and below; the
+ *     spare column / rows are kept at zero, so a 3x3 tap is just a constant offset dy*S + dx in the flattened
+ *     position index — no bounds tests in the MFMA loop.
+ *   - LDS rows are XOR-swizzled at 16-byte granularity so that the 16 lanes of a ds_read_b128 group hit 16
+ *     different bank quads.
+ *   - Weights are pre-packed on the host in MFMA A-fragment order; each wave streams only the fragments of its
+ *     own output channels from L2 with fully coalesced 16-byte loads (no LDS round trip: no two waves of a
+ *     workgroup need the same weight fragment).
+ *   - The grid is persistent (one workgroup per CU) and strides over the batch.
+ */
+#include "agx_internal.hpp"
+
+#include <vector>
+#include <cstring>
+#include <cmath>
+
+namespace
+{
+	typedef _Float16 half_t;
+	typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+	typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+	typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+	struct NetParams
+	{
+			const half8 *w_in;      // packed conv5x5 fragments
+			const half8 *w_tower;   // packed 3x3 fragments: 2*blocks layers, then the policy conv
+			const float *bias;      // [1 + 2*blocks + 1][F]
+			const float *wp2;       // [F]
+			const float *wv1;       // [F][4]
+			const half_t *wv2;      // [HW*4][D]
+			const float *bv2;       // [D]
+			const float *wv3;       // [D][3]
+			float bp2;
+			float bv1[4];
+			float bv3[3];
+			int blocks;
+			int batch;
+	};
+
+	template<int F, int ROWS, int COLS>
+	struct Geometry
+	{
+			static constexpr int S = COLS + 1;                                   // row stride in positions
+			static constexpr int NT = (ROWS * S + 15) / 16;                      // 16-position tiles of the output
+			static constexpr int NPOS = 1 + S + NT * 16 + S + 2;                  // stored positions (index = position + 1)
+			static constexpr int CH = F / 8;                                     // 16-byte chunks per position
+			static constexpr int PPR = (16 / CH) > 0 ? (16 / CH) : 1;            // positions per 256-byte bank row
+			static constexpr int PLANE_BYTES = NPOS * F * 2;
+			static constexpr int MT = F / 64;                                    // 16-channel output tiles per wave
+			static constexpr int MTILES = F / 16;
+			static constexpr int KC = F / 32;                                    // k-steps per tap
+			static constexpr int S5 = S + 4;                                     // row stride of the padded input plane
+			static constexpr int NPOS5 = (ROWS + 4) * S5 + 4;
+			static constexpr int HW = ROWS * COLS;
+			static constexpr int D = (2 * F < 256) ? 2 * F : 256;
+			static constexpr int SCRATCH_FLOATS = HW * 4 + D + 256 + 8;
+			static constexpr int LDS_BYTES = 2 * PLANE_BYTES + SCRATCH_FLOATS * 4;
+	};
+
+	template<typename G>
+	__device__ __forceinline__ int plane_offset(int index, int chunk)
+	{ // byte offset of a 16-byte chunk of stored position `index` (= position + 1)
+		const int swz = (index / G::PPR) % G::CH;
+		return (index * G::CH + (chunk ^ swz)) * 16;
+	}
+
+	/*
+	 * 3x3 convolution + bias (+ skip) + ReLU over one board held in LDS.
+	 * src, dst: activation planes; if SKIP the residual input is read from (and the result written to) dst.
+	 */
+	template<int F, int ROWS, int COLS, bool SKIP>
+	__device__ __forceinline__ void conv3x3(const char *src, char *dst, const half8 *__restrict__ wpk, const float *__restrict__ bias, int wave,
+			int lane)
+	{
+		typedef Geometry<F, ROWS, COLS> G;
+		const int r = lane & 15;
+		const int q4 = lane >> 4;
+
+		floatx4 acc[G::MT][G::NT];
+#pragma unroll
+		for (int i = 0; i < G::MT; i++)
+#pragma unroll
+			for (int n = 0; n < G::NT; n++)
+				acc[i][n] = floatx4 { 0.0f, 0.0f, 0.0f, 0.0f };
+
+		const half8 *wp = wpk + (wave * G::MT) * 64 + lane;
+		half8 a_next[G::MT];
+#pragma unroll
+		for (int i = 0; i < G::MT; i++)
+			a_next[i] = wp[i * 64];
+
+		for (int t = 0; t < 9; t++)
+		{
+			const int off = (t / 3 - 1) * G::S + (t % 3 - 1);
+			const int index0 = 1 + G::S + r + off; // stored index of this lane's position in tile 0
+			const int swz0 = (index0 / G::PPR) % G::CH; // invariant over tiles: 16 positions == whole bank rows
+			const char *src0 = src + index0 * G::CH * 16;
+#pragma unroll
+			for (int kc = 0; kc < G::KC; kc++)
+			{
+				half8 a[G::MT];
+#pragma unroll
+				for (int i = 0; i < G::MT; i++)
+					a[i] = a_next[i];
+				const int step = t * G::KC + kc + 1;
+				if (step < 9 * G::KC)
+				{
+#pragma unroll
+					for (int i = 0; i < G::MT; i++)
+						a_next[i] = wp[(step * G::MTILES + i) * 64];
+				}
+#pragma unroll
+				for (int n = 0; n < G::NT; n++)
+				{
+					const half8 b = *reinterpret_cast<const half8*>(src0 + n * (16 * G::CH * 16) + (((kc * 4 + q4) ^ swz0) * 16));
+#pragma unroll
+					for (int i = 0; i < G::MT; i++)
+						acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b, acc[i][n], 0, 0, 0);
+				}
+			}
+		}
+
+		// epilogue: lane holds out-channels 4*q4 .. 4*q4+3 of tile i for position r of tile n
+#pragma unroll
+		for (int i = 0; i < G::MT; i++)
+		{
+			const int ch = (wave * G::MT + i) * 16 + 4 * q4;
+			const floatx4 bv = *reinterpret_cast<const floatx4*>(bias + ch);
+#pragma unroll
+			for (int n = 0; n < G::NT; n++)
+			{
+				const int pos = G::S + n * 16 + r;
+				const int x = pos % G::S;
+				const int y = pos / G::S - 1;
+				const bool valid = (x < COLS) && (y < ROWS);
+				char *ptr = dst + plane_offset<G>(pos + 1, ch / 8) + (ch % 8) * 2;
+				floatx4 v = acc[i][n] + bv;
+				if (SKIP)
+				{
+					const half4 s = *reinterpret_cast<const half4*>(ptr);
+					v[0] += static_cast<float>(s[0]);
+					v[1] += static_cast<float>(s[1]);
+					v[2] += static_cast<float>(s[2]);
+					v[3] += static_cast<float>(s[3]);
+				}
+				half4 o;
+				o[0] = static_cast<half_t>(valid ? fmaxf(v[0], 0.0f) : 0.0f);
+				o[1] = static_cast<half_t>(valid ? fmaxf(v[1], 0.0f) : 0.0f);
+				o[2] = static_cast<half_t>(valid ? fmaxf(v[2], 0.0f) : 0.0f);
+				o[3] = static_cast<half_t>(valid ? fmaxf(v[3], 0.0f) : 0.0f);
+				*reinterpret_cast<half4*>(ptr) = o;
+			}
+		}
+	}
+
+	/*
+	 * Input block: bit-unpack + 5x5 convolution (Cin = 32) + bias + ReLU.  `in5` is the padded input plane
+	 * (stride S5, 64 bytes per position, chunk-swizzled by (index >> 2) & 3).
+	 */
+	template<int F, int ROWS, int COLS>
+	__device__ __forceinline__ void conv5x5_input(const char *in5, char *dst, const half8 *__restrict__ wpk, const float *__restrict__ bias,
+			int wave, int lane)
+	{
+		typedef Geometry<F, ROWS, COLS> G;
+		const int r = lane & 15;
+		const int q4 = lane >> 4;
+
+		floatx4 acc[G::MT][G::NT];
+#pragma unroll
+		for (int i = 0; i < G::MT; i++)
+#pragma unroll
+			for (int n = 0; n < G::NT; n++)
+				acc[i][n] = floatx4 { 0.0f, 0.0f, 0.0f, 0.0f };
+
+		// padded-plane index of the (dy = 0, dx = 0) input cell of this lane's position in every tile
+		int q0[G::NT];
+#pragma unroll
+		for (int n = 0; n < G::NT; n++)
+		{
+			const int pos = G::S + n * 16 + r;
+			const int x = pos % G::S;
+			const int y = pos / G::S - 1;
+			q0[n] = (y + 2) * G::S5 + (x + 2);
+		}
+
+		const half8 *wp = wpk + (wave * G::MT) * 64 + lane;
+		for (int t = 0; t < 25; t++)
+		{
+			const int off = (t / 5 - 2) * G::S5 + (t % 5 - 2);
+			half8 a[G::MT];
+#pragma unroll
+			for (int i = 0; i < G::MT; i++)
+				a[i] = wp[(t * G::MTILES + i) * 64];
+#pragma unroll
+			for (int n = 0; n < G::NT; n++)
+			{
+				int q = q0[n] + off;
+				q = (q < 0) ? 0 : ((q >= G::NPOS5) ? (G::NPOS5 - 1) : q); // only dummy (spare-column / overhang) positions can fall outside
+				const half8 b = *reinterpret_cast<const half8*>(in5 + (q * 4 + (q4 ^ ((q >> 2) & 3))) * 16);
+#pragma unroll
+				for (int i = 0; i < G::MT; i++)
+					acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b, acc[i][n], 0, 0, 0);
+			}
+		}
+#pragma unroll
+		for (int i = 0; i < G::MT; i++)
+		{
+			const int ch = (wave * G::MT + i) * 16 + 4 * q4;
+			const floatx4 bv = *reinterpret_cast<const floatx4*>(bias + ch);
+#pragma unroll
+			for (int n = 0; n < G::NT; n++)
+			{
+				const int pos = G::S + n * 16 + r;
+				const int x = pos % G::S;
+				const int y = pos / G::S - 1;
+				const bool valid = (x < COLS) && (y < ROWS);
+				char *ptr = dst + plane_offset<G>(pos + 1, ch / 8) + (ch % 8) * 2;
+				const floatx4 v = acc[i][n] + bv;
+				half4 o;
+				o[0] = static_cast<half_t>(valid ? fmaxf(v[0], 0.0f) : 0.0f);
+				o[1] = static_cast<half_t>(valid ? fmaxf(v[1], 0.0f) : 0.0f);
+				o[2] = static_cast<half_t>(valid ? fmaxf(v[2], 0.0f) : 0.0f);
+				o[3] = static_cast<half_t>(valid ? fmaxf(v[3], 0.0f) : 0.0f);
+				*reinterpret_cast<half4*>(ptr) = o;
+			}
+		}
+	}
+
+	__device__ __forceinline__ float block_reduce_max(float v, float *red, int tid)
+	{
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1)
+			v = fmaxf(v, __shfl_xor(v, o));
+		__syncthreads();
+		if ((tid & 63) == 0)
+			red[tid >> 6] = v;
+		__syncthreads();
+		return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+	}
+	__device__ __forceinline__ float block_reduce_sum(float v, float *red, int tid)
+	{
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1)
+			v += __shfl_xor(v, o);
+		__syncthreads();
+		if ((tid & 63) == 0)
+			red[tid >> 6] = v;
+		__syncthreads();
+		return (red[0] + red[1]) + (red[2] + red[3]);
+	}
+
+	template<int F, int ROWS, int COLS>
+	__global__ __launch_bounds__(256, 1) void nn_tower_kernel(NetParams p, const uint32_t *__restrict__ features, float *__restrict__ policy,
+			float *__restrict__ value)
+	{
+		typedef Geometry<F, ROWS, COLS> G;
+		static_assert(G::LDS_BYTES <= 163840, "board does not fit in LDS");
+		static_assert(G::NPOS5 * 64 <= G::PLANE_BYTES, "padded input plane must fit into an activation plane");
+		__shared__ __attribute__((aligned(16))) char lds[G::LDS_BYTES];
+		char *plane_x = lds;
+		char *plane_t = lds + G::PLANE_BYTES;
+		float *vbuf = reinterpret_cast<float*>(lds + 2 * G::PLANE_BYTES); // [HW*4]
+		float *hid = vbuf + G::HW * 4;                                     // [D]
+		float *red = hid + G::D;                                           // [256 + 8]
+
+		const int tid = threadIdx.x;
+		const int wave = tid >> 6;
+		const int lane = tid & 63;
+		const int layer_halves8 = 9 * G::KC * G::MTILES * 64; // half8 elements per packed 3x3 layer
+
+		const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+		for (int i = tid; i < G::PLANE_BYTES / 16; i += 256)
+			reinterpret_cast<uint4*>(plane_x)[i] = zero4;
+
+		for (int b = blockIdx.x; b < p.batch; b += gridDim.x)
+		{
+			// ---- stage the bit-unpacked input into the padded plane (aliases plane_t) ----
+			__syncthreads();
+			for (int i = tid; i < G::NPOS5 * 4; i += 256)
+				reinterpret_cast<uint4*>(plane_t)[i] = zero4;
+			__syncthreads();
+			for (int c = tid; c < G::HW; c += 256)
+			{
+				const uint32_t word = features[static_cast<size_t>(b) * G::HW + c];
+				const int q = (c / COLS + 2) * G::S5 + (c % COLS + 2);
+#pragma unroll
+				for (int k = 0; k < 4; k++)
+				{
+					const uint32_t bits = (word >> (8 * k)) & 255u;
+					uint4 v;
+					v.x = ((bits & 1u) ? 0x3C00u : 0u) | ((bits & 2u) ? 0x3C000000u : 0u);
+					v.y = ((bits & 4u) ? 0x3C00u : 0u) | ((bits & 8u) ? 0x3C000000u : 0u);
+					v.z = ((bits & 16u) ? 0x3C00u : 0u) | ((bits & 32u) ? 0x3C000000u : 0u);
+					v.w = ((bits & 64u) ? 0x3C00u : 0u) | ((bits & 128u) ? 0x3C000000u : 0u);
+					*reinterpret_cast<uint4*>(plane_t + (q * 4 + (k ^ ((q >> 2) & 3))) * 16) = v;
+				}
+			}
+			__syncthreads();
+			conv5x5_input<F, ROWS, COLS>(plane_t, plane_x, p.w_in, p.bias, wave, lane);
+			__syncthreads();
+			for (int i = tid; i < G::PLANE_BYTES / 16; i += 256)
+				reinterpret_cast<uint4*>(plane_t)[i] = zero4; // restore the zero border of plane_t
+			__syncthreads();
+
+			// ---- residual tower ----
+			for (int blk = 0; blk < p.blocks; blk++)
+			{
+				conv3x3<F, ROWS, COLS, false>(plane_x, plane_t, p.w_tower + (2 * blk) * layer_halves8, p.bias + (1 + 2 * blk) * F, wave, lane);
+				__syncthreads();
+				conv3x3<F, ROWS, COLS, true>(plane_t, plane_x, p.w_tower + (2 * blk + 1) * layer_halves8, p.bias + (2 + 2 * blk) * F, wave, lane);
+				__syncthreads();
+			}
+
+			// ---- value head, stage 1: conv1x1 F->4 + ReLU into vbuf (NHWC flatten order) ----
+			for (int c = tid; c < G::HW; c += 256)
+			{
+				const int index = 1 + G::S + (c / COLS) * G::S + (c % COLS);
+				float s0 = p.bv1[0], s1 = p.bv1[1], s2 = p.bv1[2], s3 = p.bv1[3];
+				for (int k = 0; k < G::CH; k++)
+				{
+					const half8 xv = *reinterpret_cast<const half8*>(plane_x + plane_offset<G>(index, k));
+#pragma unroll
+					for (int j = 0; j < 8; j++)
+					{
+						const float xf = static_cast<float>(xv[j]);
+						const floatx4 w = *reinterpret_cast<const floatx4*>(p.wv1 + (k * 8 + j) * 4);
+						s0 += xf * w[0];
+						s1 += xf * w[1];
+						s2 += xf * w[2];
+						s3 += xf * w[3];
+					}
+				}
+				vbuf[c * 4 + 0] = fmaxf(s0, 0.0f);
+				vbuf[c * 4 + 1] = fmaxf(s1, 0.0f);
+				vbuf[c * 4 + 2] = fmaxf(s2, 0.0f);
+				vbuf[c * 4 + 3] = fmaxf(s3, 0.0f);
+			}
+			// ---- policy head: conv3x3 + ReLU into plane_t ----
+			conv3x3<F, ROWS, COLS, false>(plane_x, plane_t, p.w_tower + (2 * p.blocks) * layer_halves8, p.bias + (1 + 2 * p.blocks) * F, wave, lane);
+			__syncthreads();
+
+			// ---- policy head: conv1x1 F->1 + bias, softmax over the board ----
+			{
+				float logit = -3.0e38f;
+				const int c = tid;
+				if (c < G::HW)
+				{
+					const int index = 1 + G::S + (c / COLS) * G::S + (c % COLS);
+					float s = p.bp2;
+					for (int k = 0; k < G::CH; k++)
+					{
+						const half8 tv = *reinterpret_cast<const half8*>(plane_t + plane_offset<G>(index, k));
+#pragma unroll
+						for (int j = 0; j < 8; j++)
+							s += static_cast<float>(tv[j]) * p.wp2[k * 8 + j];
+					}
+					logit = s;
+				}
+				static_assert(G::HW <= 256, "policy softmax assumes one cell per thread");
+				const float m = block_reduce_max(logit, red, tid);
+				const float e = (c < G::HW) ? __expf(logit - m) : 0.0f;
+				const float sum = block_reduce_sum(e, red, tid);
+				if (c < G::HW)
+					policy[static_cast<size_t>(b) * G::HW + c] = e / sum;
+			}
+
+			// ---- value head, stage 2: dense HW*4 -> D + ReLU, dense D -> 3, softmax ----
+			if (tid < G::D)
+			{
+				float s = p.bv2[tid];
+				const half_t *w = p.wv2 + tid;
+#pragma unroll 4
+				for (int i = 0; i < G::HW * 4; i++)
+					s += vbuf[i] * static_cast<float>(w[static_cast<size_t>(i) * G::D]);
+				hid[tid] = fmaxf(s, 0.0f);
+			}
+			__syncthreads();
+			if (wave < 3)
+			{ // wave k reduces output k
+				float s = 0.0f;
+				for (int j = lane; j < G::D; j += 64)
+					s += hid[j] * p.wv3[j * 3 + wave];
+#pragma unroll
+				for (int o = 32; o > 0; o >>= 1)
+					s += __shfl_xor(s, o);
+				if (lane == 0)
+					red[256 + wave] = s + p.bv3[wave];
+			}
+			__syncthreads();
+			if (tid == 0)
+			{
+				const float z0 = red[256], z1 = red[257], z2 = red[258];
+				const float m = fmaxf(z0, fmaxf(z1, z2));
+				const float e0 = __expf(z0 - m), e1 = __expf(z1 - m), e2 = __expf(z2 - m);
+				const float inv = 1.0f / (e0 + e1 + e2);
+				value[static_cast<size_t>(b) * 3 + 0] = e0 * inv;
+				value[static_cast<size_t>(b) * 3 + 1] = e1 * inv;
+				value[static_cast<size_t>(b) * 3 + 2] = e2 * inv;
+			}
+		}
+	}
+
+	/*
+	 * Host side: pack canonical [kh][kw][cin][cout] fp32 weights into MFMA A-fragment order
+	 * [tap][kc][mtile][lane][8]: lane l holds out-channel mtile*16 + (l & 15), in-channels kc*32 + 8*(l >> 4) + j.
+	 */
+	void pack_conv(const float *w, int taps, int cin, int cout, std::vector<half_t> &dst)
+	{
+		const int kcs = cin / 32;
+		const int mtiles = cout / 16;
+		const size_t base = dst.size();
+		dst.resize(base + static_cast<size_t>(taps) * kcs * mtiles * 512);
+		half_t *out = dst.data() + base;
+		for (int t = 0; t < taps; t++)
+			for (int kc = 0; kc < kcs; kc++)
+				for (int mt = 0; mt < mtiles; mt++)
+					for (int lane = 0; lane < 64; lane++)
+						for (int j = 0; j < 8; j++)
+						{
+							const int oc = mt * 16 + (lane & 15);
+							const int ic = kc * 32 + 8 * (lane >> 4) + j;
+							const float v = w[(static_cast<size_t>(t) * cin + ic) * cout + oc];
+							out[(((static_cast<size_t>(t) * kcs + kc) * mtiles + mt) * 64 + lane) * 8 + j] = static_cast<half_t>(v);
+						}
+	}
+}
+
+struct AgxNet
+{
+		AgxNetDesc desc;
+		bool loaded = false;
+		void *d_w_in = nullptr;
+		void *d_w_tower = nullptr;
+		void *d_bias = nullptr;
+		void *d_wp2 = nullptr;
+		void *d_wv1 = nullptr;
+		void *d_wv2 = nullptr;
+		void *d_bv2 = nullptr;
+		void *d_wv3 = nullptr;
+		float bp2 = 0.0f;
+		float bv1[4] = { 0, 0, 0, 0 };
+		float bv3[3] = { 0, 0, 0 };
+		int num_cus = 256;
+};
+
+namespace
+{
+	bool is_supported(const AgxNetDesc &d)
+	{
+		return d.rows == 15 && d.cols == 15 && (d.filters == 64 || d.filters == 128) && d.in_channels == 32 && d.blocks >= 0
+				&& d.value_hidden == ((2 * d.filters < 256) ? 2 * d.filters : 256);
+	}
+	void free_net_buffers(AgxNet *net)
+	{
+		void **ptrs[] = { &net->d_w_in, &net->d_w_tower, &net->d_bias, &net->d_wp2, &net->d_wv1, &net->d_wv2, &net->d_bv2, &net->d_wv3 };
+		for (void **p : ptrs)
+		{
+			if (*p != nullptr)
+				(void) hipFree(*p);
+			*p = nullptr;
+		}
+	}
+	template<typename T>
+	int upload(void **dst, const std::vector<T> &src)
+	{
+		AGX_HIP_CHECK(hipMalloc(dst, src.size() * sizeof(T)));
+		AGX_HIP_CHECK(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+		return AGX_OK;
+	}
+}
+
+extern "C" {
+
+size_t agx_net_blob_floats(const AgxNetDesc *d)
+{
+	if (d == nullptr)
+		return 0;
+	const size_t F = d->filters, C = d->in_channels, HW = static_cast<size_t>(d->rows) * d->cols, D = d->value_hidden;
+	size_t n = 25 * C * F + F;
+	n += static_cast<size_t>(d->blocks) * 2 * (9 * F * F + F);
+	n += 9 * F * F + F + F + 1;
+	n += F * 4 + 4 + HW * 4 * D + D + D * 3 + 3;
+	return n;
+}
+
+int agx_net_create(const AgxNetDesc *desc, AgxNet **out)
+{
+	AGX_REQUIRE(desc != nullptr && out != nullptr, AGX_ERR_INVALID, "agx_net_create: null argument");
+	AGX_REQUIRE(is_supported(*desc), AGX_ERR_UNSUPPORTED,
+			"agx_net_create: unsupported network %dx%d blocks=%d filters=%d cin=%d hidden=%d (supported: 15x15, F in {64,128}, cin 32)", desc->rows,
+			desc->cols, desc->blocks, desc->filters, desc->in_channels, desc->value_hidden);
+	AgxNet *net = new AgxNet();
+	net->desc = *desc;
+	int dev = 0;
+	hipDeviceProp_t prop;
+	if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+		net->num_cus = prop.multiProcessorCount;
+	*out = net;
+	return AGX_OK;
+}
+
+int agx_net_load_weights(AgxNet *net, const float *h_blob, size_t n_floats)
+{
+	AGX_REQUIRE(net != nullptr && h_blob != nullptr, AGX_ERR_INVALID, "agx_net_load_weights: null argument");
+	AGX_REQUIRE(n_floats == agx_net_blob_floats(&net->desc), AGX_ERR_INVALID, "agx_net_load_weights: blob has %zu floats, expected %zu", n_floats,
+			agx_net_blob_floats(&net->desc));
+	free_net_buffers(net);
+	net->loaded = false;
+
+	const int F = net->desc.filters, C = net->desc.in_channels, HW = net->desc.rows * net->desc.cols, D = net->desc.value_hidden;
+	const int blocks = net->desc.blocks;
+	const float *ptr = h_blob;
+
+	std::vector<half_t> w_in, w_tower, wv2;
+	std::vector<float> bias, wp2, wv1, bv2, wv3;
+
+	pack_conv(ptr, 25, C, F, w_in);
+	ptr += 25 * C * F;
+	bias.insert(bias.end(), ptr, ptr + F);
+	ptr += F;
+	for (int l = 0; l < 2 * blocks + 1; l++)
+	{
+		pack_conv(ptr, 9, F, F, w_tower);
+		ptr += 9 * F * F;
+		bias.insert(bias.end(), ptr, ptr + F);
+		ptr += F;
+	}
+	wp2.assign(ptr, ptr + F);
+	ptr += F;
+	net->bp2 = *ptr++;
+	wv1.assign(ptr, ptr + F * 4);
+	ptr += F * 4;
+	for (int i = 0; i < 4; i++)
+		net->bv1[i] = *ptr++;
+	wv2.resize(static_cast<size_t>(HW) * 4 * D);
+	for (size_t i = 0; i < wv2.size(); i++)
+		wv2[i] = static_cast<half_t>(ptr[i]);
+	ptr += static_cast<size_t>(HW) * 4 * D;
+	bv2.assign(ptr, ptr + D);
+	ptr += D;
+	wv3.assign(ptr, ptr + D * 3);
+	ptr += D * 3;
+	for (int i = 0; i < 3; i++)
+		net->bv3[i] = *ptr++;
+
+	int status = AGX_OK;
+	if ((status = upload(&net->d_w_in, w_in)) != AGX_OK || (status = upload(&net->d_w_tower, w_tower)) != AGX_OK
+			|| (status = upload(&net->d_bias, bias)) != AGX_OK || (status = upload(&net->d_wp2, wp2)) != AGX_OK
+			|| (status = upload(&net->d_wv1, wv1)) != AGX_OK || (status = upload(&net->d_wv2, wv2)) != AGX_OK
+			|| (status = upload(&net->d_bv2, bv2)) != AGX_OK || (status = upload(&net->d_wv3, wv3)) != AGX_OK)
+	{
+		free_net_buffers(net);
+		return status;
+	}
+	net->loaded = true;
+	return AGX_OK;
+}
+
+int agx_nn_forward(AgxNet *net, const uint32_t *d_features, int batch, float *d_policy, float *d_value, void *stream)
+{
+	AGX_REQUIRE(net != nullptr, AGX_ERR_INVALID, "agx_nn_forward: null network");
+	AGX_REQUIRE(net->loaded, AGX_ERR_STATE, "agx_nn_forward: weights not loaded");
+	AGX_REQUIRE(batch >= 0, AGX_ERR_INVALID, "agx_nn_forward: negative batch");
+	if (batch == 0)
+		return AGX_OK;
+	AGX_REQUIRE(d_features != nullptr && d_policy != nullptr && d_value != nullptr, AGX_ERR_INVALID, "agx_nn_forward: null buffer");
+
+	NetParams p;
+	p.w_in = static_cast<const half8*>(net->d_w_in);
+	p.w_tower = static_cast<const half8*>(net->d_w_tower);
+	p.bias = static_cast<const float*>(net->d_bias);
+	p.wp2 = static_cast<const float*>(net->d_wp2);
+	p.wv1 = static_cast<const float*>(net->d_wv1);
+	p.wv2 = static_cast<const half_t*>(net->d_wv2);
+	p.bv2 = static_cast<const float*>(net->d_bv2);
+	p.wv3 = static_cast<const float*>(net->d_wv3);
+	p.bp2 = net->bp2;
+	for (int i = 0; i < 4; i++)
+		p.bv1[i] = net->bv1[i];
+	for (int i = 0; i < 3; i++)
+		p.bv3[i] = net->bv3[i];
+	p.blocks = net->desc.blocks;
+	p.batch = batch;
+
+	const int grid = (batch < net->num_cus) ? batch : net->num_cus;
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	if (net->desc.filters == 128)
+		hipLaunchKernelGGL((nn_tower_kernel<128, 15, 15>), dim3(grid), dim3(256), 0, s, p, d_features, d_policy, d_value);
+	else
+		hipLaunchKernelGGL((nn_tower_kernel<64, 15, 15>), dim3(grid), dim3(256), 0, s, p, d_features, d_policy, d_value);
+	AGX_HIP_CHECK(hipGetLastError());
+	return AGX_OK;
+}
+
+int agx_net_destroy(AgxNet *net)
+{
+	if (net == nullptr)
+		return AGX_OK;
+	free_net_buffers(net);
+	delete net;
+	return AGX_OK;
+}
+
+} /* extern "C" */

@@ -1,0 +1,53 @@
+"""Synthetic inputs for tests and the benchmark (there is no network access for checkpoints or datasets).
+
+Weights: He-normal fp32, fixed seed; BatchNorm already folded (scale folded into the weights = 1, shift = small
+normal bias), i.e. the state of the graph after AGNetwork::optimize(2) (src/networks/AGNetwork.cpp:136-160).
+"""
+import numpy as np
+
+
+def net_desc(rows=15, cols=15, blocks=6, filters=128, in_channels=32):
+    return dict(rows=rows, cols=cols, blocks=blocks, filters=filters, in_channels=in_channels,
+                value_hidden=min(256, 2 * filters))
+
+
+def make_weights(desc, seed=1234):
+    """Returns (blob, parts): the canonical fp32 blob of include/agx.h and the list of named arrays in blob order."""
+    rng = np.random.default_rng(seed)
+    F, C, HW, D = desc["filters"], desc["in_channels"], desc["rows"] * desc["cols"], desc["value_hidden"]
+
+    def he(shape, fan_in):
+        return (rng.standard_normal(shape) * np.sqrt(2.0 / fan_in)).astype(np.float32)
+
+    def shift(n):
+        return (0.01 * rng.standard_normal(n)).astype(np.float32)
+
+    parts = [("conv_in.w", he((5, 5, C, F), 25 * C)), ("conv_in.b", shift(F))]
+    for i in range(desc["blocks"]):
+        parts += [("block%d.w1" % i, he((3, 3, F, F), 9 * F)), ("block%d.b1" % i, shift(F)),
+                  ("block%d.w2" % i, he((3, 3, F, F), 9 * F)), ("block%d.b2" % i, shift(F))]
+    parts += [("policy.w1", he((3, 3, F, F), 9 * F)), ("policy.b1", shift(F)),
+              ("policy.w2", he((F,), F)), ("policy.b2", shift(1))]
+    parts += [("value.w1", he((F, 4), F)), ("value.b1", shift(4)),
+              ("value.w2", he((HW * 4, D), HW * 4)), ("value.b2", shift(D)),
+              ("value.w3", he((D, 3), D)), ("value.b3", shift(3))]
+    blob = np.concatenate([p[1].reshape(-1) for p in parts]).astype(np.float32)
+    return blob, parts
+
+
+def random_features(batch, rows, cols, seed=0):
+    """Random bit-packed feature words with plausible sparsity (stones/legal bits dense, threat bits sparse)."""
+    rng = np.random.default_rng(seed)
+    hw = rows * cols
+    stone = rng.integers(0, 3, size=(batch, hw))  # 0 empty, 1 own, 2 opponent
+    words = np.zeros((batch, hw), dtype=np.uint32)
+    words |= (stone == 0).astype(np.uint32) << 0
+    words |= (stone == 1).astype(np.uint32) << 1
+    words |= (stone == 2).astype(np.uint32) << 2
+    words |= np.uint32(1) << 3
+    colour = rng.integers(0, 2, size=(batch, 1)).astype(np.uint32)
+    words |= (colour << 4) | ((1 - colour) << 5)
+    sparse = (rng.random((batch, hw, 24)) < 0.03)
+    for bit in range(24):
+        words |= (sparse[:, :, bit] & (stone == 0)).astype(np.uint32) << np.uint32(8 + bit)
+    return words

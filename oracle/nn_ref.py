@@ -1,0 +1,88 @@
+"""
+oracle/nn_ref.py — TEST INFRASTRUCTURE ONLY (never imported by the product path).
+
+fp32 numpy restatement of the ResnetPV forward pass: layer definitions from the reference
+src/networks/blocks.cpp:32-38 (input block: conv5x5 no bias + BN(relu, no gamma)), :45-55 (residual block:
+conv3x3+BN relu, conv3x3+BN linear, Add relu), :99-107 (policy head: conv3x3+BN relu, conv1x1 F->1 with bias,
+softmax over H*W), :108-118 (value head: conv1x1 F->4 + BN relu, Dense 4HW->D + BN relu, Dense D->3 with bias,
+softmax), network assembly src/networks/networks.cpp:71-93, input bit expansion ml::unpackInput
+(src/networks/AGNetwork.cpp:249-258: bit c of the int32 word -> channel c in {0,1}).
+
+PARITY UNPINNED: the arithmetic lives in the third-party MinML library, which is not vendored in /root/reference
+and has no pinned version; the reference holds no test at the network-output boundary.  Conventions
+that MinML fixes and that cannot be recovered from the reference are chosen here and documented in include/agx.h:
+"same" zero padding, cross-correlation tap order [kh][kw][cin][cout], NHWC flatten order for the value head.
+BatchNorm is taken as already folded (AGNetwork::optimize(2), AGNetwork.cpp:136-160): each conv/dense carries a
+per-channel shift.
+"""
+import numpy as np
+
+
+def split_blob(desc, blob):
+    F, C, HW, D = desc["filters"], desc["in_channels"], desc["rows"] * desc["cols"], desc["value_hidden"]
+    shapes = [(5, 5, C, F), (F,)]
+    for _ in range(desc["blocks"]):
+        shapes += [(3, 3, F, F), (F,), (3, 3, F, F), (F,)]
+    shapes += [(3, 3, F, F), (F,), (F,), (1,), (F, 4), (4,), (HW * 4, D), (D,), (D, 3), (3,)]
+    out, pos = [], 0
+    for s in shapes:
+        n = int(np.prod(s))
+        out.append(np.asarray(blob[pos:pos + n], dtype=np.float32).reshape(s))
+        pos += n
+    assert pos == len(blob)
+    return out
+
+
+def unpack_input(features, rows, cols, channels=32):
+    """uint32 [B, HW] -> float32 [B, H, W, C] in {0, 1}"""
+    f = np.asarray(features, dtype=np.uint32).reshape(-1, rows, cols, 1)
+    bits = (f >> np.arange(channels, dtype=np.uint32).reshape(1, 1, 1, channels)) & np.uint32(1)
+    return bits.astype(np.float32)
+
+
+def conv2d_same(x, w, b):
+    """x [B,H,W,Cin], w [kh,kw,Cin,Cout] (cross-correlation), zero padding"""
+    B, H, W, Cin = x.shape
+    kh, kw, _, Cout = w.shape
+    ph, pw = kh // 2, kw // 2
+    xp = np.zeros((B, H + 2 * ph, W + 2 * pw, Cin), dtype=np.float32)
+    xp[:, ph:ph + H, pw:pw + W, :] = x
+    y = np.zeros((B, H, W, Cout), dtype=np.float32)
+    for i in range(kh):
+        for j in range(kw):
+            y += np.tensordot(xp[:, i:i + H, j:j + W, :], w[i, j], axes=([3], [0])).astype(np.float32)
+    return y + b.reshape(1, 1, 1, -1)
+
+
+def relu(x):
+    return np.maximum(x, 0.0)
+
+
+def softmax(x, axis):
+    m = x.max(axis=axis, keepdims=True)
+    e = np.exp(x - m)
+    return e / e.sum(axis=axis, keepdims=True)
+
+
+def forward(desc, blob, features):
+    """Returns (policy [B, HW], value [B, 3] = (win, draw, loss)) in float32."""
+    rows, cols = desc["rows"], desc["cols"]
+    parts = split_blob(desc, blob)
+    it = iter(parts)
+    x = unpack_input(features, rows, cols, desc["in_channels"])
+    x = relu(conv2d_same(x, next(it), next(it)))
+    for _ in range(desc["blocks"]):
+        w1, b1, w2, b2 = next(it), next(it), next(it), next(it)
+        y = relu(conv2d_same(x, w1, b1))
+        y = conv2d_same(y, w2, b2)
+        x = relu(x + y)
+    wp1, bp1, wp2, bp2 = next(it), next(it), next(it), next(it)
+    p = relu(conv2d_same(x, wp1, bp1))
+    logits = np.tensordot(p, wp2, axes=([3], [0])) + bp2[0]
+    policy = softmax(logits.reshape(logits.shape[0], -1), axis=1)
+    wv1, bv1, wv2, bv2, wv3, bv3 = next(it), next(it), next(it), next(it), next(it), next(it)
+    v = relu(np.tensordot(x, wv1, axes=([3], [0])) + bv1.reshape(1, 1, 1, 4))
+    v = v.reshape(v.shape[0], -1)
+    h = relu(v @ wv2 + bv2)
+    value = softmax(h @ wv3 + bv3, axis=1)
+    return policy.astype(np.float32), value.astype(np.float32)

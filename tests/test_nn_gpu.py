@@ -1,0 +1,65 @@
+"""Parity of the HIP whole-tower forward (through the C ABI) against the fp32 numpy oracle.
+
+Tolerance (stated per BASELINE north_star "within a stated fp32 tolerance on policy/value"): activations and weights
+are fp16 with fp32 accumulation, the oracle is fp32 end to end -> |policy - ref| <= 4e-3 and |value - ref| <= 4e-3
+absolute on softmax outputs (measured on MI355X: 9.0e-4 / 5.5e-4 for the 6x128 net, 1.7e-5 / 2.2e-4 for 2x64)."""
+import numpy as np
+import pytest
+
+from alphagomoku_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+POLICY_TOL = 4e-3
+VALUE_TOL = 4e-3
+
+
+@pytest.mark.parametrize("blocks,filters", [(2, 64), (6, 128), (10, 128)])
+def test_forward_matches_oracle(agx_lib, blocks, filters):
+    from alphagomoku_amd.networks import AGNetwork
+    from oracle import nn_ref
+    d = synthetic.net_desc(blocks=blocks, filters=filters)
+    blob, _ = synthetic.make_weights(d)
+    net = AGNetwork(d)
+    net.loadWeights(blob)
+    f = synthetic.random_features(12, 15, 15, seed=blocks)
+    f[0, :] = 0                       # empty input edge case
+    f[1, :] = 0xFFFFFFFF              # all bits set
+    p, v = net.forward(f)
+    pr, vr = nn_ref.forward(d, blob, f)
+    assert np.abs(p - pr).max() <= POLICY_TOL
+    assert np.abs(v - vr).max() <= VALUE_TOL
+    assert (p.argmax(1) == pr.argmax(1)).all()
+    net.close()
+
+
+def test_grid_stride_and_ragged_batches(agx_lib):
+    """Batches larger than the CU count go through the persistent grid-stride loop; results must not depend on
+    where in the batch a board sits (size-independent property used at full size)."""
+    from alphagomoku_amd.networks import AGNetwork
+    d = synthetic.net_desc(blocks=2, filters=64)
+    blob, _ = synthetic.make_weights(d)
+    net = AGNetwork(d)
+    net.loadWeights(blob)
+    f = synthetic.random_features(1024, 15, 15, seed=9)
+    p, v = net.forward(f)
+    for batch in (1, 3, 255, 257, 700):
+        idx = np.random.default_rng(batch).permutation(1024)[:batch]
+        p2, v2 = net.forward(f[idx])
+        assert np.array_equal(p2, p[idx]) and np.array_equal(v2, v[idx])
+    assert np.allclose(p.sum(1), 1.0, atol=1e-4) and np.allclose(v.sum(1), 1.0, atol=1e-4)
+    net.close()
+
+
+def test_error_paths(agx_lib):
+    from alphagomoku_amd.networks import AGNetwork
+    from alphagomoku_amd import AgxError
+    d = synthetic.net_desc(blocks=1, filters=64)
+    net = AGNetwork(d)
+    with pytest.raises(AgxError):
+        net.forward(synthetic.random_features(1, 15, 15))      # weights not loaded
+    with pytest.raises(AgxError):
+        net.loadWeights(np.zeros(10, dtype=np.float32))          # wrong blob size
+    with pytest.raises(AgxError):
+        AGNetwork(synthetic.net_desc(blocks=1, filters=96))      # unsupported width
+    net.close()

@@ -1,0 +1,46 @@
+"""The fp32 numpy network oracle against an independent torch-CPU implementation of the same layer definitions."""
+import numpy as np
+import torch
+import torch.nn.functional as Fn
+
+from alphagomoku_amd import synthetic
+from oracle import nn_ref
+
+
+def torch_forward(d, blob, f):
+    it = iter(nn_ref.split_blob(d, blob))
+    rows, cols = d["rows"], d["cols"]
+
+    def conv(x, w, b):
+        return Fn.conv2d(x, torch.from_numpy(w).permute(3, 2, 0, 1), torch.from_numpy(b), padding=w.shape[0] // 2)
+
+    x = torch.from_numpy(nn_ref.unpack_input(f, rows, cols)).permute(0, 3, 1, 2)
+    x = torch.relu(conv(x, next(it), next(it)))
+    for _ in range(d["blocks"]):
+        w1, b1, w2, b2 = next(it), next(it), next(it), next(it)
+        x = torch.relu(x + conv(torch.relu(conv(x, w1, b1)), w2, b2))
+    wp1, bp1, wp2, bp2 = next(it), next(it), next(it), next(it)
+    p = torch.relu(conv(x, wp1, bp1)).permute(0, 2, 3, 1) @ torch.from_numpy(wp2) + float(bp2[0])
+    policy = torch.softmax(p.reshape(p.shape[0], -1), 1)
+    wv1, bv1, wv2, bv2, wv3, bv3 = [torch.from_numpy(next(it)) for _ in range(6)]
+    v = torch.relu(x.permute(0, 2, 3, 1) @ wv1 + bv1).reshape(x.shape[0], -1)
+    value = torch.softmax(torch.relu(v @ wv2 + bv2) @ wv3 + bv3, 1)
+    return policy.numpy(), value.numpy()
+
+
+def test_numpy_oracle_matches_torch():
+    d = synthetic.net_desc(blocks=2, filters=64)
+    blob, _ = synthetic.make_weights(d, seed=7)
+    f = synthetic.random_features(3, 15, 15, seed=11)
+    p, v = nn_ref.forward(d, blob, f)
+    pt, vt = torch_forward(d, blob, f)
+    assert np.abs(p - pt).max() < 1e-6
+    assert np.abs(v - vt).max() < 1e-5
+    assert np.allclose(p.sum(1), 1.0, atol=1e-5)
+
+
+def test_unpack_input_bits():
+    f = np.array([[0x80000001, 0x00000100]], dtype=np.uint32)
+    x = nn_ref.unpack_input(np.tile(f, (1, 1)).repeat(1, 0)[:, :2].reshape(1, 2), 1, 2)
+    assert x[0, 0, 0, 0] == 1 and x[0, 0, 0, 31] == 1 and x[0, 0, 0, 1:31].sum() == 0
+    assert x[0, 0, 1, 8] == 1 and x[0, 0, 1].sum() == 1
