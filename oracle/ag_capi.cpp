@@ -1,0 +1,463 @@
+/*
+ * oracle/ag_capi.cpp — TEST INFRASTRUCTURE ONLY.  extern "C" surface of the CPU oracle for ctypes (tests, smoke, and
+ * the cpu_baseline leg of bench.py).
+ */
+#include "agoracle.hpp"
+
+#include <chrono>
+#include <thread>
+
+using namespace ago;
+
+namespace
+{
+	GameConfig make_cfg(int rules, int rows, int cols)
+	{
+		GameConfig c;
+		c.rules = static_cast<Rules>(rules);
+		c.rows = rows;
+		c.cols = cols;
+		c.draw_after = rows * cols;
+		return c;
+	}
+	struct GameHandle
+	{
+			Game game;
+			std::vector<uint32_t> features;
+			GameHandle(GameConfig c, const SearchConfig &sc) : game(c, sc) {}
+	};
+}
+
+extern "C" {
+
+struct AgoSearchConfig
+{
+		int max_batch_size;
+		float exploration_constant;
+		float exploration_scaling;
+		int init_to;
+		int max_children;
+		float policy_expansion_threshold;
+		float information_leak_threshold;
+		int tss_max_positions;
+		uint64_t tss_table_entries;
+		int max_simulations;
+		uint64_t zobrist_seed;
+};
+
+static SearchConfig convert(const AgoSearchConfig *c)
+{
+	SearchConfig s;
+	s.max_batch_size = c->max_batch_size;
+	s.exploration_constant = c->exploration_constant;
+	s.exploration_scaling = c->exploration_scaling;
+	s.init_to = c->init_to;
+	s.max_children = c->max_children;
+	s.policy_expansion_threshold = c->policy_expansion_threshold;
+	s.information_leak_threshold = c->information_leak_threshold;
+	s.tss_max_positions = c->tss_max_positions;
+	s.tss_table_entries = c->tss_table_entries;
+	s.max_simulations = c->max_simulations;
+	s.zobrist_seed = c->zobrist_seed;
+	return s;
+}
+
+void ago_tables(int rules, uint8_t *types, uint8_t *half_open_3, uint8_t *threats)
+{
+	const Tables &t = Tables::get(static_cast<Rules>(rules));
+	std::memcpy(types, t.pattern_types.data(), 1u << 20);
+	std::memcpy(half_open_3, t.half_open_3.data(), 1u << 20);
+	std::memcpy(threats, t.threats, 4096 * 2);
+}
+uint16_t ago_defensive_moves(int rules, uint32_t extended_pattern, int defender, int pattern_type)
+{
+	return Tables::get(static_cast<Rules>(rules)).defensive_moves(extended_pattern, static_cast<Sign>(defender), static_cast<PatternType>(pattern_type));
+}
+uint16_t ago_open_three_promotion_moves(uint32_t normal_pattern)
+{
+	return open_three_promotion_moves(normal_pattern);
+}
+uint16_t ago_score_op(uint16_t raw, int op)
+{
+	const Score s = Score::raw(raw);
+	switch (op)
+	{
+		case 0: return invert_up(s).d;
+		case 1: return invert_down(s).d;
+		case 2: return negate(s).d;
+		default: return raw;
+	}
+}
+int ago_score_info(uint16_t raw, int *out_distance, float *out_value)
+{
+	const Score s = Score::raw(raw);
+	*out_distance = s.distance();
+	const Value v = s.to_value();
+	out_value[0] = v.win;
+	out_value[1] = v.draw;
+	return (s.is_proven() ? 1 : 0) | (s.is_win() ? 2 : 0) | (s.is_loss() ? 4 : 0) | (s.is_draw() ? 8 : 0) | (s.is_unproven() ? 16 : 0) | (s.is_infinite() ? 32 : 0);
+}
+uint16_t ago_score_make(int pv, int eval)
+{
+	return Score(static_cast<ProvenValue>(pv), eval).d;
+}
+void ago_edge_update_value(float *win_draw, int *visits, float ew, float ed)
+{
+	Edge e;
+	e.value = Value(win_draw[0], win_draw[1]);
+	e.visits = *visits;
+	e.update_value(Value(ew, ed));
+	win_draw[0] = e.value.win;
+	win_draw[1] = e.value.draw;
+	*visits = e.visits;
+}
+void ago_node_update_value(float *win_draw, int *visits, float ew, float ed)
+{
+	Node n;
+	n.value = Value(win_draw[0], win_draw[1]);
+	n.visits = *visits;
+	n.update_value(Value(ew, ed));
+	win_draw[0] = n.value.win;
+	win_draw[1] = n.value.draw;
+	*visits = n.visits;
+}
+uint16_t ago_move_to_short(int sign, int row, int col)
+{
+	return Move(static_cast<Sign>(sign), row, col).to_short();
+}
+
+void ago_encode_features(int rules, int rows, int cols, const uint8_t *board, int sign_to_move, uint32_t *out)
+{
+	Calc calc(make_cfg(rules, rows, cols));
+	calc.set_board(board, static_cast<Sign>(sign_to_move));
+	encode_features(calc, out);
+}
+/* per cell: pattern types [cell][2][4], threats [cell][2]; lists: for each sign, for each threat type 0..9: count then (row, col) pairs */
+int ago_pattern_state(int rules, int rows, int cols, const uint8_t *board, int sign_to_move, const uint16_t *moves, int n_moves, uint8_t *ptypes,
+		uint8_t *threats, int16_t *lists, int lists_capacity)
+{ // applies add_move for moves[i] (Move::to_short encoding); a move with sign 0 means "undo the most recent not-yet-undone move"
+	Calc calc(make_cfg(rules, rows, cols));
+	calc.set_board(board, static_cast<Sign>(sign_to_move));
+	std::vector<Move> done;
+	for (int i = 0; i < n_moves; i++)
+	{
+		const Move m = Move::from_short(moves[i]);
+		if (m.sign == NONE)
+		{
+			calc.undo_move(done.back());
+			done.pop_back();
+		}
+		else
+		{
+			calc.add_move(m);
+			done.push_back(m);
+		}
+	}
+	for (int i = 0; i < rows * cols; i++)
+	{
+		std::memcpy(ptypes + i * 8, calc.ptype[i], 8);
+		threats[2 * i] = calc.threat[i][0];
+		threats[2 * i + 1] = calc.threat[i][1];
+	}
+	int pos = 0;
+	for (int s = 0; s < 2; s++)
+		for (int t = 0; t < 10; t++)
+		{
+			const LocList &l = calc.hist[s][t];
+			if (pos + 1 + 2 * l.size() > lists_capacity)
+				return -1;
+			lists[pos++] = static_cast<int16_t>(l.size());
+			for (const Loc &x : l.v)
+			{
+				lists[pos++] = x.row;
+				lists[pos++] = x.col;
+			}
+		}
+	return pos;
+}
+int ago_outcome(int rules, int rows, int cols, const uint8_t *board, int sign, int row, int col, int draw_after)
+{
+	return get_outcome(static_cast<Rules>(rules), board, rows, cols, Move(static_cast<Sign>(sign), row, col), draw_after);
+}
+int ago_is_forbidden(int rows, int cols, const uint8_t *board, int sign, int row, int col)
+{
+	return is_forbidden_static(board, rows, cols, Move(static_cast<Sign>(sign), row, col)) ? 1 : 0;
+}
+/* returns the number of actions; moves as Move::to_short, scores raw; flags: bit0 must_defend, bit1 has_initiative, bit2 fully expanded */
+int ago_movegen(int rules, int rows, int cols, const uint8_t *board, int sign_to_move, int mode, int draw_after, uint16_t *moves, uint16_t *scores,
+		int *flags, uint16_t *result_score)
+{
+	GameConfig cfg = make_cfg(rules, rows, cols);
+	if (draw_after > 0)
+		cfg.draw_after = draw_after;
+	Calc calc(cfg);
+	calc.set_board(board, static_cast<Sign>(sign_to_move));
+	MoveGen gen(cfg, calc);
+	ActionStack stack;
+	stack.data.resize(4096);
+	ActionList list;
+	list.stack = &stack;
+	const Score s = gen.generate(list, static_cast<GenMode>(mode));
+	for (int i = 0; i < list.size; i++)
+	{
+		moves[i] = list[i].move.to_short();
+		scores[i] = list[i].score.d;
+	}
+	*flags = (list.must_defend ? 1 : 0) | (list.has_initiative ? 2 : 0) | (list.is_fully_expanded ? 4 : 0);
+	*result_score = s.d;
+	return list.size;
+}
+
+/* persistent solver (keeps its transposition table across calls like one AlphaBetaSearch per game) */
+void* ago_solver_create(int rules, int rows, int cols, uint64_t table_entries, uint64_t zobrist_seed, int max_nodes)
+{
+	Solver *s = new Solver(make_cfg(rules, rows, cols), table_entries, zobrist_seed);
+	s->max_nodes = max_nodes;
+	return s;
+}
+void ago_solver_destroy(void *h)
+{
+	delete static_cast<Solver*>(h);
+}
+void ago_solver_zobrist(void *h, uint64_t *out)
+{
+	Solver *s = static_cast<Solver*>(h);
+	for (size_t i = 0; i < s->zobrist.size(); i++)
+	{
+		out[2 * i] = s->zobrist[i].lo;
+		out[2 * i + 1] = s->zobrist[i].hi;
+	}
+}
+void ago_solver_new_generation(void *h)
+{
+	static_cast<Solver*>(h)->increase_generation();
+}
+int ago_solver_solve(void *h, const uint8_t *board, int sign_to_move, uint32_t *features, uint16_t *moves, uint16_t *scores, int *flags,
+		uint16_t *result_score, int *nodes)
+{
+	Solver *s = static_cast<Solver*>(h);
+	Solver::Output out;
+	s->solve(board, static_cast<Sign>(sign_to_move), features, out);
+	for (size_t i = 0; i < out.actions.size(); i++)
+	{
+		moves[i] = out.actions[i].move.to_short();
+		scores[i] = out.actions[i].score.d;
+	}
+	*flags = out.must_defend ? 1 : 0;
+	*result_score = out.score.d;
+	*nodes = out.nodes;
+	return static_cast<int>(out.actions.size());
+}
+
+/* deterministic stand-in evaluator: a pure function of the feature words (used where the NN itself is not under test) */
+void ago_fake_eval(int count, int hw, const uint32_t *features, float *policy, float *value)
+{
+	for (int b = 0; b < count; b++)
+	{
+		const uint32_t *f = features + static_cast<size_t>(b) * hw;
+		float *p = policy + static_cast<size_t>(b) * hw;
+		uint32_t acc = 2166136261u;
+		float sum = 0.0f;
+		for (int i = 0; i < hw; i++)
+		{
+			uint32_t h = (f[i] ^ (static_cast<uint32_t>(i) * 2654435761u)) * 2246822519u;
+			h ^= h >> 15;
+			acc = (acc ^ f[i]) * 16777619u;
+			float w = 0.0f;
+			if (f[i] & 1u)
+			{
+				const int threat_bits = __builtin_popcount(f[i] >> 8);
+				w = 1.0f + static_cast<float>(h % 1024u) * (1.0f / 1024.0f) + 2.0f * threat_bits;
+			}
+			p[i] = w;
+			sum += w;
+		}
+		if (sum > 0.0f)
+		{
+			const float inv = 1.0f / sum;
+			for (int i = 0; i < hw; i++)
+				p[i] *= inv;
+		}
+		acc ^= acc >> 13;
+		value[2 * b] = 0.25f + 0.5f * static_cast<float>(acc % 4096u) * (1.0f / 4096.0f);
+		value[2 * b + 1] = 0.125f;
+	}
+}
+
+int ago_prepare_opening(int rules, int rows, int cols, uint32_t seed, uint16_t *moves)
+{
+	const std::vector<Move> o = prepare_opening(make_cfg(rules, rows, cols), seed);
+	for (size_t i = 0; i < o.size(); i++)
+		moves[i] = o[i].to_short();
+	return static_cast<int>(o.size());
+}
+
+void* ago_game_create(int rules, int rows, int cols, const AgoSearchConfig *cfg)
+{
+	return new GameHandle(make_cfg(rules, rows, cols), convert(cfg));
+}
+void ago_game_destroy(void *h)
+{
+	delete static_cast<GameHandle*>(h);
+}
+void ago_game_begin(void *h, const uint16_t *opening, int n)
+{
+	std::vector<Move> o;
+	for (int i = 0; i < n; i++)
+		o.push_back(Move::from_short(opening[i]));
+	static_cast<GameHandle*>(h)->game.begin(o);
+}
+/* returns number of positions to evaluate; features copied to out (capacity in positions) */
+int ago_game_step_select(void *h, uint32_t *features_out, int capacity)
+{
+	GameHandle *g = static_cast<GameHandle*>(h);
+	const int n = g->game.step_select(g->features);
+	if (n > capacity)
+		return -1;
+	std::memcpy(features_out, g->features.data(), g->features.size() * sizeof(uint32_t));
+	return n;
+}
+int ago_game_step_expand(void *h, const float *policy, const float *value)
+{
+	return static_cast<GameHandle*>(h)->game.step_expand(policy, value);
+}
+int ago_game_outcome(void *h)
+{
+	return static_cast<GameHandle*>(h)->game.outcome;
+}
+int ago_game_num_records(void *h)
+{
+	return static_cast<int>(static_cast<GameHandle*>(h)->game.records.size());
+}
+/* record i: move (short), root visits, root value, root score, and per edge: move, visits, prior bits, win bits, draw bits, score */
+int ago_game_record(void *h, int index, uint16_t *move, int *root_visits, float *root_value, uint16_t *root_score, uint16_t *edge_moves,
+		int32_t *edge_visits, float *edge_prior, float *edge_value, uint16_t *edge_score, int capacity)
+{
+	const Game::MoveRecord &r = static_cast<GameHandle*>(h)->game.records.at(index);
+	*move = r.move.to_short();
+	*root_visits = r.root_visits;
+	root_value[0] = r.root_value.win;
+	root_value[1] = r.root_value.draw;
+	*root_score = r.root_score.d;
+	const int n = static_cast<int>(r.root_edges.size());
+	if (n > capacity)
+		return -1;
+	for (int i = 0; i < n; i++)
+	{
+		edge_moves[i] = r.root_edges[i].move.to_short();
+		edge_visits[i] = r.root_edges[i].visits;
+		edge_prior[i] = r.root_edges[i].prior;
+		edge_value[2 * i] = r.root_edges[i].value.win;
+		edge_value[2 * i + 1] = r.root_edges[i].value.draw;
+		edge_score[i] = r.root_edges[i].score.d;
+	}
+	return n;
+}
+/* stats: nodes, nn_evals, leaks, duplicates, proven, wasted, solver_nodes, select_levels, select_edges, tree nodes, tree edges */
+void ago_game_stats(void *h, uint64_t *out)
+{
+	GameHandle *g = static_cast<GameHandle*>(h);
+	const Stats &s = g->game.search.stats;
+	out[0] = s.nodes;
+	out[1] = s.nn_evals;
+	out[2] = s.leaks;
+	out[3] = s.duplicates;
+	out[4] = s.proven;
+	out[5] = s.wasted;
+	out[6] = s.solver_nodes;
+	out[7] = g->game.tree.stats.select_levels;
+	out[8] = g->game.tree.stats.select_edges;
+	out[9] = g->game.tree.nodes.size();
+	out[10] = g->game.tree.edges.size();
+}
+/* current root snapshot (for step-by-step parity): returns number of edges */
+int ago_game_root(void *h, int *root_visits, float *root_value, uint16_t *root_score, uint16_t *edge_moves, int32_t *edge_visits, float *edge_prior,
+		float *edge_value, uint16_t *edge_score, uint16_t *edge_flag_vl, int capacity)
+{
+	Game &g = static_cast<GameHandle*>(h)->game;
+	if (g.tree.root < 0)
+		return 0;
+	const Node &r = g.tree.nodes[g.tree.root];
+	*root_visits = r.visits;
+	root_value[0] = r.value.win;
+	root_value[1] = r.value.draw;
+	*root_score = r.score.d;
+	if (r.n_edges > capacity)
+		return -1;
+	for (int i = 0; i < r.n_edges; i++)
+	{
+		const Edge &e = g.tree.edges[r.edge_begin + i];
+		edge_moves[i] = e.move.to_short();
+		edge_visits[i] = e.visits;
+		edge_prior[i] = e.prior;
+		edge_value[2 * i] = e.value.win;
+		edge_value[2 * i + 1] = e.value.draw;
+		edge_score[i] = e.score.d;
+		edge_flag_vl[i] = e.flag_vl;
+	}
+	return r.n_edges;
+}
+
+/*
+ * CPU baseline: plays `games_per_thread` self-play games on each of `threads` host threads with the stand-in evaluator
+ * (network cost = 0), for at most `max_seconds`; returns evaluated nodes, completed games and moves made.
+ */
+void ago_cpu_baseline(int rules, int rows, int cols, const AgoSearchConfig *cfg, int threads, int games_per_thread, double max_seconds, uint64_t *out_nodes,
+		uint64_t *out_games, uint64_t *out_moves, double *out_seconds, uint64_t *out_stats)
+{
+	const GameConfig gc = make_cfg(rules, rows, cols);
+	const SearchConfig sc = convert(cfg);
+	Tables::get(gc.rules);
+	std::vector<uint64_t> nodes(threads, 0), games(threads, 0), moves(threads, 0);
+	std::vector<std::vector<uint64_t>> st(threads, std::vector<uint64_t>(9, 0));
+	const auto t0 = std::chrono::steady_clock::now();
+	auto worker = [&](int tid)
+	{
+		const int hw = rows * cols;
+		std::vector<uint32_t> features;
+		std::vector<float> policy(static_cast<size_t>(sc.max_batch_size) * hw), value(2 * sc.max_batch_size);
+		Game game(gc, sc);
+		for (int gi = 0; gi < games_per_thread; gi++)
+		{
+			game.begin(prepare_opening(gc, 1000u * tid + gi));
+			while (!game.is_over())
+			{
+				const int n = game.step_select(features);
+				ago_fake_eval(n, hw, features.data(), policy.data(), value.data());
+				moves[tid] += game.step_expand(policy.data(), value.data());
+				const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+				if (el > max_seconds)
+					break;
+			}
+			if (game.is_over())
+				games[tid]++;
+			const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+			if (el > max_seconds)
+				break;
+		}
+		nodes[tid] = game.search.stats.nodes;
+		const Stats &s = game.search.stats;
+		const uint64_t vals[9] = { s.nodes, s.nn_evals, s.leaks, s.duplicates, s.proven, s.wasted, s.solver_nodes, game.tree.stats.select_levels, game.tree.stats.select_edges };
+		for (int k = 0; k < 9; k++)
+			st[tid][k] = vals[k];
+	};
+	std::vector<std::thread> pool;
+	for (int t = 0; t < threads; t++)
+		pool.emplace_back(worker, t);
+	for (auto &t : pool)
+		t.join();
+	*out_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+	*out_nodes = *out_games = *out_moves = 0;
+	for (int k = 0; k < 9; k++)
+		out_stats[k] = 0;
+	for (int t = 0; t < threads; t++)
+	{
+		*out_nodes += nodes[t];
+		*out_games += games[t];
+		*out_moves += moves[t];
+		for (int k = 0; k < 9; k++)
+			out_stats[k] += st[t][k];
+	}
+}
+
+} /* extern "C" */

@@ -1,0 +1,495 @@
+/*
+ * oracle/agoracle.hpp — TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement (plain scalar C++17, no intrinsics) of the AlphaGomoku self-play hot path, used as the checker for
+ * the HIP implementation in alphagomoku_amd/csrc and as the timed CPU baseline ("port") of bench.py.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load anything built from this directory.
+ *
+ * Pinning:
+ *   - tables, score algebra, record layouts: compared entry-by-entry with the real reference compiled from its own
+ *     sources (oracle/_ref/libagref.so, oracle/ref_driver.cpp) and with checksums committed under tests/golden;
+ *   - rules / NN input features / move generator: the reference's own test fixtures (test/game/*.cpp,
+ *     test/networks/test_NNInputFeatures.cpp, test/search/alpha_beta/test_move_generator.cpp) restated as data in
+ *     tests/golden;
+ *   - alpha-beta solver, Tree/Search/GameGenerator: PARITY UNPINNED — the reference's tests for them are commented out
+ *     (test/search/monte_carlo/test_Tree.cpp:16-125 ...) and those translation units cannot be compiled here without
+ *     writing stand-ins for the absent MinML headers.
+ *
+ * Each function cites the reference file:line it follows.
+ */
+#ifndef AGORACLE_HPP_
+#define AGORACLE_HPP_
+
+#include <cstdint>
+#include <cstring>
+#include <vector>
+#include <string>
+#include <algorithm>
+#include <cassert>
+#include <cmath>
+#include <limits>
+
+namespace ago
+{
+	/* ---- basic records ---- */
+	enum Rules : int { FREESTYLE = 0, STANDARD = 1, RENJU = 2, CARO5 = 3, CARO6 = 4 }; // game/rules.hpp:18-25
+	typedef uint8_t Sign;                                                             // game/Move.hpp:17-23
+	constexpr Sign NONE = 0, CROSS = 1, CIRCLE = 2, ILLEGAL = 3;
+	inline Sign invert_sign(Sign s) { return (s == CROSS) ? CIRCLE : ((s == CIRCLE) ? CROSS : s); }
+
+	typedef int Direction; // patterns/common.hpp:27-49: 0 horizontal, 1 vertical, 2 diagonal (r+,c+), 3 antidiagonal (r+,c-)
+	inline int row_step(Direction d) { return d == 0 ? 0 : 1; }
+	inline int col_step(Direction d) { return d == 0 ? 1 : (d == 1 ? 0 : (d == 2 ? 1 : -1)); }
+
+	struct Loc
+	{
+			int8_t row = 0, col = 0;
+			Loc() = default;
+			Loc(int r, int c) : row(static_cast<int8_t>(r)), col(static_cast<int8_t>(c)) {}
+			bool operator==(const Loc &o) const { return row == o.row && col == o.col; }
+			bool operator!=(const Loc &o) const { return !(*this == o); }
+	};
+	inline Loc shift(Direction d, int dist, Loc o) { return Loc(o.row + dist * row_step(d), o.col + dist * col_step(d)); }
+
+	struct Move
+	{ // game/Move.hpp:92-174
+			Sign sign = NONE;
+			int8_t row = 0, col = 0;
+			Move() = default;
+			Move(Sign s, int r, int c) : sign(s), row(static_cast<int8_t>(r)), col(static_cast<int8_t>(c)) {}
+			Move(Sign s, Loc l) : sign(s), row(l.row), col(l.col) {}
+			Loc loc() const { return Loc(row, col); }
+			uint16_t to_short() const { return static_cast<uint16_t>(sign) | (static_cast<uint16_t>(row) << 2) | (static_cast<uint16_t>(col) << 9); } // :144-147
+			static Move from_short(uint16_t s) { return Move(static_cast<Sign>(s & 3), (s >> 2) & 127, (s >> 9) & 127); }
+			bool operator==(const Move &o) const { return sign == o.sign && row == o.row && col == o.col; }
+			bool operator!=(const Move &o) const { return !(*this == o); }
+	};
+
+	struct Value
+	{ // search/Value.hpp:26-114
+			float win = 0.0f, draw = 0.0f;
+			Value() = default;
+			Value(float w, float d = 0.0f) : win(w), draw(d) {}
+			float loss() const { return 1.0f - (win + draw); }
+			float expectation() const { return win + 0.5f * draw; }
+			Value inverted() const { return Value(loss(), draw); }
+			float abs() const { return fabsf(win) + fabsf(draw); }
+			void clip() { win = std::max(0.0f, std::min(1.0f, win)); draw = std::max(0.0f, std::min(1.0f, draw)); }
+			friend Value operator+(Value a, Value b) { return Value(a.win + b.win, a.draw + b.draw); }
+			friend Value operator-(Value a, Value b) { return Value(a.win - b.win, a.draw - b.draw); }
+			friend Value operator*(Value a, float s) { return Value(a.win * s, a.draw * s); }
+	};
+
+	enum ProvenValue : int { PV_LOSS = 0, PV_DRAW = 1, PV_UNKNOWN = 2, PV_WIN = 3 }; // search/Score.hpp:26-32
+	enum Bound : int { B_NONE = 0, B_LOWER = 1, B_UPPER = 2, B_EXACT = 3 };          // :37-43
+
+	struct Score
+	{ // search/Score.hpp:47-320 — 16 bits: proven value << 13 | (eval + 4000)
+			uint16_t d;
+			Score() : d(static_cast<uint16_t>((PV_UNKNOWN << 13) | 4000)) {}
+			explicit Score(int eval) : d(static_cast<uint16_t>((PV_UNKNOWN << 13) | (4000 + eval))) {}
+			Score(ProvenValue pv, int eval) : d(static_cast<uint16_t>((static_cast<unsigned>(pv) << 13) | static_cast<unsigned>(4000 + eval))) {}
+			static Score raw(uint16_t r) { Score s; s.d = r; return s; }
+			static Score minus_inf() { return raw(0x0000); } // :152-159
+			static Score plus_inf() { return raw(0xFFFF); }
+			static Score loss_in(int n) { return Score(PV_LOSS, n); } // :178-201
+			static Score draw_in(int n) { return Score(PV_DRAW, n); }
+			static Score win_in(int n) { return Score(PV_WIN, -n); }
+			int eval() const { return (d & 8191) - 4000; }
+			ProvenValue pv() const { return static_cast<ProvenValue>((d >> 13) & 3); }
+			bool is_infinite() const { return d == 0x0000 || d == 0xFFFF; }
+			bool is_finite() const { return !is_infinite(); }
+			bool is_unproven() const { return pv() == PV_UNKNOWN; }
+			bool is_proven() const { return pv() != PV_UNKNOWN && is_finite(); }
+			bool is_loss() const { return pv() == PV_LOSS && is_finite(); }
+			bool is_draw() const { return pv() == PV_DRAW; }
+			bool is_win() const { return pv() == PV_WIN && is_finite(); }
+			int distance() const { return (pv() == PV_LOSS || pv() == PV_DRAW) ? eval() : (pv() == PV_WIN ? -eval() : 0); } // :100-114
+			Value to_value() const
+			{ // :266-283
+				switch (pv())
+				{
+					case PV_LOSS: return Value(0.0f, 0.0f);
+					case PV_DRAW: return Value(0.0f, 1.0f);
+					case PV_UNKNOWN: return Value((1000 + eval()) / 2000.0f, 0.0f);
+					default: return is_finite() ? Value(1.0f, 0.0f) : Value();
+				}
+			}
+			friend bool operator==(Score a, Score b) { return a.d == b.d; }
+			friend bool operator!=(Score a, Score b) { return a.d != b.d; }
+			friend bool operator<(Score a, Score b) { return a.d < b.d; } // :250 total order = raw compare
+			friend bool operator<=(Score a, Score b) { return a.d <= b.d; }
+			friend bool operator>(Score a, Score b) { return a.d > b.d; }
+			friend bool operator>=(Score a, Score b) { return a.d >= b.d; }
+	};
+	Score negate(Score s);      // Score.hpp:213-228
+	Score invert_up(Score s);   // :285-300
+	Score invert_down(Score s); // :303-318
+
+	/* ---- pattern / threat vocabulary ---- */
+	enum PatternType : uint8_t { P_NONE = 0, P_HALF_OPEN_3, P_OPEN_3, P_HALF_OPEN_4, P_OPEN_4, P_DOUBLE_4, P_FIVE, P_OVERLINE }; // PatternTable.hpp:22-32
+	enum ThreatType : uint8_t { T_NONE = 0, T_HALF_OPEN_3, T_OPEN_3, T_FORK_3x3, T_HALF_OPEN_4, T_FORK_4x3, T_FORK_4x4, T_OPEN_4, T_FIVE, T_OVERLINE }; // ThreatTable.hpp:22-34
+
+	struct Tables
+	{
+			Rules rules;
+			std::vector<uint8_t> pattern_types;   // [4^10] low nibble cross, high nibble circle (PatternTable.hpp:36-70), HALF_OPEN_3 stored as NONE
+			std::vector<uint8_t> half_open_3;     // [4^10] bit0 cross, bit1 circle (PatternTable.cpp:139-150)
+			uint8_t threats[4096][2];             // ThreatTable.cpp:179-189
+			uint16_t five_defense[5][256][2];     // DefensiveMoveTable.cpp:503-526, [..][0] for cross defending, [1] circle defending
+			uint16_t open_four_defense[4][256][2];
+			uint16_t double_four_defense[6][256][2];
+			static const Tables& get(Rules r);
+			static uint32_t narrow(uint32_t x) { return (x & 1023u) | ((x & 4190208u) >> 2); } // PatternTable.hpp:131-134
+			uint8_t pattern_type(uint32_t normal_pattern, Sign s) const
+			{
+				const uint8_t e = pattern_types[narrow(normal_pattern)];
+				return (s == CROSS) ? (e & 15) : (e >> 4);
+			}
+			bool is_half_open_three(uint32_t normal_pattern, Sign s) const { return (half_open_3[narrow(normal_pattern)] >> (s == CROSS ? 0 : 1)) & 1; }
+			ThreatType threat(const uint8_t pt[4], Sign s) const { return static_cast<ThreatType>(threats[pt[0] | (pt[1] << 3) | (pt[2] << 6) | (pt[3] << 9)][s == CROSS ? 0 : 1]); }
+			uint16_t defensive_moves(uint32_t extended_pattern, Sign defender, PatternType threat_to_defend) const; // DefensiveMoveTable.cpp:380-461
+	};
+	uint16_t open_three_promotion_moves(uint32_t normal_pattern); // DefensiveMoveTable.cpp:329-377
+
+	struct GameConfig
+	{
+			Rules rules = FREESTYLE;
+			int rows = 15, cols = 15, draw_after = 225;
+			GameConfig() = default;
+			GameConfig(Rules r, int n) : rules(r), rows(n), cols(n), draw_after(n * n) {}
+	};
+
+	enum Outcome : int { O_UNKNOWN = 0, O_DRAW = 1, O_CROSS_WIN = 2, O_CIRCLE_WIN = 3 }; // game/rules.hpp:29-35
+
+	/* ---- incremental pattern/threat state (patterns/PatternCalculator.{hpp,cpp}) ---- */
+	struct LocList
+	{ // ThreatHistogram.hpp:39-113: push-back add, swap-with-last remove
+			std::vector<Loc> v;
+			int size() const { return static_cast<int>(v.size()); }
+			void add(Loc l) { v.push_back(l); }
+			void remove(Loc l)
+			{
+				for (size_t i = 0; i < v.size(); i++)
+					if (v[i] == l)
+					{
+						v[i] = v.back();
+						v.pop_back();
+						return;
+					}
+			}
+	};
+
+	class Calc
+	{
+		public:
+			static constexpr int MAXN = 20;
+			GameConfig cfg;
+			const Tables *tab = nullptr;
+			Sign sign_to_move = NONE;
+			int depth = 0;
+			Sign board[MAXN * MAXN];
+			uint8_t ptype[MAXN * MAXN][2][4]; // [cell][0 cross / 1 circle][dir]
+			uint8_t threat[MAXN * MAXN][2];
+			uint32_t legal[MAXN];             // bit col of row
+			LocList hist[2][10];
+
+			explicit Calc(GameConfig c);
+			int idx(int r, int c) const { return r * cfg.cols + c; }
+			bool inside(int r, int c) const { return r >= 0 && r < cfg.rows && c >= 0 && c < cfg.cols; }
+			Sign at(int r, int c) const { return board[idx(r, c)]; }
+			uint32_t raw_pattern(int r, int c, Direction d, int pad) const; // RawPatternCalculator.hpp:62-78,196-210 semantics
+			uint32_t normal_pattern(int r, int c, Direction d) const { return raw_pattern(r, c, d, 5); }
+			void set_board(const Sign *b, Sign to_move);             // PatternCalculator.cpp:40-66
+			void add_move(Move m);                                   // :68-86
+			void undo_move(Move m);                                  // :87-105
+			const uint8_t* patterns(Sign s, int r, int c) const { return ptype[idx(r, c)][s == CROSS ? 0 : 1]; }
+			ThreatType threat_at(Sign s, int r, int c) const { return static_cast<ThreatType>(threat[idx(r, c)][s == CROSS ? 0 : 1]); }
+			const LocList& threats(Sign s, ThreatType t) const { return hist[s == CROSS ? 0 : 1][t]; }
+			bool has_any_four(Sign s) const; // ThreatHistogram.hpp:130-134
+			int defensive_moves(Sign defender, int r, int c, Direction d, Loc out[6]) const; // PatternCalculator.hpp:150-160
+			bool is_forbidden(Sign s, int r, int c);                 // PatternCalculator.hpp:161-177
+		private:
+			bool is_3x3_forbidden(Sign s, int r, int c);             // PatternCalculator.cpp:213-244
+			void update_around(int r, int c, bool added, Loc removed_from); // :278-329
+			void update_cell(int r, int c, Direction d);             // :330-367
+	};
+
+	Outcome get_outcome(Rules rules, const Sign *board, int rows, int cols, Move last, int draw_after); // game/rules.cpp:110-133
+	bool is_forbidden_static(const Sign *board, int rows, int cols, Move m);                              // game/rules.cpp:134-173
+	void encode_features(Calc &calc, uint32_t *out);                                                      // NNInputFeatures.cpp:59-113
+
+	/* ---- move generator (search/alpha_beta/MoveGenerator.cpp) ---- */
+	struct Action
+	{
+			Move move;
+			Score score;
+	};
+	enum GenMode : int { G_BASIC = 0, G_THREATS = 1, G_OPTIMAL = 2, G_REDUCED = 3, G_LEGAL = 4 }; // MoveGenerator.hpp:27-34
+
+	struct ActionStack
+	{ // ActionList.hpp:42-99
+			std::vector<Action> data;
+			size_t offset = 0, max_offset = 0;
+	};
+	struct ActionList
+	{ // ActionList.hpp:101-268 (a window on the shared stack)
+			ActionStack *stack = nullptr;
+			size_t base = 0;
+			int size = 0;
+			int distance_from_root = 0;
+			Score baseline_score;
+			bool is_fully_expanded = false, has_initiative = false, must_defend = false;
+			Action& operator[](int i) { return stack->data[base + i]; }
+			const Action& operator[](int i) const { return stack->data[base + i]; }
+			void add(Move m, Score s, int num = 1);
+			void release(); // what ~ActionList does
+	};
+
+	class MoveGen
+	{
+		public:
+			MoveGen(GameConfig c, Calc &calc) : cfg(c), pc(calc) {}
+			Score generate(ActionList &actions, GenMode mode); // MoveGenerator.cpp:159-223
+		private:
+			struct Result { bool must_continue = true; Score score; };
+			GameConfig cfg;
+			Calc &pc;
+			ActionList *act = nullptr;
+			uint32_t added[Calc::MAXN];
+			std::vector<std::pair<Loc, bool>> forbidden_cache;
+			Sign own() const { return pc.sign_to_move; }
+			Sign opp() const { return invert_sign(pc.sign_to_move); }
+			bool anything_forbidden_for(Sign s) const { return cfg.rules == RENJU && s == CROSS; }
+			bool is_forbidden(Sign s, Loc l);
+			void add_move(Loc l, Score s, bool override_duplicate);
+			void add_moves(const std::vector<Loc> &ls, Score s, bool override_duplicate);
+			int get_defensive_moves(Loc move, Direction d, Loc out[8]);
+			Result try_draw_in_1();
+			Result try_win_in_1();
+			Result defend_loss_in_2();
+			Result try_win_in_3();
+			Result defend_loss_in_4();
+			Result try_win_in_5();
+			Result defend_loss_in_6();
+			Score add_own_4x3_forks();
+			void add_own_half_open_fours();
+			Score try_solve_own_fork_4x3(Loc move);
+			void mark_forbidden_moves();
+			void mark_neighborhood(uint32_t out[Calc::MAXN]);
+			void mark_star_like_pattern_for(Sign s, uint32_t out[Calc::MAXN]);
+			void create_remaining_moves(const uint32_t mask[Calc::MAXN], Score s);
+			int number_of_available_fours_for(Sign s) const;
+	};
+
+	/* ---- in-loop alpha-beta solver (search/alpha_beta/AlphaBetaSearch.cpp, SharedHashTable.hpp) ---- */
+	struct Key128 { uint64_t lo = 0, hi = 0; };
+	struct TTEntry { uint64_t key_hi = 0; uint64_t data = 0; };
+
+	class Solver
+	{
+		public:
+			Solver(GameConfig c, size_t table_entries, uint64_t zobrist_seed);
+			GameConfig cfg;
+			Calc calc;
+			MoveGen gen;
+			int max_nodes = 100;
+			int max_depth = 100;
+			int generation = 0;
+			void clear();
+			void increase_generation() { generation = (generation + 1) % 64; }
+			struct Output
+			{
+					std::vector<Action> actions; // root actions in final list order
+					Score score;
+					bool must_defend = false;
+					int nodes = 0;
+			};
+			/* sets the board, encodes the features (AlphaBetaSearch.cpp:83-84) and solves */
+			void solve(const Sign *board, Sign to_move, uint32_t *features_out, Output &out); // :77-156
+			std::vector<Key128> zobrist; // [2*HW] FastZobristHashing keys (ZobristHashing.cpp:35-43); values are this oracle's own (documented)
+		private:
+			ActionStack stack;
+			std::vector<TTEntry> table; // buckets of 4
+			uint64_t bucket_mask = 0;
+			Key128 hash;
+			int node_counter = 0;
+			Score recursive_solve(int depth_remaining, Score alpha, Score beta, ActionList &actions); // :185-339
+			Score evaluate();                                                                        // :345-365
+			uint64_t tt_seek(const Key128 &k) const;                                                  // SharedHashTable.hpp:142-150
+			void tt_insert(const Key128 &k, uint64_t value);                                          // :151-175
+	};
+	uint64_t splitmix64(uint64_t &state);
+
+	/* ---- MCTS (search/monte_carlo) ---- */
+	struct Edge
+	{ // Edge.hpp:23-32 (24 bytes in the reference)
+			float prior = 0.0f;
+			Value value;
+			int32_t visits = 0;
+			Move move;
+			Score score;
+			uint16_t flag_vl = 0; // bit15 being expanded, bits0-14 virtual loss
+			int vl() const { return flag_vl & 0x7FFF; }
+			bool being_expanded() const { return (flag_vl & 0x8000u) != 0; }
+			void update_value(Value eval)
+			{ // Edge.hpp:111-117
+				visits++;
+				const float tmp = 1.0f / visits;
+				value = value + (eval - value) * tmp;
+				value.clip();
+			}
+	};
+	struct Node
+	{ // Node.hpp:24-42 (40 bytes in the reference, with an Edge* instead of an offset)
+			int32_t edge_begin = -1;
+			Value value;
+			float moves_left = 0.0f;
+			int32_t visits = 0;
+			Score score;
+			int16_t n_edges = 0, depth = 0, vl = 0;
+			Sign sign_to_move = NONE;
+			uint16_t flags = 0; // root 2, fully expanded 4, static 8, recursive 16, must defend 32 (Node.hpp:26-31)
+			bool fully_expanded() const { return (flags & 4) != 0; }
+			void update_value(Value eval)
+			{ // Node.hpp:268-274 — NB the reciprocal is computed in double and narrowed
+				visits++;
+				const float tmp = static_cast<float>(1.0 / visits);
+				value = value + (eval - value) * tmp;
+				value.clip();
+			}
+	};
+
+	struct SearchConfig
+	{ // utils/configs.hpp (TreeConfig, EdgeSelectorConfig, MCTSConfig, TSSConfig, SearchConfig)
+			int max_batch_size = 8;
+			float exploration_constant = 1.25f;
+			float exploration_scaling = 0.0f;
+			int init_to = 0;                 // 0 q_head, 1 parent, 2 draw, 3 loss (EdgeSelector.cpp:1140-1165)
+			int max_children = std::numeric_limits<int>::max();
+			float policy_expansion_threshold = 1.0e-4f;
+			float information_leak_threshold = 0.01f;
+			int tss_max_positions = 100;
+			size_t tss_table_entries = 4u * 1024u * 1024u; // AlphaBetaSearch.cpp:59
+			int max_simulations = 400;
+			uint64_t zobrist_seed = 0x9E3779B97F4A7C15ull;
+	};
+
+	struct Task
+	{ // SearchTask.hpp:35-329
+			std::vector<std::pair<int, int>> path; // (node index, edge index into the global edge pool)
+			std::vector<Edge> edges;
+			std::vector<Sign> board;
+			std::vector<uint32_t> features;
+			std::vector<float> policy;
+			std::vector<Value> action_values;
+			std::vector<Score> action_scores;
+			Value value;
+			Score score;
+			float moves_left = 0.0f;
+			int final_node = -1;
+			Sign sign_to_move = NONE;
+			bool must_defend = false, statically_solved = false, recursively_solved = false;
+			bool by_network = false, by_solver = false, skip_edge_generation = false;
+			bool is_ready() const { return score.is_proven() || by_network; }
+	};
+
+	struct Stats
+	{
+			uint64_t nodes = 0, nn_evals = 0, leaks = 0, duplicates = 0, proven = 0, wasted = 0, solver_nodes = 0, select_levels = 0, select_edges = 0;
+	};
+
+	class Tree
+	{
+		public:
+			Tree(GameConfig c, const SearchConfig &sc);
+			GameConfig cfg;
+			SearchConfig scfg;
+			std::vector<Node> nodes;
+			std::vector<Edge> edges;
+			std::vector<std::vector<Sign>> node_boards;
+			std::vector<Sign> base_board;
+			Sign sign_to_move = NONE;
+			int root = -1;
+			void clear();
+			void set_board(const Sign *board, Sign to_move);  // Tree.cpp:128-151 + NodeCache.cpp:221-249
+			int seek(const Sign *board, Sign to_move) const;  // NodeCache.cpp:250-264
+			int select(Task &t);                              // Tree.cpp:226-251; returns 0 leaf, 1 leak, 2 proven edge
+			void generate_edges(Task &t) const;               // EdgeGenerator.cpp:269-303
+			int expand(Task &t);                              // Tree.cpp:257-298; 0 success, 1 already expanded, 2 skipped
+			void backup(const Task &t);                       // Tree.cpp:299-351
+			void correct_information_leak(const Task &t);     // :352-376
+			void cancel_virtual_loss(const Task &t);          // :377-384
+			int simulation_count() const { return root < 0 ? 0 : nodes[root].visits; }
+			bool root_proven() const { return root >= 0 && nodes[root].score.is_proven(); }
+			int select_edge(int node) const;                  // EdgeSelector.cpp:1123-1166 (puct), :562-586
+			int select_best_edge(int node) const;             // BestEdge :515-536 ("best" final selector)
+			mutable Stats stats;
+		private:
+			std::vector<std::vector<int>> bins;
+			std::vector<uint64_t> node_hash;
+			std::vector<uint64_t> keys;
+			uint64_t hash_of(const Sign *board, Sign to_move) const; // ZobristHashing.cpp:21-33
+			bool has_information_leak(const Edge &e, int node) const; // Tree.cpp:75-85
+			void update_node_score(int node);                        // :93-104
+	};
+
+	typedef void (*EvalFn)(void *ctx, int count, const uint32_t *features, float *policy, float *value); // value = (win, draw) pairs
+
+	class Search
+	{ // search/monte_carlo/Search.cpp
+		public:
+			Search(GameConfig c, const SearchConfig &sc);
+			GameConfig cfg;
+			SearchConfig scfg;
+			Solver solver;
+			std::vector<Task> tasks;
+			int stored = 0;
+			void select(Tree &tree, int max_simulations); // :117-158
+			void solve();                                 // :159-183
+			int schedule(std::vector<int> &out) const;    // :184-199 — indices of the tasks that need the network
+			void generate_edges(const Tree &tree);        // :206-213
+			void expand(Tree &tree);                      // :214-223
+			void backup(Tree &tree);                      // :224-232
+			void cleanup(Tree &tree);                     // :233-242
+			Stats stats;
+	};
+
+	class Game
+	{ // selfplay/GameGenerator.cpp:46-121,145-185 + game/Game.cpp (one self-play game, NN supplied by the caller)
+		public:
+			Game(GameConfig c, const SearchConfig &sc);
+			GameConfig cfg;
+			SearchConfig scfg;
+			Tree tree;
+			Search search;
+			std::vector<Sign> board;
+			std::vector<Move> moves;
+			Sign sign_to_move = CROSS;
+			Outcome outcome = O_UNKNOWN;
+			void begin(const std::vector<Move> &opening);
+			/* phase 1: select + solve; returns the number of tasks that need evaluation and their features */
+			int step_select(std::vector<uint32_t> &features_out);
+			/* phase 2: policy [n][HW], value (win, draw) [n][2] for the scheduled tasks, in schedule order; returns 1 if a move was made */
+			int step_expand(const float *policy, const float *value);
+			struct MoveRecord
+			{
+					Move move;
+					int root_visits;
+					std::vector<Edge> root_edges;
+					Value root_value;
+					Score root_score;
+			};
+			std::vector<MoveRecord> records;
+			bool is_over() const { return outcome != O_UNKNOWN; }
+		private:
+			std::vector<int> scheduled;
+			void prepare_search();
+			void make_move();
+	};
+
+	std::vector<Move> prepare_opening(GameConfig cfg, uint32_t seed); // utils/misc.cpp:142-170 (distribution restated; RNG is mt19937(seed))
+
+} /* namespace ago */
+
+#endif /* AGORACLE_HPP_ */

@@ -1,0 +1,136 @@
+/*
+ * oracle/ref_driver.cpp — TEST INFRASTRUCTURE ONLY.
+ *
+ * Thin extern "C" driver over the subset of the reference that compiles from its own sources WITHOUT the absent
+ * MinML library (no stand-in headers are written): src/patterns/{PatternTable,PatternClassifier,ThreatTable,
+ * DefensiveMoveTable}.cpp, src/game/Move.cpp, src/search/{Score,Value,ZobristHashing}.cpp,
+ * src/search/monte_carlo/{Edge,Node}.cpp, src/utils/random.cpp.
+ * Built by oracle/Makefile into oracle/_ref/libagref.so straight from /root/reference; used by tests to pin the
+ * restatement in oracle/ (tables, score algebra, struct layouts) and to generate tests/golden fixtures.
+ * Everything that includes utils/configs.hpp (PatternCalculator, rules, MoveGenerator, AlphaBetaSearch, Tree, Search,
+ * NNInputFeatures ...) pulls in <minml/...> and is therefore unbuildable here.
+ */
+#include <alphagomoku/patterns/PatternTable.hpp>
+#include <alphagomoku/patterns/ThreatTable.hpp>
+#include <alphagomoku/patterns/DefensiveMoveTable.hpp>
+#include <alphagomoku/search/Score.hpp>
+#include <alphagomoku/search/Value.hpp>
+#include <alphagomoku/search/monte_carlo/Edge.hpp>
+#include <alphagomoku/search/monte_carlo/Node.hpp>
+#include <alphagomoku/game/rules.hpp>
+
+#include <cstdint>
+#include <cstring>
+
+using namespace ag;
+
+extern "C" {
+
+/* out[i] = PatternEncoding byte (cross | circle << 4) for the 20-bit narrowed index i (center removed) */
+void ref_pattern_table(int rules, uint8_t *types, uint8_t *half_open_3)
+{
+	const PatternTable &t = PatternTable::get(static_cast<GameRules>(rules));
+	for (uint32_t i = 0; i < (1u << 20); i++)
+	{
+		const uint32_t expanded = (i & 1023u) | ((i & 1047552u) << 2u);
+		const PatternEncoding e = t.getPatternType(NormalPattern(expanded));
+		types[i] = static_cast<uint8_t>(e.forCross()) | (static_cast<uint8_t>(e.forCircle()) << 4);
+		half_open_3[i] = (t.isHalfOpenThree(NormalPattern(expanded), Sign::CROSS) ? 1 : 0) | (t.isHalfOpenThree(NormalPattern(expanded), Sign::CIRCLE) ? 2 : 0);
+	}
+}
+/* out[2*i] = threat for cross, out[2*i+1] = threat for circle; i = h | v<<3 | d<<6 | a<<9 */
+void ref_threat_table(int rules, uint8_t *out)
+{
+	const ThreatTable &t = ThreatTable::get(static_cast<GameRules>(rules));
+	for (int i = 0; i < 4096; i++)
+	{
+		DirectionGroup<PatternType> g;
+		g.horizontal = static_cast<PatternType>(i & 7);
+		g.vertical = static_cast<PatternType>((i >> 3) & 7);
+		g.diagonal = static_cast<PatternType>((i >> 6) & 7);
+		g.antidiagonal = static_cast<PatternType>((i >> 9) & 7);
+		out[2 * i] = static_cast<uint8_t>(t.getThreat<Sign::CROSS>(g));
+		out[2 * i + 1] = static_cast<uint8_t>(t.getThreat<Sign::CIRCLE>(g));
+	}
+}
+uint16_t ref_defensive_moves(int rules, uint32_t extended_pattern, int defender_sign, int pattern_type)
+{
+	const DefensiveMoveTable &t = DefensiveMoveTable::get(static_cast<GameRules>(rules));
+	return t.getMoves(ExtendedPattern(extended_pattern), static_cast<Sign>(defender_sign), static_cast<PatternType>(pattern_type)).raw();
+}
+uint16_t ref_open_three_promotion_moves(uint32_t normal_pattern)
+{
+	return getOpenThreePromotionMoves(NormalPattern(normal_pattern)).raw();
+}
+/* score algebra: op 0 invert_up, 1 invert_down, 2 negate, 3 +1, 4 -1, 5 increaseDistance, 6 decreaseDistance */
+uint16_t ref_score_op(uint16_t raw, int op)
+{
+	Score s = Score::from_short(raw);
+	switch (op)
+	{
+		case 0: return Score::to_short(invert_up(s));
+		case 1: return Score::to_short(invert_down(s));
+		case 2: return Score::to_short(-s);
+		case 3: return Score::to_short(s + 1);
+		case 4: return Score::to_short(s - 1);
+		case 5: s.increaseDistance(); return Score::to_short(s);
+		case 6: s.decreaseDistance(); return Score::to_short(s);
+		default: return raw;
+	}
+}
+/* flags: bit0 isProven, bit1 isWin, bit2 isLoss, bit3 isDraw, bit4 isUnproven, bit5 isInfinite; distance in out_distance */
+int ref_score_info(uint16_t raw, int *out_distance, float *out_value)
+{
+	const Score s = Score::from_short(raw);
+	*out_distance = s.getDistance();
+	const Value v = s.convertToValue();
+	out_value[0] = v.win_rate;
+	out_value[1] = v.draw_rate;
+	return (s.isProven() ? 1 : 0) | (s.isWin() ? 2 : 0) | (s.isLoss() ? 4 : 0) | (s.isDraw() ? 8 : 0) | (s.isUnproven() ? 16 : 0) | (s.isInfinite() ? 32 : 0);
+}
+uint16_t ref_score_make(int proven_value, int eval)
+{
+	return Score::to_short(Score(static_cast<ProvenValue>(proven_value), eval));
+}
+int ref_sizeof(int what)
+{
+	switch (what)
+	{
+		case 0: return sizeof(Edge);
+		case 1: return sizeof(Node);
+		case 2: return sizeof(Move);
+		case 3: return sizeof(Score);
+		case 4: return sizeof(Value);
+		default: return -1;
+	}
+}
+/* running-mean updates exactly as Edge::updateValue / Node::updateValue (Edge.hpp:111-117, Node.hpp:268-274) */
+void ref_edge_update_value(float *win_draw, int *visits, float ew, float ed)
+{
+	Edge e;
+	e.setValue(Value(win_draw[0], win_draw[1]));
+	for (int i = 0; i < *visits; i++)
+		e.updateValue(e.getValue()); // restores the visit counter without changing the value
+	e.setValue(Value(win_draw[0], win_draw[1]));
+	e.updateValue(Value(ew, ed));
+	win_draw[0] = e.getValue().win_rate;
+	win_draw[1] = e.getValue().draw_rate;
+	*visits = e.getVisits();
+}
+void ref_node_update_value(float *win_draw, int *visits, float ew, float ed)
+{
+	Node n;
+	n.setValue(Value(win_draw[0], win_draw[1]));
+	for (int i = 0; i < *visits; i++)
+		n.updateValue(n.getValue());
+	n.setValue(Value(win_draw[0], win_draw[1]));
+	n.updateValue(Value(ew, ed));
+	win_draw[0] = n.getValue().win_rate;
+	win_draw[1] = n.getValue().draw_rate;
+	*visits = n.getVisits();
+}
+uint16_t ref_move_to_short(int sign, int row, int col)
+{
+	return Move(row, col, static_cast<Sign>(sign)).toShort();
+}
+} /* extern "C" */

@@ -1,0 +1,95 @@
+"""ctypes loader of the CPU oracle (tests / smoke / bench cpu_baseline only)."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RULES = {"FREESTYLE": 0, "STANDARD": 1, "RENJU": 2, "CARO5": 3, "CARO6": 4}
+SIGNS = {"NONE": 0, "CROSS": 1, "CIRCLE": 2}
+MODES = {"BASIC": 0, "THREATS": 1, "OPTIMAL": 2, "REDUCED": 3, "LEGAL": 4}
+OUTCOMES = {"UNKNOWN": 0, "DRAW": 1, "CROSS_WIN": 2, "CIRCLE_WIN": 3}
+
+
+class AgoSearchConfig(ctypes.Structure):
+    _fields_ = [("max_batch_size", ctypes.c_int), ("exploration_constant", ctypes.c_float),
+                ("exploration_scaling", ctypes.c_float), ("init_to", ctypes.c_int), ("max_children", ctypes.c_int),
+                ("policy_expansion_threshold", ctypes.c_float), ("information_leak_threshold", ctypes.c_float),
+                ("tss_max_positions", ctypes.c_int), ("tss_table_entries", ctypes.c_uint64),
+                ("max_simulations", ctypes.c_int), ("zobrist_seed", ctypes.c_uint64)]
+
+
+def default_search_config(max_batch_size=8, max_simulations=400, table_entries=1 << 16):
+    return AgoSearchConfig(max_batch_size, 1.25, 0.0, 0, 2 ** 31 - 1, 1.0e-4, 0.01, 100, table_entries,
+                           max_simulations, 0x9E3779B97F4A7C15)
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        path = os.path.join(ROOT, "oracle", "libagoracle.so")
+        if os.path.exists(os.path.join(ROOT, "oracle", "Makefile")):
+            subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "libagoracle.so"])
+        lib = ctypes.CDLL(path)
+        for name in ["ago_defensive_moves", "ago_open_three_promotion_moves", "ago_score_op", "ago_score_make", "ago_move_to_short"]:
+            getattr(lib, name).restype = ctypes.c_uint16
+        for name in ["ago_solver_create", "ago_game_create"]:
+            getattr(lib, name).restype = ctypes.c_void_p
+        lib.ago_solver_create.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int]
+        lib.ago_game_create.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(AgoSearchConfig)]
+        for name in ["ago_solver_destroy", "ago_solver_new_generation", "ago_game_destroy"]:
+            getattr(lib, name).argtypes = [ctypes.c_void_p]
+        lib.ago_solver_zobrist.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        lib.ago_solver_solve.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 6
+        lib.ago_game_begin.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        lib.ago_game_step_select.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        lib.ago_game_step_expand.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        lib.ago_game_outcome.argtypes = [ctypes.c_void_p]
+        lib.ago_game_num_records.argtypes = [ctypes.c_void_p]
+        lib.ago_game_record.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 9 + [ctypes.c_int]
+        lib.ago_game_root.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 9 + [ctypes.c_int]
+        lib.ago_game_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        lib.ago_cpu_baseline.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(AgoSearchConfig), ctypes.c_int, ctypes.c_int,
+                                         ctypes.c_double] + [ctypes.c_void_p] * 5
+        _lib = lib
+    return _lib
+
+
+def ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def board_array(board):
+    return np.ascontiguousarray(np.array(board, dtype=np.uint8))
+
+
+def move_short(m):
+    return m["sign"] | (m["row"] << 2) | (m["col"] << 9)
+
+
+def short_to_move(s):
+    return dict(sign=s & 3, row=(s >> 2) & 127, col=(s >> 9) & 127)
+
+
+def movegen(lib, rules, board, sign, mode, draw_after=-1):
+    b = board_array(board)
+    rows, cols = b.shape
+    moves = np.zeros(1024, np.uint16)
+    scores = np.zeros(1024, np.uint16)
+    flags = ctypes.c_int()
+    result = ctypes.c_uint16()
+    n = lib.ago_movegen(rules, rows, cols, ptr(b), sign, mode, draw_after, ptr(moves), ptr(scores), ctypes.byref(flags), ctypes.byref(result))
+    return dict(moves=[int(x) for x in moves[:n]], scores=[int(x) for x in scores[:n]], must_defend=bool(flags.value & 1),
+                has_initiative=bool(flags.value & 2), fully_expanded=bool(flags.value & 4), score=result.value)
+
+
+def encode_features(lib, rules, board, sign):
+    b = board_array(board)
+    rows, cols = b.shape
+    out = np.zeros(rows * cols, np.uint32)
+    lib.ago_encode_features(rules, rows, cols, ptr(b), sign, ptr(out))
+    return out.reshape(rows, cols)

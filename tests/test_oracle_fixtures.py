@@ -1,0 +1,89 @@
+"""The CPU oracle against the known-answer cases of the reference's own unit tests (restated as data in
+tests/golden/ref_*_cases.json by tests/golden/extract_reference_fixtures.py): game rules incl. renju fouls, NN input
+bit layout, staged move generator (37 test functions)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return json.load(open(os.path.join(GOLDEN, name)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return ol.load()
+
+
+@pytest.mark.parametrize("case", load("ref_rules_cases.json"), ids=lambda c: c["name"])
+def test_rules(lib, case):
+    b = ol.board_array(case["board"])
+    rows, cols = b.shape
+    for chk in case["checks"]:
+        m = chk["move"]
+        if chk["kind"] == "outcome":
+            got = lib.ago_outcome(ol.RULES[chk["rules"]], rows, cols, ol.ptr(b), m["sign"], m["row"], m["col"], -1)
+            assert got == ol.OUTCOMES[chk["expected"]], chk
+        else:
+            got = lib.ago_is_forbidden(rows, cols, ol.ptr(b), m["sign"], m["row"], m["col"])
+            assert bool(got) == chk["expected"], chk
+            # the incremental calculator must agree with the static rule (test/game/test_renju.cpp:45-51): bit 6 of the features
+            if b[m["row"], m["col"]] == 0:
+                f = ol.encode_features(lib, ol.RULES["RENJU"], case["board"], 1)
+                assert bool((int(f[m["row"], m["col"]]) >> 6) & 1) == chk["expected"], chk
+
+
+@pytest.mark.parametrize("case", load("ref_features_cases.json"), ids=lambda c: c["name"])
+def test_features(lib, case):
+    sign = ol.SIGNS[case["sign_to_move"]]
+    f = ol.encode_features(lib, ol.RULES[case["rules"]], case["board"], sign)
+    b = np.array(case["board"])
+    own, opp = sign, 3 - sign
+    # generic per-cell layout (test/networks/test_NNInputFeatures.cpp:112-141)
+    assert np.array_equal((f >> 0) & 1, (b == 0).astype(np.uint32))
+    assert np.array_equal((f >> 1) & 1, (b == own).astype(np.uint32))
+    assert np.array_equal((f >> 2) & 1, (b == opp).astype(np.uint32))
+    assert ((f >> 3) & 1).all()
+    assert (((f >> 4) & 1) == (1 if sign == 1 else 0)).all()
+    assert (((f >> 5) & 1) == (1 if sign == 2 else 0)).all()
+    assert not ((f >> 6) & 1).any() and not ((f >> 7) & 1).any()
+    for chk in case["bits"]:
+        assert bool((int(f[chk["row"], chk["col"]]) >> chk["bit"]) & 1) == chk["expected"], chk
+
+
+MOVEGEN = load("ref_movegen_cases.json")
+
+
+def run_movegen(lib, case):
+    return ol.movegen(lib, ol.RULES[case["rules"]], case["board"], ol.SIGNS[case["sign_to_move"]], ol.MODES[case["mode"]])
+
+
+@pytest.mark.parametrize("case", MOVEGEN, ids=lambda c: c["name"])
+def test_move_generator(lib, case):
+    got = run_movegen(lib, case)
+    locs = [(m >> 2 & 127, m >> 9 & 127) for m in got["moves"]]
+    assert len(set(locs)) == len(locs)
+    if case["size"] is not None:
+        assert len(got["moves"]) == case["size"], (locs,)
+    if case["must_defend"] is not None:
+        assert got["must_defend"] == case["must_defend"]
+    if case["has_initiative"] is not None:
+        assert got["has_initiative"] == case["has_initiative"]
+    for m in case["contains"]:
+        assert ol.move_short(m) in got["moves"], (m, locs)
+    for m in case["not_contains"]:
+        assert ol.move_short(m) not in got["moves"], (m, locs)
+    for s in case["scores"]:
+        idx = got["moves"].index(ol.move_short(s["move"]))
+        expected = lib.ago_score_make({"loss_in": 0, "draw_in": 1, "win_in": 3}[s["kind"]], s["n"] if s["kind"] != "win_in" else -s["n"])
+        assert got["scores"][idx] == expected
+    if "equals" in case:
+        other = run_movegen(lib, [c for c in MOVEGEN if c["name"] == case["equals"]][0])
+        assert sorted(other["moves"]) == sorted(got["moves"])
+        assert (other["must_defend"], other["has_initiative"], other["fully_expanded"]) == (got["must_defend"], got["has_initiative"], got["fully_expanded"])

@@ -1,0 +1,164 @@
+"""Pins the oracle's tables / score algebra / record arithmetic against the REAL reference code compiled from its own
+sources (oracle/_ref/libagref.so, built by oracle/Makefile from /root/reference without any stand-in header), and —
+where the prebuilt reference library is unavailable — against checksums committed in tests/golden/tables.json that were
+produced from it (tests/golden/make_tables_golden.py)."""
+import ctypes
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RULES = ["FREESTYLE", "STANDARD", "RENJU", "CARO5", "CARO6"]
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    import subprocess
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "libagoracle.so"])
+    lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "libagoracle.so"))
+    lib.ago_defensive_moves.restype = ctypes.c_uint16
+    lib.ago_open_three_promotion_moves.restype = ctypes.c_uint16
+    lib.ago_score_op.restype = ctypes.c_uint16
+    lib.ago_score_make.restype = ctypes.c_uint16
+    lib.ago_move_to_short.restype = ctypes.c_uint16
+    return lib
+
+
+@pytest.fixture(scope="module")
+def ref():
+    path = os.path.join(ROOT, "oracle", "_ref", "libagref.so")
+    if not os.path.exists(path):
+        if os.path.isdir("/root/reference/src"):
+            import subprocess
+            subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "_ref/libagref.so"])
+        else:
+            pytest.skip("reference library not built")
+    lib = ctypes.CDLL(path)
+    lib.ref_defensive_moves.restype = ctypes.c_uint16
+    lib.ref_open_three_promotion_moves.restype = ctypes.c_uint16
+    lib.ref_score_op.restype = ctypes.c_uint16
+    lib.ref_score_make.restype = ctypes.c_uint16
+    lib.ref_move_to_short.restype = ctypes.c_uint16
+    return lib
+
+
+def oracle_tables(oracle, rules):
+    types = np.zeros(1 << 20, np.uint8)
+    ho3 = np.zeros(1 << 20, np.uint8)
+    thr = np.zeros(4096 * 2, np.uint8)
+    oracle.ago_tables(rules, types.ctypes.data_as(ctypes.c_void_p), ho3.ctypes.data_as(ctypes.c_void_p), thr.ctypes.data_as(ctypes.c_void_p))
+    return types, ho3, thr
+
+
+def valid_extended_patterns(rng, count):
+    """random 13-cell lines whose off-board cells (3) are contiguous from the outside and whose centre is empty"""
+    out = []
+    for _ in range(count):
+        cells = rng.integers(0, 3, size=13)
+        left = int(rng.integers(0, 7)) if rng.random() < 0.3 else 0
+        right = int(rng.integers(0, 7)) if rng.random() < 0.3 else 0
+        cells[:left] = 3
+        if right:
+            cells[13 - right:] = 3
+        cells[6] = 0
+        out.append(int(sum(int(c) << (2 * i) for i, c in enumerate(cells))))
+    return out
+
+
+@pytest.mark.parametrize("rules", range(5))
+def test_pattern_and_threat_tables_equal_reference(oracle, ref, rules):
+    types, ho3, thr = oracle_tables(oracle, rules)
+    rt = np.zeros(1 << 20, np.uint8)
+    rh = np.zeros(1 << 20, np.uint8)
+    rthr = np.zeros(4096 * 2, np.uint8)
+    ref.ref_pattern_table(rules, rt.ctypes.data_as(ctypes.c_void_p), rh.ctypes.data_as(ctypes.c_void_p))
+    ref.ref_threat_table(rules, rthr.ctypes.data_as(ctypes.c_void_p))
+    assert np.array_equal(types, rt)
+    assert np.array_equal(ho3, rh)
+    assert np.array_equal(thr, rthr)
+
+
+@pytest.mark.parametrize("rules", range(5))
+def test_table_checksums_match_golden(oracle, rules):
+    golden = json.load(open(os.path.join(ROOT, "tests", "golden", "tables.json")))
+    types, ho3, thr = oracle_tables(oracle, rules)
+    g = golden[RULES[rules]]
+    assert hashlib.sha256(types.tobytes()).hexdigest() == g["pattern_types_sha256"]
+    assert hashlib.sha256(ho3.tobytes()).hexdigest() == g["half_open_3_sha256"]
+    assert hashlib.sha256(thr.tobytes()).hexdigest() == g["threats_sha256"]
+    rng = np.random.default_rng(12345)
+    pats = valid_extended_patterns(rng, 4000)
+    acc = hashlib.sha256()
+    for p in pats:
+        for defender in (1, 2):
+            for pt in (2, 3, 4, 5, 6):
+                acc.update(int(oracle.ago_defensive_moves(rules, p, defender, pt)).to_bytes(2, "little"))
+    assert acc.hexdigest() == g["defensive_moves_sha256"]
+
+
+@pytest.mark.parametrize("rules", range(5))
+def test_defensive_moves_equal_reference(oracle, ref, rules):
+    rng = np.random.default_rng(777 + rules)
+    for p in valid_extended_patterns(rng, 6000):
+        for defender in (1, 2):
+            for pt in (2, 3, 4, 5, 6):
+                assert oracle.ago_defensive_moves(rules, p, defender, pt) == ref.ref_defensive_moves(rules, p, defender, pt), (p, defender, pt)
+
+
+def test_open_three_promotion_moves_equal_reference(oracle, ref):
+    # every 11-cell line that contains one of the four open-three shapes for cross, centre empty
+    shapes = [[0, 1, 1, 1, 0, 0], [0, 1, 1, 0, 1, 0], [0, 1, 0, 1, 1, 0], [0, 0, 1, 1, 1, 0]]
+    checked = 0
+    for shape in shapes:
+        for start in range(0, 6):
+            cells = [0] * 11
+            cells[start:start + 6] = shape
+            # the centre must be one of the cross stones of the shape, removed (patterns have an empty centre)
+            if not (start <= 5 < start + 6) or cells[5] != 1:
+                continue
+            cells[5] = 0
+            p = sum(c << (2 * i) for i, c in enumerate(cells))
+            assert oracle.ago_open_three_promotion_moves(p) == ref.ref_open_three_promotion_moves(p)
+            checked += 1
+    assert checked >= 9
+
+
+def test_score_algebra_equals_reference_on_every_raw_value(oracle, ref):
+    d1, d2 = ctypes.c_int(), ctypes.c_int()
+    v1, v2 = (ctypes.c_float * 2)(), (ctypes.c_float * 2)()
+    for raw in range(0, 65536):
+        pv, ev = (raw >> 13) & 3, (raw & 8191) - 4000
+        if not (raw in (0, 0xFFFF) or -3000 <= ev <= 3000):
+            continue  # constructors assert |eval| <= 4000; +-1 steps must stay inside
+        for op in (0, 1, 2):
+            assert oracle.ago_score_op(raw, op) == ref.ref_score_op(raw, op), (raw, op)
+        f1 = oracle.ago_score_info(raw, ctypes.byref(d1), v1)
+        f2 = ref.ref_score_info(raw, ctypes.byref(d2), v2)
+        assert f1 == f2 and d1.value == d2.value and tuple(v1) == tuple(v2), raw
+    for pv in range(4):
+        for ev in (-1000, -1, 0, 1, 7, 1000):
+            assert oracle.ago_score_make(pv, ev) == ref.ref_score_make(pv, ev)
+
+
+def test_running_means_equal_reference(oracle, ref):
+    rng = np.random.default_rng(5)
+    for _ in range(500):
+        w, d = float(np.float32(rng.random() * 0.8)), float(np.float32(rng.random() * 0.2))
+        ew, ed = float(np.float32(rng.random() * 0.7)), float(np.float32(rng.random() * 0.3))
+        visits = int(rng.integers(0, 2000))
+        for name in ("edge", "node"):
+            a = (ctypes.c_float * 2)(w, d)
+            b = (ctypes.c_float * 2)(w, d)
+            va, vb = ctypes.c_int(visits), ctypes.c_int(visits)
+            getattr(oracle, "ago_%s_update_value" % name)(a, ctypes.byref(va), ctypes.c_float(ew), ctypes.c_float(ed))
+            getattr(ref, "ref_%s_update_value" % name)(b, ctypes.byref(vb), ctypes.c_float(ew), ctypes.c_float(ed))
+            assert tuple(a) == tuple(b) and va.value == vb.value
+
+
+def test_record_layouts(ref, oracle):
+    assert [ref.ref_sizeof(i) for i in range(5)] == [24, 40, 4, 2, 8]
+    for sign, r, c in [(1, 0, 0), (2, 14, 3), (1, 19, 19)]:
+        assert oracle.ago_move_to_short(sign, r, c) == ref.ref_move_to_short(sign, r, c)
