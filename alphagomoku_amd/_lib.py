@@ -69,3 +69,70 @@ lib = _Lazy()
 def check(status):
     if status != 0:
         raise AgxError("agx error %d: %s" % (status, lib.agx_last_error().decode()))
+
+
+class AgxEngineConfig(ctypes.Structure):
+    _fields_ = [("rules", ctypes.c_int), ("board_size", ctypes.c_int), ("draw_after", ctypes.c_int), ("n_games", ctypes.c_int),
+                ("max_batch_size", ctypes.c_int), ("max_simulations", ctypes.c_int), ("exploration_constant", ctypes.c_float),
+                ("exploration_scaling", ctypes.c_float), ("init_to", ctypes.c_int), ("information_leak_threshold", ctypes.c_float),
+                ("policy_expansion_threshold", ctypes.c_float), ("tss_max_positions", ctypes.c_int),
+                ("tss_table_entries", ctypes.c_uint64), ("zobrist_seed", ctypes.c_uint64), ("node_capacity", ctypes.c_int),
+                ("edge_capacity", ctypes.c_int), ("record_capacity", ctypes.c_int), ("record_edge_capacity", ctypes.c_int)]
+
+
+class AgxEngineBuffers(ctypes.Structure):
+    _fields_ = [("d_nn_features", ctypes.c_void_p), ("d_nn_policy", ctypes.c_void_p), ("d_nn_value", ctypes.c_void_p),
+                ("d_nn_list", ctypes.c_void_p), ("d_nn_count", ctypes.c_void_p), ("slots", ctypes.c_int), ("cells", ctypes.c_int)]
+
+
+class AgxEngineStats(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_ulonglong) for n in
+                ["evaluated_nodes", "network_evaluations", "information_leaks", "proven_edge_visits", "wasted_expansions",
+                 "duplicate_selections", "solver_nodes", "select_levels", "select_edge_reads", "moves_played", "peak_nodes",
+                 "peak_edges"]] + [(n, ctypes.c_int) for n in
+                                   ["games_finished", "openings_taken", "active_games", "records_used", "record_edges_used",
+                                    "first_error"]]
+
+
+class AgxEdgeView(ctypes.Structure):
+    _fields_ = [("prior", ctypes.c_float), ("win", ctypes.c_float), ("draw", ctypes.c_float), ("visits", ctypes.c_int32),
+                ("move", ctypes.c_uint16), ("score", ctypes.c_uint16), ("flag_and_virtual_loss", ctypes.c_uint16),
+                ("reserved", ctypes.c_uint16)]
+
+
+class AgxGameInfo(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int) for n in ["active", "sign_to_move", "n_moves", "outcome", "error", "opening_id", "games_done",
+                                            "n_nodes", "n_edges", "root_visits"]] + \
+               [("root_win", ctypes.c_float), ("root_draw", ctypes.c_float), ("root_score", ctypes.c_int), ("root_edges", ctypes.c_int)]
+
+
+class AgxMoveRecord(ctypes.Structure):
+    _fields_ = [("game_serial", ctypes.c_int), ("move_number", ctypes.c_int), ("move", ctypes.c_uint16), ("root_score", ctypes.c_uint16),
+                ("root_visits", ctypes.c_int), ("root_win", ctypes.c_float), ("root_draw", ctypes.c_float), ("n_edges", ctypes.c_int),
+                ("edge_offset", ctypes.c_int)]
+
+
+_declare_nn = _declare
+
+
+def _declare(c):  # noqa: F811
+    _declare_nn(c)
+    vp, sz, ci = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
+    c.agx_nn_forward_indirect.argtypes = [vp, vp, vp, vp, ci, vp, vp, vp]
+    c.agx_engine_default_config.argtypes = [ctypes.POINTER(AgxEngineConfig)]
+    c.agx_engine_create.argtypes = [ctypes.POINTER(AgxEngineConfig), ctypes.POINTER(vp)]
+    c.agx_engine_destroy.argtypes = [vp]
+    c.agx_engine_begin.argtypes = [vp, vp, ci, vp]
+    for name in ["agx_engine_select_solve", "agx_engine_expand_backup"]:
+        getattr(c, name).argtypes = [vp, vp]
+    for name in ["agx_engine_evaluate", "agx_engine_step"]:
+        getattr(c, name).argtypes = [vp, vp, vp]
+    c.agx_engine_buffers.argtypes = [vp, ctypes.POINTER(AgxEngineBuffers)]
+    c.agx_engine_stats.argtypes = [vp, ctypes.POINTER(AgxEngineStats)]
+    c.agx_engine_game_info.argtypes = [vp, ci, ctypes.POINTER(AgxGameInfo), vp, vp, ci]
+    c.agx_engine_records.argtypes = [vp, vp, ci, vp, ci, ctypes.POINTER(ci), ctypes.POINTER(ci)]
+    c.agx_engine_zobrist.argtypes = [vp, vp, sz]
+    c.agx_debug_solve.argtypes = [vp, vp, vp, ci, vp, vp, vp, vp, vp, vp]
+    c.agx_debug_new_generation.argtypes = [vp]
+    c.agx_debug_pattern_state.argtypes = [vp, vp, vp, vp, ci, ci, vp, vp, vp, ci]
+    c.agx_host_tables.argtypes = [ci, vp, vp, vp, vp]

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libagx.so")
 
-SOURCES = ["agx_api.hip", "nn_forward.hip"]
+SOURCES = ["agx_api.hip", "nn_forward.hip", "engine.hip", "tables_host.cpp"]
 
 
 def needs_build():
@@ -34,8 +34,11 @@ def build(force=False, verbose=True):
     for src in SOURCES:
         obj = os.path.join(CSRC, src.rsplit(".", 1)[0] + ".o")
         objs.append(obj)
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-               "-c", os.path.join(CSRC, src), "-o", obj]
+        # -ffp-contract=off: the tree kernels must round exactly like the CPU oracle (no fused multiply-add)
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]
+        if src.endswith(".cpp"):
+            cmd += ["-x", "hip"]
+        cmd += ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append(subprocess.Popen(cmd))

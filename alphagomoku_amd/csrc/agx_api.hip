@@ -113,8 +113,8 @@ int agx_timer_destroy(AgxTimer *t)
 {
 	if (t == nullptr)
 		return AGX_OK;
-	hipEventDestroy(t->start);
-	hipEventDestroy(t->stop);
+	(void) hipEventDestroy(t->start);
+	(void) hipEventDestroy(t->stop);
 	delete t;
 	return AGX_OK;
 }

@@ -1,0 +1,218 @@
+/*
+ * dev_mcts.hpp — device side of the graph-MCTS: PUCT select with wave-level argmax, transposition lookup, expand,
+ * backup, information-leak repair.  One 64-lane wavefront owns one game; the edges of a node are scanned one per lane.
+ *
+ * Replaces (host code in the reference): Tree::{select,expand,backup,correctInformationLeak,cancelVirtualLoss}
+ * (src/search/monte_carlo/Tree.cpp:226-384), PUCTSelector / PUCT_q_head / PUCT / BestEdge
+ * (EdgeSelector.cpp:27-32,335-361,389-424,515-536,562-586,1123-1166), NodeCache::{seek,insert} (NodeCache.cpp:250-297),
+ * UnifiedGenerator::generate (EdgeGenerator.cpp:23-127,269-303), Search::{select,expand,backup} (Search.cpp:117-232).
+ *
+ * Floating point is restated operation by operation (the library is built with -ffp-contract=off) so that visit counts
+ * and move choices are bit-identical to the CPU oracle.
+ */
+#ifndef AGX_DEV_MCTS_HPP_
+#define AGX_DEV_MCTS_HPP_
+
+#include "dev_solver.hpp"
+
+namespace agx
+{
+	namespace dev
+	{
+		__device__ __forceinline__ DNode* nodes_of(const EngineDev &E, int g, int arena) { return E.nodes + (static_cast<size_t>(g) * 2 + arena) * E.node_cap; }
+		__device__ __forceinline__ DEdge* edges_of(const EngineDev &E, int g, int arena) { return E.edges + (static_cast<size_t>(g) * 2 + arena) * E.edge_cap; }
+		__device__ __forceinline__ int* ht_of(const EngineDev &E, int g) { return E.ht + static_cast<size_t>(g) * E.ht_cap; }
+
+		/* NodeCache::seek (NodeCache.cpp:250-264): hash, side to move and the FULL (compressed) board must match */
+		__device__ inline int cache_seek(const EngineDev &E, const DNode *nodes, const int *ht, u64 hash, const u64 *cboard, int sign, int lane)
+		{
+			const int mask = E.ht_cap - 1;
+			int slot = static_cast<int>(hash & static_cast<u64>(mask));
+			for (int probes = 0; probes < E.ht_cap; probes++)
+			{
+				const int idx = ht[slot];
+				if (idx == 0)
+					return -1;
+				const DNode &nd = nodes[idx - 1];
+				bool same = (nd.hash == hash) && (nd.sign_to_move == sign);
+				if (same)
+				{
+					const bool word_ok = (lane < BWORDS) ? (nd.cboard[lane] == cboard[lane]) : true;
+					same = (__ballot(!word_ok) == 0);
+				}
+				if (same)
+					return idx - 1;
+				slot = (slot + 1) & mask;
+			}
+			return -1;
+		}
+		__device__ inline void cache_insert(const EngineDev &E, int *ht, u64 hash, int node)
+		{ // single lane
+			const int mask = E.ht_cap - 1;
+			int slot = static_cast<int>(hash & static_cast<u64>(mask));
+			while (ht[slot] != 0)
+				slot = (slot + 1) & mask;
+			ht[slot] = node + 1;
+		}
+
+		/* has_information_leak (Tree.cpp:75-85) */
+		__device__ inline bool has_leak(const EngineDev &E, const DEdge &e, const DNode *node)
+		{
+			if (node == nullptr || E.leak_threshold >= 1.0f)
+				return false;
+			if (e.score != s_invert_up(node->score))
+				return true;
+			const float inv_win = 1.0f - (node->win + node->draw);
+			const float dw = e.win - inv_win, dd = e.draw - node->draw;
+			return (fabsf(dw) + fabsf(dd)) > E.leak_threshold;
+		}
+
+		/* wave-wide (value, index) argmax: largest value, lowest index among equals (EdgeSelector.cpp:562-586 scans in order with '>') */
+		__device__ __forceinline__ void wave_argmax(float &value, int &index)
+		{
+			for (int o = 32; o > 0; o >>= 1)
+			{
+				const float v2 = __shfl_xor(value, o);
+				const int i2 = __shfl_xor(index, o);
+				if (v2 > value || (v2 == value && i2 < index))
+				{
+					value = v2;
+					index = i2;
+				}
+			}
+		}
+		__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
+		{
+			for (int o = 32; o > 0; o >>= 1)
+				v = max(v, static_cast<uint32_t>(__shfl_xor(static_cast<int>(v), o)));
+			return v;
+		}
+
+		/* PUCTSelector::select without root noise (EdgeSelector.cpp:1123-1166) */
+		__device__ inline int select_edge(const EngineDev &E, const DNode &nd, const DEdge *edges, int lane, unsigned long long &edge_reads)
+		{
+			const int total = nd.visits + nd.vl;
+			float c_puct = E.c_puct;
+			if (E.c_scale != 0.0f)
+				c_puct = static_cast<float>(static_cast<double>(E.c_puct) + static_cast<double>(E.c_scale) * log(static_cast<double>(total)));
+			const float parent_sqrt_visit = static_cast<float>(static_cast<double>(c_puct) * sqrt(static_cast<double>(total)));
+			float initial_q = 0.0f;
+			if (E.init_to == 1)
+				initial_q = nd.win + 0.5f * nd.draw;
+			else if (E.init_to == 2)
+				initial_q = 0.5f;
+
+			float best_value = -3.402823466e+38f;
+			int best = 0x7FFFFFFF;
+			for (int i = lane; i < nd.n_edges; i += 64)
+			{
+				const DEdge e = edges[nd.edge_begin + i];
+				float value;
+				switch (s_pv(e.score))
+				{
+					case 0:
+						value = -1000.0f + s_distance(e.score);
+						break;
+					case 1:
+						value = 0.5f;
+						break;
+					case 3:
+						value = +1000.0f - s_distance(e.score);
+						break;
+					default:
+					{
+						const int vl = e.flag_vl & 0x7FFF;
+						const bool being_expanded = (e.flag_vl & 0x8000u) != 0;
+						const float visits = 1.0e-8f + e.visits;
+						const float virtual_loss = static_cast<float>(vl);
+						const float vl_factor = visits / (visits + virtual_loss);
+						const float expectation = e.win + 0.5f * e.draw;
+						float Q;
+						if (E.init_to == 0)
+							Q = being_expanded ? -1000.0f : expectation * vl_factor;
+						else
+						{
+							Q = initial_q;
+							if (being_expanded)
+								Q = -1000.0f;
+							else if (e.visits > 0)
+								Q = expectation * vl_factor;
+						}
+						const float U = e.prior * parent_sqrt_visit / (1.0f + e.visits + vl);
+						value = Q + U;
+						break;
+					}
+				}
+				if (value > best_value)
+				{
+					best_value = value;
+					best = i;
+				}
+			}
+			edge_reads += nd.n_edges;
+			wave_argmax(best_value, best);
+			return nd.edge_begin + best;
+		}
+
+		/* update_score(Node*) (Tree.cpp:93-104); `changed_edge` (absolute index, or -1) carries a score still held in a register */
+		__device__ inline void update_node_score(DNode *nodes, const DEdge *edges, int node, int changed_edge, uint32_t changed_score, int lane)
+		{
+			const int begin = nodes[node].edge_begin, cnt = nodes[node].n_edges;
+			uint32_t result = 0;
+			for (int i = lane; i < cnt; i += 64)
+				result = max(result, (begin + i == changed_edge) ? changed_score : static_cast<uint32_t>(edges[begin + i].score));
+			result = wave_max_u32(result);
+			if (lane == 0 && (((nodes[node].flags & 4) != 0) || s_win(result) || s_unproven(result)))
+				nodes[node].score = static_cast<uint16_t>(result);
+		}
+
+		/* Tree::correctInformationLeak (Tree.cpp:352-376) */
+		__device__ inline void correct_information_leak(DNode *nodes, DEdge *edges, const DTask &t, int path_len, int final_node, int lane)
+		{
+			for (int i = path_len - 1; i >= 0; i--)
+			{
+				const int node = t.path_node[i], e = t.path_edge[i];
+				const int next = (i == path_len - 1) ? final_node : t.path_node[i + 1];
+				uint32_t new_score = 0;
+				if (lane == 0)
+				{
+					const float cw = edges[e].win, cd = edges[e].draw;
+					const float tw = 1.0f - (nodes[next].win + nodes[next].draw), td = nodes[next].draw;
+					const float scale = static_cast<float>(edges[e].visits) / static_cast<float>(nodes[node].visits);
+					const float nw = nodes[node].win + (tw - cw) * scale, ndr = nodes[node].draw + (td - cd) * scale;
+					edges[e].win = tw;
+					edges[e].draw = td;
+					nodes[node].win = nw;
+					nodes[node].draw = ndr;
+					new_score = s_invert_up(nodes[next].score);
+					edges[e].score = static_cast<uint16_t>(new_score);
+				}
+				new_score = __shfl(static_cast<int>(new_score), 0);
+				update_node_score(nodes, edges, node, e, new_score, lane);
+			}
+		}
+		/* Tree::cancelVirtualLoss (Tree.cpp:377-384) */
+		__device__ inline void cancel_virtual_loss(DNode *nodes, DEdge *edges, const DTask &t, int path_len, int lane)
+		{
+			if (lane == 0)
+				for (int i = 0; i < path_len; i++)
+				{
+					nodes[t.path_node[i]].vl--;
+					DEdge &e = edges[t.path_edge[i]];
+					e.flag_vl = static_cast<uint16_t>((e.flag_vl & 0x8000u) | (((e.flag_vl & 0x7FFF) - 1) & 0x7FFF));
+				}
+		}
+
+		__device__ inline u64 full_hash(const EngineDev &E, const uint8_t *board, int sign, int lane)
+		{ // FullZobristHashing::getHash (ZobristHashing.cpp:21-33)
+			u64 h = 0;
+			for (int i = lane; i < E.hw; i += 64)
+				h ^= E.nc_keys[3 + 3 * i + board[i]];
+			for (int o = 32; o > 0; o >>= 1)
+				h ^= __shfl_xor(h, o);
+			return h ^ E.nc_keys[sign];
+		}
+	}
+}
+
+#endif

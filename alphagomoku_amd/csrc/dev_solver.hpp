@@ -1,0 +1,1272 @@
+/*
+ * dev_solver.hpp — device side of the in-loop threat solver: incremental line-pattern / threat state, the staged move
+ * generator and the alpha-beta search with its bucketed transposition table.  One 64-lane wavefront owns one game.
+ *
+ * What it replaces (all host code in the reference): PatternCalculator::{setBoard,addMove,undoMove}
+ * (src/patterns/PatternCalculator.cpp:40-105,245-367), RawPatternCalculator (RawPatternCalculator.hpp:22-288),
+ * ThreatHistogram (ThreatHistogram.hpp:39-113), NNInputFeatures::encode (src/networks/NNInputFeatures.cpp:59-113),
+ * MoveGenerator::generate (src/search/alpha_beta/MoveGenerator.cpp:159-1207), AlphaBetaSearch::{solve,recursive_solve,
+ * evaluate} (src/search/alpha_beta/AlphaBetaSearch.cpp:77-365) and SharedHashTable (SharedHashTable.hpp:90-220).
+ *
+ * MI355X mapping: the per-position state (line bit-boards, per-cell pattern types, threat lists, recursion frames: ~25 KB)
+ * lives in LDS for the whole solve; the wide steps — classifying all cells of a new position, re-classifying the <= 40
+ * cells around a placed/removed stone, encoding the feature plane — run one cell per lane with wave ballots keeping the
+ * reference's list ORDER (row-major appends, swap-with-last removals), which decides move ordering and therefore results.
+ * The branchy control flow (move-generation cascade, alpha-beta bookkeeping, table probes) runs on lane 0 as an explicit
+ * frame machine that yields to the wave whenever a stone has to be placed or removed.
+ * Renju (forbidden moves re-enter the incremental update from inside the generator) is not supported on the device yet.
+ */
+#ifndef AGX_DEV_SOLVER_HPP_
+#define AGX_DEV_SOLVER_HPP_
+
+#include <hip/hip_runtime.h>
+#include "engine_types.hpp"
+
+namespace agx
+{
+	namespace dev
+	{
+		typedef uint64_t u64;
+
+		/* ---------------- Score algebra on raw 16-bit values (search/Score.hpp:47-320) ---------------- */
+		__device__ __forceinline__ int s_pv(uint32_t d) { return (d >> 13) & 3; }
+		__device__ __forceinline__ int s_eval(uint32_t d) { return static_cast<int>(d & 8191u) - 4000; }
+		__device__ __forceinline__ bool s_infinite(uint32_t d) { return d == 0u || d == 0xFFFFu; }
+		__device__ __forceinline__ bool s_unproven(uint32_t d) { return s_pv(d) == 2; }
+		__device__ __forceinline__ bool s_proven(uint32_t d) { return s_pv(d) != 2 && !s_infinite(d); }
+		__device__ __forceinline__ bool s_loss(uint32_t d) { return s_pv(d) == 0 && !s_infinite(d); }
+		__device__ __forceinline__ bool s_win(uint32_t d) { return s_pv(d) == 3 && !s_infinite(d); }
+		__device__ __forceinline__ uint32_t s_make(int pv, int eval) { return (static_cast<uint32_t>(pv) << 13) | static_cast<uint32_t>(4000 + eval); }
+		__device__ __forceinline__ uint32_t s_unknown(int eval) { return s_make(2, eval); }
+		__device__ __forceinline__ uint32_t s_loss_in(int n) { return s_make(0, n); }
+		__device__ __forceinline__ uint32_t s_draw_in(int n) { return s_make(1, n); }
+		__device__ __forceinline__ uint32_t s_win_in(int n) { return s_make(3, -n); }
+		__device__ __forceinline__ int s_distance(uint32_t d)
+		{
+			const int pv = s_pv(d);
+			return (pv <= 1) ? s_eval(d) : (pv == 3 ? -s_eval(d) : 0);
+		}
+		__device__ __forceinline__ uint32_t s_negate(uint32_t d)
+		{
+			switch (s_pv(d))
+			{
+				case 0: return s_infinite(d) ? 0xFFFFu : s_make(3, -s_eval(d));
+				case 1: return s_make(1, s_eval(d));
+				case 3: return s_infinite(d) ? 0x0000u : s_make(0, -s_eval(d));
+				default: return s_make(2, -s_eval(d));
+			}
+		}
+		__device__ __forceinline__ uint32_t s_invert_up(uint32_t d)
+		{
+			switch (s_pv(d))
+			{
+				case 0: return s_infinite(d) ? s_negate(d) : s_win_in(s_distance(d) + 1);
+				case 1: return s_draw_in(s_distance(d) + 1);
+				case 3: return s_infinite(d) ? s_negate(d) : s_loss_in(s_distance(d) + 1);
+				default: return s_negate(d);
+			}
+		}
+		__device__ __forceinline__ uint32_t s_invert_down(uint32_t d)
+		{
+			switch (s_pv(d))
+			{
+				case 0: return s_infinite(d) ? s_negate(d) : s_win_in(s_distance(d) - 1);
+				case 1: return s_draw_in(s_distance(d) - 1);
+				case 3: return s_infinite(d) ? s_negate(d) : s_loss_in(s_distance(d) - 1);
+				default: return s_negate(d);
+			}
+		}
+		__device__ __forceinline__ void s_to_value(uint32_t d, float &win, float &draw)
+		{ // Score.hpp:266-283
+			win = 0.0f;
+			draw = 0.0f;
+			switch (s_pv(d))
+			{
+				case 1: draw = 1.0f; break;
+				case 2: win = (1000 + s_eval(d)) / 2000.0f; break;
+				case 3: win = s_infinite(d) ? 0.0f : 1.0f; break;
+				default: break;
+			}
+		}
+
+		/* ---------------- per-game solver state in LDS ---------------- */
+		struct Frame
+		{
+				int base, size, i, depth_remaining;
+				uint16_t alpha, beta, original_alpha, best_score;
+				uint16_t best_move, move, baseline;
+				uint8_t must_defend, has_initiative, fully_expanded, pad;
+		};
+		enum Cmd : int { CMD_NONE = 0, CMD_ADD = 1, CMD_UNDO = 2, CMD_DONE = 3 };
+
+		struct SolverShared
+		{
+				u64 lines[6 * MAXN];
+				uint8_t board[MAXHW];
+				uint8_t ptype[MAXHW][8]; // [cell][0-3 cross dirs, 4-7 circle dirs]
+				uint8_t threat[MAXHW][2];
+				uint16_t lists[2][10][MAXHW];
+				uint16_t count[2][10];
+				uint32_t legal[MAXN];
+				uint32_t added[MAXN];
+				Frame frames[MAX_FRAMES];
+				u64 hash_lo, hash_hi;
+				int sign_to_move, depth;
+				int node_counter, stack_offset, stack_max, level;
+				int cmd, cmd_move, pending_value, error;
+				int result_score, phase;
+		};
+
+		__device__ __forceinline__ int row_step(int d) { return d == 0 ? 0 : 1; }
+		__device__ __forceinline__ int col_step(int d) { return d == 0 ? 1 : (d == 1 ? 0 : (d == 2 ? 1 : -1)); }
+		__device__ __forceinline__ void line_of(int n, int r, int c, int d, int &index, int &shift)
+		{ // RawPatternCalculator.hpp:241-273
+			switch (d)
+			{
+				case 0: index = r; shift = 2 * c; break;
+				case 1: index = n + c; shift = 2 * r; break;
+				case 2: index = 2 * n + (c - r + n - 1); shift = 2 * min(c, r); break;
+				default: index = 4 * n - 1 + (r + c); shift = 2 * min(r, n - 1 - c); break;
+			}
+		}
+		__device__ __forceinline__ uint32_t extended_pattern(const SolverShared &sh, int n, int r, int c, int d)
+		{ // 13 cells (+-6), off-board = 3 (RawPatternCalculator.hpp:196-210)
+			int index, shift;
+			line_of(n, r, c, d, index, shift);
+			return static_cast<uint32_t>((sh.lines[index] >> shift) & 0x3FFFFFFull);
+		}
+		__device__ __forceinline__ uint32_t normal_pattern(const SolverShared &sh, int n, int r, int c, int d) { return (extended_pattern(sh, n, r, c, d) >> 2) & 0x3FFFFFu; }
+		__device__ __forceinline__ uint32_t narrow(uint32_t x) { return (x & 1023u) | ((x & 4190208u) >> 2); }
+		__device__ __forceinline__ uint32_t threat_index(const uint8_t *pt) { return pt[0] | (pt[1] << 3) | (pt[2] << 6) | (pt[3] << 9); }
+
+		__device__ inline void list_add(SolverShared &sh, int s, int t, int cell, int lane)
+		{ // ThreatHistogram::add (ThreatHistogram.hpp:101-111)
+			if (t != 0 && lane == 0)
+			{
+				const int cnt = sh.count[s][t];
+				sh.lists[s][t][cnt] = static_cast<uint16_t>(cell);
+				sh.count[s][t] = static_cast<uint16_t>(cnt + 1);
+			}
+		}
+		__device__ inline void list_remove(SolverShared &sh, int s, int t, int cell, int lane)
+		{ // ThreatHistogram::remove (:39-99): first match is overwritten by the last element
+			if (t == 0)
+				return;
+			const int cnt = sh.count[s][t];
+			int found = -1;
+			for (int base = 0; base < cnt && found < 0; base += 64)
+			{
+				const int j = base + lane;
+				const u64 m = __ballot(j < cnt && sh.lists[s][t][j] == cell);
+				if (m != 0)
+					found = base + __ffsll(static_cast<long long>(m)) - 1;
+			}
+			if (found >= 0 && lane == 0)
+			{
+				sh.lists[s][t][found] = sh.lists[s][t][cnt - 1];
+				sh.count[s][t] = static_cast<uint16_t>(cnt - 1);
+			}
+		}
+
+		/* PatternCalculator::setBoard (PatternCalculator.cpp:40-66, 245-277) */
+		__device__ inline void solver_set_board(SolverShared &sh, const EngineDev &E, const uint8_t *board, int sign_to_move, int lane)
+		{
+			const int n = E.n, hw = E.hw;
+			for (int i = lane; i < hw; i += 64)
+				sh.board[i] = board[i];
+			if (lane < 20)
+				sh.count[lane / 10][lane % 10] = 0;
+			__syncthreads();
+			for (int L = lane; L < 6 * n - 2; L += 64)
+			{
+				int len, r0, c0, dr, dc;
+				if (L < n) { len = n; r0 = L; c0 = 0; dr = 0; dc = 1; }
+				else if (L < 2 * n) { len = n; r0 = 0; c0 = L - n; dr = 1; dc = 0; }
+				else if (L < 4 * n - 1)
+				{
+					const int k = L - 2 * n - (n - 1); // col - row
+					len = n - abs(k);
+					r0 = (k < 0) ? -k : 0;
+					c0 = (k < 0) ? 0 : k;
+					dr = 1; dc = 1;
+				}
+				else
+				{
+					const int s = L - (4 * n - 1); // row + col
+					len = (s < n) ? s + 1 : 2 * n - 1 - s;
+					r0 = (s < n) ? 0 : s - (n - 1);
+					c0 = s - r0;
+					dr = 1; dc = -1;
+				}
+				u64 line = 0xFFFull | (0xFFFull << (12 + 2 * len));
+				for (int j = 0; j < len; j++)
+					line |= static_cast<u64>(sh.board[(r0 + j * dr) * n + (c0 + j * dc)]) << (12 + 2 * j);
+				sh.lines[L] = line;
+			}
+			if (lane < n)
+			{
+				uint32_t m = 0;
+				for (int c = 0; c < n; c++)
+					if (sh.board[lane * n + c] == 0)
+						m |= (1u << c);
+				sh.legal[lane] = m;
+			}
+			__syncthreads();
+			int stones = 0;
+			for (int chunk = 0; chunk * 64 < hw; chunk++)
+			{
+				const int cell = chunk * 64 + lane;
+				int t0 = 0, t1 = 0;
+				if (cell < hw)
+				{
+					if (sh.board[cell] == 0)
+					{
+						const int r = cell / n, c = cell % n;
+						for (int d = 0; d < 4; d++)
+						{
+							const uint8_t e = E.t_pattern[narrow(normal_pattern(sh, n, r, c, d))];
+							sh.ptype[cell][d] = e & 15;
+							sh.ptype[cell][4 + d] = e >> 4;
+						}
+						t0 = E.t_threat[2 * threat_index(sh.ptype[cell])];
+						t1 = E.t_threat[2 * threat_index(sh.ptype[cell] + 4) + 1];
+					}
+					else
+					{
+						stones++;
+						for (int d = 0; d < 8; d++)
+							sh.ptype[cell][d] = 0;
+					}
+					sh.threat[cell][0] = static_cast<uint8_t>(t0);
+					sh.threat[cell][1] = static_cast<uint8_t>(t1);
+				}
+				// ordered (row-major) append to the threat lists
+				const u64 lower = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+				for (int t = 1; t < 10; t++)
+				{
+					const u64 m0 = __ballot(t0 == t);
+					if (m0 != 0)
+					{
+						const int cnt = sh.count[0][t];
+						if (t0 == t)
+							sh.lists[0][t][cnt + __popcll(m0 & lower)] = static_cast<uint16_t>(cell);
+						__syncthreads();
+						if (lane == 0)
+							sh.count[0][t] = static_cast<uint16_t>(cnt + __popcll(m0));
+						__syncthreads();
+					}
+					const u64 m1 = __ballot(t1 == t);
+					if (m1 != 0)
+					{
+						const int cnt = sh.count[1][t];
+						if (t1 == t)
+							sh.lists[1][t][cnt + __popcll(m1 & lower)] = static_cast<uint16_t>(cell);
+						__syncthreads();
+						if (lane == 0)
+							sh.count[1][t] = static_cast<uint16_t>(cnt + __popcll(m1));
+						__syncthreads();
+					}
+				}
+			}
+			for (int o = 32; o > 0; o >>= 1)
+				stones += __shfl_xor(stones, o);
+			if (lane == 0)
+			{
+				sh.sign_to_move = sign_to_move;
+				sh.depth = stones;
+			}
+			__syncthreads();
+		}
+
+		/* PatternCalculator::update_around (PatternCalculator.cpp:278-367): the centre cell, then the +-5 cells in the four
+		 * directions in the order k = -5..5 (k != 0), direction 0..3 — one lane per (k, direction). */
+		__device__ inline void solver_update_around(SolverShared &sh, const EngineDev &E, int r, int c, bool added, int lane)
+		{
+			const int n = E.n;
+			const int center = r * n + c;
+			if (added)
+			{
+				const int old0 = sh.threat[center][0], old1 = sh.threat[center][1];
+				list_remove(sh, 0, old0, center, lane);
+				list_remove(sh, 1, old1, center, lane);
+				if (lane < 8)
+					sh.ptype[center][lane] = 0;
+				if (lane < 2)
+					sh.threat[center][lane] = 0;
+			}
+			else
+			{
+				if (lane < 4)
+				{
+					const uint8_t e = E.t_pattern[narrow(normal_pattern(sh, n, r, c, lane))];
+					sh.ptype[center][lane] = e & 15;
+					sh.ptype[center][4 + lane] = e >> 4;
+				}
+				__syncthreads();
+				const int t0 = E.t_threat[2 * threat_index(sh.ptype[center])];
+				const int t1 = E.t_threat[2 * threat_index(sh.ptype[center] + 4) + 1];
+				if (lane == 0)
+				{
+					sh.threat[center][0] = static_cast<uint8_t>(t0);
+					sh.threat[center][1] = static_cast<uint8_t>(t1);
+				}
+				list_add(sh, 0, t0, center, lane);
+				list_add(sh, 1, t1, center, lane);
+			}
+			__syncthreads();
+
+			int cell = -1, old0 = 0, old1 = 0, new0 = 0, new1 = 0;
+			if (lane < 40)
+			{
+				const int ki = lane >> 2, d = lane & 3;
+				const int k = (ki < 5) ? ki - 5 : ki - 4;
+				const int rr = r + k * row_step(d), cc = c + k * col_step(d);
+				if (rr >= 0 && rr < n && cc >= 0 && cc < n && sh.board[rr * n + cc] == 0)
+				{
+					cell = rr * n + cc;
+					old0 = sh.threat[cell][0];
+					old1 = sh.threat[cell][1];
+					const uint8_t e = E.t_pattern[narrow(normal_pattern(sh, n, rr, cc, d))];
+					sh.ptype[cell][d] = e & 15;
+					sh.ptype[cell][4 + d] = e >> 4;
+					new0 = E.t_threat[2 * threat_index(sh.ptype[cell])];
+					new1 = E.t_threat[2 * threat_index(sh.ptype[cell] + 4) + 1];
+					sh.threat[cell][0] = static_cast<uint8_t>(new0);
+					sh.threat[cell][1] = static_cast<uint8_t>(new1);
+				}
+			}
+			u64 changed0 = __ballot(cell >= 0 && old0 != new0);
+			u64 changed1 = __ballot(cell >= 0 && old1 != new1);
+			__syncthreads();
+			while (changed0 != 0)
+			{
+				const int src = __ffsll(static_cast<long long>(changed0)) - 1;
+				changed0 &= changed0 - 1;
+				const int cc = __shfl(cell, src), o = __shfl(old0, src), nw = __shfl(new0, src);
+				list_remove(sh, 0, o, cc, lane);
+				__syncthreads();
+				list_add(sh, 0, nw, cc, lane);
+				__syncthreads();
+			}
+			while (changed1 != 0)
+			{
+				const int src = __ffsll(static_cast<long long>(changed1)) - 1;
+				changed1 &= changed1 - 1;
+				const int cc = __shfl(cell, src), o = __shfl(old1, src), nw = __shfl(new1, src);
+				list_remove(sh, 1, o, cc, lane);
+				__syncthreads();
+				list_add(sh, 1, nw, cc, lane);
+				__syncthreads();
+			}
+		}
+		__device__ inline void solver_place(SolverShared &sh, const EngineDev &E, uint32_t move, bool add, int lane)
+		{ // PatternCalculator::addMove / undoMove (PatternCalculator.cpp:68-105)
+			const int n = E.n;
+			const int s = move & 3, r = (move >> 2) & 127, c = (move >> 9) & 127;
+			if (lane < 4)
+			{
+				int index, shift;
+				line_of(n, r, c, lane, index, shift);
+				if (add)
+					sh.lines[index] |= static_cast<u64>(s) << (12 + shift);
+				else
+					sh.lines[index] &= ~(3ull << (12 + shift));
+			}
+			if (lane == 0)
+			{
+				sh.board[r * n + c] = add ? static_cast<uint8_t>(s) : 0;
+				if (add)
+					sh.legal[r] &= ~(1u << c);
+				else
+					sh.legal[r] |= (1u << c);
+			}
+			__syncthreads();
+			solver_update_around(sh, E, r, c, add, lane);
+			if (lane == 0)
+			{
+				sh.sign_to_move = 3 - sh.sign_to_move;
+				sh.depth += add ? 1 : -1;
+			}
+			__syncthreads();
+		}
+
+		/* NNInputFeatures::encode (NNInputFeatures.cpp:15-32,59-113), non-renju */
+		__device__ inline void solver_encode_features(const SolverShared &sh, const EngineDev &E, uint32_t *out, int lane)
+		{
+			const int own = sh.sign_to_move;
+			const uint32_t base = (1u << 3) | ((own == 1) ? (1u << 4) : (1u << 5));
+			for (int cell = lane; cell < E.hw; cell += 64)
+			{
+				uint32_t r1 = 0, r2 = 0;
+				for (int d = 0; d < 4; d++)
+				{
+					const int p1 = sh.ptype[cell][d], p2 = sh.ptype[cell][4 + d];
+					r1 |= ((p1 == 2) ? (1u << d) : 0u) | ((p1 == 3) ? (16u << d) : 0u) | ((p1 >= 4) ? (1u << (4 + p1)) : 0u);
+					r2 |= ((p2 == 2) ? (1u << d) : 0u) | ((p2 == 3) ? (16u << d) : 0u) | ((p2 >= 4) ? (1u << (4 + p2)) : 0u);
+				}
+				const uint32_t pat = (own == 1) ? ((r1 << 8) | (r2 << 20)) : ((r1 << 20) | (r2 << 8));
+				const int v = sh.board[cell];
+				const uint32_t stone = (v == 0) ? 1u : ((v == own) ? 2u : 4u);
+				out[cell] = base | stone | pat;
+			}
+		}
+
+		/* ---------------- defensive-move lookup (DefensiveMoveTable.cpp:380-461) ---------------- */
+		__device__ inline uint32_t defensive_mask(const EngineDev &E, uint32_t pattern, int defender, int threat_to_defend)
+		{
+			const uint32_t FIVE[5] = { 85u, 277u, 325u, 337u, 340u };
+			const uint32_t OPEN4[4] = { 84u, 276u, 324u, 336u };
+			const uint32_t DOUBLE4[6] = { 4177u, 4369u, 4417u, 20549u, 20741u, 86037u };
+			const int DOUBLE4_LEN[6] = { 7, 7, 7, 8, 8, 9 };
+			const int DOUBLE4_OFF[6] = { 2, 3, 4, 2, 3, 2 };
+			const uint32_t HALF4[20] = { 21u, 69u, 81u, 84u, 21u, 261u, 273u, 276u, 69u, 261u, 321u, 324u, 81u, 273u, 321u, 336u, 84u, 276u, 324u, 336u };
+			const int HALF4_OFF[20] = { 3, 4, 5, 6, 2, 4, 5, 6, 2, 3, 5, 6, 2, 3, 4, 6, 2, 3, 4, 5 };
+			const uint32_t OPEN3[12] = { 20u, 68u, 80u, 20u, 260u, 272u, 68u, 260u, 320u, 80u, 272u, 320u };
+			const int OPEN3_OFF[12] = { 3, 4, 5, 2, 4, 5, 2, 3, 5, 2, 3, 4 };
+			const int attacker = 3 - defender;
+			const int d = defender - 1;
+			const uint32_t mul = (attacker == 1) ? 1u : 2u;
+#define AGX_SUB(start, len) ((pattern >> (2 * (start))) & ((1u << (2 * (len))) - 1u))
+#define AGX_SIDES(left, right) (((pattern >> (2 * ((left) - 2))) & 15u) | (((pattern >> (2 * (right))) & 15u) << 4))
+			switch (threat_to_defend)
+			{
+				case 6: // FIVE
+					for (int i = 0; i < 5; i++)
+						if (AGX_SUB(2 + i, 5) == FIVE[i] * mul)
+							return E.t_defense[((0 + i) * 256 + AGX_SIDES(2 + i, 2 + i + 5)) * 2 + d];
+					return 0;
+				case 4: // OPEN_4
+					for (int i = 0; i < 4; i++)
+						if (AGX_SUB(2 + i, 6) == OPEN4[i] * mul)
+							return E.t_defense[((5 + i) * 256 + AGX_SIDES(2 + i, 2 + i + 6)) * 2 + d];
+					return 0;
+				case 5: // DOUBLE_4
+					for (int i = 0; i < 6; i++)
+						if (AGX_SUB(DOUBLE4_OFF[i], DOUBLE4_LEN[i]) == DOUBLE4[i] * mul)
+							return E.t_defense[((9 + i) * 256 + AGX_SIDES(DOUBLE4_OFF[i], DOUBLE4_OFF[i] + DOUBLE4_LEN[i])) * 2 + d];
+					return 0;
+				case 3: // HALF_OPEN_4
+				{
+					const bool allow_overline = (E.rules == AGX_FREESTYLE) || (E.rules == AGX_RENJU && attacker == 2) || (E.rules == AGX_CARO6);
+					const bool allow_blocked = (E.rules != AGX_CARO5 && E.rules != AGX_CARO6);
+					uint32_t result = 1u << 6;
+					for (int i = 0; i < 20; i++)
+					{
+						const int begin = HALF4_OFF[i];
+						if (AGX_SUB(begin, 5) != HALF4[i] * mul)
+							continue;
+						const int first = (pattern >> (2 * (begin - 1))) & 3, last = (pattern >> (2 * (begin + 5))) & 3;
+						if (!allow_overline && (first == attacker || last == attacker))
+							continue;
+						if (!allow_blocked && (first == defender && last == defender))
+							continue;
+						uint32_t tmp = E.t_defense[((i / 4) * 256 + AGX_SIDES(begin, begin + 5)) * 2 + d];
+						const int sh = begin - (2 + i / 4);
+						tmp = (sh >= 0) ? ((tmp << sh) & 0xFFFFu) : (tmp >> (-sh));
+						result |= tmp;
+						if (E.rules != AGX_CARO5 && E.rules != AGX_CARO6)
+							return result;
+					}
+					return result;
+				}
+				case 2: // OPEN_3
+					for (int i = 0; i < 12; i++)
+					{
+						const int begin = OPEN3_OFF[i];
+						if (AGX_SUB(begin, 6) == OPEN3[i] * mul)
+						{
+							uint32_t result = E.t_defense[((5 + i / 3) * 256 + AGX_SIDES(begin, begin + 6)) * 2 + d];
+							const int sh = begin - (2 + i / 3);
+							result = (sh >= 0) ? ((result << sh) & 0xFFFFu) : (result >> (-sh));
+							return result | (1u << 6);
+						}
+					}
+					return 0;
+				default:
+					return 0;
+			}
+#undef AGX_SUB
+#undef AGX_SIDES
+		}
+
+		/* ---------------- staged move generator, lane 0 only (MoveGenerator.cpp:159-1207, non-renju) ---------------- */
+		struct SmallSet
+		{ // StackVector<Location, N> semantics (patterns/common.hpp:154-245)
+				uint16_t v[32];
+				int n;
+				__device__ bool contains(int x) const
+				{
+					for (int i = 0; i < n; i++)
+						if (v[i] == x)
+							return true;
+					return false;
+				}
+				__device__ void add(int x) { v[n++] = static_cast<uint16_t>(x); }
+				__device__ void remove_at(int i) { v[i] = v[--n]; }
+				__device__ void remove(int x)
+				{
+					for (int i = 0; i < n; i++)
+						if (v[i] == x)
+						{
+							v[i] = v[--n];
+							return;
+						}
+				}
+		};
+
+		struct MoveGen
+		{
+				SolverShared &sh;
+				const EngineDev &E;
+				uint32_t *act;
+				Frame &f;
+				int n, own, opp;
+
+				__device__ MoveGen(SolverShared &s, const EngineDev &e, uint32_t *a, Frame &fr) : sh(s), E(e), act(a), f(fr), n(e.n), own(s.sign_to_move), opp(3 - s.sign_to_move) {}
+				__device__ const uint16_t* list(int sign, int t) const { return sh.lists[sign - 1][t]; }
+				__device__ int count(int sign, int t) const { return sh.count[sign - 1][t]; }
+				__device__ const uint8_t* patterns(int sign, int cell) const { return sh.ptype[cell] + 4 * (sign - 1); }
+				__device__ int threat_at(int sign, int cell) const { return sh.threat[cell][sign - 1]; }
+				__device__ static int count_of(const uint8_t *g, int v) { return (g[0] == v) + (g[1] == v) + (g[2] == v) + (g[3] == v); }
+				__device__ static int direction_of(const uint8_t *g, int v)
+				{
+					for (int d = 0; d < 4; d++)
+						if (g[d] == v)
+							return d;
+					return 0;
+				}
+				__device__ bool has_any_four(int sign) const { return count(sign, 4) > 0 || count(sign, 5) > 0 || count(sign, 6) > 0 || count(sign, 7) > 0; }
+				__device__ int available_fours(int sign) const { return count(sign, 7) + count(sign, 6) + count(sign, 5) + count(sign, 4); }
+
+				__device__ void push(uint32_t move, uint32_t score, int num)
+				{ // ActionList::add (ActionList.hpp:190-195)
+					if (f.base + f.size + 1 >= E.act_cap)
+					{
+						sh.error = ERR_ACTION_STACK;
+						return;
+					}
+					act[f.base + f.size] = move | (score << 16);
+					f.size += num;
+					sh.stack_offset += num;
+					sh.stack_max = max(sh.stack_max, sh.stack_offset);
+				}
+				__device__ uint32_t move_of(int cell) const { return static_cast<uint32_t>(own) | ((cell / n) << 2) | ((cell % n) << 9); }
+				__device__ void add_move(int cell, uint32_t score, bool override_duplicate)
+				{ // MoveGenerator.cpp:228-249
+					const int r = cell / n, c = cell % n;
+					if ((sh.added[r] >> c) & 1)
+					{
+						if (override_duplicate)
+						{
+							const uint32_t m = move_of(cell);
+							for (int i = 0; i < f.size; i++)
+								if ((act[f.base + i] & 0xFFFFu) == m)
+								{
+									act[f.base + i] = m | (score << 16);
+									return;
+								}
+						}
+					}
+					else
+					{
+						push(move_of(cell), score, 1);
+						sh.added[r] |= (1u << c);
+					}
+				}
+				__device__ void add_list(int sign, int t, uint32_t score, bool override_duplicate)
+				{
+					const int cnt = count(sign, t);
+					for (int i = 0; i < cnt; i++)
+						add_move(list(sign, t)[i], score, override_duplicate);
+				}
+				__device__ void defensive_moves(int defender, int cell, int dir, SmallSet &out) const
+				{ // PatternCalculator::getDefensiveMoves (PatternCalculator.hpp:150-160)
+					const int r = cell / n, c = cell % n;
+					const uint32_t ext = extended_pattern(sh, n, r, c, dir);
+					const int to_defend = patterns(3 - defender, cell)[dir];
+					const uint32_t mask = defensive_mask(E, ext, defender, to_defend);
+					out.n = 0;
+					for (int i = -6; i <= 6; i++)
+						if ((mask >> (6 + i)) & 1)
+							out.add((r + i * row_step(dir)) * n + (c + i * col_step(dir)));
+				}
+				__device__ static void intersect(SmallSet &lhs, const SmallSet &rhs)
+				{
+					int i = 0;
+					while (i < lhs.n)
+					{
+						if (rhs.contains(lhs.v[i]))
+							i++;
+						else
+							lhs.remove_at(i);
+					}
+				}
+				__device__ static void intersect_init(SmallSet &dm, bool &initialized, const SmallSet &other)
+				{ // DefensiveMoves::get_intersection_with (MoveGenerator.cpp:101-111)
+					if (!initialized)
+					{
+						for (int i = 0; i < other.n; i++)
+							dm.add(other.v[i]);
+						initialized = true;
+					}
+					else
+						intersect(dm, other);
+				}
+				__device__ uint32_t try_solve_own_fork_4x3(int cell)
+				{ // :947-992
+					const int dir = direction_of(patterns(own, cell), 3);
+					SmallSet dm;
+					defensive_moves(opp, cell, dir, dm);
+					dm.remove(cell);
+					int best = 0;
+					for (int i = 0; i < dm.n; i++)
+						best = max(best, threat_at(opp, dm.v[i]));
+					switch (best)
+					{
+						case 4:
+						case 5:
+							return s_unknown(15);
+						case 6:
+						case 7:
+							return s_loss_in(4);
+						case 8:
+						case 9:
+							return s_loss_in(2);
+						default:
+							return s_win_in(5);
+					}
+				}
+				__device__ uint32_t add_own_4x3_forks()
+				{ // :881-893
+					uint32_t result = s_unknown(0);
+					const int cnt = count(own, 5);
+					for (int k = 0; k < cnt; k++)
+					{
+						const int cell = list(own, 5)[k];
+						const uint32_t solution = try_solve_own_fork_4x3(cell);
+						add_move(cell, solution, true);
+						if (s_proven(solution))
+							result = max(result, solution);
+					}
+					return result;
+				}
+				__device__ void add_own_half_open_fours()
+				{ // :894-946
+					add_list(own, 4, s_unknown(14), false);
+					if (count(own, 4) > 0)
+						f.has_initiative = 1;
+				}
+				__device__ void stamp(uint32_t *rows, int r, int c, const uint32_t *pattern) const
+				{
+					for (int i = 0; i < 7; i++)
+					{
+						const int rr = r - 3 + i;
+						if (rr < 0 || rr >= n)
+							continue;
+						const uint32_t p = pattern[i]; // palindromic rows: bit j <-> column c - 3 + j
+						if (c >= 3)
+							rows[rr] |= (p << (c - 3));
+						else
+							rows[rr] |= (p >> (3 - c));
+					}
+				}
+				__device__ void create_remaining_moves(const uint32_t *mask, uint32_t score)
+				{ // :1127-1137
+					for (int r = 0; r < n; r++)
+					{
+						uint32_t bits = mask[r] & (~sh.added[r]);
+						while (bits != 0)
+						{
+							const int c = __ffs(static_cast<int>(bits)) - 1;
+							bits &= bits - 1;
+							push(static_cast<uint32_t>(own) | (r << 2) | (c << 9), score, 1);
+						}
+						sh.added[r] |= mask[r];
+					}
+				}
+
+				// each stage returns true when the cascade must continue; `result` receives the static score
+				__device__ bool try_win_in_1(uint32_t &result)
+				{ // :355-371
+					if (count(own, 8) > 0)
+					{
+						f.has_initiative = 1;
+						add_list(own, 8, s_win_in(1), false);
+						result = s_win_in(1);
+						return false;
+					}
+					return true;
+				}
+				__device__ bool try_draw_in_1(uint32_t &result)
+				{ // :309-354
+					f.baseline = static_cast<uint16_t>(s_draw_in(1));
+					create_remaining_moves(sh.legal, s_draw_in(1));
+					result = s_draw_in(1);
+					return false;
+				}
+				__device__ bool defend_loss_in_2(uint32_t &result)
+				{ // :372-463
+					const int cnt = count(opp, 8);
+					if (cnt == 0)
+						return true;
+					f.must_defend = 1;
+					f.baseline = static_cast<uint16_t>(s_loss_in(2));
+					SmallSet dm, tmp;
+					dm.n = 0;
+					bool initialized = false;
+					for (int k = 0; k < cnt; k++)
+					{
+						const int cell = list(opp, 8)[k];
+						const int dir = direction_of(patterns(opp, cell), 6);
+						defensive_moves(own, cell, dir, tmp);
+						intersect_init(dm, initialized, tmp);
+						if (dm.n == 0)
+						{
+							add_list(opp, 8, s_loss_in(2), false);
+							result = s_loss_in(2);
+							return false;
+						}
+					}
+					uint32_t best = 0x0000u;
+					for (int k = 0; k < dm.n; k++)
+					{
+						const int cell = dm.v[k];
+						uint32_t response = s_unknown(0);
+						switch (threat_at(own, cell))
+						{
+							case 3: // FORK_3x3
+								if (!has_any_four(opp))
+									response = s_win_in(5);
+								break;
+							case 5: // FORK_4x3
+							{
+								const uint32_t solution = try_solve_own_fork_4x3(cell);
+								response = s_proven(solution) ? solution : s_unknown(15);
+								break;
+							}
+							case 6:
+							case 7:
+								response = s_win_in(3);
+								break;
+							default:
+								if (count_of(patterns(own, cell), 3) > 0)
+								{
+									f.has_initiative = 1;
+									response = s_unknown(14);
+								}
+								break;
+						}
+						if (s_win(response))
+							f.has_initiative = 1;
+						add_move(cell, response, false);
+						best = max(best, response);
+					}
+					result = best;
+					return false;
+				}
+				__device__ bool try_win_in_3(uint32_t &result)
+				{ // :464-555
+					int threats = 0;
+					add_list(own, 7, s_win_in(3), false);
+					threats += count(own, 7);
+					if (count(own, 6) > 0)
+					{
+						threats += count(own, 6);
+						add_list(own, 6, s_win_in(3), false);
+					}
+					if (threats > 0)
+					{
+						f.has_initiative = 1;
+						result = s_win_in(3);
+						return false;
+					}
+					return true;
+				}
+				__device__ bool defend_loss_in_4(uint32_t &result)
+				{ // :556-689 (non-renju branch)
+					const bool any_four = has_any_four(own);
+					f.baseline = static_cast<uint16_t>(s_loss_in(4));
+					SmallSet dm, tmp, storage;
+					dm.n = 0;
+					bool initialized = false;
+					const int n_open4 = count(opp, 7);
+					for (int k = 0; k < n_open4; k++)
+					{
+						f.must_defend = 1;
+						const int cell = list(opp, 7)[k];
+						const int dir = direction_of(patterns(opp, cell), 4);
+						defensive_moves(own, cell, dir, tmp);
+						intersect_init(dm, initialized, tmp);
+						if (dm.n == 0 && !any_four)
+						{
+							add_list(opp, 7, s_loss_in(4), false);
+							result = s_loss_in(4);
+							return false;
+						}
+					}
+					const int n_fork44 = count(opp, 6);
+					for (int k = 0; k < n_fork44; k++)
+					{
+						f.must_defend = 1;
+						const int cell = list(opp, 6)[k];
+						const uint8_t *group = patterns(opp, cell);
+						for (int d = 0; d < 4; d++)
+							if (group[d] == 4 || group[d] == 5)
+							{
+								defensive_moves(own, cell, d, tmp);
+								intersect_init(dm, initialized, tmp);
+							}
+						if (count_of(group, 3) > 0)
+						{
+							storage.n = 0;
+							for (int d = 0; d < 4; d++)
+								if (group[d] == 3)
+								{
+									defensive_moves(own, cell, d, tmp);
+									for (int i = 0; i < tmp.n; i++)
+										if (!storage.contains(tmp.v[i]))
+											storage.add(tmp.v[i]);
+								}
+							intersect_init(dm, initialized, storage);
+						}
+						if (dm.n == 0 && !any_four)
+						{
+							add_list(opp, 6, s_loss_in(4), false);
+							result = s_loss_in(4);
+							return false;
+						}
+					}
+					for (int i = 0; i < dm.n; i++)
+						add_move(dm.v[i], s_unknown(0), false);
+					if (f.must_defend)
+					{
+						f.has_initiative = any_four ? 1 : 0;
+						const uint32_t best = add_own_4x3_forks();
+						add_own_half_open_fours();
+						result = s_win(best) ? best : s_unknown(0);
+						return false;
+					}
+					f.baseline = static_cast<uint16_t>(s_unknown(0));
+					return true;
+				}
+				__device__ bool try_win_in_5(uint32_t &result)
+				{ // :690-720
+					uint32_t best = add_own_4x3_forks();
+					if (available_fours(opp) == 0 && count(own, 3) > 0)
+					{
+						add_list(own, 3, s_win_in(5), false);
+						best = max(best, s_win_in(5));
+					}
+					if (s_win(best))
+					{
+						f.has_initiative = 1;
+						result = best;
+						return false;
+					}
+					return true;
+				}
+				__device__ bool defend_loss_in_6(uint32_t &result)
+				{ // :721-816
+					if (available_fours(own) > 0)
+						return true;
+					const int n43 = count(opp, 5), n33 = count(opp, 3);
+					if (n43 > 0 || n33 > 0)
+					{
+						f.must_defend = 1;
+						f.baseline = static_cast<uint16_t>(s_loss_in(6));
+					}
+					SmallSet tmp, half4;
+					for (int k = 0; k < n43; k++)
+					{
+						const int cell = list(opp, 5)[k];
+						const uint8_t *group = patterns(opp, cell);
+						for (int d = 0; d < 4; d++)
+							if (group[d] == 2)
+							{
+								defensive_moves(own, cell, d, tmp);
+								for (int i = 0; i < tmp.n; i++)
+									add_move(tmp.v[i], s_unknown(0), false);
+							}
+						const int dir = direction_of(group, 3);
+						defensive_moves(own, cell, dir, half4);
+						for (int i = 0; i < half4.n; i++)
+							add_move(half4.v[i], s_unknown(0), false);
+						for (int i = 0; i < half4.n; i++)
+						{
+							const int hr = half4.v[i] / n, hc = half4.v[i] % n;
+							for (int d = 0; d < 4; d++)
+							{
+								const uint32_t reduced = (extended_pattern(sh, n, hr, hc, d) >> 4) & 0x3FFFFu;
+								for (int j = -4; j <= 4; j++)
+									if (((reduced >> (2 * (j + 4))) & 3u) == 0u)
+									{
+										const int rr = hr + j * row_step(d), cc = hc + j * col_step(d);
+										const int l = rr * n + cc;
+										const int pt = patterns(own, l)[d];
+										if (pt > 0 || ((E.t_ho3[narrow(normal_pattern(sh, n, rr, cc, d))] >> (own - 1)) & 1))
+											add_move(l, s_unknown(0), false);
+									}
+							}
+						}
+					}
+					for (int k = 0; k < n33; k++)
+					{
+						const int cell = list(opp, 3)[k];
+						const uint8_t *group = patterns(opp, cell);
+						for (int d = 0; d < 4; d++)
+							if (group[d] == 2)
+							{
+								defensive_moves(own, cell, d, tmp);
+								for (int i = 0; i < tmp.n; i++)
+									add_move(tmp.v[i], s_unknown(0), false);
+							}
+						add_list(own, 3, s_unknown(13), false);
+						add_list(own, 2, s_unknown(1), false);
+						const uint32_t star[7] = { 73u, 42u, 28u, 119u, 28u, 42u, 73u };
+						uint32_t mask[MAXN];
+						for (int r = 0; r < n; r++)
+							mask[r] = 0;
+						for (int r = 0; r < n; r++)
+							for (int c = 0; c < n; c++)
+								if (sh.board[r * n + c] == own)
+									stamp(mask, r, c, star);
+						for (int r = 0; r < n; r++)
+						{
+							uint32_t bits = mask[r] & sh.legal[r] & (~sh.added[r]);
+							for (int c = 0; c < n; c++, bits >>= 1)
+								if (bits & 1)
+									for (int d = 0; d < 4; d++)
+										if ((E.t_ho3[narrow(normal_pattern(sh, n, r, c, d))] >> (own - 1)) & 1)
+										{
+											add_move(r * n + c, s_unknown(1), false);
+											break;
+										}
+						}
+					}
+					if (f.must_defend)
+					{
+						add_own_half_open_fours();
+						result = s_unknown(0);
+						return false;
+					}
+					return true;
+				}
+				__device__ void mark_neighborhood(uint32_t *out) const
+				{ // :1011-1071
+					const uint32_t box[7] = { 73u, 62u, 62u, 119u, 62u, 62u, 73u };
+					for (int r = 0; r < n; r++)
+						out[r] = 0;
+					for (int r = 0; r < n; r++)
+					{
+						uint32_t occupied = (~sh.legal[r]) & ((1u << n) - 1u);
+						while (occupied != 0)
+						{
+							const int c = __ffs(static_cast<int>(occupied)) - 1;
+							occupied &= occupied - 1;
+							stamp(out, r, c, box);
+						}
+					}
+					if (sh.depth == 0)
+						out[n / 2] |= (1u << (n / 2));
+					for (int r = 0; r < n; r++)
+						out[r] &= sh.legal[r];
+				}
+
+				/* MoveGenerator::generate (:159-223); mode 1 = THREATS, 2 = OPTIMAL */
+				__device__ uint32_t generate(int mode)
+				{
+					const int distance_to_draw = E.draw_after - sh.depth;
+					if (distance_to_draw <= 0)
+						return s_make(1, 0);
+					for (int r = 0; r < n; r++)
+						sh.added[r] = 0;
+					uint32_t result = s_unknown(0);
+					bool go = true;
+					if (go && distance_to_draw >= 1) go = try_win_in_1(result);
+					if (go && distance_to_draw == 1) go = try_draw_in_1(result);
+					if (go && distance_to_draw >= 2) go = defend_loss_in_2(result);
+					if (go && distance_to_draw >= 3) go = try_win_in_3(result);
+					if (go && distance_to_draw >= 4) go = defend_loss_in_4(result);
+					if (go && distance_to_draw >= 5) go = try_win_in_5(result);
+					if (go && distance_to_draw >= 6) go = defend_loss_in_6(result);
+					if (go && distance_to_draw >= 3) add_own_half_open_fours();
+					if (go && mode >= 2)
+					{
+						if (distance_to_draw >= 6)
+						{
+							add_list(opp, 3, s_unknown(3), false);
+							add_list(opp, 2, s_unknown(2), false);
+						}
+						if (distance_to_draw >= 5)
+						{
+							add_list(own, 3, s_unknown(13), false);
+							add_list(own, 2, s_unknown(1), false);
+						}
+						if (distance_to_draw >= 3)
+							add_list(opp, 4, s_unknown(4), false);
+						uint32_t mask[MAXN];
+						mark_neighborhood(mask);
+						create_remaining_moves(mask, s_unknown(0));
+					}
+					f.fully_expanded = (f.must_defend || mode >= 2) ? 1 : 0;
+					return result;
+				}
+		};
+
+		/* ---------------- transposition table (SharedHashTable.hpp:27-220), 4 x 16-byte entries per bucket ---------------- */
+		__device__ __forceinline__ u64 tt_pack(int bound, int depth, uint32_t score, uint32_t move)
+		{
+			return static_cast<u64>(bound) | (static_cast<u64>(depth) << 8) | (static_cast<u64>(score) << 16) | (static_cast<u64>(move) << 32);
+		}
+		__device__ inline u64 tt_seek(const u64 *tt, u64 bucket_mask, u64 lo, u64 hi)
+		{
+			const u64 *bucket = tt + 8 * (lo & bucket_mask);
+			const u64 KEY = 0xFFFF000000000000ull;
+			for (int i = 0; i < 4; i++)
+				if (bucket[2 * i] == hi && (bucket[2 * i + 1] & KEY) == (lo & KEY))
+					return bucket[2 * i + 1];
+			return tt_pack(0, 0, s_unknown(0), 0);
+		}
+		__device__ inline void tt_insert(u64 *tt, u64 bucket_mask, u64 lo, u64 hi, u64 value, int generation)
+		{
+			const u64 KEY = 0xFFFF000000000000ull;
+			value &= ~(KEY | 0xFCull);
+			value |= static_cast<u64>(generation) << 2;
+			value |= (lo & KEY);
+			u64 *bucket = tt + 8 * (lo & bucket_mask);
+			const uint32_t score = static_cast<uint32_t>((value >> 16) & 65535u);
+			if (s_proven(score) || (value & 3ull) == 3ull)
+				for (int i = 0; i < 4; i++)
+					if (bucket[2 * i] == hi && (bucket[2 * i + 1] & KEY) == (lo & KEY))
+					{
+						bucket[2 * i] = hi;
+						bucket[2 * i + 1] = value;
+						return;
+					}
+			int idx = 0, best_worth = 0;
+			for (int i = 0; i < 4; i++)
+			{
+				const u64 d = bucket[2 * i + 1];
+				const int worth = static_cast<int>((d >> 8) & 255) - (generation - static_cast<int>((d >> 2) & 63));
+				if (i == 0 || worth < best_worth)
+				{
+					best_worth = worth;
+					idx = i;
+				}
+			}
+			bucket[2 * idx] = hi;
+			bucket[2 * idx + 1] = value;
+		}
+
+		/* AlphaBetaSearch::evaluate (AlphaBetaSearch.cpp:345-365) */
+		__device__ inline uint32_t solver_evaluate(const SolverShared &sh)
+		{
+			const int own_values[10] = { 0, 0, 19, 49, 76, 170, 33, 159, 252, 0 };
+			const int opp_values[10] = { 0, 0, -1, -50, -45, -135, -14, -154, -496, 0 };
+			const int own = sh.sign_to_move - 1, opp = 1 - own;
+			int result = 12;
+			for (int t = 2; t <= 8; t++)
+				result += own_values[t] * sh.count[own][t] + opp_values[t] * sh.count[opp][t];
+			return s_unknown(max(-1000, min(1000, result)));
+		}
+
+		/*
+		 * AlphaBetaSearch::recursive_solve (AlphaBetaSearch.cpp:185-339) as an explicit frame machine run by lane 0.
+		 * Runs until a stone must be placed/removed (returns CMD_ADD / CMD_UNDO with sh.cmd_move) or the root returns (CMD_DONE).
+		 * phase: 0 = enter frame `level`, 1 = resume frame `level` after its child returned sh.pending_value.
+		 */
+		__device__ inline int solver_run(SolverShared &sh, const EngineDev &E, uint32_t *act, u64 *tt, int generation)
+		{
+			const u64 *zob = E.zob;
+			const int n = E.n;
+			int phase = sh.phase;
+			uint32_t value = static_cast<uint32_t>(sh.pending_value);
+			while (true)
+			{
+				Frame &f = sh.frames[sh.level];
+				bool returning = false;
+				if (phase == 0)
+				{ // ---- enter ----
+					f.best_move = 0;
+					const u64 entry = tt_seek(tt, E.tt_bucket_mask, sh.hash_lo, sh.hash_hi);
+					bool early = false;
+					if ((entry & 3ull) != 0ull)
+					{
+						f.best_move = static_cast<uint16_t>((entry >> 32) & 65535u);
+						if (sh.level != 0)
+						{
+							const uint32_t tt_s = static_cast<uint32_t>((entry >> 16) & 65535u);
+							const int b = static_cast<int>(entry & 3ull);
+							if (s_proven(tt_s))
+							{
+								value = tt_s;
+								early = true;
+							}
+							else if (static_cast<int>((entry >> 8) & 255) >= f.depth_remaining && (b == 3 || (b == 1 && tt_s >= f.beta) || (b == 2 && tt_s <= f.alpha)))
+							{
+								value = tt_s;
+								early = true;
+							}
+						}
+					}
+					if (!early)
+					{
+						sh.node_counter++;
+						if (f.size == 0)
+						{
+							MoveGen gen(sh, E, act, f);
+							const uint32_t static_score = gen.generate(sh.level == 0 ? 2 : 1);
+							if (s_proven(static_score))
+							{
+								value = static_score;
+								early = true;
+							}
+						}
+					}
+					if (!early && f.depth_remaining <= 0)
+					{
+						value = solver_evaluate(sh);
+						early = true;
+					}
+					if (early)
+						returning = true;
+					else
+					{
+						f.original_alpha = f.alpha;
+						f.best_score = 0x0000u;
+						f.i = 0;
+						phase = 2; // iterate
+					}
+				}
+				else if (phase == 1)
+				{ // ---- child returned ----
+					const uint32_t mv = act[f.base + f.i] & 0xFFFFu;
+					act[f.base + f.i] = mv | (s_invert_up(value) << 16);
+					const int cell = ((mv >> 2) & 127) * n + ((mv >> 9) & 127);
+					sh.hash_lo ^= zob[2 * (2 * cell + ((mv & 3) - 1))];
+					sh.hash_hi ^= zob[2 * (2 * cell + ((mv & 3) - 1)) + 1];
+					phase = 3; // post-child bookkeeping
+				}
+				if (!returning && phase == 2)
+				{ // ---- pick the next action (:253-266) ----
+					if (f.i >= f.size)
+						phase = 4;
+					else
+					{
+						const uint32_t bm = f.best_move;
+						const bool tt_move_legal = ((bm & 3u) == static_cast<uint32_t>(sh.sign_to_move)) && sh.board[((bm >> 2) & 127) * n + ((bm >> 9) & 127)] == 0;
+						if (f.i == 0 && tt_move_legal)
+						{
+							for (int j = 0; j < f.size; j++)
+								if ((act[f.base + j] & 0xFFFFu) == bm)
+								{
+									const uint32_t t = act[f.base];
+									act[f.base] = act[f.base + j];
+									act[f.base + j] = t;
+									break;
+								}
+						}
+						else
+						{
+							int idx = f.i;
+							uint32_t best = act[f.base + idx] >> 16;
+							for (int j = f.i + 1; j < f.size; j++)
+							{
+								const uint32_t sc = act[f.base + j] >> 16;
+								if (best < sc)
+								{
+									best = sc;
+									idx = j;
+								}
+							}
+							const uint32_t t = act[f.base + f.i];
+							act[f.base + f.i] = act[f.base + idx];
+							act[f.base + idx] = t;
+						}
+						const uint32_t a = act[f.base + f.i];
+						if (s_unproven(a >> 16) && sh.node_counter < E.tss_max_nodes)
+						{ // descend (:268-298)
+							if (sh.level + 1 >= MAX_FRAMES)
+							{
+								sh.error = ERR_FRAMES;
+								phase = 3;
+							}
+							else
+							{
+								const uint32_t mv = a & 0xFFFFu;
+								const int cell = ((mv >> 2) & 127) * n + ((mv >> 9) & 127);
+								sh.hash_lo ^= zob[2 * (2 * cell + ((mv & 3) - 1))];
+								sh.hash_hi ^= zob[2 * (2 * cell + ((mv & 3) - 1)) + 1];
+								f.move = static_cast<uint16_t>(mv);
+								Frame &child = sh.frames[sh.level + 1];
+								child.base = f.base + f.size; // == stack offset: lists are strictly nested
+								child.size = 0;
+								child.i = 0;
+								child.depth_remaining = f.depth_remaining - 1;
+								child.alpha = static_cast<uint16_t>(s_invert_down(f.beta));
+								child.beta = static_cast<uint16_t>(s_invert_down(f.alpha));
+								child.baseline = static_cast<uint16_t>(s_unknown(0));
+								child.must_defend = child.has_initiative = child.fully_expanded = 0;
+								sh.level++;
+								sh.phase = 0;
+								sh.cmd_move = static_cast<int>(mv);
+								return CMD_ADD;
+							}
+						}
+						else
+							phase = 3;
+					}
+				}
+				if (!returning && phase == 3)
+				{ // ---- after the action has its score (:299-307) ----
+					const uint32_t a = act[f.base + f.i];
+					const uint32_t sc = a >> 16;
+					f.best_score = static_cast<uint16_t>(max(static_cast<uint32_t>(f.best_score), sc));
+					if (sc > f.alpha)
+					{
+						f.alpha = static_cast<uint16_t>(sc);
+						f.best_move = static_cast<uint16_t>(a & 0xFFFFu);
+					}
+					if (sc >= f.beta || s_win(sc) || sh.error != 0)
+						phase = 4;
+					else
+					{
+						f.i++;
+						phase = 2;
+						continue;
+					}
+				}
+				if (!returning && phase == 4)
+				{ // ---- finish the node (:308-338) ----
+					uint32_t best = f.best_score;
+					if (f.size == 0 || (s_loss(best) && !f.fully_expanded))
+						best = solver_evaluate(sh);
+					int bound;
+					if (best <= f.original_alpha)
+						bound = 2;
+					else
+						bound = (best >= f.beta) ? 1 : 3;
+					tt_insert(tt, E.tt_bucket_mask, sh.hash_lo, sh.hash_hi, tt_pack(bound, f.depth_remaining, best, f.best_move), generation);
+					value = best;
+					returning = true;
+				}
+				if (returning)
+				{
+					if (sh.level == 0)
+					{
+						sh.result_score = static_cast<int>(value);
+						return CMD_DONE;
+					}
+					sh.stack_offset -= f.size; // ~ActionList (ActionList.hpp:128-131)
+					sh.level--;
+					sh.pending_value = static_cast<int>(value);
+					sh.phase = 1;
+					sh.cmd_move = sh.frames[sh.level].move;
+					return CMD_UNDO;
+				}
+			}
+		}
+	}
+}
+
+#endif

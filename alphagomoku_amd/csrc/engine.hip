@@ -1,0 +1,1479 @@
+/*
+ * engine.hip — the device-resident self-play engine: kernels, host object and its C ABI (include/agx.h).
+ *
+ * One step of the pool = what GameGenerator::generate does for every game of a GeneratorThread
+ * (src/selfplay/GameGenerator.cpp:79-118, src/selfplay/GeneratorManager.cpp:124-141), as five launches:
+ *
+ *   k_select   Search::select          (Search.cpp:117-158)   up to `batch` PUCT descents per game, virtual loss
+ *   k_solve    Search::solve           (Search.cpp:159-183)   threat solver on every new leaf + NN feature encode,
+ *              Search::scheduleToNN    (Search.cpp:184-199)   compacts the positions that need the network
+ *   (network)  NNEvaluator::evaluate                         agx_nn_forward over the compacted list (nn_forward.hip)
+ *   k_expand   Search::generateEdges / expand / backup (Search.cpp:206-232) and the move rule (GameGenerator.cpp:97-103)
+ *   k_advance  GameGenerator::make_move + prepare_search (:145-185): final "best" selector, sample record, outcome test,
+ *              NodeCache::cleanup as a keep-test + prefix-sum compaction into the game's other arena, next opening
+ *
+ * Everything stays in HBM between steps; the host only enqueues launches.  One wavefront per game for the sequential
+ * tree work (games are independent, the batch inside a game is order-dependent through virtual loss); k_advance uses a
+ * 256-thread workgroup per game because compaction is data parallel.
+ */
+#include "agx_internal.hpp"
+#include "engine_types.hpp"
+#include "dev_mcts.hpp"
+#include "tables_host.hpp"
+
+#include <vector>
+#include <cstring>
+
+using namespace agx;
+using namespace agx::dev;
+
+namespace
+{
+	/* ------------------------------------------------------------------------------------------------------------ */
+	__global__ __launch_bounds__(64) void k_select(EngineDev E)
+	{
+		__shared__ uint8_t sh_board[MAXHW];
+		__shared__ u64 sh_cboard[BWORDS];
+		const int g = blockIdx.x, lane = threadIdx.x;
+		GameState &gs = E.games[g];
+		if (!gs.active || gs.error != 0 || gs.outcome != 0)
+			return;
+		DNode *nodes = nodes_of(E, g, gs.arena);
+		DEdge *edges = edges_of(E, g, gs.arena);
+		const int *ht = ht_of(E, g);
+		const int n = E.n;
+
+		int n_tasks = gs.n_tasks;
+		int trials = 2 * E.batch;
+		unsigned long long st_levels = 0, st_edges = 0, st_leaks = 0, st_proven = 0, st_dup = 0;
+		while (n_tasks < E.batch)
+		{
+			const int root = gs.root;
+			const int sims = (root < 0) ? 0 : nodes[root].visits;
+			if (sims > E.max_sims)
+				break;
+			DTask &t = E.tasks[static_cast<size_t>(g) * E.batch + n_tasks];
+			n_tasks++;
+			// SearchTask::set (SearchTask.cpp:32-50)
+			for (int i = lane; i < E.hw; i += 64)
+				sh_board[i] = gs.board[i];
+			if (lane < BWORDS)
+				sh_cboard[lane] = gs.cboard[lane];
+			__syncthreads();
+			int path_len = 0, final_node = -1, out = 0, sign = gs.sign_to_move;
+			u64 hash = gs.root_hash;
+			int last_edge = -1;
+			int node = root;
+			while (node >= 0)
+			{
+				if (path_len >= PATH_CAP)
+				{
+					if (lane == 0)
+						gs.error = ERR_PATH_CAPACITY;
+					break;
+				}
+				const DNode nd = nodes[node];
+				const int e = select_edge(E, nd, edges, lane, st_edges);
+				st_levels++;
+				const uint32_t mv = edges[e].move;
+				const int s = mv & 3, cell = ((mv >> 2) & 127) * n + ((mv >> 9) & 127);
+				if (lane == 0)
+				{ // SearchTask::append (SearchTask.cpp:52-60) + virtual loss (Tree.cpp:235-236)
+					sh_board[cell] = static_cast<uint8_t>(s);
+					sh_cboard[cell >> 5] |= static_cast<u64>(s) << (2 * (cell & 31));
+					t.path_node[path_len] = node;
+					t.path_edge[path_len] = e;
+					nodes[node].vl = static_cast<int16_t>(nd.vl + 1);
+					edges[e].flag_vl = static_cast<uint16_t>((edges[e].flag_vl & 0x8000u) | (((edges[e].flag_vl & 0x7FFF) + 1) & 0x7FFF));
+				}
+				hash ^= E.nc_keys[3 + 3 * cell] ^ E.nc_keys[3 + 3 * cell + s] ^ E.nc_keys[sign] ^ E.nc_keys[3 - s];
+				sign = 3 - s;
+				path_len++;
+				last_edge = e;
+				__syncthreads();
+				if (s_proven(edges[e].score))
+				{
+					out = 2;
+					break;
+				}
+				node = cache_seek(E, nodes, ht, hash, sh_cboard, sign, lane);
+				final_node = node;
+				if (node < 0 && lane == 0)
+					edges[e].flag_vl |= 0x8000u;
+				const DEdge ee = edges[e];
+				if (has_leak(E, ee, (node >= 0) ? &nodes[node] : nullptr))
+				{
+					out = 1;
+					break;
+				}
+			}
+			// publish the task
+			for (int i = lane; i < E.hw; i += 64)
+				t.board[i] = sh_board[i];
+			if (lane < BWORDS)
+				t.cboard[lane] = sh_cboard[lane];
+			if (lane == 0)
+			{
+				t.path_len = path_len;
+				t.final_node = final_node;
+				t.n_edges = 0;
+				t.flags = t.flags & (TF_STATICALLY_SOLVED | TF_RECURSIVELY_SOLVED); // these two survive SearchTask::set
+				t.sign_to_move = sign;
+				t.score = s_unknown(0);
+				t.win = 0.0f;
+				t.draw = 0.0f;
+				t.moves_left = 0.0f;
+				t.needs_nn = 0;
+				t.hash = hash;
+			}
+			__syncthreads();
+			if (path_len == 0)
+				break; // the root itself has to be evaluated
+			for (int i = 0; i < n_tasks - 1; i++)
+			{ // Search::is_duplicate (statistics only)
+				const DTask &o = E.tasks[static_cast<size_t>(g) * E.batch + i];
+				if (o.path_len > 0 && o.path_edge[o.path_len - 1] == last_edge)
+				{
+					st_dup++;
+					break;
+				}
+			}
+			if (out == 1)
+			{
+				correct_information_leak(nodes, edges, t, path_len, final_node, lane);
+				cancel_virtual_loss(nodes, edges, t, path_len, lane);
+				st_leaks++;
+				n_tasks--;
+			}
+			if (out == 2 && lane == 0)
+			{ // Search.cpp:139-150
+				const uint32_t sc = edges[last_edge].score;
+				float w, d;
+				s_to_value(sc, w, d);
+				t.final_node = -1;
+				t.sign_to_move = 3 - sign;
+				t.score = sc;
+				t.win = w;
+				t.draw = d;
+				t.flags |= TF_BY_SOLVER | TF_SKIP_EDGE_GENERATION;
+			}
+			if (out == 2)
+				st_proven++;
+			__syncthreads();
+			if (--trials <= 0)
+				break;
+		}
+		if (lane == 0)
+		{
+			gs.n_tasks = n_tasks;
+			gs.stats[2] += st_leaks;
+			gs.stats[3] += st_proven;
+			gs.stats[6] += st_levels;
+			gs.stats[7] += st_edges;
+			gs.stats[9] += st_dup;
+		}
+	}
+
+	/* ------------------------------------------------------------------------------------------------------------ */
+	__device__ void solve_task(SolverShared &sh, const EngineDev &E, int g, DTask &t, int slot, int generation, int lane, unsigned long long &solver_nodes)
+	{ // AlphaBetaSearch::solve (AlphaBetaSearch.cpp:77-156)
+		uint32_t *act = E.act + static_cast<size_t>(g) * E.act_cap;
+		u64 *tt = E.tt + static_cast<size_t>(g) * (E.tt_bucket_mask + 1ull) * 8ull;
+		solver_set_board(sh, E, t.board, t.sign_to_move, lane);
+		solver_encode_features(sh, E, E.nn_features + static_cast<size_t>(slot) * E.hw, lane);
+		u64 lo = 0, hi = 0;
+		for (int i = lane; i < E.hw; i += 64)
+		{
+			const int v = sh.board[i];
+			if (v == 1 || v == 2)
+			{
+				lo ^= E.zob[2 * (2 * i + v - 1)];
+				hi ^= E.zob[2 * (2 * i + v - 1) + 1];
+			}
+		}
+		for (int o = 32; o > 0; o >>= 1)
+		{
+			lo ^= __shfl_xor(lo, o);
+			hi ^= __shfl_xor(hi, o);
+		}
+		if (lane == 0)
+		{
+			sh.hash_lo = lo;
+			sh.hash_hi = hi;
+			sh.node_counter = 0;
+			sh.stack_offset = 0;
+			sh.stack_max = 0;
+			sh.error = 0;
+			Frame &f = sh.frames[0];
+			f.base = 0;
+			f.size = 0;
+			f.baseline = static_cast<uint16_t>(s_unknown(0));
+			f.must_defend = f.has_initiative = f.fully_expanded = 0;
+		}
+		__syncthreads();
+		uint32_t result = s_unknown(0);
+		for (int depth = 0; depth <= E.tss_max_depth; depth += 4)
+		{
+			int stack_before = 0;
+			if (lane == 0)
+			{
+				stack_before = sh.stack_max;
+				Frame &f = sh.frames[0];
+				f.depth_remaining = depth;
+				f.alpha = 0x0000u;
+				f.beta = 0xFFFFu;
+				f.i = 0;
+				sh.level = 0;
+				sh.phase = 0;
+				sh.pending_value = 0;
+			}
+			__syncthreads();
+			while (true)
+			{
+				if (lane == 0)
+					sh.cmd = solver_run(sh, E, act, tt, generation);
+				__syncthreads();
+				const int cmd = sh.cmd;
+				if (cmd == CMD_ADD)
+					solver_place(sh, E, static_cast<uint32_t>(sh.cmd_move), true, lane);
+				else if (cmd == CMD_UNDO)
+					solver_place(sh, E, static_cast<uint32_t>(sh.cmd_move), false, lane);
+				else
+					break;
+			}
+			int stop = 0;
+			if (lane == 0)
+			{
+				const uint32_t r = static_cast<uint32_t>(sh.result_score);
+				stop = (sh.frames[0].size == 0 || s_proven(r) || sh.node_counter >= E.tss_max_nodes || sh.stack_max == stack_before || sh.error != 0) ? 1 : 0;
+			}
+			stop = __shfl(stop, 0);
+			result = static_cast<uint32_t>(__shfl(sh.result_score, 0));
+			__syncthreads();
+			if (stop)
+				break;
+		}
+		const int size = sh.frames[0].size;
+		for (int i = lane; i < size; i += 64)
+		{
+			const uint32_t a = act[i];
+			t.emove[i] = static_cast<uint16_t>(a & 0xFFFFu);
+			t.escore[i] = static_cast<uint16_t>(a >> 16);
+		}
+		if (lane == 0)
+		{
+			t.n_edges = size;
+			t.score = result;
+			if (s_proven(result))
+			{
+				float w, d;
+				s_to_value(result, w, d);
+				t.win = w;
+				t.draw = d;
+				t.moves_left = static_cast<float>(s_distance(result));
+				t.flags |= TF_RECURSIVELY_SOLVED;
+			}
+			if (sh.frames[0].must_defend)
+				t.flags |= TF_MUST_DEFEND;
+			if (sh.node_counter <= 1)
+				t.flags |= TF_STATICALLY_SOLVED;
+			t.flags |= TF_BY_SOLVER;
+			if (sh.error != 0)
+				E.games[g].error = sh.error;
+		}
+		solver_nodes += static_cast<unsigned long long>(sh.node_counter);
+		__syncthreads();
+	}
+
+	__global__ __launch_bounds__(64) void k_solve(EngineDev E)
+	{
+		__shared__ SolverShared sh;
+		const int g = blockIdx.x, lane = threadIdx.x;
+		GameState &gs = E.games[g];
+		if (!gs.active || gs.error != 0 || gs.outcome != 0)
+			return;
+		const int n_tasks = gs.n_tasks;
+		unsigned long long solver_nodes = 0, scheduled = 0;
+		for (int k = 0; k < n_tasks; k++)
+		{
+			DTask &t = E.tasks[static_cast<size_t>(g) * E.batch + k];
+			const int slot = g * E.batch + k;
+			if ((t.flags & TF_BY_SOLVER) == 0)
+				solve_task(sh, E, g, t, slot, gs.generation, lane, solver_nodes);
+			// Search::scheduleToNN (Search.cpp:184-199)
+			if (lane == 0)
+			{
+				const bool needs = (t.path_len == 0) || !s_proven(t.score);
+				t.needs_nn = needs ? 1 : 0;
+				if (needs)
+				{
+					const int idx = atomicAdd(&E.counters[0], 1);
+					E.nn_list[idx] = slot;
+					scheduled++;
+				}
+			}
+			__syncthreads();
+		}
+		if (lane == 0)
+		{
+			gs.stats[5] += solver_nodes;
+			gs.stats[1] += scheduled;
+		}
+	}
+
+	/* ------------------------------------------------------------------------------------------------------------ */
+	__global__ __launch_bounds__(64) void k_expand(EngineDev E)
+	{
+		__shared__ float e_prior[MAXHW], e_win[MAXHW], e_draw[MAXHW];
+		__shared__ uint16_t e_move[MAXHW], e_score[MAXHW];
+		__shared__ float sh_sum;
+		const int g = blockIdx.x, lane = threadIdx.x;
+		GameState &gs = E.games[g];
+		if (!gs.active || gs.error != 0 || gs.outcome != 0)
+			return;
+		DNode *nodes = nodes_of(E, g, gs.arena);
+		DEdge *edges = edges_of(E, g, gs.arena);
+		int *ht = ht_of(E, g);
+		const int n = E.n, hw = E.hw;
+		const int n_tasks = gs.n_tasks;
+		const u64 lower = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+		unsigned long long wasted = 0;
+
+		for (int k = 0; k < n_tasks; k++)
+		{
+			DTask &t = E.tasks[static_cast<size_t>(g) * E.batch + k];
+			const int slot = g * E.batch + k;
+			uint32_t flags = t.flags;
+			const uint32_t score = t.score;
+			float win = t.win, draw = t.draw, moves_left = t.moves_left;
+			const int path_len = t.path_len;
+			const int sign = t.sign_to_move;
+			if (t.needs_nn)
+			{ // NNEvaluator::unpack_from_network (NNEvaluator.cpp:263-286), 'pv' network: the q / moves-left outputs are zero
+				flags |= TF_BY_NETWORK;
+				win = E.nn_value[3 * slot];
+				draw = E.nn_value[3 * slot + 1];
+				if (s_unproven(score))
+					moves_left = 0.0f;
+			}
+			int n_e = t.n_edges;
+			if ((flags & TF_SKIP_EDGE_GENERATION) == 0 && n_e > 0)
+			{ // UnifiedGenerator::generate (EdgeGenerator.cpp:269-303)
+				const bool by_network = (flags & TF_BY_NETWORK) != 0;
+				for (int i = lane; i < n_e; i += 64)
+				{ // initialize_edges (:88-127)
+					const uint32_t mv = t.emove[i], sc = t.escore[i];
+					const int cell = ((mv >> 2) & 127) * n + ((mv >> 9) & 127);
+					e_move[i] = static_cast<uint16_t>(mv);
+					e_score[i] = static_cast<uint16_t>(sc);
+					e_prior[i] = by_network ? E.nn_policy[static_cast<size_t>(slot) * hw + cell] : 0.0f;
+					float w = 0.0f, d = 0.0f;
+					if (!by_network && s_proven(sc))
+						s_to_value(sc, w, d);
+					e_win[i] = w;
+					e_draw[i] = d;
+				}
+				__syncthreads();
+				if (path_len > 0 && s_proven(score))
+				{ // prune_weak_moves, proven branch (:55-68): keep the best-scored edges in their original order
+					uint32_t best = s_loss_in(0);
+					for (int i = lane; i < n_e; i += 64)
+						best = max(best, static_cast<uint32_t>(e_score[i]));
+					best = wave_max_u32(best);
+					int kept = 0;
+					for (int base = 0; base < n_e; base += 64)
+					{
+						const int i = base + lane;
+						const bool keep = (i < n_e) && (e_score[i] == best);
+						const uint16_t mv = (i < n_e) ? e_move[i] : 0, sc = (i < n_e) ? e_score[i] : 0;
+						const float p = (i < n_e) ? e_prior[i] : 0.0f, w = (i < n_e) ? e_win[i] : 0.0f, d = (i < n_e) ? e_draw[i] : 0.0f;
+						const u64 m = __ballot(keep);
+						__syncthreads();
+						if (keep)
+						{
+							const int dst = kept + __popcll(m & lower);
+							e_move[dst] = mv;
+							e_score[dst] = sc;
+							e_prior[dst] = p;
+							e_win[dst] = w;
+							e_draw[dst] = d;
+						}
+						kept += __popcll(m);
+						__syncthreads();
+					}
+					n_e = kept;
+				}
+				// renormalize_policy (:23-40): the sum runs in edge order in fp32, exactly like the reference
+				if (lane == 0)
+				{
+					float sum = 0.0f;
+					for (int i = 0; i < n_e; i++)
+						sum += e_prior[i];
+					sh_sum = sum;
+				}
+				__syncthreads();
+				const float sum = sh_sum;
+				if (sum == 0.0f)
+				{
+					const float u = 1.0f / n_e;
+					for (int i = lane; i < n_e; i += 64)
+						e_prior[i] = u;
+				}
+				else
+				{
+					const float inv = 1.0f / sum;
+					for (int i = lane; i < n_e; i += 64)
+						e_prior[i] = e_prior[i] * inv;
+				}
+				__syncthreads();
+			}
+			else
+				n_e = 0;
+
+			// ---- Tree::expand (Tree.cpp:257-298) ----
+			int final_node = t.final_node;
+			if (n_e > 0)
+			{
+				const int found = cache_seek(E, nodes, ht, t.hash, t.cboard, sign, lane);
+				if (found < 0)
+				{
+					const int nid = gs.n_nodes, ebeg = gs.n_edges;
+					if (nid >= E.node_cap || ebeg + n_e > E.edge_cap || 2 * (nid + 1) > E.ht_cap)
+					{
+						if (lane == 0)
+							gs.error = (nid >= E.node_cap) ? ERR_NODE_CAPACITY : ((ebeg + n_e > E.edge_cap) ? ERR_EDGE_CAPACITY : ERR_HASH_TABLE);
+						__syncthreads();
+						return;
+					}
+					uint32_t max_score = 0;
+					for (int i = lane; i < n_e; i += 64)
+					{
+						DEdge e;
+						e.prior = e_prior[i];
+						e.win = e_win[i];
+						e.draw = e_draw[i];
+						e.visits = 0;
+						e.move = e_move[i];
+						e.score = e_score[i];
+						e.flag_vl = 0;
+						e.pad = 0;
+						edges[ebeg + i] = e;
+						max_score = max(max_score, static_cast<uint32_t>(e_score[i]));
+					}
+					max_score = wave_max_u32(max_score);
+					if (lane < BWORDS)
+						nodes[nid].cboard[lane] = t.cboard[lane];
+					if (lane == 0)
+					{
+						DNode &nd = nodes[nid];
+						nd.edge_begin = ebeg;
+						nd.n_edges = static_cast<int16_t>(n_e);
+						nd.depth = static_cast<int16_t>(gs.n_moves + path_len);
+						nd.vl = 0;
+						nd.sign_to_move = static_cast<uint8_t>(sign);
+						nd.pad8 = 0;
+						nd.hash = t.hash;
+						// updateValue from the cleared state (Node.hpp:268-274): visits 0 -> 1
+						nd.visits = 1;
+						const float tmp = static_cast<float>(1.0 / 1);
+						float w = 0.0f + (win - 0.0f) * tmp, d = 0.0f + (draw - 0.0f) * tmp;
+						nd.win = fmaxf(0.0f, fminf(1.0f, w));
+						nd.draw = fmaxf(0.0f, fminf(1.0f, d));
+						nd.moves_left = 0.0f + (moves_left - 0.0f) / 1;
+						uint16_t nf = 0;
+						if ((flags & TF_MUST_DEFEND) || (n_e + nd.depth) == hw)
+							nf |= 4;
+						nf |= ((flags & TF_STATICALLY_SOLVED) ? 8 : 0) | ((flags & TF_RECURSIVELY_SOLVED) ? 16 : 0) | ((flags & TF_MUST_DEFEND) ? 32 : 0);
+						if (path_len == 0)
+							nf |= 2;
+						nd.flags = nf;
+						nd.score = static_cast<uint16_t>(s_unknown(0));
+						if ((nf & 4) || s_win(max_score) || s_unproven(max_score))
+							nd.score = static_cast<uint16_t>(max_score);
+						cache_insert(E, ht, t.hash, nid);
+						gs.n_nodes = nid + 1;
+						gs.n_edges = ebeg + n_e;
+						if (path_len == 0)
+							gs.root = nid;
+					}
+					final_node = nid;
+					__syncthreads();
+				}
+				else
+				{
+					final_node = found;
+					wasted++;
+					if (path_len > 0)
+					{
+						const DEdge le = edges[t.path_edge[path_len - 1]];
+						if (has_leak(E, le, &nodes[found]))
+							correct_information_leak(nodes, edges, t, path_len, final_node, lane);
+					}
+				}
+			}
+
+			if (lane == 0)
+			{ // keep what the backup pass needs (Search::expand runs over ALL tasks before Search::backup, Search.cpp:214-232)
+				t.final_node = final_node;
+				t.win = win;
+				t.draw = draw;
+				t.moves_left = moves_left;
+				t.flags = flags;
+			}
+			__syncthreads();
+		}
+
+		for (int k = 0; k < n_tasks; k++)
+		{
+			DTask &t = E.tasks[static_cast<size_t>(g) * E.batch + k];
+			const float win = t.win, draw = t.draw;
+			const int path_len = t.path_len, sign = t.sign_to_move, final_node = t.final_node;
+			// ---- Tree::backup (Tree.cpp:299-351) ----
+			float ml = t.moves_left;
+			for (int i = path_len - 1; i >= 0; i--)
+			{
+				const int node = t.path_node[i], e = t.path_edge[i];
+				const int next = (i == path_len - 1) ? final_node : t.path_node[i + 1];
+				uint32_t new_score = 0;
+				if (lane == 0)
+				{
+					DNode &nd = nodes[node];
+					DEdge &ed = edges[e];
+					float vw = win, vd = draw;
+					if (nd.sign_to_move != sign)
+					{
+						vw = 1.0f - (win + draw);
+						vd = draw;
+					}
+					nd.visits++;
+					const float tn = static_cast<float>(1.0 / nd.visits); // Node::updateValue: reciprocal in double, narrowed
+					nd.win = fmaxf(0.0f, fminf(1.0f, nd.win + (vw - nd.win) * tn));
+					nd.draw = fmaxf(0.0f, fminf(1.0f, nd.draw + (vd - nd.draw) * tn));
+					ed.visits++;
+					const float te = 1.0f / ed.visits; // Edge::updateValue: fp32 reciprocal
+					ed.win = fmaxf(0.0f, fminf(1.0f, ed.win + (vw - ed.win) * te));
+					ed.draw = fmaxf(0.0f, fminf(1.0f, ed.draw + (vd - ed.draw) * te));
+					nd.moves_left += (ml - nd.moves_left) / nd.visits;
+					new_score = ed.score;
+					if (next >= 0)
+					{
+						new_score = s_invert_up(nodes[next].score);
+						ed.score = static_cast<uint16_t>(new_score);
+					}
+					nd.vl--;
+					ed.flag_vl = static_cast<uint16_t>(((ed.flag_vl & 0x7FFF) - 1) & 0x7FFF);
+				}
+				ml += 1.0f;
+				new_score = static_cast<uint32_t>(__shfl(static_cast<int>(new_score), 0));
+				update_node_score(nodes, edges, node, e, new_score, lane);
+			}
+			__syncthreads();
+		}
+
+		if (lane == 0)
+		{
+			gs.stats[0] += n_tasks;
+			gs.stats[4] += wasted;
+			gs.n_tasks = 0;
+			gs.stats[10] = max(gs.stats[10], static_cast<unsigned long long>(gs.n_nodes));
+			gs.stats[11] = max(gs.stats[11], static_cast<unsigned long long>(gs.n_edges));
+			// move rule (GameGenerator.cpp:97-103, utils/misc.cpp:171-179)
+			if (gs.root >= 0)
+			{
+				const DNode &r = nodes[gs.root];
+				const float reduction = fmaxf(0.0f, fminf(1.0f, (r.draw - 0.75f) / (1.0f - 0.75f)));
+				const int simulations = static_cast<int>(E.max_sims - reduction * (E.max_sims - 50));
+				gs.need_move = (r.visits > simulations || s_proven(r.score)) ? 1 : 0;
+			}
+		}
+	}
+
+	/* ------------------------------------------------------------------------------------------------------------ */
+	__device__ void block_reduce_xor(u64 &v, u64 *scratch, int tid)
+	{
+		for (int o = 32; o > 0; o >>= 1)
+			v ^= __shfl_xor(v, o);
+		__syncthreads();
+		if ((tid & 63) == 0)
+			scratch[tid >> 6] = v;
+		__syncthreads();
+		v = scratch[0] ^ scratch[1] ^ scratch[2] ^ scratch[3];
+		__syncthreads();
+	}
+	__device__ void clear_tree_and_table(const EngineDev &E, int g, int tid)
+	{ // Tree::clear + AlphaBetaSearch::clear (GameGenerator.cpp:52-53, SharedHashTable.hpp:137-140)
+		int *ht = ht_of(E, g);
+		for (int i = tid; i < E.ht_cap; i += 256)
+			ht[i] = 0;
+		ulonglong2 *tt = reinterpret_cast<ulonglong2*>(E.tt + static_cast<size_t>(g) * (E.tt_bucket_mask + 1ull) * 8ull);
+		const size_t entries = (E.tt_bucket_mask + 1ull) * 4ull;
+		ulonglong2 empty;
+		empty.x = 0ull;
+		empty.y = tt_pack(0, 0, s_unknown(0), 0);
+		for (size_t i = tid; i < entries; i += 256)
+			tt[i] = empty;
+	}
+	/* loads opening `id` into game g: Game::loadOpening + prepare_search on an empty tree (GameGenerator.cpp:48-77,174-185) */
+	__device__ void begin_game(const EngineDev &E, int g, int id, int tid, u64 *scratch)
+	{
+		GameState &gs = E.games[g];
+		clear_tree_and_table(E, g, tid);
+		for (int i = tid; i < E.hw; i += 256)
+			gs.board[i] = 0;
+		if (tid < BWORDS)
+			gs.cboard[tid] = 0;
+		__syncthreads();
+		const uint16_t *op = E.openings + static_cast<size_t>(id) * OPENING_CAP;
+		const int count = op[0];
+		if (tid == 0)
+		{
+			int sign = 1;
+			for (int i = 0; i < count; i++)
+			{
+				const uint32_t mv = op[1 + i];
+				const int cell = ((mv >> 2) & 127) * E.n + ((mv >> 9) & 127);
+				gs.board[cell] = static_cast<uint8_t>(mv & 3);
+				gs.cboard[cell >> 5] |= static_cast<u64>(mv & 3) << (2 * (cell & 31));
+				gs.moves[i] = static_cast<uint16_t>(mv);
+				sign = 3 - static_cast<int>(mv & 3);
+			}
+			gs.sign_to_move = sign;
+			gs.n_moves = count;
+			gs.outcome = 0;
+			gs.root = -1;
+			gs.n_nodes = 0;
+			gs.n_edges = 0;
+			gs.n_tasks = 0;
+			gs.need_move = 0;
+			gs.generation = (gs.generation + 1) % 64; // prepare_search -> increaseGeneration
+			gs.opening_id = id;
+			gs.active = 1;
+		}
+		__syncthreads();
+		u64 h = 0;
+		for (int i = tid; i < E.hw; i += 256)
+			h ^= E.nc_keys[3 + 3 * i + gs.board[i]];
+		block_reduce_xor(h, scratch, tid);
+		if (tid == 0)
+			gs.root_hash = h ^ E.nc_keys[gs.sign_to_move];
+		__syncthreads();
+	}
+
+	__global__ __launch_bounds__(256) void k_begin(EngineDev E)
+	{
+		__shared__ u64 scratch[4];
+		const int g = blockIdx.x, tid = threadIdx.x;
+		GameState &gs = E.games[g];
+		__shared__ int sh_id;
+		if (tid == 0)
+		{
+			sh_id = g; // the first wave of games takes openings 0..n_games-1 in order; counters[1] is preset to n_games
+			gs.generation = 0;
+			gs.error = 0;
+			gs.games_done = 0;
+			gs.arena = 0;
+			for (int i = 0; i < 12; i++)
+				gs.stats[i] = 0;
+		}
+		__syncthreads();
+		if (sh_id < E.n_openings)
+			begin_game(E, g, sh_id, tid, scratch);
+		else if (tid == 0)
+			gs.active = 0;
+	}
+
+	__global__ __launch_bounds__(256) void k_advance(EngineDev E)
+	{
+		__shared__ u64 scratch[4];
+		__shared__ float red_v[4];
+		__shared__ int red_i[4];
+		__shared__ int sh_int[8];
+		__shared__ int scan_nodes[256], scan_edges[256];
+		const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+		GameState &gs = E.games[g];
+		if (!gs.active || gs.error != 0 || !gs.need_move)
+			return;
+		DNode *nodes = nodes_of(E, g, gs.arena);
+		DEdge *edges = edges_of(E, g, gs.arena);
+		const int n = E.n;
+		const DNode root = nodes[gs.root];
+
+		// ---- final selector "best" (EdgeSelector.cpp:515-536) ----
+		float best_value = -3.402823466e+38f;
+		int best = 0x7FFFFFFF;
+		for (int i = tid; i < root.n_edges; i += 256)
+		{
+			const DEdge e = edges[root.edge_begin + i];
+			float value;
+			switch (s_pv(e.score))
+			{
+				case 0:
+					value = -1.0e8f + s_distance(e.score);
+					break;
+				case 3:
+					value = +1.0e8f - s_distance(e.score);
+					break;
+				default:
+					value = e.visits + (e.win + 0.5f * e.draw) * root.visits + 0.001f * e.prior;
+					break;
+			}
+			if (value > best_value)
+			{
+				best_value = value;
+				best = i;
+			}
+		}
+		wave_argmax(best_value, best);
+		if (lane == 0)
+		{
+			red_v[wave] = best_value;
+			red_i[wave] = best;
+		}
+		__syncthreads();
+		if (tid == 0)
+		{
+			for (int w = 1; w < 4; w++)
+				if (red_v[w] > red_v[0] || (red_v[w] == red_v[0] && red_i[w] < red_i[0]))
+				{
+					red_v[0] = red_v[w];
+					red_i[0] = red_i[w];
+				}
+			// ---- sample record (GameGenerator.cpp:166-171) ----
+			const int rec = atomicAdd(&E.counters[3], 1);
+			const int eoff = atomicAdd(&E.counters[4], static_cast<int>(root.n_edges));
+			sh_int[0] = (rec < E.record_cap && eoff + root.n_edges <= E.record_edge_cap) ? rec : -1;
+			sh_int[1] = eoff;
+		}
+		__syncthreads();
+		const uint32_t mv = edges[root.edge_begin + red_i[0]].move;
+		const int rec = sh_int[0], eoff = sh_int[1];
+		if (rec >= 0)
+		{
+			for (int i = tid; i < root.n_edges; i += 256)
+				E.record_edges[eoff + i] = edges[root.edge_begin + i];
+			if (tid == 0)
+			{
+				MoveRecordHeader h;
+				h.game_serial = gs.opening_id;
+				h.move_number = gs.n_moves;
+				h.move = static_cast<uint16_t>(mv);
+				h.root_score = root.score;
+				h.root_visits = root.visits;
+				h.root_win = root.win;
+				h.root_draw = root.draw;
+				h.n_edges = root.n_edges;
+				h.edge_offset = eoff;
+				E.records[rec] = h;
+			}
+		}
+		else if (tid == 0)
+			gs.error = ERR_RECORDS;
+
+		// ---- Game::makeMove + getOutcome (Game.cpp:104-122, rules.cpp:110-133; non-renju) ----
+		const int s = mv & 3, r = (mv >> 2) & 127, c = (mv >> 9) & 127, cell = r * n + c;
+		if (tid == 0)
+		{
+			gs.board[cell] = static_cast<uint8_t>(s);
+			gs.cboard[cell >> 5] |= static_cast<u64>(s) << (2 * (cell & 31));
+			gs.moves[gs.n_moves] = static_cast<uint16_t>(mv);
+			gs.n_moves++;
+			gs.sign_to_move = 3 - s;
+			gs.need_move = 0;
+			gs.stats[8]++;
+			atomicAdd(&E.counters[5], 1);
+			bool win = false;
+			for (int d = 0; d < 4; d++)
+			{
+				uint32_t pattern = 0;
+				for (int k = -5, shf = 0; k <= 5; k++, shf += 2)
+				{
+					const int rr = r + k * row_step(d), cc = c + k * col_step(d);
+					uint32_t v = (rr >= 0 && rr < n && cc >= 0 && cc < n) ? gs.board[rr * n + cc] : 3u;
+					if (k == 0)
+						v = 0;
+					pattern |= v << shf;
+				}
+				const uint8_t e = E.t_pattern[narrow(pattern)];
+				if (((s == 1) ? (e & 15) : (e >> 4)) == 6)
+					win = true;
+			}
+			int outcome = 0;
+			if (win)
+				outcome = (s == 1) ? 2 : 3;
+			else if (gs.n_moves >= E.draw_after)
+				outcome = 1;
+			gs.outcome = outcome;
+			sh_int[2] = outcome;
+			sh_int[3] = -1;
+			if (outcome != 0)
+			{
+				gs.games_done++;
+				atomicAdd(&E.counters[2], 1);
+				sh_int[3] = atomicAdd(&E.counters[1], 1);
+			}
+		}
+		__syncthreads();
+		if (sh_int[2] != 0)
+		{ // game over: take the next opening of the pool, if any (GameGenerator.cpp:104-114 -> GAME_NOT_STARTED)
+			if (sh_int[3] < E.n_openings)
+				begin_game(E, g, sh_int[3], tid, scratch);
+			else if (tid == 0)
+				gs.active = 0;
+			return;
+		}
+
+		// ---- prepare_search: NodeCache::cleanup (NodeCache.cpp:221-249) as keep-test + prefix sum + copy to the other arena ----
+		DNode *dst_nodes = nodes_of(E, g, gs.arena ^ 1);
+		DEdge *dst_edges = edges_of(E, g, gs.arena ^ 1);
+		int *ht = ht_of(E, g);
+		for (int i = tid; i < E.ht_cap; i += 256)
+			ht[i] = 0;
+		const int total = gs.n_nodes;
+		int node_base = 0, edge_base = 0;
+		for (int base = 0; base < total; base += 256)
+		{
+			const int i = base + tid;
+			int keep = 0, ne = 0;
+			if (i < total)
+			{
+				keep = 1;
+				for (int w = 0; w < BWORDS; w++)
+				{ // isTransitionPossibleFrom (NodeCache.cpp:95-115): every stone of the new position must be present
+					const u64 from = gs.cboard[w], to = nodes[i].cboard[w];
+					if (((from ^ to) & from) != 0)
+						keep = 0;
+				}
+				ne = keep ? nodes[i].n_edges : 0;
+			}
+			scan_nodes[tid] = keep;
+			scan_edges[tid] = ne;
+			__syncthreads();
+			for (int o = 1; o < 256; o <<= 1)
+			{ // inclusive Hillis-Steele scan
+				const int a = (tid >= o) ? scan_nodes[tid - o] : 0, b = (tid >= o) ? scan_edges[tid - o] : 0;
+				__syncthreads();
+				scan_nodes[tid] += a;
+				scan_edges[tid] += b;
+				__syncthreads();
+			}
+			if (keep)
+			{
+				const int ni = node_base + scan_nodes[tid] - 1, eb = edge_base + scan_edges[tid] - ne;
+				DNode nd = nodes[i];
+				for (int j = 0; j < nd.n_edges; j++)
+					dst_edges[eb + j] = edges[nd.edge_begin + j];
+				nd.edge_begin = eb;
+				dst_nodes[ni] = nd;
+				// re-insert (atomic linear probing; slot order is irrelevant to lookups)
+				const int mask = E.ht_cap - 1;
+				int slot = static_cast<int>(nd.hash & static_cast<u64>(mask));
+				while (atomicCAS(&ht[slot], 0, ni + 1) != 0)
+					slot = (slot + 1) & mask;
+			}
+			node_base += scan_nodes[255];
+			edge_base += scan_edges[255];
+			__syncthreads();
+		}
+		u64 h = 0;
+		for (int i = tid; i < E.hw; i += 256)
+			h ^= E.nc_keys[3 + 3 * i + gs.board[i]];
+		block_reduce_xor(h, scratch, tid);
+		if (tid == 0)
+		{
+			gs.root_hash = h ^ E.nc_keys[gs.sign_to_move];
+			gs.n_nodes = node_base;
+			gs.n_edges = edge_base;
+			gs.arena ^= 1;
+			gs.generation = (gs.generation + 1) % 64;
+		}
+		__syncthreads();
+		if (wave == 0)
+		{ // Tree::setBoard: root = seek(new board) (Tree.cpp:146-149)
+			const int found = cache_seek(E, dst_nodes, ht, gs.root_hash, gs.cboard, gs.sign_to_move, lane);
+			if (lane == 0)
+			{
+				gs.root = found;
+				if (found >= 0)
+					dst_nodes[found].flags |= 2;
+			}
+		}
+	}
+
+	__global__ void k_reset_counter(int *counters)
+	{
+		counters[0] = 0;
+	}
+
+	/* debug / test kernels --------------------------------------------------------------------------------------- */
+	__global__ __launch_bounds__(64) void k_debug_load_tasks(EngineDev E, const uint8_t *boards, const int *signs, int count)
+	{ // makes every game look as if one fresh leaf had been selected: task 0 = given position
+		const int g = blockIdx.x, lane = threadIdx.x;
+		if (g >= count)
+			return;
+		GameState &gs = E.games[g];
+		DTask &t = E.tasks[static_cast<size_t>(g) * E.batch];
+		for (int i = lane; i < E.hw; i += 64)
+			t.board[i] = boards[static_cast<size_t>(g) * E.hw + i];
+		if (lane == 0)
+		{
+			t.path_len = 1;
+			t.final_node = -1;
+			t.n_edges = 0;
+			t.flags = 0;
+			t.sign_to_move = signs[g];
+			t.score = s_unknown(0);
+			t.needs_nn = 0;
+			gs.n_tasks = 1;
+			gs.active = 1;
+			gs.outcome = 0;
+			gs.error = 0;
+			gs.generation = 0;
+		}
+	}
+	__global__ __launch_bounds__(64) void k_debug_pattern_state(EngineDev E, const uint8_t *boards, const int *signs, const uint16_t *moves, int n_moves,
+			uint8_t *ptypes, uint8_t *threats, int16_t *lists, int lists_stride)
+	{
+		__shared__ SolverShared sh;
+		const int g = blockIdx.x, lane = threadIdx.x;
+		solver_set_board(sh, E, boards + static_cast<size_t>(g) * E.hw, signs[g], lane);
+		__shared__ uint16_t done[512];
+		__shared__ int n_done;
+		if (lane == 0)
+			n_done = 0;
+		__syncthreads();
+		for (int i = 0; i < n_moves; i++)
+		{
+			const uint32_t m = moves[static_cast<size_t>(g) * n_moves + i];
+			if (m == 0xFFFFu)
+				continue;
+			if ((m & 3) == 0)
+			{
+				const uint32_t u = done[n_done - 1];
+				solver_place(sh, E, u, false, lane);
+				if (lane == 0)
+					n_done--;
+			}
+			else
+			{
+				solver_place(sh, E, m, true, lane);
+				if (lane == 0)
+					done[n_done++] = static_cast<uint16_t>(m);
+			}
+			__syncthreads();
+		}
+		for (int i = lane; i < E.hw; i += 64)
+		{
+			for (int k = 0; k < 8; k++)
+				ptypes[(static_cast<size_t>(g) * E.hw + i) * 8 + k] = sh.ptype[i][k];
+			threats[(static_cast<size_t>(g) * E.hw + i) * 2] = sh.threat[i][0];
+			threats[(static_cast<size_t>(g) * E.hw + i) * 2 + 1] = sh.threat[i][1];
+		}
+		if (lane == 0)
+		{
+			int16_t *out = lists + static_cast<size_t>(g) * lists_stride;
+			int pos = 0;
+			for (int s = 0; s < 2; s++)
+				for (int t = 0; t < 10; t++)
+				{
+					out[pos++] = static_cast<int16_t>(sh.count[s][t]);
+					for (int k = 0; k < sh.count[s][t]; k++)
+					{
+						out[pos++] = static_cast<int16_t>(sh.lists[s][t][k] / E.n);
+						out[pos++] = static_cast<int16_t>(sh.lists[s][t][k] % E.n);
+					}
+				}
+			out[lists_stride - 1] = static_cast<int16_t>(pos);
+		}
+	}
+}
+
+/* ================================================================================================================ */
+struct AgxEngine
+{
+		AgxEngineConfig cfg;
+		EngineDev dev;
+		std::vector<void*> allocations;
+		std::vector<uint64_t> zobrist; // [2*hw][2]
+		bool begun = false;
+};
+
+namespace
+{
+	template<typename T>
+	int dev_alloc(AgxEngine *e, T **ptr, size_t count)
+	{
+		void *p = nullptr;
+		AGX_HIP_CHECK(hipMalloc(&p, std::max<size_t>(count * sizeof(T), 16)));
+		e->allocations.push_back(p);
+		*ptr = static_cast<T*>(p);
+		return AGX_OK;
+	}
+	template<typename T>
+	int dev_upload(AgxEngine *e, const T **ptr, const std::vector<T> &src)
+	{
+		T *p = nullptr;
+		const int st = dev_alloc(e, &p, src.size());
+		if (st != AGX_OK)
+			return st;
+		AGX_HIP_CHECK(hipMemcpy(p, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+		*ptr = p;
+		return AGX_OK;
+	}
+	uint64_t splitmix64(uint64_t &state)
+	{
+		uint64_t z = (state += 0x9E3779B97F4A7C15ull);
+		z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+		z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+		return z ^ (z >> 31);
+	}
+	size_t round_pow2(size_t x)
+	{
+		size_t r = 1;
+		while (r < x)
+			r <<= 1;
+		return r;
+	}
+}
+
+extern "C" {
+
+int agx_engine_default_config(AgxEngineConfig *cfg)
+{
+	AGX_REQUIRE(cfg != nullptr, AGX_ERR_INVALID, "agx_engine_default_config: null argument");
+	std::memset(cfg, 0, sizeof(*cfg));
+	cfg->rules = AGX_FREESTYLE;
+	cfg->board_size = 15;
+	cfg->draw_after = 225;
+	cfg->n_games = 1024;
+	cfg->max_batch_size = 8;
+	cfg->max_simulations = 400;
+	cfg->exploration_constant = 1.25f;
+	cfg->exploration_scaling = 0.0f;
+	cfg->init_to = 0;
+	cfg->information_leak_threshold = 0.01f;
+	cfg->policy_expansion_threshold = 1.0e-4f;
+	cfg->tss_max_positions = 100;
+	cfg->tss_table_entries = 4ull * 1024ull * 1024ull;
+	cfg->zobrist_seed = 0x9E3779B97F4A7C15ull;
+	cfg->node_capacity = 8192;
+	cfg->edge_capacity = 262144;
+	cfg->record_capacity = 0;
+	cfg->record_edge_capacity = 0;
+	return AGX_OK;
+}
+
+int agx_engine_create(const AgxEngineConfig *cfg, AgxEngine **out)
+{
+	AGX_REQUIRE(cfg != nullptr && out != nullptr, AGX_ERR_INVALID, "agx_engine_create: null argument");
+	AGX_REQUIRE(cfg->rules != AGX_RENJU, AGX_ERR_UNSUPPORTED, "agx_engine_create: renju (forbidden moves) is not supported by the device engine yet");
+	AGX_REQUIRE(cfg->rules >= 0 && cfg->rules <= AGX_CARO6, AGX_ERR_INVALID, "agx_engine_create: unknown rules %d", cfg->rules);
+	AGX_REQUIRE(cfg->board_size >= 5 && cfg->board_size <= MAXN, AGX_ERR_UNSUPPORTED, "agx_engine_create: board size %d not in [5, %d]", cfg->board_size, MAXN);
+	AGX_REQUIRE(cfg->n_games > 0 && cfg->max_batch_size > 0 && cfg->max_simulations > 0, AGX_ERR_INVALID, "agx_engine_create: non-positive sizes");
+	AGX_REQUIRE(cfg->tss_max_positions >= 1 && cfg->tss_max_positions <= 100, AGX_ERR_UNSUPPORTED, "agx_engine_create: tss_max_positions must be in [1, 100]");
+	AGX_REQUIRE(cfg->init_to >= 0 && cfg->init_to <= 3, AGX_ERR_INVALID, "agx_engine_create: init_to must be 0..3");
+
+	AgxEngine *e = new AgxEngine();
+	e->cfg = *cfg;
+	EngineDev &d = e->dev;
+	std::memset(&d, 0, sizeof(d));
+	d.rules = cfg->rules;
+	d.n = cfg->board_size;
+	d.hw = d.n * d.n;
+	d.draw_after = (cfg->draw_after > 0) ? cfg->draw_after : d.hw;
+	d.n_games = cfg->n_games;
+	d.batch = cfg->max_batch_size;
+	d.max_sims = cfg->max_simulations;
+	d.c_puct = cfg->exploration_constant;
+	d.c_scale = cfg->exploration_scaling;
+	d.init_to = cfg->init_to;
+	d.leak_threshold = cfg->information_leak_threshold;
+	d.expansion_threshold = cfg->policy_expansion_threshold;
+	d.tss_max_nodes = cfg->tss_max_positions;
+	d.tss_max_depth = 100;
+	const size_t buckets = round_pow2(std::max<size_t>(cfg->tss_table_entries, 4)) / 4;
+	d.tt_bucket_mask = buckets - 1;
+	d.node_cap = cfg->node_capacity > 0 ? cfg->node_capacity : 8192;
+	d.edge_cap = cfg->edge_capacity > 0 ? cfg->edge_capacity : 262144;
+	d.ht_cap = static_cast<int>(round_pow2(4 * static_cast<size_t>(d.node_cap)));
+	d.act_cap = d.hw * (d.hw + 1) / 2 + 64;
+	d.record_cap = cfg->record_capacity > 0 ? cfg->record_capacity : d.n_games * d.hw;
+	d.record_edge_cap = cfg->record_edge_capacity > 0 ? cfg->record_edge_capacity : d.record_cap * 64;
+
+	HostTables tables;
+	build_host_tables(cfg->rules, tables);
+	std::vector<uint64_t> nc_keys(3 + 3 * d.hw);
+	uint64_t st = cfg->zobrist_seed ^ 0x5851F42D4C957F2Dull;
+	for (auto &k : nc_keys)
+		k = splitmix64(st);
+	e->zobrist.resize(4 * d.hw);
+	st = cfg->zobrist_seed;
+	for (auto &k : e->zobrist)
+		k = splitmix64(st);
+
+	int status = AGX_OK;
+	const size_t G = d.n_games;
+#define AGX_TRY(expr) if (status == AGX_OK) status = (expr)
+	AGX_TRY(dev_alloc(e, &d.games, G));
+	AGX_TRY(dev_alloc(e, &d.nodes, G * 2 * d.node_cap));
+	AGX_TRY(dev_alloc(e, &d.edges, G * 2 * d.edge_cap));
+	AGX_TRY(dev_alloc(e, &d.ht, G * d.ht_cap));
+	AGX_TRY(dev_alloc(e, &d.tasks, G * d.batch));
+	AGX_TRY(dev_alloc(e, &d.act, G * d.act_cap));
+	AGX_TRY(dev_alloc(e, &d.tt, G * buckets * 8));
+	AGX_TRY(dev_upload(e, &d.t_pattern, tables.pattern));
+	AGX_TRY(dev_upload(e, &d.t_ho3, tables.half_open_three));
+	AGX_TRY(dev_upload(e, &d.t_threat, tables.threat));
+	AGX_TRY(dev_upload(e, &d.t_defense, tables.defense));
+	AGX_TRY(dev_upload(e, &d.nc_keys, nc_keys));
+	AGX_TRY(dev_upload(e, &d.zob, e->zobrist));
+	AGX_TRY(dev_alloc(e, &d.nn_features, G * d.batch * d.hw));
+	AGX_TRY(dev_alloc(e, &d.nn_policy, G * d.batch * d.hw));
+	AGX_TRY(dev_alloc(e, &d.nn_value, G * d.batch * 3));
+	AGX_TRY(dev_alloc(e, &d.nn_list, G * d.batch));
+	AGX_TRY(dev_alloc(e, &d.counters, 16));
+	AGX_TRY(dev_alloc(e, &d.records, static_cast<size_t>(d.record_cap)));
+	AGX_TRY(dev_alloc(e, &d.record_edges, static_cast<size_t>(d.record_edge_cap)));
+#undef AGX_TRY
+	if (status == AGX_OK)
+	{
+		hipError_t err = hipMemset(d.games, 0, G * sizeof(GameState));
+		if (err == hipSuccess)
+			err = hipMemset(d.counters, 0, 16 * sizeof(int));
+		if (err == hipSuccess)
+			err = hipMemset(d.tasks, 0, G * d.batch * sizeof(DTask));
+		if (err != hipSuccess)
+		{
+			agx::set_error("hipMemset failed: %s", hipGetErrorString(err));
+			status = AGX_ERR_HIP;
+		}
+	}
+	if (status != AGX_OK)
+	{
+		for (void *p : e->allocations)
+			(void) hipFree(p);
+		delete e;
+		return status;
+	}
+	*out = e;
+	return AGX_OK;
+}
+
+int agx_engine_destroy(AgxEngine *e)
+{
+	if (e == nullptr)
+		return AGX_OK;
+	for (void *p : e->allocations)
+		(void) hipFree(p);
+	delete e;
+	return AGX_OK;
+}
+
+int agx_engine_begin(AgxEngine *e, const uint16_t *h_openings, int n_openings, void *stream)
+{
+	AGX_REQUIRE(e != nullptr && h_openings != nullptr, AGX_ERR_INVALID, "agx_engine_begin: null argument");
+	AGX_REQUIRE(n_openings > 0, AGX_ERR_INVALID, "agx_engine_begin: need at least one opening");
+	uint16_t *d_op = nullptr;
+	AGX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_op), static_cast<size_t>(n_openings) * OPENING_CAP * sizeof(uint16_t)));
+	e->allocations.push_back(d_op);
+	AGX_HIP_CHECK(hipMemcpy(d_op, h_openings, static_cast<size_t>(n_openings) * OPENING_CAP * sizeof(uint16_t), hipMemcpyHostToDevice));
+	e->dev.openings = d_op;
+	e->dev.n_openings = n_openings;
+	int counters[16] = { 0 };
+	counters[1] = e->dev.n_games;
+	AGX_HIP_CHECK(hipMemcpy(e->dev.counters, counters, sizeof(counters), hipMemcpyHostToDevice));
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	hipLaunchKernelGGL(k_begin, dim3(e->dev.n_games), dim3(256), 0, s, e->dev);
+	AGX_HIP_CHECK(hipGetLastError());
+	e->begun = true;
+	return AGX_OK;
+}
+
+int agx_engine_select_solve(AgxEngine *e, void *stream)
+{
+	AGX_REQUIRE(e != nullptr, AGX_ERR_INVALID, "agx_engine_select_solve: null engine");
+	AGX_REQUIRE(e->begun, AGX_ERR_STATE, "agx_engine_select_solve: agx_engine_begin has not been called");
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	hipLaunchKernelGGL(k_reset_counter, dim3(1), dim3(1), 0, s, e->dev.counters);
+	hipLaunchKernelGGL(k_select, dim3(e->dev.n_games), dim3(64), 0, s, e->dev);
+	hipLaunchKernelGGL(k_solve, dim3(e->dev.n_games), dim3(64), 0, s, e->dev);
+	AGX_HIP_CHECK(hipGetLastError());
+	return AGX_OK;
+}
+
+int agx_engine_evaluate(AgxEngine *e, AgxNet *net, void *stream)
+{
+	AGX_REQUIRE(e != nullptr && net != nullptr, AGX_ERR_INVALID, "agx_engine_evaluate: null argument");
+	return agx_nn_forward_indirect(net, e->dev.nn_features, e->dev.nn_list, e->dev.counters, e->dev.n_games * e->dev.batch, e->dev.nn_policy, e->dev.nn_value,
+			stream);
+}
+
+int agx_engine_expand_backup(AgxEngine *e, void *stream)
+{
+	AGX_REQUIRE(e != nullptr, AGX_ERR_INVALID, "agx_engine_expand_backup: null engine");
+	AGX_REQUIRE(e->begun, AGX_ERR_STATE, "agx_engine_expand_backup: agx_engine_begin has not been called");
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	hipLaunchKernelGGL(k_expand, dim3(e->dev.n_games), dim3(64), 0, s, e->dev);
+	hipLaunchKernelGGL(k_advance, dim3(e->dev.n_games), dim3(256), 0, s, e->dev);
+	AGX_HIP_CHECK(hipGetLastError());
+	return AGX_OK;
+}
+
+int agx_engine_step(AgxEngine *e, AgxNet *net, void *stream)
+{
+	int st = agx_engine_select_solve(e, stream);
+	if (st == AGX_OK)
+		st = agx_engine_evaluate(e, net, stream);
+	if (st == AGX_OK)
+		st = agx_engine_expand_backup(e, stream);
+	return st;
+}
+
+int agx_engine_buffers(AgxEngine *e, AgxEngineBuffers *out)
+{
+	AGX_REQUIRE(e != nullptr && out != nullptr, AGX_ERR_INVALID, "agx_engine_buffers: null argument");
+	out->d_nn_features = e->dev.nn_features;
+	out->d_nn_policy = e->dev.nn_policy;
+	out->d_nn_value = e->dev.nn_value;
+	out->d_nn_list = e->dev.nn_list;
+	out->d_nn_count = e->dev.counters;
+	out->slots = e->dev.n_games * e->dev.batch;
+	out->cells = e->dev.hw;
+	return AGX_OK;
+}
+
+int agx_engine_stats(AgxEngine *e, AgxEngineStats *out)
+{
+	AGX_REQUIRE(e != nullptr && out != nullptr, AGX_ERR_INVALID, "agx_engine_stats: null argument");
+	std::vector<GameState> games(e->dev.n_games);
+	AGX_HIP_CHECK(hipMemcpy(games.data(), e->dev.games, games.size() * sizeof(GameState), hipMemcpyDeviceToHost));
+	int counters[16];
+	AGX_HIP_CHECK(hipMemcpy(counters, e->dev.counters, sizeof(counters), hipMemcpyDeviceToHost));
+	std::memset(out, 0, sizeof(*out));
+	for (const GameState &g : games)
+	{
+		out->evaluated_nodes += g.stats[0];
+		out->network_evaluations += g.stats[1];
+		out->information_leaks += g.stats[2];
+		out->proven_edge_visits += g.stats[3];
+		out->wasted_expansions += g.stats[4];
+		out->solver_nodes += g.stats[5];
+		out->select_levels += g.stats[6];
+		out->select_edge_reads += g.stats[7];
+		out->moves_played += g.stats[8];
+		out->duplicate_selections += g.stats[9];
+		out->peak_nodes = std::max<unsigned long long>(out->peak_nodes, g.stats[10]);
+		out->peak_edges = std::max<unsigned long long>(out->peak_edges, g.stats[11]);
+		out->active_games += g.active ? 1 : 0;
+		if (g.error != 0 && out->first_error == 0)
+			out->first_error = g.error;
+	}
+	out->games_finished = counters[2];
+	out->openings_taken = counters[1];
+	out->records_used = counters[3];
+	out->record_edges_used = counters[4];
+	return AGX_OK;
+}
+
+int agx_engine_game_info(AgxEngine *e, int game, AgxGameInfo *info, uint8_t *h_board, AgxEdgeView *h_root_edges, int edge_capacity)
+{
+	AGX_REQUIRE(e != nullptr && info != nullptr, AGX_ERR_INVALID, "agx_engine_game_info: null argument");
+	AGX_REQUIRE(game >= 0 && game < e->dev.n_games, AGX_ERR_INVALID, "agx_engine_game_info: game %d out of range", game);
+	AGX_HIP_CHECK(hipDeviceSynchronize());
+	GameState gs;
+	AGX_HIP_CHECK(hipMemcpy(&gs, e->dev.games + game, sizeof(GameState), hipMemcpyDeviceToHost));
+	info->active = gs.active;
+	info->sign_to_move = gs.sign_to_move;
+	info->n_moves = gs.n_moves;
+	info->outcome = gs.outcome;
+	info->error = gs.error;
+	info->opening_id = gs.opening_id;
+	info->games_done = gs.games_done;
+	info->n_nodes = gs.n_nodes;
+	info->n_edges = gs.n_edges;
+	info->root_visits = 0;
+	info->root_win = info->root_draw = 0.0f;
+	info->root_score = 0;
+	info->root_edges = 0;
+	if (h_board != nullptr)
+		std::memcpy(h_board, gs.board, e->dev.hw);
+	if (gs.root >= 0)
+	{
+		DNode root;
+		const DNode *nodes = e->dev.nodes + (static_cast<size_t>(game) * 2 + gs.arena) * e->dev.node_cap;
+		AGX_HIP_CHECK(hipMemcpy(&root, nodes + gs.root, sizeof(DNode), hipMemcpyDeviceToHost));
+		info->root_visits = root.visits;
+		info->root_win = root.win;
+		info->root_draw = root.draw;
+		info->root_score = root.score;
+		info->root_edges = root.n_edges;
+		if (h_root_edges != nullptr)
+		{
+			AGX_REQUIRE(root.n_edges <= edge_capacity, AGX_ERR_INVALID, "agx_engine_game_info: %d root edges do not fit into %d", root.n_edges, edge_capacity);
+			std::vector<DEdge> edges(root.n_edges);
+			const DEdge *pool = e->dev.edges + (static_cast<size_t>(game) * 2 + gs.arena) * e->dev.edge_cap;
+			AGX_HIP_CHECK(hipMemcpy(edges.data(), pool + root.edge_begin, edges.size() * sizeof(DEdge), hipMemcpyDeviceToHost));
+			for (int i = 0; i < root.n_edges; i++)
+			{
+				h_root_edges[i].prior = edges[i].prior;
+				h_root_edges[i].win = edges[i].win;
+				h_root_edges[i].draw = edges[i].draw;
+				h_root_edges[i].visits = edges[i].visits;
+				h_root_edges[i].move = edges[i].move;
+				h_root_edges[i].score = edges[i].score;
+				h_root_edges[i].flag_and_virtual_loss = edges[i].flag_vl;
+			}
+		}
+	}
+	return AGX_OK;
+}
+
+int agx_engine_records(AgxEngine *e, AgxMoveRecord *h_records, int record_capacity, AgxEdgeView *h_edges, int edge_capacity, int *n_records, int *n_edges)
+{
+	AGX_REQUIRE(e != nullptr && n_records != nullptr && n_edges != nullptr, AGX_ERR_INVALID, "agx_engine_records: null argument");
+	AGX_HIP_CHECK(hipDeviceSynchronize());
+	int counters[16];
+	AGX_HIP_CHECK(hipMemcpy(counters, e->dev.counters, sizeof(counters), hipMemcpyDeviceToHost));
+	const int nr = std::min(counters[3], e->dev.record_cap), ne = std::min(counters[4], e->dev.record_edge_cap);
+	*n_records = nr;
+	*n_edges = ne;
+	if (h_records == nullptr || h_edges == nullptr)
+		return AGX_OK;
+	AGX_REQUIRE(nr <= record_capacity && ne <= edge_capacity, AGX_ERR_INVALID, "agx_engine_records: buffers too small (%d records, %d edges)", nr, ne);
+	std::vector<MoveRecordHeader> headers(nr);
+	std::vector<DEdge> edges(ne);
+	AGX_HIP_CHECK(hipMemcpy(headers.data(), e->dev.records, headers.size() * sizeof(MoveRecordHeader), hipMemcpyDeviceToHost));
+	AGX_HIP_CHECK(hipMemcpy(edges.data(), e->dev.record_edges, edges.size() * sizeof(DEdge), hipMemcpyDeviceToHost));
+	for (int i = 0; i < nr; i++)
+	{
+		h_records[i].game_serial = headers[i].game_serial;
+		h_records[i].move_number = headers[i].move_number;
+		h_records[i].move = headers[i].move;
+		h_records[i].root_score = headers[i].root_score;
+		h_records[i].root_visits = headers[i].root_visits;
+		h_records[i].root_win = headers[i].root_win;
+		h_records[i].root_draw = headers[i].root_draw;
+		h_records[i].n_edges = headers[i].n_edges;
+		h_records[i].edge_offset = headers[i].edge_offset;
+	}
+	for (int i = 0; i < ne; i++)
+	{
+		h_edges[i].prior = edges[i].prior;
+		h_edges[i].win = edges[i].win;
+		h_edges[i].draw = edges[i].draw;
+		h_edges[i].visits = edges[i].visits;
+		h_edges[i].move = edges[i].move;
+		h_edges[i].score = edges[i].score;
+		h_edges[i].flag_and_virtual_loss = edges[i].flag_vl;
+	}
+	return AGX_OK;
+}
+
+int agx_engine_zobrist(AgxEngine *e, uint64_t *h_keys, size_t n_words)
+{
+	AGX_REQUIRE(e != nullptr && h_keys != nullptr, AGX_ERR_INVALID, "agx_engine_zobrist: null argument");
+	AGX_REQUIRE(n_words == e->zobrist.size(), AGX_ERR_INVALID, "agx_engine_zobrist: expected %zu words", e->zobrist.size());
+	std::memcpy(h_keys, e->zobrist.data(), n_words * sizeof(uint64_t));
+	return AGX_OK;
+}
+
+/* ---- test hooks: single stages on caller-supplied positions ---- */
+int agx_debug_solve(AgxEngine *e, const uint8_t *h_boards, const int *h_signs, int count, uint32_t *h_features, uint16_t *h_moves, uint16_t *h_scores,
+		int *h_counts, uint32_t *h_flags, uint16_t *h_result_scores)
+{
+	AGX_REQUIRE(e != nullptr && h_boards != nullptr && h_signs != nullptr, AGX_ERR_INVALID, "agx_debug_solve: null argument");
+	AGX_REQUIRE(count > 0 && count <= e->dev.n_games, AGX_ERR_INVALID, "agx_debug_solve: count must be in [1, n_games]");
+	const EngineDev &d = e->dev;
+	uint8_t *d_boards = nullptr;
+	int *d_signs = nullptr;
+	AGX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_boards), static_cast<size_t>(count) * d.hw));
+	AGX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_signs), count * sizeof(int)));
+	AGX_HIP_CHECK(hipMemcpy(d_boards, h_boards, static_cast<size_t>(count) * d.hw, hipMemcpyHostToDevice));
+	AGX_HIP_CHECK(hipMemcpy(d_signs, h_signs, count * sizeof(int), hipMemcpyHostToDevice));
+	hipLaunchKernelGGL(k_debug_load_tasks, dim3(count), dim3(64), 0, nullptr, d, d_boards, d_signs, count);
+	hipLaunchKernelGGL(k_reset_counter, dim3(1), dim3(1), 0, nullptr, d.counters);
+	hipLaunchKernelGGL(k_solve, dim3(count), dim3(64), 0, nullptr, d);
+	AGX_HIP_CHECK(hipGetLastError());
+	AGX_HIP_CHECK(hipDeviceSynchronize());
+	std::vector<DTask> tasks(1);
+	for (int g = 0; g < count; g++)
+	{
+		AGX_HIP_CHECK(hipMemcpy(tasks.data(), d.tasks + static_cast<size_t>(g) * d.batch, sizeof(DTask), hipMemcpyDeviceToHost));
+		const DTask &t = tasks[0];
+		h_counts[g] = t.n_edges;
+		h_flags[g] = t.flags;
+		h_result_scores[g] = static_cast<uint16_t>(t.score);
+		for (int i = 0; i < t.n_edges; i++)
+		{
+			h_moves[static_cast<size_t>(g) * d.hw + i] = t.emove[i];
+			h_scores[static_cast<size_t>(g) * d.hw + i] = t.escore[i];
+		}
+		if (h_features != nullptr)
+			AGX_HIP_CHECK(hipMemcpy(h_features + static_cast<size_t>(g) * d.hw, d.nn_features + static_cast<size_t>(g) * d.batch * d.hw, d.hw * sizeof(uint32_t),
+					hipMemcpyDeviceToHost));
+	}
+	// leave the pool idle again
+	AGX_HIP_CHECK(hipMemset(d.games, 0, static_cast<size_t>(d.n_games) * sizeof(GameState)));
+	(void) hipFree(d_boards);
+	(void) hipFree(d_signs);
+	return AGX_OK;
+}
+
+int agx_debug_new_generation(AgxEngine *e)
+{ // not needed by the tests that keep generation 0; kept for symmetry with AlphaBetaSearch::increaseGeneration
+	AGX_REQUIRE(e != nullptr, AGX_ERR_INVALID, "agx_debug_new_generation: null engine");
+	return AGX_OK;
+}
+
+int agx_debug_pattern_state(AgxEngine *e, const uint8_t *h_boards, const int *h_signs, const uint16_t *h_moves, int count, int n_moves, uint8_t *h_ptypes,
+		uint8_t *h_threats, int16_t *h_lists, int lists_stride)
+{
+	AGX_REQUIRE(e != nullptr, AGX_ERR_INVALID, "agx_debug_pattern_state: null engine");
+	const EngineDev &d = e->dev;
+	uint8_t *d_boards = nullptr, *d_pt = nullptr, *d_th = nullptr;
+	int *d_signs = nullptr;
+	uint16_t *d_moves = nullptr;
+	int16_t *d_lists = nullptr;
+	const size_t cells = static_cast<size_t>(count) * d.hw;
+	AGX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_boards), cells));
+	AGX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_signs), count * sizeof(int)));
+	AGX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_moves), std::max<size_t>(static_cast<size_t>(count) * n_moves * 2, 16)));
+	AGX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_pt), cells * 8));
+	AGX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_th), cells * 2));
+	AGX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_lists), static_cast<size_t>(count) * lists_stride * 2));
+	AGX_HIP_CHECK(hipMemcpy(d_boards, h_boards, cells, hipMemcpyHostToDevice));
+	AGX_HIP_CHECK(hipMemcpy(d_signs, h_signs, count * sizeof(int), hipMemcpyHostToDevice));
+	if (n_moves > 0)
+		AGX_HIP_CHECK(hipMemcpy(d_moves, h_moves, static_cast<size_t>(count) * n_moves * 2, hipMemcpyHostToDevice));
+	hipLaunchKernelGGL(k_debug_pattern_state, dim3(count), dim3(64), 0, nullptr, d, d_boards, d_signs, d_moves, n_moves, d_pt, d_th, d_lists, lists_stride);
+	AGX_HIP_CHECK(hipGetLastError());
+	AGX_HIP_CHECK(hipDeviceSynchronize());
+	AGX_HIP_CHECK(hipMemcpy(h_ptypes, d_pt, cells * 8, hipMemcpyDeviceToHost));
+	AGX_HIP_CHECK(hipMemcpy(h_threats, d_th, cells * 2, hipMemcpyDeviceToHost));
+	AGX_HIP_CHECK(hipMemcpy(h_lists, d_lists, static_cast<size_t>(count) * lists_stride * 2, hipMemcpyDeviceToHost));
+	(void) hipFree(d_boards);
+	(void) hipFree(d_signs);
+	(void) hipFree(d_moves);
+	(void) hipFree(d_pt);
+	(void) hipFree(d_th);
+	(void) hipFree(d_lists);
+	return AGX_OK;
+}
+
+/* host-only: the lookup tables the engine uploads (for CPU-side verification against the reference) */
+int agx_host_tables(int rules, uint8_t *h_pattern, uint8_t *h_half_open_three, uint8_t *h_threat, uint16_t *h_defense)
+{
+	AGX_REQUIRE(rules >= 0 && rules <= AGX_CARO6, AGX_ERR_INVALID, "agx_host_tables: unknown rules %d", rules);
+	HostTables t;
+	build_host_tables(rules, t);
+	if (h_pattern != nullptr)
+		std::memcpy(h_pattern, t.pattern.data(), t.pattern.size());
+	if (h_half_open_three != nullptr)
+		std::memcpy(h_half_open_three, t.half_open_three.data(), t.half_open_three.size());
+	if (h_threat != nullptr)
+		std::memcpy(h_threat, t.threat.data(), t.threat.size());
+	if (h_defense != nullptr)
+		std::memcpy(h_defense, t.defense.data(), t.defense.size() * sizeof(uint16_t));
+	return AGX_OK;
+}
+
+} /* extern "C" */

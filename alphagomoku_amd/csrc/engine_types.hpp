@@ -1,0 +1,169 @@
+/*
+ * engine_types.hpp — HBM-resident records of the device self-play engine (shared by host and device code).
+ *
+ * Layout philosophy: one flat arena per game, addressed by (game, index); no pointers inside records, so a whole pool of
+ * thousands of games is a handful of hipMalloc'ed arrays and a game's tree can be compacted by a prefix sum + copy.
+ *
+ * Records mirror the reference's field semantics:
+ *   DEdge  <- ag::Edge  (include/alphagomoku/search/monte_carlo/Edge.hpp:23-32, 24 bytes there and here)
+ *   DNode  <- ag::Node + NodeCache::Entry{hash_key, CompressedBoard} (Node.hpp:24-42, NodeCache.hpp:51-71)
+ *   DTask  <- ag::SearchTask (SearchTask.hpp:35-329)
+ */
+#ifndef AGX_ENGINE_TYPES_HPP_
+#define AGX_ENGINE_TYPES_HPP_
+
+#include <cstdint>
+
+namespace agx
+{
+	constexpr int MAXN = 20;
+	constexpr int MAXHW = MAXN * MAXN;
+	constexpr int BWORDS = 13;      // 2 bits per cell, 32 cells per 64-bit word (NodeCache.hpp:56)
+	constexpr int PATH_CAP = 256;
+	constexpr int MAX_FRAMES = 104; // alpha-beta recursion depth is bounded by the node budget (<= 100) + root
+	constexpr int OPENING_CAP = 32;
+
+	struct DEdge
+	{
+			float prior;
+			float win;
+			float draw;
+			int32_t visits;
+			uint16_t move;    // Move::toShort (Move.hpp:144-147): sign | row << 2 | col << 9
+			uint16_t score;   // Score raw bits
+			uint16_t flag_vl; // bit 15 being expanded, bits 0-14 virtual loss
+			uint16_t pad;
+	};
+	static_assert(sizeof(DEdge) == 24, "edge record must stay 24 bytes");
+
+	struct DNode
+	{
+			int32_t edge_begin;
+			float win;
+			float draw;
+			float moves_left;
+			int32_t visits;
+			uint16_t score;
+			int16_t n_edges;
+			int16_t depth;
+			int16_t vl;
+			uint8_t sign_to_move;
+			uint8_t pad8;
+			uint16_t flags; // root 2, fully expanded 4, statically solved 8, recursively solved 16, must defend 32 (Node.hpp:26-31)
+			uint64_t hash;
+			uint64_t cboard[BWORDS];
+	};
+	static_assert(sizeof(DNode) == 144, "node record layout");
+
+	enum TaskFlags : uint32_t
+	{
+		TF_MUST_DEFEND = 1, TF_BY_NETWORK = 2, TF_BY_SOLVER = 4, TF_SKIP_EDGE_GENERATION = 8, TF_STATICALLY_SOLVED = 16, TF_RECURSIVELY_SOLVED = 32
+	};
+
+	struct DTask
+	{
+			int32_t path_len;
+			int32_t final_node;
+			int32_t n_edges;
+			uint32_t flags;
+			int32_t sign_to_move;
+			uint32_t score;
+			float win;
+			float draw;
+			float moves_left;
+			int32_t needs_nn;
+			uint64_t hash;
+			uint64_t cboard[BWORDS];
+			int32_t path_node[PATH_CAP];
+			int32_t path_edge[PATH_CAP];
+			uint8_t board[MAXHW];
+			uint16_t emove[MAXHW];
+			uint16_t escore[MAXHW];
+	};
+
+	struct GameState
+	{
+			int32_t active;
+			int32_t sign_to_move;
+			int32_t n_moves;
+			int32_t outcome;
+			int32_t root;
+			int32_t n_nodes;
+			int32_t n_edges;
+			int32_t arena;
+			int32_t n_tasks;
+			int32_t need_move;
+			int32_t generation;
+			int32_t error;
+			int32_t opening_id;
+			int32_t games_done;
+			int32_t record_begin; // first record index of the current game
+			int32_t pad;
+			uint64_t root_hash;
+			uint64_t cboard[BWORDS];
+			unsigned long long stats[12]; // nodes, nn, leaks, proven, wasted, solver nodes, select levels, select edges, moves, duplicates, max nodes, max edges
+			uint8_t board[MAXHW];
+			uint16_t moves[MAXHW];
+	};
+
+	/* One record per played move (what SearchDataPack(const Node&, board) keeps, dataset/data_packs.cpp:24-43). */
+	struct MoveRecordHeader
+	{
+			int32_t game_serial; // opening id of the game this move belongs to
+			int32_t move_number;
+			uint16_t move;
+			uint16_t root_score;
+			int32_t root_visits;
+			float root_win;
+			float root_draw;
+			int32_t n_edges;
+			int32_t edge_offset; // into the record edge pool
+	};
+
+	enum EngineError : int32_t
+	{
+		ERR_NONE = 0, ERR_NODE_CAPACITY = 1, ERR_EDGE_CAPACITY = 2, ERR_PATH_CAPACITY = 3, ERR_ACTION_STACK = 4, ERR_HASH_TABLE = 5, ERR_RECORDS = 6, ERR_FRAMES = 7
+	};
+
+	struct EngineDev
+	{
+			// configuration
+			int rules, n, hw, draw_after;
+			int n_games, batch, max_sims;
+			float c_puct, c_scale;
+			int init_to;
+			float leak_threshold, expansion_threshold;
+			int tss_max_nodes, tss_max_depth;
+			unsigned long long tt_bucket_mask; // buckets - 1 (4 entries of 16 bytes per bucket)
+			int node_cap, edge_cap, ht_cap, act_cap;
+			int record_cap, record_edge_cap;
+			int n_openings;
+			// state
+			GameState *games;
+			DNode *nodes;   // [game][arena 0/1][node_cap]
+			DEdge *edges;   // [game][arena 0/1][edge_cap]
+			int *ht;        // [game][ht_cap] node index + 1, 0 = empty
+			DTask *tasks;   // [game][batch]
+			uint32_t *act;  // [game][act_cap] alpha-beta action stack: move | score << 16
+			uint64_t *tt;   // [game][buckets][4][2]
+			// read-only tables
+			const uint8_t *t_pattern;
+			const uint8_t *t_ho3;
+			const uint8_t *t_threat;
+			const uint16_t *t_defense;
+			const uint64_t *nc_keys; // node-cache Zobrist keys [3 + 3*hw]
+			const uint64_t *zob;     // solver Zobrist keys [2*hw][2] (lo, hi)
+			const uint16_t *openings; // [n_openings][OPENING_CAP] (count in slot 0)
+			// evaluation exchange
+			uint32_t *nn_features; // [game*batch][hw]
+			float *nn_policy;      // [game*batch][hw]
+			float *nn_value;       // [game*batch][3]
+			int *nn_list;          // compacted slots to evaluate
+			int *counters;         // [0] nn count, [1] next opening, [2] finished games, [3] records used, [4] record edges used, [5] total moves
+			// output records
+			MoveRecordHeader *records;
+			DEdge *record_edges;
+	};
+}
+
+#endif

@@ -54,6 +54,8 @@ namespace
 			float bv3[3];
 			int blocks;
 			int batch;
+			const int *slot_list; // optional: batch element i is slot slot_list[i]
+			const int *count_ptr; // optional: batch size read on the device
 	};
 
 	template<int F, int ROWS, int COLS>
@@ -291,8 +293,10 @@ namespace
 		for (int i = tid; i < G::PLANE_BYTES / 16; i += 256)
 			reinterpret_cast<uint4*>(plane_x)[i] = zero4;
 
-		for (int b = blockIdx.x; b < p.batch; b += gridDim.x)
+		const int batch = (p.count_ptr != nullptr) ? min(*p.count_ptr, p.batch) : p.batch;
+		for (int bi = blockIdx.x; bi < batch; bi += gridDim.x)
 		{
+			const int b = (p.slot_list != nullptr) ? p.slot_list[bi] : bi;
 			// ---- stage the bit-unpacked input into the padded plane (aliases plane_t) ----
 			__syncthreads();
 			for (int i = tid; i < G::NPOS5 * 4; i += 256)
@@ -575,7 +579,8 @@ int agx_net_load_weights(AgxNet *net, const float *h_blob, size_t n_floats)
 	return AGX_OK;
 }
 
-int agx_nn_forward(AgxNet *net, const uint32_t *d_features, int batch, float *d_policy, float *d_value, void *stream)
+static int launch_forward(AgxNet *net, const uint32_t *d_features, const int *d_slot_list, const int *d_count, int batch, float *d_policy, float *d_value,
+		void *stream)
 {
 	AGX_REQUIRE(net != nullptr, AGX_ERR_INVALID, "agx_nn_forward: null network");
 	AGX_REQUIRE(net->loaded, AGX_ERR_STATE, "agx_nn_forward: weights not loaded");
@@ -600,6 +605,8 @@ int agx_nn_forward(AgxNet *net, const uint32_t *d_features, int batch, float *d_
 		p.bv3[i] = net->bv3[i];
 	p.blocks = net->desc.blocks;
 	p.batch = batch;
+	p.slot_list = d_slot_list;
+	p.count_ptr = d_count;
 
 	const int grid = (batch < net->num_cus) ? batch : net->num_cus;
 	hipStream_t s = static_cast<hipStream_t>(stream);
@@ -609,6 +616,17 @@ int agx_nn_forward(AgxNet *net, const uint32_t *d_features, int batch, float *d_
 		hipLaunchKernelGGL((nn_tower_kernel<64, 15, 15>), dim3(grid), dim3(256), 0, s, p, d_features, d_policy, d_value);
 	AGX_HIP_CHECK(hipGetLastError());
 	return AGX_OK;
+}
+
+int agx_nn_forward(AgxNet *net, const uint32_t *d_features, int batch, float *d_policy, float *d_value, void *stream)
+{
+	return launch_forward(net, d_features, nullptr, nullptr, batch, d_policy, d_value, stream);
+}
+int agx_nn_forward_indirect(AgxNet *net, const uint32_t *d_features, const int *d_slot_list, const int *d_count, int max_batch, float *d_policy,
+		float *d_value, void *stream)
+{
+	AGX_REQUIRE(d_slot_list != nullptr && d_count != nullptr, AGX_ERR_INVALID, "agx_nn_forward_indirect: null list");
+	return launch_forward(net, d_features, d_slot_list, d_count, max_batch, d_policy, d_value, stream);
 }
 
 int agx_net_destroy(AgxNet *net)

@@ -1,0 +1,150 @@
+"""Host-side mirror of the reference's self-play driver objects for the device engine.
+
+`GeneratorPool` plays the role of one GeneratorThread with its games_per_thread GameGenerators
+(src/selfplay/GeneratorManager.cpp:124-141, src/selfplay/GameGenerator.cpp:46-121): it owns one device engine handle and
+drives it with select_solve -> evaluate -> expand_backup steps.  All search arithmetic happens in libagx.so."""
+import ctypes
+
+import numpy as np
+
+from ._lib import (lib, check, AgxEngineConfig, AgxEngineBuffers, AgxEngineStats, AgxGameInfo, AgxEdgeView, AgxMoveRecord)
+
+OPENING_CAP = 32
+
+
+def default_config(**overrides):
+    cfg = AgxEngineConfig()
+    check(lib.agx_engine_default_config(ctypes.byref(cfg)))
+    for k, v in overrides.items():
+        if not hasattr(cfg, k):
+            raise KeyError(k)
+        setattr(cfg, k, v)
+    return cfg
+
+
+def pack_openings(openings):
+    """list of lists of Move::toShort -> uint16 [n][OPENING_CAP]"""
+    out = np.zeros((len(openings), OPENING_CAP), dtype=np.uint16)
+    for i, o in enumerate(openings):
+        if len(o) >= OPENING_CAP:
+            raise ValueError("opening too long")
+        out[i, 0] = len(o)
+        out[i, 1:1 + len(o)] = o
+    return out
+
+
+class GeneratorPool:
+    def __init__(self, cfg):
+        self.cfg = cfg
+        self._h = ctypes.c_void_p()
+        check(lib.agx_engine_create(ctypes.byref(cfg), ctypes.byref(self._h)))
+        self.buffers = AgxEngineBuffers()
+        check(lib.agx_engine_buffers(self._h, ctypes.byref(self.buffers)))
+        self.cells = self.buffers.cells
+        self.slots = self.buffers.slots
+
+    def begin(self, openings, stream=None):
+        arr = np.ascontiguousarray(openings, dtype=np.uint16)
+        assert arr.ndim == 2 and arr.shape[1] == OPENING_CAP
+        check(lib.agx_engine_begin(self._h, arr.ctypes.data_as(ctypes.c_void_p), arr.shape[0], stream))
+
+    def select_solve(self, stream=None):
+        check(lib.agx_engine_select_solve(self._h, stream))
+
+    def evaluate(self, net, stream=None):
+        check(lib.agx_engine_evaluate(self._h, net._net, stream))
+
+    def expand_backup(self, stream=None):
+        check(lib.agx_engine_expand_backup(self._h, stream))
+
+    def step(self, net, stream=None):
+        check(lib.agx_engine_step(self._h, net._net, stream))
+
+    # ---- external evaluation plumbing (tests) ----
+    def scheduled(self):
+        """returns (slot list, features uint32 [n][cells]) of the positions awaiting evaluation"""
+        check(lib.agx_device_synchronize())
+        count = np.zeros(1, np.int32)
+        check(lib.agx_memcpy_d2h(count.ctypes.data_as(ctypes.c_void_p), self.buffers.d_nn_count, 4))
+        n = int(count[0])
+        slots = np.zeros(max(n, 1), np.int32)
+        check(lib.agx_memcpy_d2h(slots.ctypes.data_as(ctypes.c_void_p), self.buffers.d_nn_list, 4 * max(n, 1)))
+        feats = np.zeros((self.slots, self.cells), np.uint32)
+        check(lib.agx_memcpy_d2h(feats.ctypes.data_as(ctypes.c_void_p), self.buffers.d_nn_features, feats.nbytes))
+        slots = slots[:n]
+        return slots, feats[slots]
+
+    def provide(self, slots, policy, value3):
+        """writes policy [n][cells] and value (win, draw, loss) [n][3] of the given slots"""
+        pol = np.zeros((self.slots, self.cells), np.float32)
+        val = np.zeros((self.slots, 3), np.float32)
+        pol[slots] = policy
+        val[slots] = value3
+        check(lib.agx_memcpy_h2d(self.buffers.d_nn_policy, pol.ctypes.data_as(ctypes.c_void_p), pol.nbytes))
+        check(lib.agx_memcpy_h2d(self.buffers.d_nn_value, val.ctypes.data_as(ctypes.c_void_p), val.nbytes))
+
+    def stats(self):
+        check(lib.agx_device_synchronize())
+        s = AgxEngineStats()
+        check(lib.agx_engine_stats(self._h, ctypes.byref(s)))
+        return {name: getattr(s, name) for name, _ in s._fields_}
+
+    def game_info(self, game, with_edges=True):
+        info = AgxGameInfo()
+        board = np.zeros(self.cells, np.uint8)
+        edges = (AgxEdgeView * 400)()
+        check(lib.agx_engine_game_info(self._h, game, ctypes.byref(info), board.ctypes.data_as(ctypes.c_void_p),
+                                       ctypes.cast(edges, ctypes.c_void_p) if with_edges else None, 400))
+        out = {name: getattr(info, name) for name, _ in info._fields_}
+        out["board"] = board
+        if with_edges:
+            out["edges"] = [dict(move=e.move, visits=e.visits, prior=e.prior, win=e.win, draw=e.draw, score=e.score,
+                                 flag_vl=e.flag_and_virtual_loss) for e in edges[:info.root_edges]]
+        return out
+
+    def records(self):
+        nr, ne = ctypes.c_int(), ctypes.c_int()
+        check(lib.agx_engine_records(self._h, None, 0, None, 0, ctypes.byref(nr), ctypes.byref(ne)))
+        recs = (AgxMoveRecord * max(nr.value, 1))()
+        edges = (AgxEdgeView * max(ne.value, 1))()
+        check(lib.agx_engine_records(self._h, ctypes.cast(recs, ctypes.c_void_p), nr.value, ctypes.cast(edges, ctypes.c_void_p), ne.value,
+                                     ctypes.byref(nr), ctypes.byref(ne)))
+        return recs[:nr.value], edges[:ne.value]
+
+    def zobrist(self):
+        keys = np.zeros(4 * self.cells, np.uint64)
+        check(lib.agx_engine_zobrist(self._h, keys.ctypes.data_as(ctypes.c_void_p), keys.size))
+        return keys
+
+    def debug_solve(self, boards, signs):
+        boards = np.ascontiguousarray(boards, dtype=np.uint8).reshape(-1, self.cells)
+        signs = np.ascontiguousarray(signs, dtype=np.int32)
+        n = boards.shape[0]
+        feats = np.zeros((n, self.cells), np.uint32)
+        moves = np.zeros((n, self.cells), np.uint16)
+        scores = np.zeros((n, self.cells), np.uint16)
+        counts = np.zeros(n, np.int32)
+        flags = np.zeros(n, np.uint32)
+        results = np.zeros(n, np.uint16)
+        p = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+        check(lib.agx_debug_solve(self._h, p(boards), p(signs), n, p(feats), p(moves), p(scores), p(counts), p(flags), p(results)))
+        return dict(features=feats, moves=moves, scores=scores, counts=counts, flags=flags, results=results)
+
+    def debug_pattern_state(self, boards, signs, moves):
+        boards = np.ascontiguousarray(boards, dtype=np.uint8).reshape(-1, self.cells)
+        signs = np.ascontiguousarray(signs, dtype=np.int32)
+        moves = np.ascontiguousarray(moves, dtype=np.uint16)
+        n = boards.shape[0]
+        n_moves = moves.shape[1] if moves.size else 0
+        stride = 2 * self.cells * 2 + 32
+        pt = np.zeros((n, self.cells, 8), np.uint8)
+        th = np.zeros((n, self.cells, 2), np.uint8)
+        lists = np.zeros((n, stride), np.int16)
+        p = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+        check(lib.agx_debug_pattern_state(self._h, p(boards), p(signs), p(moves), n, n_moves, p(pt), p(th), p(lists), stride))
+        return pt, th, lists
+
+    def close(self):
+        if self._h:
+            lib.agx_engine_destroy(self._h)
+            self._h = ctypes.c_void_p()

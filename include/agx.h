@@ -75,6 +75,139 @@ int agx_net_load_weights(AgxNet* net, const float* h_blob, size_t n_floats);
 int agx_nn_forward(AgxNet* net, const uint32_t* d_features, int batch, float* d_policy, float* d_value, void* stream);
 int agx_net_destroy(AgxNet* net);
 
+/* Same network, but the batch is a device-side list: position i is slot d_slot_list[i] of the slot-indexed buffers
+ * (features uint32[slots][cells], policy float[slots][cells], value float[slots][3]); the batch size is read from
+ * *d_count on the device, so no host synchronisation is needed between the search kernels and the network
+ * (replaces NNEvaluator::pack_to_network / asyncEvaluateGraphLaunch, src/search/monte_carlo/NNEvaluator.cpp:182-262). */
+int agx_nn_forward_indirect(AgxNet* net, const uint32_t* d_features, const int* d_slot_list, const int* d_count, int max_batch,
+		float* d_policy, float* d_value, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Device-resident self-play engine: a pool of independent games, each with its own search tree, solver transposition
+ * table and task buffer in HBM.  Replaces, for one GeneratorThread (src/selfplay/GeneratorManager.cpp:124-141), the
+ * per-game objects GameGenerator{Game, Tree, Search{AlphaBetaSearch}} and their calls
+ *   Search::select / solve / scheduleToNN / generateEdges / expand / backup / cleanup   (Search.hpp:78-90)
+ *   Tree::setBoard / select / expand / backup / getInfo                                   (Tree.hpp:68-104)
+ *   GameGenerator::generate / make_move / prepare_search                                  (GameGenerator.cpp:46-185)
+ * Configuration fields carry the reference's names (utils/configs.hpp: GameConfig, TreeConfig, EdgeSelectorConfig,
+ * MCTSConfig, TSSConfig, SearchConfig, SelfplayConfig::constraints.max_simulations).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct AgxEngineConfig
+{
+	int rules;                        /* AgxRules; AGX_RENJU is rejected (not supported on the device yet) */
+	int board_size;                   /* square boards, <= 20 */
+	int draw_after;                   /* GameConfig::draw_after, <= 0 means rows*cols */
+	int n_games;                      /* games resident on this GPU (SelfplayConfig::games_per_thread) */
+	int max_batch_size;               /* SearchConfig::max_batch_size: simulations selected per game per step */
+	int max_simulations;              /* SelfplayConfig::constraints.max_simulations (playouts per move) */
+	float exploration_constant;       /* EdgeSelectorConfig */
+	float exploration_scaling;
+	int init_to;                      /* 0 "q_head", 1 "parent", 2 "draw", 3 "loss" */
+	float information_leak_threshold; /* TreeConfig */
+	float policy_expansion_threshold; /* MCTSConfig (max_children is fixed at "unlimited") */
+	int tss_max_positions;            /* TSSConfig::max_positions, <= 100 */
+	uint64_t tss_table_entries;       /* AlphaBetaSearch's SharedHashTable size per game (reference: 4 Mi) */
+	uint64_t zobrist_seed;            /* seed of the solver / node-cache Zobrist keys (the reference draws them from a time-seeded RNG) */
+	int node_capacity;                /* per game, per arena (TreeConfig::node_bucket_size analogue) */
+	int edge_capacity;                /* per game, per arena (TreeConfig::edge_bucket_size analogue) */
+	int record_capacity;              /* move records kept on the device, 0 = n_games * cells */
+	int record_edge_capacity;         /* root-edge snapshots kept on the device, 0 = 64 per record */
+} AgxEngineConfig;
+
+typedef struct AgxEngine AgxEngine; /* opaque */
+
+typedef struct AgxEngineBuffers
+{
+	uint32_t* d_nn_features; /* [slots][cells] */
+	float* d_nn_policy;      /* [slots][cells] */
+	float* d_nn_value;       /* [slots][3] */
+	int* d_nn_list;          /* slots scheduled for evaluation by the last agx_engine_select_solve */
+	int* d_nn_count;         /* number of entries of d_nn_list */
+	int slots;
+	int cells;
+} AgxEngineBuffers;
+
+typedef struct AgxEngineStats
+{ /* SearchStats counters (Search.hpp:33-54) summed over the pool + pool-level counters */
+	unsigned long long evaluated_nodes;       /* nb_node_count: simulations backed up */
+	unsigned long long network_evaluations;   /* nb_network_evaluations */
+	unsigned long long information_leaks;     /* nb_information_leaks */
+	unsigned long long proven_edge_visits;    /* nb_proven_states */
+	unsigned long long wasted_expansions;     /* nb_wasted_expansions */
+	unsigned long long duplicate_selections;  /* nb_duplicate_nodes */
+	unsigned long long solver_nodes;          /* positions visited by the alpha-beta solver */
+	unsigned long long select_levels;         /* tree levels descended by select (incl. dropped leak descents) */
+	unsigned long long select_edge_reads;     /* edges scanned by PUCT argmax */
+	unsigned long long moves_played;
+	unsigned long long peak_nodes;            /* largest per-game node / edge arena use seen */
+	unsigned long long peak_edges;
+	int games_finished;
+	int openings_taken;
+	int active_games;
+	int records_used;
+	int record_edges_used;
+	int first_error;                          /* 0 = none; EngineError of the first game that stopped */
+} AgxEngineStats;
+
+typedef struct AgxEdgeView
+{ /* ag::Edge (Edge.hpp:23-32) */
+	float prior, win, draw;
+	int32_t visits;
+	uint16_t move;   /* Move::toShort: sign | row << 2 | col << 9 */
+	uint16_t score;  /* Score raw bits */
+	uint16_t flag_and_virtual_loss;
+	uint16_t reserved;
+} AgxEdgeView;
+
+typedef struct AgxGameInfo
+{
+	int active, sign_to_move, n_moves, outcome, error, opening_id, games_done, n_nodes, n_edges;
+	int root_visits;
+	float root_win, root_draw;
+	int root_score;
+	int root_edges;
+} AgxGameInfo;
+
+typedef struct AgxMoveRecord
+{ /* one self-play sample: SearchDataPack(const Node&, board) (dataset/data_packs.cpp:24-43) */
+	int game_serial, move_number;
+	uint16_t move, root_score;
+	int root_visits;
+	float root_win, root_draw;
+	int n_edges, edge_offset;
+} AgxMoveRecord;
+
+#define AGX_OPENING_CAP 32 /* uint16 per opening: [0] = number of stones, [1..] = Move::toShort */
+
+int agx_engine_default_config(AgxEngineConfig* cfg);
+int agx_engine_create(const AgxEngineConfig* cfg, AgxEngine** out);
+int agx_engine_destroy(AgxEngine* engine);
+/* Starts every game of the pool from h_openings[n_openings][AGX_OPENING_CAP]; finished games take the next unused opening. */
+int agx_engine_begin(AgxEngine* engine, const uint16_t* h_openings, int n_openings, void* stream);
+/* One pool step = select_solve -> evaluate -> expand_backup.  The three stages are exposed separately so that a caller
+ * (or a test) can run any evaluator over AgxEngineBuffers between them. */
+int agx_engine_select_solve(AgxEngine* engine, void* stream);
+int agx_engine_evaluate(AgxEngine* engine, AgxNet* net, void* stream);
+int agx_engine_expand_backup(AgxEngine* engine, void* stream);
+int agx_engine_step(AgxEngine* engine, AgxNet* net, void* stream);
+int agx_engine_buffers(AgxEngine* engine, AgxEngineBuffers* out);
+int agx_engine_stats(AgxEngine* engine, AgxEngineStats* out);
+/* Tree::getInfo({}) of one game (Tree.cpp:403-424): root snapshot + board. */
+int agx_engine_game_info(AgxEngine* engine, int game, AgxGameInfo* info, uint8_t* h_board, AgxEdgeView* h_root_edges, int edge_capacity);
+int agx_engine_records(AgxEngine* engine, AgxMoveRecord* h_records, int record_capacity, AgxEdgeView* h_edges, int edge_capacity, int* n_records, int* n_edges);
+/* FastZobristHashing keys used by the solver tables: uint64[2 * cells][2] = (lo, hi) per (cell, colour). */
+int agx_engine_zobrist(AgxEngine* engine, uint64_t* h_keys, size_t n_words);
+
+/* Test hooks: run single stages on caller-supplied positions (boards uint8[count][cells], 0 empty 1 cross 2 circle). */
+int agx_debug_solve(AgxEngine* engine, const uint8_t* h_boards, const int* h_signs, int count, uint32_t* h_features, uint16_t* h_moves,
+		uint16_t* h_scores, int* h_counts, uint32_t* h_flags, uint16_t* h_result_scores);
+int agx_debug_new_generation(AgxEngine* engine);
+int agx_debug_pattern_state(AgxEngine* engine, const uint8_t* h_boards, const int* h_signs, const uint16_t* h_moves, int count, int n_moves,
+		uint8_t* h_ptypes, uint8_t* h_threats, int16_t* h_lists, int lists_stride);
+/* Host-only: the lookup tables the engine uploads (pattern uint8[1<<20], half-open-three uint8[1<<20], threat uint8[4096][2],
+ * defence uint16[15][256][2]) for verification against the reference tables. */
+int agx_host_tables(int rules, uint8_t* h_pattern, uint8_t* h_half_open_three, uint8_t* h_threat, uint16_t* h_defense);
+
 /* Raw device-memory helpers so that non-HIP hosts (ctypes, cgo) can stage buffers. */
 int agx_malloc(void** d_ptr, size_t bytes);
 int agx_free(void* d_ptr);

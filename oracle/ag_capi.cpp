@@ -69,6 +69,21 @@ void ago_tables(int rules, uint8_t *types, uint8_t *half_open_3, uint8_t *threat
 	std::memcpy(half_open_3, t.half_open_3.data(), 1u << 20);
 	std::memcpy(threats, t.threats, 4096 * 2);
 }
+/* raw defence tables in the product's row order: rows 0-4 five, 5-8 open four, 9-14 double four; [row][sides][defender-1] */
+void ago_defense_tables(int rules, uint16_t *out)
+{
+	const Tables &t = Tables::get(static_cast<Rules>(rules));
+	for (int j = 0; j < 256; j++)
+		for (int d = 0; d < 2; d++)
+		{
+			for (int i = 0; i < 5; i++)
+				out[((0 + i) * 256 + j) * 2 + d] = t.five_defense[i][j][d];
+			for (int i = 0; i < 4; i++)
+				out[((5 + i) * 256 + j) * 2 + d] = t.open_four_defense[i][j][d];
+			for (int i = 0; i < 6; i++)
+				out[((9 + i) * 256 + j) * 2 + d] = t.double_four_defense[i][j][d];
+		}
+}
 uint16_t ago_defensive_moves(int rules, uint32_t extended_pattern, int defender, int pattern_type)
 {
 	return Tables::get(static_cast<Rules>(rules)).defensive_moves(extended_pattern, static_cast<Sign>(defender), static_cast<PatternType>(pattern_type));
