@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py — MCTS simulations/s of the device-resident self-play engine (BASELINE.json metric).
+
+A "step" is one pass of the hot path over the whole game pool of this rank: select (<= max_batch_size PUCT descents per game)
+-> threat solver + feature encode -> policy/value network on the scheduled positions -> edge generation, expand, backup ->
+move decision / tree compaction.  Workload at N = 1: BASELINE.json configs[1] — freestyle 15x15, 6-block / 128-filter net,
+400 playouts per move, 1024 parallel games on one MI355X, synthetic random openings, synthetic He-init weights.
+
+Multi-GPU: games are independent, so each rank runs its own pool of 1024 games (weak scaling); there is no data-path
+collective, torch.distributed is only used for the barrier and the max-over-ranks timing the contract asks for.
+
+Usage: python bench.py [--gpus N] [--steps K] [--warmup W]     (N > 1: launched by torch.distributed.run, one rank per GPU)
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+
+def nn_flops_per_position(desc):
+    F, C, HW, D, blocks = desc["filters"], desc["in_channels"], desc["rows"] * desc["cols"], desc["value_hidden"], desc["blocks"]
+    return 2 * HW * (25 * C * F + blocks * 2 * 9 * F * F + 9 * F * F + F + 4 * F) + 2 * 4 * HW * D + 6 * D
+
+
+def cpu_baseline(args, max_seconds):
+    """Times the CPU oracle (a scalar restatement of the reference search, oracle/) on this box's host cores with a stand-in
+    evaluator (network cost = 0).  This is the ONLY place where bench.py touches oracle/."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    lib = ol.load()
+    cores = os.cpu_count() or 1
+    threads = max(1, min(cores, 64))
+    cfg = ol.default_search_config(max_batch_size=args.batch, max_simulations=args.sims, table_entries=4 * 1024 * 1024)
+    nodes, games, moves = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+    seconds = ctypes.c_double()
+    stats = (ctypes.c_uint64 * 9)()
+    lib.ago_cpu_baseline(args.rules, args.board, args.board, ctypes.byref(cfg), threads, 1000, ctypes.c_double(max_seconds),
+                         ctypes.byref(nodes), ctypes.byref(games), ctypes.byref(moves), ctypes.byref(seconds), stats)
+    return dict(value=nodes.value / seconds.value, unit="simulations/s", cores=threads, kind="port",
+                sample="%d threads x 1 self-play game each (same rules/board/playouts/batch, stand-in evaluator, NN cost excluded), %.1f s wall, %d simulations, %d moves"
+                       % (threads, seconds.value, nodes.value, moves.value),
+                host_cpus=cores)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=150)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--games", type=int, default=1024, help="games per GPU")
+    ap.add_argument("--sims", type=int, default=400)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--blocks", type=int, default=6)
+    ap.add_argument("--filters", type=int, default=128)
+    ap.add_argument("--board", type=int, default=15)
+    ap.add_argument("--rules", type=int, default=0)
+    ap.add_argument("--table-entries", type=int, default=4 * 1024 * 1024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from alphagomoku_amd import build
+    if rank == 0:
+        build.build(verbose=False)
+    if dist is not None:
+        dist.barrier()
+    from alphagomoku_amd import lib, check, synthetic, selfplay
+    from alphagomoku_amd.networks import AGNetwork
+
+    check(lib.agx_set_device(local_rank))
+    desc = synthetic.net_desc(rows=args.board, cols=args.board, blocks=args.blocks, filters=args.filters)
+    blob, _ = synthetic.make_weights(desc)
+    net = AGNetwork(desc)
+    net.loadWeights(blob)
+    cfg = selfplay.default_config(rules=args.rules, board_size=args.board, n_games=args.games, max_batch_size=args.batch,
+                                  max_simulations=args.sims, tss_table_entries=args.table_entries)
+    pool = selfplay.GeneratorPool(cfg)
+    # enough openings for every game that can finish during the run; seeds are disjoint across ranks
+    n_openings = args.games * 3
+    openings = synthetic.make_openings(args.board, n_openings, seed0=rank * 1000003)
+    pool.begin(selfplay.pack_openings(openings))
+    check(lib.agx_device_synchronize())
+
+    def make_timers(n):
+        out = []
+        for _ in range(n):
+            t = ctypes.c_void_p()
+            check(lib.agx_timer_create(ctypes.byref(t)))
+            out.append(t)
+        return out
+
+    for _ in range(args.warmup):
+        pool.step(net)
+    check(lib.agx_device_synchronize())
+    s0 = pool.stats()
+    t_sel, t_nn, t_exp = make_timers(args.steps), make_timers(args.steps), make_timers(args.steps)
+
+    if dist is not None:
+        dist.barrier()
+    check(lib.agx_device_synchronize())
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        check(lib.agx_timer_start(t_sel[i], None))
+        pool.select_solve()
+        check(lib.agx_timer_stop(t_sel[i], None))
+        check(lib.agx_timer_start(t_nn[i], None))
+        pool.evaluate(net)
+        check(lib.agx_timer_stop(t_nn[i], None))
+        check(lib.agx_timer_start(t_exp[i], None))
+        pool.expand_backup()
+        check(lib.agx_timer_stop(t_exp[i], None))
+    check(lib.agx_device_synchronize())
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    s1 = pool.stats()
+
+    def total_ms(timers):
+        acc = 0.0
+        ms = ctypes.c_float()
+        for t in timers:
+            check(lib.agx_timer_elapsed_ms(t, ctypes.byref(ms)))
+            acc += ms.value
+        return acc
+
+    ms_sel, ms_nn, ms_exp = total_ms(t_sel), total_ms(t_nn), total_ms(t_exp)
+    sims = s1["evaluated_nodes"] - s0["evaluated_nodes"]
+    evals = s1["network_evaluations"] - s0["network_evaluations"]
+    moves = s1["moves_played"] - s0["moves_played"]
+    games_done = s1["games_finished"] - s0["games_finished"]
+    levels = s1["select_levels"] - s0["select_levels"]
+    edge_reads = s1["select_edge_reads"] - s0["select_edge_reads"]
+    solver_nodes = s1["solver_nodes"] - s0["solver_nodes"]
+    leaks = s1["information_leaks"] - s0["information_leaks"]
+    if s1["first_error"] != 0:
+        raise RuntimeError("device engine stopped with error code %d" % s1["first_error"])
+
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        c = torch.tensor([sims, evals, moves, games_done], dtype=torch.float64, device="cuda")
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        sims, evals, moves, games_done = [float(x) for x in c.tolist()]
+
+    if rank == 0:
+        flops = nn_flops_per_position(desc)
+        # dominant kernel: the policy/value tower (one launch per step); algorithmic FLOPs per launch = positions x FLOPs/position
+        local_evals = s1["network_evaluations"] - s0["network_evaluations"]
+        nn_tflops = (local_evals * flops) / (ms_nn * 1e-3) / 1e12 if ms_nn > 0 else 0.0
+        depth = levels / max(1, (s1["evaluated_nodes"] - s0["evaluated_nodes"]) + leaks)
+        edges_per_level = edge_reads / max(1, levels)
+        result = {
+            "metric": "MCTS simulations/sec (self-play, 15x15 freestyle)",
+            "value": sims / elapsed,
+            "unit": "simulations/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f16 (network, fp32 accumulate) + int/fp32 (tree)",
+            "data": "synthetic (random openings, He-init weights seed 1234)",
+            "config": {"workload": "freestyle %dx%d, %d-block/%d-filter net, %d playouts/move, %d parallel self-play games per GPU, max_batch_size %d"
+                                   % (args.board, args.board, args.blocks, args.filters, args.sims, args.games, args.batch),
+                       "games_per_gpu": args.games, "parallelism": "independent game pools x%d (no collective)" % world},
+            "moves_per_sec": moves / elapsed,
+            "games_per_sec": games_done / elapsed,
+            "nn_positions_per_sec": evals / elapsed,
+            "stage_ms_per_step": {"select_solve": ms_sel / args.steps, "network": ms_nn / args.steps, "expand_backup_advance": ms_exp / args.steps},
+            "shape": {"mean_select_depth": depth, "mean_edges_per_level": edges_per_level,
+                      "solver_nodes_per_simulation": solver_nodes / max(1, s1["evaluated_nodes"] - s0["evaluated_nodes"]),
+                      "nn_evals_per_simulation": local_evals / max(1, s1["evaluated_nodes"] - s0["evaluated_nodes"])},
+            "roofline": {"bound": "mfma", "kernel": "nn_tower_kernel<%d,%d,%d>" % (args.filters, args.board, args.board),
+                         "achieved": nn_tflops, "peak": 2500.0, "unit": "TFLOP/s", "frac": nn_tflops / 2500.0, "traffic": None,
+                         "flops_per_position": flops, "positions_per_launch": local_evals / args.steps,
+                         "avg_launch_ms": ms_nn / args.steps},
+        }
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
+        print(json.dumps(result))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

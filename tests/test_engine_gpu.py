@@ -1,0 +1,308 @@
+"""Bit-exact parity of the device search engine (through the C ABI) against the CPU oracle.
+
+  1. incremental pattern / threat state after random place / remove sequences  (PatternCalculator)
+  2. threat solver per position: action ORDER, scores, flags, result, and the encoded NN features (AlphaBetaSearch + MoveGenerator)
+  3. whole self-play games, compared after EVERY step: scheduled positions and their features, root edge list (moves, visit
+     counts, priors, values, scores), root value, moves played — with the same evaluator outputs fed to both sides
+  4. the same with the HIP network in the loop (oracle fed with the device network's outputs)
+Integer / index data must be identical; floats are compared bit for bit (the tree arithmetic is restated operation by operation)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from alphagomoku_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+N = 15
+HW = N * N
+
+
+@pytest.fixture(scope="module")
+def olib():
+    return ol.load()
+
+
+def clustered_board(rng, stones, n=N):
+    b = np.zeros((n, n), np.uint8)
+    r, c = n // 2, n // 2
+    for k in range(stones):
+        for _ in range(100):
+            rr, cc = r + rng.integers(-2, 3), c + rng.integers(-2, 3)
+            if 0 <= rr < n and 0 <= cc < n and b[rr, cc] == 0:
+                b[rr, cc] = 1 + (k & 1)
+                r, c = rr, cc
+                break
+    return b.reshape(-1)
+
+
+def random_board(rng, stones, n=N):
+    b = np.zeros(n * n, np.uint8)
+    for k, i in enumerate(rng.permutation(n * n)[:stones]):
+        b[i] = 1 + (k & 1)
+    return b
+
+
+@pytest.mark.parametrize("rules", [0, 1, 3, 4])
+def test_pattern_state_after_move_sequences(agx_lib, olib, rules):
+    from alphagomoku_amd import selfplay
+    rng = np.random.default_rng(10 + rules)
+    pool = selfplay.GeneratorPool(selfplay.default_config(rules=rules, n_games=64, max_batch_size=2, tss_table_entries=1 << 12,
+                                                          node_capacity=256, edge_capacity=4096))
+    G, NM = 64, 14
+    boards, signs, moves = [], [], []
+    for g in range(G):
+        b = clustered_board(rng, int(rng.integers(0, 45))) if g % 2 else random_board(rng, int(rng.integers(0, 80)))
+        if g == 0:
+            b[:] = 0  # empty board edge case
+        sign = 1 if int((b != 0).sum()) % 2 == 0 else 2
+        seq, cur, s, done = [], b.copy(), sign, []
+        for _ in range(NM):
+            if done and rng.random() < 0.35:
+                seq.append(0)
+                m = done.pop()
+                cur[(m >> 2 & 127) * N + (m >> 9 & 127)] = 0
+            else:
+                cell = int(rng.choice(np.flatnonzero(cur == 0)))
+                m = s | ((cell // N) << 2) | ((cell % N) << 9)
+                seq.append(m)
+                done.append(m)
+                cur[cell] = s
+            s = 3 - s
+        boards.append(b)
+        signs.append(sign)
+        moves.append(seq)
+    pt, th, lists = pool.debug_pattern_state(np.array(boards), signs, np.array(moves, np.uint16))
+    for g in range(G):
+        opt = np.zeros((HW, 8), np.uint8)
+        oth = np.zeros((HW, 2), np.uint8)
+        olists = np.zeros(4096, np.int16)
+        mv = np.array(moves[g], np.uint16)
+        n = olib.ago_pattern_state(rules, N, N, ol.ptr(boards[g]), signs[g], ol.ptr(mv), len(mv), ol.ptr(opt), ol.ptr(oth), ol.ptr(olists), 4096)
+        assert np.array_equal(pt[g], opt), g
+        assert np.array_equal(th[g], oth), g
+        assert int(lists[g, -1]) == n and np.array_equal(lists[g, :n], olists[:n]), g  # threat lists incl. their ORDER
+    pool.close()
+
+
+@pytest.mark.parametrize("rules", [0, 1, 3])
+def test_solver_matches_oracle_per_position(agx_lib, olib, rules):
+    from alphagomoku_amd import selfplay, lib, check
+    rng = np.random.default_rng(20 + rules)
+    cfg = selfplay.default_config(rules=rules, n_games=128, max_batch_size=2, tss_table_entries=1 << 16, node_capacity=256, edge_capacity=4096)
+    pool = selfplay.GeneratorPool(cfg)
+    pool.begin(selfplay.pack_openings([[] for _ in range(128)]))   # clears the transposition tables
+    check(lib.agx_device_synchronize())
+    boards, signs = [], []
+    for g in range(128):
+        b = clustered_board(rng, int(rng.integers(0, 60))) if g % 4 else random_board(rng, int(rng.integers(0, 120)))
+        boards.append(b)
+        signs.append(1 if int((b != 0).sum()) % 2 == 0 else 2)
+    out = pool.debug_solve(np.array(boards), signs)
+    zob = pool.zobrist()
+    proven = 0
+    for g in range(128):
+        s = olib.ago_solver_create(rules, N, N, 1 << 16, cfg.zobrist_seed, 100)
+        z = np.zeros(4 * HW, np.uint64)
+        olib.ago_solver_zobrist(s, ol.ptr(z))
+        assert np.array_equal(z, zob)
+        feat = np.zeros(HW, np.uint32)
+        mv = np.zeros(HW, np.uint16)
+        sc = np.zeros(HW, np.uint16)
+        fl, rs, nodes = ctypes.c_int(), ctypes.c_uint16(), ctypes.c_int()
+        n = olib.ago_solver_solve(s, ol.ptr(boards[g]), signs[g], ol.ptr(feat), ol.ptr(mv), ol.ptr(sc), ctypes.byref(fl), ctypes.byref(rs), ctypes.byref(nodes))
+        olib.ago_solver_destroy(s)
+        assert n == out["counts"][g], g
+        assert np.array_equal(mv[:n], out["moves"][g, :n]), g          # same actions in the same ORDER
+        assert np.array_equal(sc[:n], out["scores"][g, :n]), g
+        assert rs.value == out["results"][g], g
+        assert bool(fl.value & 1) == bool(out["flags"][g] & 1), g     # must_defend
+        assert np.array_equal(feat, out["features"][g]), g
+        proven += int(((rs.value >> 13) & 3) != 2)
+    assert proven > 3   # the sample must exercise proven results too
+    pool.close()
+
+
+def _oracle_root(olib, h):
+    rv, rs = ctypes.c_int(), ctypes.c_uint16()
+    rval = (ctypes.c_float * 2)()
+    em = np.zeros(512, np.uint16)
+    ev = np.zeros(512, np.int32)
+    ep = np.zeros(512, np.float32)
+    evl = np.zeros(1024, np.float32)
+    es = np.zeros(512, np.uint16)
+    ef = np.zeros(512, np.uint16)
+    n = olib.ago_game_root(h, ctypes.byref(rv), rval, ctypes.byref(rs), ol.ptr(em), ol.ptr(ev), ol.ptr(ep), ol.ptr(evl), ol.ptr(es), ol.ptr(ef), 512)
+    return dict(n=n, visits=rv.value, win=np.float32(rval[0]), draw=np.float32(rval[1]), score=rs.value, moves=em[:n].copy(), ev=ev[:n].copy(),
+                prior=ep[:n].copy(), val=evl[:2 * n].copy(), es=es[:n].copy())
+
+
+def _play_and_compare(olib, rules, games, batch, sims, max_steps, evaluator, table_entries=1 << 16):
+    """evaluator(features uint32 [n][HW]) -> (policy [n][HW] f32, value [n][2] f32 (win, draw)); used for BOTH sides"""
+    from alphagomoku_amd import selfplay
+    cfg = selfplay.default_config(rules=rules, n_games=games, max_batch_size=batch, max_simulations=sims, tss_table_entries=table_entries,
+                                  node_capacity=4096, edge_capacity=65536)
+    pool = selfplay.GeneratorPool(cfg)
+    ocfg = ol.default_search_config(max_batch_size=batch, max_simulations=sims, table_entries=table_entries)
+    openings, handles = [], []
+    for g in range(games):
+        op = np.zeros(64, np.uint16)
+        k = olib.ago_prepare_opening(rules, N, N, 100 + g, ol.ptr(op))
+        openings.append([int(x) for x in op[:k]])
+        h = olib.ago_game_create(rules, N, N, ctypes.byref(ocfg))
+        olib.ago_game_begin(h, ol.ptr(op), k)
+        handles.append(h)
+    pool.begin(selfplay.pack_openings(openings))
+    compared = 0
+    for step in range(max_steps):
+        pool.select_solve()
+        slots, feats = pool.scheduled()
+        pol, val = evaluator(feats) if len(slots) else (np.zeros((0, HW), np.float32), np.zeros((0, 2), np.float32))
+        v3 = np.concatenate([val, 1 - val.sum(1, keepdims=True)], 1).astype(np.float32)
+        pool.provide(slots, pol, v3)
+        by_slot = {int(s): i for i, s in enumerate(slots)}
+        for g in range(games):
+            if olib.ago_game_outcome(handles[g]) != 0:
+                continue
+            f = np.zeros((batch, HW), np.uint32)
+            c = olib.ago_game_step_select(handles[g], ol.ptr(f), batch)
+            mine = sorted(s for s in by_slot if s // batch == g)
+            assert c == len(mine), (step, g)
+            idx = [by_slot[s] for s in mine]
+            assert np.array_equal(feats[idx], f[:c]), (step, g)                      # same leaves, same features
+            p = np.ascontiguousarray(pol[idx])
+            v = np.ascontiguousarray(val[idx])
+            olib.ago_game_step_expand(handles[g], ol.ptr(p), ol.ptr(v))
+        pool.expand_backup()
+        for g in range(games):
+            info = pool.game_info(g)
+            assert info["error"] == 0
+            if info["opening_id"] != g or not info["active"] or olib.ago_game_outcome(handles[g]) != 0:
+                continue
+            r = _oracle_root(olib, handles[g])
+            e = info["edges"]
+            assert info["n_moves"] == len(openings[g]) + olib.ago_game_num_records(handles[g]), (step, g)
+            assert r["n"] == info["root_edges"] and r["visits"] == info["root_visits"], (step, g)
+            assert np.array_equal(np.array([x["move"] for x in e], np.uint16), r["moves"]), (step, g)
+            assert np.array_equal(np.array([x["visits"] for x in e], np.int32), r["ev"]), (step, g)   # visit counts
+            assert np.array_equal(np.array([x["score"] for x in e], np.uint16), r["es"]), (step, g)
+            assert np.array_equal(np.array([x["prior"] for x in e], np.float32), r["prior"]), (step, g)
+            assert np.array_equal(np.array([[x["win"], x["draw"]] for x in e], np.float32).reshape(-1), r["val"]), (step, g)
+            assert np.float32(info["root_win"]) == r["win"] and np.float32(info["root_draw"]) == r["draw"] and info["root_score"] == r["score"], (step, g)
+            compared += 1
+        if all(olib.ago_game_outcome(h) != 0 for h in handles):
+            break
+    # the played moves (the path's output records) must be identical
+    recs, _ = pool.records()
+    for g in range(games):
+        dev_moves = [r.move for r in recs if r.game_serial == g]
+        n = olib.ago_game_num_records(handles[g])
+        om = []
+        for i in range(n):
+            mv, rv, rs = ctypes.c_uint16(), ctypes.c_int(), ctypes.c_uint16()
+            rval = (ctypes.c_float * 2)()
+            em = np.zeros(512, np.uint16)
+            ev = np.zeros(512, np.int32)
+            ep = np.zeros(512, np.float32)
+            evl = np.zeros(1024, np.float32)
+            es = np.zeros(512, np.uint16)
+            olib.ago_game_record(handles[g], i, ctypes.byref(mv), ctypes.byref(rv), rval, ctypes.byref(rs), ol.ptr(em), ol.ptr(ev), ol.ptr(ep), ol.ptr(evl), ol.ptr(es), 512)
+            om.append(mv.value)
+        assert dev_moves == om, g
+    stats = pool.stats()
+    pool.close()
+    for h in handles:
+        olib.ago_game_destroy(h)
+    return compared, stats
+
+
+def _stand_in_evaluator(olib):
+    def f(feats):
+        feats = np.ascontiguousarray(feats, dtype=np.uint32)
+        pol = np.zeros((len(feats), HW), np.float32)
+        val = np.zeros((len(feats), 2), np.float32)
+        olib.ago_fake_eval(len(feats), HW, ol.ptr(feats), ol.ptr(pol), ol.ptr(val))
+        return pol, val
+    return f
+
+
+@pytest.mark.parametrize("rules,batch,sims", [(0, 1, 100), (0, 8, 100), (1, 4, 100), (3, 4, 60)])
+def test_whole_games_bit_exact_with_stand_in_evaluator(agx_lib, olib, rules, batch, sims):
+    compared, stats = _play_and_compare(olib, rules, games=6, batch=batch, sims=sims, max_steps=4000, evaluator=_stand_in_evaluator(olib))
+    assert compared > 500
+    assert stats["games_finished"] == 6 and stats["information_leaks"] > 0 and stats["proven_edge_visits"] > 0
+
+
+def test_games_bit_exact_with_the_hip_network_in_the_loop(agx_lib, olib):
+    """C1-shaped plumbing check: 2-block / 64-filter network evaluated by the HIP tower; the oracle tree is fed the same outputs."""
+    from alphagomoku_amd.networks import AGNetwork
+    d = synthetic.net_desc(blocks=2, filters=64)
+    blob, _ = synthetic.make_weights(d)
+    net = AGNetwork(d)
+    net.loadWeights(blob)
+
+    def evaluator(feats):
+        p, v = net.forward(np.ascontiguousarray(feats, dtype=np.uint32))
+        return p, np.ascontiguousarray(v[:, :2])
+    compared, stats = _play_and_compare(olib, 0, games=4, batch=4, sims=100, max_steps=250, evaluator=evaluator)
+    assert compared > 300 and stats["moves_played"] > 0
+    net.close()
+
+
+def test_pool_step_with_device_network_is_deterministic_and_consistent(agx_lib):
+    """agx_engine_step (network evaluated on the device through the indirect slot list) twice from the same openings gives identical
+    records; counters are consistent (size-independent properties that also hold at BASELINE sizes)."""
+    from alphagomoku_amd import selfplay
+    from alphagomoku_amd.networks import AGNetwork
+    d = synthetic.net_desc(blocks=2, filters=64)
+    blob, _ = synthetic.make_weights(d)
+    net = AGNetwork(d)
+    net.loadWeights(blob)
+    openings = selfplay.pack_openings(synthetic.make_openings(N, 64, seed0=5))
+
+    def run():
+        pool = selfplay.GeneratorPool(selfplay.default_config(n_games=32, max_batch_size=8, max_simulations=60, tss_table_entries=1 << 14,
+                                                              node_capacity=2048, edge_capacity=32768))
+        pool.begin(openings)
+        for _ in range(120):
+            pool.step(net)
+        st = pool.stats()
+        recs, edges = pool.records()
+        out = sorted((r.game_serial, r.move_number, r.move, r.root_visits, r.n_edges,
+                      tuple((e.move, e.visits) for e in edges[r.edge_offset:r.edge_offset + r.n_edges])) for r in recs)
+        pool.close()
+        return st, out
+    s1, r1 = run()
+    s2, r2 = run()
+    assert r1 == r2 and s1 == s2
+    assert s1["first_error"] == 0 and s1["moves_played"] == len(r1) and s1["moves_played"] > 32
+    assert s1["network_evaluations"] <= s1["evaluated_nodes"] + 32
+    for serial, number, move, visits, n_edges, edges in r1:
+        assert sum(v for _, v in edges) <= visits        # edge visits never exceed the root's
+        assert any(m == move for m, _ in edges)         # the played move is one of the root edges
+    net.close()
+
+
+def test_engine_error_paths(agx_lib):
+    from alphagomoku_amd import selfplay, AgxError
+    with pytest.raises(AgxError):
+        selfplay.GeneratorPool(selfplay.default_config(rules=2))                      # renju not supported on the device yet
+    with pytest.raises(AgxError):
+        selfplay.GeneratorPool(selfplay.default_config(board_size=25))
+    pool = selfplay.GeneratorPool(selfplay.default_config(n_games=2, tss_table_entries=1 << 10, node_capacity=64, edge_capacity=1024))
+    with pytest.raises(AgxError):
+        pool.select_solve()                                                           # begin() not called
+    # capacity overflow must be reported, not silently corrupt the tree
+    pool.begin(selfplay.pack_openings([[], []]))
+    olib = ol.load()
+    ev = _stand_in_evaluator(olib)
+    for _ in range(200):
+        pool.select_solve()
+        slots, feats = pool.scheduled()
+        if len(slots):
+            p, v = ev(feats)
+            pool.provide(slots, p, np.concatenate([v, 1 - v.sum(1, keepdims=True)], 1).astype(np.float32))
+        pool.expand_backup()
+    assert pool.stats()["first_error"] in (1, 2, 5)
+    pool.close()
