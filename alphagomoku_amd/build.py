@@ -36,6 +36,8 @@ def build(force=False, verbose=True):
         objs.append(obj)
         # -ffp-contract=off: the tree kernels must round exactly like the CPU oracle (no fused multiply-add)
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]
+        if os.environ.get("AGX_SOLVER_PROFILE"):
+            cmd += ["-DAGX_SOLVER_PROFILE"]
         if src.endswith(".cpp"):
             cmd += ["-x", "hip"]
         cmd += ["-c", os.path.join(CSRC, src), "-o", obj]

@@ -179,8 +179,14 @@ namespace
 	{ // AlphaBetaSearch::solve (AlphaBetaSearch.cpp:77-156)
 		uint32_t *act = E.act + static_cast<size_t>(g) * E.act_cap;
 		u64 *tt = E.tt + static_cast<size_t>(g) * (E.tt_bucket_mask + 1ull) * 8ull;
+#ifdef AGX_SOLVER_PROFILE
+		unsigned long long c0 = wall_clock64(), c_run = 0, c_place = 0, n_place = 0;
+#endif
 		solver_set_board(sh, E, t.board, t.sign_to_move, lane);
 		solver_encode_features(sh, E, E.nn_features + static_cast<size_t>(slot) * E.hw, lane);
+#ifdef AGX_SOLVER_PROFILE
+		unsigned long long c1 = wall_clock64();
+#endif
 		u64 lo = 0, hi = 0;
 		for (int i = lane; i < E.hw; i += 64)
 		{
@@ -230,9 +236,16 @@ namespace
 			__syncthreads();
 			while (true)
 			{
+#ifdef AGX_SOLVER_PROFILE
+				const unsigned long long r0 = wall_clock64();
+#endif
 				if (lane == 0)
 					sh.cmd = solver_run(sh, E, act, tt, generation);
 				__syncthreads();
+#ifdef AGX_SOLVER_PROFILE
+				const unsigned long long r1 = wall_clock64();
+				c_run += r1 - r0;
+#endif
 				const int cmd = sh.cmd;
 				if (cmd == CMD_ADD)
 					solver_place(sh, E, static_cast<uint32_t>(sh.cmd_move), true, lane);
@@ -240,6 +253,10 @@ namespace
 					solver_place(sh, E, static_cast<uint32_t>(sh.cmd_move), false, lane);
 				else
 					break;
+#ifdef AGX_SOLVER_PROFILE
+				c_place += wall_clock64() - r1;
+				n_place++;
+#endif
 			}
 			int stop = 0;
 			if (lane == 0)
@@ -282,6 +299,18 @@ namespace
 				E.games[g].error = sh.error;
 		}
 		solver_nodes += static_cast<unsigned long long>(sh.node_counter);
+#ifdef AGX_SOLVER_PROFILE
+		if (lane == 0)
+		{
+			GameState &pg = E.games[g];
+			pg.prof[0] += c1 - c0;               // set_board + encode
+			pg.prof[1] += c_run;                 // lane-0 frame machine (move generation, table probes, ordering)
+			pg.prof[2] += c_place;               // place / remove stone
+			pg.prof[3] += n_place;
+			pg.prof[4] += wall_clock64() - c0;   // whole solve
+			pg.prof[5] += 1;
+		}
+#endif
 		__syncthreads();
 	}
 
@@ -1267,6 +1296,16 @@ int agx_engine_stats(AgxEngine *e, AgxEngineStats *out)
 		if (g.error != 0 && out->first_error == 0)
 			out->first_error = g.error;
 	}
+#ifdef AGX_SOLVER_PROFILE
+	{
+		unsigned long long p[8] = { 0 };
+		for (const GameState &g : games)
+			for (int i = 0; i < 8; i++)
+				p[i] += g.prof[i];
+		fprintf(stderr, "[solver profile, 100 MHz ticks] solves %llu: set_board+encode %.1f us, frame machine %.1f us, place/remove %.1f us (%.1f per solve, %.2f us each), total %.1f us per solve\n",
+				p[5], p[0] / 100.0 / p[5], p[1] / 100.0 / p[5], p[2] / 100.0 / p[5], (double) p[3] / p[5], p[2] / 100.0 / (p[3] ? p[3] : 1), p[4] / 100.0 / p[5]);
+	}
+#endif
 	out->games_finished = counters[2];
 	out->openings_taken = counters[1];
 	out->records_used = counters[3];

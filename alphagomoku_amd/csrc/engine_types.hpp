@@ -101,6 +101,7 @@ namespace agx
 			int32_t pad;
 			uint64_t root_hash;
 			uint64_t cboard[BWORDS];
+			unsigned long long prof[8];   // optional cycle counters (AGX_SOLVER_PROFILE builds only)
 			unsigned long long stats[12]; // nodes, nn, leaks, proven, wasted, solver nodes, select levels, select edges, moves, duplicates, max nodes, max edges
 			uint8_t board[MAXHW];
 			uint16_t moves[MAXHW];
