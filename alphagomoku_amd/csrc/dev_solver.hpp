@@ -98,6 +98,7 @@ namespace agx
 				uint8_t must_defend, has_initiative, fully_expanded, pad;
 		};
 		enum Cmd : int { CMD_NONE = 0, CMD_ADD = 1, CMD_UNDO = 2, CMD_DONE = 3 };
+		constexpr int ACT_LDS = 2048;
 
 		struct SolverShared
 		{
@@ -110,6 +111,15 @@ namespace agx
 				uint32_t legal[MAXN];
 				uint32_t added[MAXN];
 				Frame frames[MAX_FRAMES];
+				uint32_t act[ACT_LDS];   // head of the action stack (the tail, if ever needed, spills to HBM)
+				uint32_t row_mask[MAXN]; // scratch row masks of the move generator
+				uint16_t sets[5][32];    // small location sets of the move generator (kept out of per-lane scratch memory)
+				u64 pf_bucket[8];        // transposition-table bucket prefetched for the child about to be entered
+				u64 pf_lo;
+				int pf_valid;
+#ifdef AGX_SOLVER_PROFILE
+				unsigned long long prof[8];
+#endif
 				u64 hash_lo, hash_hi;
 				int sign_to_move, depth;
 				int node_counter, stack_offset, stack_max, level;
@@ -412,17 +422,23 @@ namespace agx
 		}
 
 		/* ---------------- defensive-move lookup (DefensiveMoveTable.cpp:380-461) ---------------- */
+		// line shapes of the attacker (cross stones; circle = 2x), read through the scalar cache
+		__constant__ const uint32_t FIVE[5] = { 85u, 277u, 325u, 337u, 340u };
+		__constant__ const uint32_t OPEN4[4] = { 84u, 276u, 324u, 336u };
+		__constant__ const uint32_t DOUBLE4[6] = { 4177u, 4369u, 4417u, 20549u, 20741u, 86037u };
+		__constant__ const int DOUBLE4_LEN[6] = { 7, 7, 7, 8, 8, 9 };
+		__constant__ const int DOUBLE4_OFF[6] = { 2, 3, 4, 2, 3, 2 };
+		__constant__ const uint32_t HALF4[20] = { 21u, 69u, 81u, 84u, 21u, 261u, 273u, 276u, 69u, 261u, 321u, 324u, 81u, 273u, 321u, 336u, 84u, 276u, 324u, 336u };
+		__constant__ const int HALF4_OFF[20] = { 3, 4, 5, 6, 2, 4, 5, 6, 2, 3, 5, 6, 2, 3, 4, 6, 2, 3, 4, 5 };
+		__constant__ const uint32_t OPEN3[12] = { 20u, 68u, 80u, 20u, 260u, 272u, 68u, 260u, 320u, 80u, 272u, 320u };
+		__constant__ const int OPEN3_OFF[12] = { 3, 4, 5, 2, 4, 5, 2, 3, 5, 2, 3, 4 };
+		__constant__ const uint32_t STENCIL_BOX[7] = { 73u, 62u, 62u, 119u, 62u, 62u, 73u };   // MoveGenerator.cpp:1014-1023
+		__constant__ const uint32_t STENCIL_STAR[7] = { 73u, 42u, 28u, 119u, 28u, 42u, 73u };  // MoveGenerator.cpp:1075-1084
+		__constant__ const int EVAL_OWN[10] = { 0, 0, 19, 49, 76, 170, 33, 159, 252, 0 };      // AlphaBetaSearch.cpp:356-357
+		__constant__ const int EVAL_OPP[10] = { 0, 0, -1, -50, -45, -135, -14, -154, -496, 0 };
+
 		__device__ inline uint32_t defensive_mask(const EngineDev &E, uint32_t pattern, int defender, int threat_to_defend)
 		{
-			const uint32_t FIVE[5] = { 85u, 277u, 325u, 337u, 340u };
-			const uint32_t OPEN4[4] = { 84u, 276u, 324u, 336u };
-			const uint32_t DOUBLE4[6] = { 4177u, 4369u, 4417u, 20549u, 20741u, 86037u };
-			const int DOUBLE4_LEN[6] = { 7, 7, 7, 8, 8, 9 };
-			const int DOUBLE4_OFF[6] = { 2, 3, 4, 2, 3, 2 };
-			const uint32_t HALF4[20] = { 21u, 69u, 81u, 84u, 21u, 261u, 273u, 276u, 69u, 261u, 321u, 324u, 81u, 273u, 321u, 336u, 84u, 276u, 324u, 336u };
-			const int HALF4_OFF[20] = { 3, 4, 5, 6, 2, 4, 5, 6, 2, 3, 5, 6, 2, 3, 4, 6, 2, 3, 4, 5 };
-			const uint32_t OPEN3[12] = { 20u, 68u, 80u, 20u, 260u, 272u, 68u, 260u, 320u, 80u, 272u, 320u };
-			const int OPEN3_OFF[12] = { 3, 4, 5, 2, 4, 5, 2, 3, 5, 2, 3, 4 };
 			const int attacker = 3 - defender;
 			const int d = defender - 1;
 			const uint32_t mul = (attacker == 1) ? 1u : 2u;
@@ -491,9 +507,10 @@ namespace agx
 
 		/* ---------------- staged move generator, lane 0 only (MoveGenerator.cpp:159-1207, non-renju) ---------------- */
 		struct SmallSet
-		{ // StackVector<Location, N> semantics (patterns/common.hpp:154-245)
-				uint16_t v[32];
+		{ // StackVector<Location, N> semantics (patterns/common.hpp:154-245); storage is one of SolverShared::sets
+				uint16_t *v;
 				int n;
+				__device__ explicit SmallSet(uint16_t *storage) : v(storage), n(0) {}
 				__device__ bool contains(int x) const
 				{
 					for (int i = 0; i < n; i++)
@@ -514,15 +531,38 @@ namespace agx
 				}
 		};
 
+		/* The action stack: entries [0, ACT_LDS) live in LDS, deeper ones (a full board of candidate moves on top of a long
+		 * forced line) in the per-game HBM spill area. */
+		__device__ __forceinline__ uint32_t act_get(const SolverShared &sh, const uint32_t *spill, int i) { return (i < ACT_LDS) ? sh.act[i] : spill[i]; }
+		__device__ __forceinline__ void act_set(SolverShared &sh, uint32_t *spill, int i, uint32_t v)
+		{
+			if (i < ACT_LDS)
+				sh.act[i] = v;
+			else
+				spill[i] = v;
+		}
+		/* first index in [begin, end) whose move field equals `move`, or -1 (all lanes call) */
+		__device__ inline int act_find_move(const SolverShared &sh, const uint32_t *spill, int begin, int end, uint32_t move, int lane)
+		{
+			for (int base = begin; base < end; base += 64)
+			{
+				const int j = base + lane;
+				const u64 m = __ballot(j < end && (act_get(sh, spill, j) & 0xFFFFu) == move);
+				if (m != 0)
+					return base + __ffsll(static_cast<long long>(m)) - 1;
+			}
+			return -1;
+		}
+
 		struct MoveGen
 		{
 				SolverShared &sh;
 				const EngineDev &E;
 				uint32_t *act;
 				Frame &f;
-				int n, own, opp;
+				int n, own, opp, lane;
 
-				__device__ MoveGen(SolverShared &s, const EngineDev &e, uint32_t *a, Frame &fr) : sh(s), E(e), act(a), f(fr), n(e.n), own(s.sign_to_move), opp(3 - s.sign_to_move) {}
+				__device__ MoveGen(SolverShared &s, const EngineDev &e, uint32_t *a, Frame &fr, int ln) : sh(s), E(e), act(a), f(fr), n(e.n), own(s.sign_to_move), opp(3 - s.sign_to_move), lane(ln) {}
 				__device__ const uint16_t* list(int sign, int t) const { return sh.lists[sign - 1][t]; }
 				__device__ int count(int sign, int t) const { return sh.count[sign - 1][t]; }
 				__device__ const uint8_t* patterns(int sign, int cell) const { return sh.ptype[cell] + 4 * (sign - 1); }
@@ -545,7 +585,7 @@ namespace agx
 						sh.error = ERR_ACTION_STACK;
 						return;
 					}
-					act[f.base + f.size] = move | (score << 16);
+					act_set(sh, act, f.base + f.size, move | (score << 16));
 					f.size += num;
 					sh.stack_offset += num;
 					sh.stack_max = max(sh.stack_max, sh.stack_offset);
@@ -559,12 +599,9 @@ namespace agx
 						if (override_duplicate)
 						{
 							const uint32_t m = move_of(cell);
-							for (int i = 0; i < f.size; i++)
-								if ((act[f.base + i] & 0xFFFFu) == m)
-								{
-									act[f.base + i] = m | (score << 16);
-									return;
-								}
+							const int at = act_find_move(sh, act, f.base, f.base + f.size, m, lane);
+							if (at >= 0)
+								act_set(sh, act, at, m | (score << 16));
 						}
 					}
 					else
@@ -615,7 +652,7 @@ namespace agx
 				__device__ uint32_t try_solve_own_fork_4x3(int cell)
 				{ // :947-992
 					const int dir = direction_of(patterns(own, cell), 3);
-					SmallSet dm;
+					SmallSet dm(sh.sets[4]);
 					defensive_moves(opp, cell, dir, dm);
 					dm.remove(cell);
 					int best = 0;
@@ -656,33 +693,61 @@ namespace agx
 					if (count(own, 4) > 0)
 						f.has_initiative = 1;
 				}
-				__device__ void stamp(uint32_t *rows, int r, int c, const uint32_t *pattern) const
+				/* 7x7 stencil (vertically and horizontally symmetric) OR-ed around every set bit of `occupied` rows: row R of the result
+				 * only depends on rows R-3..R+3, so each lane builds one row (MoveGenerator.cpp:1011-1126 does it stone by stone). */
+				__device__ uint32_t stencil_row(const uint32_t *stencil, int which_sign) const
 				{
-					for (int i = 0; i < 7; i++)
-					{
-						const int rr = r - 3 + i;
-						if (rr < 0 || rr >= n)
-							continue;
-						const uint32_t p = pattern[i]; // palindromic rows: bit j <-> column c - 3 + j
-						if (c >= 3)
-							rows[rr] |= (p << (c - 3));
-						else
-							rows[rr] |= (p >> (3 - c));
-					}
+					uint32_t m = 0;
+					if (lane < n)
+						for (int dr = -3; dr <= 3; dr++)
+						{
+							const int rr = lane + dr;
+							if (rr < 0 || rr >= n)
+								continue;
+							uint32_t occ = 0;
+							if (which_sign == 0)
+								occ = (~sh.legal[rr]) & ((1u << n) - 1u);
+							else
+								for (int c = 0; c < n; c++)
+									if (sh.board[rr * n + c] == which_sign)
+										occ |= (1u << c);
+							const uint32_t p = stencil[3 - dr];
+							for (int j = 0; j < 7; j++)
+								if ((p >> j) & 1)
+									m |= (j >= 3) ? (occ << (j - 3)) : (occ >> (3 - j));
+						}
+					return m;
 				}
 				__device__ void create_remaining_moves(const uint32_t *mask, uint32_t score)
-				{ // :1127-1137
-					for (int r = 0; r < n; r++)
+				{ // :1127-1137 — row-major append; one row per lane, offsets by a wave prefix sum
+					uint32_t bits = (lane < n) ? (mask[lane] & (~sh.added[lane])) : 0u;
+					const int mine = __popc(bits);
+					int offset = mine;
+					for (int o = 1; o < 32; o <<= 1)
 					{
-						uint32_t bits = mask[r] & (~sh.added[r]);
-						while (bits != 0)
-						{
-							const int c = __ffs(static_cast<int>(bits)) - 1;
-							bits &= bits - 1;
-							push(static_cast<uint32_t>(own) | (r << 2) | (c << 9), score, 1);
-						}
-						sh.added[r] |= mask[r];
+						const int v = __shfl_up(offset, o);
+						if (lane >= o)
+							offset += v;
 					}
+					const int total = __shfl(offset, 31);
+					offset -= mine;
+					if (f.base + f.size + total + 1 >= E.act_cap)
+					{
+						sh.error = ERR_ACTION_STACK;
+						return;
+					}
+					int at = f.base + f.size + offset;
+					while (bits != 0)
+					{
+						const int c = __ffs(static_cast<int>(bits)) - 1;
+						bits &= bits - 1;
+						act_set(sh, act, at++, (static_cast<uint32_t>(own) | (lane << 2) | (c << 9)) | (score << 16));
+					}
+					if (lane < n)
+						sh.added[lane] |= mask[lane];
+					f.size += total;
+					sh.stack_offset += total;
+					sh.stack_max = max(sh.stack_max, sh.stack_offset);
 				}
 
 				// each stage returns true when the cascade must continue; `result` receives the static score
@@ -711,8 +776,7 @@ namespace agx
 						return true;
 					f.must_defend = 1;
 					f.baseline = static_cast<uint16_t>(s_loss_in(2));
-					SmallSet dm, tmp;
-					dm.n = 0;
+					SmallSet dm(sh.sets[0]), tmp(sh.sets[1]);
 					bool initialized = false;
 					for (int k = 0; k < cnt; k++)
 					{
@@ -786,8 +850,7 @@ namespace agx
 				{ // :556-689 (non-renju branch)
 					const bool any_four = has_any_four(own);
 					f.baseline = static_cast<uint16_t>(s_loss_in(4));
-					SmallSet dm, tmp, storage;
-					dm.n = 0;
+					SmallSet dm(sh.sets[0]), tmp(sh.sets[1]), storage(sh.sets[2]);
 					bool initialized = false;
 					const int n_open4 = count(opp, 7);
 					for (int k = 0; k < n_open4; k++)
@@ -875,7 +938,7 @@ namespace agx
 						f.must_defend = 1;
 						f.baseline = static_cast<uint16_t>(s_loss_in(6));
 					}
-					SmallSet tmp, half4;
+					SmallSet tmp(sh.sets[1]), half4(sh.sets[3]);
 					for (int k = 0; k < n43; k++)
 					{
 						const int cell = list(opp, 5)[k];
@@ -922,17 +985,11 @@ namespace agx
 							}
 						add_list(own, 3, s_unknown(13), false);
 						add_list(own, 2, s_unknown(1), false);
-						const uint32_t star[7] = { 73u, 42u, 28u, 119u, 28u, 42u, 73u };
-						uint32_t mask[MAXN];
-						for (int r = 0; r < n; r++)
-							mask[r] = 0;
-						for (int r = 0; r < n; r++)
-							for (int c = 0; c < n; c++)
-								if (sh.board[r * n + c] == own)
-									stamp(mask, r, c, star);
+						if (lane < n)
+							sh.row_mask[lane] = stencil_row(STENCIL_STAR, own);
 						for (int r = 0; r < n; r++)
 						{
-							uint32_t bits = mask[r] & sh.legal[r] & (~sh.added[r]);
+							uint32_t bits = sh.row_mask[r] & sh.legal[r] & (~sh.added[r]);
 							for (int c = 0; c < n; c++, bits >>= 1)
 								if (bits & 1)
 									for (int d = 0; d < 4; d++)
@@ -951,25 +1008,13 @@ namespace agx
 					}
 					return true;
 				}
-				__device__ void mark_neighborhood(uint32_t *out) const
-				{ // :1011-1071
-					const uint32_t box[7] = { 73u, 62u, 62u, 119u, 62u, 62u, 73u };
-					for (int r = 0; r < n; r++)
-						out[r] = 0;
-					for (int r = 0; r < n; r++)
-					{
-						uint32_t occupied = (~sh.legal[r]) & ((1u << n) - 1u);
-						while (occupied != 0)
-						{
-							const int c = __ffs(static_cast<int>(occupied)) - 1;
-							occupied &= occupied - 1;
-							stamp(out, r, c, box);
-						}
-					}
-					if (sh.depth == 0)
-						out[n / 2] |= (1u << (n / 2));
-					for (int r = 0; r < n; r++)
-						out[r] &= sh.legal[r];
+				__device__ void mark_neighborhood() const
+				{ // :1011-1071 -> sh.row_mask
+					uint32_t m = stencil_row(STENCIL_BOX, 0);
+					if (sh.depth == 0 && lane == n / 2)
+						m |= (1u << (n / 2));
+					if (lane < n)
+						sh.row_mask[lane] = m & sh.legal[lane];
 				}
 
 				/* MoveGenerator::generate (:159-223); mode 1 = THREATS, 2 = OPTIMAL */
@@ -1004,9 +1049,8 @@ namespace agx
 						}
 						if (distance_to_draw >= 3)
 							add_list(opp, 4, s_unknown(4), false);
-						uint32_t mask[MAXN];
-						mark_neighborhood(mask);
-						create_remaining_moves(mask, s_unknown(0));
+						mark_neighborhood();
+						create_remaining_moves(sh.row_mask, s_unknown(0));
 					}
 					f.fully_expanded = (f.must_defend || mode >= 2) ? 1 : 0;
 					return result;
@@ -1061,12 +1105,10 @@ namespace agx
 		/* AlphaBetaSearch::evaluate (AlphaBetaSearch.cpp:345-365) */
 		__device__ inline uint32_t solver_evaluate(const SolverShared &sh)
 		{
-			const int own_values[10] = { 0, 0, 19, 49, 76, 170, 33, 159, 252, 0 };
-			const int opp_values[10] = { 0, 0, -1, -50, -45, -135, -14, -154, -496, 0 };
 			const int own = sh.sign_to_move - 1, opp = 1 - own;
 			int result = 12;
 			for (int t = 2; t <= 8; t++)
-				result += own_values[t] * sh.count[own][t] + opp_values[t] * sh.count[opp][t];
+				result += EVAL_OWN[t] * sh.count[own][t] + EVAL_OPP[t] * sh.count[opp][t];
 			return s_unknown(max(-1000, min(1000, result)));
 		}
 
@@ -1075,8 +1117,8 @@ namespace agx
 		 * Runs until a stone must be placed/removed (returns CMD_ADD / CMD_UNDO with sh.cmd_move) or the root returns (CMD_DONE).
 		 * phase: 0 = enter frame `level`, 1 = resume frame `level` after its child returned sh.pending_value.
 		 */
-		__device__ inline int solver_run(SolverShared &sh, const EngineDev &E, uint32_t *act, u64 *tt, int generation)
-		{
+		__device__ inline int solver_run(SolverShared &sh, const EngineDev &E, uint32_t *act, u64 *tt, int generation, int lane)
+		{ // executed by ALL lanes with identical (wave-uniform) state: stores are same-address / same-value, scans are lane-parallel
 			const u64 *zob = E.zob;
 			const int n = E.n;
 			int phase = sh.phase;
@@ -1087,8 +1129,22 @@ namespace agx
 				bool returning = false;
 				if (phase == 0)
 				{ // ---- enter ----
+#ifdef AGX_SOLVER_PROFILE
+					const unsigned long long p0 = wall_clock64();
+#endif
 					f.best_move = 0;
-					const u64 entry = tt_seek(tt, E.tt_bucket_mask, sh.hash_lo, sh.hash_hi);
+					u64 entry;
+					if (sh.pf_valid && sh.pf_lo == sh.hash_lo)
+					{ // bucket fetched while the stone was being placed
+						const u64 KEY = 0xFFFF000000000000ull;
+						entry = tt_pack(0, 0, s_unknown(0), 0);
+						for (int k = 3; k >= 0; k--)
+							if (sh.pf_bucket[2 * k] == sh.hash_hi && (sh.pf_bucket[2 * k + 1] & KEY) == (sh.hash_lo & KEY))
+								entry = sh.pf_bucket[2 * k + 1];
+					}
+					else
+						entry = tt_seek(tt, E.tt_bucket_mask, sh.hash_lo, sh.hash_hi);
+					sh.pf_valid = 0;
 					bool early = false;
 					if ((entry & 3ull) != 0ull)
 					{
@@ -1109,12 +1165,16 @@ namespace agx
 							}
 						}
 					}
+#ifdef AGX_SOLVER_PROFILE
+					const unsigned long long p1 = wall_clock64();
+					sh.prof[0] += p1 - p0; // table seek
+#endif
 					if (!early)
 					{
 						sh.node_counter++;
 						if (f.size == 0)
 						{
-							MoveGen gen(sh, E, act, f);
+							MoveGen gen(sh, E, act, f, lane);
 							const uint32_t static_score = gen.generate(sh.level == 0 ? 2 : 1);
 							if (s_proven(static_score))
 							{
@@ -1123,6 +1183,10 @@ namespace agx
 							}
 						}
 					}
+#ifdef AGX_SOLVER_PROFILE
+					const unsigned long long p2 = wall_clock64();
+					sh.prof[1] += p2 - p1; // move generation
+#endif
 					if (!early && f.depth_remaining <= 0)
 					{
 						value = solver_evaluate(sh);
@@ -1140,13 +1204,16 @@ namespace agx
 				}
 				else if (phase == 1)
 				{ // ---- child returned ----
-					const uint32_t mv = act[f.base + f.i] & 0xFFFFu;
-					act[f.base + f.i] = mv | (s_invert_up(value) << 16);
+					const uint32_t mv = act_get(sh, act, f.base + f.i) & 0xFFFFu;
+					act_set(sh, act, f.base + f.i, mv | (s_invert_up(value) << 16));
 					const int cell = ((mv >> 2) & 127) * n + ((mv >> 9) & 127);
 					sh.hash_lo ^= zob[2 * (2 * cell + ((mv & 3) - 1))];
 					sh.hash_hi ^= zob[2 * (2 * cell + ((mv & 3) - 1)) + 1];
 					phase = 3; // post-child bookkeeping
 				}
+#ifdef AGX_SOLVER_PROFILE
+				const unsigned long long p3 = wall_clock64();
+#endif
 				if (!returning && phase == 2)
 				{ // ---- pick the next action (:253-266) ----
 					if (f.i >= f.size)
@@ -1157,33 +1224,42 @@ namespace agx
 						const bool tt_move_legal = ((bm & 3u) == static_cast<uint32_t>(sh.sign_to_move)) && sh.board[((bm >> 2) & 127) * n + ((bm >> 9) & 127)] == 0;
 						if (f.i == 0 && tt_move_legal)
 						{
-							for (int j = 0; j < f.size; j++)
-								if ((act[f.base + j] & 0xFFFFu) == bm)
-								{
-									const uint32_t t = act[f.base];
-									act[f.base] = act[f.base + j];
-									act[f.base + j] = t;
-									break;
-								}
+							const int at = act_find_move(sh, act, f.base, f.base + f.size, bm, lane);
+							if (at >= 0)
+							{
+								const uint32_t t = act_get(sh, act, f.base);
+								act_set(sh, act, f.base, act_get(sh, act, at));
+								act_set(sh, act, at, t);
+							}
 						}
 						else
-						{
-							int idx = f.i;
-							uint32_t best = act[f.base + idx] >> 16;
-							for (int j = f.i + 1; j < f.size; j++)
+						{ // first maximum of the remaining actions: one action per lane, (score, lowest index) reduction
+							uint32_t best = 0;
+							int idx = 0x7FFFFFFF;
+							for (int j = f.i + lane; j < f.size; j += 64)
 							{
-								const uint32_t sc = act[f.base + j] >> 16;
-								if (best < sc)
+								const uint32_t sc = act_get(sh, act, f.base + j) >> 16;
+								if (idx == 0x7FFFFFFF || best < sc)
 								{
 									best = sc;
 									idx = j;
 								}
 							}
-							const uint32_t t = act[f.base + f.i];
-							act[f.base + f.i] = act[f.base + idx];
-							act[f.base + idx] = t;
+							for (int o = 32; o > 0; o >>= 1)
+							{
+								const uint32_t b2 = static_cast<uint32_t>(__shfl_xor(static_cast<int>(best), o));
+								const int i2 = __shfl_xor(idx, o);
+								if (i2 != 0x7FFFFFFF && (idx == 0x7FFFFFFF || b2 > best || (b2 == best && i2 < idx)))
+								{
+									best = b2;
+									idx = i2;
+								}
+							}
+							const uint32_t t = act_get(sh, act, f.base + f.i);
+							act_set(sh, act, f.base + f.i, act_get(sh, act, f.base + idx));
+							act_set(sh, act, f.base + idx, t);
 						}
-						const uint32_t a = act[f.base + f.i];
+						const uint32_t a = act_get(sh, act, f.base + f.i);
 						if (s_unproven(a >> 16) && sh.node_counter < E.tss_max_nodes)
 						{ // descend (:268-298)
 							if (sh.level + 1 >= MAX_FRAMES)
@@ -1210,6 +1286,15 @@ namespace agx
 								sh.level++;
 								sh.phase = 0;
 								sh.cmd_move = static_cast<int>(mv);
+								// SharedHashTable::prefetch (AlphaBetaSearch.cpp:273): fetch the child's bucket now, it is consumed
+								// when the child frame is entered after the stone has been placed
+								if (lane < 8)
+									sh.pf_bucket[lane] = tt[8 * (sh.hash_lo & E.tt_bucket_mask) + lane];
+								sh.pf_lo = sh.hash_lo;
+								sh.pf_valid = 1;
+#ifdef AGX_SOLVER_PROFILE
+								sh.prof[2] += wall_clock64() - p3; // ordering + descend bookkeeping
+#endif
 								return CMD_ADD;
 							}
 						}
@@ -1219,7 +1304,7 @@ namespace agx
 				}
 				if (!returning && phase == 3)
 				{ // ---- after the action has its score (:299-307) ----
-					const uint32_t a = act[f.base + f.i];
+					const uint32_t a = act_get(sh, act, f.base + f.i);
 					const uint32_t sc = a >> 16;
 					f.best_score = static_cast<uint16_t>(max(static_cast<uint32_t>(f.best_score), sc));
 					if (sc > f.alpha)
@@ -1236,6 +1321,10 @@ namespace agx
 						continue;
 					}
 				}
+#ifdef AGX_SOLVER_PROFILE
+				const unsigned long long p4 = wall_clock64();
+				sh.prof[2] += p4 - p3;
+#endif
 				if (!returning && phase == 4)
 				{ // ---- finish the node (:308-338) ----
 					uint32_t best = f.best_score;
@@ -1249,6 +1338,9 @@ namespace agx
 					tt_insert(tt, E.tt_bucket_mask, sh.hash_lo, sh.hash_hi, tt_pack(bound, f.depth_remaining, best, f.best_move), generation);
 					value = best;
 					returning = true;
+#ifdef AGX_SOLVER_PROFILE
+					sh.prof[3] += wall_clock64() - p4; // evaluate + table insert
+#endif
 				}
 				if (returning)
 				{

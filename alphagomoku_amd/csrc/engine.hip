@@ -210,6 +210,11 @@ namespace
 			sh.stack_offset = 0;
 			sh.stack_max = 0;
 			sh.error = 0;
+			sh.pf_valid = 0;
+#ifdef AGX_SOLVER_PROFILE
+			for (int i = 0; i < 8; i++)
+				sh.prof[i] = 0;
+#endif
 			Frame &f = sh.frames[0];
 			f.base = 0;
 			f.size = 0;
@@ -239,8 +244,9 @@ namespace
 #ifdef AGX_SOLVER_PROFILE
 				const unsigned long long r0 = wall_clock64();
 #endif
+				const int cmd_now = solver_run(sh, E, act, tt, generation, lane);
 				if (lane == 0)
-					sh.cmd = solver_run(sh, E, act, tt, generation);
+					sh.cmd = cmd_now;
 				__syncthreads();
 #ifdef AGX_SOLVER_PROFILE
 				const unsigned long long r1 = wall_clock64();
@@ -273,7 +279,7 @@ namespace
 		const int size = sh.frames[0].size;
 		for (int i = lane; i < size; i += 64)
 		{
-			const uint32_t a = act[i];
+			const uint32_t a = act_get(sh, act, i);
 			t.emove[i] = static_cast<uint16_t>(a & 0xFFFFu);
 			t.escore[i] = static_cast<uint16_t>(a >> 16);
 		}
@@ -309,6 +315,8 @@ namespace
 			pg.prof[3] += n_place;
 			pg.prof[4] += wall_clock64() - c0;   // whole solve
 			pg.prof[5] += 1;
+			pg.prof[6] += sh.prof[0] | (sh.prof[1] << 32);
+			pg.prof[7] += sh.prof[2] | (sh.prof[3] << 32);
 		}
 #endif
 		__syncthreads();
@@ -1298,12 +1306,20 @@ int agx_engine_stats(AgxEngine *e, AgxEngineStats *out)
 	}
 #ifdef AGX_SOLVER_PROFILE
 	{
-		unsigned long long p[8] = { 0 };
+		unsigned long long p[10] = { 0 };
 		for (const GameState &g : games)
-			for (int i = 0; i < 8; i++)
+		{
+			for (int i = 0; i < 6; i++)
 				p[i] += g.prof[i];
+			p[6] += g.prof[6] & 0xFFFFFFFFull;
+			p[7] += g.prof[6] >> 32;
+			p[8] += g.prof[7] & 0xFFFFFFFFull;
+			p[9] += g.prof[7] >> 32;
+		}
 		fprintf(stderr, "[solver profile, 100 MHz ticks] solves %llu: set_board+encode %.1f us, frame machine %.1f us, place/remove %.1f us (%.1f per solve, %.2f us each), total %.1f us per solve\n",
 				p[5], p[0] / 100.0 / p[5], p[1] / 100.0 / p[5], p[2] / 100.0 / p[5], (double) p[3] / p[5], p[2] / 100.0 / (p[3] ? p[3] : 1), p[4] / 100.0 / p[5]);
+		fprintf(stderr, "[frame machine split, us per solve] table seek %.1f, move generation %.1f, ordering %.1f, evaluate+insert %.1f\n",
+				p[6] / 100.0 / p[5], p[7] / 100.0 / p[5], p[8] / 100.0 / p[5], p[9] / 100.0 / p[5]);
 	}
 #endif
 	out->games_finished = counters[2];

@@ -67,14 +67,16 @@ namespace
 			static constexpr int CH = F / 8;                                     // 16-byte chunks per position
 			static constexpr int PPR = (16 / CH) > 0 ? (16 / CH) : 1;            // positions per 256-byte bank row
 			static constexpr int PLANE_BYTES = NPOS * F * 2;
-			static constexpr int MT = F / 64;                                    // 16-channel output tiles per wave
+			static constexpr int MT = F / 64;                                    // 16-channel output tiles per wave (4 channel groups)
+			static constexpr int NTW = (NT + 1) / 2;                             // position tiles per wave (2 position halves)
+			static constexpr int THREADS = 512;                                  // 8 waves = 4 channel groups x 2 position halves, 2 per SIMD
 			static constexpr int MTILES = F / 16;
 			static constexpr int KC = F / 32;                                    // k-steps per tap
 			static constexpr int S5 = S + 4;                                     // row stride of the padded input plane
 			static constexpr int NPOS5 = (ROWS + 4) * S5 + 4;
 			static constexpr int HW = ROWS * COLS;
 			static constexpr int D = (2 * F < 256) ? 2 * F : 256;
-			static constexpr int SCRATCH_FLOATS = HW * 4 + D + 256 + 8;
+			static constexpr int SCRATCH_FLOATS = HW * 4 + D + 256 + 8 + F * 4 + F;
 			static constexpr int LDS_BYTES = 2 * PLANE_BYTES + SCRATCH_FLOATS * 4;
 	};
 
@@ -96,25 +98,34 @@ namespace
 		typedef Geometry<F, ROWS, COLS> G;
 		const int r = lane & 15;
 		const int q4 = lane >> 4;
+		const int mg = wave & 3;                       // channel group: output channels [mg*16*MT, (mg+1)*16*MT)
+		const int n0 = (wave >> 2) * G::NTW;           // first position tile of this wave
+		const int my_tiles = (wave >> 2) ? (G::NT - G::NTW) : G::NTW;
 
-		floatx4 acc[G::MT][G::NT];
+		floatx4 acc[G::MT][G::NTW];
 #pragma unroll
 		for (int i = 0; i < G::MT; i++)
 #pragma unroll
-			for (int n = 0; n < G::NT; n++)
+			for (int n = 0; n < G::NTW; n++)
 				acc[i][n] = floatx4 { 0.0f, 0.0f, 0.0f, 0.0f };
 
-		const half8 *wp = wpk + (wave * G::MT) * 64 + lane;
+		/*
+		 * 9*KC k-steps (one k-step = 32 input channels of one tap).  Two waves share a SIMD, so while one waits for its LDS /
+		 * L2 operands the other issues MFMAs; inside a wave the activation fragments of step s+1 and the weight fragments of
+		 * step s+1 are requested before the MFMAs of step s (two register sets each).
+		 */
+		constexpr int STEPS = 9 * G::KC;
+		const half8 *wp = wpk + (mg * G::MT) * 64 + lane;
 		half8 a_next[G::MT];
 #pragma unroll
 		for (int i = 0; i < G::MT; i++)
 			a_next[i] = wp[i * 64];
-
+#pragma unroll 1
 		for (int t = 0; t < 9; t++)
 		{
 			const int off = (t / 3 - 1) * G::S + (t % 3 - 1);
-			const int index0 = 1 + G::S + r + off; // stored index of this lane's position in tile 0
-			const int swz0 = (index0 / G::PPR) % G::CH; // invariant over tiles: 16 positions == whole bank rows
+			const int index0 = 1 + G::S + n0 * 16 + r + off;    // stored index of this lane's position in the wave's first tile
+			const int swz0 = (index0 / G::PPR) % G::CH;          // invariant over tiles: 16 positions == whole bank rows
 			const char *src0 = src + index0 * G::CH * 16;
 #pragma unroll
 			for (int kc = 0; kc < G::KC; kc++)
@@ -124,20 +135,24 @@ namespace
 				for (int i = 0; i < G::MT; i++)
 					a[i] = a_next[i];
 				const int step = t * G::KC + kc + 1;
-				if (step < 9 * G::KC)
+				if (step < STEPS)
 				{
 #pragma unroll
 					for (int i = 0; i < G::MT; i++)
 						a_next[i] = wp[(step * G::MTILES + i) * 64];
 				}
+				half8 b[G::NTW];
 #pragma unroll
-				for (int n = 0; n < G::NT; n++)
-				{
-					const half8 b = *reinterpret_cast<const half8*>(src0 + n * (16 * G::CH * 16) + (((kc * 4 + q4) ^ swz0) * 16));
+				for (int n = 0; n < G::NTW; n++)
+					b[n] = *reinterpret_cast<const half8*>(src0 + ((n < my_tiles) ? n : 0) * (16 * G::CH * 16) + (((kc * 4 + q4) ^ swz0) * 16));
 #pragma unroll
-					for (int i = 0; i < G::MT; i++)
-						acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b, acc[i][n], 0, 0, 0);
-				}
+				for (int n = 0; n < G::NTW; n++)
+					if (n < my_tiles)
+					{
+#pragma unroll
+						for (int i = 0; i < G::MT; i++)
+							acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[n], acc[i][n], 0, 0, 0);
+					}
 			}
 		}
 
@@ -145,32 +160,33 @@ namespace
 #pragma unroll
 		for (int i = 0; i < G::MT; i++)
 		{
-			const int ch = (wave * G::MT + i) * 16 + 4 * q4;
+			const int ch = (mg * G::MT + i) * 16 + 4 * q4;
 			const floatx4 bv = *reinterpret_cast<const floatx4*>(bias + ch);
 #pragma unroll
-			for (int n = 0; n < G::NT; n++)
-			{
-				const int pos = G::S + n * 16 + r;
-				const int x = pos % G::S;
-				const int y = pos / G::S - 1;
-				const bool valid = (x < COLS) && (y < ROWS);
-				char *ptr = dst + plane_offset<G>(pos + 1, ch / 8) + (ch % 8) * 2;
-				floatx4 v = acc[i][n] + bv;
-				if (SKIP)
+			for (int n = 0; n < G::NTW; n++)
+				if (n < my_tiles)
 				{
-					const half4 s = *reinterpret_cast<const half4*>(ptr);
-					v[0] += static_cast<float>(s[0]);
-					v[1] += static_cast<float>(s[1]);
-					v[2] += static_cast<float>(s[2]);
-					v[3] += static_cast<float>(s[3]);
+					const int pos = G::S + (n0 + n) * 16 + r;
+					const int x = pos % G::S;
+					const int y = pos / G::S - 1;
+					const bool valid = (x < COLS) && (y < ROWS);
+					char *ptr = dst + plane_offset<G>(pos + 1, ch / 8) + (ch % 8) * 2;
+					floatx4 v = acc[i][n] + bv;
+					if (SKIP)
+					{
+						const half4 sk = *reinterpret_cast<const half4*>(ptr);
+						v[0] += static_cast<float>(sk[0]);
+						v[1] += static_cast<float>(sk[1]);
+						v[2] += static_cast<float>(sk[2]);
+						v[3] += static_cast<float>(sk[3]);
+					}
+					half4 o;
+					o[0] = static_cast<half_t>(valid ? fmaxf(v[0], 0.0f) : 0.0f);
+					o[1] = static_cast<half_t>(valid ? fmaxf(v[1], 0.0f) : 0.0f);
+					o[2] = static_cast<half_t>(valid ? fmaxf(v[2], 0.0f) : 0.0f);
+					o[3] = static_cast<half_t>(valid ? fmaxf(v[3], 0.0f) : 0.0f);
+					*reinterpret_cast<half4*>(ptr) = o;
 				}
-				half4 o;
-				o[0] = static_cast<half_t>(valid ? fmaxf(v[0], 0.0f) : 0.0f);
-				o[1] = static_cast<half_t>(valid ? fmaxf(v[1], 0.0f) : 0.0f);
-				o[2] = static_cast<half_t>(valid ? fmaxf(v[2], 0.0f) : 0.0f);
-				o[3] = static_cast<half_t>(valid ? fmaxf(v[3], 0.0f) : 0.0f);
-				*reinterpret_cast<half4*>(ptr) = o;
-			}
 		}
 	}
 
@@ -185,26 +201,30 @@ namespace
 		typedef Geometry<F, ROWS, COLS> G;
 		const int r = lane & 15;
 		const int q4 = lane >> 4;
+		const int mg = wave & 3;
+		const int n0 = (wave >> 2) * G::NTW;
+		const int my_tiles = (wave >> 2) ? (G::NT - G::NTW) : G::NTW;
 
-		floatx4 acc[G::MT][G::NT];
+		floatx4 acc[G::MT][G::NTW];
 #pragma unroll
 		for (int i = 0; i < G::MT; i++)
 #pragma unroll
-			for (int n = 0; n < G::NT; n++)
+			for (int n = 0; n < G::NTW; n++)
 				acc[i][n] = floatx4 { 0.0f, 0.0f, 0.0f, 0.0f };
 
 		// padded-plane index of the (dy = 0, dx = 0) input cell of this lane's position in every tile
-		int q0[G::NT];
+		int q0[G::NTW];
 #pragma unroll
-		for (int n = 0; n < G::NT; n++)
+		for (int n = 0; n < G::NTW; n++)
 		{
-			const int pos = G::S + n * 16 + r;
+			const int pos = G::S + (n0 + n) * 16 + r;
 			const int x = pos % G::S;
 			const int y = pos / G::S - 1;
 			q0[n] = (y + 2) * G::S5 + (x + 2);
 		}
 
-		const half8 *wp = wpk + (wave * G::MT) * 64 + lane;
+		const half8 *wp = wpk + (mg * G::MT) * 64 + lane;
+#pragma unroll 1
 		for (int t = 0; t < 25; t++)
 		{
 			const int off = (t / 5 - 2) * G::S5 + (t % 5 - 2);
@@ -213,37 +233,39 @@ namespace
 			for (int i = 0; i < G::MT; i++)
 				a[i] = wp[(t * G::MTILES + i) * 64];
 #pragma unroll
-			for (int n = 0; n < G::NT; n++)
-			{
-				int q = q0[n] + off;
-				q = (q < 0) ? 0 : ((q >= G::NPOS5) ? (G::NPOS5 - 1) : q); // only dummy (spare-column / overhang) positions can fall outside
-				const half8 b = *reinterpret_cast<const half8*>(in5 + (q * 4 + (q4 ^ ((q >> 2) & 3))) * 16);
+			for (int n = 0; n < G::NTW; n++)
+				if (n < my_tiles)
+				{
+					int q = q0[n] + off;
+					q = (q < 0) ? 0 : ((q >= G::NPOS5) ? (G::NPOS5 - 1) : q); // only dummy (spare-column / overhang) positions can fall outside
+					const half8 b = *reinterpret_cast<const half8*>(in5 + (q * 4 + (q4 ^ ((q >> 2) & 3))) * 16);
 #pragma unroll
-				for (int i = 0; i < G::MT; i++)
-					acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b, acc[i][n], 0, 0, 0);
-			}
+					for (int i = 0; i < G::MT; i++)
+						acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b, acc[i][n], 0, 0, 0);
+				}
 		}
 #pragma unroll
 		for (int i = 0; i < G::MT; i++)
 		{
-			const int ch = (wave * G::MT + i) * 16 + 4 * q4;
+			const int ch = (mg * G::MT + i) * 16 + 4 * q4;
 			const floatx4 bv = *reinterpret_cast<const floatx4*>(bias + ch);
 #pragma unroll
-			for (int n = 0; n < G::NT; n++)
-			{
-				const int pos = G::S + n * 16 + r;
-				const int x = pos % G::S;
-				const int y = pos / G::S - 1;
-				const bool valid = (x < COLS) && (y < ROWS);
-				char *ptr = dst + plane_offset<G>(pos + 1, ch / 8) + (ch % 8) * 2;
-				const floatx4 v = acc[i][n] + bv;
-				half4 o;
-				o[0] = static_cast<half_t>(valid ? fmaxf(v[0], 0.0f) : 0.0f);
-				o[1] = static_cast<half_t>(valid ? fmaxf(v[1], 0.0f) : 0.0f);
-				o[2] = static_cast<half_t>(valid ? fmaxf(v[2], 0.0f) : 0.0f);
-				o[3] = static_cast<half_t>(valid ? fmaxf(v[3], 0.0f) : 0.0f);
-				*reinterpret_cast<half4*>(ptr) = o;
-			}
+			for (int n = 0; n < G::NTW; n++)
+				if (n < my_tiles)
+				{
+					const int pos = G::S + (n0 + n) * 16 + r;
+					const int x = pos % G::S;
+					const int y = pos / G::S - 1;
+					const bool valid = (x < COLS) && (y < ROWS);
+					char *ptr = dst + plane_offset<G>(pos + 1, ch / 8) + (ch % 8) * 2;
+					const floatx4 v = acc[i][n] + bv;
+					half4 o;
+					o[0] = static_cast<half_t>(valid ? fmaxf(v[0], 0.0f) : 0.0f);
+					o[1] = static_cast<half_t>(valid ? fmaxf(v[1], 0.0f) : 0.0f);
+					o[2] = static_cast<half_t>(valid ? fmaxf(v[2], 0.0f) : 0.0f);
+					o[3] = static_cast<half_t>(valid ? fmaxf(v[3], 0.0f) : 0.0f);
+					*reinterpret_cast<half4*>(ptr) = o;
+				}
 		}
 	}
 
@@ -256,7 +278,7 @@ namespace
 		if ((tid & 63) == 0)
 			red[tid >> 6] = v;
 		__syncthreads();
-		return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+		return fmaxf(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])), fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7])));
 	}
 	__device__ __forceinline__ float block_reduce_sum(float v, float *red, int tid)
 	{
@@ -267,11 +289,11 @@ namespace
 		if ((tid & 63) == 0)
 			red[tid >> 6] = v;
 		__syncthreads();
-		return (red[0] + red[1]) + (red[2] + red[3]);
+		return ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
 	}
 
 	template<int F, int ROWS, int COLS>
-	__global__ __launch_bounds__(256, 1) void nn_tower_kernel(NetParams p, const uint32_t *__restrict__ features, float *__restrict__ policy,
+	__global__ __launch_bounds__(512, 2) void nn_tower_kernel(NetParams p, const uint32_t *__restrict__ features, float *__restrict__ policy,
 			float *__restrict__ value)
 	{
 		typedef Geometry<F, ROWS, COLS> G;
@@ -282,7 +304,9 @@ namespace
 		char *plane_t = lds + G::PLANE_BYTES;
 		float *vbuf = reinterpret_cast<float*>(lds + 2 * G::PLANE_BYTES); // [HW*4]
 		float *hid = vbuf + G::HW * 4;                                     // [D]
-		float *red = hid + G::D;                                           // [256 + 8]
+		float *red = hid + G::D;                                           // [256 + 8]: [0..7] wave partials, [256..258] value logits
+		float *s_wv1 = red + 256 + 8;                                      // [F][4] value-head 1x1 weights (kept in LDS, not in registers)
+		float *s_wp2 = s_wv1 + F * 4;                                      // [F] policy-head 1x1 weights
 
 		const int tid = threadIdx.x;
 		const int wave = tid >> 6;
@@ -290,8 +314,12 @@ namespace
 		const int layer_halves8 = 9 * G::KC * G::MTILES * 64; // half8 elements per packed 3x3 layer
 
 		const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
-		for (int i = tid; i < G::PLANE_BYTES / 16; i += 256)
+		for (int i = tid; i < G::PLANE_BYTES / 16; i += G::THREADS)
 			reinterpret_cast<uint4*>(plane_x)[i] = zero4;
+		for (int i = tid; i < F * 4; i += G::THREADS)
+			s_wv1[i] = p.wv1[i];
+		for (int i = tid; i < F; i += G::THREADS)
+			s_wp2[i] = p.wp2[i];
 
 		const int batch = (p.count_ptr != nullptr) ? min(*p.count_ptr, p.batch) : p.batch;
 		for (int bi = blockIdx.x; bi < batch; bi += gridDim.x)
@@ -299,10 +327,10 @@ namespace
 			const int b = (p.slot_list != nullptr) ? p.slot_list[bi] : bi;
 			// ---- stage the bit-unpacked input into the padded plane (aliases plane_t) ----
 			__syncthreads();
-			for (int i = tid; i < G::NPOS5 * 4; i += 256)
+			for (int i = tid; i < G::NPOS5 * 4; i += G::THREADS)
 				reinterpret_cast<uint4*>(plane_t)[i] = zero4;
 			__syncthreads();
-			for (int c = tid; c < G::HW; c += 256)
+			for (int c = tid; c < G::HW; c += G::THREADS)
 			{
 				const uint32_t word = features[static_cast<size_t>(b) * G::HW + c];
 				const int q = (c / COLS + 2) * G::S5 + (c % COLS + 2);
@@ -321,7 +349,7 @@ namespace
 			__syncthreads();
 			conv5x5_input<F, ROWS, COLS>(plane_t, plane_x, p.w_in, p.bias, wave, lane);
 			__syncthreads();
-			for (int i = tid; i < G::PLANE_BYTES / 16; i += 256)
+			for (int i = tid; i < G::PLANE_BYTES / 16; i += G::THREADS)
 				reinterpret_cast<uint4*>(plane_t)[i] = zero4; // restore the zero border of plane_t
 			__syncthreads();
 
@@ -335,7 +363,7 @@ namespace
 			}
 
 			// ---- value head, stage 1: conv1x1 F->4 + ReLU into vbuf (NHWC flatten order) ----
-			for (int c = tid; c < G::HW; c += 256)
+			for (int c = tid; c < G::HW; c += G::THREADS)
 			{
 				const int index = 1 + G::S + (c / COLS) * G::S + (c % COLS);
 				float s0 = p.bv1[0], s1 = p.bv1[1], s2 = p.bv1[2], s3 = p.bv1[3];
@@ -346,7 +374,7 @@ namespace
 					for (int j = 0; j < 8; j++)
 					{
 						const float xf = static_cast<float>(xv[j]);
-						const floatx4 w = *reinterpret_cast<const floatx4*>(p.wv1 + (k * 8 + j) * 4);
+						const floatx4 w = *reinterpret_cast<const floatx4*>(s_wv1 + (k * 8 + j) * 4);
 						s0 += xf * w[0];
 						s1 += xf * w[1];
 						s2 += xf * w[2];
@@ -375,11 +403,11 @@ namespace
 						const half8 tv = *reinterpret_cast<const half8*>(plane_t + plane_offset<G>(index, k));
 #pragma unroll
 						for (int j = 0; j < 8; j++)
-							s += static_cast<float>(tv[j]) * p.wp2[k * 8 + j];
+							s += static_cast<float>(tv[j]) * s_wp2[k * 8 + j];
 					}
 					logit = s;
 				}
-				static_assert(G::HW <= 256, "policy softmax assumes one cell per thread");
+				static_assert(G::HW <= G::THREADS, "policy softmax assumes one cell per thread");
 				const float m = block_reduce_max(logit, red, tid);
 				const float e = (c < G::HW) ? __expf(logit - m) : 0.0f;
 				const float sum = block_reduce_sum(e, red, tid);
@@ -611,9 +639,9 @@ static int launch_forward(AgxNet *net, const uint32_t *d_features, const int *d_
 	const int grid = (batch < net->num_cus) ? batch : net->num_cus;
 	hipStream_t s = static_cast<hipStream_t>(stream);
 	if (net->desc.filters == 128)
-		hipLaunchKernelGGL((nn_tower_kernel<128, 15, 15>), dim3(grid), dim3(256), 0, s, p, d_features, d_policy, d_value);
+		hipLaunchKernelGGL((nn_tower_kernel<128, 15, 15>), dim3(grid), dim3(512), 0, s, p, d_features, d_policy, d_value);
 	else
-		hipLaunchKernelGGL((nn_tower_kernel<64, 15, 15>), dim3(grid), dim3(256), 0, s, p, d_features, d_policy, d_value);
+		hipLaunchKernelGGL((nn_tower_kernel<64, 15, 15>), dim3(grid), dim3(512), 0, s, p, d_features, d_policy, d_value);
 	AGX_HIP_CHECK(hipGetLastError());
 	return AGX_OK;
 }
