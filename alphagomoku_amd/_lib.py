@@ -127,6 +127,13 @@ def _declare(c):  # noqa: F811
         getattr(c, name).argtypes = [vp, vp]
     for name in ["agx_engine_evaluate", "agx_engine_step"]:
         getattr(c, name).argtypes = [vp, vp, vp]
+    for name in ["agx_engine_select_solve_group", "agx_engine_expand_backup_group"]:
+        getattr(c, name).argtypes = [vp, ci, ci, vp]
+    for name in ["agx_engine_evaluate_group", "agx_engine_step_group"]:
+        getattr(c, name).argtypes = [vp, vp, ci, ci, vp]
+    c.agx_stream_create.argtypes = [ctypes.POINTER(vp)]
+    c.agx_stream_destroy.argtypes = [vp]
+    c.agx_stream_synchronize.argtypes = [vp]
     c.agx_engine_buffers.argtypes = [vp, ctypes.POINTER(AgxEngineBuffers)]
     c.agx_engine_stats.argtypes = [vp, ctypes.POINTER(AgxEngineStats)]
     c.agx_engine_game_info.argtypes = [vp, ci, ctypes.POINTER(AgxGameInfo), vp, vp, ci]
@@ -136,3 +143,4 @@ def _declare(c):  # noqa: F811
     c.agx_debug_new_generation.argtypes = [vp]
     c.agx_debug_pattern_state.argtypes = [vp, vp, vp, vp, ci, ci, vp, vp, vp, ci]
     c.agx_host_tables.argtypes = [ci, vp, vp, vp, vp]
+    c.agx_make_opening.argtypes = [ci, ci, ctypes.c_uint32, vp]

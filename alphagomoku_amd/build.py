@@ -10,7 +10,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libagx.so")
 
-SOURCES = ["agx_api.hip", "nn_forward.hip", "engine.hip", "tables_host.cpp"]
+SOURCES = ["agx_api.hip", "nn_forward.hip", "engine.hip", "tables_host.cpp", "host_util.cpp"]
+DRIVER = os.path.join(HERE, "agx_selfplay")
 
 
 def needs_build():
@@ -48,6 +49,12 @@ def build(force=False, verbose=True):
         if p.wait() != 0:
             raise RuntimeError("hipcc failed")
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    # native C++ host driver over the C ABI (include/agx.hpp)
+    cmd = [os.environ.get("CXX", "g++"), "-std=c++17", "-O2", "-o", DRIVER, os.path.join(CSRC, "selfplay_main.cpp"),
+           "-L" + HERE, "-lagx", "-Wl,-rpath," + HERE]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -34,7 +34,7 @@ namespace
 	{
 		__shared__ uint8_t sh_board[MAXHW];
 		__shared__ u64 sh_cboard[BWORDS];
-		const int g = blockIdx.x, lane = threadIdx.x;
+		const int g = E.g0 + blockIdx.x, lane = threadIdx.x;
 		GameState &gs = E.games[g];
 		if (!gs.active || gs.error != 0 || gs.outcome != 0)
 			return;
@@ -325,7 +325,7 @@ namespace
 	__global__ __launch_bounds__(64) void k_solve(EngineDev E)
 	{
 		__shared__ SolverShared sh;
-		const int g = blockIdx.x, lane = threadIdx.x;
+		const int g = E.g0 + blockIdx.x, lane = threadIdx.x;
 		GameState &gs = E.games[g];
 		if (!gs.active || gs.error != 0 || gs.outcome != 0)
 			return;
@@ -344,8 +344,8 @@ namespace
 				t.needs_nn = needs ? 1 : 0;
 				if (needs)
 				{
-					const int idx = atomicAdd(&E.counters[0], 1);
-					E.nn_list[idx] = slot;
+					const int idx = atomicAdd(&E.counters[E.nn_counter], 1);
+					E.nn_list[static_cast<size_t>(E.g0) * E.batch + idx] = slot; // each group owns the list segment of its games
 					scheduled++;
 				}
 			}
@@ -364,7 +364,7 @@ namespace
 		__shared__ float e_prior[MAXHW], e_win[MAXHW], e_draw[MAXHW];
 		__shared__ uint16_t e_move[MAXHW], e_score[MAXHW];
 		__shared__ float sh_sum;
-		const int g = blockIdx.x, lane = threadIdx.x;
+		const int g = E.g0 + blockIdx.x, lane = threadIdx.x;
 		GameState &gs = E.games[g];
 		if (!gs.active || gs.error != 0 || gs.outcome != 0)
 			return;
@@ -726,7 +726,7 @@ namespace
 		__shared__ int red_i[4];
 		__shared__ int sh_int[8];
 		__shared__ int scan_nodes[256], scan_edges[256];
-		const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+		const int g = E.g0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 		GameState &gs = E.games[g];
 		if (!gs.active || gs.error != 0 || !gs.need_move)
 			return;
@@ -936,9 +936,9 @@ namespace
 		}
 	}
 
-	__global__ void k_reset_counter(int *counters)
+	__global__ void k_reset_counter(int *counter)
 	{
-		counters[0] = 0;
+		*counter = 0;
 	}
 
 	/* debug / test kernels --------------------------------------------------------------------------------------- */
@@ -1167,7 +1167,7 @@ int agx_engine_create(const AgxEngineConfig *cfg, AgxEngine **out)
 	AGX_TRY(dev_alloc(e, &d.nn_policy, G * d.batch * d.hw));
 	AGX_TRY(dev_alloc(e, &d.nn_value, G * d.batch * 3));
 	AGX_TRY(dev_alloc(e, &d.nn_list, G * d.batch));
-	AGX_TRY(dev_alloc(e, &d.counters, 16));
+	AGX_TRY(dev_alloc(e, &d.counters, 64));
 	AGX_TRY(dev_alloc(e, &d.records, static_cast<size_t>(d.record_cap)));
 	AGX_TRY(dev_alloc(e, &d.record_edges, static_cast<size_t>(d.record_edge_cap)));
 #undef AGX_TRY
@@ -1175,7 +1175,7 @@ int agx_engine_create(const AgxEngineConfig *cfg, AgxEngine **out)
 	{
 		hipError_t err = hipMemset(d.games, 0, G * sizeof(GameState));
 		if (err == hipSuccess)
-			err = hipMemset(d.counters, 0, 16 * sizeof(int));
+			err = hipMemset(d.counters, 0, 64 * sizeof(int));
 		if (err == hipSuccess)
 			err = hipMemset(d.tasks, 0, G * d.batch * sizeof(DTask));
 		if (err != hipSuccess)
@@ -1215,7 +1215,7 @@ int agx_engine_begin(AgxEngine *e, const uint16_t *h_openings, int n_openings, v
 	AGX_HIP_CHECK(hipMemcpy(d_op, h_openings, static_cast<size_t>(n_openings) * OPENING_CAP * sizeof(uint16_t), hipMemcpyHostToDevice));
 	e->dev.openings = d_op;
 	e->dev.n_openings = n_openings;
-	int counters[16] = { 0 };
+	int counters[64] = { 0 };
 	counters[1] = e->dev.n_games;
 	AGX_HIP_CHECK(hipMemcpy(e->dev.counters, counters, sizeof(counters), hipMemcpyHostToDevice));
 	hipStream_t s = static_cast<hipStream_t>(stream);
@@ -1225,45 +1225,78 @@ int agx_engine_begin(AgxEngine *e, const uint16_t *h_openings, int n_openings, v
 	return AGX_OK;
 }
 
-int agx_engine_select_solve(AgxEngine *e, void *stream)
+/* games [first, first + count) of group `group` out of `n_groups` equal parts of the pool */
+static int group_range(const AgxEngine *e, int group, int n_groups, EngineDev &d, int &count)
+{
+	AGX_REQUIRE(n_groups >= 1 && n_groups <= 32 && group >= 0 && group < n_groups, AGX_ERR_INVALID, "group %d of %d is not valid (1..32 groups)", group, n_groups);
+	const int per = (e->dev.n_games + n_groups - 1) / n_groups;
+	d = e->dev;
+	d.g0 = group * per;
+	count = std::min(per, e->dev.n_games - d.g0);
+	d.nn_counter = 16 + group;
+	AGX_REQUIRE(count > 0, AGX_ERR_INVALID, "group %d of %d is empty for %d games", group, n_groups, e->dev.n_games);
+	return AGX_OK;
+}
+
+int agx_engine_select_solve_group(AgxEngine *e, int group, int n_groups, void *stream)
 {
 	AGX_REQUIRE(e != nullptr, AGX_ERR_INVALID, "agx_engine_select_solve: null engine");
 	AGX_REQUIRE(e->begun, AGX_ERR_STATE, "agx_engine_select_solve: agx_engine_begin has not been called");
+	EngineDev d;
+	int count = 0;
+	const int st = group_range(e, group, n_groups, d, count);
+	if (st != AGX_OK)
+		return st;
 	hipStream_t s = static_cast<hipStream_t>(stream);
-	hipLaunchKernelGGL(k_reset_counter, dim3(1), dim3(1), 0, s, e->dev.counters);
-	hipLaunchKernelGGL(k_select, dim3(e->dev.n_games), dim3(64), 0, s, e->dev);
-	hipLaunchKernelGGL(k_solve, dim3(e->dev.n_games), dim3(64), 0, s, e->dev);
+	hipLaunchKernelGGL(k_reset_counter, dim3(1), dim3(1), 0, s, d.counters + d.nn_counter);
+	hipLaunchKernelGGL(k_select, dim3(count), dim3(64), 0, s, d);
+	hipLaunchKernelGGL(k_solve, dim3(count), dim3(64), 0, s, d);
 	AGX_HIP_CHECK(hipGetLastError());
 	return AGX_OK;
 }
 
-int agx_engine_evaluate(AgxEngine *e, AgxNet *net, void *stream)
+int agx_engine_evaluate_group(AgxEngine *e, AgxNet *net, int group, int n_groups, void *stream)
 {
 	AGX_REQUIRE(e != nullptr && net != nullptr, AGX_ERR_INVALID, "agx_engine_evaluate: null argument");
-	return agx_nn_forward_indirect(net, e->dev.nn_features, e->dev.nn_list, e->dev.counters, e->dev.n_games * e->dev.batch, e->dev.nn_policy, e->dev.nn_value,
-			stream);
+	EngineDev d;
+	int count = 0;
+	const int st = group_range(e, group, n_groups, d, count);
+	if (st != AGX_OK)
+		return st;
+	return agx_nn_forward_indirect(net, d.nn_features, d.nn_list + static_cast<size_t>(d.g0) * d.batch, d.counters + d.nn_counter, count * d.batch, d.nn_policy,
+			d.nn_value, stream);
 }
 
-int agx_engine_expand_backup(AgxEngine *e, void *stream)
+int agx_engine_expand_backup_group(AgxEngine *e, int group, int n_groups, void *stream)
 {
 	AGX_REQUIRE(e != nullptr, AGX_ERR_INVALID, "agx_engine_expand_backup: null engine");
 	AGX_REQUIRE(e->begun, AGX_ERR_STATE, "agx_engine_expand_backup: agx_engine_begin has not been called");
+	EngineDev d;
+	int count = 0;
+	const int st = group_range(e, group, n_groups, d, count);
+	if (st != AGX_OK)
+		return st;
 	hipStream_t s = static_cast<hipStream_t>(stream);
-	hipLaunchKernelGGL(k_expand, dim3(e->dev.n_games), dim3(64), 0, s, e->dev);
-	hipLaunchKernelGGL(k_advance, dim3(e->dev.n_games), dim3(256), 0, s, e->dev);
+	hipLaunchKernelGGL(k_expand, dim3(count), dim3(64), 0, s, d);
+	hipLaunchKernelGGL(k_advance, dim3(count), dim3(256), 0, s, d);
 	AGX_HIP_CHECK(hipGetLastError());
 	return AGX_OK;
 }
 
-int agx_engine_step(AgxEngine *e, AgxNet *net, void *stream)
+int agx_engine_step_group(AgxEngine *e, AgxNet *net, int group, int n_groups, void *stream)
 {
-	int st = agx_engine_select_solve(e, stream);
+	int st = agx_engine_select_solve_group(e, group, n_groups, stream);
 	if (st == AGX_OK)
-		st = agx_engine_evaluate(e, net, stream);
+		st = agx_engine_evaluate_group(e, net, group, n_groups, stream);
 	if (st == AGX_OK)
-		st = agx_engine_expand_backup(e, stream);
+		st = agx_engine_expand_backup_group(e, group, n_groups, stream);
 	return st;
 }
+
+int agx_engine_select_solve(AgxEngine *e, void *stream) { return agx_engine_select_solve_group(e, 0, 1, stream); }
+int agx_engine_evaluate(AgxEngine *e, AgxNet *net, void *stream) { return agx_engine_evaluate_group(e, net, 0, 1, stream); }
+int agx_engine_expand_backup(AgxEngine *e, void *stream) { return agx_engine_expand_backup_group(e, 0, 1, stream); }
+int agx_engine_step(AgxEngine *e, AgxNet *net, void *stream) { return agx_engine_step_group(e, net, 0, 1, stream); }
 
 int agx_engine_buffers(AgxEngine *e, AgxEngineBuffers *out)
 {
@@ -1272,7 +1305,7 @@ int agx_engine_buffers(AgxEngine *e, AgxEngineBuffers *out)
 	out->d_nn_policy = e->dev.nn_policy;
 	out->d_nn_value = e->dev.nn_value;
 	out->d_nn_list = e->dev.nn_list;
-	out->d_nn_count = e->dev.counters;
+	out->d_nn_count = e->dev.counters + 16; /* group 0 of 1 */
 	out->slots = e->dev.n_games * e->dev.batch;
 	out->cells = e->dev.hw;
 	return AGX_OK;
@@ -1431,6 +1464,26 @@ int agx_engine_zobrist(AgxEngine *e, uint64_t *h_keys, size_t n_words)
 	return AGX_OK;
 }
 
+int agx_stream_create(void **out)
+{
+	AGX_REQUIRE(out != nullptr, AGX_ERR_INVALID, "agx_stream_create: null argument");
+	hipStream_t s = nullptr;
+	AGX_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+	*out = s;
+	return AGX_OK;
+}
+int agx_stream_destroy(void *stream)
+{
+	if (stream != nullptr)
+		AGX_HIP_CHECK(hipStreamDestroy(static_cast<hipStream_t>(stream)));
+	return AGX_OK;
+}
+int agx_stream_synchronize(void *stream)
+{
+	AGX_HIP_CHECK(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+	return AGX_OK;
+}
+
 /* ---- test hooks: single stages on caller-supplied positions ---- */
 int agx_debug_solve(AgxEngine *e, const uint8_t *h_boards, const int *h_signs, int count, uint32_t *h_features, uint16_t *h_moves, uint16_t *h_scores,
 		int *h_counts, uint32_t *h_flags, uint16_t *h_result_scores)
@@ -1445,8 +1498,11 @@ int agx_debug_solve(AgxEngine *e, const uint8_t *h_boards, const int *h_signs, i
 	AGX_HIP_CHECK(hipMemcpy(d_boards, h_boards, static_cast<size_t>(count) * d.hw, hipMemcpyHostToDevice));
 	AGX_HIP_CHECK(hipMemcpy(d_signs, h_signs, count * sizeof(int), hipMemcpyHostToDevice));
 	hipLaunchKernelGGL(k_debug_load_tasks, dim3(count), dim3(64), 0, nullptr, d, d_boards, d_signs, count);
-	hipLaunchKernelGGL(k_reset_counter, dim3(1), dim3(1), 0, nullptr, d.counters);
-	hipLaunchKernelGGL(k_solve, dim3(count), dim3(64), 0, nullptr, d);
+	EngineDev dd = d;
+	dd.g0 = 0;
+	dd.nn_counter = 16;
+	hipLaunchKernelGGL(k_reset_counter, dim3(1), dim3(1), 0, nullptr, dd.counters + dd.nn_counter);
+	hipLaunchKernelGGL(k_solve, dim3(count), dim3(64), 0, nullptr, dd);
 	AGX_HIP_CHECK(hipGetLastError());
 	AGX_HIP_CHECK(hipDeviceSynchronize());
 	std::vector<DTask> tasks(1);

@@ -139,6 +139,8 @@ namespace agx
 			int node_cap, edge_cap, ht_cap, act_cap;
 			int record_cap, record_edge_cap;
 			int n_openings;
+			int g0;          // first game handled by this launch (a launch covers games [g0, g0 + gridDim.x): one "group" of the pool)
+			int nn_counter;  // index into counters[] of this group's scheduled-position count
 			// state
 			GameState *games;
 			DNode *nodes;   // [game][arena 0/1][node_cap]
@@ -160,7 +162,7 @@ namespace agx
 			float *nn_policy;      // [game*batch][hw]
 			float *nn_value;       // [game*batch][3]
 			int *nn_list;          // compacted slots to evaluate
-			int *counters;         // [0] nn count, [1] next opening, [2] finished games, [3] records used, [4] record edges used, [5] total moves
+			int *counters;         // [0] (unused), [1] next opening, [2] finished games, [3] records used, [4] record edges used, [5] total moves, [16 + group] positions scheduled for the network by that group
 			// output records
 			MoveRecordHeader *records;
 			DEdge *record_edges;

@@ -1,0 +1,138 @@
+/*
+ * host_util.cpp — host-side helpers of the C ABI that need no GPU: synthetic openings.
+ *
+ * agx_make_opening restates the distribution of the reference's prepareOpening (src/utils/misc.cpp:142-170, with
+ * generateOpeningMap :108-141 and randomizeMove :84-103): max(1, U[0,6)+U[0,6)+U[0,6)) stones (1 in 1000: none), the first one
+ * drawn proportionally to 1.5^-(distance to the board centre - 1), the following ones proportionally to
+ * sum over stones of t^-(distance - 1) with t ~ U[2,3) (plus 1e-6 on every empty cell); an opening whose last stone already
+ * ends the game is rejected and redrawn.  The random stream is std::mt19937(seed) — the reference uses time-seeded thread-local
+ * generators (src/utils/random.cpp:17-23), so streams cannot be matched, only the distribution.
+ */
+#include "agx_internal.hpp"
+#include "tables_host.hpp"
+
+#include <cmath>
+#include <cstring>
+#include <mutex>
+#include <memory>
+#include <random>
+#include <vector>
+
+namespace
+{
+	const agx::HostTables& tables_for(int rules)
+	{
+		static std::mutex mtx;
+		static std::unique_ptr<agx::HostTables> cache[5];
+		std::lock_guard<std::mutex> lock(mtx);
+		if (!cache[rules])
+		{
+			cache[rules].reset(new agx::HostTables());
+			agx::build_host_tables(rules, *cache[rules]);
+		}
+		return *cache[rules];
+	}
+	bool last_move_wins(const agx::HostTables &t, const std::vector<uint8_t> &board, int n, int r, int c, int sign)
+	{ // getOutcome's win test (src/game/rules.cpp:110-122): a FIVE for the mover in any direction through the last stone
+		const int dr[4] = { 0, 1, 1, 1 }, dc[4] = { 1, 0, 1, -1 };
+		for (int d = 0; d < 4; d++)
+		{
+			uint32_t pattern = 0;
+			for (int k = -5, sh = 0; k <= 5; k++, sh += 2)
+			{
+				const int rr = r + k * dr[d], cc = c + k * dc[d];
+				uint32_t v = (rr >= 0 && rr < n && cc >= 0 && cc < n) ? board[rr * n + cc] : 3u;
+				if (k == 0)
+					v = 0;
+				pattern |= v << sh;
+			}
+			const uint32_t idx = (pattern & 1023u) | ((pattern & 4190208u) >> 2);
+			const uint8_t e = t.pattern[idx];
+			if (((sign == 1) ? (e & 15) : (e >> 4)) == 6)
+				return true;
+		}
+		return false;
+	}
+}
+
+extern "C" int agx_make_opening(int rules, int board_size, uint32_t seed, uint16_t *h_opening)
+{
+	AGX_REQUIRE(h_opening != nullptr, AGX_ERR_INVALID, "agx_make_opening: null output");
+	AGX_REQUIRE(rules >= 0 && rules <= AGX_CARO6 && rules != AGX_RENJU, AGX_ERR_UNSUPPORTED, "agx_make_opening: rules %d not supported", rules);
+	AGX_REQUIRE(board_size >= 5 && board_size <= 20, AGX_ERR_INVALID, "agx_make_opening: board size %d", board_size);
+	const agx::HostTables &tables = tables_for(rules);
+	const int n = board_size, hw = n * n;
+	std::mt19937 rng(seed);
+	auto rand_int = [&](int m) { return static_cast<int>(rng() % static_cast<uint32_t>(m)); };
+	auto rand_float = [&]() { return static_cast<float>(rng() >> 8) * (1.0f / 16777216.0f); };
+	std::vector<float> dist(hw, 0.0f);
+	std::vector<uint8_t> board(hw);
+	while (true)
+	{
+		std::fill(board.begin(), board.end(), 0);
+		std::vector<uint16_t> moves;
+		int sign = 1, last_r = 0, last_c = 0;
+		int count = std::max(1, rand_int(6) + rand_int(6) + rand_int(6));
+		if (rand_int(1000) == 0)
+			count = 0;
+		for (int k = 0; k < count; k++)
+		{
+			if (moves.empty())
+			{
+				for (int i = 0; i < n; i++)
+					for (int j = 0; j < n; j++)
+						dist[i * n + j] = static_cast<float>(std::pow(1.5, -(std::hypot(0.5 + i - 0.5 * n, 0.5 + j - 0.5 * n) - 1.0)));
+			}
+			else
+			{
+				for (int i = 0; i < hw; i++)
+					dist[i] = (board[i] != 0) ? 0.0f : 1.0e-6f;
+				const float t = 2.0f + rand_float();
+				for (int p = 0; p < n; p++)
+					for (int q = 0; q < n; q++)
+						if (board[p * n + q] != 0)
+							for (int i = 0; i < n; i++)
+								for (int j = 0; j < n; j++)
+									if (board[i * n + j] == 0)
+										dist[i * n + j] += static_cast<float>(std::pow(t, -(std::hypot(static_cast<double>(i - p), static_cast<double>(j - q)) - 1.0)));
+			}
+			float total = 0.0f;
+			for (int i = 0; i < hw; i++)
+				total += dist[i];
+			const float pick = total * rand_float();
+			float acc = 0.0f;
+			int cell = -1;
+			for (int i = 0; i < hw; i++)
+			{
+				acc += dist[i];
+				if (pick < acc)
+				{
+					cell = i;
+					break;
+				}
+			}
+			if (cell < 0 || board[cell] != 0)
+			{ // rounding tail: take the last empty cell
+				for (int i = hw - 1; i >= 0; i--)
+					if (board[i] == 0)
+					{
+						cell = i;
+						break;
+					}
+			}
+			board[cell] = static_cast<uint8_t>(sign);
+			last_r = cell / n;
+			last_c = cell % n;
+			moves.push_back(static_cast<uint16_t>(sign | (last_r << 2) | (last_c << 9)));
+			sign = 3 - sign;
+		}
+		if (moves.empty() || !last_move_wins(tables, board, n, last_r, last_c, 3 - sign))
+		{
+			std::memset(h_opening, 0, AGX_OPENING_CAP * sizeof(uint16_t));
+			h_opening[0] = static_cast<uint16_t>(moves.size());
+			for (size_t i = 0; i < moves.size(); i++)
+				h_opening[1 + i] = moves[i];
+			return AGX_OK;
+		}
+	}
+}

@@ -60,6 +60,18 @@ class GeneratorPool:
     def step(self, net, stream=None):
         check(lib.agx_engine_step(self._h, net._net, stream))
 
+    def step_group(self, net, group, n_groups, stream=None):
+        check(lib.agx_engine_step_group(self._h, net._net, group, n_groups, stream))
+
+    def select_solve_group(self, group, n_groups, stream=None):
+        check(lib.agx_engine_select_solve_group(self._h, group, n_groups, stream))
+
+    def evaluate_group(self, net, group, n_groups, stream=None):
+        check(lib.agx_engine_evaluate_group(self._h, net._net, group, n_groups, stream))
+
+    def expand_backup_group(self, group, n_groups, stream=None):
+        check(lib.agx_engine_expand_backup_group(self._h, group, n_groups, stream))
+
     # ---- external evaluation plumbing (tests) ----
     def scheduled(self):
         """returns (slot list, features uint32 [n][cells]) of the positions awaiting evaluation"""

@@ -53,58 +53,14 @@ def random_features(batch, rows, cols, seed=0):
     return words
 
 
-def _has_five(board, n):
-    """any run of >= 5 equal stones (conservative terminal test for synthetic openings)"""
-    for r in range(n):
-        for c in range(n):
-            s = board[r, c]
-            if s == 0:
-                continue
-            for dr, dc in ((0, 1), (1, 0), (1, 1), (1, -1)):
-                k = 1
-                rr, cc = r + dr, c + dc
-                while 0 <= rr < n and 0 <= cc < n and board[rr, cc] == s:
-                    k += 1
-                    rr += dr
-                    cc += dc
-                if k >= 5:
-                    return True
-    return False
-
-
-def make_opening(n, seed):
-    """Random opening in the spirit of the reference's prepareOpening (src/utils/misc.cpp:108-170): the number of stones is
-    max(1, U[0,6)+U[0,6)+U[0,6)) (1 in 1000: empty board); the first stone is drawn ∝ 1.5^-(distance to centre - 1), the next
-    ones ∝ Σ_stones t^-(distance - 1) with t ~ U[2,3); openings that already contain a five are rejected.
-    Returns a list of Move::toShort values (sign | row << 2 | col << 9), cross first."""
-    rng = np.random.default_rng(seed)
-    rows, cols = np.mgrid[0:n, 0:n]
-    while True:
-        board = np.zeros((n, n), dtype=np.int8)
-        moves = []
-        count = max(1, int(rng.integers(0, 6)) + int(rng.integers(0, 6)) + int(rng.integers(0, 6)))
-        if rng.integers(0, 1000) == 0:
-            count = 0
-        sign = 1
-        for _ in range(count):
-            if not moves:
-                d = np.hypot(0.5 + rows - 0.5 * n, 0.5 + cols - 0.5 * n) - 1.0
-                w = np.power(1.5, -d)
-            else:
-                t = 2.0 + rng.random()
-                w = np.full((n, n), 1.0e-6)
-                for (r, c) in zip(*np.nonzero(board)):
-                    w += np.power(t, -(np.hypot(rows - r, cols - c) - 1.0))
-                w[board != 0] = 0.0
-            p = (w / w.sum()).reshape(-1)
-            cell = int(rng.choice(n * n, p=p))
-            r, c = divmod(cell, n)
-            board[r, c] = sign
-            moves.append(sign | (r << 2) | (c << 9))
-            sign = 3 - sign
-        if not _has_five(board, n):
-            return moves
-
-
-def make_openings(n, count, seed0=0):
-    return [make_opening(n, seed0 + i) for i in range(count)]
+def make_openings(n, count, seed0=0, rules=0):
+    """`count` synthetic random openings from the library's restatement of the reference's prepareOpening
+    (agx_make_opening, csrc/host_util.cpp); returns lists of Move::toShort words (cross first)."""
+    import ctypes
+    from ._lib import lib, check
+    out = []
+    buf = np.zeros(32, dtype=np.uint16)
+    for i in range(count):
+        check(lib.agx_make_opening(rules, n, seed0 + i, buf.ctypes.data_as(ctypes.c_void_p)))
+        out.append([int(x) for x in buf[1:1 + int(buf[0])]])
+    return out

@@ -179,6 +179,10 @@ typedef struct AgxMoveRecord
 
 #define AGX_OPENING_CAP 32 /* uint16 per opening: [0] = number of stones, [1..] = Move::toShort */
 
+/* Host-only: one synthetic random opening with the distribution of the reference's prepareOpening (utils/misc.cpp:142-170);
+ * h_opening receives AGX_OPENING_CAP words ([0] = stones, then Move::toShort, cross first). */
+int agx_make_opening(int rules, int board_size, uint32_t seed, uint16_t* h_opening);
+
 int agx_engine_default_config(AgxEngineConfig* cfg);
 int agx_engine_create(const AgxEngineConfig* cfg, AgxEngine** out);
 int agx_engine_destroy(AgxEngine* engine);
@@ -190,6 +194,16 @@ int agx_engine_select_solve(AgxEngine* engine, void* stream);
 int agx_engine_evaluate(AgxEngine* engine, AgxNet* net, void* stream);
 int agx_engine_expand_backup(AgxEngine* engine, void* stream);
 int agx_engine_step(AgxEngine* engine, AgxNet* net, void* stream);
+/* The same stages restricted to group `group` of `n_groups` equal slices of the pool.  Games are independent, so slices can be
+ * driven from different streams and drift apart: while one slice waits for its slowest solver wave, the others use the CUs
+ * (this is how bench.py runs the pool).  Results per game do not depend on the grouping. */
+int agx_engine_select_solve_group(AgxEngine* engine, int group, int n_groups, void* stream);
+int agx_engine_evaluate_group(AgxEngine* engine, AgxNet* net, int group, int n_groups, void* stream);
+int agx_engine_expand_backup_group(AgxEngine* engine, int group, int n_groups, void* stream);
+int agx_engine_step_group(AgxEngine* engine, AgxNet* net, int group, int n_groups, void* stream);
+int agx_stream_create(void** out_stream);
+int agx_stream_destroy(void* stream);
+int agx_stream_synchronize(void* stream);
 int agx_engine_buffers(AgxEngine* engine, AgxEngineBuffers* out);
 int agx_engine_stats(AgxEngine* engine, AgxEngineStats* out);
 /* Tree::getInfo({}) of one game (Tree.cpp:403-424): root snapshot + board. */

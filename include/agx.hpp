@@ -1,0 +1,204 @@
+/*
+ * agx.hpp — C++ host facade over the C ABI (agx.h), mirroring the reference's operator interface for the self-play path.
+ *
+ * Same names, argument meaning and error behaviour as the reference classes it stands in for:
+ *   agx::AGNetwork      <- ag::AGNetwork   (include/alphagomoku/networks/AGNetwork.hpp:60-98): loadWeights / forward / setBatchSize-free
+ *   agx::NNEvaluator    <- ag::NNEvaluator (include/alphagomoku/search/monte_carlo/NNEvaluator.hpp:61-77): evaluateGraph over the engine's queue
+ *   agx::GeneratorPool  <- one ag::GeneratorThread with its GameGenerators (src/selfplay/GeneratorManager.cpp:124-141,
+ *                          src/selfplay/GameGenerator.cpp:46-121): generate() = one select/solve/evaluate/expand/backup/move step
+ * Errors surface as std::runtime_error / std::logic_error exactly where the reference throws (NNEvaluator.cpp:149,185-187).
+ * Header-only; link with -lagx.
+ */
+#ifndef AGX_HPP_
+#define AGX_HPP_
+
+#include "agx.h"
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace agx
+{
+	inline void check(int status)
+	{
+		if (status == AGX_OK)
+			return;
+		const std::string msg = agx_last_error();
+		if (status == AGX_ERR_INVALID || status == AGX_ERR_STATE)
+			throw std::logic_error(msg);
+		throw std::runtime_error(msg);
+	}
+
+	struct GameConfig
+	{ // ag::GameConfig (utils/configs.hpp:23-44)
+			int rules = AGX_FREESTYLE;
+			int rows = 15, cols = 15;
+			int draw_after = 225;
+	};
+
+	class AGNetwork
+	{
+			AgxNet *m_net = nullptr;
+			AgxNetDesc m_desc { };
+		public:
+			AGNetwork(const GameConfig &cfg, int blocks, int filters)
+			{
+				m_desc.rows = cfg.rows;
+				m_desc.cols = cfg.cols;
+				m_desc.blocks = blocks;
+				m_desc.filters = filters;
+				m_desc.in_channels = 32;
+				m_desc.value_hidden = (2 * filters < 256) ? 2 * filters : 256;
+				check(agx_net_create(&m_desc, &m_net));
+			}
+			AGNetwork(const AGNetwork&) = delete;
+			AGNetwork& operator=(const AGNetwork&) = delete;
+			~AGNetwork()
+			{
+				agx_net_destroy(m_net);
+			}
+			size_t numberOfWeights() const
+			{
+				return agx_net_blob_floats(&m_desc);
+			}
+			void loadWeights(const std::vector<float> &blob)
+			{
+				check(agx_net_load_weights(m_net, blob.data(), blob.size()));
+			}
+			/* device buffers: features uint32[batch][rows*cols] -> policy float[batch][rows*cols], value float[batch][3] */
+			void forward(const uint32_t *d_features, int batch, float *d_policy, float *d_value, void *stream = nullptr)
+			{
+				check(agx_nn_forward(m_net, d_features, batch, d_policy, d_value, stream));
+			}
+			AgxNet* handle() const noexcept
+			{
+				return m_net;
+			}
+			const AgxNetDesc& description() const noexcept
+			{
+				return m_desc;
+			}
+	};
+
+	struct SearchConfig
+	{ // the fields of ag::SearchConfig / MCTSConfig / EdgeSelectorConfig / TreeConfig / TSSConfig that the path reads
+			int max_batch_size = 8;
+			float exploration_constant = 1.25f;
+			float exploration_scaling = 0.0f;
+			std::string init_to = "q_head";
+			float policy_expansion_threshold = 1.0e-4f;
+			float information_leak_threshold = 0.01f;
+			int tss_max_positions = 100;
+			uint64_t tss_table_entries = 4ull * 1024ull * 1024ull;
+	};
+
+	struct SelfplayConfig
+	{ // ag::SelfplayConfig subset (utils/configs.hpp:205-255)
+			int games_per_thread = 1024;
+			int max_simulations = 400;
+			SearchConfig search_config;
+	};
+
+	class GeneratorPool
+	{
+			AgxEngine *m_engine = nullptr;
+			AgxEngineBuffers m_buffers { };
+		public:
+			GeneratorPool(const GameConfig &game, const SelfplayConfig &selfplay)
+			{
+				AgxEngineConfig c;
+				check(agx_engine_default_config(&c));
+				c.rules = game.rules;
+				c.board_size = game.rows;
+				c.draw_after = game.draw_after;
+				c.n_games = selfplay.games_per_thread;
+				c.max_batch_size = selfplay.search_config.max_batch_size;
+				c.max_simulations = selfplay.max_simulations;
+				c.exploration_constant = selfplay.search_config.exploration_constant;
+				c.exploration_scaling = selfplay.search_config.exploration_scaling;
+				const std::string &init = selfplay.search_config.init_to;
+				c.init_to = (init == "q_head") ? 0 : (init == "parent") ? 1 : (init == "draw") ? 2 : 3; // EdgeSelector.cpp:1140-1165
+				c.policy_expansion_threshold = selfplay.search_config.policy_expansion_threshold;
+				c.information_leak_threshold = selfplay.search_config.information_leak_threshold;
+				c.tss_max_positions = selfplay.search_config.tss_max_positions;
+				c.tss_table_entries = selfplay.search_config.tss_table_entries;
+				if (game.rows != game.cols)
+					throw std::logic_error("GeneratorPool: only square boards are supported");
+				check(agx_engine_create(&c, &m_engine));
+				check(agx_engine_buffers(m_engine, &m_buffers));
+			}
+			GeneratorPool(const GeneratorPool&) = delete;
+			GeneratorPool& operator=(const GeneratorPool&) = delete;
+			~GeneratorPool()
+			{
+				agx_engine_destroy(m_engine);
+			}
+			/* openings: n x AGX_OPENING_CAP uint16 ([0] = stone count, then Move::toShort words), cf. prepareOpening (utils/misc.cpp:142-170) */
+			void begin(const std::vector<uint16_t> &openings, void *stream = nullptr)
+			{
+				if (openings.empty() || openings.size() % AGX_OPENING_CAP != 0)
+					throw std::logic_error("GeneratorPool::begin: openings must hold a positive multiple of AGX_OPENING_CAP words");
+				check(agx_engine_begin(m_engine, openings.data(), static_cast<int>(openings.size() / AGX_OPENING_CAP), stream));
+			}
+			/* GameGenerator::generate for every game of the pool: one select -> solve -> evaluate -> expand/backup -> move step */
+			void generate(AGNetwork &network, void *stream = nullptr)
+			{
+				check(agx_engine_step(m_engine, network.handle(), stream));
+			}
+			/* the three stages separately (Search::select+solve+scheduleToNN / NNEvaluator::evaluateGraph / generateEdges+expand+backup) */
+			void selectSolveSchedule(void *stream = nullptr)
+			{
+				check(agx_engine_select_solve(m_engine, stream));
+			}
+			void evaluateGraph(AGNetwork &network, void *stream = nullptr)
+			{
+				check(agx_engine_evaluate(m_engine, network.handle(), stream));
+			}
+			void expandBackup(void *stream = nullptr)
+			{
+				check(agx_engine_expand_backup(m_engine, stream));
+			}
+			AgxEngineStats getStats() const
+			{
+				AgxEngineStats s;
+				check(agx_engine_stats(m_engine, &s));
+				return s;
+			}
+			/* Tree::getInfo({}) of one game */
+			AgxGameInfo getInfo(int game, std::vector<AgxEdgeView> *root_edges = nullptr, std::vector<uint8_t> *board = nullptr) const
+			{
+				AgxGameInfo info;
+				std::vector<AgxEdgeView> edges(400);
+				std::vector<uint8_t> b(m_buffers.cells);
+				check(agx_engine_game_info(m_engine, game, &info, b.data(), edges.data(), static_cast<int>(edges.size())));
+				if (root_edges != nullptr)
+					root_edges->assign(edges.begin(), edges.begin() + info.root_edges);
+				if (board != nullptr)
+					*board = b;
+				return info;
+			}
+			/* samples produced so far (one per played move): what GameGenerator::make_move hands to GameDataStorage */
+			void getRecords(std::vector<AgxMoveRecord> &records, std::vector<AgxEdgeView> &edges) const
+			{
+				int nr = 0, ne = 0;
+				check(agx_engine_records(m_engine, nullptr, 0, nullptr, 0, &nr, &ne));
+				records.resize(nr > 0 ? nr : 1);
+				edges.resize(ne > 0 ? ne : 1);
+				check(agx_engine_records(m_engine, records.data(), nr, edges.data(), ne, &nr, &ne));
+				records.resize(nr);
+				edges.resize(ne);
+			}
+			const AgxEngineBuffers& buffers() const noexcept
+			{
+				return m_buffers;
+			}
+			AgxEngine* handle() const noexcept
+			{
+				return m_engine;
+			}
+	};
+}
+
+#endif /* AGX_HPP_ */
