@@ -76,7 +76,7 @@ namespace
 			static constexpr int NPOS5 = (ROWS + 4) * S5 + 4;
 			static constexpr int HW = ROWS * COLS;
 			static constexpr int D = (2 * F < 256) ? 2 * F : 256;
-			static constexpr int SCRATCH_FLOATS = HW * 4 + D + 256 + 8 + F * 4 + F;
+			static constexpr int SCRATCH_FLOATS = HW * 4 + D + 8 + 256 + 8 + F * 4 + F;
 			static constexpr int LDS_BYTES = 2 * PLANE_BYTES + SCRATCH_FLOATS * 4;
 	};
 
@@ -115,11 +115,15 @@ namespace
 		 * step s+1 are requested before the MFMAs of step s (two register sets each).
 		 */
 		constexpr int STEPS = 9 * G::KC;
+		constexpr int RING = (G::KC == 4) ? 4 : 2; // weight fragments are fetched RING-1 k-steps ahead (L2 latency > one k-step of MFMAs)
+		static_assert(G::KC % RING == 0, "ring index must be static inside the unrolled k loop");
 		const half8 *wp = wpk + (mg * G::MT) * 64 + lane;
-		half8 a_next[G::MT];
+		half8 a_ring[RING][G::MT];
 #pragma unroll
-		for (int i = 0; i < G::MT; i++)
-			a_next[i] = wp[i * 64];
+		for (int u = 0; u < RING - 1; u++)
+#pragma unroll
+			for (int i = 0; i < G::MT; i++)
+				a_ring[u][i] = wp[(u * G::MTILES + i) * 64];
 #pragma unroll 1
 		for (int t = 0; t < 9; t++)
 		{
@@ -130,16 +134,12 @@ namespace
 #pragma unroll
 			for (int kc = 0; kc < G::KC; kc++)
 			{
-				half8 a[G::MT];
-#pragma unroll
-				for (int i = 0; i < G::MT; i++)
-					a[i] = a_next[i];
-				const int step = t * G::KC + kc + 1;
-				if (step < STEPS)
+				const int ahead = t * G::KC + kc + RING - 1;
+				if (ahead < STEPS)
 				{
 #pragma unroll
 					for (int i = 0; i < G::MT; i++)
-						a_next[i] = wp[(step * G::MTILES + i) * 64];
+						a_ring[(kc + RING - 1) % RING][i] = wp[(ahead * G::MTILES + i) * 64];
 				}
 				half8 b[G::NTW];
 #pragma unroll
@@ -151,7 +151,7 @@ namespace
 					{
 #pragma unroll
 						for (int i = 0; i < G::MT; i++)
-							acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[n], acc[i][n], 0, 0, 0);
+							acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_ring[kc % RING][i], b[n], acc[i][n], 0, 0, 0);
 					}
 			}
 		}
@@ -304,8 +304,8 @@ namespace
 		char *plane_t = lds + G::PLANE_BYTES;
 		float *vbuf = reinterpret_cast<float*>(lds + 2 * G::PLANE_BYTES); // [HW*4]
 		float *hid = vbuf + G::HW * 4;                                     // [D]
-		float *red = hid + G::D;                                           // [256 + 8]: [0..7] wave partials, [256..258] value logits
-		float *s_wv1 = red + 256 + 8;                                      // [F][4] value-head 1x1 weights (kept in LDS, not in registers)
+		float *red = hid + G::D;                                           // [8 + 256 + 8]: [0..7] wave partials, [8..8+D) value-head partials, [264..266] value logits
+		float *s_wv1 = red + 8 + 256 + 8;                                      // [F][4] value-head 1x1 weights (kept in LDS, not in registers)
 		float *s_wp2 = s_wv1 + F * 4;                                      // [F] policy-head 1x1 weights
 
 		const int tid = threadIdx.x;
@@ -416,14 +416,27 @@ namespace
 			}
 
 			// ---- value head, stage 2: dense HW*4 -> D + ReLU, dense D -> 3, softmax ----
-			if (tid < G::D)
-			{
-				float s = p.bv2[tid];
-				const half_t *w = p.wv2 + tid;
-#pragma unroll 4
-				for (int i = 0; i < G::HW * 4; i++)
-					s += vbuf[i] * static_cast<float>(w[static_cast<size_t>(i) * G::D]);
-				hid[tid] = fmaxf(s, 0.0f);
+			{ // every thread owns one hidden unit and one half of the 4*HW inputs; the halves meet in LDS
+				static_assert(2 * G::D <= G::THREADS, "value head assumes two threads per hidden unit");
+				constexpr int HALF = (G::HW * 4) / 2;
+				const int j = tid % G::D, part = tid / G::D;
+				float s0 = 0.0f, s1 = 0.0f;
+				if (part < 2)
+				{
+					const half_t *w = p.wv2 + static_cast<size_t>(part * HALF) * G::D + j;
+					const float *x = vbuf + part * HALF;
+#pragma unroll 10
+					for (int i = 0; i < HALF; i += 2)
+					{
+						s0 += x[i] * static_cast<float>(w[static_cast<size_t>(i) * G::D]);
+						s1 += x[i + 1] * static_cast<float>(w[static_cast<size_t>(i + 1) * G::D]);
+					}
+				}
+				if (part == 1)
+					red[8 + j] = s0 + s1; // red[8 .. 8 + D) is free here (D <= 248 is not guaranteed, so use the tail of the scratch area)
+				__syncthreads();
+				if (part == 0)
+					hid[j] = fmaxf((s0 + s1) + red[8 + j] + p.bv2[j], 0.0f);
 			}
 			__syncthreads();
 			if (wave < 3)
@@ -435,12 +448,12 @@ namespace
 				for (int o = 32; o > 0; o >>= 1)
 					s += __shfl_xor(s, o);
 				if (lane == 0)
-					red[256 + wave] = s + p.bv3[wave];
+					red[264 + wave] = s + p.bv3[wave];
 			}
 			__syncthreads();
 			if (tid == 0)
 			{
-				const float z0 = red[256], z1 = red[257], z2 = red[258];
+				const float z0 = red[264], z1 = red[265], z2 = red[266];
 				const float m = fmaxf(z0, fmaxf(z1, z2));
 				const float e0 = __expf(z0 - m), e1 = __expf(z1 - m), e2 = __expf(z2 - m);
 				const float inv = 1.0f / (e0 + e1 + e2);
