@@ -28,6 +28,17 @@ namespace agx
 	{
 		typedef uint64_t u64;
 
+		/* Solver Zobrist keys (FastZobristHashing, ZobristHashing.cpp:35-43 draws 2*HW 128-bit keys from an RNG): key word j is the
+		 * j-th output of splitmix64 seeded with the engine's zobrist_seed, so it can be recomputed in registers instead of being
+		 * gathered from memory (lo word of (cell, colour) = output 2*(2*cell + colour - 1), hi word = the next one). */
+		__device__ __forceinline__ u64 zobrist_word(u64 seed, uint32_t j)
+		{
+			u64 z = seed + (static_cast<u64>(j) + 1ull) * 0x9E3779B97F4A7C15ull;
+			z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+			z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+			return z ^ (z >> 31);
+		}
+
 		/* ---------------- Score algebra on raw 16-bit values (search/Score.hpp:47-320) ---------------- */
 		__device__ __forceinline__ int s_pv(uint32_t d) { return (d >> 13) & 3; }
 		__device__ __forceinline__ int s_eval(uint32_t d) { return static_cast<int>(d & 8191u) - 4000; }
@@ -149,7 +160,7 @@ namespace agx
 		__device__ __forceinline__ uint32_t narrow(uint32_t x) { return (x & 1023u) | ((x & 4190208u) >> 2); }
 		__device__ __forceinline__ uint32_t threat_index(const uint8_t *pt) { return pt[0] | (pt[1] << 3) | (pt[2] << 6) | (pt[3] << 9); }
 
-		__device__ inline void list_add(SolverShared &sh, int s, int t, int cell, int lane)
+		__device__ __forceinline__ void list_add(SolverShared &sh, int s, int t, int cell, int lane)
 		{ // ThreatHistogram::add (ThreatHistogram.hpp:101-111)
 			if (t != 0 && lane == 0)
 			{
@@ -158,7 +169,7 @@ namespace agx
 				sh.count[s][t] = static_cast<uint16_t>(cnt + 1);
 			}
 		}
-		__device__ inline void list_remove(SolverShared &sh, int s, int t, int cell, int lane)
+		__device__ __forceinline__ void list_remove(SolverShared &sh, int s, int t, int cell, int lane)
 		{ // ThreatHistogram::remove (:39-99): first match is overwritten by the last element
 			if (t == 0)
 				return;
@@ -179,7 +190,7 @@ namespace agx
 		}
 
 		/* PatternCalculator::setBoard (PatternCalculator.cpp:40-66, 245-277) */
-		__device__ inline void solver_set_board(SolverShared &sh, const EngineDev &E, const uint8_t *board, int sign_to_move, int lane)
+		__device__ __forceinline__ void solver_set_board(SolverShared &sh, const EngineDev &E, const uint8_t *board, int sign_to_move, int lane)
 		{
 			const int n = E.n, hw = E.hw;
 			for (int i = lane; i < hw; i += 64)
@@ -290,7 +301,7 @@ namespace agx
 
 		/* PatternCalculator::update_around (PatternCalculator.cpp:278-367): the centre cell, then the +-5 cells in the four
 		 * directions in the order k = -5..5 (k != 0), direction 0..3 — one lane per (k, direction). */
-		__device__ inline void solver_update_around(SolverShared &sh, const EngineDev &E, int r, int c, bool added, int lane)
+		__device__ __forceinline__ void solver_update_around(SolverShared &sh, const EngineDev &E, int r, int c, bool added, int lane)
 		{
 			const int n = E.n;
 			const int center = r * n + c;
@@ -369,7 +380,7 @@ namespace agx
 				__syncthreads();
 			}
 		}
-		__device__ inline void solver_place(SolverShared &sh, const EngineDev &E, uint32_t move, bool add, int lane)
+		__device__ __forceinline__ void solver_place(SolverShared &sh, const EngineDev &E, uint32_t move, bool add, int lane)
 		{ // PatternCalculator::addMove / undoMove (PatternCalculator.cpp:68-105)
 			const int n = E.n;
 			const int s = move & 3, r = (move >> 2) & 127, c = (move >> 9) & 127;
@@ -401,7 +412,7 @@ namespace agx
 		}
 
 		/* NNInputFeatures::encode (NNInputFeatures.cpp:15-32,59-113), non-renju */
-		__device__ inline void solver_encode_features(const SolverShared &sh, const EngineDev &E, uint32_t *out, int lane)
+		__device__ __forceinline__ void solver_encode_features(const SolverShared &sh, const EngineDev &E, uint32_t *out, int lane)
 		{
 			const int own = sh.sign_to_move;
 			const uint32_t base = (1u << 3) | ((own == 1) ? (1u << 4) : (1u << 5));
@@ -437,7 +448,7 @@ namespace agx
 		__constant__ const int EVAL_OWN[10] = { 0, 0, 19, 49, 76, 170, 33, 159, 252, 0 };      // AlphaBetaSearch.cpp:356-357
 		__constant__ const int EVAL_OPP[10] = { 0, 0, -1, -50, -45, -135, -14, -154, -496, 0 };
 
-		__device__ inline uint32_t defensive_mask(const EngineDev &E, uint32_t pattern, int defender, int threat_to_defend)
+		__device__ __forceinline__ uint32_t defensive_mask(const EngineDev &E, uint32_t pattern, int defender, int threat_to_defend)
 		{
 			const int attacker = 3 - defender;
 			const int d = defender - 1;
@@ -511,16 +522,16 @@ namespace agx
 				uint16_t *v;
 				int n;
 				__device__ explicit SmallSet(uint16_t *storage) : v(storage), n(0) {}
-				__device__ bool contains(int x) const
+				__device__ __forceinline__ bool contains(int x) const
 				{
 					for (int i = 0; i < n; i++)
 						if (v[i] == x)
 							return true;
 					return false;
 				}
-				__device__ void add(int x) { v[n++] = static_cast<uint16_t>(x); }
-				__device__ void remove_at(int i) { v[i] = v[--n]; }
-				__device__ void remove(int x)
+				__device__ __forceinline__ void add(int x) { v[n++] = static_cast<uint16_t>(x); }
+				__device__ __forceinline__ void remove_at(int i) { v[i] = v[--n]; }
+				__device__ __forceinline__ void remove(int x)
 				{
 					for (int i = 0; i < n; i++)
 						if (v[i] == x)
@@ -542,7 +553,7 @@ namespace agx
 				spill[i] = v;
 		}
 		/* first index in [begin, end) whose move field equals `move`, or -1 (all lanes call) */
-		__device__ inline int act_find_move(const SolverShared &sh, const uint32_t *spill, int begin, int end, uint32_t move, int lane)
+		__device__ __forceinline__ int act_find_move(const SolverShared &sh, const uint32_t *spill, int begin, int end, uint32_t move, int lane)
 		{
 			for (int base = begin; base < end; base += 64)
 			{
@@ -561,24 +572,35 @@ namespace agx
 				uint32_t *act;
 				Frame &f;
 				int n, own, opp, lane;
+				int stack_offset, stack_max, board_depth;
+				int own_cnt[10], opp_cnt[10]; // list sizes, read once: the generator never changes the threat lists (non-renju)
 
-				__device__ MoveGen(SolverShared &s, const EngineDev &e, uint32_t *a, Frame &fr, int ln) : sh(s), E(e), act(a), f(fr), n(e.n), own(s.sign_to_move), opp(3 - s.sign_to_move), lane(ln) {}
-				__device__ const uint16_t* list(int sign, int t) const { return sh.lists[sign - 1][t]; }
-				__device__ int count(int sign, int t) const { return sh.count[sign - 1][t]; }
-				__device__ const uint8_t* patterns(int sign, int cell) const { return sh.ptype[cell] + 4 * (sign - 1); }
-				__device__ int threat_at(int sign, int cell) const { return sh.threat[cell][sign - 1]; }
-				__device__ static int count_of(const uint8_t *g, int v) { return (g[0] == v) + (g[1] == v) + (g[2] == v) + (g[3] == v); }
-				__device__ static int direction_of(const uint8_t *g, int v)
+				__device__ __forceinline__ MoveGen(SolverShared &s, const EngineDev &e, uint32_t *a, Frame &fr, int ln, int offset, int maximum) :
+						sh(s), E(e), act(a), f(fr), n(e.n), own(s.sign_to_move), opp(3 - s.sign_to_move), lane(ln), stack_offset(offset), stack_max(maximum), board_depth(s.depth)
+				{
+#pragma unroll
+					for (int t = 0; t < 10; t++)
+					{
+						own_cnt[t] = s.count[own - 1][t];
+						opp_cnt[t] = s.count[opp - 1][t];
+					}
+				}
+				__device__ __forceinline__ const uint16_t* list(int sign, int t) const { return sh.lists[sign - 1][t]; }
+				__device__ __forceinline__ int count(int sign, int t) const { return (sign == own) ? own_cnt[t] : opp_cnt[t]; }
+				__device__ __forceinline__ const uint8_t* patterns(int sign, int cell) const { return sh.ptype[cell] + 4 * (sign - 1); }
+				__device__ __forceinline__ int threat_at(int sign, int cell) const { return sh.threat[cell][sign - 1]; }
+				__device__ __forceinline__ static int count_of(const uint8_t *g, int v) { return (g[0] == v) + (g[1] == v) + (g[2] == v) + (g[3] == v); }
+				__device__ __forceinline__ static int direction_of(const uint8_t *g, int v)
 				{
 					for (int d = 0; d < 4; d++)
 						if (g[d] == v)
 							return d;
 					return 0;
 				}
-				__device__ bool has_any_four(int sign) const { return count(sign, 4) > 0 || count(sign, 5) > 0 || count(sign, 6) > 0 || count(sign, 7) > 0; }
-				__device__ int available_fours(int sign) const { return count(sign, 7) + count(sign, 6) + count(sign, 5) + count(sign, 4); }
+				__device__ __forceinline__ bool has_any_four(int sign) const { return count(sign, 4) > 0 || count(sign, 5) > 0 || count(sign, 6) > 0 || count(sign, 7) > 0; }
+				__device__ __forceinline__ int available_fours(int sign) const { return count(sign, 7) + count(sign, 6) + count(sign, 5) + count(sign, 4); }
 
-				__device__ void push(uint32_t move, uint32_t score, int num)
+				__device__ __forceinline__ void push(uint32_t move, uint32_t score, int num)
 				{ // ActionList::add (ActionList.hpp:190-195)
 					if (f.base + f.size + 1 >= E.act_cap)
 					{
@@ -587,11 +609,11 @@ namespace agx
 					}
 					act_set(sh, act, f.base + f.size, move | (score << 16));
 					f.size += num;
-					sh.stack_offset += num;
-					sh.stack_max = max(sh.stack_max, sh.stack_offset);
+					stack_offset += num;
+					stack_max = max(stack_max, stack_offset);
 				}
-				__device__ uint32_t move_of(int cell) const { return static_cast<uint32_t>(own) | ((cell / n) << 2) | ((cell % n) << 9); }
-				__device__ void add_move(int cell, uint32_t score, bool override_duplicate)
+				__device__ __forceinline__ uint32_t move_of(int cell) const { return static_cast<uint32_t>(own) | ((cell / n) << 2) | ((cell % n) << 9); }
+				__device__ __forceinline__ void add_move(int cell, uint32_t score, bool override_duplicate)
 				{ // MoveGenerator.cpp:228-249
 					const int r = cell / n, c = cell % n;
 					if ((sh.added[r] >> c) & 1)
@@ -610,13 +632,13 @@ namespace agx
 						sh.added[r] |= (1u << c);
 					}
 				}
-				__device__ void add_list(int sign, int t, uint32_t score, bool override_duplicate)
+				__device__ __forceinline__ void add_list(int sign, int t, uint32_t score, bool override_duplicate)
 				{
 					const int cnt = count(sign, t);
 					for (int i = 0; i < cnt; i++)
 						add_move(list(sign, t)[i], score, override_duplicate);
 				}
-				__device__ void defensive_moves(int defender, int cell, int dir, SmallSet &out) const
+				__device__ __forceinline__ void defensive_moves(int defender, int cell, int dir, SmallSet &out) const
 				{ // PatternCalculator::getDefensiveMoves (PatternCalculator.hpp:150-160)
 					const int r = cell / n, c = cell % n;
 					const uint32_t ext = extended_pattern(sh, n, r, c, dir);
@@ -627,7 +649,7 @@ namespace agx
 						if ((mask >> (6 + i)) & 1)
 							out.add((r + i * row_step(dir)) * n + (c + i * col_step(dir)));
 				}
-				__device__ static void intersect(SmallSet &lhs, const SmallSet &rhs)
+				__device__ __forceinline__ static void intersect(SmallSet &lhs, const SmallSet &rhs)
 				{
 					int i = 0;
 					while (i < lhs.n)
@@ -638,7 +660,7 @@ namespace agx
 							lhs.remove_at(i);
 					}
 				}
-				__device__ static void intersect_init(SmallSet &dm, bool &initialized, const SmallSet &other)
+				__device__ __forceinline__ static void intersect_init(SmallSet &dm, bool &initialized, const SmallSet &other)
 				{ // DefensiveMoves::get_intersection_with (MoveGenerator.cpp:101-111)
 					if (!initialized)
 					{
@@ -649,7 +671,7 @@ namespace agx
 					else
 						intersect(dm, other);
 				}
-				__device__ uint32_t try_solve_own_fork_4x3(int cell)
+				__device__ __forceinline__ uint32_t try_solve_own_fork_4x3(int cell)
 				{ // :947-992
 					const int dir = direction_of(patterns(own, cell), 3);
 					SmallSet dm(sh.sets[4]);
@@ -673,7 +695,7 @@ namespace agx
 							return s_win_in(5);
 					}
 				}
-				__device__ uint32_t add_own_4x3_forks()
+				__device__ __forceinline__ uint32_t add_own_4x3_forks()
 				{ // :881-893
 					uint32_t result = s_unknown(0);
 					const int cnt = count(own, 5);
@@ -687,7 +709,7 @@ namespace agx
 					}
 					return result;
 				}
-				__device__ void add_own_half_open_fours()
+				__device__ __forceinline__ void add_own_half_open_fours()
 				{ // :894-946
 					add_list(own, 4, s_unknown(14), false);
 					if (count(own, 4) > 0)
@@ -695,7 +717,7 @@ namespace agx
 				}
 				/* 7x7 stencil (vertically and horizontally symmetric) OR-ed around every set bit of `occupied` rows: row R of the result
 				 * only depends on rows R-3..R+3, so each lane builds one row (MoveGenerator.cpp:1011-1126 does it stone by stone). */
-				__device__ uint32_t stencil_row(const uint32_t *stencil, int which_sign) const
+				__device__ __forceinline__ uint32_t stencil_row(const uint32_t *stencil, int which_sign) const
 				{
 					uint32_t m = 0;
 					if (lane < n)
@@ -718,7 +740,7 @@ namespace agx
 						}
 					return m;
 				}
-				__device__ void create_remaining_moves(const uint32_t *mask, uint32_t score)
+				__device__ __forceinline__ void create_remaining_moves(const uint32_t *mask, uint32_t score)
 				{ // :1127-1137 — row-major append; one row per lane, offsets by a wave prefix sum
 					uint32_t bits = (lane < n) ? (mask[lane] & (~sh.added[lane])) : 0u;
 					const int mine = __popc(bits);
@@ -746,12 +768,12 @@ namespace agx
 					if (lane < n)
 						sh.added[lane] |= mask[lane];
 					f.size += total;
-					sh.stack_offset += total;
-					sh.stack_max = max(sh.stack_max, sh.stack_offset);
+					stack_offset += total;
+					stack_max = max(stack_max, stack_offset);
 				}
 
 				// each stage returns true when the cascade must continue; `result` receives the static score
-				__device__ bool try_win_in_1(uint32_t &result)
+				__device__ __forceinline__ bool try_win_in_1(uint32_t &result)
 				{ // :355-371
 					if (count(own, 8) > 0)
 					{
@@ -762,14 +784,14 @@ namespace agx
 					}
 					return true;
 				}
-				__device__ bool try_draw_in_1(uint32_t &result)
+				__device__ __forceinline__ bool try_draw_in_1(uint32_t &result)
 				{ // :309-354
 					f.baseline = static_cast<uint16_t>(s_draw_in(1));
 					create_remaining_moves(sh.legal, s_draw_in(1));
 					result = s_draw_in(1);
 					return false;
 				}
-				__device__ bool defend_loss_in_2(uint32_t &result)
+				__device__ __forceinline__ bool defend_loss_in_2(uint32_t &result)
 				{ // :372-463
 					const int cnt = count(opp, 8);
 					if (cnt == 0)
@@ -828,7 +850,7 @@ namespace agx
 					result = best;
 					return false;
 				}
-				__device__ bool try_win_in_3(uint32_t &result)
+				__device__ __forceinline__ bool try_win_in_3(uint32_t &result)
 				{ // :464-555
 					int threats = 0;
 					add_list(own, 7, s_win_in(3), false);
@@ -846,7 +868,7 @@ namespace agx
 					}
 					return true;
 				}
-				__device__ bool defend_loss_in_4(uint32_t &result)
+				__device__ __forceinline__ bool defend_loss_in_4(uint32_t &result)
 				{ // :556-689 (non-renju branch)
 					const bool any_four = has_any_four(own);
 					f.baseline = static_cast<uint16_t>(s_loss_in(4));
@@ -912,7 +934,7 @@ namespace agx
 					f.baseline = static_cast<uint16_t>(s_unknown(0));
 					return true;
 				}
-				__device__ bool try_win_in_5(uint32_t &result)
+				__device__ __forceinline__ bool try_win_in_5(uint32_t &result)
 				{ // :690-720
 					uint32_t best = add_own_4x3_forks();
 					if (available_fours(opp) == 0 && count(own, 3) > 0)
@@ -928,7 +950,7 @@ namespace agx
 					}
 					return true;
 				}
-				__device__ bool defend_loss_in_6(uint32_t &result)
+				__device__ __forceinline__ bool defend_loss_in_6(uint32_t &result)
 				{ // :721-816
 					if (available_fours(own) > 0)
 						return true;
@@ -1008,19 +1030,19 @@ namespace agx
 					}
 					return true;
 				}
-				__device__ void mark_neighborhood() const
+				__device__ __forceinline__ void mark_neighborhood() const
 				{ // :1011-1071 -> sh.row_mask
 					uint32_t m = stencil_row(STENCIL_BOX, 0);
-					if (sh.depth == 0 && lane == n / 2)
+					if (board_depth == 0 && lane == n / 2)
 						m |= (1u << (n / 2));
 					if (lane < n)
 						sh.row_mask[lane] = m & sh.legal[lane];
 				}
 
 				/* MoveGenerator::generate (:159-223); mode 1 = THREATS, 2 = OPTIMAL */
-				__device__ uint32_t generate(int mode)
+				__device__ __forceinline__ uint32_t generate(int mode)
 				{
-					const int distance_to_draw = E.draw_after - sh.depth;
+					const int distance_to_draw = E.draw_after - board_depth;
 					if (distance_to_draw <= 0)
 						return s_make(1, 0);
 					for (int r = 0; r < n; r++)
@@ -1062,7 +1084,7 @@ namespace agx
 		{
 			return static_cast<u64>(bound) | (static_cast<u64>(depth) << 8) | (static_cast<u64>(score) << 16) | (static_cast<u64>(move) << 32);
 		}
-		__device__ inline u64 tt_seek(const u64 *tt, u64 bucket_mask, u64 lo, u64 hi)
+		__device__ __forceinline__ u64 tt_seek(const u64 *tt, u64 bucket_mask, u64 lo, u64 hi)
 		{
 			const u64 *bucket = tt + 8 * (lo & bucket_mask);
 			const u64 KEY = 0xFFFF000000000000ull;
@@ -1071,7 +1093,7 @@ namespace agx
 					return bucket[2 * i + 1];
 			return tt_pack(0, 0, s_unknown(0), 0);
 		}
-		__device__ inline void tt_insert(u64 *tt, u64 bucket_mask, u64 lo, u64 hi, u64 value, int generation)
+		__device__ __forceinline__ void tt_insert(u64 *tt, u64 bucket_mask, u64 lo, u64 hi, u64 value, int generation)
 		{
 			const u64 KEY = 0xFFFF000000000000ull;
 			value &= ~(KEY | 0xFCull);
@@ -1103,7 +1125,7 @@ namespace agx
 		}
 
 		/* AlphaBetaSearch::evaluate (AlphaBetaSearch.cpp:345-365) */
-		__device__ inline uint32_t solver_evaluate(const SolverShared &sh)
+		__device__ __forceinline__ uint32_t solver_evaluate(const SolverShared &sh)
 		{
 			const int own = sh.sign_to_move - 1, opp = 1 - own;
 			int result = 12;
@@ -1117,39 +1139,57 @@ namespace agx
 		 * Runs until a stone must be placed/removed (returns CMD_ADD / CMD_UNDO with sh.cmd_move) or the root returns (CMD_DONE).
 		 * phase: 0 = enter frame `level`, 1 = resume frame `level` after its child returned sh.pending_value.
 		 */
-		__device__ inline int solver_run(SolverShared &sh, const EngineDev &E, uint32_t *act, u64 *tt, int generation, int lane)
-		{ // executed by ALL lanes with identical (wave-uniform) state: stores are same-address / same-value, scans are lane-parallel
-			const u64 *zob = E.zob;
+		__device__ __forceinline__ int solver_run(SolverShared &sh, const EngineDev &E, uint32_t *act, u64 *tt, int generation, int lane)
+		{ // executed by ALL lanes with identical (wave-uniform) state: stores are same-address / same-value, scans are lane-parallel.
+		  // The scalars of the machine and the current frame are held in registers and written back to LDS only when the machine yields.
+			const u64 zseed = E.zobrist_seed;
 			const int n = E.n;
-			int phase = sh.phase;
+			int phase = sh.phase, level = sh.level;
+			int node_counter = sh.node_counter, stack_offset = sh.stack_offset, stack_max = sh.stack_max, error = sh.error;
+			u64 hash_lo = sh.hash_lo, hash_hi = sh.hash_hi;
 			uint32_t value = static_cast<uint32_t>(sh.pending_value);
+			Frame f = sh.frames[level];
+			auto yield = [&](int cmd, int move)
+			{
+				sh.phase = phase;
+				sh.level = level;
+				sh.node_counter = node_counter;
+				sh.stack_offset = stack_offset;
+				sh.stack_max = stack_max;
+				sh.error = error;
+				sh.hash_lo = hash_lo;
+				sh.hash_hi = hash_hi;
+				sh.pending_value = static_cast<int>(value);
+				sh.cmd_move = move;
+				return cmd;
+			};
 			while (true)
 			{
-				Frame &f = sh.frames[sh.level];
 				bool returning = false;
+#ifdef AGX_SOLVER_PROFILE
+				const unsigned long long p0 = wall_clock64();
+				unsigned long long p1 = p0, p2 = p0;
+#endif
 				if (phase == 0)
 				{ // ---- enter ----
-#ifdef AGX_SOLVER_PROFILE
-					const unsigned long long p0 = wall_clock64();
-#endif
 					f.best_move = 0;
 					u64 entry;
-					if (sh.pf_valid && sh.pf_lo == sh.hash_lo)
+					if (sh.pf_valid && sh.pf_lo == hash_lo)
 					{ // bucket fetched while the stone was being placed
 						const u64 KEY = 0xFFFF000000000000ull;
 						entry = tt_pack(0, 0, s_unknown(0), 0);
 						for (int k = 3; k >= 0; k--)
-							if (sh.pf_bucket[2 * k] == sh.hash_hi && (sh.pf_bucket[2 * k + 1] & KEY) == (sh.hash_lo & KEY))
+							if (sh.pf_bucket[2 * k] == hash_hi && (sh.pf_bucket[2 * k + 1] & KEY) == (hash_lo & KEY))
 								entry = sh.pf_bucket[2 * k + 1];
 					}
 					else
-						entry = tt_seek(tt, E.tt_bucket_mask, sh.hash_lo, sh.hash_hi);
+						entry = tt_seek(tt, E.tt_bucket_mask, hash_lo, hash_hi);
 					sh.pf_valid = 0;
 					bool early = false;
 					if ((entry & 3ull) != 0ull)
 					{
 						f.best_move = static_cast<uint16_t>((entry >> 32) & 65535u);
-						if (sh.level != 0)
+						if (level != 0)
 						{
 							const uint32_t tt_s = static_cast<uint32_t>((entry >> 16) & 65535u);
 							const int b = static_cast<int>(entry & 3ull);
@@ -1166,16 +1206,20 @@ namespace agx
 						}
 					}
 #ifdef AGX_SOLVER_PROFILE
-					const unsigned long long p1 = wall_clock64();
+					p1 = wall_clock64();
 					sh.prof[0] += p1 - p0; // table seek
 #endif
 					if (!early)
 					{
-						sh.node_counter++;
+						node_counter++;
 						if (f.size == 0)
 						{
-							MoveGen gen(sh, E, act, f, lane);
-							const uint32_t static_score = gen.generate(sh.level == 0 ? 2 : 1);
+							MoveGen gen(sh, E, act, f, lane, stack_offset, stack_max);
+							const uint32_t static_score = gen.generate(level == 0 ? 2 : 1);
+							stack_offset = gen.stack_offset;
+							stack_max = gen.stack_max;
+							if (sh.error != 0)
+								error = sh.error;
 							if (s_proven(static_score))
 							{
 								value = static_score;
@@ -1184,7 +1228,7 @@ namespace agx
 						}
 					}
 #ifdef AGX_SOLVER_PROFILE
-					const unsigned long long p2 = wall_clock64();
+					p2 = wall_clock64();
 					sh.prof[1] += p2 - p1; // move generation
 #endif
 					if (!early && f.depth_remaining <= 0)
@@ -1207,8 +1251,8 @@ namespace agx
 					const uint32_t mv = act_get(sh, act, f.base + f.i) & 0xFFFFu;
 					act_set(sh, act, f.base + f.i, mv | (s_invert_up(value) << 16));
 					const int cell = ((mv >> 2) & 127) * n + ((mv >> 9) & 127);
-					sh.hash_lo ^= zob[2 * (2 * cell + ((mv & 3) - 1))];
-					sh.hash_hi ^= zob[2 * (2 * cell + ((mv & 3) - 1)) + 1];
+					hash_lo ^= zobrist_word(zseed, 2 * (2 * cell + ((mv & 3) - 1)));
+					hash_hi ^= zobrist_word(zseed, 2 * (2 * cell + ((mv & 3) - 1)) + 1);
 					phase = 3; // post-child bookkeeping
 				}
 #ifdef AGX_SOLVER_PROFILE
@@ -1255,47 +1299,55 @@ namespace agx
 									idx = i2;
 								}
 							}
-							const uint32_t t = act_get(sh, act, f.base + f.i);
-							act_set(sh, act, f.base + f.i, act_get(sh, act, f.base + idx));
-							act_set(sh, act, f.base + idx, t);
+							if (idx != f.i)
+							{
+								const uint32_t t = act_get(sh, act, f.base + f.i);
+								act_set(sh, act, f.base + f.i, act_get(sh, act, f.base + idx));
+								act_set(sh, act, f.base + idx, t);
+							}
 						}
 						const uint32_t a = act_get(sh, act, f.base + f.i);
-						if (s_unproven(a >> 16) && sh.node_counter < E.tss_max_nodes)
+						if (s_unproven(a >> 16) && node_counter < E.tss_max_nodes)
 						{ // descend (:268-298)
-							if (sh.level + 1 >= MAX_FRAMES)
+							if (level + 1 >= MAX_FRAMES)
 							{
-								sh.error = ERR_FRAMES;
+								error = ERR_FRAMES;
 								phase = 3;
 							}
 							else
 							{
 								const uint32_t mv = a & 0xFFFFu;
 								const int cell = ((mv >> 2) & 127) * n + ((mv >> 9) & 127);
-								sh.hash_lo ^= zob[2 * (2 * cell + ((mv & 3) - 1))];
-								sh.hash_hi ^= zob[2 * (2 * cell + ((mv & 3) - 1)) + 1];
+								hash_lo ^= zobrist_word(zseed, 2 * (2 * cell + ((mv & 3) - 1)));
+								hash_hi ^= zobrist_word(zseed, 2 * (2 * cell + ((mv & 3) - 1)) + 1);
 								f.move = static_cast<uint16_t>(mv);
-								Frame &child = sh.frames[sh.level + 1];
+								sh.frames[level] = f;
+								Frame child;
 								child.base = f.base + f.size; // == stack offset: lists are strictly nested
 								child.size = 0;
 								child.i = 0;
 								child.depth_remaining = f.depth_remaining - 1;
 								child.alpha = static_cast<uint16_t>(s_invert_down(f.beta));
 								child.beta = static_cast<uint16_t>(s_invert_down(f.alpha));
+								child.original_alpha = child.alpha;
+								child.best_score = 0;
+								child.best_move = 0;
+								child.move = 0;
 								child.baseline = static_cast<uint16_t>(s_unknown(0));
-								child.must_defend = child.has_initiative = child.fully_expanded = 0;
-								sh.level++;
-								sh.phase = 0;
-								sh.cmd_move = static_cast<int>(mv);
+								child.must_defend = child.has_initiative = child.fully_expanded = child.pad = 0;
+								sh.frames[level + 1] = child;
+								level++;
+								phase = 0;
 								// SharedHashTable::prefetch (AlphaBetaSearch.cpp:273): fetch the child's bucket now, it is consumed
 								// when the child frame is entered after the stone has been placed
 								if (lane < 8)
-									sh.pf_bucket[lane] = tt[8 * (sh.hash_lo & E.tt_bucket_mask) + lane];
-								sh.pf_lo = sh.hash_lo;
+									sh.pf_bucket[lane] = tt[8 * (hash_lo & E.tt_bucket_mask) + lane];
+								sh.pf_lo = hash_lo;
 								sh.pf_valid = 1;
 #ifdef AGX_SOLVER_PROFILE
 								sh.prof[2] += wall_clock64() - p3; // ordering + descend bookkeeping
 #endif
-								return CMD_ADD;
+								return yield(CMD_ADD, static_cast<int>(mv));
 							}
 						}
 						else
@@ -1312,12 +1364,15 @@ namespace agx
 						f.alpha = static_cast<uint16_t>(sc);
 						f.best_move = static_cast<uint16_t>(a & 0xFFFFu);
 					}
-					if (sc >= f.beta || s_win(sc) || sh.error != 0)
+					if (sc >= f.beta || s_win(sc) || error != 0)
 						phase = 4;
 					else
 					{
 						f.i++;
 						phase = 2;
+#ifdef AGX_SOLVER_PROFILE
+						sh.prof[2] += wall_clock64() - p3;
+#endif
 						continue;
 					}
 				}
@@ -1335,7 +1390,7 @@ namespace agx
 						bound = 2;
 					else
 						bound = (best >= f.beta) ? 1 : 3;
-					tt_insert(tt, E.tt_bucket_mask, sh.hash_lo, sh.hash_hi, tt_pack(bound, f.depth_remaining, best, f.best_move), generation);
+					tt_insert(tt, E.tt_bucket_mask, hash_lo, hash_hi, tt_pack(bound, f.depth_remaining, best, f.best_move), generation);
 					value = best;
 					returning = true;
 #ifdef AGX_SOLVER_PROFILE
@@ -1344,17 +1399,16 @@ namespace agx
 				}
 				if (returning)
 				{
-					if (sh.level == 0)
+					if (level == 0)
 					{
+						sh.frames[0] = f;
 						sh.result_score = static_cast<int>(value);
-						return CMD_DONE;
+						return yield(CMD_DONE, 0);
 					}
-					sh.stack_offset -= f.size; // ~ActionList (ActionList.hpp:128-131)
-					sh.level--;
-					sh.pending_value = static_cast<int>(value);
-					sh.phase = 1;
-					sh.cmd_move = sh.frames[sh.level].move;
-					return CMD_UNDO;
+					stack_offset -= f.size; // ~ActionList (ActionList.hpp:128-131)
+					level--;
+					phase = 1;
+					return yield(CMD_UNDO, sh.frames[level].move);
 				}
 			}
 		}

@@ -175,7 +175,7 @@ namespace
 	}
 
 	/* ------------------------------------------------------------------------------------------------------------ */
-	__device__ void solve_task(SolverShared &sh, const EngineDev &E, int g, DTask &t, int slot, int generation, int lane, unsigned long long &solver_nodes)
+	__device__ __forceinline__ void solve_task(SolverShared &sh, const EngineDev &E, int g, DTask &t, int slot, int generation, int lane, unsigned long long &solver_nodes)
 	{ // AlphaBetaSearch::solve (AlphaBetaSearch.cpp:77-156)
 		uint32_t *act = E.act + static_cast<size_t>(g) * E.act_cap;
 		u64 *tt = E.tt + static_cast<size_t>(g) * (E.tt_bucket_mask + 1ull) * 8ull;
@@ -193,8 +193,8 @@ namespace
 			const int v = sh.board[i];
 			if (v == 1 || v == 2)
 			{
-				lo ^= E.zob[2 * (2 * i + v - 1)];
-				hi ^= E.zob[2 * (2 * i + v - 1) + 1];
+				lo ^= zobrist_word(E.zobrist_seed, 2 * (2 * i + v - 1));
+				hi ^= zobrist_word(E.zobrist_seed, 2 * (2 * i + v - 1) + 1);
 			}
 		}
 		for (int o = 32; o > 0; o >>= 1)
@@ -1129,6 +1129,7 @@ int agx_engine_create(const AgxEngineConfig *cfg, AgxEngine **out)
 	d.tss_max_depth = 100;
 	const size_t buckets = round_pow2(std::max<size_t>(cfg->tss_table_entries, 4)) / 4;
 	d.tt_bucket_mask = buckets - 1;
+	d.zobrist_seed = cfg->zobrist_seed;
 	d.node_cap = cfg->node_capacity > 0 ? cfg->node_capacity : 8192;
 	d.edge_cap = cfg->edge_capacity > 0 ? cfg->edge_capacity : 262144;
 	d.ht_cap = static_cast<int>(round_pow2(4 * static_cast<size_t>(d.node_cap)));

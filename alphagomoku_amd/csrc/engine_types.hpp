@@ -135,6 +135,7 @@ namespace agx
 			int init_to;
 			float leak_threshold, expansion_threshold;
 			int tss_max_nodes, tss_max_depth;
+			unsigned long long zobrist_seed;
 			unsigned long long tt_bucket_mask; // buckets - 1 (4 entries of 16 bytes per bucket)
 			int node_cap, edge_cap, ht_cap, act_cap;
 			int record_cap, record_edge_cap;
