@@ -77,7 +77,8 @@ class AgxEngineConfig(ctypes.Structure):
                 ("exploration_scaling", ctypes.c_float), ("init_to", ctypes.c_int), ("information_leak_threshold", ctypes.c_float),
                 ("policy_expansion_threshold", ctypes.c_float), ("tss_max_positions", ctypes.c_int),
                 ("tss_table_entries", ctypes.c_uint64), ("zobrist_seed", ctypes.c_uint64), ("node_capacity", ctypes.c_int),
-                ("edge_capacity", ctypes.c_int), ("record_capacity", ctypes.c_int), ("record_edge_capacity", ctypes.c_int)]
+                ("edge_capacity", ctypes.c_int), ("record_capacity", ctypes.c_int), ("record_edge_capacity", ctypes.c_int),
+                ("solver_yield_fraction", ctypes.c_float)]
 
 
 class AgxEngineBuffers(ctypes.Structure):

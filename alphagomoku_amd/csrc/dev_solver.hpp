@@ -28,6 +28,17 @@ namespace agx
 	{
 		typedef uint64_t u64;
 
+		/* One wavefront owns the whole workgroup in the solver kernel: its lanes run in lockstep and the LDS executes one wave's
+		 * instructions in order, so hand-offs between lanes through LDS need no s_barrier and no s_waitcnt vmcnt(0) — only the
+		 * compiler must not reorder the accesses.  (A real __syncthreads() would also drain the table prefetch that is meant to stay
+		 * in flight while a stone is placed.) */
+		__device__ __forceinline__ void wave_sync()
+		{
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+		}
+
 		/* Solver Zobrist keys (FastZobristHashing, ZobristHashing.cpp:35-43 draws 2*HW 128-bit keys from an RNG): key word j is the
 		 * j-th output of splitmix64 seeded with the engine's zobrist_seed, so it can be recomputed in registers instead of being
 		 * gathered from memory (lo word of (cell, colour) = output 2*(2*cell + colour - 1), hi word = the next one). */
@@ -197,7 +208,7 @@ namespace agx
 				sh.board[i] = board[i];
 			if (lane < 20)
 				sh.count[lane / 10][lane % 10] = 0;
-			__syncthreads();
+			wave_sync();
 			for (int L = lane; L < 6 * n - 2; L += 64)
 			{
 				int len, r0, c0, dr, dc;
@@ -232,7 +243,7 @@ namespace agx
 						m |= (1u << c);
 				sh.legal[lane] = m;
 			}
-			__syncthreads();
+			wave_sync();
 			int stones = 0;
 			for (int chunk = 0; chunk * 64 < hw; chunk++)
 			{
@@ -271,10 +282,10 @@ namespace agx
 						const int cnt = sh.count[0][t];
 						if (t0 == t)
 							sh.lists[0][t][cnt + __popcll(m0 & lower)] = static_cast<uint16_t>(cell);
-						__syncthreads();
+						wave_sync();
 						if (lane == 0)
 							sh.count[0][t] = static_cast<uint16_t>(cnt + __popcll(m0));
-						__syncthreads();
+						wave_sync();
 					}
 					const u64 m1 = __ballot(t1 == t);
 					if (m1 != 0)
@@ -282,10 +293,10 @@ namespace agx
 						const int cnt = sh.count[1][t];
 						if (t1 == t)
 							sh.lists[1][t][cnt + __popcll(m1 & lower)] = static_cast<uint16_t>(cell);
-						__syncthreads();
+						wave_sync();
 						if (lane == 0)
 							sh.count[1][t] = static_cast<uint16_t>(cnt + __popcll(m1));
-						__syncthreads();
+						wave_sync();
 					}
 				}
 			}
@@ -296,7 +307,7 @@ namespace agx
 				sh.sign_to_move = sign_to_move;
 				sh.depth = stones;
 			}
-			__syncthreads();
+			wave_sync();
 		}
 
 		/* PatternCalculator::update_around (PatternCalculator.cpp:278-367): the centre cell, then the +-5 cells in the four
@@ -323,7 +334,7 @@ namespace agx
 					sh.ptype[center][lane] = e & 15;
 					sh.ptype[center][4 + lane] = e >> 4;
 				}
-				__syncthreads();
+				wave_sync();
 				const int t0 = E.t_threat[2 * threat_index(sh.ptype[center])];
 				const int t1 = E.t_threat[2 * threat_index(sh.ptype[center] + 4) + 1];
 				if (lane == 0)
@@ -334,7 +345,7 @@ namespace agx
 				list_add(sh, 0, t0, center, lane);
 				list_add(sh, 1, t1, center, lane);
 			}
-			__syncthreads();
+			wave_sync();
 
 			int cell = -1, old0 = 0, old1 = 0, new0 = 0, new1 = 0;
 			if (lane < 40)
@@ -358,16 +369,16 @@ namespace agx
 			}
 			u64 changed0 = __ballot(cell >= 0 && old0 != new0);
 			u64 changed1 = __ballot(cell >= 0 && old1 != new1);
-			__syncthreads();
+			wave_sync();
 			while (changed0 != 0)
 			{
 				const int src = __ffsll(static_cast<long long>(changed0)) - 1;
 				changed0 &= changed0 - 1;
 				const int cc = __shfl(cell, src), o = __shfl(old0, src), nw = __shfl(new0, src);
 				list_remove(sh, 0, o, cc, lane);
-				__syncthreads();
+				wave_sync();
 				list_add(sh, 0, nw, cc, lane);
-				__syncthreads();
+				wave_sync();
 			}
 			while (changed1 != 0)
 			{
@@ -375,9 +386,9 @@ namespace agx
 				changed1 &= changed1 - 1;
 				const int cc = __shfl(cell, src), o = __shfl(old1, src), nw = __shfl(new1, src);
 				list_remove(sh, 1, o, cc, lane);
-				__syncthreads();
+				wave_sync();
 				list_add(sh, 1, nw, cc, lane);
-				__syncthreads();
+				wave_sync();
 			}
 		}
 		__device__ __forceinline__ void solver_place(SolverShared &sh, const EngineDev &E, uint32_t move, bool add, int lane)
@@ -401,14 +412,14 @@ namespace agx
 				else
 					sh.legal[r] |= (1u << c);
 			}
-			__syncthreads();
+			wave_sync();
 			solver_update_around(sh, E, r, c, add, lane);
 			if (lane == 0)
 			{
 				sh.sign_to_move = 3 - sh.sign_to_move;
 				sh.depth += add ? 1 : -1;
 			}
-			__syncthreads();
+			wave_sync();
 		}
 
 		/* NNInputFeatures::encode (NNInputFeatures.cpp:15-32,59-113), non-renju */
@@ -1139,7 +1150,7 @@ namespace agx
 		 * Runs until a stone must be placed/removed (returns CMD_ADD / CMD_UNDO with sh.cmd_move) or the root returns (CMD_DONE).
 		 * phase: 0 = enter frame `level`, 1 = resume frame `level` after its child returned sh.pending_value.
 		 */
-		__device__ __forceinline__ int solver_run(SolverShared &sh, const EngineDev &E, uint32_t *act, u64 *tt, int generation, int lane)
+		__device__ __forceinline__ int solver_run(SolverShared &sh, const EngineDev &E, uint32_t *act, u64 *tt, int generation, int lane, u64 &pf_word)
 		{ // executed by ALL lanes with identical (wave-uniform) state: stores are same-address / same-value, scans are lane-parallel.
 		  // The scalars of the machine and the current frame are held in registers and written back to LDS only when the machine yields.
 			const u64 zseed = E.zobrist_seed;
@@ -1175,7 +1186,10 @@ namespace agx
 					f.best_move = 0;
 					u64 entry;
 					if (sh.pf_valid && sh.pf_lo == hash_lo)
-					{ // bucket fetched while the stone was being placed
+					{ // bucket fetched while the stone was being placed (lanes 0-7 still hold its words in a register)
+						if (lane < 8)
+							sh.pf_bucket[lane] = pf_word;
+						wave_sync();
 						const u64 KEY = 0xFFFF000000000000ull;
 						entry = tt_pack(0, 0, s_unknown(0), 0);
 						for (int k = 3; k >= 0; k--)
@@ -1341,7 +1355,7 @@ namespace agx
 								// SharedHashTable::prefetch (AlphaBetaSearch.cpp:273): fetch the child's bucket now, it is consumed
 								// when the child frame is entered after the stone has been placed
 								if (lane < 8)
-									sh.pf_bucket[lane] = tt[8 * (hash_lo & E.tt_bucket_mask) + lane];
+									pf_word = tt[8 * (hash_lo & E.tt_bucket_mask) + lane];
 								sh.pf_lo = hash_lo;
 								sh.pf_valid = 1;
 #ifdef AGX_SOLVER_PROFILE

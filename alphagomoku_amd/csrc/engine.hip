@@ -36,7 +36,7 @@ namespace
 		__shared__ u64 sh_cboard[BWORDS];
 		const int g = E.g0 + blockIdx.x, lane = threadIdx.x;
 		GameState &gs = E.games[g];
-		if (!gs.active || gs.error != 0 || gs.outcome != 0)
+		if (!gs.active || gs.error != 0 || gs.outcome != 0 || gs.solve_pending)
 			return;
 		DNode *nodes = nodes_of(E, g, gs.arena);
 		DEdge *edges = edges_of(E, g, gs.arena);
@@ -221,8 +221,9 @@ namespace
 			f.baseline = static_cast<uint16_t>(s_unknown(0));
 			f.must_defend = f.has_initiative = f.fully_expanded = 0;
 		}
-		__syncthreads();
+		wave_sync();
 		uint32_t result = s_unknown(0);
+		u64 pf_word = 0; // lanes 0-7: the transposition-table bucket prefetched for the frame about to be entered
 		for (int depth = 0; depth <= E.tss_max_depth; depth += 4)
 		{
 			int stack_before = 0;
@@ -238,16 +239,16 @@ namespace
 				sh.phase = 0;
 				sh.pending_value = 0;
 			}
-			__syncthreads();
+			wave_sync();
 			while (true)
 			{
 #ifdef AGX_SOLVER_PROFILE
 				const unsigned long long r0 = wall_clock64();
 #endif
-				const int cmd_now = solver_run(sh, E, act, tt, generation, lane);
+				const int cmd_now = solver_run(sh, E, act, tt, generation, lane, pf_word);
 				if (lane == 0)
 					sh.cmd = cmd_now;
-				__syncthreads();
+				wave_sync();
 #ifdef AGX_SOLVER_PROFILE
 				const unsigned long long r1 = wall_clock64();
 				c_run += r1 - r0;
@@ -272,7 +273,7 @@ namespace
 			}
 			stop = __shfl(stop, 0);
 			result = static_cast<uint32_t>(__shfl(sh.result_score, 0));
-			__syncthreads();
+			wave_sync();
 			if (stop)
 				break;
 		}
@@ -319,7 +320,7 @@ namespace
 			pg.prof[7] += sh.prof[2] | (sh.prof[3] << 32);
 		}
 #endif
-		__syncthreads();
+		wave_sync();
 	}
 
 	__global__ __launch_bounds__(64) void k_solve(EngineDev E)
@@ -327,34 +328,72 @@ namespace
 		__shared__ SolverShared sh;
 		const int g = E.g0 + blockIdx.x, lane = threadIdx.x;
 		GameState &gs = E.games[g];
-		if (!gs.active || gs.error != 0 || gs.outcome != 0)
-			return;
-		const int n_tasks = gs.n_tasks;
+		const bool idle = (!gs.active || gs.error != 0 || gs.outcome != 0);
+		const int n_tasks = idle ? 0 : gs.n_tasks;
 		unsigned long long solver_nodes = 0, scheduled = 0;
-		for (int k = 0; k < n_tasks; k++)
+		/*
+		 * The tasks of a game are solved strictly in order (they share the game's transposition table), so a launch lasts as long as
+		 * its slowest game.  To keep the other CUs from idling behind stragglers a game may YIELD between two tasks once
+		 * yield_fraction of the launch's games have finished: it keeps its position in the batch, sits out this step's network /
+		 * expand stages and resumes in the next launch.  Each game still sees exactly the same sequence of operations.
+		 */
+		const int threshold = (E.yield_fraction > 0.0f) ? static_cast<int>(E.yield_fraction * gridDim.x) : 0x7FFFFFFF;
+		int k = idle ? 0 : gs.solve_pos;
+		bool yielded = false;
+		for (; k < n_tasks; k++)
 		{
 			DTask &t = E.tasks[static_cast<size_t>(g) * E.batch + k];
 			const int slot = g * E.batch + k;
 			if ((t.flags & TF_BY_SOLVER) == 0)
+			{
+				if (threshold != 0x7FFFFFFF && k > gs.solve_pos)
+				{ // at least one task per launch is always solved, so every game makes progress
+					int done = 0;
+					if (lane == 0)
+						done = __hip_atomic_load(&E.counters[E.yield_counter], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					done = __shfl(done, 0);
+					if (done >= threshold)
+					{
+						yielded = true;
+						break;
+					}
+				}
 				solve_task(sh, E, g, t, slot, gs.generation, lane, solver_nodes);
-			// Search::scheduleToNN (Search.cpp:184-199)
+			}
+		}
+		if (yielded)
+		{
 			if (lane == 0)
 			{
+				gs.solve_pos = k;
+				gs.solve_pending = 1;
+				gs.stats[5] += solver_nodes;
+			}
+			return;
+		}
+		// Search::scheduleToNN (Search.cpp:184-199), once the whole batch has been solved
+		if (lane == 0)
+		{
+			for (int j = 0; j < n_tasks; j++)
+			{
+				DTask &t = E.tasks[static_cast<size_t>(g) * E.batch + j];
 				const bool needs = (t.path_len == 0) || !s_proven(t.score);
 				t.needs_nn = needs ? 1 : 0;
 				if (needs)
 				{
 					const int idx = atomicAdd(&E.counters[E.nn_counter], 1);
-					E.nn_list[static_cast<size_t>(E.g0) * E.batch + idx] = slot; // each group owns the list segment of its games
+					E.nn_list[static_cast<size_t>(E.g0) * E.batch + idx] = g * E.batch + j; // each group owns the list segment of its games
 					scheduled++;
 				}
 			}
-			__syncthreads();
-		}
-		if (lane == 0)
-		{
-			gs.stats[5] += solver_nodes;
-			gs.stats[1] += scheduled;
+			if (!idle)
+			{
+				gs.solve_pos = 0;
+				gs.solve_pending = 0;
+				gs.stats[5] += solver_nodes;
+				gs.stats[1] += scheduled;
+			}
+			atomicAdd(&E.counters[E.yield_counter], 1);
 		}
 	}
 
@@ -366,7 +405,7 @@ namespace
 		__shared__ float sh_sum;
 		const int g = E.g0 + blockIdx.x, lane = threadIdx.x;
 		GameState &gs = E.games[g];
-		if (!gs.active || gs.error != 0 || gs.outcome != 0)
+		if (!gs.active || gs.error != 0 || gs.outcome != 0 || gs.solve_pending)
 			return;
 		DNode *nodes = nodes_of(E, g, gs.arena);
 		DEdge *edges = edges_of(E, g, gs.arena);
@@ -682,6 +721,8 @@ namespace
 			gs.n_edges = 0;
 			gs.n_tasks = 0;
 			gs.need_move = 0;
+			gs.solve_pos = 0;
+			gs.solve_pending = 0;
 			gs.generation = (gs.generation + 1) % 64; // prepare_search -> increaseGeneration
 			gs.opening_id = id;
 			gs.active = 1;
@@ -728,7 +769,7 @@ namespace
 		__shared__ int scan_nodes[256], scan_edges[256];
 		const int g = E.g0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 		GameState &gs = E.games[g];
-		if (!gs.active || gs.error != 0 || !gs.need_move)
+		if (!gs.active || gs.error != 0 || !gs.need_move || gs.solve_pending)
 			return;
 		DNode *nodes = nodes_of(E, g, gs.arena);
 		DEdge *edges = edges_of(E, g, gs.arena);
@@ -936,9 +977,11 @@ namespace
 		}
 	}
 
-	__global__ void k_reset_counter(int *counter)
+	__global__ void k_reset_counter(int *counter, int *second)
 	{
 		*counter = 0;
+		if (second != nullptr)
+			*second = 0;
 	}
 
 	/* debug / test kernels --------------------------------------------------------------------------------------- */
@@ -965,6 +1008,8 @@ namespace
 			gs.outcome = 0;
 			gs.error = 0;
 			gs.generation = 0;
+			gs.solve_pos = 0;
+			gs.solve_pending = 0;
 		}
 	}
 	__global__ __launch_bounds__(64) void k_debug_pattern_state(EngineDev E, const uint8_t *boards, const int *signs, const uint16_t *moves, int n_moves,
@@ -1096,6 +1141,7 @@ int agx_engine_default_config(AgxEngineConfig *cfg)
 	cfg->edge_capacity = 262144;
 	cfg->record_capacity = 0;
 	cfg->record_edge_capacity = 0;
+	cfg->solver_yield_fraction = 0.0f;
 	return AGX_OK;
 }
 
@@ -1108,6 +1154,7 @@ int agx_engine_create(const AgxEngineConfig *cfg, AgxEngine **out)
 	AGX_REQUIRE(cfg->n_games > 0 && cfg->max_batch_size > 0 && cfg->max_simulations > 0, AGX_ERR_INVALID, "agx_engine_create: non-positive sizes");
 	AGX_REQUIRE(cfg->tss_max_positions >= 1 && cfg->tss_max_positions <= 100, AGX_ERR_UNSUPPORTED, "agx_engine_create: tss_max_positions must be in [1, 100]");
 	AGX_REQUIRE(cfg->init_to >= 0 && cfg->init_to <= 3, AGX_ERR_INVALID, "agx_engine_create: init_to must be 0..3");
+	AGX_REQUIRE(cfg->solver_yield_fraction >= 0.0f && cfg->solver_yield_fraction <= 1.0f, AGX_ERR_INVALID, "agx_engine_create: solver_yield_fraction must be in [0, 1]");
 
 	AgxEngine *e = new AgxEngine();
 	e->cfg = *cfg;
@@ -1127,6 +1174,7 @@ int agx_engine_create(const AgxEngineConfig *cfg, AgxEngine **out)
 	d.expansion_threshold = cfg->policy_expansion_threshold;
 	d.tss_max_nodes = cfg->tss_max_positions;
 	d.tss_max_depth = 100;
+	d.yield_fraction = cfg->solver_yield_fraction;
 	const size_t buckets = round_pow2(std::max<size_t>(cfg->tss_table_entries, 4)) / 4;
 	d.tt_bucket_mask = buckets - 1;
 	d.zobrist_seed = cfg->zobrist_seed;
@@ -1235,6 +1283,7 @@ static int group_range(const AgxEngine *e, int group, int n_groups, EngineDev &d
 	d.g0 = group * per;
 	count = std::min(per, e->dev.n_games - d.g0);
 	d.nn_counter = 16 + group;
+	d.yield_counter = 32 + group;
 	AGX_REQUIRE(count > 0, AGX_ERR_INVALID, "group %d of %d is empty for %d games", group, n_groups, e->dev.n_games);
 	return AGX_OK;
 }
@@ -1249,7 +1298,7 @@ int agx_engine_select_solve_group(AgxEngine *e, int group, int n_groups, void *s
 	if (st != AGX_OK)
 		return st;
 	hipStream_t s = static_cast<hipStream_t>(stream);
-	hipLaunchKernelGGL(k_reset_counter, dim3(1), dim3(1), 0, s, d.counters + d.nn_counter);
+	hipLaunchKernelGGL(k_reset_counter, dim3(1), dim3(1), 0, s, d.counters + d.nn_counter, d.counters + d.yield_counter);
 	hipLaunchKernelGGL(k_select, dim3(count), dim3(64), 0, s, d);
 	hipLaunchKernelGGL(k_solve, dim3(count), dim3(64), 0, s, d);
 	AGX_HIP_CHECK(hipGetLastError());
@@ -1502,7 +1551,8 @@ int agx_debug_solve(AgxEngine *e, const uint8_t *h_boards, const int *h_signs, i
 	EngineDev dd = d;
 	dd.g0 = 0;
 	dd.nn_counter = 16;
-	hipLaunchKernelGGL(k_reset_counter, dim3(1), dim3(1), 0, nullptr, dd.counters + dd.nn_counter);
+	dd.yield_fraction = 0.0f;
+	hipLaunchKernelGGL(k_reset_counter, dim3(1), dim3(1), 0, nullptr, dd.counters + dd.nn_counter, static_cast<int*>(nullptr));
 	hipLaunchKernelGGL(k_solve, dim3(count), dim3(64), 0, nullptr, dd);
 	AGX_HIP_CHECK(hipGetLastError());
 	AGX_HIP_CHECK(hipDeviceSynchronize());

@@ -97,8 +97,8 @@ namespace agx
 			int32_t error;
 			int32_t opening_id;
 			int32_t games_done;
-			int32_t record_begin; // first record index of the current game
-			int32_t pad;
+			int32_t solve_pos;     // first task of the batch that still has to be solved (solver launches may yield between tasks)
+			int32_t solve_pending; // 1 while the batch is only partly solved: the game sits out select / network / expand until it is done
 			uint64_t root_hash;
 			uint64_t cboard[BWORDS];
 			unsigned long long prof[8];   // optional cycle counters (AGX_SOLVER_PROFILE builds only)
@@ -140,6 +140,8 @@ namespace agx
 			int node_cap, edge_cap, ht_cap, act_cap;
 			int record_cap, record_edge_cap;
 			int n_openings;
+			float yield_fraction; // 0 = never; else a game yields between two solves once this fraction of the launch's games is done
+			int yield_counter;    // index into counters[] of the launch's "games done" count
 			int g0;          // first game handled by this launch (a launch covers games [g0, g0 + gridDim.x): one "group" of the pool)
 			int nn_counter;  // index into counters[] of this group's scheduled-position count
 			// state

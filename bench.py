@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--board", type=int, default=15)
     ap.add_argument("--rules", type=int, default=0)
     ap.add_argument("--table-entries", type=int, default=4 * 1024 * 1024)
+    ap.add_argument("--yield-fraction", type=float, default=0.75, help="solver straggler cut-off (0 = lock-step pool)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -90,7 +91,7 @@ def main():
     net = AGNetwork(desc)
     net.loadWeights(blob)
     cfg = selfplay.default_config(rules=args.rules, board_size=args.board, n_games=args.games, max_batch_size=args.batch,
-                                  max_simulations=args.sims, tss_table_entries=args.table_entries)
+                                  max_simulations=args.sims, tss_table_entries=args.table_entries, solver_yield_fraction=args.yield_fraction)
     pool = selfplay.GeneratorPool(cfg)
     # enough openings for every game that can finish during the run; seeds are disjoint across ranks
     n_openings = args.games * 3

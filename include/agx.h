@@ -112,6 +112,10 @@ typedef struct AgxEngineConfig
 	int edge_capacity;                /* per game, per arena (TreeConfig::edge_bucket_size analogue) */
 	int record_capacity;              /* move records kept on the device, 0 = n_games * cells */
 	int record_edge_capacity;         /* root-edge snapshots kept on the device, 0 = 64 per record */
+	float solver_yield_fraction;      /* 0 = off.  A pool step lasts as long as its slowest game's solver batch; with f in (0,1] a game
+	                                     whose batch is only partly solved when a fraction f of the launch's games are done sits out the
+	                                     rest of this step (network / expand) and resumes in the next one.  Per-game results are
+	                                     unchanged (every game executes the same sequence of operations), only the pacing differs. */
 } AgxEngineConfig;
 
 typedef struct AgxEngine AgxEngine; /* opaque */

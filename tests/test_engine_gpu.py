@@ -234,6 +234,57 @@ def test_whole_games_bit_exact_with_stand_in_evaluator(agx_lib, olib, rules, bat
     assert stats["games_finished"] == 6 and stats["information_leaks"] > 0 and stats["proven_edge_visits"] > 0
 
 
+def test_yielding_pool_gives_the_same_games(agx_lib, olib):
+    """solver_yield_fraction only changes the pacing (stragglers sit out a step): every game must still produce exactly the
+    oracle's moves and root visit counts.  Compared through the output records, game by game."""
+    from alphagomoku_amd import selfplay
+    games, batch, sims = 12, 8, 60
+    cfg = selfplay.default_config(n_games=games, max_batch_size=batch, max_simulations=sims, tss_table_entries=1 << 16, node_capacity=4096,
+                                  edge_capacity=65536, solver_yield_fraction=0.5)
+    pool = selfplay.GeneratorPool(cfg)
+    ocfg = ol.default_search_config(max_batch_size=batch, max_simulations=sims, table_entries=1 << 16)
+    ev = _stand_in_evaluator(olib)
+    openings = []
+    for g in range(games):
+        op = np.zeros(64, np.uint16)
+        k = olib.ago_prepare_opening(0, N, N, 300 + g, ol.ptr(op))
+        openings.append([int(x) for x in op[:k]])
+    pool.begin(selfplay.pack_openings(openings))
+    for _ in range(6000):
+        pool.select_solve()
+        slots, feats = pool.scheduled()
+        if len(slots):
+            p, v = ev(feats)
+            pool.provide(slots, p, np.concatenate([v, 1 - v.sum(1, keepdims=True)], 1).astype(np.float32))
+        pool.expand_backup()
+        if pool.stats()["active_games"] == 0:
+            break
+    st = pool.stats()
+    assert st["first_error"] == 0 and st["games_finished"] == games
+    recs, edges = pool.records()
+    for g in range(games):
+        h = olib.ago_game_create(0, N, N, ctypes.byref(ocfg))
+        op = np.array(openings[g] + [0] * (64 - len(openings[g])), np.uint16)
+        olib.ago_game_begin(h, ol.ptr(op), len(openings[g]))
+        f = np.zeros((batch, HW), np.uint32)
+        while olib.ago_game_outcome(h) == 0:
+            c = olib.ago_game_step_select(h, ol.ptr(f), batch)
+            p, v = ev(f[:c]) if c else (np.zeros((0, HW), np.float32), np.zeros((0, 2), np.float32))
+            olib.ago_game_step_expand(h, ol.ptr(np.ascontiguousarray(p)), ol.ptr(np.ascontiguousarray(v)))
+        mine = sorted((r.move_number, r) for r in recs if r.game_serial == g)
+        assert len(mine) == olib.ago_game_num_records(h), g
+        for i, (_, r) in enumerate(mine):
+            mv, rv, rs = ctypes.c_uint16(), ctypes.c_int(), ctypes.c_uint16()
+            rval = (ctypes.c_float * 2)()
+            em, ev_ = np.zeros(512, np.uint16), np.zeros(512, np.int32)
+            ep, evl, es = np.zeros(512, np.float32), np.zeros(1024, np.float32), np.zeros(512, np.uint16)
+            ne = olib.ago_game_record(h, i, ctypes.byref(mv), ctypes.byref(rv), rval, ctypes.byref(rs), ol.ptr(em), ol.ptr(ev_), ol.ptr(ep), ol.ptr(evl), ol.ptr(es), 512)
+            assert (r.move, r.root_visits, r.n_edges) == (mv.value, rv.value, ne), (g, i)
+            assert [e.visits for e in edges[r.edge_offset:r.edge_offset + r.n_edges]] == [int(x) for x in ev_[:ne]], (g, i)
+        olib.ago_game_destroy(h)
+    pool.close()
+
+
 def test_games_bit_exact_with_the_hip_network_in_the_loop(agx_lib, olib):
     """C1-shaped plumbing check: 2-block / 64-filter network evaluated by the HIP tower; the oracle tree is fed the same outputs."""
     from alphagomoku_amd.networks import AGNetwork
