@@ -169,6 +169,12 @@ def main():
         nn_tflops = (local_evals * flops) / (ms_nn * 1e-3) / 1e12 if ms_nn > 0 else 0.0
         depth = levels / max(1, (s1["evaluated_nodes"] - s0["evaluated_nodes"]) + leaks)
         edges_per_level = edge_reads / max(1, levels)
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+        if os.path.exists(pmc_path) and args.games == 1024 and args.filters == 128 and args.blocks == 6:
+            # HBM-side bytes per network launch from the committed rocprofv3 --pmc passes of this same command (FETCH_SIZE doubled per
+            # the gfx950 correction + WRITE_SIZE); PMC counters cannot be sampled from inside this process
+            traffic = json.load(open(pmc_path)).get("nn_tower_bytes_per_launch_corrected")
         result = {
             "metric": "MCTS simulations/sec (self-play, 15x15 freestyle)",
             "value": sims / elapsed,
@@ -193,7 +199,7 @@ def main():
                       "solver_nodes_per_simulation": solver_nodes / max(1, s1["evaluated_nodes"] - s0["evaluated_nodes"]),
                       "nn_evals_per_simulation": local_evals / max(1, s1["evaluated_nodes"] - s0["evaluated_nodes"])},
             "roofline": {"bound": "mfma", "kernel": "nn_tower_kernel<%d,%d,%d>" % (args.filters, args.board, args.board),
-                         "achieved": nn_tflops, "peak": 2500.0, "unit": "TFLOP/s", "frac": nn_tflops / 2500.0, "traffic": None,
+                         "achieved": nn_tflops, "peak": 2500.0, "unit": "TFLOP/s", "frac": nn_tflops / 2500.0, "traffic": traffic,
                          "flops_per_position": flops, "positions_per_launch": local_evals / args.steps,
                          "avg_launch_ms": ms_nn / args.steps},
         }
