@@ -1,0 +1,45 @@
+"""Multi-GPU plumbing of the benchmark / launcher: one process per GPU, each with its own independent game pool.
+
+There is NO collective on the data path (games never talk to each other, exactly like the reference's one-thread-per-device
+GeneratorManager, src/selfplay/GeneratorManager.cpp:146-152).  torch.distributed is used only for the start/stop barrier and to
+combine the per-rank measurements: wall time = MAX over ranks, work counters = SUM over ranks."""
+import os
+
+
+def env_ranks():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def init(backend=None, device=None):
+    """returns the torch.distributed module (initialised) or None for a single process"""
+    rank, local_rank, world = env_ranks()
+    if world <= 1:
+        return None
+    import torch
+    import torch.distributed as dist
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    kwargs = {}
+    if backend == "nccl":
+        torch.cuda.set_device(local_rank)
+        kwargs["device_id"] = torch.device("cuda", local_rank)
+    dist.init_process_group(backend=backend, **kwargs)
+    return dist
+
+
+def combine(dist, elapsed_seconds, counters):
+    """elapsed -> MAX over ranks, counters (list of numbers) -> SUM over ranks; identity for a single process"""
+    if dist is None:
+        return float(elapsed_seconds), [float(c) for c in counters]
+    import torch
+    device = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([elapsed_seconds], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    c = torch.tensor([float(x) for x in counters], dtype=torch.float64, device=device)
+    dist.all_reduce(c, op=dist.ReduceOp.SUM)
+    return float(t.item()), [float(x) for x in c.tolist()]
+
+
+def rank_seed_base(rank):
+    """disjoint opening seeds per rank so that the ranks play different games"""
+    return rank * 1000003

@@ -67,15 +67,11 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    from alphagomoku_amd import distributed
+    rank, local_rank, world = distributed.env_ranks()
+    # the ranks only exchange a barrier and two tiny reductions of host scalars -> gloo on CPU tensors keeps torch off the GPUs
+    # (set AGX_DIST_BACKEND=nccl to run the same reductions over RCCL)
+    dist = distributed.init(backend=os.environ.get("AGX_DIST_BACKEND", "gloo"))
 
     from alphagomoku_amd import build
     if rank == 0:
@@ -95,7 +91,7 @@ def main():
     pool = selfplay.GeneratorPool(cfg)
     # enough openings for every game that can finish during the run; seeds are disjoint across ranks
     n_openings = args.games * 3
-    openings = synthetic.make_openings(args.board, n_openings, seed0=rank * 1000003)
+    openings = synthetic.make_openings(args.board, n_openings, seed0=distributed.rank_seed_base(rank), rules=args.rules)
     pool.begin(selfplay.pack_openings(openings))
     check(lib.agx_device_synchronize())
 
@@ -153,14 +149,7 @@ def main():
     if s1["first_error"] != 0:
         raise RuntimeError("device engine stopped with error code %d" % s1["first_error"])
 
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        c = torch.tensor([sims, evals, moves, games_done], dtype=torch.float64, device="cuda")
-        dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        sims, evals, moves, games_done = [float(x) for x in c.tolist()]
+    elapsed, (sims, evals, moves, games_done) = distributed.combine(dist, elapsed, [sims, evals, moves, games_done])
 
     if rank == 0:
         flops = nn_flops_per_position(desc)
