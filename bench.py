@@ -81,7 +81,7 @@ def main():
     from alphagomoku_amd import lib, check, synthetic, selfplay
     from alphagomoku_amd.networks import AGNetwork
 
-    check(lib.agx_set_device(local_rank))
+    check(lib.agx_set_device(int(os.environ.get("AGX_FORCE_DEVICE", local_rank))))  # AGX_FORCE_DEVICE: test the N > 1 flow on a 1-GPU box
     desc = synthetic.net_desc(rows=args.board, cols=args.board, blocks=args.blocks, filters=args.filters)
     blob, _ = synthetic.make_weights(desc)
     net = AGNetwork(desc)
@@ -192,7 +192,7 @@ def main():
                          "flops_per_position": flops, "positions_per_launch": local_evals / args.steps,
                          "avg_launch_ms": ms_nn / args.steps},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only
             result["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
         print(json.dumps(result))
     if dist is not None:
