@@ -145,3 +145,4 @@ def _declare(c):  # noqa: F811
     c.agx_debug_pattern_state.argtypes = [vp, vp, vp, vp, ci, ci, vp, vp, vp, ci]
     c.agx_host_tables.argtypes = [ci, vp, vp, vp, vp]
     c.agx_make_opening.argtypes = [ci, ci, ctypes.c_uint32, vp]
+    c.agx_get_outcome.argtypes = [ci, ci, vp, ci, ci, ci, ci, vp]

@@ -136,6 +136,11 @@ namespace agx
 				uint32_t act[ACT_LDS];   // head of the action stack (the tail, if ever needed, spills to HBM)
 				uint32_t row_mask[MAXN]; // scratch row masks of the move generator
 				uint16_t sets[5][32];    // small location sets of the move generator (kept out of per-lane scratch memory)
+				uint16_t tmp_list[MAXHW]; // copy of a threat list that renju foul checks would permute while it is iterated
+				uint16_t foul_cell[64];  // MoveGenerator::forbidden_moves_cache (MoveGenerator.hpp:74)
+				uint8_t foul_flag[64];
+				int foul_count;
+				int fstack[16][5];       // explicit stack of the recursive renju 3x3 check: cell, dir, i, count, promotion mask
 				u64 pf_bucket[8];        // transposition-table bucket prefetched for the child about to be entered
 				u64 pf_lo;
 				int pf_valid;
@@ -422,7 +427,193 @@ namespace agx
 			wave_sync();
 		}
 
-		/* NNInputFeatures::encode (NNInputFeatures.cpp:15-32,59-113), non-renju */
+		/* getOpenThreePromotionMoves (DefensiveMoveTable.cpp:329-377): first matching shape wins */
+		__constant__ const uint32_t PROMO_PATTERNS[12] = { 320u, 4352u, 20480u, 80u, 16640u, 69632u, 272u, 4160u, 81920u, 320u, 4352u, 20480u };
+		__constant__ const uint32_t PROMO_MASKS[12] = { 65520u, 262080u, 1048320u, 16380u, 262080u, 1048320u, 16380u, 65520u, 1048320u, 16380u, 65520u, 262080u };
+		__constant__ const uint32_t PROMO_RESULTS[12] = { 196u, 392u, 784u, 82u, 328u, 656u, 74u, 148u, 592u, 70u, 140u, 280u };
+		__device__ __forceinline__ uint32_t promotion_moves(uint32_t pattern)
+		{
+			for (int i = 0; i < 12; i++)
+				if ((pattern & PROMO_MASKS[i]) == PROMO_PATTERNS[i])
+					return PROMO_RESULTS[i];
+			return 0;
+		}
+		__device__ __forceinline__ bool straight_four_at(const SolverShared &sh, int n, int r, int c, int d)
+		{ // RawPatternCalculator::isStraightFourAt (RawPatternCalculator.hpp:142-178) on the byte board, cross stone assumed at (r, c)
+			uint32_t line = 0;
+			for (int k = -5, shf = 0; k <= 5; k++, shf += 2)
+			{
+				const int rr = r + k * row_step(d), cc = c + k * col_step(d);
+				uint32_t v = (rr >= 0 && rr < n && cc >= 0 && cc < n) ? sh.board[rr * n + cc] : 3u;
+				if (k == 0)
+					v |= 1u;
+				line |= v << shf;
+			}
+			for (int k = 0; k < 7; k++, line >>= 2)
+				if ((line & 255u) == 85u)
+					return true;
+			return false;
+		}
+		/*
+		 * PatternCalculator::isForbidden + is_3x3_forbidden (PatternCalculator.hpp:161-177, PatternCalculator.cpp:213-244) for the
+		 * cross player under renju.  The reference recurses through addMove / isForbidden / undoMove; here the recursion is an
+		 * explicit stack, and the stone placement is the same wave-wide incremental update as everywhere else (so the threat lists are
+		 * permuted exactly as in the reference).  Called by ALL lanes.
+		 */
+		__device__ __noinline__ bool renju_is_forbidden(SolverShared &sh, const EngineDev &E, int cell0, int lane)
+		{
+			const int n = E.n;
+			if (sh.board[cell0] != 0)
+				return false;
+			{
+				const int t = sh.threat[cell0][0];
+				if (t == 9 || t == 6)
+					return true;
+				if (t != 3)
+					return false;
+			}
+			int sp = 0;
+			bool ret = false;
+			int phase = 0; // 0 start of frame, 1 scan directions, 2 scan promotion moves, 3 child returned
+			if (lane == 0)
+				sh.fstack[0][0] = cell0;
+			wave_sync();
+			while (true)
+			{
+				const int cell = sh.fstack[sp][0];
+				const int r = cell / n, c = cell % n;
+				if (phase == 0)
+				{
+					bool decided = true;
+					if (sh.board[cell] != 0)
+						ret = false;
+					else
+					{
+						const int t = sh.threat[cell][0];
+						if (t == 9 || t == 6)
+							ret = true;
+						else if (t != 3)
+							ret = false;
+						else
+							decided = false;
+					}
+					if (decided)
+					{
+						if (sp == 0)
+							return ret;
+						sp--;
+						phase = 3;
+						continue;
+					}
+					if (lane == 0)
+					{
+						sh.fstack[sp][1] = 0; // dir
+						sh.fstack[sp][3] = 0; // count
+					}
+					wave_sync();
+					phase = 1;
+				}
+				if (phase == 1)
+				{
+					int dir = sh.fstack[sp][1];
+					while (dir < 4 && sh.ptype[cell][dir] != 2)
+						dir++;
+					if (dir >= 4)
+					{
+						ret = sh.fstack[sp][3] >= 2;
+						if (sp == 0)
+							return ret;
+						sp--;
+						phase = 3;
+						continue;
+					}
+					const uint32_t promo = promotion_moves(normal_pattern(sh, n, r, c, dir));
+					if (lane == 0)
+					{
+						sh.fstack[sp][1] = dir;
+						sh.fstack[sp][2] = -5;
+						sh.fstack[sp][4] = static_cast<int>(promo);
+						sh.board[cell] = 1; // Board::putMove on the raw board only
+					}
+					wave_sync();
+					phase = 2;
+				}
+				if (phase == 2)
+				{
+					const int dir = sh.fstack[sp][1];
+					const uint32_t promo = static_cast<uint32_t>(sh.fstack[sp][4]);
+					int i = sh.fstack[sp][2];
+					int found = -1;
+					for (; i <= 5; i++)
+						if ((promo >> (5 + i)) & 1)
+						{
+							const int rr = r + i * row_step(dir), cc = c + i * col_step(dir);
+							if (sh.board[rr * n + cc] == 0 && straight_four_at(sh, n, rr, cc, dir))
+							{
+								found = rr * n + cc;
+								break;
+							}
+						}
+					if (found < 0)
+					{
+						if (lane == 0)
+						{
+							sh.board[cell] = 0;
+							sh.fstack[sp][1] = dir + 1;
+						}
+						wave_sync();
+						phase = 1;
+						continue;
+					}
+					if (sp + 1 >= 16)
+					{
+						sh.error = ERR_FRAMES;
+						if (lane == 0)
+							sh.board[cell] = 0;
+						wave_sync();
+						return true;
+					}
+					if (lane == 0)
+					{
+						sh.fstack[sp][2] = i;
+						sh.board[cell] = 0;
+						sh.fstack[sp + 1][0] = found;
+					}
+					wave_sync();
+					solver_place(sh, E, 1u | (static_cast<uint32_t>(r) << 2) | (static_cast<uint32_t>(c) << 9), true, lane);
+					sp++;
+					phase = 0;
+					continue;
+				}
+				if (phase == 3)
+				{ // the child (at sp + 1) returned `ret`
+					solver_place(sh, E, 1u | (static_cast<uint32_t>(r) << 2) | (static_cast<uint32_t>(c) << 9), false, lane);
+					if (!ret)
+					{
+						if (lane == 0)
+						{
+							sh.fstack[sp][3] += 1;
+							sh.board[cell] = 0;
+							sh.fstack[sp][1] += 1; // leave this direction ("break")
+						}
+						wave_sync();
+						phase = 1;
+					}
+					else
+					{
+						if (lane == 0)
+						{
+							sh.board[cell] = 1;
+							sh.fstack[sp][2] += 1;
+						}
+						wave_sync();
+						phase = 2;
+					}
+				}
+			}
+		}
+
+		/* NNInputFeatures::encode (NNInputFeatures.cpp:15-32,59-113) */
 		__device__ __forceinline__ void solver_encode_features(const SolverShared &sh, const EngineDev &E, uint32_t *out, int lane)
 		{
 			const int own = sh.sign_to_move;
@@ -441,6 +632,25 @@ namespace agx
 				const uint32_t stone = (v == 0) ? 1u : ((v == own) ? 2u : 4u);
 				out[cell] = base | stone | pat;
 			}
+		}
+		/* the renju part of encode (NNInputFeatures.cpp:105-112): bit 6 on every cell that is a foul for cross, probed in row-major
+		 * order (the probes of 3x3 forks place and remove stones, i.e. permute the threat lists, exactly like the reference) */
+		__device__ __forceinline__ void solver_encode_forbidden(SolverShared &sh, const EngineDev &E, uint32_t *out, int lane)
+		{
+			if (E.rules != AGX_RENJU || sh.sign_to_move != 1)
+				return;
+			wave_sync();
+			for (int cell = 0; cell < E.hw; cell++)
+			{
+				const int t = sh.threat[cell][0];
+				if (sh.board[cell] == 0 && (t == 9 || t == 6 || t == 3))
+					if (renju_is_forbidden(sh, E, cell, lane))
+					{
+						if (lane == 0)
+							out[cell] |= (1u << 6);
+					}
+			}
+			wave_sync();
 		}
 
 		/* ---------------- defensive-move lookup (DefensiveMoveTable.cpp:380-461) ---------------- */
@@ -576,6 +786,7 @@ namespace agx
 			return -1;
 		}
 
+		template<bool RENJU>
 		struct MoveGen
 		{
 				SolverShared &sh;
@@ -609,7 +820,37 @@ namespace agx
 					return 0;
 				}
 				__device__ __forceinline__ bool has_any_four(int sign) const { return count(sign, 4) > 0 || count(sign, 5) > 0 || count(sign, 6) > 0 || count(sign, 7) > 0; }
-				__device__ __forceinline__ int available_fours(int sign) const { return count(sign, 7) + count(sign, 6) + count(sign, 5) + count(sign, 4); }
+				__device__ __forceinline__ bool fouls_possible_for(int sign) const { return RENJU && sign == 1; } // MoveGenerator.cpp:1155-1158
+				__device__ __forceinline__ int available_fours(int sign) const
+				{ // :1198-1207
+					return count(sign, 7) + (fouls_possible_for(sign) ? 0 : count(sign, 6)) + count(sign, 5) + count(sign, 4);
+				}
+				__device__ __forceinline__ bool is_foul(int sign, int cell)
+				{ // MoveGenerator::is_forbidden with its per-generate cache (:1159-1173)
+					if (!fouls_possible_for(sign))
+						return false;
+					const int cached = sh.foul_count;
+					for (int k = 0; k < cached; k++)
+						if (sh.foul_cell[k] == cell)
+							return sh.foul_flag[k] != 0;
+					const bool r = renju_is_forbidden(sh, E, cell, lane);
+					if (cached < 64)
+					{
+						sh.foul_cell[cached] = static_cast<uint16_t>(cell);
+						sh.foul_flag[cached] = r ? 1 : 0;
+						sh.foul_count = cached + 1;
+					}
+					wave_sync();
+					return r;
+				}
+				__device__ __forceinline__ int copy_list(int sign, int t)
+				{ // MoveGenerator::get_copy_of (:1174-1178)
+					const int cnt = count(sign, t);
+					for (int i = lane; i < cnt; i += 64)
+						sh.tmp_list[i] = list(sign, t)[i];
+					wave_sync();
+					return cnt;
+				}
 
 				__device__ __forceinline__ void push(uint32_t move, uint32_t score, int num)
 				{ // ActionList::add (ActionList.hpp:190-195)
@@ -660,6 +901,44 @@ namespace agx
 						if ((mask >> (6 + i)) & 1)
 							out.add((r + i * row_step(dir)) * n + (c + i * col_step(dir)));
 				}
+				__device__ __forceinline__ void get_defensive_moves(int cell, int dir, SmallSet &out)
+				{ // MoveGenerator::get_defensive_moves (:263-308): defender is the side to move
+					defensive_moves(own, cell, dir, out);
+					if (fouls_possible_for(own))
+					{
+						int i = 0;
+						while (i < out.n)
+						{
+							const int candidate = out.v[i];
+							if (is_foul(own, candidate))
+							{
+								add_move(candidate, s_loss_in(1), true);
+								out.remove_at(i);
+							}
+							else
+								i++;
+						}
+					}
+					else if (fouls_possible_for(opp))
+					{
+						if (patterns(opp, cell)[dir] == 4)
+						{
+							const int r = cell / n, c = cell % n;
+							const uint32_t raw = extended_pattern(sh, n, r, c, dir);
+							int type = 0;
+							if ((raw & 65520u) == 1344u)
+								type = -1;
+							if ((raw & 4193280u) == 344064u)
+								type = +1;
+							if (type != 0)
+							{
+								const int far = (r + 4 * type * row_step(dir)) * n + (c + 4 * type * col_step(dir));
+								if (is_foul(opp, far))
+									out.add((r - type * row_step(dir)) * n + (c - type * col_step(dir)));
+							}
+						}
+					}
+				}
 				__device__ __forceinline__ static void intersect(SmallSet &lhs, const SmallSet &rhs)
 				{
 					int i = 0;
@@ -684,13 +963,19 @@ namespace agx
 				}
 				__device__ __forceinline__ uint32_t try_solve_own_fork_4x3(int cell)
 				{ // :947-992
+					if (fouls_possible_for(own))
+						return s_unknown(15);
 					const int dir = direction_of(patterns(own, cell), 3);
 					SmallSet dm(sh.sets[4]);
 					defensive_moves(opp, cell, dir, dm);
 					dm.remove(cell);
 					int best = 0;
 					for (int i = 0; i < dm.n; i++)
-						best = max(best, threat_at(opp, dm.v[i]));
+					{
+						const int tt = threat_at(opp, dm.v[i]);
+						if ((tt != 6 && tt != 9) || !fouls_possible_for(opp))
+							best = max(best, tt);
+					}
 					switch (best)
 					{
 						case 4:
@@ -722,8 +1007,22 @@ namespace agx
 				}
 				__device__ __forceinline__ void add_own_half_open_fours()
 				{ // :894-946
+					int hidden = 0;
+					if (fouls_possible_for(own))
+					{ // a half-open four hidden inside a legal 3x3 fork
+						const int cnt = copy_list(own, 3);
+						for (int k = 0; k < cnt; k++)
+						{
+							const int cell = sh.tmp_list[k];
+							if (count_of(patterns(own, cell), 3) > 0 && !is_foul(own, cell))
+							{
+								add_move(cell, s_unknown(14), false);
+								hidden++;
+							}
+						}
+					}
 					add_list(own, 4, s_unknown(14), false);
-					if (count(own, 4) > 0)
+					if (hidden + count(own, 4) > 0)
 						f.has_initiative = 1;
 				}
 				/* 7x7 stencil (vertically and horizontally symmetric) OR-ed around every set bit of `occupied` rows: row R of the result
@@ -798,6 +1097,26 @@ namespace agx
 				__device__ __forceinline__ bool try_draw_in_1(uint32_t &result)
 				{ // :309-354
 					f.baseline = static_cast<uint16_t>(s_draw_in(1));
+					if (fouls_possible_for(own))
+					{
+						bool found = false;
+						for (int cell = 0; cell < n * n; cell++)
+							if (sh.board[cell] == 0)
+							{
+								const int t = threat_at(own, cell);
+								if (t == 6 || t == 9)
+									add_move(cell, s_loss_in(1), false);
+								else if (t == 3 && is_foul(own, cell))
+									add_move(cell, s_loss_in(1), false);
+								else
+								{
+									add_move(cell, s_draw_in(1), false);
+									found = true;
+								}
+							}
+						result = found ? s_draw_in(1) : s_loss_in(1);
+						return false;
+					}
 					create_remaining_moves(sh.legal, s_draw_in(1));
 					result = s_draw_in(1);
 					return false;
@@ -815,7 +1134,7 @@ namespace agx
 					{
 						const int cell = list(opp, 8)[k];
 						const int dir = direction_of(patterns(opp, cell), 6);
-						defensive_moves(own, cell, dir, tmp);
+						get_defensive_moves(cell, dir, tmp);
 						intersect_init(dm, initialized, tmp);
 						if (dm.n == 0)
 						{
@@ -832,7 +1151,12 @@ namespace agx
 						switch (threat_at(own, cell))
 						{
 							case 3: // FORK_3x3
-								if (!has_any_four(opp))
+								if (fouls_possible_for(own))
+								{
+									if (count_of(patterns(own, cell), 4) > 0)
+										response = s_win_in(3); // an open four hidden inside a legal 3x3 fork
+								}
+								else if (!has_any_four(opp))
 									response = s_win_in(5);
 								break;
 							case 5: // FORK_4x3
@@ -864,12 +1188,49 @@ namespace agx
 				__device__ __forceinline__ bool try_win_in_3(uint32_t &result)
 				{ // :464-555
 					int threats = 0;
+					if (fouls_possible_for(own))
+					{ // an open four hidden inside a legal 3x3 fork
+						const int cnt = copy_list(own, 3);
+						for (int k = 0; k < cnt; k++)
+						{
+							const int cell = sh.tmp_list[k];
+							if (count_of(patterns(own, cell), 4) > 0 && !is_foul(own, cell))
+							{
+								threats++;
+								add_move(cell, s_win_in(3), false);
+							}
+						}
+					}
 					add_list(own, 7, s_win_in(3), false);
 					threats += count(own, 7);
-					if (count(own, 6) > 0)
+					if (count(own, 6) > 0 && !fouls_possible_for(own))
 					{
 						threats += count(own, 6);
 						add_list(own, 6, s_win_in(3), false);
+					}
+					if (fouls_possible_for(opp))
+					{ // a four whose only defence is a foul for the opponent (circle to move)
+						const int cnt = copy_list(own, 4);
+						for (int k = 0; k < cnt; k++)
+						{
+							const int cell = sh.tmp_list[k];
+							const int dir = direction_of(patterns(own, cell), 3);
+							bool winning = false;
+							const int ot = threat_at(opp, cell);
+							if (ot == 3)
+								winning = (patterns(opp, cell)[dir] != 2) && is_foul(opp, cell);
+							else if (ot == 6 || ot == 9)
+								winning = true;
+							if (winning)
+							{
+								SmallSet two(sh.sets[4]);
+								defensive_moves(opp, cell, dir, two);
+								const int original = (two.v[0] == cell) ? two.v[1] : two.v[0];
+								add_move(original, s_win_in(3), false);
+								result = s_win_in(3);
+								return false;
+							}
+						}
 					}
 					if (threats > 0)
 					{
@@ -879,19 +1240,86 @@ namespace agx
 					}
 					return true;
 				}
+				__device__ __forceinline__ bool defend_loss_in_4_renju(bool any_four, uint32_t &result)
+				{ // :621-677: no intersection of defences in renju, every defensive move of every threat is kept
+					SmallSet tmp(sh.sets[1]);
+					{
+						const int cnt = copy_list(opp, 7);
+						for (int k = 0; k < cnt; k++)
+						{
+							f.must_defend = 1;
+							const int cell = sh.tmp_list[k];
+							const int dir = direction_of(patterns(opp, cell), 4);
+							get_defensive_moves(cell, dir, tmp);
+							for (int i = 0; i < tmp.n; i++)
+								add_move(tmp.v[i], s_unknown(0), false);
+						}
+					}
+					if (fouls_possible_for(opp))
+					{
+						const int cnt = copy_list(opp, 3);
+						for (int k = 0; k < cnt; k++)
+						{
+							const int cell = sh.tmp_list[k];
+							if (count_of(patterns(opp, cell), 4) > 0 && !is_foul(opp, cell))
+							{
+								f.must_defend = 1;
+								const int dir = direction_of(patterns(opp, cell), 4);
+								get_defensive_moves(cell, dir, tmp);
+								for (int i = 0; i < tmp.n; i++)
+									add_move(tmp.v[i], s_unknown(0), false);
+							}
+						}
+					}
+					else
+					{
+						const int cnt = copy_list(opp, 6);
+						for (int k = 0; k < cnt; k++)
+						{
+							f.must_defend = 1;
+							const int cell = sh.tmp_list[k];
+							for (int d = 0; d < 4; d++)
+							{
+								const int pt = patterns(opp, cell)[d];
+								if (pt == 3 || pt == 4 || pt == 5)
+								{
+									get_defensive_moves(cell, d, tmp);
+									for (int i = 0; i < tmp.n; i++)
+										add_move(tmp.v[i], s_unknown(0), false);
+								}
+							}
+						}
+					}
+					return finish_defend_loss_in_4(any_four, result);
+				}
+				__device__ __forceinline__ bool finish_defend_loss_in_4(bool any_four, uint32_t &result)
+				{
+					if (f.must_defend)
+					{
+						f.has_initiative = any_four ? 1 : 0;
+						const uint32_t best = add_own_4x3_forks();
+						add_own_half_open_fours();
+						result = s_win(best) ? best : s_unknown(0);
+						return false;
+					}
+					f.baseline = static_cast<uint16_t>(s_unknown(0));
+					return true;
+				}
 				__device__ __forceinline__ bool defend_loss_in_4(uint32_t &result)
-				{ // :556-689 (non-renju branch)
+				{ // :556-689
 					const bool any_four = has_any_four(own);
 					f.baseline = static_cast<uint16_t>(s_loss_in(4));
 					SmallSet dm(sh.sets[0]), tmp(sh.sets[1]), storage(sh.sets[2]);
 					bool initialized = false;
+					if (RENJU)
+						return defend_loss_in_4_renju(any_four, result);
 					const int n_open4 = count(opp, 7);
 					for (int k = 0; k < n_open4; k++)
 					{
 						f.must_defend = 1;
 						const int cell = list(opp, 7)[k];
 						const int dir = direction_of(patterns(opp, cell), 4);
-						defensive_moves(own, cell, dir, tmp);
+						get_defensive_moves(cell, dir, tmp);
 						intersect_init(dm, initialized, tmp);
 						if (dm.n == 0 && !any_four)
 						{
@@ -909,7 +1337,7 @@ namespace agx
 						for (int d = 0; d < 4; d++)
 							if (group[d] == 4 || group[d] == 5)
 							{
-								defensive_moves(own, cell, d, tmp);
+								get_defensive_moves(cell, d, tmp);
 								intersect_init(dm, initialized, tmp);
 							}
 						if (count_of(group, 3) > 0)
@@ -918,7 +1346,7 @@ namespace agx
 							for (int d = 0; d < 4; d++)
 								if (group[d] == 3)
 								{
-									defensive_moves(own, cell, d, tmp);
+									get_defensive_moves(cell, d, tmp);
 									for (int i = 0; i < tmp.n; i++)
 										if (!storage.contains(tmp.v[i]))
 											storage.add(tmp.v[i]);
@@ -948,7 +1376,7 @@ namespace agx
 				__device__ __forceinline__ bool try_win_in_5(uint32_t &result)
 				{ // :690-720
 					uint32_t best = add_own_4x3_forks();
-					if (available_fours(opp) == 0 && count(own, 3) > 0)
+					if (!fouls_possible_for(own) && available_fours(opp) == 0 && count(own, 3) > 0)
 					{
 						add_list(own, 3, s_win_in(5), false);
 						best = max(best, s_win_in(5));
@@ -979,12 +1407,12 @@ namespace agx
 						for (int d = 0; d < 4; d++)
 							if (group[d] == 2)
 							{
-								defensive_moves(own, cell, d, tmp);
+								get_defensive_moves(cell, d, tmp);
 								for (int i = 0; i < tmp.n; i++)
 									add_move(tmp.v[i], s_unknown(0), false);
 							}
 						const int dir = direction_of(group, 3);
-						defensive_moves(own, cell, dir, half4);
+						get_defensive_moves(cell, dir, half4);
 						for (int i = 0; i < half4.n; i++)
 							add_move(half4.v[i], s_unknown(0), false);
 						for (int i = 0; i < half4.n; i++)
@@ -1012,7 +1440,7 @@ namespace agx
 						for (int d = 0; d < 4; d++)
 							if (group[d] == 2)
 							{
-								defensive_moves(own, cell, d, tmp);
+								get_defensive_moves(cell, d, tmp);
 								for (int i = 0; i < tmp.n; i++)
 									add_move(tmp.v[i], s_unknown(0), false);
 							}
@@ -1051,6 +1479,15 @@ namespace agx
 				}
 
 				/* MoveGenerator::generate (:159-223); mode 1 = THREATS, 2 = OPTIMAL */
+				__device__ __forceinline__ void mark_forbidden_moves()
+				{ // :993-1010
+					add_list(own, 9, s_loss_in(1), true);
+					add_list(own, 6, s_loss_in(1), true);
+					const int cnt = copy_list(own, 3);
+					for (int k = 0; k < cnt; k++)
+						if (is_foul(1, sh.tmp_list[k]))
+							add_move(sh.tmp_list[k], s_loss_in(1), true);
+				}
 				__device__ __forceinline__ uint32_t generate(int mode)
 				{
 					const int distance_to_draw = E.draw_after - board_depth;
@@ -1058,6 +1495,7 @@ namespace agx
 						return s_make(1, 0);
 					for (int r = 0; r < n; r++)
 						sh.added[r] = 0;
+					sh.foul_count = 0;
 					uint32_t result = s_unknown(0);
 					bool go = true;
 					if (go && distance_to_draw >= 1) go = try_win_in_1(result);
@@ -1085,6 +1523,8 @@ namespace agx
 						mark_neighborhood();
 						create_remaining_moves(sh.row_mask, s_unknown(0));
 					}
+					if (fouls_possible_for(own))
+						mark_forbidden_moves();
 					f.fully_expanded = (f.must_defend || mode >= 2) ? 1 : 0;
 					return result;
 				}
@@ -1150,6 +1590,7 @@ namespace agx
 		 * Runs until a stone must be placed/removed (returns CMD_ADD / CMD_UNDO with sh.cmd_move) or the root returns (CMD_DONE).
 		 * phase: 0 = enter frame `level`, 1 = resume frame `level` after its child returned sh.pending_value.
 		 */
+		template<bool RENJU>
 		__device__ __forceinline__ int solver_run(SolverShared &sh, const EngineDev &E, uint32_t *act, u64 *tt, int generation, int lane, u64 &pf_word)
 		{ // executed by ALL lanes with identical (wave-uniform) state: stores are same-address / same-value, scans are lane-parallel.
 		  // The scalars of the machine and the current frame are held in registers and written back to LDS only when the machine yields.
@@ -1228,7 +1669,7 @@ namespace agx
 						node_counter++;
 						if (f.size == 0)
 						{
-							MoveGen gen(sh, E, act, f, lane, stack_offset, stack_max);
+							MoveGen<RENJU> gen(sh, E, act, f, lane, stack_offset, stack_max);
 							const uint32_t static_score = gen.generate(level == 0 ? 2 : 1);
 							stack_offset = gen.stack_offset;
 							stack_max = gen.stack_max;

@@ -20,6 +20,7 @@
 #include "engine_types.hpp"
 #include "dev_mcts.hpp"
 #include "tables_host.hpp"
+#include "renju_static.hpp"
 
 #include <vector>
 #include <cstring>
@@ -175,6 +176,7 @@ namespace
 	}
 
 	/* ------------------------------------------------------------------------------------------------------------ */
+	template<bool RENJU>
 	__device__ __forceinline__ void solve_task(SolverShared &sh, const EngineDev &E, int g, DTask &t, int slot, int generation, int lane, unsigned long long &solver_nodes)
 	{ // AlphaBetaSearch::solve (AlphaBetaSearch.cpp:77-156)
 		uint32_t *act = E.act + static_cast<size_t>(g) * E.act_cap;
@@ -184,6 +186,8 @@ namespace
 #endif
 		solver_set_board(sh, E, t.board, t.sign_to_move, lane);
 		solver_encode_features(sh, E, E.nn_features + static_cast<size_t>(slot) * E.hw, lane);
+		if (RENJU)
+			solver_encode_forbidden(sh, E, E.nn_features + static_cast<size_t>(slot) * E.hw, lane);
 #ifdef AGX_SOLVER_PROFILE
 		unsigned long long c1 = wall_clock64();
 #endif
@@ -245,7 +249,7 @@ namespace
 #ifdef AGX_SOLVER_PROFILE
 				const unsigned long long r0 = wall_clock64();
 #endif
-				const int cmd_now = solver_run(sh, E, act, tt, generation, lane, pf_word);
+				const int cmd_now = solver_run<RENJU>(sh, E, act, tt, generation, lane, pf_word);
 				if (lane == 0)
 					sh.cmd = cmd_now;
 				wave_sync();
@@ -323,6 +327,7 @@ namespace
 		wave_sync();
 	}
 
+	template<bool RENJU>
 	__global__ __launch_bounds__(64) void k_solve(EngineDev E)
 	{
 		__shared__ SolverShared sh;
@@ -358,7 +363,7 @@ namespace
 						break;
 					}
 				}
-				solve_task(sh, E, g, t, slot, gs.generation, lane, solver_nodes);
+				solve_task<RENJU>(sh, E, g, t, slot, gs.generation, lane, solver_nodes);
 			}
 		}
 		if (yielded)
@@ -847,7 +852,7 @@ namespace
 		else if (tid == 0)
 			gs.error = ERR_RECORDS;
 
-		// ---- Game::makeMove + getOutcome (Game.cpp:104-122, rules.cpp:110-133; non-renju) ----
+		// ---- Game::makeMove + getOutcome (Game.cpp:104-122, rules.cpp:110-133) ----
 		const int s = mv & 3, r = (mv >> 2) & 127, c = (mv >> 9) & 127, cell = r * n + c;
 		if (tid == 0)
 		{
@@ -878,6 +883,8 @@ namespace
 			int outcome = 0;
 			if (win)
 				outcome = (s == 1) ? 2 : 3;
+			else if (E.rules == AGX_RENJU && s == 1 && renju_static_foul(E.t_pattern, E.t_threat, gs.board, n, cell))
+				outcome = 3; // a foul of the cross player loses the game (rules.cpp:127-128)
 			else if (gs.n_moves >= E.draw_after)
 				outcome = 1;
 			gs.outcome = outcome;
@@ -1148,7 +1155,6 @@ int agx_engine_default_config(AgxEngineConfig *cfg)
 int agx_engine_create(const AgxEngineConfig *cfg, AgxEngine **out)
 {
 	AGX_REQUIRE(cfg != nullptr && out != nullptr, AGX_ERR_INVALID, "agx_engine_create: null argument");
-	AGX_REQUIRE(cfg->rules != AGX_RENJU, AGX_ERR_UNSUPPORTED, "agx_engine_create: renju (forbidden moves) is not supported by the device engine yet");
 	AGX_REQUIRE(cfg->rules >= 0 && cfg->rules <= AGX_CARO6, AGX_ERR_INVALID, "agx_engine_create: unknown rules %d", cfg->rules);
 	AGX_REQUIRE(cfg->board_size >= 5 && cfg->board_size <= MAXN, AGX_ERR_UNSUPPORTED, "agx_engine_create: board size %d not in [5, %d]", cfg->board_size, MAXN);
 	AGX_REQUIRE(cfg->n_games > 0 && cfg->max_batch_size > 0 && cfg->max_simulations > 0, AGX_ERR_INVALID, "agx_engine_create: non-positive sizes");
@@ -1300,7 +1306,10 @@ int agx_engine_select_solve_group(AgxEngine *e, int group, int n_groups, void *s
 	hipStream_t s = static_cast<hipStream_t>(stream);
 	hipLaunchKernelGGL(k_reset_counter, dim3(1), dim3(1), 0, s, d.counters + d.nn_counter, d.counters + d.yield_counter);
 	hipLaunchKernelGGL(k_select, dim3(count), dim3(64), 0, s, d);
-	hipLaunchKernelGGL(k_solve, dim3(count), dim3(64), 0, s, d);
+	if (d.rules == AGX_RENJU)
+		hipLaunchKernelGGL(k_solve<true>, dim3(count), dim3(64), 0, s, d);
+	else
+		hipLaunchKernelGGL(k_solve<false>, dim3(count), dim3(64), 0, s, d);
 	AGX_HIP_CHECK(hipGetLastError());
 	return AGX_OK;
 }
@@ -1553,7 +1562,10 @@ int agx_debug_solve(AgxEngine *e, const uint8_t *h_boards, const int *h_signs, i
 	dd.nn_counter = 16;
 	dd.yield_fraction = 0.0f;
 	hipLaunchKernelGGL(k_reset_counter, dim3(1), dim3(1), 0, nullptr, dd.counters + dd.nn_counter, static_cast<int*>(nullptr));
-	hipLaunchKernelGGL(k_solve, dim3(count), dim3(64), 0, nullptr, dd);
+	if (dd.rules == AGX_RENJU)
+		hipLaunchKernelGGL(k_solve<true>, dim3(count), dim3(64), 0, nullptr, dd);
+	else
+		hipLaunchKernelGGL(k_solve<false>, dim3(count), dim3(64), 0, nullptr, dd);
 	AGX_HIP_CHECK(hipGetLastError());
 	AGX_HIP_CHECK(hipDeviceSynchronize());
 	std::vector<DTask> tasks(1);

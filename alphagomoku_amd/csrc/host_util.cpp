@@ -10,6 +10,7 @@
  */
 #include "agx_internal.hpp"
 #include "tables_host.hpp"
+#include "renju_static.hpp"
 
 #include <cmath>
 #include <cstring>
@@ -58,7 +59,7 @@ namespace
 extern "C" int agx_make_opening(int rules, int board_size, uint32_t seed, uint16_t *h_opening)
 {
 	AGX_REQUIRE(h_opening != nullptr, AGX_ERR_INVALID, "agx_make_opening: null output");
-	AGX_REQUIRE(rules >= 0 && rules <= AGX_CARO6 && rules != AGX_RENJU, AGX_ERR_UNSUPPORTED, "agx_make_opening: rules %d not supported", rules);
+	AGX_REQUIRE(rules >= 0 && rules <= AGX_CARO6, AGX_ERR_UNSUPPORTED, "agx_make_opening: rules %d not supported", rules);
 	AGX_REQUIRE(board_size >= 5 && board_size <= 20, AGX_ERR_INVALID, "agx_make_opening: board size %d", board_size);
 	const agx::HostTables &tables = tables_for(rules);
 	const int n = board_size, hw = n * n;
@@ -126,7 +127,10 @@ extern "C" int agx_make_opening(int rules, int board_size, uint32_t seed, uint16
 			moves.push_back(static_cast<uint16_t>(sign | (last_r << 2) | (last_c << 9)));
 			sign = 3 - sign;
 		}
-		if (moves.empty() || !last_move_wins(tables, board, n, last_r, last_c, 3 - sign))
+		bool undecided = moves.empty() || !last_move_wins(tables, board, n, last_r, last_c, 3 - sign);
+		if (undecided && !moves.empty() && rules == AGX_RENJU && 3 - sign == 1)
+			undecided = !agx::renju_static_foul(tables.pattern.data(), tables.threat.data(), board.data(), n, last_r * n + last_c);
+		if (undecided)
 		{
 			std::memset(h_opening, 0, AGX_OPENING_CAP * sizeof(uint16_t));
 			h_opening[0] = static_cast<uint16_t>(moves.size());
@@ -135,4 +139,31 @@ extern "C" int agx_make_opening(int rules, int board_size, uint32_t seed, uint16
 			return AGX_OK;
 		}
 	}
+}
+
+extern "C" int agx_get_outcome(int rules, int board_size, const uint8_t *h_board, int sign, int row, int col, int draw_after, int *outcome)
+{
+	AGX_REQUIRE(h_board != nullptr && outcome != nullptr, AGX_ERR_INVALID, "agx_get_outcome: null argument");
+	AGX_REQUIRE(rules >= 0 && rules <= AGX_CARO6, AGX_ERR_INVALID, "agx_get_outcome: unknown rules %d", rules);
+	AGX_REQUIRE(board_size >= 5 && board_size <= 20, AGX_ERR_INVALID, "agx_get_outcome: board size %d", board_size);
+	AGX_REQUIRE(sign == AGX_CROSS || sign == AGX_CIRCLE, AGX_ERR_INVALID, "agx_get_outcome: sign %d", sign);
+	const int n = board_size;
+	*outcome = 0;
+	if (!(row >= 0 && row < n && col >= 0 && col < n))
+		return AGX_OK; // rules.cpp:112-113: a move outside the board decides nothing
+	const agx::HostTables &tables = tables_for(rules);
+	std::vector<uint8_t> board(h_board, h_board + n * n);
+	if (last_move_wins(tables, board, n, row, col, sign))
+		*outcome = (sign == AGX_CROSS) ? 2 : 3;
+	else if (rules == AGX_RENJU && sign == AGX_CROSS && agx::renju_static_foul(tables.pattern.data(), tables.threat.data(), board.data(), n, row * n + col))
+		*outcome = 3;
+	else
+	{
+		int stones = 0;
+		for (int i = 0; i < n * n; i++)
+			stones += (board[i] != 0);
+		if ((draw_after > 0) ? (stones >= draw_after) : (stones == n * n))
+			*outcome = 1;
+	}
+	return AGX_OK;
 }

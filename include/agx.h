@@ -186,6 +186,11 @@ typedef struct AgxMoveRecord
 /* Host-only: one synthetic random opening with the distribution of the reference's prepareOpening (utils/misc.cpp:142-170);
  * h_opening receives AGX_OPENING_CAP words ([0] = stones, then Move::toShort, cross first). */
 int agx_make_opening(int rules, int board_size, uint32_t seed, uint16_t* h_opening);
+/* Host-only: getOutcome (src/game/rules.cpp:110-133) after the stone `sign` was put on (row, col) of h_board (board_size^2
+ * bytes, 0 empty / 1 cross / 2 circle, the stone already on it): 0 unknown, 1 draw, 2 cross win, 3 circle win.  Under renju a
+ * foul of cross (isForbidden, rules.cpp:134-173) is a circle win.  draw_after <= 0 means "full board".  The same test runs on
+ * the device after every played move; this entry point is what openings and host-side callers use. */
+int agx_get_outcome(int rules, int board_size, const uint8_t* h_board, int sign, int row, int col, int draw_after, int* outcome);
 
 int agx_engine_default_config(AgxEngineConfig* cfg);
 int agx_engine_create(const AgxEngineConfig* cfg, AgxEngine** out);

@@ -44,7 +44,7 @@ def random_board(rng, stones, n=N):
     return b
 
 
-@pytest.mark.parametrize("rules", [0, 1, 3, 4])
+@pytest.mark.parametrize("rules", [0, 1, 2, 3, 4])
 def test_pattern_state_after_move_sequences(agx_lib, olib, rules):
     from alphagomoku_amd import selfplay
     rng = np.random.default_rng(10 + rules)
@@ -86,7 +86,7 @@ def test_pattern_state_after_move_sequences(agx_lib, olib, rules):
     pool.close()
 
 
-@pytest.mark.parametrize("rules", [0, 1, 3])
+@pytest.mark.parametrize("rules", [0, 1, 2, 3])
 def test_solver_matches_oracle_per_position(agx_lib, olib, rules):
     from alphagomoku_amd import selfplay, lib, check
     rng = np.random.default_rng(20 + rules)
@@ -101,7 +101,7 @@ def test_solver_matches_oracle_per_position(agx_lib, olib, rules):
         signs.append(1 if int((b != 0).sum()) % 2 == 0 else 2)
     out = pool.debug_solve(np.array(boards), signs)
     zob = pool.zobrist()
-    proven = 0
+    proven = fouls = 0
     for g in range(128):
         s = olib.ago_solver_create(rules, N, N, 1 << 16, cfg.zobrist_seed, 100)
         z = np.zeros(4 * HW, np.uint64)
@@ -120,7 +120,9 @@ def test_solver_matches_oracle_per_position(agx_lib, olib, rules):
         assert bool(fl.value & 1) == bool(out["flags"][g] & 1), g     # must_defend
         assert np.array_equal(feat, out["features"][g]), g
         proven += int(((rs.value >> 13) & 3) != 2)
+        fouls += int(((feat >> 6) & 1).sum())
     assert proven > 3   # the sample must exercise proven results too
+    assert rules != 2 or fouls > 20   # ... and, under renju, forbidden cells (overline, 4x4 and recursive 3x3 checks)
     pool.close()
 
 
@@ -227,7 +229,7 @@ def _stand_in_evaluator(olib):
     return f
 
 
-@pytest.mark.parametrize("rules,batch,sims", [(0, 1, 100), (0, 8, 100), (1, 4, 100), (3, 4, 60)])
+@pytest.mark.parametrize("rules,batch,sims", [(0, 1, 100), (0, 8, 100), (1, 4, 100), (2, 4, 100), (2, 8, 60), (3, 4, 60)])
 def test_whole_games_bit_exact_with_stand_in_evaluator(agx_lib, olib, rules, batch, sims):
     compared, stats = _play_and_compare(olib, rules, games=6, batch=batch, sims=sims, max_steps=4000, evaluator=_stand_in_evaluator(olib))
     assert compared > 500
@@ -338,7 +340,7 @@ def test_pool_step_with_device_network_is_deterministic_and_consistent(agx_lib):
 def test_engine_error_paths(agx_lib):
     from alphagomoku_amd import selfplay, AgxError
     with pytest.raises(AgxError):
-        selfplay.GeneratorPool(selfplay.default_config(rules=2))                      # renju not supported on the device yet
+        selfplay.GeneratorPool(selfplay.default_config(rules=7))                      # unknown rules
     with pytest.raises(AgxError):
         selfplay.GeneratorPool(selfplay.default_config(board_size=25))
     pool = selfplay.GeneratorPool(selfplay.default_config(n_games=2, tss_table_entries=1 << 10, node_capacity=64, edge_capacity=1024))
