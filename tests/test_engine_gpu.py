@@ -140,11 +140,12 @@ def _oracle_root(olib, h):
                 prior=ep[:n].copy(), val=evl[:2 * n].copy(), es=es[:n].copy())
 
 
-def _play_and_compare(olib, rules, games, batch, sims, max_steps, evaluator, table_entries=1 << 16):
+def _play_and_compare(olib, rules, games, batch, sims, max_steps, evaluator, table_entries=1 << 16, n=N):
     """evaluator(features uint32 [n][HW]) -> (policy [n][HW] f32, value [n][2] f32 (win, draw)); used for BOTH sides"""
     from alphagomoku_amd import selfplay
-    cfg = selfplay.default_config(rules=rules, n_games=games, max_batch_size=batch, max_simulations=sims, tss_table_entries=table_entries,
-                                  node_capacity=4096, edge_capacity=65536)
+    N, HW = n, n * n   # noqa: N806 (shadow the 15x15 module defaults)
+    cfg = selfplay.default_config(rules=rules, board_size=n, draw_after=n * n, n_games=games, max_batch_size=batch, max_simulations=sims,
+                                  tss_table_entries=table_entries, node_capacity=4096, edge_capacity=65536 if n <= 15 else 131072)
     pool = selfplay.GeneratorPool(cfg)
     ocfg = ol.default_search_config(max_batch_size=batch, max_simulations=sims, table_entries=table_entries)
     openings, handles = [], []
@@ -219,12 +220,12 @@ def _play_and_compare(olib, rules, games, batch, sims, max_steps, evaluator, tab
     return compared, stats
 
 
-def _stand_in_evaluator(olib):
+def _stand_in_evaluator(olib, hw=HW):
     def f(feats):
         feats = np.ascontiguousarray(feats, dtype=np.uint32)
-        pol = np.zeros((len(feats), HW), np.float32)
+        pol = np.zeros((len(feats), hw), np.float32)
         val = np.zeros((len(feats), 2), np.float32)
-        olib.ago_fake_eval(len(feats), HW, ol.ptr(feats), ol.ptr(pol), ol.ptr(val))
+        olib.ago_fake_eval(len(feats), hw, ol.ptr(feats), ol.ptr(pol), ol.ptr(val))
         return pol, val
     return f
 
@@ -234,6 +235,14 @@ def test_whole_games_bit_exact_with_stand_in_evaluator(agx_lib, olib, rules, bat
     compared, stats = _play_and_compare(olib, rules, games=6, batch=batch, sims=sims, max_steps=4000, evaluator=_stand_in_evaluator(olib))
     assert compared > 500
     assert stats["games_finished"] == 6 and stats["information_leaks"] > 0 and stats["proven_edge_visits"] > 0
+
+
+@pytest.mark.parametrize("rules,batch,sims", [(3, 8, 60), (0, 4, 60)])
+def test_whole_games_on_the_20x20_board(agx_lib, olib, rules, batch, sims):
+    """BASELINE configs[3] shape (caro, 20x20): solver lists, node-cache board words and record sizes at the largest board"""
+    compared, stats = _play_and_compare(olib, rules, games=4, batch=batch, sims=sims, max_steps=6000, evaluator=_stand_in_evaluator(olib, 400), n=20)
+    assert compared > 300
+    assert stats["games_finished"] == 4
 
 
 def test_yielding_pool_gives_the_same_games(agx_lib, olib):
