@@ -1084,10 +1084,53 @@ struct AgxEngine
 		std::vector<void*> allocations;
 		std::vector<uint64_t> zobrist; // [2*hw][2]
 		bool begun = false;
+		// optional per-kernel timing (agx_engine_kernel_timing): HIP events on the launch stream around every kernel of a step
+		bool timing = false;
+		std::vector<hipEvent_t> events;   // groups of (before, after) per kernel launch
+		std::vector<int> event_kernel;    // kernel id of each pair: 0 select, 1 solve, 2 expand, 3 advance
+		std::vector<hipEvent_t> free_events;
 };
 
 namespace
 {
+	hipEvent_t timing_event(AgxEngine *e)
+	{
+		hipEvent_t ev = nullptr;
+		if (!e->free_events.empty())
+		{
+			ev = e->free_events.back();
+			e->free_events.pop_back();
+		}
+		else
+			(void) hipEventCreate(&ev);
+		return ev;
+	}
+	struct KernelTimer
+	{ // records an event pair around one kernel launch when timing is enabled
+			AgxEngine *e;
+			hipStream_t s;
+			hipEvent_t a = nullptr;
+			KernelTimer(AgxEngine *engine, hipStream_t stream, int kernel) :
+					e(engine), s(stream)
+			{
+				if (e->timing)
+				{
+					a = timing_event(e);
+					(void) hipEventRecord(a, s);
+					e->event_kernel.push_back(kernel);
+				}
+			}
+			~KernelTimer()
+			{
+				if (e->timing)
+				{
+					hipEvent_t b = timing_event(e);
+					(void) hipEventRecord(b, s);
+					e->events.push_back(a);
+					e->events.push_back(b);
+				}
+			}
+	};
 	template<typename T>
 	int dev_alloc(AgxEngine *e, T **ptr, size_t count)
 	{
@@ -1256,6 +1299,10 @@ int agx_engine_destroy(AgxEngine *e)
 		return AGX_OK;
 	for (void *p : e->allocations)
 		(void) hipFree(p);
+	for (hipEvent_t ev : e->events)
+		(void) hipEventDestroy(ev);
+	for (hipEvent_t ev : e->free_events)
+		(void) hipEventDestroy(ev);
 	delete e;
 	return AGX_OK;
 }
@@ -1305,11 +1352,17 @@ int agx_engine_select_solve_group(AgxEngine *e, int group, int n_groups, void *s
 		return st;
 	hipStream_t s = static_cast<hipStream_t>(stream);
 	hipLaunchKernelGGL(k_reset_counter, dim3(1), dim3(1), 0, s, d.counters + d.nn_counter, d.counters + d.yield_counter);
-	hipLaunchKernelGGL(k_select, dim3(count), dim3(64), 0, s, d);
-	if (d.rules == AGX_RENJU)
-		hipLaunchKernelGGL(k_solve<true>, dim3(count), dim3(64), 0, s, d);
-	else
-		hipLaunchKernelGGL(k_solve<false>, dim3(count), dim3(64), 0, s, d);
+	{
+		KernelTimer t(e, s, 0);
+		hipLaunchKernelGGL(k_select, dim3(count), dim3(64), 0, s, d);
+	}
+	{
+		KernelTimer t(e, s, 1);
+		if (d.rules == AGX_RENJU)
+			hipLaunchKernelGGL(k_solve<true>, dim3(count), dim3(64), 0, s, d);
+		else
+			hipLaunchKernelGGL(k_solve<false>, dim3(count), dim3(64), 0, s, d);
+	}
 	AGX_HIP_CHECK(hipGetLastError());
 	return AGX_OK;
 }
@@ -1336,8 +1389,14 @@ int agx_engine_expand_backup_group(AgxEngine *e, int group, int n_groups, void *
 	if (st != AGX_OK)
 		return st;
 	hipStream_t s = static_cast<hipStream_t>(stream);
-	hipLaunchKernelGGL(k_expand, dim3(count), dim3(64), 0, s, d);
-	hipLaunchKernelGGL(k_advance, dim3(count), dim3(256), 0, s, d);
+	{
+		KernelTimer t(e, s, 2);
+		hipLaunchKernelGGL(k_expand, dim3(count), dim3(64), 0, s, d);
+	}
+	{
+		KernelTimer t(e, s, 3);
+		hipLaunchKernelGGL(k_advance, dim3(count), dim3(256), 0, s, d);
+	}
 	AGX_HIP_CHECK(hipGetLastError());
 	return AGX_OK;
 }
@@ -1544,6 +1603,34 @@ int agx_stream_synchronize(void *stream)
 }
 
 /* ---- test hooks: single stages on caller-supplied positions ---- */
+int agx_engine_kernel_timing(AgxEngine *e, int enable, double *ms_out, long long *launches_out)
+{
+	AGX_REQUIRE(e != nullptr, AGX_ERR_INVALID, "agx_engine_kernel_timing: null engine");
+	AGX_HIP_CHECK(hipDeviceSynchronize());
+	double ms[4] = { 0.0, 0.0, 0.0, 0.0 };
+	long long launches[4] = { 0, 0, 0, 0 };
+	for (size_t i = 0; i < e->event_kernel.size(); i++)
+	{
+		float t = 0.0f;
+		AGX_HIP_CHECK(hipEventElapsedTime(&t, e->events[2 * i], e->events[2 * i + 1]));
+		ms[e->event_kernel[i]] += t;
+		launches[e->event_kernel[i]]++;
+		e->free_events.push_back(e->events[2 * i]);
+		e->free_events.push_back(e->events[2 * i + 1]);
+	}
+	e->events.clear();
+	e->event_kernel.clear();
+	for (int k = 0; k < 4; k++)
+	{
+		if (ms_out != nullptr)
+			ms_out[k] = ms[k];
+		if (launches_out != nullptr)
+			launches_out[k] = launches[k];
+	}
+	e->timing = (enable != 0);
+	return AGX_OK;
+}
+
 int agx_debug_solve(AgxEngine *e, const uint8_t *h_boards, const int *h_signs, int count, uint32_t *h_features, uint16_t *h_moves, uint16_t *h_scores,
 		int *h_counts, uint32_t *h_flags, uint16_t *h_result_scores)
 {

@@ -31,6 +31,7 @@
 #include <vector>
 #include <cstring>
 #include <cmath>
+#include <cstdlib>
 
 namespace
 {
@@ -56,6 +57,7 @@ namespace
 			int batch;
 			const int *slot_list; // optional: batch element i is slot slot_list[i]
 			const int *count_ptr; // optional: batch size read on the device
+			half4 *skip;          // single-plane variant only: residual inputs in accumulator layout, [workgroup][wave][MT][NTW][lane]
 	};
 
 	template<int F, int ROWS, int COLS>
@@ -78,6 +80,9 @@ namespace
 			static constexpr int D = (2 * F < 256) ? 2 * F : 256;
 			static constexpr int SCRATCH_FLOATS = HW * 4 + D + 8 + 256 + 8 + F * 4 + F;
 			static constexpr int LDS_BYTES = 2 * PLANE_BYTES + SCRATCH_FLOATS * 4;
+			// single-plane variant (boards whose two planes do not fit): one plane + scratch + policy partial sums [4][NT*16]
+			static constexpr int LDS_BYTES_INPLACE = PLANE_BYTES + SCRATCH_FLOATS * 4 + 4 * NT * 16 * 4;
+			static constexpr int SKIP_PER_WG = 8 * MT * NTW * 64;               // half4 elements of residual scratch per workgroup
 	};
 
 	template<typename G>
@@ -91,9 +96,9 @@ namespace
 	 * 3x3 convolution + bias (+ skip) + ReLU over one board held in LDS.
 	 * src, dst: activation planes; if SKIP the residual input is read from (and the result written to) dst.
 	 */
-	template<int F, int ROWS, int COLS, bool SKIP>
-	__device__ __forceinline__ void conv3x3(const char *src, char *dst, const half8 *__restrict__ wpk, const float *__restrict__ bias, int wave,
-			int lane)
+	template<int F, int ROWS, int COLS>
+	__device__ __forceinline__ void conv3x3_mac(const char *src, const half8 *__restrict__ wpk, int wave, int lane,
+			floatx4 (&acc)[Geometry<F, ROWS, COLS>::MT][Geometry<F, ROWS, COLS>::NTW])
 	{
 		typedef Geometry<F, ROWS, COLS> G;
 		const int r = lane & 15;
@@ -102,7 +107,6 @@ namespace
 		const int n0 = (wave >> 2) * G::NTW;           // first position tile of this wave
 		const int my_tiles = (wave >> 2) ? (G::NT - G::NTW) : G::NTW;
 
-		floatx4 acc[G::MT][G::NTW];
 #pragma unroll
 		for (int i = 0; i < G::MT; i++)
 #pragma unroll
@@ -155,6 +159,20 @@ namespace
 					}
 			}
 		}
+	}
+
+	template<int F, int ROWS, int COLS, bool SKIP>
+	__device__ __forceinline__ void conv3x3(const char *src, char *dst, const half8 *__restrict__ wpk, const float *__restrict__ bias, int wave,
+			int lane)
+	{
+		typedef Geometry<F, ROWS, COLS> G;
+		const int r = lane & 15;
+		const int q4 = lane >> 4;
+		const int mg = wave & 3;
+		const int n0 = (wave >> 2) * G::NTW;
+		const int my_tiles = (wave >> 2) ? (G::NT - G::NTW) : G::NTW;
+		floatx4 acc[G::MT][G::NTW];
+		conv3x3_mac<F, ROWS, COLS>(src, wpk, wave, lane, acc);
 
 		// epilogue: lane holds out-channels 4*q4 .. 4*q4+3 of tile i for position r of tile n
 #pragma unroll
@@ -191,12 +209,117 @@ namespace
 	}
 
 	/*
+	 * Single-plane variant of the 3x3 convolution for boards whose two planes do not fit into LDS (20x20 with F = 128: one plane is
+	 * 119 KB).  A wave keeps ALL its outputs in accumulators until every wave has finished reading the plane, so the layer can
+	 * be written over its own input.  The residual input cannot stay in LDS then: each lane parks the values it will need again
+	 * (same accumulator layout, 8 bytes per lane and tile) in a per-workgroup scratch in global memory — written and read by the
+	 * same lane, fully coalesced, 2 x 110 KB per residual block against ~120 MFLOP of MFMA work.
+	 * MODE 0: first conv of a block (ReLU)   MODE 1: second conv (+ skip, ReLU, new skip saved)
+	 * MODE 2: policy conv + ReLU folded with the 1x1 policy conv: per-channel-group partial logits into `ppart` [4][NT*16].
+	 */
+	template<int F, int ROWS, int COLS, int MODE>
+	__device__ __forceinline__ void conv3x3_inplace(char *plane, const half8 *__restrict__ wpk, const float *__restrict__ bias, half4 *skip,
+			const float *__restrict__ wp2, float *ppart, int wave, int lane)
+	{
+		typedef Geometry<F, ROWS, COLS> G;
+		const int r = lane & 15;
+		const int q4 = lane >> 4;
+		const int mg = wave & 3;
+		const int n0 = (wave >> 2) * G::NTW;
+		const int my_tiles = (wave >> 2) ? (G::NT - G::NTW) : G::NTW;
+		floatx4 acc[G::MT][G::NTW];
+		conv3x3_mac<F, ROWS, COLS>(plane, wpk, wave, lane, acc);
+
+		if (MODE == 2)
+		{
+			float part[G::NTW];
+#pragma unroll
+			for (int n = 0; n < G::NTW; n++)
+				part[n] = 0.0f;
+#pragma unroll
+			for (int i = 0; i < G::MT; i++)
+			{
+				const int ch = (mg * G::MT + i) * 16 + 4 * q4;
+				const floatx4 bv = *reinterpret_cast<const floatx4*>(bias + ch);
+				const floatx4 wv = *reinterpret_cast<const floatx4*>(wp2 + ch);
+#pragma unroll
+				for (int n = 0; n < G::NTW; n++)
+				{
+					const floatx4 v = acc[i][n] + bv;
+					// the two-plane kernel rounds the ReLU output to fp16 before the 1x1 conv; keep that rounding so both agree
+					part[n] += static_cast<float>(static_cast<half_t>(fmaxf(v[0], 0.0f))) * wv[0];
+					part[n] += static_cast<float>(static_cast<half_t>(fmaxf(v[1], 0.0f))) * wv[1];
+					part[n] += static_cast<float>(static_cast<half_t>(fmaxf(v[2], 0.0f))) * wv[2];
+					part[n] += static_cast<float>(static_cast<half_t>(fmaxf(v[3], 0.0f))) * wv[3];
+				}
+			}
+#pragma unroll
+			for (int n = 0; n < G::NTW; n++)
+			{
+				float s = part[n];
+				s += __shfl_xor(s, 16);
+				s += __shfl_xor(s, 32);
+				if (q4 == 0 && n < my_tiles)
+					ppart[mg * (G::NT * 16) + (n0 + n) * 16 + r] = s;
+			}
+			return;
+		}
+
+		half4 *my_skip = skip + (wave * G::MT * G::NTW) * 64 + lane;
+		half4 out[G::MT][G::NTW];
+#pragma unroll
+		for (int i = 0; i < G::MT; i++)
+		{
+			const int ch = (mg * G::MT + i) * 16 + 4 * q4;
+			const floatx4 bv = *reinterpret_cast<const floatx4*>(bias + ch);
+#pragma unroll
+			for (int n = 0; n < G::NTW; n++)
+			{
+				const int pos = G::S + (n0 + n) * 16 + r;
+				const int x = pos % G::S;
+				const int y = pos / G::S - 1;
+				const bool valid = (x < COLS) && (y < ROWS) && (n < my_tiles);
+				floatx4 v = acc[i][n] + bv;
+				if (MODE == 1)
+				{
+					const half4 sk = my_skip[(i * G::NTW + n) * 64];
+					v[0] += static_cast<float>(sk[0]);
+					v[1] += static_cast<float>(sk[1]);
+					v[2] += static_cast<float>(sk[2]);
+					v[3] += static_cast<float>(sk[3]);
+				}
+				half4 o;
+				o[0] = static_cast<half_t>(valid ? fmaxf(v[0], 0.0f) : 0.0f);
+				o[1] = static_cast<half_t>(valid ? fmaxf(v[1], 0.0f) : 0.0f);
+				o[2] = static_cast<half_t>(valid ? fmaxf(v[2], 0.0f) : 0.0f);
+				o[3] = static_cast<half_t>(valid ? fmaxf(v[3], 0.0f) : 0.0f);
+				out[i][n] = o;
+				if (MODE == 1)
+					my_skip[(i * G::NTW + n) * 64] = o;
+			}
+		}
+		__syncthreads(); // every wave has consumed the plane: it can be overwritten now
+#pragma unroll
+		for (int i = 0; i < G::MT; i++)
+		{
+			const int ch = (mg * G::MT + i) * 16 + 4 * q4;
+#pragma unroll
+			for (int n = 0; n < G::NTW; n++)
+				if (n < my_tiles)
+				{
+					const int pos = G::S + (n0 + n) * 16 + r;
+					*reinterpret_cast<half4*>(plane + plane_offset<G>(pos + 1, ch / 8) + (ch % 8) * 2) = out[i][n];
+				}
+		}
+	}
+
+	/*
 	 * Input block: bit-unpack + 5x5 convolution (Cin = 32) + bias + ReLU.  `in5` is the padded input plane
 	 * (stride S5, 64 bytes per position, chunk-swizzled by (index >> 2) & 3).
 	 */
-	template<int F, int ROWS, int COLS>
+	template<int F, int ROWS, int COLS, bool INPLACE>
 	__device__ __forceinline__ void conv5x5_input(const char *in5, char *dst, const half8 *__restrict__ wpk, const float *__restrict__ bias,
-			int wave, int lane)
+			half4 *skip, int wave, int lane)
 	{
 		typedef Geometry<F, ROWS, COLS> G;
 		const int r = lane & 15;
@@ -244,6 +367,15 @@ namespace
 						acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b, acc[i][n], 0, 0, 0);
 				}
 		}
+		if (INPLACE)
+		{ // the padded input plane aliases the output plane: wait for every wave, clear the plane (zero borders), then write
+			__syncthreads();
+			const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+			for (int i = wave * 64 + lane; i < G::PLANE_BYTES / 16; i += G::THREADS)
+				reinterpret_cast<uint4*>(dst)[i] = zero4;
+			__syncthreads();
+		}
+		half4 *my_skip = skip + (wave * G::MT * G::NTW) * 64 + lane;
 #pragma unroll
 		for (int i = 0; i < G::MT; i++)
 		{
@@ -265,6 +397,8 @@ namespace
 					o[2] = static_cast<half_t>(valid ? fmaxf(v[2], 0.0f) : 0.0f);
 					o[3] = static_cast<half_t>(valid ? fmaxf(v[3], 0.0f) : 0.0f);
 					*reinterpret_cast<half4*>(ptr) = o;
+					if (INPLACE)
+						my_skip[(i * G::NTW + n) * 64] = o; // residual input of the first block
 				}
 		}
 	}
@@ -292,21 +426,24 @@ namespace
 		return ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
 	}
 
-	template<int F, int ROWS, int COLS>
+	template<int F, int ROWS, int COLS, bool INPLACE>
 	__global__ __launch_bounds__(512, 2) void nn_tower_kernel(NetParams p, const uint32_t *__restrict__ features, float *__restrict__ policy,
 			float *__restrict__ value)
 	{
 		typedef Geometry<F, ROWS, COLS> G;
-		static_assert(G::LDS_BYTES <= 163840, "board does not fit in LDS");
+		constexpr int LDS_TOTAL = INPLACE ? G::LDS_BYTES_INPLACE : G::LDS_BYTES;
+		static_assert(LDS_TOTAL <= 163840, "board does not fit in LDS");
 		static_assert(G::NPOS5 * 64 <= G::PLANE_BYTES, "padded input plane must fit into an activation plane");
-		__shared__ __attribute__((aligned(16))) char lds[G::LDS_BYTES];
+		__shared__ __attribute__((aligned(16))) char lds[LDS_TOTAL];
 		char *plane_x = lds;
-		char *plane_t = lds + G::PLANE_BYTES;
-		float *vbuf = reinterpret_cast<float*>(lds + 2 * G::PLANE_BYTES); // [HW*4]
+		char *plane_t = INPLACE ? lds : lds + G::PLANE_BYTES; // single-plane variant: every layer is computed in place
+		float *vbuf = reinterpret_cast<float*>(lds + (INPLACE ? 1 : 2) * G::PLANE_BYTES); // [HW*4]
 		float *hid = vbuf + G::HW * 4;                                     // [D]
 		float *red = hid + G::D;                                           // [8 + 256 + 8]: [0..7] wave partials, [8..8+D) value-head partials, [264..266] value logits
 		float *s_wv1 = red + 8 + 256 + 8;                                      // [F][4] value-head 1x1 weights (kept in LDS, not in registers)
 		float *s_wp2 = s_wv1 + F * 4;                                      // [F] policy-head 1x1 weights
+		float *ppart = s_wp2 + F;                                          // [4][NT*16] policy partial logits (single-plane variant only)
+		half4 *skip = INPLACE ? (p.skip + static_cast<size_t>(blockIdx.x) * G::SKIP_PER_WG) : nullptr;
 
 		const int tid = threadIdx.x;
 		const int wave = tid >> 6;
@@ -347,19 +484,33 @@ namespace
 				}
 			}
 			__syncthreads();
-			conv5x5_input<F, ROWS, COLS>(plane_t, plane_x, p.w_in, p.bias, wave, lane);
+			conv5x5_input<F, ROWS, COLS, INPLACE>(plane_t, plane_x, p.w_in, p.bias, skip, wave, lane);
 			__syncthreads();
-			for (int i = tid; i < G::PLANE_BYTES / 16; i += G::THREADS)
-				reinterpret_cast<uint4*>(plane_t)[i] = zero4; // restore the zero border of plane_t
-			__syncthreads();
+			if (!INPLACE)
+			{
+				for (int i = tid; i < G::PLANE_BYTES / 16; i += G::THREADS)
+					reinterpret_cast<uint4*>(plane_t)[i] = zero4; // restore the zero border of plane_t
+				__syncthreads();
+			}
 
 			// ---- residual tower ----
 			for (int blk = 0; blk < p.blocks; blk++)
 			{
-				conv3x3<F, ROWS, COLS, false>(plane_x, plane_t, p.w_tower + (2 * blk) * layer_halves8, p.bias + (1 + 2 * blk) * F, wave, lane);
-				__syncthreads();
-				conv3x3<F, ROWS, COLS, true>(plane_t, plane_x, p.w_tower + (2 * blk + 1) * layer_halves8, p.bias + (2 + 2 * blk) * F, wave, lane);
-				__syncthreads();
+				if (INPLACE)
+				{
+					conv3x3_inplace<F, ROWS, COLS, 0>(plane_x, p.w_tower + (2 * blk) * layer_halves8, p.bias + (1 + 2 * blk) * F, skip, nullptr, nullptr, wave, lane);
+					__syncthreads();
+					conv3x3_inplace<F, ROWS, COLS, 1>(plane_x, p.w_tower + (2 * blk + 1) * layer_halves8, p.bias + (2 + 2 * blk) * F, skip, nullptr, nullptr, wave,
+							lane);
+					__syncthreads();
+				}
+				else
+				{
+					conv3x3<F, ROWS, COLS, false>(plane_x, plane_t, p.w_tower + (2 * blk) * layer_halves8, p.bias + (1 + 2 * blk) * F, wave, lane);
+					__syncthreads();
+					conv3x3<F, ROWS, COLS, true>(plane_t, plane_x, p.w_tower + (2 * blk + 1) * layer_halves8, p.bias + (2 + 2 * blk) * F, wave, lane);
+					__syncthreads();
+				}
 			}
 
 			// ---- value head, stage 1: conv1x1 F->4 + ReLU into vbuf (NHWC flatten order) ----
@@ -387,7 +538,11 @@ namespace
 				vbuf[c * 4 + 3] = fmaxf(s3, 0.0f);
 			}
 			// ---- policy head: conv3x3 + ReLU into plane_t ----
-			conv3x3<F, ROWS, COLS, false>(plane_x, plane_t, p.w_tower + (2 * p.blocks) * layer_halves8, p.bias + (1 + 2 * p.blocks) * F, wave, lane);
+			if (INPLACE)
+				conv3x3_inplace<F, ROWS, COLS, 2>(plane_x, p.w_tower + (2 * p.blocks) * layer_halves8, p.bias + (1 + 2 * p.blocks) * F, nullptr, s_wp2, ppart,
+						wave, lane);
+			else
+				conv3x3<F, ROWS, COLS, false>(plane_x, plane_t, p.w_tower + (2 * p.blocks) * layer_halves8, p.bias + (1 + 2 * p.blocks) * F, wave, lane);
 			__syncthreads();
 
 			// ---- policy head: conv1x1 F->1 + bias, softmax over the board ----
@@ -396,14 +551,22 @@ namespace
 				const int c = tid;
 				if (c < G::HW)
 				{
-					const int index = 1 + G::S + (c / COLS) * G::S + (c % COLS);
 					float s = p.bp2;
-					for (int k = 0; k < G::CH; k++)
+					if (INPLACE)
 					{
-						const half8 tv = *reinterpret_cast<const half8*>(plane_t + plane_offset<G>(index, k));
+						const int idx = (c / COLS) * G::S + (c % COLS);
+						s += (ppart[idx] + ppart[G::NT * 16 + idx]) + (ppart[2 * G::NT * 16 + idx] + ppart[3 * G::NT * 16 + idx]);
+					}
+					else
+					{
+						const int index = 1 + G::S + (c / COLS) * G::S + (c % COLS);
+						for (int k = 0; k < G::CH; k++)
+						{
+							const half8 tv = *reinterpret_cast<const half8*>(plane_t + plane_offset<G>(index, k));
 #pragma unroll
-						for (int j = 0; j < 8; j++)
-							s += static_cast<float>(tv[j]) * s_wp2[k * 8 + j];
+							for (int j = 0; j < 8; j++)
+								s += static_cast<float>(tv[j]) * s_wp2[k * 8 + j];
+						}
 					}
 					logit = s;
 				}
@@ -501,6 +664,8 @@ struct AgxNet
 		void *d_wv2 = nullptr;
 		void *d_bv2 = nullptr;
 		void *d_wv3 = nullptr;
+		void *d_skip = nullptr; // single-plane variant: residual scratch, one slice per workgroup of the persistent grid
+		bool inplace = false;
 		float bp2 = 0.0f;
 		float bv1[4] = { 0, 0, 0, 0 };
 		float bv3[3] = { 0, 0, 0 };
@@ -511,12 +676,12 @@ namespace
 {
 	bool is_supported(const AgxNetDesc &d)
 	{
-		return d.rows == 15 && d.cols == 15 && (d.filters == 64 || d.filters == 128) && d.in_channels == 32 && d.blocks >= 0
+		return ((d.rows == 15 && d.cols == 15) || (d.rows == 20 && d.cols == 20)) && (d.filters == 64 || d.filters == 128) && d.in_channels == 32 && d.blocks >= 0
 				&& d.value_hidden == ((2 * d.filters < 256) ? 2 * d.filters : 256);
 	}
 	void free_net_buffers(AgxNet *net)
 	{
-		void **ptrs[] = { &net->d_w_in, &net->d_w_tower, &net->d_bias, &net->d_wp2, &net->d_wv1, &net->d_wv2, &net->d_bv2, &net->d_wv3 };
+		void **ptrs[] = { &net->d_w_in, &net->d_w_tower, &net->d_bias, &net->d_wp2, &net->d_wv1, &net->d_wv2, &net->d_bv2, &net->d_wv3, &net->d_skip };
 		for (void **p : ptrs)
 		{
 			if (*p != nullptr)
@@ -607,6 +772,15 @@ int agx_net_load_weights(AgxNet *net, const float *h_blob, size_t n_floats)
 	for (int i = 0; i < 3; i++)
 		net->bv3[i] = *ptr++;
 
+	// 20x20 boards use the single-plane kernel (two planes do not fit into LDS); AGX_NN_SINGLE_PLANE=1 selects it for 15x15 too
+	const char *force = getenv("AGX_NN_SINGLE_PLANE");
+	net->inplace = (net->desc.rows == 20) || (force != nullptr && force[0] == '1');
+	if (net->inplace)
+	{
+		const size_t per_wg = (net->desc.rows == 20) ? ((F == 128) ? Geometry<128, 20, 20>::SKIP_PER_WG : Geometry<64, 20, 20>::SKIP_PER_WG)
+				: ((F == 128) ? Geometry<128, 15, 15>::SKIP_PER_WG : Geometry<64, 15, 15>::SKIP_PER_WG);
+		AGX_HIP_CHECK(hipMalloc(&net->d_skip, per_wg * 8 * static_cast<size_t>(net->num_cus)));
+	}
 	int status = AGX_OK;
 	if ((status = upload(&net->d_w_in, w_in)) != AGX_OK || (status = upload(&net->d_w_tower, w_tower)) != AGX_OK
 			|| (status = upload(&net->d_bias, bias)) != AGX_OK || (status = upload(&net->d_wp2, wp2)) != AGX_OK
@@ -651,10 +825,23 @@ static int launch_forward(AgxNet *net, const uint32_t *d_features, const int *d_
 
 	const int grid = (batch < net->num_cus) ? batch : net->num_cus;
 	hipStream_t s = static_cast<hipStream_t>(stream);
-	if (net->desc.filters == 128)
-		hipLaunchKernelGGL((nn_tower_kernel<128, 15, 15>), dim3(grid), dim3(512), 0, s, p, d_features, d_policy, d_value);
+	p.skip = static_cast<half4*>(net->d_skip);
+	const bool big = (net->desc.rows == 20);
+	if (net->inplace)
+	{
+		if (big && net->desc.filters == 128)
+			hipLaunchKernelGGL((nn_tower_kernel<128, 20, 20, true>), dim3(grid), dim3(512), 0, s, p, d_features, d_policy, d_value);
+		else if (big)
+			hipLaunchKernelGGL((nn_tower_kernel<64, 20, 20, true>), dim3(grid), dim3(512), 0, s, p, d_features, d_policy, d_value);
+		else if (net->desc.filters == 128)
+			hipLaunchKernelGGL((nn_tower_kernel<128, 15, 15, true>), dim3(grid), dim3(512), 0, s, p, d_features, d_policy, d_value);
+		else
+			hipLaunchKernelGGL((nn_tower_kernel<64, 15, 15, true>), dim3(grid), dim3(512), 0, s, p, d_features, d_policy, d_value);
+	}
+	else if (net->desc.filters == 128)
+		hipLaunchKernelGGL((nn_tower_kernel<128, 15, 15, false>), dim3(grid), dim3(512), 0, s, p, d_features, d_policy, d_value);
 	else
-		hipLaunchKernelGGL((nn_tower_kernel<64, 15, 15>), dim3(grid), dim3(512), 0, s, p, d_features, d_policy, d_value);
+		hipLaunchKernelGGL((nn_tower_kernel<64, 15, 15, false>), dim3(grid), dim3(512), 0, s, p, d_features, d_policy, d_value);
 	AGX_HIP_CHECK(hipGetLastError());
 	return AGX_OK;
 }

@@ -95,6 +95,13 @@ class GeneratorPool:
         check(lib.agx_memcpy_h2d(self.buffers.d_nn_policy, pol.ctypes.data_as(ctypes.c_void_p), pol.nbytes))
         check(lib.agx_memcpy_h2d(self.buffers.d_nn_value, val.ctypes.data_as(ctypes.c_void_p), val.nbytes))
 
+    def kernel_timing(self, enable):
+        """(ms[4], launches[4]) of k_select / k_solve / k_expand / k_advance since the previous call; then recording on/off"""
+        ms = (ctypes.c_double * 4)()
+        n = (ctypes.c_longlong * 4)()
+        check(lib.agx_engine_kernel_timing(self._h, 1 if enable else 0, ms, n))
+        return list(ms), list(n)
+
     def stats(self):
         check(lib.agx_device_synchronize())
         s = AgxEngineStats()

@@ -107,6 +107,7 @@ def main():
         pool.step(net)
     check(lib.agx_device_synchronize())
     s0 = pool.stats()
+    pool.kernel_timing(True)   # HIP events around every engine kernel, on the launch stream
     t_sel, t_nn, t_exp = make_timers(args.steps), make_timers(args.steps), make_timers(args.steps)
 
     if dist is not None:
@@ -128,6 +129,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     s1 = pool.stats()
+    kernel_ms, kernel_launches = pool.kernel_timing(False)
 
     def total_ms(timers):
         acc = 0.0
@@ -158,6 +160,16 @@ def main():
         nn_tflops = (local_evals * flops) / (ms_nn * 1e-3) / 1e12 if ms_nn > 0 else 0.0
         depth = levels / max(1, (s1["evaluated_nodes"] - s0["evaluated_nodes"]) + leaks)
         edges_per_level = edge_reads / max(1, levels)
+        RULE_NAMES = ["freestyle", "standard", "renju", "caro5", "caro6"]
+        # HBM-side roof of the tree kernels (k_select + k_expand + k_advance): algorithmic bytes per simulation per SURVEY 8(d)
+        # with the MEASURED mean select depth d and edges per level E (new-leaf edge count taken as E):
+        #   select d*(40 + 24E) + virtual loss 4d + hash probe d*(8 + 104) + expand 176 + 24E + backup 128d + 2dE + encode 10*HW
+        hw = args.board * args.board
+        tree_bytes = (depth * (40 + 24 * edges_per_level) + 4 * depth + depth * 112 + 176 + 24 * edges_per_level + 128 * depth
+                      + 2 * depth * edges_per_level + 10 * hw)
+        tree_ms = kernel_ms[0] + kernel_ms[2] + kernel_ms[3]
+        local_sims = s1["evaluated_nodes"] - s0["evaluated_nodes"]
+        tree_gbs = local_sims * tree_bytes / (tree_ms * 1e-3) / 1e9 if tree_ms > 0 else 0.0
         traffic = None
         pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
         if os.path.exists(pmc_path) and args.games == 1024 and args.filters == 128 and args.blocks == 6:
@@ -165,7 +177,7 @@ def main():
             # the gfx950 correction + WRITE_SIZE); PMC counters cannot be sampled from inside this process
             traffic = json.load(open(pmc_path)).get("nn_tower_bytes_per_launch_corrected")
         result = {
-            "metric": "MCTS simulations/sec (self-play, 15x15 freestyle)",
+            "metric": "MCTS simulations/sec (self-play, %dx%d %s)" % (args.board, args.board, RULE_NAMES[args.rules]),
             "value": sims / elapsed,
             "unit": "simulations/s",
             "n_gpus": world,
@@ -177,13 +189,15 @@ def main():
             "vs_baseline": None,
             "dtype": "f16 (network, fp32 accumulate) + int/fp32 (tree)",
             "data": "synthetic (random openings, He-init weights seed 1234)",
-            "config": {"workload": "freestyle %dx%d, %d-block/%d-filter net, %d playouts/move, %d parallel self-play games per GPU, max_batch_size %d"
-                                   % (args.board, args.board, args.blocks, args.filters, args.sims, args.games, args.batch),
+            "config": {"workload": "%s %dx%d, %d-block/%d-filter net, %d playouts/move, %d parallel self-play games per GPU, max_batch_size %d"
+                                   % (RULE_NAMES[args.rules], args.board, args.board, args.blocks, args.filters, args.sims, args.games, args.batch),
                        "games_per_gpu": args.games, "parallelism": "independent game pools x%d (no collective)" % world},
             "moves_per_sec": moves / elapsed,
             "games_per_sec": games_done / elapsed,
             "nn_positions_per_sec": evals / elapsed,
             "stage_ms_per_step": {"select_solve": ms_sel / args.steps, "network": ms_nn / args.steps, "expand_backup_advance": ms_exp / args.steps},
+            "kernel_ms_per_step": {"k_select": kernel_ms[0] / args.steps, "k_solve": kernel_ms[1] / args.steps, "nn_tower": ms_nn / args.steps,
+                                   "k_expand": kernel_ms[2] / args.steps, "k_advance": kernel_ms[3] / args.steps},
             "shape": {"mean_select_depth": depth, "mean_edges_per_level": edges_per_level,
                       "solver_nodes_per_simulation": solver_nodes / max(1, s1["evaluated_nodes"] - s0["evaluated_nodes"]),
                       "nn_evals_per_simulation": local_evals / max(1, s1["evaluated_nodes"] - s0["evaluated_nodes"])},
@@ -191,6 +205,10 @@ def main():
                          "achieved": nn_tflops, "peak": 2500.0, "unit": "TFLOP/s", "frac": nn_tflops / 2500.0, "traffic": traffic,
                          "flops_per_position": flops, "positions_per_launch": local_evals / args.steps,
                          "avg_launch_ms": ms_nn / args.steps},
+            # second roof ("two kernels, two roofs"): the tree kernels are gathers/scans over the flat node/edge arrays
+            "roofline_tree": {"bound": "hbm", "kernels": "k_select + k_expand + k_advance", "achieved": tree_gbs, "peak": 8000.0, "unit": "GB/s",
+                              "frac": tree_gbs / 8000.0, "bytes_per_simulation": tree_bytes, "ms_per_step": tree_ms / args.steps,
+                              "note": "latency-bound by one wave per game, not by bandwidth; k_solve (threat solver) has no HBM/MFMA roof"},
         }
         if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only
             result["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)

@@ -215,6 +215,11 @@ int agx_stream_destroy(void* stream);
 int agx_stream_synchronize(void* stream);
 int agx_engine_buffers(AgxEngine* engine, AgxEngineBuffers* out);
 int agx_engine_stats(AgxEngine* engine, AgxEngineStats* out);
+/* Per-kernel timing of the engine's own launches, by HIP events recorded on the launch stream around every kernel (the role of
+ * SearchStats' TimedStat members, search/monte_carlo/Search.hpp, for the device kernels).  Synchronises the device, returns the
+ * time and launch count accumulated since the previous call in ms_out[4] / launches_out[4] (0 k_select, 1 k_solve, 2 k_expand,
+ * 3 k_advance; either pointer may be null), then switches recording on or off. */
+int agx_engine_kernel_timing(AgxEngine* engine, int enable, double* ms_out, long long* launches_out);
 /* Tree::getInfo({}) of one game (Tree.cpp:403-424): root snapshot + board. */
 int agx_engine_game_info(AgxEngine* engine, int game, AgxGameInfo* info, uint8_t* h_board, AgxEdgeView* h_root_edges, int edge_capacity);
 int agx_engine_records(AgxEngine* engine, AgxMoveRecord* h_records, int record_capacity, AgxEdgeView* h_edges, int edge_capacity, int* n_records, int* n_edges);

@@ -44,6 +44,32 @@ def test_forward_matches_oracle(agx_lib, blocks, filters):
     net.close()
 
 
+@pytest.mark.parametrize("rows,blocks,filters,single", [(20, 2, 64, "0"), (20, 10, 128, "0"), (15, 6, 128, "1"), (15, 2, 64, "1")])
+def test_single_plane_kernel_matches_oracle(agx_lib, monkeypatch, rows, blocks, filters, single):
+    """20x20 boards (BASELINE configs[3]) run the single-plane kernel: layers computed in place, residual input parked in a
+    per-workgroup global scratch, policy 1x1 folded into the policy conv.  AGX_NN_SINGLE_PLANE=1 selects it for 15x15 as well."""
+    from alphagomoku_amd.networks import AGNetwork
+    from oracle import nn_ref
+    monkeypatch.setenv("AGX_NN_SINGLE_PLANE", single)
+    d = synthetic.net_desc(rows=rows, cols=rows, blocks=blocks, filters=filters)
+    blob, _ = synthetic.make_weights(d)
+    net = AGNetwork(d)
+    net.loadWeights(blob)
+    f = synthetic.random_features(10, rows, rows, seed=blocks + rows)
+    p, v = net.forward(f)
+    pr, vr = nn_ref.forward(d, blob, f)
+    tol = POLICY_TOL if blocks <= 6 else DEEP_TOL
+    assert np.abs(p - pr).max() <= tol and np.abs(v - vr).max() <= tol
+    assert (p.argmax(1) == pr.argmax(1)).all()
+    # position independence through the persistent grid-stride loop (more boards than CUs)
+    big = synthetic.random_features(600, rows, rows, seed=77)
+    pb, vb = net.forward(big)
+    idx = np.random.default_rng(5).permutation(600)[:37]
+    p2, v2 = net.forward(big[idx])
+    assert np.array_equal(p2, pb[idx]) and np.array_equal(v2, vb[idx])
+    net.close()
+
+
 def test_grid_stride_and_ragged_batches(agx_lib):
     """Batches larger than the CU count go through the persistent grid-stride loop; results must not depend on
     where in the batch a board sits (size-independent property used at full size)."""
