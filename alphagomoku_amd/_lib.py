@@ -78,7 +78,8 @@ class AgxEngineConfig(ctypes.Structure):
                 ("policy_expansion_threshold", ctypes.c_float), ("tss_max_positions", ctypes.c_int),
                 ("tss_table_entries", ctypes.c_uint64), ("zobrist_seed", ctypes.c_uint64), ("node_capacity", ctypes.c_int),
                 ("edge_capacity", ctypes.c_int), ("record_capacity", ctypes.c_int), ("record_edge_capacity", ctypes.c_int),
-                ("solver_yield_fraction", ctypes.c_float)]
+                ("solver_yield_fraction", ctypes.c_float), ("final_selector", ctypes.c_int), ("use_symmetries", ctypes.c_int),
+                ("symmetry_seed", ctypes.c_uint64)]
 
 
 class AgxEngineBuffers(ctypes.Structure):

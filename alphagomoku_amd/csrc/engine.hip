@@ -377,13 +377,35 @@ namespace
 			return;
 		}
 		// Search::scheduleToNN (Search.cpp:184-199), once the whole batch has been solved
-		if (lane == 0)
+		int queued = idle ? 0 : gs.nn_queued;
+		for (int j = 0; j < n_tasks; j++)
 		{
-			for (int j = 0; j < n_tasks; j++)
+			DTask &t = E.tasks[static_cast<size_t>(g) * E.batch + j];
+			const bool needs = (t.path_len == 0) || !s_proven(t.score);
+			int symmetry = 0;
+			if (needs && E.use_symmetries)
+			{ // NNEvaluator::addToQueue + pack_to_network (NNEvaluator.cpp:134-141,244-262): augment the features in place
+				symmetry = static_cast<int>(symmetry_mix(E.symmetry_seed ^ (static_cast<u64>(static_cast<uint32_t>(gs.opening_id)) << 32) ^ static_cast<uint32_t>(queued)) >> 61);
+				if (symmetry != 0)
+				{
+					uint32_t *feat = E.nn_features + static_cast<size_t>(g * E.batch + j) * E.hw;
+					__threadfence_block();
+					for (int i = lane; i < E.hw; i += 64)
+						sh.act[i] = feat[i]; // the action stack is idle between solves
+					wave_sync();
+					for (int i = lane; i < E.hw; i += 64)
+					{
+						int sr, sc;
+						symmetry_source(symmetry, E.n, i / E.n, i % E.n, sr, sc);
+						feat[i] = shuffle_feature_directions(sh.act[sr * E.n + sc], symmetry);
+					}
+					wave_sync();
+				}
+			}
+			if (lane == 0)
 			{
-				DTask &t = E.tasks[static_cast<size_t>(g) * E.batch + j];
-				const bool needs = (t.path_len == 0) || !s_proven(t.score);
 				t.needs_nn = needs ? 1 : 0;
+				t.symmetry = symmetry;
 				if (needs)
 				{
 					const int idx = atomicAdd(&E.counters[E.nn_counter], 1);
@@ -391,10 +413,16 @@ namespace
 					scheduled++;
 				}
 			}
+			if (needs)
+				queued++;
+		}
+		if (lane == 0)
+		{
 			if (!idle)
 			{
 				gs.solve_pos = 0;
 				gs.solve_pending = 0;
+				gs.nn_queued = queued;
 				gs.stats[5] += solver_nodes;
 				gs.stats[1] += scheduled;
 			}
@@ -441,10 +469,13 @@ namespace
 			if ((flags & TF_SKIP_EDGE_GENERATION) == 0 && n_e > 0)
 			{ // UnifiedGenerator::generate (EdgeGenerator.cpp:269-303)
 				const bool by_network = (flags & TF_BY_NETWORK) != 0;
+				const int inv_symmetry = inverse_symmetry(t.symmetry);
 				for (int i = lane; i < n_e; i += 64)
 				{ // initialize_edges (:88-127)
 					const uint32_t mv = t.emove[i], sc = t.escore[i];
-					const int cell = ((mv >> 2) & 127) * n + ((mv >> 9) & 127);
+					int pr, pc; // the network saw the position under t.symmetry: task policy = apply_symmetry(output, inverse) (NNEvaluator.cpp:277-279)
+					symmetry_source(inv_symmetry, n, (mv >> 2) & 127, (mv >> 9) & 127, pr, pc);
+					const int cell = pr * n + pc;
 					e_move[i] = static_cast<uint16_t>(mv);
 					e_score[i] = static_cast<uint16_t>(sc);
 					e_prior[i] = by_network ? E.nn_policy[static_cast<size_t>(slot) * hw + cell] : 0.0f;
@@ -728,6 +759,7 @@ namespace
 			gs.need_move = 0;
 			gs.solve_pos = 0;
 			gs.solve_pending = 0;
+			gs.nn_queued = 0;
 			gs.generation = (gs.generation + 1) % 64; // prepare_search -> increaseGeneration
 			gs.opening_id = id;
 			gs.active = 1;
@@ -781,23 +813,54 @@ namespace
 		const int n = E.n;
 		const DNode root = nodes[gs.root];
 
-		// ---- final selector "best" (EdgeSelector.cpp:515-536) ----
+		// ---- final selector: "best" (EdgeSelector.cpp:515-536) or max_visit / min_visit / max_value / max_policy (:476-514) ----
 		float best_value = -3.402823466e+38f;
 		int best = 0x7FFFFFFF;
 		for (int i = tid; i < root.n_edges; i += 256)
 		{
 			const DEdge e = edges[root.edge_begin + i];
 			float value;
-			switch (s_pv(e.score))
+			switch (E.final_selector)
 			{
-				case 0:
-					value = -1.0e8f + s_distance(e.score);
+				default:
+					switch (s_pv(e.score))
+					{
+						case 0:
+							value = -1.0e8f + s_distance(e.score);
+							break;
+						case 3:
+							value = +1.0e8f - s_distance(e.score);
+							break;
+						default:
+							value = e.visits + (e.win + 0.5f * e.draw) * root.visits + 0.001f * e.prior;
+							break;
+					}
+					break;
+				case 1:
+					value = e.visits;
+					break;
+				case 2:
+					value = -e.visits;
 					break;
 				case 3:
-					value = +1.0e8f - s_distance(e.score);
+					switch (s_pv(e.score))
+					{
+						case 0:
+							value = -1000.0f + s_distance(e.score);
+							break;
+						case 1:
+							value = 0.5f; // Value::draw().getExpectation()
+							break;
+						case 3:
+							value = +1000.0f - s_distance(e.score);
+							break;
+						default:
+							value = e.win + 0.5f * e.draw;
+							break;
+					}
 					break;
-				default:
-					value = e.visits + (e.win + 0.5f * e.draw) * root.visits + 0.001f * e.prior;
+				case 4:
+					value = e.prior;
 					break;
 			}
 			if (value > best_value)
@@ -1017,6 +1080,7 @@ namespace
 			gs.generation = 0;
 			gs.solve_pos = 0;
 			gs.solve_pending = 0;
+			gs.nn_queued = 0;
 		}
 	}
 	__global__ __launch_bounds__(64) void k_debug_pattern_state(EngineDev E, const uint8_t *boards, const int *signs, const uint16_t *moves, int n_moves,
@@ -1192,6 +1256,9 @@ int agx_engine_default_config(AgxEngineConfig *cfg)
 	cfg->record_capacity = 0;
 	cfg->record_edge_capacity = 0;
 	cfg->solver_yield_fraction = 0.0f;
+	cfg->final_selector = 0;
+	cfg->use_symmetries = 0;
+	cfg->symmetry_seed = 0x5DEECE66Dull;
 	return AGX_OK;
 }
 
@@ -1204,6 +1271,7 @@ int agx_engine_create(const AgxEngineConfig *cfg, AgxEngine **out)
 	AGX_REQUIRE(cfg->tss_max_positions >= 1 && cfg->tss_max_positions <= 100, AGX_ERR_UNSUPPORTED, "agx_engine_create: tss_max_positions must be in [1, 100]");
 	AGX_REQUIRE(cfg->init_to >= 0 && cfg->init_to <= 3, AGX_ERR_INVALID, "agx_engine_create: init_to must be 0..3");
 	AGX_REQUIRE(cfg->solver_yield_fraction >= 0.0f && cfg->solver_yield_fraction <= 1.0f, AGX_ERR_INVALID, "agx_engine_create: solver_yield_fraction must be in [0, 1]");
+	AGX_REQUIRE(cfg->final_selector >= 0 && cfg->final_selector <= 4, AGX_ERR_INVALID, "agx_engine_create: final_selector must be 0..4");
 
 	AgxEngine *e = new AgxEngine();
 	e->cfg = *cfg;
@@ -1224,6 +1292,9 @@ int agx_engine_create(const AgxEngineConfig *cfg, AgxEngine **out)
 	d.tss_max_nodes = cfg->tss_max_positions;
 	d.tss_max_depth = 100;
 	d.yield_fraction = cfg->solver_yield_fraction;
+	d.final_selector = cfg->final_selector;
+	d.use_symmetries = cfg->use_symmetries;
+	d.symmetry_seed = cfg->symmetry_seed;
 	const size_t buckets = round_pow2(std::max<size_t>(cfg->tss_table_entries, 4)) / 4;
 	d.tt_bucket_mask = buckets - 1;
 	d.zobrist_seed = cfg->zobrist_seed;

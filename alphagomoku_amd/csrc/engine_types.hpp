@@ -72,6 +72,8 @@ namespace agx
 			float draw;
 			float moves_left;
 			int32_t needs_nn;
+			int32_t symmetry; // input symmetry the position was handed to the network with (0 = identity)
+			int32_t pad;
 			uint64_t hash;
 			uint64_t cboard[BWORDS];
 			int32_t path_node[PATH_CAP];
@@ -99,6 +101,8 @@ namespace agx
 			int32_t games_done;
 			int32_t solve_pos;     // first task of the batch that still has to be solved (solver launches may yield between tasks)
 			int32_t solve_pending; // 1 while the batch is only partly solved: the game sits out select / network / expand until it is done
+			int32_t nn_queued;     // positions handed to the network so far in this game (index of the symmetry hash)
+			int32_t pad;
 			uint64_t root_hash;
 			uint64_t cboard[BWORDS];
 			unsigned long long prof[8];   // optional cycle counters (AGX_SOLVER_PROFILE builds only)
@@ -142,6 +146,8 @@ namespace agx
 			int n_openings;
 			float yield_fraction; // 0 = never; else a game yields between two solves once this fraction of the launch's games is done
 			int yield_counter;    // index into counters[] of the launch's "games done" count
+			int final_selector, use_symmetries;
+			unsigned long long symmetry_seed;
 			int g0;          // first game handled by this launch (a launch covers games [g0, g0 + gridDim.x): one "group" of the pool)
 			int nn_counter;  // index into counters[] of this group's scheduled-position count
 			// state

@@ -93,11 +93,22 @@ namespace agx
 			int tss_max_positions = 100;
 			uint64_t tss_table_entries = 4ull * 1024ull * 1024ull;
 	};
+	inline int final_selector_id(const std::string &policy)
+	{ // EdgeSelector::create (EdgeSelector.cpp:680-711): the selectors GameGenerator::make_move can be configured with
+		if (policy == "best") return 0;
+		if (policy == "max_visit") return 1;
+		if (policy == "min_visit") return 2;
+		if (policy == "max_value") return 3;
+		if (policy == "max_policy") return 4;
+		throw std::logic_error("Unknown selection policy '" + policy + "'");
+	}
 
 	struct SelfplayConfig
 	{ // ag::SelfplayConfig subset (utils/configs.hpp:205-255)
 			int games_per_thread = 1024;
 			int max_simulations = 400;
+			bool use_symmetries = false;         // SelfplayConfig::use_symmetries -> NNEvaluator::useSymmetries
+			std::string final_selector = "best"; // SelfplayConfig::final_selector.policy
 			SearchConfig search_config;
 	};
 
@@ -124,6 +135,8 @@ namespace agx
 				c.information_leak_threshold = selfplay.search_config.information_leak_threshold;
 				c.tss_max_positions = selfplay.search_config.tss_max_positions;
 				c.tss_table_entries = selfplay.search_config.tss_table_entries;
+				c.final_selector = final_selector_id(selfplay.final_selector);
+				c.use_symmetries = selfplay.use_symmetries ? 1 : 0;
 				if (game.rows != game.cols)
 					throw std::logic_error("GeneratorPool: only square boards are supported");
 				check(agx_engine_create(&c, &m_engine));

@@ -43,6 +43,9 @@ struct AgoSearchConfig
 		uint64_t tss_table_entries;
 		int max_simulations;
 		uint64_t zobrist_seed;
+		int final_selector;
+		int use_symmetries;
+		uint64_t symmetry_seed;
 };
 
 static SearchConfig convert(const AgoSearchConfig *c)
@@ -59,6 +62,9 @@ static SearchConfig convert(const AgoSearchConfig *c)
 	s.tss_table_entries = c->tss_table_entries;
 	s.max_simulations = c->max_simulations;
 	s.zobrist_seed = c->zobrist_seed;
+	s.final_selector = c->final_selector;
+	s.use_symmetries = c->use_symmetries;
+	s.symmetry_seed = c->symmetry_seed;
 	return s;
 }
 
@@ -314,6 +320,25 @@ void* ago_game_create(int rules, int rows, int cols, const AgoSearchConfig *cfg)
 void ago_game_destroy(void *h)
 {
 	delete static_cast<GameHandle*>(h);
+}
+void ago_game_set_serial(void *h, int serial)
+{
+	static_cast<GameHandle*>(h)->game.serial = serial;
+}
+/* out[r * n + c] = in[source of (r, c) under symmetry s], with the feature direction bits shuffled when `features` != 0 */
+void ago_apply_symmetry(int n, int s, int features, const uint32_t *in, uint32_t *out)
+{
+	for (int r = 0; r < n; r++)
+		for (int c = 0; c < n; c++)
+		{
+			int sr, sc;
+			symmetry_source(s, n, r, c, sr, sc);
+			out[r * n + c] = features ? shuffle_feature_directions(in[sr * n + sc], s) : in[sr * n + sc];
+		}
+}
+int ago_inverse_symmetry(int s)
+{
+	return inverse_symmetry(s);
 }
 void ago_game_begin(void *h, const uint16_t *opening, int n)
 {

@@ -164,6 +164,54 @@ namespace ago
 		stats.select_levels++;
 		return n.edge_begin + best;
 	}
+	int Tree::select_final_edge(int node, int selector) const
+	{ // MaxVisit / MinVisit / MaxValue / MaxPolicy ops under find_best_edge (EdgeSelector.cpp:476-514,562-586): first maximum wins
+		if (selector == 0)
+			return select_best_edge(node);
+		const Node &n = nodes[node];
+		int best = -1;
+		float best_value = std::numeric_limits<float>::lowest();
+		for (int i = 0; i < n.n_edges; i++)
+		{
+			const Edge &e = edges[n.edge_begin + i];
+			float value;
+			switch (selector)
+			{
+				case 1:
+					value = e.visits;
+					break;
+				case 2:
+					value = -e.visits;
+					break;
+				case 3:
+					switch (e.score.pv())
+					{
+						case PV_LOSS:
+							value = -1000.0f + e.score.distance();
+							break;
+						case PV_DRAW:
+							value = Value(0.0f, 1.0f).expectation();
+							break;
+						case PV_WIN:
+							value = +1000.0f - e.score.distance();
+							break;
+						default:
+							value = e.value.expectation();
+							break;
+					}
+					break;
+				default:
+					value = e.prior;
+					break;
+			}
+			if (value > best_value)
+			{
+				best_value = value;
+				best = i;
+			}
+		}
+		return n.edge_begin + best;
+	}
 	int Tree::select_best_edge(int node) const
 	{ // BestEdgeSelector / BestEdge (EdgeSelector.cpp:515-536)
 		const Node &n = nodes[node];
@@ -520,6 +568,7 @@ namespace ago
 		moves.clear();
 		records.clear();
 		outcome = O_UNKNOWN;
+		queued = 0;
 		tree.clear();
 		search.solver.clear();
 		search.stored = 0;
@@ -545,8 +594,29 @@ namespace ago
 		search.stats.nn_evals += n;
 		const int hw = cfg.rows * cfg.cols;
 		features_out.resize(static_cast<size_t>(n) * hw);
+		symmetries.assign(n, 0);
 		for (int i = 0; i < n; i++)
-			std::memcpy(features_out.data() + static_cast<size_t>(i) * hw, search.tasks[scheduled[i]].features.data(), hw * sizeof(uint32_t));
+		{
+			Task &t = search.tasks[scheduled[i]];
+			if (scfg.use_symmetries)
+			{ // NNEvaluator::addToQueue + pack_to_network: features.augment(symmetry) (NNEvaluator.cpp:134-141,244-262)
+				const int s = pick_symmetry(scfg.symmetry_seed, serial, queued);
+				symmetries[i] = s;
+				if (s != 0)
+				{
+					const std::vector<uint32_t> src = t.features;
+					for (int r = 0; r < cfg.rows; r++)
+						for (int c = 0; c < cfg.cols; c++)
+						{
+							int sr, sc;
+							symmetry_source(s, cfg.rows, r, c, sr, sc);
+							t.features[r * cfg.cols + c] = shuffle_feature_directions(src[sr * cfg.cols + sc], s);
+						}
+				}
+			}
+			queued++;
+			std::memcpy(features_out.data() + static_cast<size_t>(i) * hw, t.features.data(), hw * sizeof(uint32_t));
+		}
 		return n;
 	}
 	int Game::step_expand(const float *policy, const float *value)
@@ -556,9 +626,12 @@ namespace ago
 		for (size_t i = 0; i < scheduled.size(); i++)
 		{
 			Task &t = search.tasks[scheduled[i]];
+			const int inv = inverse_symmetry(symmetries.empty() ? 0 : symmetries[i]);
 			for (int k = 0; k < hw; k++)
-			{
-				t.policy[k] = policy[i * hw + k];
+			{ // apply_symmetry(task policy, network policy, inverse symmetry) (NNEvaluator.cpp:277-279)
+				int sr, sc;
+				symmetry_source(inv, cfg.rows, k / cfg.cols, k % cfg.cols, sr, sc);
+				t.policy[k] = policy[i * hw + sr * cfg.cols + sc];
 				t.action_values[k] = Value();
 			}
 			t.value = Value(value[2 * i], value[2 * i + 1]);
@@ -584,14 +657,14 @@ namespace ago
 		return 0;
 	}
 	void Game::make_move()
-	{ // GameGenerator.cpp:145-173 with final_selector "best"
+	{ // GameGenerator.cpp:145-173
 		const Node &r = tree.nodes[tree.root];
 		MoveRecord rec;
 		rec.root_visits = r.visits;
 		rec.root_value = r.value;
 		rec.root_score = r.score;
 		rec.root_edges.assign(tree.edges.begin() + r.edge_begin, tree.edges.begin() + r.edge_begin + r.n_edges);
-		const Move m = tree.edges[tree.select_best_edge(tree.root)].move;
+		const Move m = tree.edges[tree.select_final_edge(tree.root, scfg.final_selector)].move;
 		rec.move = m;
 		records.push_back(rec);
 		board[m.row * cfg.cols + m.col] = m.sign;

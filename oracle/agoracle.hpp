@@ -373,7 +373,60 @@ namespace ago
 			size_t tss_table_entries = 4u * 1024u * 1024u; // AlphaBetaSearch.cpp:59
 			int max_simulations = 400;
 			uint64_t zobrist_seed = 0x9E3779B97F4A7C15ull;
+			int final_selector = 0;          // GameGenerator::make_move's selector: 0 best, 1 max_visit, 2 min_visit, 3 max_value, 4 max_policy (EdgeSelector.cpp:476-536)
+			int use_symmetries = 0;          // NNEvaluator::addToQueue (NNEvaluator.cpp:134-141): random input symmetry per queued task
+			uint64_t symmetry_seed = 0x5DEECE66Dull; // the reference draws randInt(8) from a time-seeded generator; here a counter-based hash
 	};
+
+	/* utils/augmentations.hpp:62-216 (square boards): source cell of destination (r, c) under symmetry s; inverse symmetry */
+	inline void symmetry_source(int s, int n, int r, int c, int &sr, int &sc)
+	{
+		const int last = n - 1;
+		switch (s)
+		{
+			default:
+			case 0: sr = r; sc = c; break;               // IDENTITY
+			case 1: sr = last - r; sc = c; break;        // FLIP_VERTICALLY
+			case 2: sr = r; sc = last - c; break;        // FLIP_HORIZONTALLY
+			case 3: sr = last - r; sc = last - c; break; // ROTATE_180
+			case 4: sr = c; sc = r; break;               // FLIP_DIAGONALLY
+			case 5: sr = last - c; sc = last - r; break; // FLIP_ANTIDIAGONALLY
+			case 6: sr = c; sc = last - r; break;        // ROTATE_90
+			case 7: sr = last - c; sc = r; break;        // ROTATE_270
+		}
+	}
+	inline int inverse_symmetry(int s) { return (s == 6) ? 7 : ((s == 7) ? 6 : s); } // augmentations.hpp:31-53
+	/* NNInputFeatures::augment's direction shuffle (NNInputFeatures.cpp:33-50,114-154) */
+	inline uint32_t shuffle_feature_directions(uint32_t data, int s)
+	{
+		int d0, d1, d2, d3;
+		switch (s)
+		{
+			case 1: case 2: d0 = 0; d1 = 1; d2 = 3; d3 = 2; break;
+			case 4: case 5: d0 = 1; d1 = 0; d2 = 2; d3 = 3; break;
+			case 6: case 7: d0 = 1; d1 = 0; d2 = 3; d3 = 2; break;
+			default: return data;
+		}
+		const uint32_t mask = (1u << 8) | (1u << 12) | (1u << 20) | (1u << 24);
+		uint32_t result = data & 0xF00F00FFu;
+		result |= ((data >> d0) & mask) << 0;
+		result |= ((data >> d1) & mask) << 1;
+		result |= ((data >> d2) & mask) << 2;
+		result |= ((data >> d3) & mask) << 3;
+		return result;
+	}
+	inline uint64_t symmetry_mix(uint64_t z)
+	{
+		z += 0x9E3779B97F4A7C15ull;
+		z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+		z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+		return z ^ (z >> 31);
+	}
+	/* symmetry of the k-th position a game hands to the network (k counts from the start of that game) */
+	inline int pick_symmetry(uint64_t seed, int game_serial, int k)
+	{
+		return static_cast<int>(symmetry_mix(seed ^ (static_cast<uint64_t>(static_cast<uint32_t>(game_serial)) << 32) ^ static_cast<uint32_t>(k)) >> 61);
+	}
 
 	struct Task
 	{ // SearchTask.hpp:35-329
@@ -423,7 +476,8 @@ namespace ago
 			int simulation_count() const { return root < 0 ? 0 : nodes[root].visits; }
 			bool root_proven() const { return root >= 0 && nodes[root].score.is_proven(); }
 			int select_edge(int node) const;                  // EdgeSelector.cpp:1123-1166 (puct), :562-586
-			int select_best_edge(int node) const;             // BestEdge :515-536 ("best" final selector)
+			int select_best_edge(int node) const;
+			int select_final_edge(int node, int selector) const;             // BestEdge :515-536 ("best" final selector)
 			mutable Stats stats;
 		private:
 			std::vector<std::vector<int>> bins;
@@ -467,6 +521,8 @@ namespace ago
 			std::vector<Move> moves;
 			Sign sign_to_move = CROSS;
 			Outcome outcome = O_UNKNOWN;
+			int serial = 0;      // identifies the game in the symmetry hash (the device uses the opening id)
+			int queued = 0;      // positions handed to the network so far in this game
 			void begin(const std::vector<Move> &opening);
 			/* phase 1: select + solve; returns the number of tasks that need evaluation and their features */
 			int step_select(std::vector<uint32_t> &features_out);
@@ -484,6 +540,7 @@ namespace ago
 			bool is_over() const { return outcome != O_UNKNOWN; }
 		private:
 			std::vector<int> scheduled;
+			std::vector<int> symmetries;
 			void prepare_search();
 			void make_move();
 	};

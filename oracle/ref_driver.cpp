@@ -4,7 +4,7 @@
  * Thin extern "C" driver over the subset of the reference that compiles from its own sources WITHOUT the absent
  * MinML library (no stand-in headers are written): src/patterns/{PatternTable,PatternClassifier,ThreatTable,
  * DefensiveMoveTable}.cpp, src/game/Move.cpp, src/search/{Score,Value,ZobristHashing}.cpp,
- * src/search/monte_carlo/{Edge,Node}.cpp, src/utils/random.cpp.
+ * src/search/monte_carlo/{Edge,Node}.cpp, src/utils/random.cpp, and the header-only utils/augmentations.hpp.
  * Built by oracle/Makefile into oracle/_ref/libagref.so straight from /root/reference; used by tests to pin the
  * restatement in oracle/ (tables, score algebra, struct layouts) and to generate tests/golden fixtures.
  * Everything that includes utils/configs.hpp (PatternCalculator, rules, MoveGenerator, AlphaBetaSearch, Tree, Search,
@@ -18,6 +18,7 @@
 #include <alphagomoku/search/monte_carlo/Edge.hpp>
 #include <alphagomoku/search/monte_carlo/Node.hpp>
 #include <alphagomoku/game/rules.hpp>
+#include <alphagomoku/utils/augmentations.hpp>
 
 #include <cstdint>
 #include <cstring>
@@ -133,4 +134,25 @@ uint16_t ref_move_to_short(int sign, int row, int col)
 {
 	return Move(row, col, static_cast<Sign>(sign)).toShort();
 }
+/* utils/augmentations.hpp: the two matrix forms (copying and in place) and the inverse map, on an n x n matrix of words */
+void ref_apply_symmetry(int n, int s, int in_place, const uint32_t *in, uint32_t *out)
+{
+	matrix<uint32_t> src(n, n), dst(n, n);
+	std::memcpy(src.data(), in, sizeof(uint32_t) * n * n);
+	if (in_place)
+	{
+		apply_symmetry_in_place(src, int_to_symmetry(s));
+		std::memcpy(out, src.data(), sizeof(uint32_t) * n * n);
+	}
+	else
+	{
+		apply_symmetry(dst, src, int_to_symmetry(s));
+		std::memcpy(out, dst.data(), sizeof(uint32_t) * n * n);
+	}
+}
+int ref_inverse_symmetry(int s)
+{
+	return static_cast<int>(get_inverse_symmetry(int_to_symmetry(s)));
+}
+
 } /* extern "C" */

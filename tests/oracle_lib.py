@@ -17,12 +17,13 @@ class AgoSearchConfig(ctypes.Structure):
                 ("exploration_scaling", ctypes.c_float), ("init_to", ctypes.c_int), ("max_children", ctypes.c_int),
                 ("policy_expansion_threshold", ctypes.c_float), ("information_leak_threshold", ctypes.c_float),
                 ("tss_max_positions", ctypes.c_int), ("tss_table_entries", ctypes.c_uint64),
-                ("max_simulations", ctypes.c_int), ("zobrist_seed", ctypes.c_uint64)]
+                ("max_simulations", ctypes.c_int), ("zobrist_seed", ctypes.c_uint64),
+                ("final_selector", ctypes.c_int), ("use_symmetries", ctypes.c_int), ("symmetry_seed", ctypes.c_uint64)]
 
 
-def default_search_config(max_batch_size=8, max_simulations=400, table_entries=1 << 16):
+def default_search_config(max_batch_size=8, max_simulations=400, table_entries=1 << 16, final_selector=0, use_symmetries=0):
     return AgoSearchConfig(max_batch_size, 1.25, 0.0, 0, 2 ** 31 - 1, 1.0e-4, 0.01, 100, table_entries,
-                           max_simulations, 0x9E3779B97F4A7C15)
+                           max_simulations, 0x9E3779B97F4A7C15, final_selector, use_symmetries, 0x5DEECE66D)
 
 
 _lib = None
@@ -46,6 +47,8 @@ def load():
         lib.ago_solver_zobrist.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         lib.ago_solver_solve.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 6
         lib.ago_game_begin.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        lib.ago_game_set_serial.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        lib.ago_apply_symmetry.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         lib.ago_game_step_select.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
         lib.ago_game_step_expand.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         lib.ago_game_outcome.argtypes = [ctypes.c_void_p]

@@ -140,20 +140,23 @@ def _oracle_root(olib, h):
                 prior=ep[:n].copy(), val=evl[:2 * n].copy(), es=es[:n].copy())
 
 
-def _play_and_compare(olib, rules, games, batch, sims, max_steps, evaluator, table_entries=1 << 16, n=N):
+def _play_and_compare(olib, rules, games, batch, sims, max_steps, evaluator, table_entries=1 << 16, n=N, final_selector=0, use_symmetries=0):
     """evaluator(features uint32 [n][HW]) -> (policy [n][HW] f32, value [n][2] f32 (win, draw)); used for BOTH sides"""
     from alphagomoku_amd import selfplay
     N, HW = n, n * n   # noqa: N806 (shadow the 15x15 module defaults)
     cfg = selfplay.default_config(rules=rules, board_size=n, draw_after=n * n, n_games=games, max_batch_size=batch, max_simulations=sims,
-                                  tss_table_entries=table_entries, node_capacity=4096, edge_capacity=65536 if n <= 15 else 131072)
+                                  tss_table_entries=table_entries, node_capacity=4096, edge_capacity=65536 if n <= 15 else 131072,
+                                  final_selector=final_selector, use_symmetries=use_symmetries)
     pool = selfplay.GeneratorPool(cfg)
-    ocfg = ol.default_search_config(max_batch_size=batch, max_simulations=sims, table_entries=table_entries)
+    ocfg = ol.default_search_config(max_batch_size=batch, max_simulations=sims, table_entries=table_entries, final_selector=final_selector,
+                                    use_symmetries=use_symmetries)
     openings, handles = [], []
     for g in range(games):
         op = np.zeros(64, np.uint16)
         k = olib.ago_prepare_opening(rules, N, N, 100 + g, ol.ptr(op))
         openings.append([int(x) for x in op[:k]])
         h = olib.ago_game_create(rules, N, N, ctypes.byref(ocfg))
+        olib.ago_game_set_serial(h, g)   # the device keys the symmetry hash by the opening id
         olib.ago_game_begin(h, ol.ptr(op), k)
         handles.append(h)
     pool.begin(selfplay.pack_openings(openings))
@@ -235,6 +238,22 @@ def test_whole_games_bit_exact_with_stand_in_evaluator(agx_lib, olib, rules, bat
     compared, stats = _play_and_compare(olib, rules, games=6, batch=batch, sims=sims, max_steps=4000, evaluator=_stand_in_evaluator(olib))
     assert compared > 500
     assert stats["games_finished"] == 6 and stats["information_leaks"] > 0 and stats["proven_edge_visits"] > 0
+
+
+@pytest.mark.parametrize("selector", [1, 2, 3, 4])
+def test_final_move_selectors(agx_lib, olib, selector):
+    """GameGenerator::make_move with final_selector max_visit / min_visit / max_value / max_policy instead of "best" """
+    compared, stats = _play_and_compare(olib, 0, games=4, batch=4, sims=60, max_steps=4000, evaluator=_stand_in_evaluator(olib), final_selector=selector)
+    assert compared > 200 and stats["games_finished"] == 4
+
+
+@pytest.mark.parametrize("rules,n", [(0, 15), (2, 15), (3, 20)])
+def test_input_symmetries(agx_lib, olib, rules, n):
+    """NNEvaluator::useSymmetries: features handed to the network are augmented (board symmetry + direction-bit shuffle), the
+    policy is mapped back with the inverse symmetry; the stand-in evaluator is not equivariant, so any slip changes the games"""
+    compared, stats = _play_and_compare(olib, rules, games=4, batch=4, sims=60, max_steps=6000, evaluator=_stand_in_evaluator(olib, n * n), n=n,
+                                        use_symmetries=1)
+    assert compared > 200 and stats["games_finished"] == 4
 
 
 @pytest.mark.parametrize("rules,batch,sims", [(3, 8, 60), (0, 4, 60)])

@@ -162,3 +162,37 @@ def test_record_layouts(ref, oracle):
     assert [ref.ref_sizeof(i) for i in range(5)] == [24, 40, 4, 2, 8]
     for sign, r, c in [(1, 0, 0), (2, 14, 3), (1, 19, 19)]:
         assert oracle.ago_move_to_short(sign, r, c) == ref.ref_move_to_short(sign, r, c)
+
+
+def test_board_symmetries_equal_reference(oracle, ref):
+    """The 8 dihedral maps used to augment network inputs (utils/augmentations.hpp): copying form, in-place form, inverse."""
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    for n in (5, 15, 20):
+        src = np.arange(n * n, dtype=np.uint32) * 7 + 3
+        for s in range(8):
+            a, b, c = np.zeros_like(src), np.zeros_like(src), np.zeros_like(src)
+            oracle.ago_apply_symmetry(n, s, 0, p(src), p(a))
+            ref.ref_apply_symmetry(n, s, 0, p(src), p(b))
+            ref.ref_apply_symmetry(n, s, 1, p(src), p(c))
+            assert np.array_equal(a, b) and np.array_equal(a, c), (n, s)
+            assert oracle.ago_inverse_symmetry(s) == ref.ref_inverse_symmetry(s)
+            back = np.zeros_like(src)
+            oracle.ago_apply_symmetry(n, oracle.ago_inverse_symmetry(s), 0, p(a), p(back))
+            assert np.array_equal(back, src)
+
+
+def test_feature_direction_shuffle(oracle):
+    """NNInputFeatures::augment (NNInputFeatures.cpp:33-50,114-154): a reflection swaps the two diagonal-direction bits, a
+    transposition swaps horizontal/vertical, a quarter turn swaps both pairs; every other bit stays."""
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    n = 5
+    base = 0xF00F00FF
+    for s, perm in [(0, (0, 1, 2, 3)), (3, (0, 1, 2, 3)), (1, (0, 1, 3, 2)), (2, (0, 1, 3, 2)), (4, (1, 0, 2, 3)), (5, (1, 0, 2, 3)),
+                    (6, (1, 0, 3, 2)), (7, (1, 0, 3, 2))]:
+        for group in (8, 12, 20, 24):
+            for d in range(4):
+                src = np.full(n * n, base | (1 << (group + d)), dtype=np.uint32)
+                out = np.zeros_like(src)
+                oracle.ago_apply_symmetry(n, s, 1, p(src), p(out))
+                want = base | (1 << (group + perm.index(d)))
+                assert (out == want).all(), (s, group, d)
