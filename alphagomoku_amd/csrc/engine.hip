@@ -1268,7 +1268,7 @@ int agx_engine_create(const AgxEngineConfig *cfg, AgxEngine **out)
 	AGX_REQUIRE(cfg->rules >= 0 && cfg->rules <= AGX_CARO6, AGX_ERR_INVALID, "agx_engine_create: unknown rules %d", cfg->rules);
 	AGX_REQUIRE(cfg->board_size >= 5 && cfg->board_size <= MAXN, AGX_ERR_UNSUPPORTED, "agx_engine_create: board size %d not in [5, %d]", cfg->board_size, MAXN);
 	AGX_REQUIRE(cfg->n_games > 0 && cfg->max_batch_size > 0 && cfg->max_simulations > 0, AGX_ERR_INVALID, "agx_engine_create: non-positive sizes");
-	AGX_REQUIRE(cfg->tss_max_positions >= 1 && cfg->tss_max_positions <= 100, AGX_ERR_UNSUPPORTED, "agx_engine_create: tss_max_positions must be in [1, 100]");
+	AGX_REQUIRE(cfg->tss_max_positions >= 1 && cfg->tss_max_positions <= 1000, AGX_ERR_UNSUPPORTED, "agx_engine_create: tss_max_positions must be in [1, 1000]");
 	AGX_REQUIRE(cfg->init_to >= 0 && cfg->init_to <= 3, AGX_ERR_INVALID, "agx_engine_create: init_to must be 0..3");
 	AGX_REQUIRE(cfg->solver_yield_fraction >= 0.0f && cfg->solver_yield_fraction <= 1.0f, AGX_ERR_INVALID, "agx_engine_create: solver_yield_fraction must be in [0, 1]");
 	AGX_REQUIRE(cfg->final_selector >= 0 && cfg->final_selector <= 4, AGX_ERR_INVALID, "agx_engine_create: final_selector must be 0..4");
@@ -1748,6 +1748,133 @@ int agx_debug_solve(AgxEngine *e, const uint8_t *h_boards, const int *h_signs, i
 	(void) hipFree(d_boards);
 	(void) hipFree(d_signs);
 	return AGX_OK;
+}
+
+/*
+ * OpeningGenerator::generate (src/selfplay/OpeningGenerator.cpp:21-78), batched: candidates from prepareOpening(config, 1), each
+ * given to the threat solver with a 1000-node budget (:61-62) and redrawn (up to 100 times, :55) while the solver proves it; the
+ * survivors are evaluated by the network and, in workspace order, accepted when |E - 0.5| < 0.1 + 0.01 * trials (:41-48).
+ */
+int agx_engine_generate_openings(AgxEngine *e, AgxNet *net, int count, uint32_t seed, uint16_t *h_openings, int *h_stats)
+{
+	AGX_REQUIRE(e != nullptr && net != nullptr && h_openings != nullptr, AGX_ERR_INVALID, "agx_engine_generate_openings: null argument");
+	AGX_REQUIRE(count > 0, AGX_ERR_INVALID, "agx_engine_generate_openings: count must be positive");
+	AGX_REQUIRE(!e->begun, AGX_ERR_STATE, "agx_engine_generate_openings: the pool is playing (the generator borrows its task slots); call it before agx_engine_begin");
+	const EngineDev &d = e->dev;
+	const int W = std::min(d.n_games, 64); // workspace entries evaluated together (the reference uses max_batch_size of them)
+	struct Entry
+	{
+			uint16_t opening[AGX_OPENING_CAP];
+			bool scheduled = false;
+			float expectation = 0.0f;
+	};
+	std::vector<Entry> workspace(W);
+	std::vector<uint8_t> boards(static_cast<size_t>(W) * d.hw);
+	std::vector<int> signs(W), todo;
+	std::vector<DTask> task(1);
+	std::vector<float> values(static_cast<size_t>(W) * d.batch * 3);
+	uint8_t *d_boards = nullptr;
+	int *d_signs = nullptr;
+	AGX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_boards), boards.size()));
+	AGX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_signs), W * sizeof(int)));
+	EngineDev dd = d;
+	dd.g0 = 0;
+	dd.nn_counter = 16;
+	dd.yield_fraction = 0.0f;
+	dd.use_symmetries = 0;
+	dd.tss_max_nodes = 1000; // solver.setNodeLimit(1000)
+	int completed = 0, trials = 0;
+	long long stats[4] = { 0, 0, 0, 0 }; // candidates drawn, proven by the solver, rejected as unbalanced, network evaluations
+	int status = AGX_OK;
+	while (completed < count && status == AGX_OK)
+	{
+		for (int attempt = 0; attempt < 100; attempt++)
+		{
+			todo.clear();
+			for (int i = 0; i < W; i++)
+				if (!workspace[i].scheduled)
+					todo.push_back(i);
+			if (todo.empty())
+				break;
+			const int m = static_cast<int>(todo.size());
+			for (int j = 0; j < m; j++)
+			{
+				Entry &en = workspace[todo[j]];
+				if ((status = agx_make_opening(d.rules, d.n, seed++, en.opening)) != AGX_OK)
+					break;
+				stats[0]++;
+				uint8_t *b = boards.data() + static_cast<size_t>(j) * d.hw;
+				std::memset(b, 0, d.hw);
+				for (int k = 0; k < en.opening[0]; k++)
+				{
+					const uint16_t mv = en.opening[1 + k];
+					b[((mv >> 2) & 127) * d.n + ((mv >> 9) & 127)] = mv & 3;
+				}
+				signs[j] = (en.opening[0] == 0) ? AGX_CROSS : (3 - (en.opening[en.opening[0]] & 3));
+			}
+			if (status != AGX_OK)
+				break;
+			AGX_HIP_CHECK(hipMemcpy(d_boards, boards.data(), static_cast<size_t>(m) * d.hw, hipMemcpyHostToDevice));
+			AGX_HIP_CHECK(hipMemcpy(d_signs, signs.data(), m * sizeof(int), hipMemcpyHostToDevice));
+			hipLaunchKernelGGL(k_debug_load_tasks, dim3(m), dim3(64), 0, nullptr, dd, d_boards, d_signs, m);
+			hipLaunchKernelGGL(k_reset_counter, dim3(1), dim3(1), 0, nullptr, dd.counters + dd.nn_counter, static_cast<int*>(nullptr));
+			if (dd.rules == AGX_RENJU)
+				hipLaunchKernelGGL(k_solve<true>, dim3(m), dim3(64), 0, nullptr, dd);
+			else
+				hipLaunchKernelGGL(k_solve<false>, dim3(m), dim3(64), 0, nullptr, dd);
+			AGX_HIP_CHECK(hipGetLastError());
+			// the unproven positions are in the pool's slot list exactly as after a search step: evaluate them
+			if ((status = agx_nn_forward_indirect(net, dd.nn_features, dd.nn_list, dd.counters + dd.nn_counter, m * dd.batch, dd.nn_policy, dd.nn_value, nullptr))
+					!= AGX_OK)
+				break;
+			AGX_HIP_CHECK(hipDeviceSynchronize());
+			AGX_HIP_CHECK(hipMemcpy(values.data(), dd.nn_value, static_cast<size_t>(m) * dd.batch * 3 * sizeof(float), hipMemcpyDeviceToHost));
+			for (int j = 0; j < m; j++)
+			{
+				AGX_HIP_CHECK(hipMemcpy(task.data(), dd.tasks + static_cast<size_t>(j) * dd.batch, offsetof(DTask, path_node), hipMemcpyDeviceToHost));
+				Entry &en = workspace[todo[j]];
+				if (task[0].needs_nn)
+				{
+					const float *v = values.data() + static_cast<size_t>(j) * dd.batch * 3;
+					en.expectation = v[0] + 0.5f * v[1];
+					en.scheduled = true;
+					stats[3]++;
+				}
+				else
+					stats[1]++;
+			}
+		}
+		if (status != AGX_OK)
+			break;
+		for (int i = 0; i < W && completed < count; i++)
+		{
+			Entry &en = workspace[i];
+			if (!en.scheduled)
+				continue; // proven 100 times in a row: the reference leaves such an entry for the next call as well
+			const float balance = std::fabs(en.expectation - 0.5f);
+			if (balance < (0.1f + 0.01f * trials))
+			{
+				std::memcpy(h_openings + static_cast<size_t>(completed) * AGX_OPENING_CAP, en.opening, sizeof(en.opening));
+				completed++;
+				trials = 0;
+			}
+			else
+			{
+				trials++;
+				stats[2]++;
+			}
+			en.scheduled = false;
+		}
+		for (Entry &en : workspace)
+			en.scheduled = false; // entries not consumed because enough openings were found
+	}
+	(void) hipMemset(d.games, 0, static_cast<size_t>(d.n_games) * sizeof(GameState)); // leave the pool idle again
+	(void) hipFree(d_boards);
+	(void) hipFree(d_signs);
+	if (h_stats != nullptr)
+		for (int i = 0; i < 4; i++)
+			h_stats[i] = static_cast<int>(stats[i]);
+	return status;
 }
 
 int agx_debug_new_generation(AgxEngine *e)

@@ -20,7 +20,7 @@ namespace agx
 	constexpr int MAXHW = MAXN * MAXN;
 	constexpr int BWORDS = 13;      // 2 bits per cell, 32 cells per 64-bit word (NodeCache.hpp:56)
 	constexpr int PATH_CAP = 256;
-	constexpr int MAX_FRAMES = 104; // alpha-beta recursion depth is bounded by the node budget (<= 100) + root
+	constexpr int MAX_FRAMES = 104; // alpha-beta recursion depth is bounded by the iterative-deepening limit (100 plies) + root
 	constexpr int OPENING_CAP = 32;
 
 	struct DEdge

@@ -95,6 +95,15 @@ class GeneratorPool:
         check(lib.agx_memcpy_h2d(self.buffers.d_nn_policy, pol.ctypes.data_as(ctypes.c_void_p), pol.nbytes))
         check(lib.agx_memcpy_h2d(self.buffers.d_nn_value, val.ctypes.data_as(ctypes.c_void_p), val.nbytes))
 
+    def generate_openings(self, net, count, seed=0):
+        """OpeningGenerator::generate: `count` solver-unproven, network-balanced openings (before begin()); returns
+        (list of Move::toShort lists, stats dict)"""
+        out = np.zeros((count, OPENING_CAP), dtype=np.uint16)
+        st = (ctypes.c_int * 4)()
+        check(lib.agx_engine_generate_openings(self._h, net._net, count, seed, out.ctypes.data_as(ctypes.c_void_p), st))
+        names = ["candidates", "proven_by_solver", "unbalanced", "network_evaluations"]
+        return [[int(x) for x in row[1:1 + int(row[0])]] for row in out], dict(zip(names, list(st)))
+
     def kernel_timing(self, enable):
         """(ms[4], launches[4]) of k_select / k_solve / k_expand / k_advance since the previous call; then recording on/off"""
         ms = (ctypes.c_double * 4)()

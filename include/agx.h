@@ -105,7 +105,7 @@ typedef struct AgxEngineConfig
 	int init_to;                      /* 0 "q_head", 1 "parent", 2 "draw", 3 "loss" */
 	float information_leak_threshold; /* TreeConfig */
 	float policy_expansion_threshold; /* MCTSConfig (max_children is fixed at "unlimited") */
-	int tss_max_positions;            /* TSSConfig::max_positions, <= 100 */
+	int tss_max_positions;            /* TSSConfig::max_positions, <= 1000 (the search depth is capped at 100 plies either way) */
 	uint64_t tss_table_entries;       /* AlphaBetaSearch's SharedHashTable size per game (reference: 4 Mi) */
 	uint64_t zobrist_seed;            /* seed of the solver / node-cache Zobrist keys (the reference draws them from a time-seeded RNG) */
 	int node_capacity;                /* per game, per arena (TreeConfig::node_bucket_size analogue) */
@@ -202,6 +202,12 @@ int agx_get_outcome(int rules, int board_size, const uint8_t* h_board, int sign,
 int agx_engine_default_config(AgxEngineConfig* cfg);
 int agx_engine_create(const AgxEngineConfig* cfg, AgxEngine** out);
 int agx_engine_destroy(AgxEngine* engine);
+/* OpeningGenerator::generate (selfplay/OpeningGenerator.cpp:21-78) for `count` openings, batched on the device: candidates from
+ * agx_make_opening(seed, seed + 1, ...) that the threat solver cannot prove within 1000 nodes are evaluated by `net` and accepted
+ * when |expectation - 0.5| < 0.1 + 0.01 * trials.  h_openings receives count x AGX_OPENING_CAP words (the layout agx_engine_begin
+ * takes); h_stats (optional, 4 ints): candidates drawn, proven by the solver, rejected as unbalanced, network evaluations.
+ * Borrows the pool's task slots: only valid before agx_engine_begin. */
+int agx_engine_generate_openings(AgxEngine* engine, AgxNet* net, int count, uint32_t seed, uint16_t* h_openings, int* h_stats);
 /* Starts every game of the pool from h_openings[n_openings][AGX_OPENING_CAP]; finished games take the next unused opening. */
 int agx_engine_begin(AgxEngine* engine, const uint16_t* h_openings, int n_openings, void* stream);
 /* One pool step = select_solve -> evaluate -> expand_backup.  The three stages are exposed separately so that a caller

@@ -155,6 +155,13 @@ namespace agx
 					throw std::logic_error("GeneratorPool::begin: openings must hold a positive multiple of AGX_OPENING_CAP words");
 				check(agx_engine_begin(m_engine, openings.data(), static_cast<int>(openings.size() / AGX_OPENING_CAP), stream));
 			}
+			/* OpeningGenerator::generate (OpeningGenerator.cpp:21-78): solver-unproven, network-balanced openings; before begin() */
+			std::vector<uint16_t> generateOpenings(AGNetwork &network, int count, uint32_t seed = 0)
+			{
+				std::vector<uint16_t> out(static_cast<size_t>(count) * AGX_OPENING_CAP);
+				check(agx_engine_generate_openings(m_engine, network.handle(), count, seed, out.data(), nullptr));
+				return out;
+			}
 			/* GameGenerator::generate for every game of the pool: one select -> solve -> evaluate -> expand/backup -> move step */
 			void generate(AGNetwork &network, void *stream = nullptr)
 			{

@@ -86,11 +86,13 @@ def test_pattern_state_after_move_sequences(agx_lib, olib, rules):
     pool.close()
 
 
-@pytest.mark.parametrize("rules", [0, 1, 2, 3])
-def test_solver_matches_oracle_per_position(agx_lib, olib, rules):
+@pytest.mark.parametrize("rules,max_nodes", [(0, 100), (1, 100), (2, 100), (3, 100), (0, 1000), (2, 1000)])
+def test_solver_matches_oracle_per_position(agx_lib, olib, rules, max_nodes):
+    """max_nodes 1000 is the budget OpeningGenerator gives the solver (OpeningGenerator.cpp:61)"""
     from alphagomoku_amd import selfplay, lib, check
     rng = np.random.default_rng(20 + rules)
-    cfg = selfplay.default_config(rules=rules, n_games=128, max_batch_size=2, tss_table_entries=1 << 16, node_capacity=256, edge_capacity=4096)
+    cfg = selfplay.default_config(rules=rules, n_games=128, max_batch_size=2, tss_table_entries=1 << 16, node_capacity=256, edge_capacity=4096,
+                                  tss_max_positions=max_nodes)
     pool = selfplay.GeneratorPool(cfg)
     pool.begin(selfplay.pack_openings([[] for _ in range(128)]))   # clears the transposition tables
     check(lib.agx_device_synchronize())
@@ -103,7 +105,7 @@ def test_solver_matches_oracle_per_position(agx_lib, olib, rules):
     zob = pool.zobrist()
     proven = fouls = 0
     for g in range(128):
-        s = olib.ago_solver_create(rules, N, N, 1 << 16, cfg.zobrist_seed, 100)
+        s = olib.ago_solver_create(rules, N, N, 1 << 16, cfg.zobrist_seed, max_nodes)
         z = np.zeros(4 * HW, np.uint64)
         olib.ago_solver_zobrist(s, ol.ptr(z))
         assert np.array_equal(z, zob)
@@ -328,6 +330,48 @@ def test_games_bit_exact_with_the_hip_network_in_the_loop(agx_lib, olib):
         return p, np.ascontiguousarray(v[:, :2])
     compared, stats = _play_and_compare(olib, 0, games=4, batch=4, sims=100, max_steps=250, evaluator=evaluator)
     assert compared > 300 and stats["moves_played"] > 0
+    net.close()
+
+
+@pytest.mark.parametrize("rules", [0, 2])
+def test_opening_generator(agx_lib, olib, rules):
+    """OpeningGenerator::generate on the device: every opening is a legal undecided position that the solver (1000 nodes) does not
+    prove and that the network rates as balanced: |E - 0.5| < 0.1 + 0.01 * trials (trials <= number of rejections)"""
+    from alphagomoku_amd import selfplay
+    from alphagomoku_amd.networks import AGNetwork
+    from oracle import nn_ref
+    d = synthetic.net_desc(blocks=2, filters=64)
+    blob, _ = synthetic.make_weights(d)
+    net = AGNetwork(d)
+    net.loadWeights(blob)
+    pool = selfplay.GeneratorPool(selfplay.default_config(rules=rules, n_games=64, max_batch_size=2, tss_table_entries=1 << 16, node_capacity=256,
+                                                          edge_capacity=4096))
+    openings, st = pool.generate_openings(net, 40, seed=7)
+    assert len(openings) == 40 and st["candidates"] >= 40 and st["network_evaluations"] >= 40
+    assert st["candidates"] == st["proven_by_solver"] + st["network_evaluations"]
+    feats = []
+    for op in openings:
+        b = np.zeros((N, N), np.uint8)
+        for k, m in enumerate(op):
+            assert (m & 3) == 1 + (k & 1) and b[(m >> 2) & 127, (m >> 9) & 127] == 0
+            b[(m >> 2) & 127, (m >> 9) & 127] = m & 3
+        if op:
+            last = op[-1]
+            assert olib.ago_outcome(rules, N, N, ol.ptr(b), last & 3, (last >> 2) & 127, (last >> 9) & 127, -1) == 0
+        sign = 1 if len(op) % 2 == 0 else 2
+        feats.append(ol.encode_features(olib, rules, b.tolist(), sign).reshape(-1))
+    _, v = nn_ref.forward(d, blob, np.array(feats, np.uint32))
+    balance = np.abs(v[:, 0] + 0.5 * v[:, 1] - 0.5)
+    assert (balance < 0.1 + 0.01 * st["unbalanced"] + 4e-3).all()
+    # the pool is usable afterwards, and the generator refuses to run under a playing pool
+    pool.begin(selfplay.pack_openings(openings))
+    for _ in range(3):
+        pool.step(net)
+    assert pool.stats()["first_error"] == 0
+    from alphagomoku_amd import AgxError
+    with pytest.raises(AgxError):
+        pool.generate_openings(net, 1)
+    pool.close()
     net.close()
 
 
