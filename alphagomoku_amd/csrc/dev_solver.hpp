@@ -146,6 +146,7 @@ namespace agx
 				int pf_valid;
 #ifdef AGX_SOLVER_PROFILE
 				unsigned long long prof[8];
+				unsigned long long dprof[24];
 #endif
 				u64 hash_lo, hash_hi;
 				int sign_to_move, depth;
@@ -154,6 +155,15 @@ namespace agx
 				int result_score, phase;
 		};
 
+#ifdef AGX_SOLVER_PROFILE
+#define AGX_PROF_BEGIN() unsigned long long agx_pt_ = clock64()
+#define AGX_PROF_MARK(SH, K) do { const unsigned long long agx_now_ = clock64(); (SH).dprof[K] += agx_now_ - agx_pt_; agx_pt_ = agx_now_; } while (0)
+#define AGX_PROF_COUNT(SH, K, V) do { (SH).dprof[K] += (V); } while (0)
+#else
+#define AGX_PROF_BEGIN() do { } while (0)
+#define AGX_PROF_MARK(SH, K) do { } while (0)
+#define AGX_PROF_COUNT(SH, K, V) do { } while (0)
+#endif
 		__device__ __forceinline__ int row_step(int d) { return d == 0 ? 0 : 1; }
 		__device__ __forceinline__ int col_step(int d) { return d == 0 ? 1 : (d == 1 ? 0 : (d == 2 ? 1 : -1)); }
 		__device__ __forceinline__ void line_of(int n, int r, int c, int d, int &index, int &shift)
@@ -321,6 +331,7 @@ namespace agx
 		{
 			const int n = E.n;
 			const int center = r * n + c;
+			AGX_PROF_BEGIN();
 			if (added)
 			{
 				const int old0 = sh.threat[center][0], old1 = sh.threat[center][1];
@@ -351,6 +362,7 @@ namespace agx
 				list_add(sh, 1, t1, center, lane);
 			}
 			wave_sync();
+			AGX_PROF_MARK(sh, 10);
 
 			int cell = -1, old0 = 0, old1 = 0, new0 = 0, new1 = 0;
 			if (lane < 40)
@@ -375,6 +387,9 @@ namespace agx
 			u64 changed0 = __ballot(cell >= 0 && old0 != new0);
 			u64 changed1 = __ballot(cell >= 0 && old1 != new1);
 			wave_sync();
+			AGX_PROF_MARK(sh, 11);
+			AGX_PROF_COUNT(sh, 13, __popcll(changed0) + __popcll(changed1));
+			AGX_PROF_COUNT(sh, 14, 1);
 			while (changed0 != 0)
 			{
 				const int src = __ffsll(static_cast<long long>(changed0)) - 1;
@@ -395,6 +410,7 @@ namespace agx
 				list_add(sh, 1, nw, cc, lane);
 				wave_sync();
 			}
+			AGX_PROF_MARK(sh, 12);
 		}
 		__device__ __forceinline__ void solver_place(SolverShared &sh, const EngineDev &E, uint32_t move, bool add, int lane)
 		{ // PatternCalculator::addMove / undoMove (PatternCalculator.cpp:68-105)
@@ -1498,14 +1514,23 @@ namespace agx
 					sh.foul_count = 0;
 					uint32_t result = s_unknown(0);
 					bool go = true;
+					AGX_PROF_BEGIN();
 					if (go && distance_to_draw >= 1) go = try_win_in_1(result);
 					if (go && distance_to_draw == 1) go = try_draw_in_1(result);
+					AGX_PROF_MARK(sh, 0);
 					if (go && distance_to_draw >= 2) go = defend_loss_in_2(result);
+					AGX_PROF_MARK(sh, 1);
 					if (go && distance_to_draw >= 3) go = try_win_in_3(result);
+					AGX_PROF_MARK(sh, 2);
 					if (go && distance_to_draw >= 4) go = defend_loss_in_4(result);
+					AGX_PROF_MARK(sh, 3);
 					if (go && distance_to_draw >= 5) go = try_win_in_5(result);
+					AGX_PROF_MARK(sh, 4);
 					if (go && distance_to_draw >= 6) go = defend_loss_in_6(result);
+					AGX_PROF_MARK(sh, 5);
 					if (go && distance_to_draw >= 3) add_own_half_open_fours();
+					AGX_PROF_MARK(sh, 6);
+					AGX_PROF_COUNT(sh, 8, 1);
 					if (go && mode >= 2)
 					{
 						if (distance_to_draw >= 6)
@@ -1525,6 +1550,7 @@ namespace agx
 					}
 					if (fouls_possible_for(own))
 						mark_forbidden_moves();
+					AGX_PROF_MARK(sh, 7);
 					f.fully_expanded = (f.must_defend || mode >= 2) ? 1 : 0;
 					return result;
 				}

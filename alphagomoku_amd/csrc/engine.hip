@@ -218,6 +218,8 @@ namespace
 #ifdef AGX_SOLVER_PROFILE
 			for (int i = 0; i < 8; i++)
 				sh.prof[i] = 0;
+			for (int i = 0; i < 24; i++)
+				sh.dprof[i] = 0;
 #endif
 			Frame &f = sh.frames[0];
 			f.base = 0;
@@ -322,6 +324,8 @@ namespace
 			pg.prof[5] += 1;
 			pg.prof[6] += sh.prof[0] | (sh.prof[1] << 32);
 			pg.prof[7] += sh.prof[2] | (sh.prof[3] << 32);
+			for (int i = 0; i < 24; i++)
+				pg.dprof[i] += sh.dprof[i];
 		}
 #endif
 		wave_sync();
@@ -1542,6 +1546,15 @@ int agx_engine_stats(AgxEngine *e, AgxEngineStats *out)
 				p[5], p[0] / 100.0 / p[5], p[1] / 100.0 / p[5], p[2] / 100.0 / p[5], (double) p[3] / p[5], p[2] / 100.0 / (p[3] ? p[3] : 1), p[4] / 100.0 / p[5]);
 		fprintf(stderr, "[frame machine split, us per solve] table seek %.1f, move generation %.1f, ordering %.1f, evaluate+insert %.1f\n",
 				p[6] / 100.0 / p[5], p[7] / 100.0 / p[5], p[8] / 100.0 / p[5], p[9] / 100.0 / p[5]);
+		unsigned long long dp[24] = { 0 };
+		for (const GameState &g : games)
+			for (int i = 0; i < 24; i++)
+				dp[i] += g.dprof[i];
+		const double solves = static_cast<double>(p[5]);
+		fprintf(stderr, "[generate(), shader cycles per solve; %.1f calls] win1 %.0f, loss2 %.0f, win3 %.0f, loss4 %.0f, win5 %.0f, loss6 %.0f, half4 %.0f, rest %.0f\n",
+				dp[8] / solves, dp[0] / solves, dp[1] / solves, dp[2] / solves, dp[3] / solves, dp[4] / solves, dp[5] / solves, dp[6] / solves, dp[7] / solves);
+		fprintf(stderr, "[update_around, shader cycles per solve; %.1f calls, %.2f list changes per call] centre %.0f, gather %.0f, lists %.0f\n",
+				dp[14] / solves, dp[13] / (dp[14] ? static_cast<double>(dp[14]) : 1.0), dp[10] / solves, dp[11] / solves, dp[12] / solves);
 	}
 #endif
 	out->games_finished = counters[2];

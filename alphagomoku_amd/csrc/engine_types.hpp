@@ -106,6 +106,7 @@ namespace agx
 			uint64_t root_hash;
 			uint64_t cboard[BWORDS];
 			unsigned long long prof[8];   // optional cycle counters (AGX_SOLVER_PROFILE builds only)
+			unsigned long long dprof[24]; // finer stage stamps of the same builds (shader cycles)
 			unsigned long long stats[12]; // nodes, nn, leaks, proven, wasted, solver nodes, select levels, select edges, moves, duplicates, max nodes, max edges
 			uint8_t board[MAXHW];
 			uint16_t moves[MAXHW];
