@@ -476,7 +476,7 @@ namespace agx
 		 * explicit stack, and the stone placement is the same wave-wide incremental update as everywhere else (so the threat lists are
 		 * permuted exactly as in the reference).  Called by ALL lanes.
 		 */
-		__device__ __noinline__ bool renju_is_forbidden(SolverShared &sh, const EngineDev &E, int cell0, int lane)
+		__device__ __forceinline__ bool renju_is_forbidden(SolverShared &sh, const EngineDev &E, int cell0, int lane)
 		{
 			const int n = E.n;
 			if (sh.board[cell0] != 0)
