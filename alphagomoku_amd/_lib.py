@@ -12,7 +12,8 @@ class AgxError(RuntimeError):
 
 class AgxNetDesc(ctypes.Structure):
     _fields_ = [("rows", ctypes.c_int), ("cols", ctypes.c_int), ("blocks", ctypes.c_int),
-                ("filters", ctypes.c_int), ("in_channels", ctypes.c_int), ("value_hidden", ctypes.c_int)]
+                ("filters", ctypes.c_int), ("in_channels", ctypes.c_int), ("value_hidden", ctypes.c_int),
+                ("action_values", ctypes.c_int)]
 
 
 def _load():
@@ -49,6 +50,8 @@ def _declare(c):
     c.agx_net_create.argtypes = [ctypes.POINTER(AgxNetDesc), ctypes.POINTER(vp)]
     c.agx_net_load_weights.argtypes = [vp, vp, sz]
     c.agx_nn_forward.argtypes = [vp, vp, ci, vp, vp, vp]
+    c.agx_nn_forward_pvq.argtypes = [vp, vp, ci, vp, vp, vp, vp]
+    c.agx_nn_forward_indirect_pvq.argtypes = [vp, vp, vp, vp, ci, vp, vp, vp, vp]
     c.agx_net_destroy.argtypes = [vp]
     c.agx_malloc.argtypes = [ctypes.POINTER(vp), sz]
     c.agx_free.argtypes = [vp]

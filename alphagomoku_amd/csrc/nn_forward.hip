@@ -57,6 +57,9 @@ namespace
 			int batch;
 			const int *slot_list; // optional: batch element i is slot slot_list[i]
 			const int *count_ptr; // optional: batch size read on the device
+			const float *wq2;     // [F][4] action-values head 1x1 weights (3 outputs, padded), null without the head
+			float bq2[3];
+			float *q;             // action values out: float[slots][HW][2] = (win, draw) per cell, null = head not evaluated
 			half4 *skip;          // single-plane variant only: residual inputs in accumulator layout, [workgroup][wave][MT][NTW][lane]
 	};
 
@@ -78,10 +81,10 @@ namespace
 			static constexpr int NPOS5 = (ROWS + 4) * S5 + 4;
 			static constexpr int HW = ROWS * COLS;
 			static constexpr int D = (2 * F < 256) ? 2 * F : 256;
-			static constexpr int SCRATCH_FLOATS = HW * 4 + D + 8 + 256 + 8 + F * 4 + F;
+			static constexpr int SCRATCH_FLOATS = HW * 4 + D + 8 + 256 + 8 + F * 4 + F + F * 4;
 			static constexpr int LDS_BYTES = 2 * PLANE_BYTES + SCRATCH_FLOATS * 4;
 			// single-plane variant (boards whose two planes do not fit): one plane + scratch + policy partial sums [4][NT*16]
-			static constexpr int LDS_BYTES_INPLACE = PLANE_BYTES + SCRATCH_FLOATS * 4 + 4 * NT * 16 * 4;
+			static constexpr int LDS_BYTES_INPLACE = PLANE_BYTES + SCRATCH_FLOATS * 4 + 4 * NT * 16 * 4 + 3 * NT * 16 * 4;
 			static constexpr int SKIP_PER_WG = 8 * MT * NTW * 64;               // half4 elements of residual scratch per workgroup
 	};
 
@@ -161,7 +164,13 @@ namespace
 		}
 	}
 
-	template<int F, int ROWS, int COLS, bool SKIP>
+	template<bool TANH>
+	__device__ __forceinline__ float activation(float x)
+	{ // ReLU of the tower / policy head, tanh of the action-values head (blocks.cpp:119-127)
+		return TANH ? tanhf(x) : fmaxf(x, 0.0f);
+	}
+
+	template<int F, int ROWS, int COLS, bool SKIP, bool TANH = false>
 	__device__ __forceinline__ void conv3x3(const char *src, char *dst, const half8 *__restrict__ wpk, const float *__restrict__ bias, int wave,
 			int lane)
 	{
@@ -199,10 +208,10 @@ namespace
 						v[3] += static_cast<float>(sk[3]);
 					}
 					half4 o;
-					o[0] = static_cast<half_t>(valid ? fmaxf(v[0], 0.0f) : 0.0f);
-					o[1] = static_cast<half_t>(valid ? fmaxf(v[1], 0.0f) : 0.0f);
-					o[2] = static_cast<half_t>(valid ? fmaxf(v[2], 0.0f) : 0.0f);
-					o[3] = static_cast<half_t>(valid ? fmaxf(v[3], 0.0f) : 0.0f);
+					o[0] = static_cast<half_t>(valid ? activation<TANH>(v[0]) : 0.0f);
+					o[1] = static_cast<half_t>(valid ? activation<TANH>(v[1]) : 0.0f);
+					o[2] = static_cast<half_t>(valid ? activation<TANH>(v[2]) : 0.0f);
+					o[3] = static_cast<half_t>(valid ? activation<TANH>(v[3]) : 0.0f);
 					*reinterpret_cast<half4*>(ptr) = o;
 				}
 		}
@@ -216,6 +225,8 @@ namespace
 	 * same lane, fully coalesced, 2 x 110 KB per residual block against ~120 MFLOP of MFMA work.
 	 * MODE 0: first conv of a block (ReLU)   MODE 1: second conv (+ skip, ReLU, new skip saved)
 	 * MODE 2: policy conv + ReLU folded with the 1x1 policy conv: per-channel-group partial logits into `ppart` [4][NT*16].
+	 * MODE 3: action-values conv + tanh folded with its 1x1 conv to 3 outputs: `ppart` is [3][NT*16], the four channel groups
+	 *         add their partial sums one after the other (fixed order, so results do not depend on wave timing).
 	 */
 	template<int F, int ROWS, int COLS, int MODE>
 	__device__ __forceinline__ void conv3x3_inplace(char *plane, const half8 *__restrict__ wpk, const float *__restrict__ bias, half4 *skip,
@@ -230,6 +241,60 @@ namespace
 		floatx4 acc[G::MT][G::NTW];
 		conv3x3_mac<F, ROWS, COLS>(plane, wpk, wave, lane, acc);
 
+		if (MODE == 3)
+		{
+			float part[3][G::NTW];
+#pragma unroll
+			for (int o = 0; o < 3; o++)
+#pragma unroll
+				for (int n = 0; n < G::NTW; n++)
+					part[o][n] = 0.0f;
+#pragma unroll
+			for (int i = 0; i < G::MT; i++)
+			{
+				const int ch = (mg * G::MT + i) * 16 + 4 * q4;
+				const floatx4 bv = *reinterpret_cast<const floatx4*>(bias + ch);
+#pragma unroll
+				for (int n = 0; n < G::NTW; n++)
+				{
+					const floatx4 v = acc[i][n] + bv;
+#pragma unroll
+					for (int j = 0; j < 4; j++)
+					{
+						const float t = static_cast<float>(static_cast<half_t>(tanhf(v[j]))); // fp16 like the two-plane kernel's plane
+						const floatx4 w = *reinterpret_cast<const floatx4*>(wp2 + (ch + j) * 4);
+						part[0][n] += t * w[0];
+						part[1][n] += t * w[1];
+						part[2][n] += t * w[2];
+					}
+				}
+			}
+#pragma unroll
+			for (int o = 0; o < 3; o++)
+#pragma unroll
+				for (int n = 0; n < G::NTW; n++)
+				{
+					part[o][n] += __shfl_xor(part[o][n], 16);
+					part[o][n] += __shfl_xor(part[o][n], 32);
+				}
+			for (int group = 0; group < 4; group++)
+			{
+				if (mg == group && q4 == 0)
+				{
+#pragma unroll
+					for (int o = 0; o < 3; o++)
+#pragma unroll
+						for (int n = 0; n < G::NTW; n++)
+							if (n < my_tiles)
+							{
+								float *dst = ppart + o * (G::NT * 16) + (n0 + n) * 16 + r;
+								*dst = (group == 0) ? part[o][n] : (*dst + part[o][n]);
+							}
+				}
+				__syncthreads();
+			}
+			return;
+		}
 		if (MODE == 2)
 		{
 			float part[G::NTW];
@@ -426,7 +491,7 @@ namespace
 		return ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
 	}
 
-	template<int F, int ROWS, int COLS, bool INPLACE>
+	template<int F, int ROWS, int COLS, bool INPLACE, bool QHEAD>
 	__global__ __launch_bounds__(512, 2) void nn_tower_kernel(NetParams p, const uint32_t *__restrict__ features, float *__restrict__ policy,
 			float *__restrict__ value)
 	{
@@ -442,7 +507,9 @@ namespace
 		float *red = hid + G::D;                                           // [8 + 256 + 8]: [0..7] wave partials, [8..8+D) value-head partials, [264..266] value logits
 		float *s_wv1 = red + 8 + 256 + 8;                                      // [F][4] value-head 1x1 weights (kept in LDS, not in registers)
 		float *s_wp2 = s_wv1 + F * 4;                                      // [F] policy-head 1x1 weights
-		float *ppart = s_wp2 + F;                                          // [4][NT*16] policy partial logits (single-plane variant only)
+		float *s_wq2 = s_wp2 + F;                                          // [F][4] action-values head 1x1 weights
+		float *ppart = s_wq2 + F * 4;                                      // [4][NT*16] policy partial logits (single-plane variant only)
+		float *qpart = ppart + 4 * G::NT * 16;                             // [3][NT*16] action-value logits (single-plane variant only)
 		half4 *skip = INPLACE ? (p.skip + static_cast<size_t>(blockIdx.x) * G::SKIP_PER_WG) : nullptr;
 
 		const int tid = threadIdx.x;
@@ -457,6 +524,9 @@ namespace
 			s_wv1[i] = p.wv1[i];
 		for (int i = tid; i < F; i += G::THREADS)
 			s_wp2[i] = p.wp2[i];
+		if (QHEAD)
+			for (int i = tid; i < F * 4; i += G::THREADS)
+				s_wq2[i] = p.wq2[i];
 
 		const int batch = (p.count_ptr != nullptr) ? min(*p.count_ptr, p.batch) : p.batch;
 		for (int bi = blockIdx.x; bi < batch; bi += gridDim.x)
@@ -624,6 +694,56 @@ namespace
 				value[static_cast<size_t>(b) * 3 + 1] = e1 * inv;
 				value[static_cast<size_t>(b) * 3 + 2] = e2 * inv;
 			}
+
+			// ---- action-values head (blocks.cpp:119-127): conv3x3 + tanh, conv1x1 F -> 3 + bias, softmax over the 3 per cell ----
+			if (QHEAD)
+			{
+				const half8 *wq1 = p.w_tower + (2 * p.blocks + 1) * layer_halves8;
+				const float *bq1 = p.bias + (2 + 2 * p.blocks) * F;
+				__syncthreads(); // the policy head is done with plane_t / the partial-sum buffers
+				if (INPLACE)
+					conv3x3_inplace<F, ROWS, COLS, 3>(plane_x, wq1, bq1, nullptr, s_wq2, qpart, wave, lane);
+				else
+				{
+					conv3x3<F, ROWS, COLS, false, true>(plane_x, plane_t, wq1, bq1, wave, lane);
+					__syncthreads();
+				}
+				const int c = tid;
+				if (c < G::HW)
+				{
+					float z0 = p.bq2[0], z1 = p.bq2[1], z2 = p.bq2[2];
+					if (INPLACE)
+					{
+						const int idx = (c / COLS) * G::S + (c % COLS);
+						z0 += qpart[idx];
+						z1 += qpart[G::NT * 16 + idx];
+						z2 += qpart[2 * G::NT * 16 + idx];
+					}
+					else
+					{
+						const int index = 1 + G::S + (c / COLS) * G::S + (c % COLS);
+						for (int k = 0; k < G::CH; k++)
+						{
+							const half8 tv = *reinterpret_cast<const half8*>(plane_t + plane_offset<G>(index, k));
+#pragma unroll
+							for (int j = 0; j < 8; j++)
+							{
+								const float t = static_cast<float>(tv[j]);
+								const floatx4 w = *reinterpret_cast<const floatx4*>(s_wq2 + (k * 8 + j) * 4);
+								z0 += t * w[0];
+								z1 += t * w[1];
+								z2 += t * w[2];
+							}
+						}
+					}
+					const float m = fmaxf(z0, fmaxf(z1, z2));
+					const float e0 = __expf(z0 - m), e1 = __expf(z1 - m), e2 = __expf(z2 - m);
+					const float inv = 1.0f / (e0 + e1 + e2);
+					float *out = p.q + (static_cast<size_t>(b) * G::HW + c) * 2;
+					out[0] = e0 * inv; // win
+					out[1] = e1 * inv; // draw
+				}
+			}
 		}
 	}
 
@@ -664,6 +784,8 @@ struct AgxNet
 		void *d_wv2 = nullptr;
 		void *d_bv2 = nullptr;
 		void *d_wv3 = nullptr;
+		void *d_wq2 = nullptr;  // action-values head 1x1 weights [F][4] (padded), only with desc.action_values
+		float bq2[3] = { 0, 0, 0 };
 		void *d_skip = nullptr; // single-plane variant: residual scratch, one slice per workgroup of the persistent grid
 		bool inplace = false;
 		float bp2 = 0.0f;
@@ -677,11 +799,11 @@ namespace
 	bool is_supported(const AgxNetDesc &d)
 	{
 		return ((d.rows == 15 && d.cols == 15) || (d.rows == 20 && d.cols == 20)) && (d.filters == 64 || d.filters == 128) && d.in_channels == 32 && d.blocks >= 0
-				&& d.value_hidden == ((2 * d.filters < 256) ? 2 * d.filters : 256);
+				&& d.value_hidden == ((2 * d.filters < 256) ? 2 * d.filters : 256) && (d.action_values == 0 || d.action_values == 1);
 	}
 	void free_net_buffers(AgxNet *net)
 	{
-		void **ptrs[] = { &net->d_w_in, &net->d_w_tower, &net->d_bias, &net->d_wp2, &net->d_wv1, &net->d_wv2, &net->d_bv2, &net->d_wv3, &net->d_skip };
+		void **ptrs[] = { &net->d_w_in, &net->d_w_tower, &net->d_bias, &net->d_wp2, &net->d_wv1, &net->d_wv2, &net->d_bv2, &net->d_wv3, &net->d_skip, &net->d_wq2 };
 		for (void **p : ptrs)
 		{
 			if (*p != nullptr)
@@ -709,6 +831,8 @@ size_t agx_net_blob_floats(const AgxNetDesc *d)
 	n += static_cast<size_t>(d->blocks) * 2 * (9 * F * F + F);
 	n += 9 * F * F + F + F + 1;
 	n += F * 4 + 4 + HW * 4 * D + D + D * 3 + 3;
+	if (d->action_values)
+		n += 9 * F * F + F + F * 3 + 3;
 	return n;
 }
 
@@ -771,6 +895,21 @@ int agx_net_load_weights(AgxNet *net, const float *h_blob, size_t n_floats)
 	ptr += D * 3;
 	for (int i = 0; i < 3; i++)
 		net->bv3[i] = *ptr++;
+	std::vector<float> wq2;
+	if (net->desc.action_values)
+	{ // createActionValuesHead (blocks.cpp:119-127): the 3x3 conv joins the packed tower layers, the 1x1 conv is kept in fp32
+		pack_conv(ptr, 9, F, F, w_tower);
+		ptr += 9 * F * F;
+		bias.insert(bias.end(), ptr, ptr + F);
+		ptr += F;
+		wq2.assign(static_cast<size_t>(F) * 4, 0.0f);
+		for (int c = 0; c < F; c++)
+			for (int o = 0; o < 3; o++)
+				wq2[c * 4 + o] = ptr[c * 3 + o];
+		ptr += F * 3;
+		for (int i = 0; i < 3; i++)
+			net->bq2[i] = *ptr++;
+	}
 
 	// 20x20 boards use the single-plane kernel (two planes do not fit into LDS); AGX_NN_SINGLE_PLANE=1 selects it for 15x15 too
 	const char *force = getenv("AGX_NN_SINGLE_PLANE");
@@ -785,7 +924,8 @@ int agx_net_load_weights(AgxNet *net, const float *h_blob, size_t n_floats)
 	if ((status = upload(&net->d_w_in, w_in)) != AGX_OK || (status = upload(&net->d_w_tower, w_tower)) != AGX_OK
 			|| (status = upload(&net->d_bias, bias)) != AGX_OK || (status = upload(&net->d_wp2, wp2)) != AGX_OK
 			|| (status = upload(&net->d_wv1, wv1)) != AGX_OK || (status = upload(&net->d_wv2, wv2)) != AGX_OK
-			|| (status = upload(&net->d_bv2, bv2)) != AGX_OK || (status = upload(&net->d_wv3, wv3)) != AGX_OK)
+			|| (status = upload(&net->d_bv2, bv2)) != AGX_OK || (status = upload(&net->d_wv3, wv3)) != AGX_OK
+			|| (!wq2.empty() && (status = upload(&net->d_wq2, wq2)) != AGX_OK))
 	{
 		free_net_buffers(net);
 		return status;
@@ -795,7 +935,7 @@ int agx_net_load_weights(AgxNet *net, const float *h_blob, size_t n_floats)
 }
 
 static int launch_forward(AgxNet *net, const uint32_t *d_features, const int *d_slot_list, const int *d_count, int batch, float *d_policy, float *d_value,
-		void *stream)
+		float *d_action_values, void *stream)
 {
 	AGX_REQUIRE(net != nullptr, AGX_ERR_INVALID, "agx_nn_forward: null network");
 	AGX_REQUIRE(net->loaded, AGX_ERR_STATE, "agx_nn_forward: weights not loaded");
@@ -822,39 +962,59 @@ static int launch_forward(AgxNet *net, const uint32_t *d_features, const int *d_
 	p.batch = batch;
 	p.slot_list = d_slot_list;
 	p.count_ptr = d_count;
+	AGX_REQUIRE(d_action_values == nullptr || net->desc.action_values, AGX_ERR_INVALID, "agx_nn_forward: the network has no action-values head");
+	p.q = d_action_values;
+	p.wq2 = (d_action_values != nullptr) ? static_cast<const float*>(net->d_wq2) : nullptr;
+	for (int i = 0; i < 3; i++)
+		p.bq2[i] = net->bq2[i];
 
 	const int grid = (batch < net->num_cus) ? batch : net->num_cus;
 	hipStream_t s = static_cast<hipStream_t>(stream);
 	p.skip = static_cast<half4*>(net->d_skip);
-	const bool big = (net->desc.rows == 20);
+	const bool big = (net->desc.rows == 20), wide = (net->desc.filters == 128), qhead = (p.q != nullptr);
+	const dim3 g(grid), t(512);
+#define AGX_LAUNCH_TOWER(FF, NN, IP, QH) hipLaunchKernelGGL((nn_tower_kernel<FF, NN, NN, IP, QH>), g, t, 0, s, p, d_features, d_policy, d_value)
+#define AGX_LAUNCH_HEADS(FF, NN, IP) do { if (qhead) AGX_LAUNCH_TOWER(FF, NN, IP, true); else AGX_LAUNCH_TOWER(FF, NN, IP, false); } while (0)
 	if (net->inplace)
 	{
-		if (big && net->desc.filters == 128)
-			hipLaunchKernelGGL((nn_tower_kernel<128, 20, 20, true>), dim3(grid), dim3(512), 0, s, p, d_features, d_policy, d_value);
+		if (big && wide)
+			AGX_LAUNCH_HEADS(128, 20, true);
 		else if (big)
-			hipLaunchKernelGGL((nn_tower_kernel<64, 20, 20, true>), dim3(grid), dim3(512), 0, s, p, d_features, d_policy, d_value);
-		else if (net->desc.filters == 128)
-			hipLaunchKernelGGL((nn_tower_kernel<128, 15, 15, true>), dim3(grid), dim3(512), 0, s, p, d_features, d_policy, d_value);
+			AGX_LAUNCH_HEADS(64, 20, true);
+		else if (wide)
+			AGX_LAUNCH_HEADS(128, 15, true);
 		else
-			hipLaunchKernelGGL((nn_tower_kernel<64, 15, 15, true>), dim3(grid), dim3(512), 0, s, p, d_features, d_policy, d_value);
+			AGX_LAUNCH_HEADS(64, 15, true);
 	}
-	else if (net->desc.filters == 128)
-		hipLaunchKernelGGL((nn_tower_kernel<128, 15, 15, false>), dim3(grid), dim3(512), 0, s, p, d_features, d_policy, d_value);
+	else if (wide)
+		AGX_LAUNCH_HEADS(128, 15, false);
 	else
-		hipLaunchKernelGGL((nn_tower_kernel<64, 15, 15, false>), dim3(grid), dim3(512), 0, s, p, d_features, d_policy, d_value);
+		AGX_LAUNCH_HEADS(64, 15, false);
+#undef AGX_LAUNCH_HEADS
+#undef AGX_LAUNCH_TOWER
 	AGX_HIP_CHECK(hipGetLastError());
 	return AGX_OK;
 }
 
 int agx_nn_forward(AgxNet *net, const uint32_t *d_features, int batch, float *d_policy, float *d_value, void *stream)
 {
-	return launch_forward(net, d_features, nullptr, nullptr, batch, d_policy, d_value, stream);
+	return launch_forward(net, d_features, nullptr, nullptr, batch, d_policy, d_value, nullptr, stream);
+}
+int agx_nn_forward_pvq(AgxNet *net, const uint32_t *d_features, int batch, float *d_policy, float *d_value, float *d_action_values, void *stream)
+{
+	return launch_forward(net, d_features, nullptr, nullptr, batch, d_policy, d_value, d_action_values, stream);
 }
 int agx_nn_forward_indirect(AgxNet *net, const uint32_t *d_features, const int *d_slot_list, const int *d_count, int max_batch, float *d_policy,
 		float *d_value, void *stream)
 {
 	AGX_REQUIRE(d_slot_list != nullptr && d_count != nullptr, AGX_ERR_INVALID, "agx_nn_forward_indirect: null list");
-	return launch_forward(net, d_features, d_slot_list, d_count, max_batch, d_policy, d_value, stream);
+	return launch_forward(net, d_features, d_slot_list, d_count, max_batch, d_policy, d_value, nullptr, stream);
+}
+int agx_nn_forward_indirect_pvq(AgxNet *net, const uint32_t *d_features, const int *d_slot_list, const int *d_count, int max_batch, float *d_policy,
+		float *d_value, float *d_action_values, void *stream)
+{
+	AGX_REQUIRE(d_slot_list != nullptr && d_count != nullptr, AGX_ERR_INVALID, "agx_nn_forward_indirect_pvq: null list");
+	return launch_forward(net, d_features, d_slot_list, d_count, max_batch, d_policy, d_value, d_action_values, stream);
 }
 
 int agx_net_destroy(AgxNet *net)

@@ -36,7 +36,7 @@ class AGNetwork:
     def __init__(self, desc):
         self.desc = dict(desc)
         self._cdesc = AgxNetDesc(desc["rows"], desc["cols"], desc["blocks"], desc["filters"],
-                                 desc["in_channels"], desc["value_hidden"])
+                                 desc["in_channels"], desc["value_hidden"], desc.get("action_values", 0))
         self._net = ctypes.c_void_p()
         check(lib.agx_net_create(ctypes.byref(self._cdesc), ctypes.byref(self._net)))
 
@@ -47,23 +47,34 @@ class AGNetwork:
         blob = np.ascontiguousarray(blob, dtype=np.float32)
         check(lib.agx_net_load_weights(self._net, blob.ctypes.data_as(ctypes.c_void_p), blob.size))
 
-    def forwardDevice(self, d_features, batch, d_policy, d_value, stream=None):
-        check(lib.agx_nn_forward(self._net, d_features, batch, d_policy, d_value, stream))
+    def forwardDevice(self, d_features, batch, d_policy, d_value, stream=None, d_action_values=None):
+        if d_action_values is None:
+            check(lib.agx_nn_forward(self._net, d_features, batch, d_policy, d_value, stream))
+        else:
+            check(lib.agx_nn_forward_pvq(self._net, d_features, batch, d_policy, d_value, d_action_values, stream))
 
     def forward(self, features):
-        """Convenience host round trip (tests): features uint32 [B, HW] -> (policy [B, HW], value [B, 3])."""
+        """Convenience host round trip (tests): features uint32 [B, HW] -> (policy [B, HW], value [B, 3]) and, for a network
+        with the action-values head, additionally q [B, HW, 2] = (win, draw) per cell."""
         features = np.ascontiguousarray(features, dtype=np.uint32)
         batch, hw = features.shape
+        with_q = bool(self.desc.get("action_values", 0))
         f = DeviceBuffer(features.nbytes)
         p = DeviceBuffer(batch * hw * 4)
         v = DeviceBuffer(batch * 3 * 4)
+        q = DeviceBuffer(batch * hw * 2 * 4) if with_q else None
         try:
             f.upload(features)
-            self.forwardDevice(f.ptr, batch, p.ptr, v.ptr)
+            self.forwardDevice(f.ptr, batch, p.ptr, v.ptr, None, q.ptr if with_q else None)
             check(lib.agx_device_synchronize())
-            return p.download((batch, hw), np.float32), v.download((batch, 3), np.float32)
+            out = (p.download((batch, hw), np.float32), v.download((batch, 3), np.float32))
+            if with_q:
+                out = out + (q.download((batch, hw, 2), np.float32),)
+            return out
         finally:
             f.free(); p.free(); v.free()
+            if q is not None:
+                q.free()
 
     def close(self):
         if self._net:

@@ -6,9 +6,9 @@ normal bias), i.e. the state of the graph after AGNetwork::optimize(2) (src/netw
 import numpy as np
 
 
-def net_desc(rows=15, cols=15, blocks=6, filters=128, in_channels=32):
+def net_desc(rows=15, cols=15, blocks=6, filters=128, in_channels=32, action_values=0):
     return dict(rows=rows, cols=cols, blocks=blocks, filters=filters, in_channels=in_channels,
-                value_hidden=min(256, 2 * filters))
+                value_hidden=min(256, 2 * filters), action_values=action_values)
 
 
 def make_weights(desc, seed=1234):
@@ -31,6 +31,8 @@ def make_weights(desc, seed=1234):
     parts += [("value.w1", he((F, 4), F)), ("value.b1", shift(4)),
               ("value.w2", he((HW * 4, D), HW * 4)), ("value.b2", shift(D)),
               ("value.w3", he((D, 3), D)), ("value.b3", shift(3))]
+    if desc.get("action_values", 0):
+        parts += [("q.w1", he((3, 3, F, F), 9 * F)), ("q.b1", shift(F)), ("q.w2", he((F, 3), F)), ("q.b2", shift(3))]
     blob = np.concatenate([p[1].reshape(-1) for p in parts]).astype(np.float32)
     return blob, parts
 

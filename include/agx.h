@@ -56,6 +56,7 @@ typedef struct AgxNetDesc
 	int filters;        /* conv filters F (64 or 128) */
 	int in_channels;    /* 32 (bit-packed features, NNInputFeatures.cpp:59-113) */
 	int value_hidden;   /* D = min(256, 2F) (blocks.cpp:113) */
+	int action_values;  /* 0: ResnetPV (outputs "pv", networks.cpp:71-93); 1: ResnetPVQ (:143-168) with the action-values head 'q' */
 } AgxNetDesc;
 
 typedef struct AgxNet AgxNet; /* opaque */
@@ -65,6 +66,8 @@ typedef struct AgxNet AgxNet; /* opaque */
  *   blocks x { W1[3][3][F][F] b1[F]  W2[3][3][F][F] b2[F] }
  *   policy   Wp1[3][3][F][F] bp1[F]  Wp2[F] bp2[1]
  *   value    Wv1[F][4] bv1[4]  Wv2[rows*cols*4][D] bv2[D]  Wv3[D][3] bv3[3]
+ *   action values (only with desc.action_values; createActionValuesHead, blocks.cpp:119-127):
+ *            Wq1[3][3][F][F] bq1[F] (tanh)  Wq2[F][3] bq2[3] (softmax over the 3 outputs of every cell)
  * Conv weights are [kh][kw][cin][cout] (cross-correlation, "same" zero padding); the value-head flatten
  * order is NHWC row-major: index = (row*cols + col)*4 + c.  */
 size_t agx_net_blob_floats(const AgxNetDesc* desc);
@@ -73,6 +76,9 @@ int agx_net_load_weights(AgxNet* net, const float* h_blob, size_t n_floats);
 /* d_features: uint32[batch][rows*cols] (one bit-packed word per cell);
  * d_policy: float[batch][rows*cols] (softmax over the board); d_value: float[batch][3] = (win, draw, loss). */
 int agx_nn_forward(AgxNet* net, const uint32_t* d_features, int batch, float* d_policy, float* d_value, void* stream);
+/* ResnetPVQ: additionally d_action_values float[batch][rows*cols][2] = (win, draw) of the per-cell softmax-3 'q' output, the part
+ * NetworkDataPack::unpackActionValues keeps (NetworkDataPack.cpp:214-224).  Passing NULL skips the head. */
+int agx_nn_forward_pvq(AgxNet* net, const uint32_t* d_features, int batch, float* d_policy, float* d_value, float* d_action_values, void* stream);
 int agx_net_destroy(AgxNet* net);
 
 /* Same network, but the batch is a device-side list: position i is slot d_slot_list[i] of the slot-indexed buffers
@@ -81,6 +87,8 @@ int agx_net_destroy(AgxNet* net);
  * (replaces NNEvaluator::pack_to_network / asyncEvaluateGraphLaunch, src/search/monte_carlo/NNEvaluator.cpp:182-262). */
 int agx_nn_forward_indirect(AgxNet* net, const uint32_t* d_features, const int* d_slot_list, const int* d_count, int max_batch,
 		float* d_policy, float* d_value, void* stream);
+int agx_nn_forward_indirect_pvq(AgxNet* net, const uint32_t* d_features, const int* d_slot_list, const int* d_count, int max_batch,
+		float* d_policy, float* d_value, float* d_action_values, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Device-resident self-play engine: a pool of independent games, each with its own search tree, solver transposition

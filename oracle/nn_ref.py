@@ -24,6 +24,8 @@ def split_blob(desc, blob):
     for _ in range(desc["blocks"]):
         shapes += [(3, 3, F, F), (F,), (3, 3, F, F), (F,)]
     shapes += [(3, 3, F, F), (F,), (F,), (1,), (F, 4), (4,), (HW * 4, D), (D,), (D, 3), (3,)]
+    if desc.get("action_values", 0):
+        shapes += [(3, 3, F, F), (F,), (F, 3), (3,)]
     out, pos = [], 0
     for s in shapes:
         n = int(np.prod(s))
@@ -85,4 +87,11 @@ def forward(desc, blob, features):
     v = v.reshape(v.shape[0], -1)
     h = relu(v @ wv2 + bv2)
     value = softmax(h @ wv3 + bv3, axis=1)
+    if desc.get("action_values", 0):
+        # createActionValuesHead (blocks.cpp:119-127): conv3x3 + BN(tanh), conv1x1 F->3 with bias, softmax over the last axis;
+        # the search keeps (win, draw) of every cell (NetworkDataPack::unpackActionValues, NetworkDataPack.cpp:214-224)
+        wq1, bq1, wq2, bq2 = next(it), next(it), next(it), next(it)
+        t = np.tanh(conv2d_same(x, wq1, bq1))
+        q = softmax(np.tensordot(t, wq2, axes=([3], [0])) + bq2.reshape(1, 1, 1, 3), axis=3)
+        return policy.astype(np.float32), value.astype(np.float32), q.reshape(q.shape[0], -1, 3)[:, :, :2].astype(np.float32)
     return policy.astype(np.float32), value.astype(np.float32)

@@ -70,6 +70,33 @@ def test_single_plane_kernel_matches_oracle(agx_lib, monkeypatch, rows, blocks, 
     net.close()
 
 
+@pytest.mark.parametrize("rows,blocks,filters,single", [(15, 6, 128, "0"), (15, 2, 64, "0"), (15, 6, 128, "1"), (20, 4, 128, "0")])
+def test_action_values_head_matches_oracle(agx_lib, monkeypatch, rows, blocks, filters, single):
+    """ResnetPVQ (networks.cpp:143-168): the extra 'q' output (conv3x3 + tanh, conv1x1 to 3, per-cell softmax) next to unchanged
+    policy / value outputs; the pv outputs of the same weights must be what the network without the head computes."""
+    from alphagomoku_amd.networks import AGNetwork
+    from oracle import nn_ref
+    monkeypatch.setenv("AGX_NN_SINGLE_PLANE", single)
+    d = synthetic.net_desc(rows=rows, cols=rows, blocks=blocks, filters=filters, action_values=1)
+    blob, _ = synthetic.make_weights(d)
+    net = AGNetwork(d)
+    net.loadWeights(blob)
+    f = synthetic.random_features(9, rows, rows, seed=31)
+    p, v, q = net.forward(f)
+    pr, vr, qr = nn_ref.forward(d, blob, f)
+    assert np.abs(p - pr).max() <= POLICY_TOL and np.abs(v - vr).max() <= VALUE_TOL
+    assert np.abs(q - qr).max() <= 1e-2          # per-cell softmax-3 of fp16 activations through one more conv layer
+    assert (q >= 0).all() and (q.sum(2) <= 1.0 + 1e-5).all()
+    d0 = dict(d, action_values=0)
+    pv_floats = nn_ref.split_blob  # noqa: F841 (documenting that the pv part is a prefix of the pvq blob)
+    net0 = AGNetwork(d0)
+    net0.loadWeights(blob[:net0.blobFloats()])
+    p0, v0 = net0.forward(f)
+    assert np.array_equal(p0, p) and np.array_equal(v0, v)
+    net.close()
+    net0.close()
+
+
 def test_grid_stride_and_ragged_batches(agx_lib):
     """Batches larger than the CU count go through the persistent grid-stride loop; results must not depend on
     where in the batch a board sits (size-independent property used at full size)."""
