@@ -50,6 +50,7 @@ def _declare(c):
     c.agx_net_create.argtypes = [ctypes.POINTER(AgxNetDesc), ctypes.POINTER(vp)]
     c.agx_net_load_weights.argtypes = [vp, vp, sz]
     c.agx_nn_forward.argtypes = [vp, vp, ci, vp, vp, vp]
+    c.agx_net_description.argtypes = [vp, vp]
     c.agx_nn_forward_pvq.argtypes = [vp, vp, ci, vp, vp, vp, vp]
     c.agx_nn_forward_indirect_pvq.argtypes = [vp, vp, vp, vp, ci, vp, vp, vp, vp]
     c.agx_net_destroy.argtypes = [vp]
@@ -82,11 +83,12 @@ class AgxEngineConfig(ctypes.Structure):
                 ("tss_table_entries", ctypes.c_uint64), ("zobrist_seed", ctypes.c_uint64), ("node_capacity", ctypes.c_int),
                 ("edge_capacity", ctypes.c_int), ("record_capacity", ctypes.c_int), ("record_edge_capacity", ctypes.c_int),
                 ("solver_yield_fraction", ctypes.c_float), ("final_selector", ctypes.c_int), ("use_symmetries", ctypes.c_int),
-                ("symmetry_seed", ctypes.c_uint64)]
+                ("symmetry_seed", ctypes.c_uint64), ("action_values", ctypes.c_int)]
 
 
 class AgxEngineBuffers(ctypes.Structure):
     _fields_ = [("d_nn_features", ctypes.c_void_p), ("d_nn_policy", ctypes.c_void_p), ("d_nn_value", ctypes.c_void_p),
+                ("d_nn_action_values", ctypes.c_void_p),
                 ("d_nn_list", ctypes.c_void_p), ("d_nn_count", ctypes.c_void_p), ("slots", ctypes.c_int), ("cells", ctypes.c_int)]
 
 

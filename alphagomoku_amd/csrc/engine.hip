@@ -486,6 +486,11 @@ namespace
 					float w = 0.0f, d = 0.0f;
 					if (!by_network && s_proven(sc))
 						s_to_value(sc, w, d);
+					if (by_network && E.has_q)
+					{ // unpack_from_network overwrites every action value with the 'q' output (NNEvaluator.cpp:277-279)
+						w = E.nn_q[(static_cast<size_t>(slot) * hw + cell) * 2];
+						d = E.nn_q[(static_cast<size_t>(slot) * hw + cell) * 2 + 1];
+					}
 					e_win[i] = w;
 					e_draw[i] = d;
 				}
@@ -1263,6 +1268,7 @@ int agx_engine_default_config(AgxEngineConfig *cfg)
 	cfg->final_selector = 0;
 	cfg->use_symmetries = 0;
 	cfg->symmetry_seed = 0x5DEECE66Dull;
+	cfg->action_values = 0;
 	return AGX_OK;
 }
 
@@ -1339,6 +1345,8 @@ int agx_engine_create(const AgxEngineConfig *cfg, AgxEngine **out)
 	AGX_TRY(dev_alloc(e, &d.nn_features, G * d.batch * d.hw));
 	AGX_TRY(dev_alloc(e, &d.nn_policy, G * d.batch * d.hw));
 	AGX_TRY(dev_alloc(e, &d.nn_value, G * d.batch * 3));
+	d.has_q = cfg->action_values ? 1 : 0;
+	AGX_TRY(dev_alloc(e, &d.nn_q, d.has_q ? G * d.batch * d.hw * 2 : 1));
 	AGX_TRY(dev_alloc(e, &d.nn_list, G * d.batch));
 	AGX_TRY(dev_alloc(e, &d.counters, 64));
 	AGX_TRY(dev_alloc(e, &d.records, static_cast<size_t>(d.record_cap)));
@@ -1450,6 +1458,16 @@ int agx_engine_evaluate_group(AgxEngine *e, AgxNet *net, int group, int n_groups
 	const int st = group_range(e, group, n_groups, d, count);
 	if (st != AGX_OK)
 		return st;
+	if (d.has_q)
+	{
+		AgxNetDesc desc;
+		const int ds = agx_net_description(net, &desc);
+		if (ds != AGX_OK)
+			return ds;
+		AGX_REQUIRE(desc.action_values, AGX_ERR_INVALID, "agx_engine_evaluate: the engine was configured for a 'pvq' network but this one has no action-values head");
+		return agx_nn_forward_indirect_pvq(net, d.nn_features, d.nn_list + static_cast<size_t>(d.g0) * d.batch, d.counters + d.nn_counter, count * d.batch,
+				d.nn_policy, d.nn_value, d.nn_q, stream);
+	}
 	return agx_nn_forward_indirect(net, d.nn_features, d.nn_list + static_cast<size_t>(d.g0) * d.batch, d.counters + d.nn_counter, count * d.batch, d.nn_policy,
 			d.nn_value, stream);
 }
@@ -1497,6 +1515,7 @@ int agx_engine_buffers(AgxEngine *e, AgxEngineBuffers *out)
 	out->d_nn_features = e->dev.nn_features;
 	out->d_nn_policy = e->dev.nn_policy;
 	out->d_nn_value = e->dev.nn_value;
+	out->d_nn_action_values = e->dev.has_q ? e->dev.nn_q : nullptr;
 	out->d_nn_list = e->dev.nn_list;
 	out->d_nn_count = e->dev.counters + 16; /* group 0 of 1 */
 	out->slots = e->dev.n_games * e->dev.batch;

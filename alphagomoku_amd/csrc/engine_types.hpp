@@ -171,6 +171,8 @@ namespace agx
 			uint32_t *nn_features; // [game*batch][hw]
 			float *nn_policy;      // [game*batch][hw]
 			float *nn_value;       // [game*batch][3]
+			float *nn_q;           // [game*batch][hw][2] action values (win, draw) per cell, 'pvq' networks only
+			int has_q;
 			int *nn_list;          // compacted slots to evaluate
 			int *counters;         // [0] (unused), [1] next opening, [2] finished games, [3] records used, [4] record edges used, [5] total moves, [16 + group] positions scheduled for the network by that group
 			// output records

@@ -1017,6 +1017,13 @@ int agx_nn_forward_indirect_pvq(AgxNet *net, const uint32_t *d_features, const i
 	return launch_forward(net, d_features, d_slot_list, d_count, max_batch, d_policy, d_value, d_action_values, stream);
 }
 
+int agx_net_description(const AgxNet *net, AgxNetDesc *out)
+{
+	AGX_REQUIRE(net != nullptr && out != nullptr, AGX_ERR_INVALID, "agx_net_description: null argument");
+	*out = net->desc;
+	return AGX_OK;
+}
+
 int agx_net_destroy(AgxNet *net)
 {
 	if (net == nullptr)

@@ -26,7 +26,10 @@ import numpy as np  # noqa: E402
 
 def nn_flops_per_position(desc):
     F, C, HW, D, blocks = desc["filters"], desc["in_channels"], desc["rows"] * desc["cols"], desc["value_hidden"], desc["blocks"]
-    return 2 * HW * (25 * C * F + blocks * 2 * 9 * F * F + 9 * F * F + F + 4 * F) + 2 * 4 * HW * D + 6 * D
+    flops = 2 * HW * (25 * C * F + blocks * 2 * 9 * F * F + 9 * F * F + F + 4 * F) + 2 * 4 * HW * D + 6 * D
+    if desc.get("action_values", 0):
+        flops += 2 * HW * (9 * F * F + 3 * F)
+    return flops
 
 
 def cpu_baseline(args, max_seconds):
@@ -61,6 +64,7 @@ def main():
     ap.add_argument("--filters", type=int, default=128)
     ap.add_argument("--board", type=int, default=15)
     ap.add_argument("--rules", type=int, default=0)
+    ap.add_argument("--action-values", type=int, default=0, help="1: ResnetPVQ network (extra action-values head feeding the edge Q)")
     ap.add_argument("--table-entries", type=int, default=4 * 1024 * 1024)
     ap.add_argument("--yield-fraction", type=float, default=0.75, help="solver straggler cut-off (0 = lock-step pool)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -82,12 +86,13 @@ def main():
     from alphagomoku_amd.networks import AGNetwork
 
     check(lib.agx_set_device(int(os.environ.get("AGX_FORCE_DEVICE", local_rank))))  # AGX_FORCE_DEVICE: test the N > 1 flow on a 1-GPU box
-    desc = synthetic.net_desc(rows=args.board, cols=args.board, blocks=args.blocks, filters=args.filters)
+    desc = synthetic.net_desc(rows=args.board, cols=args.board, blocks=args.blocks, filters=args.filters, action_values=args.action_values)
     blob, _ = synthetic.make_weights(desc)
     net = AGNetwork(desc)
     net.loadWeights(blob)
     cfg = selfplay.default_config(rules=args.rules, board_size=args.board, n_games=args.games, max_batch_size=args.batch,
-                                  max_simulations=args.sims, tss_table_entries=args.table_entries, solver_yield_fraction=args.yield_fraction)
+                                  max_simulations=args.sims, tss_table_entries=args.table_entries, solver_yield_fraction=args.yield_fraction,
+                                  action_values=args.action_values)
     pool = selfplay.GeneratorPool(cfg)
     # enough openings for every game that can finish during the run; seeds are disjoint across ranks
     n_openings = args.games * 3
@@ -189,8 +194,9 @@ def main():
             "vs_baseline": None,
             "dtype": "f16 (network, fp32 accumulate) + int/fp32 (tree)",
             "data": "synthetic (random openings, He-init weights seed 1234)",
-            "config": {"workload": "%s %dx%d, %d-block/%d-filter net, %d playouts/move, %d parallel self-play games per GPU, max_batch_size %d"
-                                   % (RULE_NAMES[args.rules], args.board, args.board, args.blocks, args.filters, args.sims, args.games, args.batch),
+            "config": {"workload": "%s %dx%d, %d-block/%d-filter net%s, %d playouts/move, %d parallel self-play games per GPU, max_batch_size %d"
+                                   % (RULE_NAMES[args.rules], args.board, args.board, args.blocks, args.filters, " (pvq)" if args.action_values else "", args.sims,
+                                      args.games, args.batch),
                        "games_per_gpu": args.games, "parallelism": "independent game pools x%d (no collective)" % world},
             "moves_per_sec": moves / elapsed,
             "games_per_sec": games_done / elapsed,

@@ -79,6 +79,7 @@ int agx_nn_forward(AgxNet* net, const uint32_t* d_features, int batch, float* d_
 /* ResnetPVQ: additionally d_action_values float[batch][rows*cols][2] = (win, draw) of the per-cell softmax-3 'q' output, the part
  * NetworkDataPack::unpackActionValues keeps (NetworkDataPack.cpp:214-224).  Passing NULL skips the head. */
 int agx_nn_forward_pvq(AgxNet* net, const uint32_t* d_features, int batch, float* d_policy, float* d_value, float* d_action_values, void* stream);
+int agx_net_description(const AgxNet* net, AgxNetDesc* out);
 int agx_net_destroy(AgxNet* net);
 
 /* Same network, but the batch is a device-side list: position i is slot d_slot_list[i] of the slot-indexed buffers
@@ -131,6 +132,10 @@ typedef struct AgxEngineConfig
 	                                     randInt(8) from a time-seeded generator; here the k-th position of game `serial` uses
 	                                     splitmix64(symmetry_seed ^ serial << 32 ^ k) >> 61, so runs are reproducible. */
 	uint64_t symmetry_seed;
+	int action_values;                /* 1: the network is a 'pvq' network (AGNetwork::getOutputConfig): agx_engine_evaluate runs its
+	                                     action-values head and new edges start from those values (initialize_edges, EdgeGenerator.cpp:
+	                                     119-124) — what the default init_to = "q_head" selector reads.  0: 'pv' network, edges start
+	                                     at (0, 0) exactly as the reference's zero-filled 'q' tensor gives (NetworkDataPack.cpp:122-126). */
 } AgxEngineConfig;
 
 typedef struct AgxEngine AgxEngine; /* opaque */
@@ -140,6 +145,7 @@ typedef struct AgxEngineBuffers
 	uint32_t* d_nn_features; /* [slots][cells] */
 	float* d_nn_policy;      /* [slots][cells] */
 	float* d_nn_value;       /* [slots][3] */
+	float* d_nn_action_values; /* [slots][cells][2] = (win, draw) per cell; read only when AgxEngineConfig.action_values is set */
 	int* d_nn_list;          /* slots scheduled for evaluation by the last agx_engine_select_solve */
 	int* d_nn_count;         /* number of entries of d_nn_list */
 	int slots;

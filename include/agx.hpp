@@ -43,8 +43,12 @@ namespace agx
 			AgxNet *m_net = nullptr;
 			AgxNetDesc m_desc { };
 		public:
-			AGNetwork(const GameConfig &cfg, int blocks, int filters)
+			/* architecture "ResnetPV" (networks.cpp:71-93) or "ResnetPVQ" (:143-168, adds the action-values head) */
+			AGNetwork(const GameConfig &cfg, int blocks, int filters, const std::string &architecture = "ResnetPV")
 			{
+				if (architecture != "ResnetPV" && architecture != "ResnetPVQ")
+					throw std::logic_error("AGNetwork: unknown architecture '" + architecture + "'");
+				m_desc.action_values = (architecture == "ResnetPVQ") ? 1 : 0;
 				m_desc.rows = cfg.rows;
 				m_desc.cols = cfg.cols;
 				m_desc.blocks = blocks;
@@ -71,6 +75,15 @@ namespace agx
 			void forward(const uint32_t *d_features, int batch, float *d_policy, float *d_value, void *stream = nullptr)
 			{
 				check(agx_nn_forward(m_net, d_features, batch, d_policy, d_value, stream));
+			}
+			/* 'pvq' networks: additionally action values float[batch][rows*cols][2] = (win, draw) */
+			void forward(const uint32_t *d_features, int batch, float *d_policy, float *d_value, float *d_action_values, void *stream)
+			{
+				check(agx_nn_forward_pvq(m_net, d_features, batch, d_policy, d_value, d_action_values, stream));
+			}
+			std::string getOutputConfig() const
+			{ // AGNetwork::getOutputConfig
+				return m_desc.action_values ? "pvq" : "pv";
 			}
 			AgxNet* handle() const noexcept
 			{
@@ -108,6 +121,7 @@ namespace agx
 			int games_per_thread = 1024;
 			int max_simulations = 400;
 			bool use_symmetries = false;         // SelfplayConfig::use_symmetries -> NNEvaluator::useSymmetries
+			std::string network_outputs = "pv";  // AGNetwork::getOutputConfig of the network that will evaluate: "pv" or "pvq"
 			std::string final_selector = "best"; // SelfplayConfig::final_selector.policy
 			SearchConfig search_config;
 	};
@@ -137,6 +151,7 @@ namespace agx
 				c.tss_table_entries = selfplay.search_config.tss_table_entries;
 				c.final_selector = final_selector_id(selfplay.final_selector);
 				c.use_symmetries = selfplay.use_symmetries ? 1 : 0;
+				c.action_values = (selfplay.network_outputs == "pvq") ? 1 : 0;
 				if (game.rows != game.cols)
 					throw std::logic_error("GeneratorPool: only square boards are supported");
 				check(agx_engine_create(&c, &m_engine));

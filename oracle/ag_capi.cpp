@@ -361,6 +361,10 @@ int ago_game_step_expand(void *h, const float *policy, const float *value)
 {
 	return static_cast<GameHandle*>(h)->game.step_expand(policy, value);
 }
+int ago_game_step_expand_q(void *h, const float *policy, const float *value, const float *action_values)
+{
+	return static_cast<GameHandle*>(h)->game.step_expand(policy, value, action_values);
+}
 int ago_game_outcome(void *h)
 {
 	return static_cast<GameHandle*>(h)->game.outcome;

@@ -619,7 +619,7 @@ namespace ago
 		}
 		return n;
 	}
-	int Game::step_expand(const float *policy, const float *value)
+	int Game::step_expand(const float *policy, const float *value, const float *action_values)
 	{ // NNEvaluator::unpack_from_network (NNEvaluator.cpp:263-286) with symmetry 0 and a 'pv' network (no 'q'/'m' heads:
 	  // those output tensors stay zero, NetworkDataPack.cpp:122-126,214-235), then GameGenerator.cpp:88-118
 		const int hw = cfg.rows * cfg.cols;
@@ -632,7 +632,8 @@ namespace ago
 				int sr, sc;
 				symmetry_source(inv, cfg.rows, k / cfg.cols, k % cfg.cols, sr, sc);
 				t.policy[k] = policy[i * hw + sr * cfg.cols + sc];
-				t.action_values[k] = Value();
+				// the 'q' tensor overwrites every action value (zero-filled for a 'pv' network), NNEvaluator.cpp:279
+				t.action_values[k] = (action_values != nullptr) ? Value(action_values[(i * hw + sr * cfg.cols + sc) * 2], action_values[(i * hw + sr * cfg.cols + sc) * 2 + 1]) : Value();
 			}
 			t.value = Value(value[2 * i], value[2 * i + 1]);
 			if (t.score.is_unproven())

@@ -527,7 +527,8 @@ namespace ago
 			/* phase 1: select + solve; returns the number of tasks that need evaluation and their features */
 			int step_select(std::vector<uint32_t> &features_out);
 			/* phase 2: policy [n][HW], value (win, draw) [n][2] for the scheduled tasks, in schedule order; returns 1 if a move was made */
-			int step_expand(const float *policy, const float *value);
+			/* action_values: null for a 'pv' network, else (win, draw) [n][HW][2] of a 'pvq' network */
+			int step_expand(const float *policy, const float *value, const float *action_values = nullptr);
 			struct MoveRecord
 			{
 					Move move;

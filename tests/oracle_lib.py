@@ -51,6 +51,7 @@ def load():
         lib.ago_apply_symmetry.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         lib.ago_game_step_select.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
         lib.ago_game_step_expand.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        lib.ago_game_step_expand_q.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         lib.ago_game_outcome.argtypes = [ctypes.c_void_p]
         lib.ago_game_num_records.argtypes = [ctypes.c_void_p]
         lib.ago_game_record.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 9 + [ctypes.c_int]

@@ -142,13 +142,14 @@ def _oracle_root(olib, h):
                 prior=ep[:n].copy(), val=evl[:2 * n].copy(), es=es[:n].copy())
 
 
-def _play_and_compare(olib, rules, games, batch, sims, max_steps, evaluator, table_entries=1 << 16, n=N, final_selector=0, use_symmetries=0):
-    """evaluator(features uint32 [n][HW]) -> (policy [n][HW] f32, value [n][2] f32 (win, draw)); used for BOTH sides"""
+def _play_and_compare(olib, rules, games, batch, sims, max_steps, evaluator, table_entries=1 << 16, n=N, final_selector=0, use_symmetries=0,
+                      action_values=0):
+    """evaluator(features uint32 [n][HW]) -> (policy [n][HW] f32, value [n][2] f32 (win, draw)[, q [n][HW][2]]); used for BOTH sides"""
     from alphagomoku_amd import selfplay
     N, HW = n, n * n   # noqa: N806 (shadow the 15x15 module defaults)
     cfg = selfplay.default_config(rules=rules, board_size=n, draw_after=n * n, n_games=games, max_batch_size=batch, max_simulations=sims,
                                   tss_table_entries=table_entries, node_capacity=4096, edge_capacity=65536 if n <= 15 else 131072,
-                                  final_selector=final_selector, use_symmetries=use_symmetries)
+                                  final_selector=final_selector, use_symmetries=use_symmetries, action_values=action_values)
     pool = selfplay.GeneratorPool(cfg)
     ocfg = ol.default_search_config(max_batch_size=batch, max_simulations=sims, table_entries=table_entries, final_selector=final_selector,
                                     use_symmetries=use_symmetries)
@@ -166,9 +167,11 @@ def _play_and_compare(olib, rules, games, batch, sims, max_steps, evaluator, tab
     for step in range(max_steps):
         pool.select_solve()
         slots, feats = pool.scheduled()
-        pol, val = evaluator(feats) if len(slots) else (np.zeros((0, HW), np.float32), np.zeros((0, 2), np.float32))
+        out = evaluator(feats) if len(slots) else (np.zeros((0, HW), np.float32), np.zeros((0, 2), np.float32), np.zeros((0, HW, 2), np.float32))
+        pol, val = out[0], out[1]
+        qv = np.ascontiguousarray(out[2], dtype=np.float32) if action_values else None
         v3 = np.concatenate([val, 1 - val.sum(1, keepdims=True)], 1).astype(np.float32)
-        pool.provide(slots, pol, v3)
+        pool.provide(slots, pol, v3, qv)
         by_slot = {int(s): i for i, s in enumerate(slots)}
         for g in range(games):
             if olib.ago_game_outcome(handles[g]) != 0:
@@ -181,7 +184,10 @@ def _play_and_compare(olib, rules, games, batch, sims, max_steps, evaluator, tab
             assert np.array_equal(feats[idx], f[:c]), (step, g)                      # same leaves, same features
             p = np.ascontiguousarray(pol[idx])
             v = np.ascontiguousarray(val[idx])
-            olib.ago_game_step_expand(handles[g], ol.ptr(p), ol.ptr(v))
+            if action_values:
+                olib.ago_game_step_expand_q(handles[g], ol.ptr(p), ol.ptr(v), ol.ptr(np.ascontiguousarray(qv[idx])))
+            else:
+                olib.ago_game_step_expand(handles[g], ol.ptr(p), ol.ptr(v))
         pool.expand_backup()
         for g in range(games):
             info = pool.game_info(g)
@@ -331,6 +337,62 @@ def test_games_bit_exact_with_the_hip_network_in_the_loop(agx_lib, olib):
     compared, stats = _play_and_compare(olib, 0, games=4, batch=4, sims=100, max_steps=250, evaluator=evaluator)
     assert compared > 300 and stats["moves_played"] > 0
     net.close()
+
+
+@pytest.mark.parametrize("rules,symmetries", [(0, 0), (1, 1), (2, 0)])
+def test_whole_games_with_action_values(agx_lib, olib, rules, symmetries):
+    """'pvq' network semantics (ResnetPVQ): every edge of a network-evaluated node starts from the 'q' output of its cell, which
+    is what the default init_to = "q_head" selector reads (EdgeSelector.cpp:335-361, EdgeGenerator.cpp:119-124)"""
+    base = _stand_in_evaluator(olib)
+
+    def evaluator(feats):
+        pol, val = base(feats)
+        h = (np.ascontiguousarray(feats, dtype=np.uint32).astype(np.uint64) * np.uint64(2654435761) + np.arange(HW, dtype=np.uint64) * np.uint64(40503)) % np.uint64(1 << 20)
+        w = (h.astype(np.float32) / np.float32(1 << 20)) * np.float32(0.8)
+        d = (np.float32(1.0) - w) * np.float32(0.25)
+        return pol, val, np.stack([w, d], axis=2).astype(np.float32)
+    compared, stats = _play_and_compare(olib, rules, games=4, batch=4, sims=80, max_steps=4000, evaluator=evaluator, use_symmetries=symmetries,
+                                        action_values=1)
+    assert compared > 200 and stats["games_finished"] == 4
+
+
+def test_pvq_network_in_the_pool(agx_lib):
+    """agx_engine_evaluate with a ResnetPVQ network == network outputs (policy, value, q) written by hand into the slot buffers"""
+    from alphagomoku_amd import selfplay, AgxError
+    from alphagomoku_amd.networks import AGNetwork
+    d = synthetic.net_desc(blocks=2, filters=64, action_values=1)
+    blob, _ = synthetic.make_weights(d)
+    net = AGNetwork(d)
+    net.loadWeights(blob)
+    openings = synthetic.make_openings(15, 8, seed0=3)
+    pools = []
+    for _ in range(2):
+        pool = selfplay.GeneratorPool(selfplay.default_config(n_games=8, max_batch_size=4, max_simulations=60, tss_table_entries=1 << 14,
+                                                              node_capacity=2048, edge_capacity=32768, action_values=1))
+        pool.begin(selfplay.pack_openings(openings))
+        pools.append(pool)
+    for step in range(40):
+        pools[0].step(net)
+        pools[1].select_solve()
+        slots, feats = pools[1].scheduled()
+        if len(slots):
+            p, v, q = net.forward(feats)
+            pools[1].provide(slots, p, v, q)
+        pools[1].expand_backup()
+        for g in range(8):
+            a, b = pools[0].game_info(g), pools[1].game_info(g)
+            assert a["root_visits"] == b["root_visits"] and a["n_moves"] == b["n_moves"], (step, g)
+            assert [(e["move"], e["visits"], e["win"], e["draw"], e["prior"]) for e in a["edges"]] == \
+                   [(e["move"], e["visits"], e["win"], e["draw"], e["prior"]) for e in b["edges"]], (step, g)
+    assert any(e["win"] != 0.0 for e in pools[0].game_info(0)["edges"])   # the q outputs really seed the edges
+    pv = AGNetwork(synthetic.net_desc(blocks=2, filters=64))
+    pv.loadWeights(blob[:pv.blobFloats()])
+    with pytest.raises(AgxError):
+        pools[0].step(pv)          # a 'pv' network cannot feed a pool configured for action values
+    for pool in pools:
+        pool.close()
+    net.close()
+    pv.close()
 
 
 @pytest.mark.parametrize("rules", [0, 2])
