@@ -326,45 +326,21 @@ namespace agx
 		}
 
 		/* PatternCalculator::update_around (PatternCalculator.cpp:278-367): the centre cell, then the +-5 cells in the four
-		 * directions in the order k = -5..5 (k != 0), direction 0..3 — one lane per (k, direction). */
+		 * directions in the order k = -5..5 (k != 0), direction 0..3 — one lane per (k, direction); lanes 40-43 re-classify the four
+		 * directions of the centre when a stone is removed.
+		 * The threat lists must end up in the reference's order (push-back add, swap-with-last remove, applied cell by cell), so the
+		 * list edits are applied one after the other — but with the 20 list sizes cached one per lane and the element to move taken
+		 * from the search's own registers, one edit costs a single LDS round trip.  LDS executes a wave's instructions in issue order,
+		 * so an edit sees the previous one without waiting for it. */
 		__device__ __forceinline__ void solver_update_around(SolverShared &sh, const EngineDev &E, int r, int c, bool added, int lane)
 		{
 			const int n = E.n;
 			const int center = r * n + c;
 			AGX_PROF_BEGIN();
-			if (added)
-			{
-				const int old0 = sh.threat[center][0], old1 = sh.threat[center][1];
-				list_remove(sh, 0, old0, center, lane);
-				list_remove(sh, 1, old1, center, lane);
-				if (lane < 8)
-					sh.ptype[center][lane] = 0;
-				if (lane < 2)
-					sh.threat[center][lane] = 0;
-			}
-			else
-			{
-				if (lane < 4)
-				{
-					const uint8_t e = E.t_pattern[narrow(normal_pattern(sh, n, r, c, lane))];
-					sh.ptype[center][lane] = e & 15;
-					sh.ptype[center][4 + lane] = e >> 4;
-				}
-				wave_sync();
-				const int t0 = E.t_threat[2 * threat_index(sh.ptype[center])];
-				const int t1 = E.t_threat[2 * threat_index(sh.ptype[center] + 4) + 1];
-				if (lane == 0)
-				{
-					sh.threat[center][0] = static_cast<uint8_t>(t0);
-					sh.threat[center][1] = static_cast<uint8_t>(t1);
-				}
-				list_add(sh, 0, t0, center, lane);
-				list_add(sh, 1, t1, center, lane);
-			}
-			wave_sync();
-			AGX_PROF_MARK(sh, 10);
+			int cnt = (lane < 20) ? sh.count[lane / 10][lane % 10] : 0; // lane 10 s + t holds the size of list (s, t)
 
 			int cell = -1, old0 = 0, old1 = 0, new0 = 0, new1 = 0;
+			uint32_t centre_bits = 0; // lanes 40-43: pattern types of the centre in direction lane - 40, as 3-bit fields of the two threat indices
 			if (lane < 40)
 			{
 				const int ki = lane >> 2, d = lane & 3;
@@ -375,41 +351,119 @@ namespace agx
 					cell = rr * n + cc;
 					old0 = sh.threat[cell][0];
 					old1 = sh.threat[cell][1];
-					const uint8_t e = E.t_pattern[narrow(normal_pattern(sh, n, rr, cc, d))];
-					sh.ptype[cell][d] = e & 15;
-					sh.ptype[cell][4 + d] = e >> 4;
-					new0 = E.t_threat[2 * threat_index(sh.ptype[cell])];
-					new1 = E.t_threat[2 * threat_index(sh.ptype[cell] + 4) + 1];
+					uint32_t w0 = *reinterpret_cast<const uint32_t*>(&sh.ptype[cell][0]); // cross, one byte per direction
+					uint32_t w1 = *reinterpret_cast<const uint32_t*>(&sh.ptype[cell][4]); // circle
+					const uint32_t e = E.t_pattern[narrow(normal_pattern(sh, n, rr, cc, d))];
+					w0 = (w0 & ~(255u << (8 * d))) | ((e & 15u) << (8 * d));
+					w1 = (w1 & ~(255u << (8 * d))) | ((e >> 4) << (8 * d));
+					sh.ptype[cell][d] = static_cast<uint8_t>(e & 15u);
+					sh.ptype[cell][4 + d] = static_cast<uint8_t>(e >> 4);
+					new0 = E.t_threat[2 * ((w0 & 7u) | (((w0 >> 8) & 7u) << 3) | (((w0 >> 16) & 7u) << 6) | (((w0 >> 24) & 7u) << 9))];
+					new1 = E.t_threat[2 * ((w1 & 7u) | (((w1 >> 8) & 7u) << 3) | (((w1 >> 16) & 7u) << 6) | (((w1 >> 24) & 7u) << 9)) + 1];
 					sh.threat[cell][0] = static_cast<uint8_t>(new0);
 					sh.threat[cell][1] = static_cast<uint8_t>(new1);
 				}
 			}
+			else if (lane < 44 && !added)
+			{
+				const int d = lane - 40;
+				const uint32_t e = E.t_pattern[narrow(normal_pattern(sh, n, r, c, d))];
+				sh.ptype[center][d] = static_cast<uint8_t>(e & 15u);
+				sh.ptype[center][4 + d] = static_cast<uint8_t>(e >> 4);
+				centre_bits = ((e & 15u) << (3 * d)) | ((e >> 4) << (16 + 3 * d));
+			}
+			// the centre: its old threats leave the lists (stone added) or its new ones join them (stone removed)
+			int c0 = 0, c1 = 0;
+			if (added)
+			{
+				c0 = sh.threat[center][0];
+				c1 = sh.threat[center][1];
+				if (lane < 8)
+					sh.ptype[center][lane] = 0;
+				if (lane < 2)
+					sh.threat[center][lane] = 0;
+			}
+			else
+			{
+				const uint32_t bits = __builtin_amdgcn_readlane(centre_bits, 40) | __builtin_amdgcn_readlane(centre_bits, 41)
+						| __builtin_amdgcn_readlane(centre_bits, 42) | __builtin_amdgcn_readlane(centre_bits, 43);
+				c0 = E.t_threat[2 * (bits & 4095u)];
+				c1 = E.t_threat[2 * ((bits >> 16) & 4095u) + 1];
+				if (lane == 0)
+				{
+					sh.threat[center][0] = static_cast<uint8_t>(c0);
+					sh.threat[center][1] = static_cast<uint8_t>(c1);
+				}
+			}
 			u64 changed0 = __ballot(cell >= 0 && old0 != new0);
 			u64 changed1 = __ballot(cell >= 0 && old1 != new1);
-			wave_sync();
 			AGX_PROF_MARK(sh, 11);
 			AGX_PROF_COUNT(sh, 13, __popcll(changed0) + __popcll(changed1));
 			AGX_PROF_COUNT(sh, 14, 1);
+
+			auto list_take = [&](int s, int t, int what)
+			{ // ThreatHistogram::remove (ThreatHistogram.hpp:39-99): the first match is overwritten by the last element
+				if (t == 0)
+					return;
+				const int size = __builtin_amdgcn_readlane(cnt, __builtin_amdgcn_readfirstlane(10 * s + t)); // v_readlane: the index is wave-uniform
+				for (int base = 0; base < size; base += 64)
+				{
+					const int j = base + lane;
+					const int v = (j < size) ? sh.lists[s][t][j] : -1;
+					const u64 m = __ballot(v == what);
+					if (m != 0)
+					{
+						const int found = base + __ffsll(static_cast<long long>(m)) - 1;
+						const int last = (size - 1 >= base && size - 1 < base + 64) ? __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane((size - 1) & 63)) : static_cast<int>(sh.lists[s][t][size - 1]);
+						if (lane == 0)
+							sh.lists[s][t][found] = static_cast<uint16_t>(last);
+						if (lane == 10 * s + t)
+							cnt--;
+						break;
+					}
+				}
+				__builtin_amdgcn_wave_barrier();
+			};
+			auto list_put = [&](int s, int t, int what)
+			{ // ThreatHistogram::add (:101-111)
+				if (t == 0)
+					return;
+				const int size = __builtin_amdgcn_readlane(cnt, __builtin_amdgcn_readfirstlane(10 * s + t)); // v_readlane: the index is wave-uniform
+				if (lane == 0)
+					sh.lists[s][t][size] = static_cast<uint16_t>(what);
+				if (lane == 10 * s + t)
+					cnt++;
+				__builtin_amdgcn_wave_barrier();
+			};
+			if (added)
+			{
+				list_take(0, c0, center);
+				list_take(1, c1, center);
+			}
+			else
+			{
+				list_put(0, c0, center);
+				list_put(1, c1, center);
+			}
 			while (changed0 != 0)
 			{
-				const int src = __ffsll(static_cast<long long>(changed0)) - 1;
+				const int src = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(changed0)) - 1);
 				changed0 &= changed0 - 1;
-				const int cc = __shfl(cell, src), o = __shfl(old0, src), nw = __shfl(new0, src);
-				list_remove(sh, 0, o, cc, lane);
-				wave_sync();
-				list_add(sh, 0, nw, cc, lane);
-				wave_sync();
+				const int cc = __builtin_amdgcn_readlane(cell, src), o = __builtin_amdgcn_readlane(old0, src), nw = __builtin_amdgcn_readlane(new0, src);
+				list_take(0, o, cc);
+				list_put(0, nw, cc);
 			}
 			while (changed1 != 0)
 			{
-				const int src = __ffsll(static_cast<long long>(changed1)) - 1;
+				const int src = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(changed1)) - 1);
 				changed1 &= changed1 - 1;
-				const int cc = __shfl(cell, src), o = __shfl(old1, src), nw = __shfl(new1, src);
-				list_remove(sh, 1, o, cc, lane);
-				wave_sync();
-				list_add(sh, 1, nw, cc, lane);
-				wave_sync();
+				const int cc = __builtin_amdgcn_readlane(cell, src), o = __builtin_amdgcn_readlane(old1, src), nw = __builtin_amdgcn_readlane(new1, src);
+				list_take(1, o, cc);
+				list_put(1, nw, cc);
 			}
+			if (lane < 20)
+				sh.count[lane / 10][lane % 10] = static_cast<uint16_t>(cnt);
+			wave_sync();
 			AGX_PROF_MARK(sh, 12);
 		}
 		__device__ __forceinline__ void solver_place(SolverShared &sh, const EngineDev &E, uint32_t move, bool add, int lane)
