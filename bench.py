@@ -176,11 +176,14 @@ def main():
         local_sims = s1["evaluated_nodes"] - s0["evaluated_nodes"]
         tree_gbs = local_sims * tree_bytes / (tree_ms * 1e-3) / 1e9 if tree_ms > 0 else 0.0
         traffic = None
+        mfma_busy = None
         pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
         if os.path.exists(pmc_path) and args.games == 1024 and args.filters == 128 and args.blocks == 6:
             # HBM-side bytes per network launch from the committed rocprofv3 --pmc passes of this same command (FETCH_SIZE doubled per
             # the gfx950 correction + WRITE_SIZE); PMC counters cannot be sampled from inside this process
-            traffic = json.load(open(pmc_path)).get("nn_tower_bytes_per_launch_corrected")
+            pmc = json.load(open(pmc_path))
+            traffic = pmc.get("nn_tower_bytes_per_launch_corrected")
+            mfma_busy = pmc.get("nn_tower_mfma_busy_fraction")
         result = {
             "metric": "MCTS simulations/sec (self-play, %dx%d %s)" % (args.board, args.board, RULE_NAMES[args.rules]),
             "value": sims / elapsed,
@@ -210,7 +213,9 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "nn_tower_kernel<%d,%d,%d>" % (args.filters, args.board, args.board),
                          "achieved": nn_tflops, "peak": 2500.0, "unit": "TFLOP/s", "frac": nn_tflops / 2500.0, "traffic": traffic,
                          "flops_per_position": flops, "positions_per_launch": local_evals / args.steps,
-                         "avg_launch_ms": ms_nn / args.steps},
+                         "avg_launch_ms": ms_nn / args.steps,
+                         # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) of the committed PMC passes of this command
+                         "mfma_busy_fraction_pmc": mfma_busy},
             # second roof ("two kernels, two roofs"): the tree kernels are gathers/scans over the flat node/edge arrays
             "roofline_tree": {"bound": "hbm", "kernels": "k_select + k_expand + k_advance", "achieved": tree_gbs, "peak": 8000.0, "unit": "GB/s",
                               "frac": tree_gbs / 8000.0, "bytes_per_simulation": tree_bytes, "ms_per_step": tree_ms / args.steps,
