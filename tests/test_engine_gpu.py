@@ -493,3 +493,20 @@ def test_engine_error_paths(agx_lib):
         pool.expand_backup()
     assert pool.stats()["first_error"] in (1, 2, 5)
     pool.close()
+
+
+def test_native_cpp_driver_over_the_c_abi(agx_lib):
+    """alphagomoku_amd/agx_selfplay: the C++ host loop (include/agx.hpp facade: AGNetwork + GeneratorPool, the stand-ins of the
+    reference's AGNetwork / GeneratorThread) drives the same library without Python"""
+    import json
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "alphagomoku_amd", "agx_selfplay")
+    assert os.path.exists(exe), "native driver not built (python -m alphagomoku_amd.build)"
+    out = subprocess.run([exe, "--games", "16", "--steps", "30", "--warmup", "3", "--sims", "50", "--batch", "4", "--blocks", "2", "--filters", "64",
+                          "--rules", "1"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["simulations_per_sec"] > 0 and line["network_evaluations"] > 0
+    bad = subprocess.run([exe, "--filters", "96", "--steps", "1"], capture_output=True, text=True, timeout=300)
+    assert bad.returncode == 1 and "unsupported network" in bad.stderr   # errors surface as exceptions with the library's message
