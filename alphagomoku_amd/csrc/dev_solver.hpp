@@ -167,14 +167,11 @@ namespace agx
 		__device__ __forceinline__ int row_step(int d) { return d == 0 ? 0 : 1; }
 		__device__ __forceinline__ int col_step(int d) { return d == 0 ? 1 : (d == 1 ? 0 : (d == 2 ? 1 : -1)); }
 		__device__ __forceinline__ void line_of(int n, int r, int c, int d, int &index, int &shift)
-		{ // RawPatternCalculator.hpp:241-273
-			switch (d)
-			{
-				case 0: index = r; shift = 2 * c; break;
-				case 1: index = n + c; shift = 2 * r; break;
-				case 2: index = 2 * n + (c - r + n - 1); shift = 2 * min(c, r); break;
-				default: index = 4 * n - 1 + (r + c); shift = 2 * min(r, n - 1 - c); break;
-			}
+		{ // RawPatternCalculator.hpp:241-273; selects instead of a switch: lanes of one wave hold different directions
+			const int i2 = 3 * n - 1 + c - r, i3 = 4 * n - 1 + r + c;
+			const int s2 = min(c, r), s3 = min(r, n - 1 - c);
+			index = (d == 0) ? r : ((d == 1) ? n + c : ((d == 2) ? i2 : i3));
+			shift = 2 * ((d == 0) ? c : ((d == 1) ? r : ((d == 2) ? s2 : s3)));
 		}
 		__device__ __forceinline__ uint32_t extended_pattern(const SolverShared &sh, int n, int r, int c, int d)
 		{ // 13 cells (+-6), off-board = 3 (RawPatternCalculator.hpp:196-210)

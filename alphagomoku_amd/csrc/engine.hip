@@ -769,6 +769,7 @@ namespace
 			gs.solve_pos = 0;
 			gs.solve_pending = 0;
 			gs.nn_queued = 0;
+			gs.restart_id = 0;
 			gs.generation = (gs.generation + 1) % 64; // prepare_search -> increaseGeneration
 			gs.opening_id = id;
 			gs.active = 1;
@@ -803,7 +804,10 @@ namespace
 		if (sh_id < E.n_openings)
 			begin_game(E, g, sh_id, tid, scratch);
 		else if (tid == 0)
+		{
 			gs.active = 0;
+			gs.restart_id = -1; // waits for an opening like a finished game
+		}
 	}
 
 	__global__ __launch_bounds__(256) void k_advance(EngineDev E)
@@ -963,21 +967,16 @@ namespace
 			sh_int[2] = outcome;
 			sh_int[3] = -1;
 			if (outcome != 0)
-			{
+			{ // game over (GameGenerator.cpp:104-114 -> GAME_NOT_STARTED): k_assign_openings / k_restart give the slot its next opening
 				gs.games_done++;
 				atomicAdd(&E.counters[2], 1);
-				sh_int[3] = atomicAdd(&E.counters[1], 1);
+				gs.active = 0;
+				gs.restart_id = -1;
 			}
 		}
 		__syncthreads();
 		if (sh_int[2] != 0)
-		{ // game over: take the next opening of the pool, if any (GameGenerator.cpp:104-114 -> GAME_NOT_STARTED)
-			if (sh_int[3] < E.n_openings)
-				begin_game(E, g, sh_int[3], tid, scratch);
-			else if (tid == 0)
-				gs.active = 0;
 			return;
-		}
 
 		// ---- prepare_search: NodeCache::cleanup (NodeCache.cpp:221-249) as keep-test + prefix sum + copy to the other arena ----
 		DNode *dst_nodes = nodes_of(E, g, gs.arena ^ 1);
@@ -1054,6 +1053,89 @@ namespace
 					dst_nodes[found].flags |= 2;
 			}
 		}
+	}
+
+	/*
+	 * Finished games take the next openings of the pool in GAME ORDER (not in the order their workgroups happen to finish), so a
+	 * run is reproducible: one workgroup scans the games of the launch's range, numbers the waiting ones and reserves that many
+	 * openings; games for which none is left keep waiting (agx_engine_add_openings can supply more).
+	 */
+	__global__ __launch_bounds__(1024) void k_assign_openings(EngineDev E, int count)
+	{
+		__shared__ int scan[1024];
+		__shared__ int sh_base, sh_take, sh_running;
+		const int tid = threadIdx.x;
+		if (tid == 0)
+			sh_running = 0;
+		__syncthreads();
+		// pass 1: how many games wait
+		int mine = 0;
+		for (int i = tid; i < count; i += 1024)
+			mine += (E.games[E.g0 + i].restart_id == -1) ? 1 : 0;
+		scan[tid] = mine;
+		__syncthreads();
+		for (int o = 512; o > 0; o >>= 1)
+		{
+			if (tid < o)
+				scan[tid] += scan[tid + o];
+			__syncthreads();
+		}
+		if (tid == 0)
+		{
+			const int wanted = scan[0];
+			int base = 0, take = 0;
+			if (wanted > 0)
+			{
+				int seen = __hip_atomic_load(&E.counters[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				while (true)
+				{ // reserve min(wanted, openings left); another group's launch may be doing the same on its stream
+					take = max(0, min(wanted, E.n_openings - seen));
+					const int prev = atomicCAS(&E.counters[1], seen, seen + take);
+					if (prev == seen)
+						break;
+					seen = prev;
+				}
+				base = seen;
+			}
+			sh_base = base;
+			sh_take = take;
+		}
+		__syncthreads();
+		if (sh_take == 0)
+			return;
+		// pass 2: number the waiting games in game order, chunk by chunk
+		for (int start = 0; start < count; start += 1024)
+		{
+			const int i = start + tid;
+			const int waiting = (i < count && E.games[E.g0 + i].restart_id == -1) ? 1 : 0;
+			__syncthreads();
+			scan[tid] = waiting;
+			__syncthreads();
+			for (int o = 1; o < 1024; o <<= 1)
+			{
+				const int v = (tid >= o) ? scan[tid - o] : 0;
+				__syncthreads();
+				scan[tid] += v;
+				__syncthreads();
+			}
+			const int rank = sh_running + scan[tid] - waiting;
+			if (waiting && rank < sh_take)
+				E.games[E.g0 + i].restart_id = sh_base + rank + 1;
+			__syncthreads();
+			if (tid == 1023)
+				sh_running += scan[1023];
+			__syncthreads();
+		}
+	}
+	__global__ __launch_bounds__(256) void k_restart(EngineDev E)
+	{
+		__shared__ u64 scratch[4];
+		const int g = E.g0 + blockIdx.x, tid = threadIdx.x;
+		const int id = E.games[g].restart_id;
+		if (id <= 0)
+			return;
+		__syncthreads();
+		begin_game(E, g, id - 1, tid, scratch);
 	}
 
 	__global__ void k_reset_counter(int *counter, int *second)
@@ -1410,6 +1492,29 @@ int agx_engine_begin(AgxEngine *e, const uint16_t *h_openings, int n_openings, v
 	return AGX_OK;
 }
 
+int agx_engine_add_openings(AgxEngine *e, const uint16_t *h_openings, int n_openings)
+{
+	AGX_REQUIRE(e != nullptr && h_openings != nullptr, AGX_ERR_INVALID, "agx_engine_add_openings: null argument");
+	AGX_REQUIRE(n_openings > 0, AGX_ERR_INVALID, "agx_engine_add_openings: need at least one opening");
+	AGX_REQUIRE(e->begun, AGX_ERR_STATE, "agx_engine_add_openings: agx_engine_begin has not been called");
+	AGX_HIP_CHECK(hipDeviceSynchronize());
+	const size_t words_old = static_cast<size_t>(e->dev.n_openings) * OPENING_CAP, words_new = static_cast<size_t>(n_openings) * OPENING_CAP;
+	uint16_t *d_op = nullptr;
+	AGX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_op), (words_old + words_new) * sizeof(uint16_t)));
+	AGX_HIP_CHECK(hipMemcpy(d_op, e->dev.openings, words_old * sizeof(uint16_t), hipMemcpyDeviceToDevice));
+	AGX_HIP_CHECK(hipMemcpy(d_op + words_old, h_openings, words_new * sizeof(uint16_t), hipMemcpyHostToDevice));
+	// the previous table is no longer referenced by any launch (device synchronised above): replace it in the allocation list
+	for (void *&p : e->allocations)
+		if (p == static_cast<const void*>(e->dev.openings))
+		{
+			(void) hipFree(p);
+			p = d_op;
+		}
+	e->dev.openings = d_op;
+	e->dev.n_openings += n_openings;
+	return AGX_OK;
+}
+
 /* games [first, first + count) of group `group` out of `n_groups` equal parts of the pool */
 static int group_range(const AgxEngine *e, int group, int n_groups, EngineDev &d, int &count)
 {
@@ -1489,6 +1594,8 @@ int agx_engine_expand_backup_group(AgxEngine *e, int group, int n_groups, void *
 	{
 		KernelTimer t(e, s, 3);
 		hipLaunchKernelGGL(k_advance, dim3(count), dim3(256), 0, s, d);
+		hipLaunchKernelGGL(k_assign_openings, dim3(1), dim3(1024), 0, s, d, count);
+		hipLaunchKernelGGL(k_restart, dim3(count), dim3(256), 0, s, d);
 	}
 	AGX_HIP_CHECK(hipGetLastError());
 	return AGX_OK;
@@ -1674,6 +1781,17 @@ int agx_engine_records(AgxEngine *e, AgxMoveRecord *h_records, int record_capaci
 		h_edges[i].score = edges[i].score;
 		h_edges[i].flag_and_virtual_loss = edges[i].flag_vl;
 	}
+	return AGX_OK;
+}
+
+int agx_engine_drain_records(AgxEngine *e, AgxMoveRecord *h_records, int record_capacity, AgxEdgeView *h_edges, int edge_capacity, int *n_records, int *n_edges)
+{
+	AGX_REQUIRE(h_records != nullptr && h_edges != nullptr, AGX_ERR_INVALID, "agx_engine_drain_records: null buffer (query the sizes with agx_engine_records)");
+	const int st = agx_engine_records(e, h_records, record_capacity, h_edges, edge_capacity, n_records, n_edges);
+	if (st != AGX_OK)
+		return st;
+	// the device is synchronised (agx_engine_records): the record pools start empty again; game_serial keeps counting
+	AGX_HIP_CHECK(hipMemset(e->dev.counters + 3, 0, 2 * sizeof(int)));
 	return AGX_OK;
 }
 

@@ -102,7 +102,7 @@ namespace agx
 			int32_t solve_pos;     // first task of the batch that still has to be solved (solver launches may yield between tasks)
 			int32_t solve_pending; // 1 while the batch is only partly solved: the game sits out select / network / expand until it is done
 			int32_t nn_queued;     // positions handed to the network so far in this game (index of the symmetry hash)
-			int32_t pad;
+			int32_t restart_id;    // 0: playing; -1: the game is over and waits for an opening; k > 0: it starts again from opening k - 1 in k_restart
 			uint64_t root_hash;
 			uint64_t cboard[BWORDS];
 			unsigned long long prof[8];   // optional cycle counters (AGX_SOLVER_PROFILE builds only)

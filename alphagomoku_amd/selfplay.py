@@ -135,14 +135,21 @@ class GeneratorPool:
                                  flag_vl=e.flag_and_virtual_loss) for e in edges[:info.root_edges]]
         return out
 
-    def records(self):
+    def records(self, drain=False):
+        """(move records, their root-edge snapshots) produced so far; drain=True also empties the device-side pools"""
         nr, ne = ctypes.c_int(), ctypes.c_int()
         check(lib.agx_engine_records(self._h, None, 0, None, 0, ctypes.byref(nr), ctypes.byref(ne)))
         recs = (AgxMoveRecord * max(nr.value, 1))()
         edges = (AgxEdgeView * max(ne.value, 1))()
-        check(lib.agx_engine_records(self._h, ctypes.cast(recs, ctypes.c_void_p), nr.value, ctypes.cast(edges, ctypes.c_void_p), ne.value,
-                                     ctypes.byref(nr), ctypes.byref(ne)))
+        fn = lib.agx_engine_drain_records if drain else lib.agx_engine_records
+        check(fn(self._h, ctypes.cast(recs, ctypes.c_void_p), max(nr.value, 1), ctypes.cast(edges, ctypes.c_void_p), max(ne.value, 1),
+                 ctypes.byref(nr), ctypes.byref(ne)))
         return recs[:nr.value], edges[:ne.value]
+
+    def add_openings(self, packed_openings):
+        """appends openings (pack_openings layout) for the games that finish from now on"""
+        a = np.ascontiguousarray(packed_openings, dtype=np.uint16)
+        check(lib.agx_engine_add_openings(self._h, a.ctypes.data_as(ctypes.c_void_p), a.shape[0]))
 
     def zobrist(self):
         keys = np.zeros(4 * self.cells, np.uint64)

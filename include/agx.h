@@ -250,6 +250,12 @@ int agx_engine_kernel_timing(AgxEngine* engine, int enable, double* ms_out, long
 /* Tree::getInfo({}) of one game (Tree.cpp:403-424): root snapshot + board. */
 int agx_engine_game_info(AgxEngine* engine, int game, AgxGameInfo* info, uint8_t* h_board, AgxEdgeView* h_root_edges, int edge_capacity);
 int agx_engine_records(AgxEngine* engine, AgxMoveRecord* h_records, int record_capacity, AgxEdgeView* h_edges, int edge_capacity, int* n_records, int* n_edges);
+/* Same, then empties the device-side record pools (what GeneratorManager::addToBuffer's hand-over does, GeneratorManager.cpp:
+ * 160-164): a long-running loop calls this every few hundred steps so that record_capacity is never exhausted. */
+int agx_engine_drain_records(AgxEngine* engine, AgxMoveRecord* h_records, int record_capacity, AgxEdgeView* h_edges, int edge_capacity, int* n_records, int* n_edges);
+/* Appends openings to the pool's list.  Finished games take the next unused opening in game order after every step; games that
+ * found none left wait and pick one up here (the reference's generators produce openings on demand, GameGenerator.cpp:54-77). */
+int agx_engine_add_openings(AgxEngine* engine, const uint16_t* h_openings, int n_openings);
 /* FastZobristHashing keys used by the solver tables: uint64[2 * cells][2] = (lo, hi) per (cell, colour). */
 int agx_engine_zobrist(AgxEngine* engine, uint64_t* h_keys, size_t n_words);
 

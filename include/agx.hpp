@@ -225,6 +225,23 @@ namespace agx
 				records.resize(nr);
 				edges.resize(ne);
 			}
+			/* hand-over to the game buffer: returns the samples and empties the device-side pools */
+			void drainRecords(std::vector<AgxMoveRecord> &records, std::vector<AgxEdgeView> &edges)
+			{
+				int nr = 0, ne = 0;
+				check(agx_engine_records(m_engine, nullptr, 0, nullptr, 0, &nr, &ne));
+				records.resize(nr > 0 ? nr : 1);
+				edges.resize(ne > 0 ? ne : 1);
+				check(agx_engine_drain_records(m_engine, records.data(), static_cast<int>(records.size()), edges.data(), static_cast<int>(edges.size()), &nr, &ne));
+				records.resize(nr);
+				edges.resize(ne);
+			}
+			void addOpenings(const std::vector<uint16_t> &openings)
+			{
+				if (openings.empty() || openings.size() % AGX_OPENING_CAP != 0)
+					throw std::logic_error("GeneratorPool::addOpenings: openings must hold a positive multiple of AGX_OPENING_CAP words");
+				check(agx_engine_add_openings(m_engine, openings.data(), static_cast<int>(openings.size() / AGX_OPENING_CAP)));
+			}
 			const AgxEngineBuffers& buffers() const noexcept
 			{
 				return m_buffers;

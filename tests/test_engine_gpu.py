@@ -510,3 +510,48 @@ def test_native_cpp_driver_over_the_c_abi(agx_lib):
     assert line["simulations_per_sec"] > 0 and line["network_evaluations"] > 0
     bad = subprocess.run([exe, "--filters", "96", "--steps", "1"], capture_output=True, text=True, timeout=300)
     assert bad.returncode == 1 and "unsupported network" in bad.stderr   # errors surface as exceptions with the library's message
+
+
+def test_long_running_loop_drains_records_and_refills_openings(agx_lib):
+    """A generator thread that runs for hours: records are handed over and the device pools emptied (agx_engine_drain_records),
+    openings are appended on demand (agx_engine_add_openings); finished games take openings in GAME order, so two runs agree."""
+    from alphagomoku_amd import selfplay
+    from alphagomoku_amd.networks import AGNetwork
+    d = synthetic.net_desc(blocks=2, filters=64)
+    blob, _ = synthetic.make_weights(d)
+    net = AGNetwork(d)
+    net.loadWeights(blob)
+    first = synthetic.make_openings(15, 12, seed0=50)
+    more = synthetic.make_openings(15, 30, seed0=500)
+
+    def run():
+        pool = selfplay.GeneratorPool(selfplay.default_config(n_games=8, max_batch_size=8, max_simulations=30, tss_table_entries=1 << 14,
+                                                              node_capacity=2048, edge_capacity=32768, record_capacity=4096))
+        pool.begin(selfplay.pack_openings(first))
+        drained, history, added = [], [], False
+        for step in range(1500):
+            pool.step(net)
+            if step % 50 == 49:
+                recs, edges = pool.records(drain=True)
+                for r in recs:
+                    e = edges[r.edge_offset:r.edge_offset + r.n_edges]
+                    drained.append((r.game_serial, r.move_number, r.move, r.root_visits, tuple(x.visits for x in e)))
+                st = pool.stats()
+                assert st["records_used"] == 0 and st["first_error"] == 0
+                history.append((st["games_finished"], st["openings_taken"], tuple(pool.game_info(g)["opening_id"] for g in range(8))))
+                if st["openings_taken"] >= 12 and not added:
+                    assert not all(pool.game_info(g)["active"] for g in range(8)) or st["games_finished"] <= 4
+                    pool.add_openings(selfplay.pack_openings(more))
+                    added = True
+                if st["games_finished"] >= 30:
+                    break
+        st = pool.stats()
+        pool.close()
+        return drained, history, st
+    d1, h1, st1 = run()
+    d2, h2, st2 = run()
+    assert st1["games_finished"] >= 30 and st1["openings_taken"] > 12
+    assert len(d1) == st1["moves_played"]                                   # every played move was handed over exactly once
+    assert len({(s, m) for s, m, _, _, _ in d1}) == len(d1)
+    assert sorted(d1) == sorted(d2) and h1 == h2                            # reproducible, including which slot got which opening
+    net.close()
