@@ -236,6 +236,84 @@ void* ago_solver_create(int rules, int rows, int cols, uint64_t table_entries, u
 	s->max_nodes = max_nodes;
 	return s;
 }
+/* transposition table alone (SharedHashTable.hpp): value packing as SharedTableData(bound, depth, score, move) */
+void ago_solver_tt_insert(void *h, uint64_t lo, uint64_t hi, int bound, int depth, uint16_t score_raw, uint16_t move_short)
+{
+	Key128 k;
+	k.lo = lo;
+	k.hi = hi;
+	const uint64_t value = static_cast<uint64_t>(bound) | (static_cast<uint64_t>(depth) << 8) | (static_cast<uint64_t>(score_raw) << 16)
+			| (static_cast<uint64_t>(move_short) << 32);
+	static_cast<Solver*>(h)->tt_insert(k, value);
+}
+uint64_t ago_solver_tt_seek(void *h, uint64_t lo, uint64_t hi)
+{
+	Key128 k;
+	k.lo = lo;
+	k.hi = hi;
+	return static_cast<const Solver*>(h)->tt_seek(k);
+}
+/* line patterns of every cell after a move sequence (0 = undo): out[(cell * 4 + dir) * 2 + {0, 1}] = normal / extended pattern */
+void ago_raw_patterns(int rows, int cols, const uint8_t *board, const uint16_t *moves, int n_moves, uint32_t *out)
+{
+	Calc calc(make_cfg(0, rows, cols));
+	calc.set_board(board, CROSS);
+	std::vector<Move> done;
+	for (int i = 0; i < n_moves; i++)
+	{
+		if (moves[i] == 0)
+		{
+			calc.undo_move(done.back());
+			done.pop_back();
+		}
+		else
+		{
+			const Move m = Move::from_short(moves[i]);
+			calc.add_move(m);
+			done.push_back(m);
+		}
+	}
+	for (int r = 0; r < rows; r++)
+		for (int c = 0; c < cols; c++)
+			for (int d = 0; d < 4; d++)
+			{
+				out[((r * cols + c) * 4 + d) * 2 + 0] = calc.raw_pattern(r, c, d, 5);
+				out[((r * cols + c) * 4 + d) * 2 + 1] = calc.raw_pattern(r, c, d, 6);
+			}
+}
+int ago_is_straight_four(int rows, int cols, const uint8_t *board, int row, int col, int dir)
+{
+	Calc calc(make_cfg(2, rows, cols));
+	calc.set_board(board, CROSS);
+	return is_straight_four_at(calc, row, col, dir) ? 1 : 0;
+}
+/* threat lists alone (ThreatHistogram.hpp): ops[4 i ..] = (1 add / 0 remove, threat type, row, col) */
+int ago_threat_histogram(const int *ops, int n_ops, int16_t *out)
+{
+	LocList lists[10];
+	for (int i = 0; i < n_ops; i++)
+	{
+		const int t = ops[4 * i + 1];
+		if (t == 0)
+			continue; // ThreatType::NONE is never stored
+		const Loc l(ops[4 * i + 2], ops[4 * i + 3]);
+		if (ops[4 * i])
+			lists[t].add(l);
+		else
+			lists[t].remove(l);
+	}
+	int pos = 0;
+	for (int t = 0; t < 10; t++)
+	{
+		out[pos++] = static_cast<int16_t>(lists[t].size());
+		for (const Loc &l : lists[t].v)
+		{
+			out[pos++] = l.row;
+			out[pos++] = l.col;
+		}
+	}
+	return pos;
+}
 void ago_solver_destroy(void *h)
 {
 	delete static_cast<Solver*>(h);

@@ -186,7 +186,7 @@ namespace ago
 		}
 		return false;
 	}
-	static bool is_straight_four_at(const Calc &pc, int r, int c, Direction d)
+	bool is_straight_four_at(const Calc &pc, int r, int c, Direction d)
 	{ // RawPatternCalculator.hpp:142-178: window +-5 with a cross stone put at the centre contains XXXX
 		uint32_t result = 0;
 		for (int i = -5, sh = 0; i <= 5; i++, sh += 2)

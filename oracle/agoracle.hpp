@@ -316,6 +316,7 @@ namespace ago
 			int node_counter = 0;
 			Score recursive_solve(int depth_remaining, Score alpha, Score beta, ActionList &actions); // :185-339
 			Score evaluate();                                                                        // :345-365
+		public:
 			uint64_t tt_seek(const Key128 &k) const;                                                  // SharedHashTable.hpp:142-150
 			void tt_insert(const Key128 &k, uint64_t value);                                          // :151-175
 	};
@@ -377,6 +378,8 @@ namespace ago
 			int use_symmetries = 0;          // NNEvaluator::addToQueue (NNEvaluator.cpp:134-141): random input symmetry per queued task
 			uint64_t symmetry_seed = 0x5DEECE66Dull; // the reference draws randInt(8) from a time-seeded generator; here a counter-based hash
 	};
+
+	bool is_straight_four_at(const Calc &pc, int r, int c, Direction d); // RawPatternCalculator.hpp:142-178
 
 	/* utils/augmentations.hpp:62-216 (square boards): source cell of destination (r, c) under symmetry s; inverse symmetry */
 	inline void symmetry_source(int s, int n, int r, int c, int &sr, int &sc)

@@ -4,7 +4,8 @@
  * Thin extern "C" driver over the subset of the reference that compiles from its own sources WITHOUT the absent
  * MinML library (no stand-in headers are written): src/patterns/{PatternTable,PatternClassifier,ThreatTable,
  * DefensiveMoveTable}.cpp, src/game/Move.cpp, src/search/{Score,Value,ZobristHashing}.cpp,
- * src/search/monte_carlo/{Edge,Node}.cpp, src/utils/random.cpp, and the header-only utils/augmentations.hpp.
+ * src/search/monte_carlo/{Edge,Node}.cpp, src/utils/random.cpp, and the header-only utils/augmentations.hpp,
+ * search/alpha_beta/SharedHashTable.hpp, patterns/RawPatternCalculator.hpp, patterns/ThreatHistogram.hpp.
  * Built by oracle/Makefile into oracle/_ref/libagref.so straight from /root/reference; used by tests to pin the
  * restatement in oracle/ (tables, score algebra, struct layouts) and to generate tests/golden fixtures.
  * Everything that includes utils/configs.hpp (PatternCalculator, rules, MoveGenerator, AlphaBetaSearch, Tree, Search,
@@ -19,6 +20,10 @@
 #include <alphagomoku/search/monte_carlo/Node.hpp>
 #include <alphagomoku/game/rules.hpp>
 #include <alphagomoku/utils/augmentations.hpp>
+#include <alphagomoku/search/alpha_beta/SharedHashTable.hpp>
+#include <alphagomoku/patterns/RawPatternCalculator.hpp>
+#include <alphagomoku/patterns/ThreatHistogram.hpp>
+#include <vector>
 
 #include <cstdint>
 #include <cstring>
@@ -153,6 +158,96 @@ void ref_apply_symmetry(int n, int s, int in_place, const uint32_t *in, uint32_t
 int ref_inverse_symmetry(int s)
 {
 	return static_cast<int>(get_inverse_symmetry(int_to_symmetry(s)));
+}
+
+/* ---- SharedHashTable (search/alpha_beta/SharedHashTable.hpp): the solver's transposition table ---- */
+void* ref_tt_create(int rows, int cols, uint64_t entries)
+{
+	return new SharedHashTable(rows, cols, entries);
+}
+void ref_tt_destroy(void *h)
+{
+	delete static_cast<SharedHashTable*>(h);
+}
+void ref_tt_increase_generation(void *h)
+{
+	static_cast<SharedHashTable*>(h)->increaseGeneration();
+}
+void ref_tt_insert(void *h, uint64_t lo, uint64_t hi, int bound, int depth, uint16_t score_raw, uint16_t move_short)
+{
+	static_cast<SharedHashTable*>(h)->insert(HashKey128(HashKey64(lo), HashKey64(hi)),
+			SharedTableData(static_cast<Bound>(bound), depth, Score::from_short(score_raw), Move(move_short)));
+}
+uint64_t ref_tt_seek(void *h, uint64_t lo, uint64_t hi)
+{
+	return static_cast<uint64_t>(static_cast<const SharedHashTable*>(h)->seek(HashKey128(HashKey64(lo), HashKey64(hi))));
+}
+
+/* ---- RawPatternCalculator: line bit-boards; out[(cell * 4 + dir) * 2 + {0, 1}] = normal (11 cells) / extended (13 cells) pattern.
+ * moves: Move::toShort words, 0 = undo the most recent not-yet-undone move ---- */
+void ref_raw_patterns(int n, const uint8_t *board, const uint16_t *moves, int n_moves, uint32_t *out)
+{
+	matrix<Sign> b(n, n);
+	for (int i = 0; i < n * n; i++)
+		b[i] = static_cast<Sign>(board[i]);
+	RawPatternCalculator calc(n, n);
+	calc.set(b);
+	std::vector<Move> done;
+	for (int i = 0; i < n_moves; i++)
+	{
+		if (moves[i] == 0)
+		{
+			calc.undoMove(done.back());
+			done.pop_back();
+		}
+		else
+		{
+			const Move m(moves[i]);
+			calc.addMove(m);
+			done.push_back(m);
+		}
+	}
+	for (int r = 0; r < n; r++)
+		for (int c = 0; c < n; c++)
+			for (int d = 0; d < 4; d++)
+			{
+				out[((r * n + c) * 4 + d) * 2 + 0] = calc.getRawPatternAt<NormalPattern>(r, c, static_cast<Direction>(d));
+				out[((r * n + c) * 4 + d) * 2 + 1] = calc.getRawPatternAt<ExtendedPattern>(r, c, static_cast<Direction>(d));
+			}
+}
+int ref_is_straight_four(int n, const uint8_t *board, int row, int col, int dir)
+{
+	matrix<Sign> b(n, n);
+	for (int i = 0; i < n * n; i++)
+		b[i] = static_cast<Sign>(board[i]);
+	return RawPatternCalculator::isStraightFourAt(b, Move(row, col, Sign::CROSS), static_cast<Direction>(dir)) ? 1 : 0;
+}
+
+/* ---- ThreatHistogram: ops[4 * i ..] = (1 add / 0 remove, threat type, row, col); out: for every threat type its count, then (row, col) pairs ---- */
+int ref_threat_histogram(const int *ops, int n_ops, int16_t *out)
+{
+	ThreatHistogram h;
+	for (int i = 0; i < n_ops; i++)
+	{
+		const ThreatType t = static_cast<ThreatType>(ops[4 * i + 1]);
+		const Location l(ops[4 * i + 2], ops[4 * i + 3]);
+		if (ops[4 * i])
+			h.add(t, l);
+		else
+			h.remove(t, l);
+	}
+	int pos = 0;
+	for (int t = 0; t < 10; t++)
+	{
+		const LocationList &list = h.get(static_cast<ThreatType>(t));
+		out[pos++] = static_cast<int16_t>(list.size());
+		for (size_t i = 0; i < list.size(); i++)
+		{
+			out[pos++] = list[i].row;
+			out[pos++] = list[i].col;
+		}
+	}
+	return pos;
 }
 
 } /* extern "C" */

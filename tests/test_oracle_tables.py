@@ -196,3 +196,112 @@ def test_feature_direction_shuffle(oracle):
                 oracle.ago_apply_symmetry(n, s, 1, p(src), p(out))
                 want = base | (1 << (group + perm.index(d)))
                 assert (out == want).all(), (s, group, d)
+
+
+def test_transposition_table_equals_reference(oracle, ref):
+    """SharedHashTable (search/alpha_beta/SharedHashTable.hpp) compiled from the reference vs the oracle's table: bucket choice,
+    key matching, replacement by depth - age, in-place update for proven / exact entries, generations."""
+    oracle.ago_solver_create.restype = ctypes.c_void_p
+    oracle.ago_solver_create.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int]
+    oracle.ago_solver_tt_insert.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_uint16, ctypes.c_uint16]
+    oracle.ago_solver_tt_seek.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64]
+    oracle.ago_solver_tt_seek.restype = ctypes.c_uint64
+    oracle.ago_solver_new_generation.argtypes = [ctypes.c_void_p]
+    oracle.ago_solver_destroy.argtypes = [ctypes.c_void_p]
+    ref.ref_tt_create.restype = ctypes.c_void_p
+    ref.ref_tt_create.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_uint64]
+    ref.ref_tt_insert.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_uint16, ctypes.c_uint16]
+    ref.ref_tt_seek.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64]
+    ref.ref_tt_seek.restype = ctypes.c_uint64
+    ref.ref_tt_increase_generation.argtypes = [ctypes.c_void_p]
+    ref.ref_tt_destroy.argtypes = [ctypes.c_void_p]
+    rng = np.random.default_rng(77)
+    entries = 64   # 16 buckets: plenty of collisions and replacements
+    a = oracle.ago_solver_create(0, 15, 15, entries, 1, 100)
+    b = ref.ref_tt_create(15, 15, entries)
+    keys = [(int(rng.integers(0, 1 << 62)) * 4 + int(rng.integers(0, 4)), int(rng.integers(0, 1 << 63))) for _ in range(200)]
+    # a few keys that share the bucket AND the 16 high bits of the low word but differ in the high word
+    keys += [(keys[0][0], keys[0][1] ^ 1), (keys[1][0] ^ (1 << 20), keys[1][1])]
+    proven_scores = [oracle.ago_score_make(pv, ev) for pv in (0, 1, 3) for ev in (0, 3, 17)]
+    checked = hits = 0
+    for step in range(6000):
+        lo, hi = keys[int(rng.integers(0, len(keys)))]
+        action = rng.random()
+        if action < 0.45:
+            score = int(proven_scores[int(rng.integers(0, len(proven_scores)))]) if rng.random() < 0.3 else int(oracle.ago_score_make(2, int(rng.integers(-500, 500))))
+            bound, depth, move = int(rng.integers(1, 4)), int(rng.integers(0, 40)), int(rng.integers(1, 1 << 16))
+            oracle.ago_solver_tt_insert(a, lo, hi, bound, depth, score, move)
+            ref.ref_tt_insert(b, lo, hi, bound, depth, score, move)
+        elif action < 0.47:
+            oracle.ago_solver_new_generation(a)
+            ref.ref_tt_increase_generation(b)
+        else:
+            x, y = oracle.ago_solver_tt_seek(a, lo, hi), ref.ref_tt_seek(b, lo, hi)
+            assert x == y, (step, hex(x), hex(y))
+            checked += 1
+            hits += int((x & 3) != 0)
+    assert checked > 2000 and hits > 500
+    oracle.ago_solver_destroy(a)
+    ref.ref_tt_destroy(b)
+
+
+def test_line_patterns_equal_reference(oracle, ref):
+    """RawPatternCalculator (line bit-boards, incremental add / undo, 11- and 13-cell windows) and isStraightFourAt"""
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    rng = np.random.default_rng(5)
+    for n in (15, 20, 9):
+        for trial in range(20):
+            board = np.zeros(n * n, np.uint8)
+            stones = rng.permutation(n * n)[:int(rng.integers(0, n * n // 2))]
+            board[stones] = rng.integers(1, 3, len(stones))
+            cur, moves, done = board.copy(), [], []
+            for _ in range(30):
+                if done and rng.random() < 0.3:
+                    moves.append(0)
+                    cur[done.pop()] = 0
+                else:
+                    cell = int(rng.choice(np.flatnonzero(cur == 0)))
+                    s = int(rng.integers(1, 3))
+                    moves.append(s | ((cell // n) << 2) | ((cell % n) << 9))
+                    done.append(cell)
+                    cur[cell] = s
+            mv = np.array(moves, np.uint16)
+            a, b = np.zeros(n * n * 8, np.uint32), np.zeros(n * n * 8, np.uint32)
+            oracle.ago_raw_patterns(n, n, p(board), p(mv), len(mv), p(a))
+            ref.ref_raw_patterns(n, p(board), p(mv), len(mv), p(b))
+            assert np.array_equal(a, b), (n, trial)
+            for _ in range(40):
+                cell = int(rng.choice(np.flatnonzero(cur == 0)))
+                d = int(rng.integers(0, 4))
+                assert oracle.ago_is_straight_four(n, n, p(cur), cell // n, cell % n, d) == ref.ref_is_straight_four(n, p(cur), cell // n, cell % n, d)
+    # a position where the answer is yes: X X . X on a row, playing the gap
+    row = np.zeros(15 * 15, np.uint8)
+    row[7 * 15 + 3] = row[7 * 15 + 4] = row[7 * 15 + 6] = 1
+    assert ref.ref_is_straight_four(15, p(row), 7, 5, 0) == 1 and oracle.ago_is_straight_four(15, 15, p(row), 7, 5, 0) == 1
+
+
+def test_threat_lists_equal_reference(oracle, ref):
+    """ThreatHistogram: push-back add, first-match swap-with-last remove (the AVX2 search of the reference included): the ORDER of
+    every list after long random add / remove sequences"""
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    rng = np.random.default_rng(8)
+    for trial in range(30):
+        present = {t: [] for t in range(10)}
+        ops = []
+        for _ in range(int(rng.integers(10, 600))):
+            t = int(rng.integers(0, 10))
+            if present[t] and rng.random() < 0.45:
+                r, c = present[t].pop(int(rng.integers(0, len(present[t]))))
+                ops += [0, t, r, c]
+            else:
+                r, c = int(rng.integers(0, 20)), int(rng.integers(0, 20))
+                if (r, c) in present[t]:
+                    continue
+                if t != 0:
+                    present[t].append((r, c))
+                ops += [1, t, r, c]
+        arr = np.array(ops, np.int32)
+        a, b = np.zeros(4096, np.int16), np.zeros(4096, np.int16)
+        na = oracle.ago_threat_histogram(p(arr), len(ops) // 4, p(a))
+        nb = ref.ref_threat_histogram(p(arr), len(ops) // 4, p(b))
+        assert na == nb and np.array_equal(a[:na], b[:nb]), trial
