@@ -508,6 +508,12 @@ def test_native_cpp_driver_over_the_c_abi(agx_lib):
     assert out.returncode == 0, out.stderr
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["simulations_per_sec"] > 0 and line["network_evaluations"] > 0
+    # the long-running shape: balanced openings from the device generator, pvq network, symmetries, draining and refilling
+    out = subprocess.run([exe, "--games", "8", "--steps", "400", "--warmup", "2", "--sims", "20", "--batch", "8", "--blocks", "2", "--filters", "64",
+                          "--balanced-openings", "1", "--drain-every", "20", "--pvq", "1", "--symmetries", "1"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["samples_drained"] > 50 and line["games_finished"] > 4 and line["opening_refills"] >= 1
     bad = subprocess.run([exe, "--filters", "96", "--steps", "1"], capture_output=True, text=True, timeout=300)
     assert bad.returncode == 1 and "unsupported network" in bad.stderr   # errors surface as exceptions with the library's message
 
