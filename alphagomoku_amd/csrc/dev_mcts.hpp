@@ -133,7 +133,7 @@ namespace agx
 		}
 
 		/* PUCTSelector::select without root noise (EdgeSelector.cpp:1123-1166) */
-		__device__ inline int select_edge(const EngineDev &E, const DNode &nd, const DEdge *edges, int lane, unsigned long long &edge_reads)
+		__device__ inline int select_edge(const EngineDev &E, const DNode &nd, const DEdge *edges, int lane, unsigned long long &edge_reads, const float *noisy_priors)
 		{
 			const int total = nd.visits + nd.vl;
 			float c_puct = E.c_puct;
@@ -182,7 +182,8 @@ namespace agx
 							else if (e.visits > 0)
 								Q = expectation * vl_factor;
 						}
-						const float U = e.prior * parent_sqrt_visit / (1.0f + e.visits + vl);
+						const float prior = (noisy_priors != nullptr) ? noisy_priors[i] : e.prior; // find_best_edge_impl<Op, UseNoise> (:562-586)
+						const float U = prior * parent_sqrt_visit / (1.0f + e.visits + vl);
 						value = Q + U;
 						break;
 					}

@@ -53,6 +53,38 @@ namespace
 			const int sims = (root < 0) ? 0 : nodes[root].visits;
 			if (sims > E.max_sims)
 				break;
+			if (E.noise_type != 0 && root >= 0 && !gs.noise_ready && nodes[root].n_edges > 0)
+			{ // PUCTSelector::select's lazy noise initialisation on the first visit of an expanded root (EdgeSelector.cpp:1127-1137)
+				if (lane == 0)
+				{
+					const DNode rn = nodes[root];
+					float *out = E.noise + static_cast<size_t>(g) * E.hw;
+					const u64 base = E.noise_seed ^ (static_cast<u64>(static_cast<uint32_t>(gs.opening_id)) << 32) ^ (static_cast<u64>(static_cast<uint32_t>(gs.n_moves)) << 20);
+					uint32_t k = 0;
+					float sum = 0.0f;
+					for (int i = 0; i < rn.n_edges; i++)
+					{ // createCustomNoise (utils/random.cpp:89-100)
+						const float u = static_cast<float>(symmetry_mix(base ^ k++) >> 40) * (1.0f / 16777216.0f);
+						double p = static_cast<double>(u);
+						p = p * p;
+						p = p * p;
+						out[i] = static_cast<float>(p * static_cast<double>(1.0f - sum));
+						sum += out[i];
+					}
+					for (int i = rn.n_edges - 1; i > 0; i--)
+					{
+						const int j = static_cast<int>(static_cast<uint32_t>(symmetry_mix(base ^ k++) >> 32) % static_cast<uint32_t>(i + 1));
+						const float tmp = out[i];
+						out[i] = out[j];
+						out[j] = tmp;
+					}
+					for (int i = 0; i < rn.n_edges; i++) // applyCustomNoise (EdgeSelector.cpp:602-608)
+						out[i] = (1.0f - E.noise_weight) * edges[rn.edge_begin + i].prior + E.noise_weight * out[i];
+					gs.noise_ready = 1;
+				}
+				__threadfence_block();
+				__syncthreads();
+			}
 			DTask &t = E.tasks[static_cast<size_t>(g) * E.batch + n_tasks];
 			n_tasks++;
 			// SearchTask::set (SearchTask.cpp:32-50)
@@ -74,7 +106,7 @@ namespace
 					break;
 				}
 				const DNode nd = nodes[node];
-				const int e = select_edge(E, nd, edges, lane, st_edges);
+				const int e = select_edge(E, nd, edges, lane, st_edges, (node == root && gs.noise_ready) ? E.noise + static_cast<size_t>(g) * E.hw : nullptr);
 				st_levels++;
 				const uint32_t mv = edges[e].move;
 				const int s = mv & 3, cell = ((mv >> 2) & 127) * n + ((mv >> 9) & 127);
@@ -770,6 +802,7 @@ namespace
 			gs.solve_pending = 0;
 			gs.nn_queued = 0;
 			gs.restart_id = 0;
+			gs.noise_ready = 0;
 			gs.generation = (gs.generation + 1) % 64; // prepare_search -> increaseGeneration
 			gs.opening_id = id;
 			gs.active = 1;
@@ -938,6 +971,7 @@ namespace
 			gs.n_moves++;
 			gs.sign_to_move = 3 - s;
 			gs.need_move = 0;
+			gs.noise_ready = 0; // prepare_search creates a fresh selector for the next move (GameGenerator.cpp:181-183)
 			gs.stats[8]++;
 			atomicAdd(&E.counters[5], 1);
 			bool win = false;
@@ -1351,6 +1385,9 @@ int agx_engine_default_config(AgxEngineConfig *cfg)
 	cfg->use_symmetries = 0;
 	cfg->symmetry_seed = 0x5DEECE66Dull;
 	cfg->action_values = 0;
+	cfg->noise_type = 0;
+	cfg->noise_weight = 0.0f;
+	cfg->noise_seed = 0x2545F4914F6CDD1Dull;
 	return AGX_OK;
 }
 
@@ -1364,6 +1401,8 @@ int agx_engine_create(const AgxEngineConfig *cfg, AgxEngine **out)
 	AGX_REQUIRE(cfg->init_to >= 0 && cfg->init_to <= 3, AGX_ERR_INVALID, "agx_engine_create: init_to must be 0..3");
 	AGX_REQUIRE(cfg->solver_yield_fraction >= 0.0f && cfg->solver_yield_fraction <= 1.0f, AGX_ERR_INVALID, "agx_engine_create: solver_yield_fraction must be in [0, 1]");
 	AGX_REQUIRE(cfg->final_selector >= 0 && cfg->final_selector <= 4, AGX_ERR_INVALID, "agx_engine_create: final_selector must be 0..4");
+	AGX_REQUIRE(cfg->noise_type == 0 || cfg->noise_type == 1, AGX_ERR_UNSUPPORTED, "agx_engine_create: noise_type must be 0 (none) or 1 (custom)");
+	AGX_REQUIRE(cfg->noise_weight >= 0.0f && cfg->noise_weight <= 1.0f, AGX_ERR_INVALID, "agx_engine_create: noise_weight must be in [0, 1]");
 
 	AgxEngine *e = new AgxEngine();
 	e->cfg = *cfg;
@@ -1387,6 +1426,9 @@ int agx_engine_create(const AgxEngineConfig *cfg, AgxEngine **out)
 	d.final_selector = cfg->final_selector;
 	d.use_symmetries = cfg->use_symmetries;
 	d.symmetry_seed = cfg->symmetry_seed;
+	d.noise_type = (cfg->noise_weight > 0.0f) ? cfg->noise_type : 0;
+	d.noise_weight = cfg->noise_weight;
+	d.noise_seed = cfg->noise_seed;
 	const size_t buckets = round_pow2(std::max<size_t>(cfg->tss_table_entries, 4)) / 4;
 	d.tt_bucket_mask = buckets - 1;
 	d.zobrist_seed = cfg->zobrist_seed;
@@ -1429,6 +1471,7 @@ int agx_engine_create(const AgxEngineConfig *cfg, AgxEngine **out)
 	AGX_TRY(dev_alloc(e, &d.nn_value, G * d.batch * 3));
 	d.has_q = cfg->action_values ? 1 : 0;
 	AGX_TRY(dev_alloc(e, &d.nn_q, d.has_q ? G * d.batch * d.hw * 2 : 1));
+	AGX_TRY(dev_alloc(e, &d.noise, d.noise_type ? G * d.hw : 1));
 	AGX_TRY(dev_alloc(e, &d.nn_list, G * d.batch));
 	AGX_TRY(dev_alloc(e, &d.counters, 64));
 	AGX_TRY(dev_alloc(e, &d.records, static_cast<size_t>(d.record_cap)));

@@ -102,6 +102,8 @@ namespace agx
 			int32_t solve_pos;     // first task of the batch that still has to be solved (solver launches may yield between tasks)
 			int32_t solve_pending; // 1 while the batch is only partly solved: the game sits out select / network / expand until it is done
 			int32_t nn_queued;     // positions handed to the network so far in this game (index of the symmetry hash)
+			int32_t noise_ready;   // 1 once the root noise of the current move has been drawn (a fresh selector per move in the reference)
+			int32_t pad;
 			int32_t restart_id;    // 0: playing; -1: the game is over and waits for an opening; k > 0: it starts again from opening k - 1 in k_restart
 			uint64_t root_hash;
 			uint64_t cboard[BWORDS];
@@ -149,6 +151,10 @@ namespace agx
 			int yield_counter;    // index into counters[] of the launch's "games done" count
 			int final_selector, use_symmetries;
 			unsigned long long symmetry_seed;
+			int noise_type;
+			float noise_weight;
+			unsigned long long noise_seed;
+			float *noise;          // [game][hw] noisy root priors of the current move
 			int g0;          // first game handled by this launch (a launch covers games [g0, g0 + gridDim.x): one "group" of the pool)
 			int nn_counter;  // index into counters[] of this group's scheduled-position count
 			// state

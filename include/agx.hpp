@@ -101,6 +101,8 @@ namespace agx
 			float exploration_constant = 1.25f;
 			float exploration_scaling = 0.0f;
 			std::string init_to = "q_head";
+			std::string noise_type = "none";      // EdgeSelectorConfig::noise_type: "none" or "custom"
+			float noise_weight = 0.0f;
 			float policy_expansion_threshold = 1.0e-4f;
 			float information_leak_threshold = 0.01f;
 			int tss_max_positions = 100;
@@ -149,6 +151,11 @@ namespace agx
 				c.information_leak_threshold = selfplay.search_config.information_leak_threshold;
 				c.tss_max_positions = selfplay.search_config.tss_max_positions;
 				c.tss_table_entries = selfplay.search_config.tss_table_entries;
+				const std::string &noise = selfplay.search_config.noise_type;
+				if (noise != "none" && noise != "custom")
+					throw std::logic_error("GeneratorPool: noise_type '" + noise + "' is not provided (none, custom)");
+				c.noise_type = (noise == "custom") ? 1 : 0;
+				c.noise_weight = selfplay.search_config.noise_weight;
 				c.final_selector = final_selector_id(selfplay.final_selector);
 				c.use_symmetries = selfplay.use_symmetries ? 1 : 0;
 				c.action_values = (selfplay.network_outputs == "pvq") ? 1 : 0;

@@ -46,6 +46,9 @@ struct AgoSearchConfig
 		int final_selector;
 		int use_symmetries;
 		uint64_t symmetry_seed;
+		int noise_type;
+		float noise_weight;
+		uint64_t noise_seed;
 };
 
 static SearchConfig convert(const AgoSearchConfig *c)
@@ -65,6 +68,9 @@ static SearchConfig convert(const AgoSearchConfig *c)
 	s.final_selector = c->final_selector;
 	s.use_symmetries = c->use_symmetries;
 	s.symmetry_seed = c->symmetry_seed;
+	s.noise_type = c->noise_type;
+	s.noise_weight = c->noise_weight;
+	s.noise_seed = c->noise_seed;
 	return s;
 }
 

@@ -116,11 +116,22 @@ namespace ago
 		else if (scfg.init_to == 2)
 			initial_q = 0.5f;
 
+		const bool use_noise = (node == root) && scfg.noise_type == 1 && scfg.noise_weight > 0.0f; // EdgeSelector.cpp:1127-1137
+		if (use_noise && noisy_policy.empty())
+		{
+			std::vector<float> priors(n.n_edges);
+			for (int i = 0; i < n.n_edges; i++)
+				priors[i] = edges[n.edge_begin + i].prior;
+			noisy_policy.resize(n.n_edges);
+			custom_root_noise(scfg.noise_seed, noise_serial, noise_move, scfg.noise_weight, priors.data(), n.n_edges, noisy_policy.data());
+		}
+
 		int best = -1;
 		float best_value = std::numeric_limits<float>::lowest();
 		for (int i = 0; i < n.n_edges; i++)
 		{
 			const Edge &e = edges[n.edge_begin + i];
+			const float policy_prior = use_noise ? noisy_policy[i] : e.prior; // find_best_edge_impl<Op, UseNoise> (:562-586)
 			float value;
 			switch (e.score.pv())
 			{
@@ -149,7 +160,7 @@ namespace ago
 						else if (e.visits > 0)
 							Q = e.value.expectation() * vl_factor;
 					}
-					const float U = e.prior * parent_sqrt_visit / (1.0f + e.visits + e.vl());
+					const float U = policy_prior * parent_sqrt_visit / (1.0f + e.visits + e.vl());
 					value = Q + U;
 					break;
 				}
@@ -584,6 +595,9 @@ namespace ago
 	{ // GameGenerator.cpp:174-185
 		search.cleanup(tree);
 		tree.set_board(board.data(), sign_to_move);
+		tree.noisy_policy.clear(); // a fresh EdgeSelector per move (GameGenerator.cpp:181-183)
+		tree.noise_serial = serial;
+		tree.noise_move = static_cast<int>(moves.size());
 		search.solver.increase_generation();
 	}
 	int Game::step_select(std::vector<uint32_t> &features_out)

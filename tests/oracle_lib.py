@@ -18,12 +18,15 @@ class AgoSearchConfig(ctypes.Structure):
                 ("policy_expansion_threshold", ctypes.c_float), ("information_leak_threshold", ctypes.c_float),
                 ("tss_max_positions", ctypes.c_int), ("tss_table_entries", ctypes.c_uint64),
                 ("max_simulations", ctypes.c_int), ("zobrist_seed", ctypes.c_uint64),
-                ("final_selector", ctypes.c_int), ("use_symmetries", ctypes.c_int), ("symmetry_seed", ctypes.c_uint64)]
+                ("final_selector", ctypes.c_int), ("use_symmetries", ctypes.c_int), ("symmetry_seed", ctypes.c_uint64),
+                ("noise_type", ctypes.c_int), ("noise_weight", ctypes.c_float), ("noise_seed", ctypes.c_uint64)]
 
 
-def default_search_config(max_batch_size=8, max_simulations=400, table_entries=1 << 16, final_selector=0, use_symmetries=0):
+def default_search_config(max_batch_size=8, max_simulations=400, table_entries=1 << 16, final_selector=0, use_symmetries=0, noise_type=0,
+                          noise_weight=0.0):
     return AgoSearchConfig(max_batch_size, 1.25, 0.0, 0, 2 ** 31 - 1, 1.0e-4, 0.01, 100, table_entries,
-                           max_simulations, 0x9E3779B97F4A7C15, final_selector, use_symmetries, 0x5DEECE66D)
+                           max_simulations, 0x9E3779B97F4A7C15, final_selector, use_symmetries, 0x5DEECE66D, noise_type, noise_weight,
+                           0x2545F4914F6CDD1D)
 
 
 _lib = None
