@@ -1783,8 +1783,11 @@ namespace agx
 					const uint32_t mv = act_get(sh, act, f.base + f.i) & 0xFFFFu;
 					act_set(sh, act, f.base + f.i, mv | (s_invert_up(value) << 16));
 					const int cell = ((mv >> 2) & 127) * n + ((mv >> 9) & 127);
-					hash_lo ^= zobrist_word(zseed, 2 * (2 * cell + ((mv & 3) - 1)));
-					hash_hi ^= zobrist_word(zseed, 2 * (2 * cell + ((mv & 3) - 1)) + 1);
+					{ // the key index is wave-uniform: in an SGPR the splitmix64 rounds run on the scalar unit
+						const uint32_t zi = __builtin_amdgcn_readfirstlane(2 * (2 * cell + ((mv & 3) - 1)));
+						hash_lo ^= zobrist_word(zseed, zi);
+						hash_hi ^= zobrist_word(zseed, zi + 1);
+					}
 					phase = 3; // post-child bookkeeping
 				}
 #ifdef AGX_SOLVER_PROFILE
@@ -1821,15 +1824,24 @@ namespace agx
 									idx = j;
 								}
 							}
-							for (int o = 32; o > 0; o >>= 1)
-							{
-								const uint32_t b2 = static_cast<uint32_t>(__shfl_xor(static_cast<int>(best), o));
-								const int i2 = __shfl_xor(idx, o);
-								if (i2 != 0x7FFFFFFF && (idx == 0x7FFFFFFF || b2 > best || (b2 == best && i2 < idx)))
+							{ // wave-wide (largest score, lowest index) by ballots: a bitwise radix pass over the 16 score bits, then — only when a
+							  // lane holds more than one action — over the index bits; no cross-lane data movement until the final read
+								bool alive = (idx != 0x7FFFFFFF);
+								for (int b = 15; b >= 0; b--)
 								{
-									best = b2;
-									idx = i2;
+									const bool bit = alive && ((best >> b) & 1u);
+									if (__ballot(bit) != 0)
+										alive = bit;
 								}
+								if (f.size - f.i > 64)
+									for (int b = 9; b >= 0; b--)
+									{
+										const bool zero = alive && (((idx >> b) & 1) == 0);
+										if (__ballot(zero) != 0)
+											alive = zero;
+									}
+								const int winner = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(__ballot(alive))) - 1);
+								idx = __builtin_amdgcn_readlane(idx, winner);
 							}
 							if (idx != f.i)
 							{
@@ -1850,8 +1862,9 @@ namespace agx
 							{
 								const uint32_t mv = a & 0xFFFFu;
 								const int cell = ((mv >> 2) & 127) * n + ((mv >> 9) & 127);
-								hash_lo ^= zobrist_word(zseed, 2 * (2 * cell + ((mv & 3) - 1)));
-								hash_hi ^= zobrist_word(zseed, 2 * (2 * cell + ((mv & 3) - 1)) + 1);
+								const uint32_t zi = __builtin_amdgcn_readfirstlane(2 * (2 * cell + ((mv & 3) - 1)));
+								hash_lo ^= zobrist_word(zseed, zi);
+								hash_hi ^= zobrist_word(zseed, zi + 1);
 								f.move = static_cast<uint16_t>(mv);
 								sh.frames[level] = f;
 								Frame child;
