@@ -832,15 +832,24 @@ namespace agx
 
 		/* The action stack: entries [0, ACT_LDS) live in LDS, deeper ones (a full board of candidate moves on top of a long
 		 * forced line) in the per-game HBM spill area. */
-		__device__ __forceinline__ uint32_t act_get(const SolverShared &sh, const uint32_t *spill, int i) { return (i < ACT_LDS) ? sh.act[i] : spill[i]; }
+		/* The action stack lives in LDS; only its tail (index >= ACT_LDS, rare) spills to HBM.  The two paths must stay two different
+		 * instructions (hence the inline assembly): as plain C++ hipcc merges them into a FLAT load / store with a selected address, and a FLAT
+		 * access to LDS costs a full vector-memory round trip on every action read (2300 cycles per move pick, measured). */
+		__device__ __forceinline__ uint32_t act_get(const SolverShared &sh, const uint32_t *spill, int i)
+		{
+			if (__builtin_expect(i < ACT_LDS, 1))
+				return sh.act[i];
+			uint32_t v;
+			asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(spill + i) : "memory");
+			return v;
+		}
 		__device__ __forceinline__ void act_set(SolverShared &sh, uint32_t *spill, int i, uint32_t v)
 		{
-			if (i < ACT_LDS)
+			if (__builtin_expect(i < ACT_LDS, 1))
 				sh.act[i] = v;
 			else
-				spill[i] = v;
+				asm volatile("global_store_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : : "v"(spill + i), "v"(v) : "memory");
 		}
-		/* first index in [begin, end) whose move field equals `move`, or -1 (all lanes call) */
 		__device__ __forceinline__ int act_find_move(const SolverShared &sh, const uint32_t *spill, int begin, int end, uint32_t move, int lane)
 		{
 			for (int base = begin; base < end; base += 64)
@@ -1671,6 +1680,7 @@ namespace agx
 		__device__ __forceinline__ int solver_run(SolverShared &sh, const EngineDev &E, uint32_t *act, u64 *tt, int generation, int lane, u64 &pf_word)
 		{ // executed by ALL lanes with identical (wave-uniform) state: stores are same-address / same-value, scans are lane-parallel.
 		  // The scalars of the machine and the current frame are held in registers and written back to LDS only when the machine yields.
+			AGX_PROF_BEGIN();
 			const u64 zseed = E.zobrist_seed;
 			const int n = E.n;
 			int phase = sh.phase, level = sh.level;
@@ -1678,6 +1688,7 @@ namespace agx
 			u64 hash_lo = sh.hash_lo, hash_hi = sh.hash_hi;
 			uint32_t value = static_cast<uint32_t>(sh.pending_value);
 			Frame f = sh.frames[level];
+			AGX_PROF_MARK(sh, 15); // resume: machine state back into registers
 			auto yield = [&](int cmd, int move)
 			{
 				sh.phase = phase;
@@ -1695,7 +1706,9 @@ namespace agx
 			while (true)
 			{
 				bool returning = false;
+				AGX_PROF_COUNT(sh, 21, 1);
 #ifdef AGX_SOLVER_PROFILE
+				agx_pt_ = clock64();
 				const unsigned long long p0 = wall_clock64();
 				unsigned long long p1 = p0, p2 = p0;
 #endif
@@ -1789,9 +1802,11 @@ namespace agx
 						hash_hi ^= zobrist_word(zseed, zi + 1);
 					}
 					phase = 3; // post-child bookkeeping
+					AGX_PROF_MARK(sh, 20); // child returned: score write-back + hash
 				}
 #ifdef AGX_SOLVER_PROFILE
 				const unsigned long long p3 = wall_clock64();
+				agx_pt_ = clock64();
 #endif
 				if (!returning && phase == 2)
 				{ // ---- pick the next action (:253-266) ----
@@ -1850,6 +1865,8 @@ namespace agx
 								act_set(sh, act, f.base + idx, t);
 							}
 						}
+						AGX_PROF_MARK(sh, 16); // pick: table move or first maximum, swap to the front
+						AGX_PROF_COUNT(sh, 22, 1);
 						const uint32_t a = act_get(sh, act, f.base + f.i);
 						if (s_unproven(a >> 16) && node_counter < E.tss_max_nodes)
 						{ // descend (:268-298)
@@ -1889,6 +1906,7 @@ namespace agx
 									pf_word = tt[8 * (hash_lo & E.tt_bucket_mask) + lane];
 								sh.pf_lo = hash_lo;
 								sh.pf_valid = 1;
+								AGX_PROF_MARK(sh, 17); // descend: frames, hash, prefetch
 #ifdef AGX_SOLVER_PROFILE
 								sh.prof[2] += wall_clock64() - p3; // ordering + descend bookkeeping
 #endif

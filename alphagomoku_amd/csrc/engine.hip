@@ -1722,6 +1722,8 @@ int agx_engine_stats(AgxEngine *e, AgxEngineStats *out)
 		const double solves = static_cast<double>(p[5]);
 		fprintf(stderr, "[generate(), shader cycles per solve; %.1f calls] win1 %.0f, loss2 %.0f, win3 %.0f, loss4 %.0f, win5 %.0f, loss6 %.0f, half4 %.0f, rest %.0f\n",
 				dp[8] / solves, dp[0] / solves, dp[1] / solves, dp[2] / solves, dp[3] / solves, dp[4] / solves, dp[5] / solves, dp[6] / solves, dp[7] / solves);
+		fprintf(stderr, "[frame machine, shader cycles per solve; %.1f loop turns, %.1f picks] resume %.0f, pick %.0f, descend %.0f, child-returned %.0f\n",
+				dp[21] / solves, dp[22] / solves, dp[15] / solves, dp[16] / solves, dp[17] / solves, dp[20] / solves);
 		fprintf(stderr, "[update_around, shader cycles per solve; %.1f calls, %.2f list changes per call] centre %.0f, gather %.0f, lists %.0f\n",
 				dp[14] / solves, dp[13] / (dp[14] ? static_cast<double>(dp[14]) : 1.0), dp[10] / solves, dp[11] / solves, dp[12] / solves);
 	}
