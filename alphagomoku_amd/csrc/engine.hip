@@ -21,6 +21,7 @@
 #include "dev_mcts.hpp"
 #include "tables_host.hpp"
 #include "renju_static.hpp"
+#include "root_noise.hpp"
 
 #include <vector>
 #include <cstring>
@@ -58,28 +59,9 @@ namespace
 				if (lane == 0)
 				{
 					const DNode rn = nodes[root];
-					float *out = E.noise + static_cast<size_t>(g) * E.hw;
-					const u64 base = E.noise_seed ^ (static_cast<u64>(static_cast<uint32_t>(gs.opening_id)) << 32) ^ (static_cast<u64>(static_cast<uint32_t>(gs.n_moves)) << 20);
-					uint32_t k = 0;
-					float sum = 0.0f;
-					for (int i = 0; i < rn.n_edges; i++)
-					{ // createCustomNoise (utils/random.cpp:89-100)
-						const float u = static_cast<float>(symmetry_mix(base ^ k++) >> 40) * (1.0f / 16777216.0f);
-						double p = static_cast<double>(u);
-						p = p * p;
-						p = p * p;
-						out[i] = static_cast<float>(p * static_cast<double>(1.0f - sum));
-						sum += out[i];
-					}
-					for (int i = rn.n_edges - 1; i > 0; i--)
-					{
-						const int j = static_cast<int>(static_cast<uint32_t>(symmetry_mix(base ^ k++) >> 32) % static_cast<uint32_t>(i + 1));
-						const float tmp = out[i];
-						out[i] = out[j];
-						out[j] = tmp;
-					}
-					for (int i = 0; i < rn.n_edges; i++) // applyCustomNoise (EdgeSelector.cpp:602-608)
-						out[i] = (1.0f - E.noise_weight) * edges[rn.edge_begin + i].prior + E.noise_weight * out[i];
+					const DEdge *root_edges = edges + rn.edge_begin;
+					make_root_noise(E.noise_type, E.noise_weight, E.noise_seed, gs.opening_id, gs.n_moves, rn.n_edges, [&](int i) { return root_edges[i].prior; },
+							E.noise + static_cast<size_t>(g) * E.hw);
 					gs.noise_ready = 1;
 				}
 				__threadfence_block();
@@ -1401,7 +1383,7 @@ int agx_engine_create(const AgxEngineConfig *cfg, AgxEngine **out)
 	AGX_REQUIRE(cfg->init_to >= 0 && cfg->init_to <= 3, AGX_ERR_INVALID, "agx_engine_create: init_to must be 0..3");
 	AGX_REQUIRE(cfg->solver_yield_fraction >= 0.0f && cfg->solver_yield_fraction <= 1.0f, AGX_ERR_INVALID, "agx_engine_create: solver_yield_fraction must be in [0, 1]");
 	AGX_REQUIRE(cfg->final_selector >= 0 && cfg->final_selector <= 4, AGX_ERR_INVALID, "agx_engine_create: final_selector must be 0..4");
-	AGX_REQUIRE(cfg->noise_type == 0 || cfg->noise_type == 1, AGX_ERR_UNSUPPORTED, "agx_engine_create: noise_type must be 0 (none) or 1 (custom)");
+	AGX_REQUIRE(cfg->noise_type >= 0 && cfg->noise_type <= 3, AGX_ERR_INVALID, "agx_engine_create: noise_type must be 0 (none), 1 (custom), 2 (dirichlet) or 3 (gumbel)");
 	AGX_REQUIRE(cfg->noise_weight >= 0.0f && cfg->noise_weight <= 1.0f, AGX_ERR_INVALID, "agx_engine_create: noise_weight must be in [0, 1]");
 
 	AgxEngine *e = new AgxEngine();

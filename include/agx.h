@@ -132,11 +132,12 @@ typedef struct AgxEngineConfig
 	                                     randInt(8) from a time-seeded generator; here the k-th position of game `serial` uses
 	                                     splitmix64(symmetry_seed ^ serial << 32 ^ k) >> 61, so runs are reproducible. */
 	uint64_t symmetry_seed;
-	int noise_type;                   /* EdgeSelectorConfig::noise_type at the root: 0 "none", 1 "custom" (createCustomNoise, utils/random.cpp:
-	                                     89-100: u^4 * (1 - sum so far), shuffled; mixed as (1 - w) prior + w noise, EdgeSelector.cpp:602-608).
+	int noise_type;                   /* EdgeSelectorConfig::noise_type at the root: 0 "none", 1 "custom", 2 "dirichlet" (alpha 0.05), 3 "gumbel"
+	                                     (create*Noise, utils/random.cpp:89-124; mixed into the priors as EdgeSelector.cpp:602-623 does).
 	                                     Drawn once per move by the first select that sees an expanded root, like the selector that
 	                                     prepare_search creates per move.  Stream: counter-based hash of (noise_seed, game serial, move
-	                                     number) — the reference uses a time-seeded mt19937.  "dirichlet" / "gumbel" are not provided. */
+	                                     number) — the reference uses a time-seeded mt19937; log / exp are fixed double-precision series
+	                                     (csrc/root_noise.hpp), so runs are reproducible and identical on host and device. */
 	float noise_weight;
 	uint64_t noise_seed;
 	int action_values;                /* 1: the network is a 'pvq' network (AGNetwork::getOutputConfig): agx_engine_evaluate runs its

@@ -101,7 +101,7 @@ namespace agx
 			float exploration_constant = 1.25f;
 			float exploration_scaling = 0.0f;
 			std::string init_to = "q_head";
-			std::string noise_type = "none";      // EdgeSelectorConfig::noise_type: "none" or "custom"
+			std::string noise_type = "none";      // EdgeSelectorConfig::noise_type: "none", "custom", "dirichlet", "gumbel"
 			float noise_weight = 0.0f;
 			float policy_expansion_threshold = 1.0e-4f;
 			float information_leak_threshold = 0.01f;
@@ -152,9 +152,9 @@ namespace agx
 				c.tss_max_positions = selfplay.search_config.tss_max_positions;
 				c.tss_table_entries = selfplay.search_config.tss_table_entries;
 				const std::string &noise = selfplay.search_config.noise_type;
-				if (noise != "none" && noise != "custom")
-					throw std::logic_error("GeneratorPool: noise_type '" + noise + "' is not provided (none, custom)");
-				c.noise_type = (noise == "custom") ? 1 : 0;
+				if (noise != "none" && noise != "custom" && noise != "dirichlet" && noise != "gumbel")
+					throw std::logic_error("GeneratorPool: unknown noise_type '" + noise + "'");
+				c.noise_type = (noise == "custom") ? 1 : ((noise == "dirichlet") ? 2 : ((noise == "gumbel") ? 3 : 0));
 				c.noise_weight = selfplay.search_config.noise_weight;
 				c.final_selector = final_selector_id(selfplay.final_selector);
 				c.use_symmetries = selfplay.use_symmetries ? 1 : 0;

@@ -3,6 +3,7 @@
  * the cpu_baseline leg of bench.py).
  */
 #include "agoracle.hpp"
+#include "ag_noise.hpp"
 
 #include <chrono>
 #include <thread>
@@ -404,6 +405,19 @@ void* ago_game_create(int rules, int rows, int cols, const AgoSearchConfig *cfg)
 void ago_game_destroy(void *h)
 {
 	delete static_cast<GameHandle*>(h);
+}
+/* root noise alone (oracle/ag_noise.hpp): out[i] = noisy prior; also the two series it is built on */
+void ago_root_noise(int type, float weight, uint64_t seed, int serial, int move_number, int n, const float *priors, float *out)
+{
+	make_root_noise(type, weight, seed, serial, move_number, n, [&](int i) { return priors[i]; }, out);
+}
+double ago_det_log(double x)
+{
+	return det_log(x);
+}
+double ago_det_exp(double x)
+{
+	return det_exp(x);
 }
 void ago_game_set_serial(void *h, int serial)
 {

@@ -5,6 +5,7 @@
  * src/selfplay/GameGenerator.cpp.  PARITY UNPINNED by reference tests (test_Tree.cpp etc. are commented out).
  */
 #include "agoracle.hpp"
+#include "ag_noise.hpp"
 
 #include <random>
 
@@ -116,14 +117,15 @@ namespace ago
 		else if (scfg.init_to == 2)
 			initial_q = 0.5f;
 
-		const bool use_noise = (node == root) && scfg.noise_type == 1 && scfg.noise_weight > 0.0f; // EdgeSelector.cpp:1127-1137
+		const bool use_noise = (node == root) && scfg.noise_type != 0 && scfg.noise_weight > 0.0f; // EdgeSelector.cpp:1127-1137
 		if (use_noise && noisy_policy.empty())
 		{
 			std::vector<float> priors(n.n_edges);
 			for (int i = 0; i < n.n_edges; i++)
 				priors[i] = edges[n.edge_begin + i].prior;
 			noisy_policy.resize(n.n_edges);
-			custom_root_noise(scfg.noise_seed, noise_serial, noise_move, scfg.noise_weight, priors.data(), n.n_edges, noisy_policy.data());
+			make_root_noise(scfg.noise_type, scfg.noise_weight, scfg.noise_seed, noise_serial, noise_move, n.n_edges, [&](int i) { return priors[i]; },
+					noisy_policy.data());
 		}
 
 		int best = -1;

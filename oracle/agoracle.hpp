@@ -377,7 +377,7 @@ namespace ago
 			int final_selector = 0;          // GameGenerator::make_move's selector: 0 best, 1 max_visit, 2 min_visit, 3 max_value, 4 max_policy (EdgeSelector.cpp:476-536)
 			int use_symmetries = 0;          // NNEvaluator::addToQueue (NNEvaluator.cpp:134-141): random input symmetry per queued task
 			uint64_t symmetry_seed = 0x5DEECE66Dull; // the reference draws randInt(8) from a time-seeded generator; here a counter-based hash
-			int noise_type = 0;              // EdgeSelectorConfig::noise_type: 0 "none", 1 "custom" (EdgeSelector.cpp:602-608, utils/random.cpp:89-100)
+			int noise_type = 0;              // EdgeSelectorConfig::noise_type: 0 "none", 1 "custom", 2 "dirichlet", 3 "gumbel" (EdgeSelector.cpp:602-623; oracle/ag_noise.hpp)
 			float noise_weight = 0.0f;
 			uint64_t noise_seed = 0x2545F4914F6CDD1Dull;
 	};
@@ -427,33 +427,6 @@ namespace ago
 		z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
 		z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
 		return z ^ (z >> 31);
-	}
-	/* createCustomNoise + applyCustomNoise (utils/random.cpp:89-100, EdgeSelector.cpp:602-608): result[i] = randFloat()^4 * (1 - sum so
-	 * far), shuffled, mixed with the priors.  The reference draws from a time-seeded mt19937; here the stream is a counter-based hash
-	 * of (seed, game serial, move number), the shuffle is a plain Fisher-Yates, and x^4 is two squarings in double precision. */
-	inline void custom_root_noise(uint64_t seed, int serial, int move_number, float weight, const float *priors, int n, float *out)
-	{
-		const uint64_t base = seed ^ (static_cast<uint64_t>(static_cast<uint32_t>(serial)) << 32) ^ (static_cast<uint64_t>(static_cast<uint32_t>(move_number)) << 20);
-		uint32_t k = 0;
-		float sum = 0.0f;
-		for (int i = 0; i < n; i++)
-		{
-			const float u = static_cast<float>(symmetry_mix(base ^ k++) >> 40) * (1.0f / 16777216.0f);
-			double p = static_cast<double>(u);
-			p = p * p;
-			p = p * p;
-			out[i] = static_cast<float>(p * static_cast<double>(1.0f - sum));
-			sum += out[i];
-		}
-		for (int i = n - 1; i > 0; i--)
-		{
-			const int j = static_cast<int>(static_cast<uint32_t>(symmetry_mix(base ^ k++) >> 32) % static_cast<uint32_t>(i + 1));
-			const float t = out[i];
-			out[i] = out[j];
-			out[j] = t;
-		}
-		for (int i = 0; i < n; i++)
-			out[i] = (1.0f - weight) * priors[i] + weight * out[i];
 	}
 	/* symmetry of the k-th position a game hands to the network (k counts from the start of that game) */
 	inline int pick_symmetry(uint64_t seed, int game_serial, int k)

@@ -143,17 +143,17 @@ def _oracle_root(olib, h):
 
 
 def _play_and_compare(olib, rules, games, batch, sims, max_steps, evaluator, table_entries=1 << 16, n=N, final_selector=0, use_symmetries=0,
-                      action_values=0, noise_weight=0.0):
+                      action_values=0, noise_weight=0.0, noise_type=1):
     """evaluator(features uint32 [n][HW]) -> (policy [n][HW] f32, value [n][2] f32 (win, draw)[, q [n][HW][2]]); used for BOTH sides"""
     from alphagomoku_amd import selfplay
     N, HW = n, n * n   # noqa: N806 (shadow the 15x15 module defaults)
     cfg = selfplay.default_config(rules=rules, board_size=n, draw_after=n * n, n_games=games, max_batch_size=batch, max_simulations=sims,
                                   tss_table_entries=table_entries, node_capacity=4096, edge_capacity=65536 if n <= 15 else 131072,
                                   final_selector=final_selector, use_symmetries=use_symmetries, action_values=action_values,
-                                  noise_type=1 if noise_weight > 0 else 0, noise_weight=noise_weight)
+                                  noise_type=noise_type if noise_weight > 0 else 0, noise_weight=noise_weight)
     pool = selfplay.GeneratorPool(cfg)
     ocfg = ol.default_search_config(max_batch_size=batch, max_simulations=sims, table_entries=table_entries, final_selector=final_selector,
-                                    use_symmetries=use_symmetries, noise_type=1 if noise_weight > 0 else 0, noise_weight=noise_weight)
+                                    use_symmetries=use_symmetries, noise_type=noise_type if noise_weight > 0 else 0, noise_weight=noise_weight)
     openings, handles = [], []
     for g in range(games):
         op = np.zeros(64, np.uint16)
@@ -256,11 +256,13 @@ def test_final_move_selectors(agx_lib, olib, selector):
     assert compared > 200 and stats["games_finished"] == 4
 
 
-@pytest.mark.parametrize("rules,weight", [(0, 0.25), (1, 0.5)])
-def test_root_noise(agx_lib, olib, rules, weight):
-    """EdgeSelectorConfig noise_type "custom": the root priors of every move are mixed with u^4-stick-breaking noise, drawn once per
-    move by the first select that sees an expanded root; the games differ from the noise-free ones and match the oracle bit for bit"""
-    compared, stats = _play_and_compare(olib, rules, games=4, batch=4, sims=60, max_steps=4000, evaluator=_stand_in_evaluator(olib), noise_weight=weight)
+@pytest.mark.parametrize("rules,weight,kind", [(0, 0.25, 1), (1, 0.5, 1), (0, 0.25, 2), (2, 0.25, 2), (0, 0.5, 3)])
+def test_root_noise(agx_lib, olib, rules, weight, kind):
+    """EdgeSelectorConfig noise_type "custom" / "dirichlet" / "gumbel": the root priors of every move are mixed with noise drawn
+    once per move by the first select that sees an expanded root; the games differ from the noise-free ones and match the oracle
+    bit for bit (the generators use only IEEE-exact operations, csrc/root_noise.hpp)"""
+    compared, stats = _play_and_compare(olib, rules, games=4, batch=4, sims=60, max_steps=4000, evaluator=_stand_in_evaluator(olib), noise_weight=weight,
+                                        noise_type=kind)
     assert compared > 200 and stats["games_finished"] == 4
     _, plain = _play_and_compare(olib, rules, games=4, batch=4, sims=60, max_steps=4000, evaluator=_stand_in_evaluator(olib))
     assert (plain["moves_played"], plain["evaluated_nodes"]) != (stats["moves_played"], stats["evaluated_nodes"])
