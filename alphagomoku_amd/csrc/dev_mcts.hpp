@@ -14,6 +14,7 @@
 #define AGX_DEV_MCTS_HPP_
 
 #include "dev_solver.hpp"
+#include "root_noise.hpp"
 
 namespace agx
 {
@@ -138,7 +139,7 @@ namespace agx
 			const int total = nd.visits + nd.vl;
 			float c_puct = E.c_puct;
 			if (E.c_scale != 0.0f)
-				c_puct = static_cast<float>(static_cast<double>(E.c_puct) + static_cast<double>(E.c_scale) * log(static_cast<double>(total)));
+				c_puct = static_cast<float>(static_cast<double>(E.c_puct) + static_cast<double>(E.c_scale) * det_log(static_cast<double>(total))); // series log: same bits as the host
 			const float parent_sqrt_visit = static_cast<float>(static_cast<double>(c_puct) * sqrt(static_cast<double>(total)));
 			float initial_q = 0.0f;
 			if (E.init_to == 1)

@@ -109,7 +109,9 @@ namespace ago
 	int Tree::select_edge(int node) const
 	{ // PUCTSelector::select (EdgeSelector.cpp:1123-1166) without root noise; ops PUCT_q_head (:335-361) / PUCT (:389-424)
 		const Node &n = nodes[node];
-		const float c_puct = static_cast<float>(scfg.exploration_constant + scfg.exploration_scaling * std::log(static_cast<double>(n.visits + n.vl)));
+		// std::log in the reference; the series log of ag_noise.hpp (error < 1e-15) is used so that the device can reproduce the bits
+		const float c_puct = (scfg.exploration_scaling == 0.0f) ? scfg.exploration_constant
+				: static_cast<float>(static_cast<double>(scfg.exploration_constant) + static_cast<double>(scfg.exploration_scaling) * det_log(static_cast<double>(n.visits + n.vl)));
 		const float parent_sqrt_visit = static_cast<float>(c_puct * std::sqrt(static_cast<double>(n.visits + n.vl)));
 		float initial_q = 0.0f;
 		if (scfg.init_to == 1)

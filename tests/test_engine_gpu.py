@@ -143,17 +143,19 @@ def _oracle_root(olib, h):
 
 
 def _play_and_compare(olib, rules, games, batch, sims, max_steps, evaluator, table_entries=1 << 16, n=N, final_selector=0, use_symmetries=0,
-                      action_values=0, noise_weight=0.0, noise_type=1):
+                      action_values=0, noise_weight=0.0, noise_type=1, exploration_scaling=0.0):
     """evaluator(features uint32 [n][HW]) -> (policy [n][HW] f32, value [n][2] f32 (win, draw)[, q [n][HW][2]]); used for BOTH sides"""
     from alphagomoku_amd import selfplay
     N, HW = n, n * n   # noqa: N806 (shadow the 15x15 module defaults)
     cfg = selfplay.default_config(rules=rules, board_size=n, draw_after=n * n, n_games=games, max_batch_size=batch, max_simulations=sims,
                                   tss_table_entries=table_entries, node_capacity=4096, edge_capacity=65536 if n <= 15 else 131072,
                                   final_selector=final_selector, use_symmetries=use_symmetries, action_values=action_values,
-                                  noise_type=noise_type if noise_weight > 0 else 0, noise_weight=noise_weight)
+                                  noise_type=noise_type if noise_weight > 0 else 0, noise_weight=noise_weight,
+                                  exploration_scaling=exploration_scaling)
     pool = selfplay.GeneratorPool(cfg)
     ocfg = ol.default_search_config(max_batch_size=batch, max_simulations=sims, table_entries=table_entries, final_selector=final_selector,
                                     use_symmetries=use_symmetries, noise_type=noise_type if noise_weight > 0 else 0, noise_weight=noise_weight)
+    ocfg.exploration_scaling = exploration_scaling
     openings, handles = [], []
     for g in range(games):
         op = np.zeros(64, np.uint16)
@@ -266,6 +268,12 @@ def test_root_noise(agx_lib, olib, rules, weight, kind):
     assert compared > 200 and stats["games_finished"] == 4
     _, plain = _play_and_compare(olib, rules, games=4, batch=4, sims=60, max_steps=4000, evaluator=_stand_in_evaluator(olib))
     assert (plain["moves_played"], plain["evaluated_nodes"]) != (stats["moves_played"], stats["evaluated_nodes"])
+
+
+def test_exploration_scaling(agx_lib, olib):
+    """c_puct = c0 + c1 * ln(N + vl) (EdgeSelector.cpp:1139): the logarithm is the fixed series on both sides"""
+    compared, stats = _play_and_compare(olib, 0, games=4, batch=4, sims=80, max_steps=4000, evaluator=_stand_in_evaluator(olib), exploration_scaling=0.35)
+    assert compared > 200 and stats["games_finished"] == 4
 
 
 @pytest.mark.parametrize("rules,n", [(0, 15), (2, 15), (3, 20)])
