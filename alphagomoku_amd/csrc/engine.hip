@@ -890,6 +890,25 @@ namespace
 				case 4:
 					value = e.prior;
 					break;
+				case 5:
+				{ // LCB (EdgeSelector.cpp:446-475): lower confidence bound on unproven edges, proven ones by distance
+					const int pv = s_pv(e.score);
+					if (pv == 0)
+						value = -1.0e6f + s_distance(e.score) + e.prior;
+					else if (pv == 3)
+						value = +1.0e6f - s_distance(e.score) + e.prior;
+					else
+					{
+						const int vl = e.flag_vl & 0x7FFF;
+						const float visits = 1.0e-8f + e.visits;
+						const float vl_factor = visits / (visits + static_cast<float>(vl));
+						const float Q = (e.visits > 0) ? (e.win + 0.5f * e.draw) : (root.win + 0.5f * root.draw);
+						const float parent_log_visit = static_cast<float>(det_log(static_cast<double>(root.visits + root.vl)));
+						const float U = E.c_puct * sqrtf(parent_log_visit / (1.0f + e.visits + vl));
+						value = Q * vl_factor - U;
+					}
+					break;
+				}
 			}
 			if (value > best_value)
 			{
@@ -1382,7 +1401,7 @@ int agx_engine_create(const AgxEngineConfig *cfg, AgxEngine **out)
 	AGX_REQUIRE(cfg->tss_max_positions >= 1 && cfg->tss_max_positions <= 1000, AGX_ERR_UNSUPPORTED, "agx_engine_create: tss_max_positions must be in [1, 1000]");
 	AGX_REQUIRE(cfg->init_to >= 0 && cfg->init_to <= 3, AGX_ERR_INVALID, "agx_engine_create: init_to must be 0..3");
 	AGX_REQUIRE(cfg->solver_yield_fraction >= 0.0f && cfg->solver_yield_fraction <= 1.0f, AGX_ERR_INVALID, "agx_engine_create: solver_yield_fraction must be in [0, 1]");
-	AGX_REQUIRE(cfg->final_selector >= 0 && cfg->final_selector <= 4, AGX_ERR_INVALID, "agx_engine_create: final_selector must be 0..4");
+	AGX_REQUIRE(cfg->final_selector >= 0 && cfg->final_selector <= 5, AGX_ERR_INVALID, "agx_engine_create: final_selector must be 0..5");
 	AGX_REQUIRE(cfg->noise_type >= 0 && cfg->noise_type <= 3, AGX_ERR_INVALID, "agx_engine_create: noise_type must be 0 (none), 1 (custom), 2 (dirichlet) or 3 (gumbel)");
 	AGX_REQUIRE(cfg->noise_weight >= 0.0f && cfg->noise_weight <= 1.0f, AGX_ERR_INVALID, "agx_engine_create: noise_weight must be in [0, 1]");
 

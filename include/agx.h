@@ -126,7 +126,8 @@ typedef struct AgxEngineConfig
 	                                     rest of this step (network / expand) and resumes in the next one.  Per-game results are
 	                                     unchanged (every game executes the same sequence of operations), only the pacing differs. */
 	int final_selector;               /* GameGenerator::make_move's EdgeSelector (SelfplayConfig::final_selector.policy): 0 "best",
-	                                     1 "max_visit", 2 "min_visit", 3 "max_value", 4 "max_policy" (EdgeSelector.cpp:476-536) */
+	                                     1 "max_visit", 2 "min_visit", 3 "max_value", 4 "max_policy", 5 "lcb" with exploration_constant
+	                                     (EdgeSelector.cpp:446-536) */
 	int use_symmetries;               /* NNEvaluator::useSymmetries (NNEvaluator.cpp:134-141,244-286): every position handed to the network
 	                                     is augmented by one of the 8 board symmetries and the policy is mapped back.  The reference draws
 	                                     randInt(8) from a time-seeded generator; here the k-th position of game `serial` uses

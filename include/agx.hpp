@@ -115,6 +115,7 @@ namespace agx
 		if (policy == "min_visit") return 2;
 		if (policy == "max_value") return 3;
 		if (policy == "max_policy") return 4;
+		if (policy == "lcb") return 5;
 		throw std::logic_error("Unknown selection policy '" + policy + "'");
 	}
 

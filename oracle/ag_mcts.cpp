@@ -215,6 +215,23 @@ namespace ago
 							break;
 					}
 					break;
+				case 5:
+				{ // LCB op (EdgeSelector.cpp:446-475) with the parent value as initial Q; ln by the series of ag_noise.hpp
+					if (e.score.pv() == PV_LOSS)
+						value = -1.0e6f + e.score.distance() + e.prior;
+					else if (e.score.pv() == PV_WIN)
+						value = +1.0e6f - e.score.distance() + e.prior;
+					else
+					{
+						const float visits = 1.0e-8f + e.visits;
+						const float vl_factor = visits / (visits + static_cast<float>(e.vl()));
+						const float Q = (e.visits > 0) ? e.value.expectation() : n.value.expectation();
+						const float parent_log_visit = static_cast<float>(det_log(static_cast<double>(n.visits + n.vl)));
+						const float U = scfg.exploration_constant * std::sqrt(parent_log_visit / (1.0f + e.visits + e.vl()));
+						value = Q * vl_factor - U;
+					}
+					break;
+				}
 				default:
 					value = e.prior;
 					break;

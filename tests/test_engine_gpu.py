@@ -251,9 +251,9 @@ def test_whole_games_bit_exact_with_stand_in_evaluator(agx_lib, olib, rules, bat
     assert stats["games_finished"] == 6 and stats["information_leaks"] > 0 and stats["proven_edge_visits"] > 0
 
 
-@pytest.mark.parametrize("selector", [1, 2, 3, 4])
+@pytest.mark.parametrize("selector", [1, 2, 3, 4, 5])
 def test_final_move_selectors(agx_lib, olib, selector):
-    """GameGenerator::make_move with final_selector max_visit / min_visit / max_value / max_policy instead of "best" """
+    """GameGenerator::make_move with final_selector max_visit / min_visit / max_value / max_policy / lcb instead of "best" """
     compared, stats = _play_and_compare(olib, 0, games=4, batch=4, sims=60, max_steps=4000, evaluator=_stand_in_evaluator(olib), final_selector=selector)
     assert compared > 200 and stats["games_finished"] == 4
 
