@@ -402,6 +402,14 @@ void* ago_game_create(int rules, int rows, int cols, const AgoSearchConfig *cfg)
 {
 	return new GameHandle(make_cfg(rules, rows, cols), convert(cfg));
 }
+/* same with GameConfig::draw_after set (a game is a draw once that many stones are on the board, rules.cpp:129-131) */
+void* ago_game_create_ex(int rules, int rows, int cols, int draw_after, const AgoSearchConfig *cfg)
+{
+	GameConfig c = make_cfg(rules, rows, cols);
+	if (draw_after > 0)
+		c.draw_after = draw_after;
+	return new GameHandle(c, convert(cfg));
+}
 void ago_game_destroy(void *h)
 {
 	delete static_cast<GameHandle*>(h);

@@ -41,7 +41,8 @@ def load():
         lib = ctypes.CDLL(path)
         for name in ["ago_defensive_moves", "ago_open_three_promotion_moves", "ago_score_op", "ago_score_make", "ago_move_to_short"]:
             getattr(lib, name).restype = ctypes.c_uint16
-        for name in ["ago_solver_create", "ago_game_create"]:
+        lib.ago_game_create_ex.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(AgoSearchConfig)]
+        for name in ["ago_solver_create", "ago_game_create", "ago_game_create_ex"]:
             getattr(lib, name).restype = ctypes.c_void_p
         lib.ago_solver_create.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int]
         lib.ago_game_create.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(AgoSearchConfig)]

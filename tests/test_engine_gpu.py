@@ -143,11 +143,11 @@ def _oracle_root(olib, h):
 
 
 def _play_and_compare(olib, rules, games, batch, sims, max_steps, evaluator, table_entries=1 << 16, n=N, final_selector=0, use_symmetries=0,
-                      action_values=0, noise_weight=0.0, noise_type=1, exploration_scaling=0.0):
+                      action_values=0, noise_weight=0.0, noise_type=1, exploration_scaling=0.0, draw_after=0):
     """evaluator(features uint32 [n][HW]) -> (policy [n][HW] f32, value [n][2] f32 (win, draw)[, q [n][HW][2]]); used for BOTH sides"""
     from alphagomoku_amd import selfplay
     N, HW = n, n * n   # noqa: N806 (shadow the 15x15 module defaults)
-    cfg = selfplay.default_config(rules=rules, board_size=n, draw_after=n * n, n_games=games, max_batch_size=batch, max_simulations=sims,
+    cfg = selfplay.default_config(rules=rules, board_size=n, draw_after=draw_after if draw_after > 0 else n * n, n_games=games, max_batch_size=batch, max_simulations=sims,
                                   tss_table_entries=table_entries, node_capacity=4096, edge_capacity=65536 if n <= 15 else 131072,
                                   final_selector=final_selector, use_symmetries=use_symmetries, action_values=action_values,
                                   noise_type=noise_type if noise_weight > 0 else 0, noise_weight=noise_weight,
@@ -161,7 +161,7 @@ def _play_and_compare(olib, rules, games, batch, sims, max_steps, evaluator, tab
         op = np.zeros(64, np.uint16)
         k = olib.ago_prepare_opening(rules, N, N, 100 + g, ol.ptr(op))
         openings.append([int(x) for x in op[:k]])
-        h = olib.ago_game_create(rules, N, N, ctypes.byref(ocfg))
+        h = olib.ago_game_create_ex(rules, N, N, draw_after, ctypes.byref(ocfg))
         olib.ago_game_set_serial(h, g)   # the device keys the symmetry hash by the opening id
         olib.ago_game_begin(h, ol.ptr(op), k)
         handles.append(h)
@@ -268,6 +268,14 @@ def test_root_noise(agx_lib, olib, rules, weight, kind):
     assert compared > 200 and stats["games_finished"] == 4
     _, plain = _play_and_compare(olib, rules, games=4, batch=4, sims=60, max_steps=4000, evaluator=_stand_in_evaluator(olib))
     assert (plain["moves_played"], plain["evaluated_nodes"]) != (stats["moves_played"], stats["evaluated_nodes"])
+
+
+@pytest.mark.parametrize("rules,draw_after", [(0, 28), (2, 40)])
+def test_short_draw_limit(agx_lib, olib, rules, draw_after):
+    """GameConfig::draw_after far below the board size: most games end as draws, the solver's distance-to-draw stages
+    (MoveGenerator.cpp:159-223) and the draw-rate reduction of the playout budget (misc.cpp:171-179) are exercised"""
+    compared, stats = _play_and_compare(olib, rules, games=6, batch=4, sims=60, max_steps=4000, evaluator=_stand_in_evaluator(olib), draw_after=draw_after)
+    assert compared > 100 and stats["games_finished"] == 6
 
 
 def test_exploration_scaling(agx_lib, olib):
