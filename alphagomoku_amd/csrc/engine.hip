@@ -454,6 +454,7 @@ namespace
 		__shared__ float e_prior[MAXHW], e_win[MAXHW], e_draw[MAXHW];
 		__shared__ uint16_t e_move[MAXHW], e_score[MAXHW];
 		__shared__ float sh_sum;
+		__shared__ u64 sort_keys[512]; // prune_weak_moves with max_children: (score band, prior, original index) of every edge
 		const int g = E.g0 + blockIdx.x, lane = threadIdx.x;
 		GameState &gs = E.games[g];
 		if (!gs.active || gs.error != 0 || gs.outcome != 0 || gs.solve_pending)
@@ -536,6 +537,81 @@ namespace
 						kept += __popcll(m);
 						__syncthreads();
 					}
+					n_e = kept;
+				}
+				else if (path_len > 0 && n_e > E.max_children && (flags & TF_MUST_DEFEND) == 0)
+				{ // prune_weak_moves, unproven branch (:69-83): the max_children best edges by EdgeComparator<MaxPolicyPrior>
+				  // (Edge.hpp:156-172: proven scores first, then prior), then those whose prior reaches threshold * (their prior sum).
+				  // std::partial_sort leaves the order of equal keys unspecified; here (and in the oracle) equal keys keep edge order.
+					for (int i = lane; i < 512; i += 64)
+					{
+						u64 key = 0;
+						if (i < n_e)
+						{
+							const uint32_t sc = e_score[i];
+							const u64 band = s_proven(sc) ? sc : 0x4000u; // every unproven score shares one band between DRAW and WIN
+							key = (band << 48) | (static_cast<u64>(__float_as_uint(e_prior[i])) << 16) | static_cast<u64>(0xFFFF - i);
+						}
+						sort_keys[i] = key;
+					}
+					__syncthreads();
+					for (int k = 2; k <= 512; k <<= 1)
+						for (int j = k >> 1; j > 0; j >>= 1)
+						{ // bitonic network, descending
+							for (int t = lane; t < 256; t += 64)
+							{
+								const int lo = ((t / j) * 2 * j) + (t % j), hi = lo + j;
+								const u64 a = sort_keys[lo], b = sort_keys[hi];
+								const bool descending = ((lo & k) == 0);
+								if ((a < b) == descending)
+								{
+									sort_keys[lo] = b;
+									sort_keys[hi] = a;
+								}
+							}
+							__syncthreads();
+						}
+					const int K = E.max_children;
+					if (lane == 0)
+					{
+						float sum = 0.0f;
+						for (int r = 0; r < K; r++)
+							sum += e_prior[0xFFFF - static_cast<int>(sort_keys[r] & 0xFFFFu)];
+						sh_sum = E.expansion_threshold * sum;
+					}
+					__syncthreads();
+					const float threshold = sh_sum;
+					// gather the survivors (a prefix of the sorted list) into registers, then overwrite the edge arrays
+					uint16_t g_mv[7], g_sc[7];
+					float g_p[7], g_w[7], g_d[7];
+					int kept = 0;
+#pragma unroll
+					for (int c = 0; c < 7; c++)
+					{
+						const int r = c * 64 + lane;
+						const int src = (r < K) ? (0xFFFF - static_cast<int>(sort_keys[r] & 0xFFFFu)) : 0;
+						g_mv[c] = e_move[src];
+						g_sc[c] = e_score[src];
+						g_p[c] = e_prior[src];
+						g_w[c] = e_win[src];
+						g_d[c] = e_draw[src];
+						kept += __popcll(__ballot(r < K && g_p[c] >= threshold));
+					}
+					__syncthreads();
+#pragma unroll
+					for (int c = 0; c < 7; c++)
+					{
+						const int r = c * 64 + lane;
+						if (r < kept)
+						{
+							e_move[r] = g_mv[c];
+							e_score[r] = g_sc[c];
+							e_prior[r] = g_p[c];
+							e_win[r] = g_w[c];
+							e_draw[r] = g_d[c];
+						}
+					}
+					__syncthreads();
 					n_e = kept;
 				}
 				// renormalize_policy (:23-40): the sum runs in edge order in fp32, exactly like the reference
@@ -1374,6 +1450,7 @@ int agx_engine_default_config(AgxEngineConfig *cfg)
 	cfg->init_to = 0;
 	cfg->information_leak_threshold = 0.01f;
 	cfg->policy_expansion_threshold = 1.0e-4f;
+	cfg->max_children = 0;
 	cfg->tss_max_positions = 100;
 	cfg->tss_table_entries = 4ull * 1024ull * 1024ull;
 	cfg->zobrist_seed = 0x9E3779B97F4A7C15ull;
@@ -1421,6 +1498,7 @@ int agx_engine_create(const AgxEngineConfig *cfg, AgxEngine **out)
 	d.init_to = cfg->init_to;
 	d.leak_threshold = cfg->information_leak_threshold;
 	d.expansion_threshold = cfg->policy_expansion_threshold;
+	d.max_children = (cfg->max_children > 0) ? cfg->max_children : 0x7FFFFFFF;
 	d.tss_max_nodes = cfg->tss_max_positions;
 	d.tss_max_depth = 100;
 	d.yield_fraction = cfg->solver_yield_fraction;

@@ -141,6 +141,7 @@ namespace agx
 			float c_puct, c_scale;
 			int init_to;
 			float leak_threshold, expansion_threshold;
+			int max_children;
 			int tss_max_nodes, tss_max_depth;
 			unsigned long long zobrist_seed;
 			unsigned long long tt_bucket_mask; // buckets - 1 (4 entries of 16 bytes per bucket)

@@ -113,7 +113,7 @@ typedef struct AgxEngineConfig
 	float exploration_scaling;
 	int init_to;                      /* 0 "q_head", 1 "parent", 2 "draw", 3 "loss" */
 	float information_leak_threshold; /* TreeConfig */
-	float policy_expansion_threshold; /* MCTSConfig (max_children is fixed at "unlimited") */
+	float policy_expansion_threshold; /* MCTSConfig */
 	int tss_max_positions;            /* TSSConfig::max_positions, <= 1000 (the search depth is capped at 100 plies either way) */
 	uint64_t tss_table_entries;       /* AlphaBetaSearch's SharedHashTable size per game (reference: 4 Mi) */
 	uint64_t zobrist_seed;            /* seed of the solver / node-cache Zobrist keys (the reference draws them from a time-seeded RNG) */
@@ -133,6 +133,9 @@ typedef struct AgxEngineConfig
 	                                     randInt(8) from a time-seeded generator; here the k-th position of game `serial` uses
 	                                     splitmix64(symmetry_seed ^ serial << 32 ^ k) >> 61, so runs are reproducible. */
 	uint64_t symmetry_seed;
+	int max_children;                 /* MCTSConfig::max_children: non-root nodes keep at most this many edges (the best by proven score, then
+	                                     prior) and of those only the ones with prior >= policy_expansion_threshold * (their prior sum)
+	                                     (prune_weak_moves, EdgeGenerator.cpp:49-86).  0 = unlimited, the reference default. */
 	int noise_type;                   /* EdgeSelectorConfig::noise_type at the root: 0 "none", 1 "custom", 2 "dirichlet" (alpha 0.05), 3 "gumbel"
 	                                     (create*Noise, utils/random.cpp:89-124; mixed into the priors as EdgeSelector.cpp:602-623 does).
 	                                     Drawn once per move by the first select that sees an expanded root, like the selector that

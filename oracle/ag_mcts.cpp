@@ -356,7 +356,9 @@ namespace ago
 							return a.score > b.score;
 						return a.prior > b.prior;
 					};
-					std::partial_sort(t.edges.begin(), t.edges.begin() + max_edges, t.edges.end(), cmp);
+					// the reference calls std::partial_sort, which leaves the order of equal elements unspecified; a stable sort of the
+					// whole list gives the same first max_edges elements whenever no two edges compare equal, and a defined order otherwise
+					std::stable_sort(t.edges.begin(), t.edges.end(), cmp);
 					float sum = 0.0f;
 					for (size_t i = 0; i < max_edges; i++)
 						sum += t.edges[i].prior;

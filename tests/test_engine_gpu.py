@@ -143,7 +143,7 @@ def _oracle_root(olib, h):
 
 
 def _play_and_compare(olib, rules, games, batch, sims, max_steps, evaluator, table_entries=1 << 16, n=N, final_selector=0, use_symmetries=0,
-                      action_values=0, noise_weight=0.0, noise_type=1, exploration_scaling=0.0, draw_after=0):
+                      action_values=0, noise_weight=0.0, noise_type=1, exploration_scaling=0.0, draw_after=0, max_children=0):
     """evaluator(features uint32 [n][HW]) -> (policy [n][HW] f32, value [n][2] f32 (win, draw)[, q [n][HW][2]]); used for BOTH sides"""
     from alphagomoku_amd import selfplay
     N, HW = n, n * n   # noqa: N806 (shadow the 15x15 module defaults)
@@ -151,11 +151,13 @@ def _play_and_compare(olib, rules, games, batch, sims, max_steps, evaluator, tab
                                   tss_table_entries=table_entries, node_capacity=4096, edge_capacity=65536 if n <= 15 else 131072,
                                   final_selector=final_selector, use_symmetries=use_symmetries, action_values=action_values,
                                   noise_type=noise_type if noise_weight > 0 else 0, noise_weight=noise_weight,
-                                  exploration_scaling=exploration_scaling)
+                                  exploration_scaling=exploration_scaling, max_children=max_children)
     pool = selfplay.GeneratorPool(cfg)
     ocfg = ol.default_search_config(max_batch_size=batch, max_simulations=sims, table_entries=table_entries, final_selector=final_selector,
                                     use_symmetries=use_symmetries, noise_type=noise_type if noise_weight > 0 else 0, noise_weight=noise_weight)
     ocfg.exploration_scaling = exploration_scaling
+    if max_children > 0:
+        ocfg.max_children = max_children
     openings, handles = [], []
     for g in range(games):
         op = np.zeros(64, np.uint16)
@@ -276,6 +278,17 @@ def test_short_draw_limit(agx_lib, olib, rules, draw_after):
     (MoveGenerator.cpp:159-223) and the draw-rate reduction of the playout budget (misc.cpp:171-179) are exercised"""
     compared, stats = _play_and_compare(olib, rules, games=6, batch=4, sims=60, max_steps=4000, evaluator=_stand_in_evaluator(olib), draw_after=draw_after)
     assert compared > 100 and stats["games_finished"] == 6
+
+
+@pytest.mark.parametrize("rules,max_children", [(0, 12), (1, 30), (2, 5)])
+def test_max_children_pruning(agx_lib, olib, rules, max_children):
+    """MCTSConfig::max_children: non-root nodes keep the best max_children edges (proven scores first, then prior) and of those
+    only the ones above the scaled expansion threshold (prune_weak_moves, EdgeGenerator.cpp:69-83); the root is never pruned"""
+    compared, stats = _play_and_compare(olib, rules, games=4, batch=4, sims=80, max_steps=4000, evaluator=_stand_in_evaluator(olib),
+                                        max_children=max_children)
+    assert compared > 200 and stats["games_finished"] == 4
+    _, plain = _play_and_compare(olib, rules, games=4, batch=4, sims=80, max_steps=4000, evaluator=_stand_in_evaluator(olib))
+    assert plain["peak_edges"] > stats["peak_edges"]      # pruned trees are smaller
 
 
 def test_exploration_scaling(agx_lib, olib):
