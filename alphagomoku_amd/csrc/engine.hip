@@ -9,8 +9,9 @@
  *              Search::scheduleToNN    (Search.cpp:184-199)   compacts the positions that need the network
  *   (network)  NNEvaluator::evaluate                         agx_nn_forward over the compacted list (nn_forward.hip)
  *   k_expand   Search::generateEdges / expand / backup (Search.cpp:206-232) and the move rule (GameGenerator.cpp:97-103)
- *   k_advance  GameGenerator::make_move + prepare_search (:145-185): final "best" selector, sample record, outcome test,
- *              NodeCache::cleanup as a keep-test + prefix-sum compaction into the game's other arena, next opening
+ *   k_advance  GameGenerator::make_move + prepare_search (:145-185): final selector, sample record, outcome test (incl. renju
+ *              fouls), NodeCache::cleanup as a keep-test + prefix-sum compaction into the game's other arena
+ *   k_assign_openings / k_restart   finished games take the next openings in game order (GAME_NOT_STARTED -> next game)
  *
  * Everything stays in HBM between steps; the host only enqueues launches.  One wavefront per game for the sequential
  * tree work (games are independent, the batch inside a game is order-dependent through virtual loss); k_advance uses a

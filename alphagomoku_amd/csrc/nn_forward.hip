@@ -1,15 +1,16 @@
 /*
  * nn_forward.hip — whole-tower policy/value forward for one board per workgroup, gfx950 (CDNA4).
  *
- * Replaces `graph.predict` of the ResnetPV graph (src/networks/networks.cpp:71-93; layers from
- * src/networks/blocks.cpp:32-38 input block, :45-55 residual block, :99-107 policy head, :108-118 value head)
+ * Replaces `graph.predict` of the ResnetPV / ResnetPVQ graphs (src/networks/networks.cpp:71-93, :143-168; layers from
+ * src/networks/blocks.cpp:32-38 input block, :45-55 residual block, :99-107 policy head, :108-118 value head, :119-127
+ * action-values head)
  * after optimize(2) folded every BatchNormalization into the preceding layer (AGNetwork.cpp:136-160), plus
  * `ml::unpackInput` (AGNetwork.cpp:249-258) which expands the bit-packed feature word of each cell
  * (NNInputFeatures.cpp:59-113) to Cin = 32 channels of {0,1}.
  *
  * MI355X-first design (not how MinML runs it):
  *   - A 15x15 board with F = 128 channels in fp16 is 57.6 KB, so TWO activation planes of a board fit in the
- *     160 KB LDS of one CU.  One workgroup (4 waves, one per SIMD) therefore carries a board through the
+ *     160 KB LDS of one CU.  One workgroup (8 waves, two per SIMD) therefore carries a board through the
  *     entire tower — conv5x5, every residual block, both heads — without a single activation byte touching
  *     HBM.  HBM traffic per position is the algorithmic minimum: 4*HW bytes in, 4*(HW+3) bytes out.
  *   - Each convolution is an implicit GEMM on the matrix cores: D[out-ch][position] += W[out-ch][k] * X[k][position]
@@ -22,9 +23,12 @@
  *   - LDS rows are XOR-swizzled at 16-byte granularity so that the 16 lanes of a ds_read_b128 group hit 16
  *     different bank quads.
  *   - Weights are pre-packed on the host in MFMA A-fragment order; each wave streams only the fragments of its
- *     own output channels from L2 with fully coalesced 16-byte loads (no LDS round trip: no two waves of a
- *     workgroup need the same weight fragment).
- *   - The grid is persistent (one workgroup per CU) and strides over the batch.
+ *     own output channels from L2 with fully coalesced 16-byte loads, fetched a few k-steps ahead (no LDS round trip).
+ *   - The grid is persistent (one workgroup per CU) and strides over the batch (a device-side slot list, so the search
+ *     kernels hand positions over without a host round trip).
+ *   - 20x20 boards do not fit two planes: the INPLACE variant computes every layer over its own input (all outputs stay in
+ *     accumulators until every wave has passed a barrier) and parks the residual input in a per-workgroup global scratch.
+ *   - Template flags keep the variants apart: <F, ROWS, COLS, INPLACE, QHEAD>; the pv kernels carry no q-head code.
  */
 #include "agx_internal.hpp"
 
