@@ -115,22 +115,17 @@ namespace agx
 		/* wave-wide (value, index) argmax: largest value, lowest index among equals (EdgeSelector.cpp:562-586 scans in order with '>') */
 		__device__ __forceinline__ void wave_argmax(float &value, int &index)
 		{
-			for (int o = 32; o > 0; o >>= 1)
-			{
-				const float v2 = __shfl_xor(value, o);
-				const int i2 = __shfl_xor(index, o);
-				if (v2 > value || (v2 == value && i2 < index))
-				{
-					value = v2;
-					index = i2;
-				}
-			}
+			// order-preserving map of the float bits to unsigned, DPP max; then the lowest index among the lanes that hold the maximum
+			const uint32_t bits = __float_as_uint(value);
+			const uint32_t key = (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
+			const uint32_t best = wave_reduce_umax(key);
+			const uint32_t mine = (key == best) ? (0x7FFFFFFFu - static_cast<uint32_t>(index)) : 0u;
+			index = static_cast<int>(0x7FFFFFFFu - wave_reduce_umax(mine));
+			value = __uint_as_float((best & 0x80000000u) ? (best & 0x7FFFFFFFu) : ~best);
 		}
 		__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 		{
-			for (int o = 32; o > 0; o >>= 1)
-				v = max(v, static_cast<uint32_t>(__shfl_xor(static_cast<int>(v), o)));
-			return v;
+			return wave_reduce_umax(v);
 		}
 
 		/* PUCTSelector::select without root noise (EdgeSelector.cpp:1123-1166) */
@@ -233,7 +228,7 @@ namespace agx
 					new_score = s_invert_up(nodes[next].score);
 					edges[e].score = static_cast<uint16_t>(new_score);
 				}
-				new_score = __shfl(static_cast<int>(new_score), 0);
+				new_score = __builtin_amdgcn_readfirstlane(static_cast<int>(new_score));
 				update_node_score(nodes, edges, node, e, new_score, lane);
 			}
 		}
@@ -254,9 +249,7 @@ namespace agx
 			u64 h = 0;
 			for (int i = lane; i < E.hw; i += 64)
 				h ^= E.nc_keys[3 + 3 * i + board[i]];
-			for (int o = 32; o > 0; o >>= 1)
-				h ^= __shfl_xor(h, o);
-			return h ^ E.nc_keys[sign];
+			return wave_reduce_xor64(h) ^ E.nc_keys[sign];
 		}
 	}
 }

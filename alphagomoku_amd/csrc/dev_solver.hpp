@@ -39,6 +39,45 @@ namespace agx
 			__builtin_amdgcn_wave_barrier();
 		}
 
+		/*
+		 * Wave-wide reductions on the DPP path.  __shfl_xor compiles to ds_bpermute_b32 + s_waitcnt on gfx950 — six LDS-crossbar
+		 * round trips per reduction; a row_shr 1/2/4/8 scan inside the 16-lane rows followed by row_bcast:15 / row_bcast:31 is six
+		 * VALU instructions, after which lane 63 holds the result (identity 0 for max / add / xor of unsigned values).
+		 */
+#define AGX_DPP_STEP(V, OP, CTRL, ROWS) V = OP(V, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(V), CTRL, ROWS, 0xf, false)))
+#define AGX_OP_MAX(a, b) max(a, b)
+#define AGX_OP_ADD(a, b) ((a) + (b))
+#define AGX_OP_XOR(a, b) ((a) ^ (b))
+#define AGX_WAVE_REDUCE(V, OP) do { AGX_DPP_STEP(V, OP, 0x111, 0xf); AGX_DPP_STEP(V, OP, 0x112, 0xf); AGX_DPP_STEP(V, OP, 0x114, 0xf); \
+		AGX_DPP_STEP(V, OP, 0x118, 0xf); AGX_DPP_STEP(V, OP, 0x142, 0xa); AGX_DPP_STEP(V, OP, 0x143, 0xc); } while (0)
+		__device__ __forceinline__ uint32_t wave_reduce_umax(uint32_t v)
+		{
+			AGX_WAVE_REDUCE(v, AGX_OP_MAX);
+			return __builtin_amdgcn_readlane(v, 63);
+		}
+		__device__ __forceinline__ uint32_t wave_reduce_add(uint32_t v)
+		{
+			AGX_WAVE_REDUCE(v, AGX_OP_ADD);
+			return __builtin_amdgcn_readlane(v, 63);
+		}
+		__device__ __forceinline__ u64 wave_reduce_xor64(u64 v)
+		{
+			uint32_t lo = static_cast<uint32_t>(v), hi = static_cast<uint32_t>(v >> 32);
+			AGX_WAVE_REDUCE(lo, AGX_OP_XOR);
+			AGX_WAVE_REDUCE(hi, AGX_OP_XOR);
+			return static_cast<u64>(static_cast<uint32_t>(__builtin_amdgcn_readlane(lo, 63))) | (static_cast<u64>(static_cast<uint32_t>(__builtin_amdgcn_readlane(hi, 63))) << 32); // readlane yields int: no sign extension
+		}
+		/* inclusive prefix sum over lanes 0..31 (the rows of a board): 16-lane scans, then row 0's total into row 1 */
+		__device__ __forceinline__ uint32_t wave_scan32_add(uint32_t v)
+		{
+			AGX_DPP_STEP(v, AGX_OP_ADD, 0x111, 0xf);
+			AGX_DPP_STEP(v, AGX_OP_ADD, 0x112, 0xf);
+			AGX_DPP_STEP(v, AGX_OP_ADD, 0x114, 0xf);
+			AGX_DPP_STEP(v, AGX_OP_ADD, 0x118, 0xf);
+			AGX_DPP_STEP(v, AGX_OP_ADD, 0x142, 0xa);
+			return v;
+		}
+
 		/* Solver Zobrist keys (FastZobristHashing, ZobristHashing.cpp:35-43 draws 2*HW 128-bit keys from an RNG): key word j is the
 		 * j-th output of splitmix64 seeded with the engine's zobrist_seed, so it can be recomputed in registers instead of being
 		 * gathered from memory (lo word of (cell, colour) = output 2*(2*cell + colour - 1), hi word = the next one). */
@@ -312,8 +351,7 @@ namespace agx
 					}
 				}
 			}
-			for (int o = 32; o > 0; o >>= 1)
-				stones += __shfl_xor(stones, o);
+			stones = static_cast<int>(wave_reduce_add(static_cast<uint32_t>(stones)));
 			if (lane == 0)
 			{
 				sh.sign_to_move = sign_to_move;
@@ -1130,14 +1168,8 @@ namespace agx
 				{ // :1127-1137 — row-major append; one row per lane, offsets by a wave prefix sum
 					uint32_t bits = (lane < n) ? (mask[lane] & (~sh.added[lane])) : 0u;
 					const int mine = __popc(bits);
-					int offset = mine;
-					for (int o = 1; o < 32; o <<= 1)
-					{
-						const int v = __shfl_up(offset, o);
-						if (lane >= o)
-							offset += v;
-					}
-					const int total = __shfl(offset, 31);
+					int offset = static_cast<int>(wave_scan32_add(static_cast<uint32_t>(mine)));
+					const int total = __builtin_amdgcn_readlane(offset, 31);
 					offset -= mine;
 					if (f.base + f.size + total + 1 >= E.act_cap)
 					{
@@ -1827,37 +1859,13 @@ namespace agx
 							}
 						}
 						else
-						{ // first maximum of the remaining actions: one action per lane, (score, lowest index) reduction
-							uint32_t best = 0;
-							int idx = 0x7FFFFFFF;
+						{ // first maximum of the remaining actions: every lane folds its actions into one key (score, lowest index), one
+						  // DPP reduction picks the winner
+							uint32_t key = 0;
 							for (int j = f.i + lane; j < f.size; j += 64)
-							{
-								const uint32_t sc = act_get(sh, act, f.base + j) >> 16;
-								if (idx == 0x7FFFFFFF || best < sc)
-								{
-									best = sc;
-									idx = j;
-								}
-							}
-							{ // wave-wide (largest score, lowest index) by ballots: a bitwise radix pass over the 16 score bits, then — only when a
-							  // lane holds more than one action — over the index bits; no cross-lane data movement until the final read
-								bool alive = (idx != 0x7FFFFFFF);
-								for (int b = 15; b >= 0; b--)
-								{
-									const bool bit = alive && ((best >> b) & 1u);
-									if (__ballot(bit) != 0)
-										alive = bit;
-								}
-								if (f.size - f.i > 64)
-									for (int b = 9; b >= 0; b--)
-									{
-										const bool zero = alive && (((idx >> b) & 1) == 0);
-										if (__ballot(zero) != 0)
-											alive = zero;
-									}
-								const int winner = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(__ballot(alive))) - 1);
-								idx = __builtin_amdgcn_readlane(idx, winner);
-							}
+								key = max(key, ((act_get(sh, act, f.base + j) >> 16) << 16) | static_cast<uint32_t>(0xFFFF - j));
+							key = wave_reduce_umax(key);
+							const int idx = 0xFFFF - static_cast<int>(key & 0xFFFFu);
 							if (idx != f.i)
 							{
 								const uint32_t t = act_get(sh, act, f.base + f.i);

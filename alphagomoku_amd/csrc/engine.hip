@@ -216,11 +216,8 @@ namespace
 				hi ^= zobrist_word(E.zobrist_seed, 2 * (2 * i + v - 1) + 1);
 			}
 		}
-		for (int o = 32; o > 0; o >>= 1)
-		{
-			lo ^= __shfl_xor(lo, o);
-			hi ^= __shfl_xor(hi, o);
-		}
+		lo = wave_reduce_xor64(lo);
+		hi = wave_reduce_xor64(hi);
 		if (lane == 0)
 		{
 			sh.hash_lo = lo;
@@ -292,8 +289,8 @@ namespace
 				const uint32_t r = static_cast<uint32_t>(sh.result_score);
 				stop = (sh.frames[0].size == 0 || s_proven(r) || sh.node_counter >= E.tss_max_nodes || sh.stack_max == stack_before || sh.error != 0) ? 1 : 0;
 			}
-			stop = __shfl(stop, 0);
-			result = static_cast<uint32_t>(__shfl(sh.result_score, 0));
+			stop = __builtin_amdgcn_readfirstlane(stop);
+			result = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(sh.result_score));
 			wave_sync();
 			if (stop)
 				break;
@@ -375,7 +372,7 @@ namespace
 					int done = 0;
 					if (lane == 0)
 						done = __hip_atomic_load(&E.counters[E.yield_counter], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-					done = __shfl(done, 0);
+					done = __builtin_amdgcn_readfirstlane(done);
 					if (done >= threshold)
 					{
 						yielded = true;
@@ -776,7 +773,7 @@ namespace
 					ed.flag_vl = static_cast<uint16_t>(((ed.flag_vl & 0x7FFF) - 1) & 0x7FFF);
 				}
 				ml += 1.0f;
-				new_score = static_cast<uint32_t>(__shfl(static_cast<int>(new_score), 0));
+				new_score = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(new_score)));
 				update_node_score(nodes, edges, node, e, new_score, lane);
 			}
 			__syncthreads();
@@ -803,8 +800,7 @@ namespace
 	/* ------------------------------------------------------------------------------------------------------------ */
 	__device__ void block_reduce_xor(u64 &v, u64 *scratch, int tid)
 	{
-		for (int o = 32; o > 0; o >>= 1)
-			v ^= __shfl_xor(v, o);
+		v = wave_reduce_xor64(v);
 		__syncthreads();
 		if ((tid & 63) == 0)
 			scratch[tid >> 6] = v;
