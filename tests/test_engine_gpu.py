@@ -603,3 +603,16 @@ def test_long_running_loop_drains_records_and_refills_openings(agx_lib):
     assert len({(s, m) for s, m, _, _, _ in d1}) == len(d1)
     assert sorted(d1) == sorted(d2) and h1 == h2                            # reproducible, including which slot got which opening
     net.close()
+
+
+def test_wave_reduction_helpers(agx_lib, tmp_path):
+    """scripts/dpp_check.hip: the DPP reductions / scan / arg-max that replaced the ds_bpermute shuffles, against a scalar loop"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "dpp_check")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-I" + os.path.join(root, "include"),
+                           "-o", exe, os.path.join(root, "scripts", "dpp_check.hip")])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0
+    assert out.stdout.strip().splitlines()[-1] == "bad: umax 0 add 0 xor 0 scan 0 argmax value 0 index 0", out.stdout
