@@ -46,3 +46,11 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
         assert "no CPU fallback" in str(e)
     else:
         raise AssertionError("expected AgxError")
+
+
+def test_header_is_plain_c(tmp_path):
+    """the boundary is a C ABI: include/agx.h must compile as C99 (no C++ types leak into the signatures)"""
+    import subprocess
+    src = tmp_path / "abi.c"
+    src.write_text('#include "agx.h"\nint main(void) { AgxEngineConfig c; AgxNetDesc d; (void) c; (void) d; return 0; }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I" + os.path.join(ROOT, "include"), str(src)])
