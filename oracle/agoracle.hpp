@@ -8,7 +8,7 @@
  * Pinning:
  *   - tables, score algebra, record layouts: compared entry-by-entry with the real reference compiled from its own
  *     sources (oracle/_ref/libagref.so, oracle/ref_driver.cpp) and with checksums committed under tests/golden;
- *   - rules / NN input features / move generator: the reference's own test fixtures (test/game/*.cpp,
+ *   - rules / NN input features / move generator: the reference's own test fixtures (test/game/test_<rules>.cpp,
  *     test/networks/test_NNInputFeatures.cpp, test/search/alpha_beta/test_move_generator.cpp) restated as data in
  *     tests/golden;
  *   - alpha-beta solver, Tree/Search/GameGenerator: PARITY UNPINNED — the reference's tests for them are commented out
