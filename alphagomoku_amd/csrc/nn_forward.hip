@@ -152,18 +152,26 @@ namespace
 					for (int i = 0; i < G::MT; i++)
 						a_ring[(kc + RING - 1) % RING][i] = wp[(ahead * G::MTILES + i) * 64];
 				}
-				half8 b[G::NTW];
+				// activation fragments in groups of at most 8 tiles (one group on 15x15; two on 20x20, where 14 live fragments at
+				// once would push the kernel over its register budget)
+				constexpr int BG = 8;
 #pragma unroll
-				for (int n = 0; n < G::NTW; n++)
-					b[n] = *reinterpret_cast<const half8*>(src0 + ((n < my_tiles) ? n : 0) * (16 * G::CH * 16) + (((kc * 4 + q4) ^ swz0) * 16));
+				for (int g0 = 0; g0 < G::NTW; g0 += BG)
+				{
+					half8 b[BG];
 #pragma unroll
-				for (int n = 0; n < G::NTW; n++)
-					if (n < my_tiles)
-					{
+					for (int n = 0; n < BG; n++)
+						if (g0 + n < G::NTW)
+							b[n] = *reinterpret_cast<const half8*>(src0 + ((g0 + n < my_tiles) ? (g0 + n) : 0) * (16 * G::CH * 16) + (((kc * 4 + q4) ^ swz0) * 16));
 #pragma unroll
-						for (int i = 0; i < G::MT; i++)
-							acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_ring[kc % RING][i], b[n], acc[i][n], 0, 0, 0);
-					}
+					for (int n = 0; n < BG; n++)
+						if (g0 + n < G::NTW && g0 + n < my_tiles)
+						{
+#pragma unroll
+							for (int i = 0; i < G::MT; i++)
+								acc[i][g0 + n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_ring[kc % RING][i], b[n], acc[i][g0 + n], 0, 0, 0);
+						}
+				}
 			}
 		}
 	}
