@@ -306,6 +306,13 @@ def test_input_symmetries(agx_lib, olib, rules, n):
     assert compared > 200 and stats["games_finished"] == 4
 
 
+@pytest.mark.parametrize("rules,n", [(0, 12), (1, 19)])
+def test_whole_games_on_other_board_sizes(agx_lib, olib, rules, n):
+    """boards other than 15x15 / 20x20 run the generic solver kernel (board size not a compile-time constant)"""
+    compared, stats = _play_and_compare(olib, rules, games=4, batch=4, sims=50, max_steps=6000, evaluator=_stand_in_evaluator(olib, n * n), n=n)
+    assert compared > 200 and stats["games_finished"] == 4
+
+
 @pytest.mark.parametrize("rules,batch,sims", [(3, 8, 60), (0, 4, 60)])
 def test_whole_games_on_the_20x20_board(agx_lib, olib, rules, batch, sims):
     """BASELINE configs[3] shape (caro, 20x20): solver lists, node-cache board words and record sizes at the largest board"""
