@@ -745,15 +745,21 @@ namespace agx
 			if (E.rules != AGX_RENJU || sh.sign_to_move != 1)
 				return;
 			wave_sync();
-			for (int cell = 0; cell < E.hw; cell++)
-			{
-				const int t = sh.threat[cell][0];
-				if (sh.board[cell] == 0 && (t == 9 || t == 6 || t == 3))
+			for (int base = 0; base < E.hw; base += 64)
+			{ // candidates of 64 cells at a time (a probe restores the position, so the threat types seen here stay valid), probed in order
+				const int mine = base + lane;
+				const int t = (mine < E.hw) ? sh.threat[mine][0] : 0;
+				u64 candidates = __ballot(mine < E.hw && sh.board[mine] == 0 && (t == 9 || t == 6 || t == 3));
+				while (candidates != 0)
+				{
+					const int cell = base + __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(candidates)) - 1);
+					candidates &= candidates - 1;
 					if (renju_is_forbidden(sh, E, cell, lane))
 					{
 						if (lane == 0)
 							out[cell] |= (1u << 6);
 					}
+				}
 			}
 			wave_sync();
 		}
