@@ -1530,20 +1530,27 @@ namespace agx
 						for (int i = 0; i < half4.n; i++)
 							add_move(half4.v[i], s_unknown(0), false);
 						for (int i = 0; i < half4.n; i++)
-						{
+						{ // the 4 x 9 (direction, offset) candidates around a defensive move: one per lane, added in (d, j) order
 							const int hr = half4.v[i] / n, hc = half4.v[i] % n;
-							for (int d = 0; d < 4; d++)
+							int l = -1;
+							bool wanted = false;
+							if (lane < 36)
 							{
+								const int d = lane / 9, j = lane % 9 - 4;
 								const uint32_t reduced = (extended_pattern(sh, n, hr, hc, d) >> 4) & 0x3FFFFu;
-								for (int j = -4; j <= 4; j++)
-									if (((reduced >> (2 * (j + 4))) & 3u) == 0u)
-									{
-										const int rr = hr + j * row_step(d), cc = hc + j * col_step(d);
-										const int l = rr * n + cc;
-										const int pt = patterns(own, l)[d];
-										if (pt > 0 || ((E.t_ho3[narrow(normal_pattern(sh, n, rr, cc, d))] >> (own - 1)) & 1))
-											add_move(l, s_unknown(0), false);
-									}
+								if (((reduced >> (2 * (j + 4))) & 3u) == 0u)
+								{
+									const int rr = hr + j * row_step(d), cc = hc + j * col_step(d);
+									l = rr * n + cc;
+									wanted = patterns(own, l)[d] > 0 || ((E.t_ho3[narrow(normal_pattern(sh, n, rr, cc, d))] >> (own - 1)) & 1);
+								}
+							}
+							u64 m = __ballot(wanted);
+							while (m != 0)
+							{
+								const int src = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(m)) - 1);
+								m &= m - 1;
+								add_move(__builtin_amdgcn_readlane(l, src), s_unknown(0), false);
 							}
 						}
 					}
@@ -1562,17 +1569,25 @@ namespace agx
 						add_list(own, 2, s_unknown(1), false);
 						if (lane < n)
 							sh.row_mask[lane] = stencil_row(STENCIL_STAR, own);
-						for (int r = 0; r < n; r++)
-						{
-							uint32_t bits = sh.row_mask[r] & sh.legal[r] & (~sh.added[r]);
-							for (int c = 0; c < n; c++, bits >>= 1)
-								if (bits & 1)
+						wave_sync();
+						for (int base = 0; base < n * n; base += 64)
+						{ // one cell per lane: inside the star mask, legal, not yet added, and a half-open three in some direction
+							const int cell = base + lane;
+							bool wanted = false;
+							if (cell < n * n)
+							{
+								const int r = cell / n, c = cell % n;
+								if (((sh.row_mask[r] & sh.legal[r] & (~sh.added[r])) >> c) & 1u)
 									for (int d = 0; d < 4; d++)
-										if ((E.t_ho3[narrow(normal_pattern(sh, n, r, c, d))] >> (own - 1)) & 1)
-										{
-											add_move(r * n + c, s_unknown(1), false);
-											break;
-										}
+										wanted = wanted || ((E.t_ho3[narrow(normal_pattern(sh, n, r, c, d))] >> (own - 1)) & 1);
+							}
+							u64 m = __ballot(wanted);
+							while (m != 0)
+							{
+								const int src = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(m)) - 1);
+								m &= m - 1;
+								add_move(base + src, s_unknown(1), false);
+							}
 						}
 					}
 					if (f.must_defend)
