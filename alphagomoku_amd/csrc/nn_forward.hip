@@ -163,6 +163,10 @@ namespace
 					for (int n = 0; n < BG; n++)
 						if (g0 + n < G::NTW)
 							b[n] = *reinterpret_cast<const half8*>(src0 + ((g0 + n < my_tiles) ? (g0 + n) : 0) * (16 * G::CH * 16) + (((kc * 4 + q4) ^ swz0) * 16));
+					// s_setprio around the MFMA cluster: with it hipcc keeps the cluster together instead of threading the MFMAs through the
+					// operand loads (+8 % on the 15x15 kernels, measured A/B on one box; slightly negative with the two groups of 20x20)
+					if (G::NTW <= BG)
+						__builtin_amdgcn_s_setprio(1);
 #pragma unroll
 					for (int n = 0; n < BG; n++)
 						if (g0 + n < G::NTW && g0 + n < my_tiles)
@@ -171,6 +175,8 @@ namespace
 							for (int i = 0; i < G::MT; i++)
 								acc[i][g0 + n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_ring[kc % RING][i], b[n], acc[i][g0 + n], 0, 0, 0);
 						}
+					if (G::NTW <= BG)
+						__builtin_amdgcn_s_setprio(0);
 				}
 			}
 		}
