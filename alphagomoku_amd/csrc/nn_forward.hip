@@ -163,10 +163,10 @@ namespace
 					for (int n = 0; n < BG; n++)
 						if (g0 + n < G::NTW)
 							b[n] = *reinterpret_cast<const half8*>(src0 + ((g0 + n < my_tiles) ? (g0 + n) : 0) * (16 * G::CH * 16) + (((kc * 4 + q4) ^ swz0) * 16));
-					// s_setprio around the MFMA cluster: with it hipcc keeps the cluster together instead of threading the MFMAs through the
-					// operand loads (+8 % on the 15x15 kernels, measured A/B on one box; slightly negative with the two groups of 20x20)
-					if (G::NTW <= BG)
-						__builtin_amdgcn_s_setprio(1);
+					// scheduling hint: hipcc otherwise threads the MFMAs of a k-step through its operand loads; iglp_opt(0) (the built-in
+					// DS-read / MFMA interleave for small GEMM loops) keeps the cluster together: +6-8 % on the 15x15 kernels (the same as
+					// s_setprio 1 / 0 around the cluster) and +3 % on 20x20, measured A/B on one box
+					__builtin_amdgcn_iglp_opt(0);
 #pragma unroll
 					for (int n = 0; n < BG; n++)
 						if (g0 + n < G::NTW && g0 + n < my_tiles)
@@ -175,8 +175,6 @@ namespace
 							for (int i = 0; i < G::MT; i++)
 								acc[i][g0 + n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_ring[kc % RING][i], b[n], acc[i][g0 + n], 0, 0, 0);
 						}
-					if (G::NTW <= BG)
-						__builtin_amdgcn_s_setprio(0);
 				}
 			}
 		}
