@@ -126,7 +126,7 @@ namespace
 		 * step s+1 are requested before the MFMAs of step s (two register sets each).
 		 */
 		constexpr int STEPS = 9 * G::KC;
-		constexpr int RING = (G::KC == 4 && G::NTW <= 8) ? 4 : 2; // weight fragments are fetched RING-1 k-steps ahead (L2 latency > one k-step of MFMAs)
+		constexpr int RING = (G::KC == 4) ? 4 : 2; // weight fragments are fetched RING-1 k-steps ahead (L2 latency > one k-step of MFMAs)
 		static_assert(G::KC % RING == 0, "ring index must be static inside the unrolled k loop");
 		const half8 *wp = wpk + (mg * G::MT) * 64 + lane;
 		half8 a_ring[RING][G::MT];
@@ -135,7 +135,7 @@ namespace
 #pragma unroll
 			for (int i = 0; i < G::MT; i++)
 				a_ring[u][i] = wp[(u * G::MTILES + i) * 64];
-#pragma unroll 1
+#pragma unroll 3
 		for (int t = 0; t < 9; t++)
 		{
 			const int off = (t / 3 - 1) * G::S + (t % 3 - 1);
