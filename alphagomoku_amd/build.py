@@ -39,9 +39,9 @@ def build(force=False, verbose=True):
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]
         if os.environ.get("AGX_SOLVER_PROFILE"):
             cmd += ["-DAGX_SOLVER_PROFILE"]
-        if src == "engine.hip":
-            # the search kernels are long scalar-like chains: the iterative-ILP machine scheduler beats the default by 3.4 % on k_solve
-            # (7.99 -> 7.72 ms, A/B on one box); the network kernel keeps the default scheduler + its own iglp_opt hint
+        if src.endswith(".hip"):
+            # the iterative-ILP machine scheduler beats the default on every kernel here (A/B on one box): k_solve 7.99 -> 7.72 ms,
+            # 20x20 network kernels +5 % (10x128) / +32 % (2x64), 15x15 network kernels unchanged (they carry an iglp_opt hint)
             cmd += ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]
         if src.endswith(".cpp"):
             cmd += ["-x", "hip"]
