@@ -1007,8 +1007,39 @@ namespace agx
 				__device__ __forceinline__ void add_list(int sign, int t, uint32_t score, bool override_duplicate)
 				{
 					const int cnt = count(sign, t);
-					for (int i = 0; i < cnt; i++)
-						add_move(list(sign, t)[i], score, override_duplicate);
+					if (override_duplicate)
+					{
+						for (int i = 0; i < cnt; i++)
+							add_move(list(sign, t)[i], score, true);
+						return;
+					}
+					// the cells of one threat list are distinct, so the not-yet-added ones can be appended in list order by all lanes at once
+					for (int base = 0; base < cnt; base += 64)
+					{
+						const int k = base + lane;
+						const int cell = (k < cnt) ? list(sign, t)[k] : 0;
+						const int r = cell / n, c = cell % n;
+						const bool fresh = (k < cnt) && (((sh.added[r] >> c) & 1u) == 0u);
+						const u64 m = __ballot(fresh);
+						const int n_new = __popcll(m);
+						if (n_new == 0)
+							continue;
+						if (f.base + f.size + n_new + 1 >= E.act_cap)
+						{
+							sh.error = ERR_ACTION_STACK;
+							return;
+						}
+						if (fresh)
+						{
+							const u64 below = (lane == 0) ? 0ull : (m & (~0ull >> (64 - lane)));
+							act_set(sh, act, f.base + f.size + __popcll(below), move_of(cell) | (score << 16));
+							atomicOr(&sh.added[r], 1u << c);
+						}
+						f.size += n_new;
+						stack_offset += n_new;
+						stack_max = max(stack_max, stack_offset);
+						wave_sync();
+					}
 				}
 				__device__ __forceinline__ void defensive_moves(int defender, int cell, int dir, SmallSet &out) const
 				{ // PatternCalculator::getDefensiveMoves (PatternCalculator.hpp:150-160)
