@@ -167,6 +167,7 @@ namespace agx
 				uint8_t board[MAXHW];
 				uint8_t ptype[MAXHW][8]; // [cell][0-3 cross dirs, 4-7 circle dirs]
 				uint8_t threat[MAXHW][2];
+				uint8_t threat_lut[4096]; // ThreatTable in LDS: cross | circle << 4 for the 4 x 3-bit pattern index (loaded per launch)
 				uint16_t lists[2][10][MAXHW];
 				uint16_t count[2][10];
 				uint32_t legal[MAXN];
@@ -251,6 +252,18 @@ namespace agx
 			}
 		}
 
+		/* ThreatTable (4096 x 2 threat types < 16) packed to one byte per index: 4 KB of LDS instead of a second dependent L2 access
+		 * for every re-classified cell.  Once per launch, before the first solver_set_board. */
+		__device__ __forceinline__ void solver_load_threat_table(SolverShared &sh, const EngineDev &E, int lane)
+		{
+			for (int i = lane; i < 4096; i += 64)
+			{
+				const uint16_t both = reinterpret_cast<const uint16_t*>(E.t_threat)[i];
+				sh.threat_lut[i] = static_cast<uint8_t>((both & 15u) | ((both >> 8) << 4));
+			}
+			wave_sync();
+		}
+
 		/* PatternCalculator::setBoard (PatternCalculator.cpp:40-66, 245-277) */
 		__device__ __forceinline__ void solver_set_board(SolverShared &sh, const EngineDev &E, const uint8_t *board, int sign_to_move, int lane)
 		{
@@ -311,8 +324,8 @@ namespace agx
 							sh.ptype[cell][d] = e & 15;
 							sh.ptype[cell][4 + d] = e >> 4;
 						}
-						t0 = E.t_threat[2 * threat_index(sh.ptype[cell])];
-						t1 = E.t_threat[2 * threat_index(sh.ptype[cell] + 4) + 1];
+						t0 = sh.threat_lut[threat_index(sh.ptype[cell])] & 15;
+						t1 = sh.threat_lut[threat_index(sh.ptype[cell] + 4)] >> 4;
 					}
 					else
 					{
@@ -393,8 +406,8 @@ namespace agx
 					w1 = (w1 & ~(255u << (8 * d))) | ((e >> 4) << (8 * d));
 					sh.ptype[cell][d] = static_cast<uint8_t>(e & 15u);
 					sh.ptype[cell][4 + d] = static_cast<uint8_t>(e >> 4);
-					new0 = E.t_threat[2 * ((w0 & 7u) | (((w0 >> 8) & 7u) << 3) | (((w0 >> 16) & 7u) << 6) | (((w0 >> 24) & 7u) << 9))];
-					new1 = E.t_threat[2 * ((w1 & 7u) | (((w1 >> 8) & 7u) << 3) | (((w1 >> 16) & 7u) << 6) | (((w1 >> 24) & 7u) << 9)) + 1];
+					new0 = sh.threat_lut[(w0 & 7u) | (((w0 >> 8) & 7u) << 3) | (((w0 >> 16) & 7u) << 6) | (((w0 >> 24) & 7u) << 9)] & 15;
+					new1 = sh.threat_lut[(w1 & 7u) | (((w1 >> 8) & 7u) << 3) | (((w1 >> 16) & 7u) << 6) | (((w1 >> 24) & 7u) << 9)] >> 4;
 					sh.threat[cell][0] = static_cast<uint8_t>(new0);
 					sh.threat[cell][1] = static_cast<uint8_t>(new1);
 				}
@@ -422,8 +435,8 @@ namespace agx
 			{
 				const uint32_t bits = __builtin_amdgcn_readlane(centre_bits, 40) | __builtin_amdgcn_readlane(centre_bits, 41)
 						| __builtin_amdgcn_readlane(centre_bits, 42) | __builtin_amdgcn_readlane(centre_bits, 43);
-				c0 = E.t_threat[2 * (bits & 4095u)];
-				c1 = E.t_threat[2 * ((bits >> 16) & 4095u) + 1];
+				c0 = sh.threat_lut[bits & 4095u] & 15;
+				c1 = sh.threat_lut[(bits >> 16) & 4095u] >> 4;
 				if (lane == 0)
 				{
 					sh.threat[center][0] = static_cast<uint8_t>(c0);

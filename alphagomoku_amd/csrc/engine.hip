@@ -358,6 +358,8 @@ namespace
 		GameState &gs = E.games[g];
 		const bool idle = (!gs.active || gs.error != 0 || gs.outcome != 0);
 		const int n_tasks = idle ? 0 : gs.n_tasks;
+		if (n_tasks > 0)
+			solver_load_threat_table(sh, E, lane);
 		unsigned long long solver_nodes = 0, scheduled = 0;
 		/*
 		 * The tasks of a game are solved strictly in order (they share the game's transposition table), so a launch lasts as long as
@@ -1294,6 +1296,7 @@ namespace
 	{
 		__shared__ SolverShared sh;
 		const int g = blockIdx.x, lane = threadIdx.x;
+		solver_load_threat_table(sh, E, lane);
 		solver_set_board(sh, E, boards + static_cast<size_t>(g) * E.hw, signs[g], lane);
 		__shared__ uint16_t done[512];
 		__shared__ int n_done;
