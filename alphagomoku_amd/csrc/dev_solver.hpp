@@ -151,13 +151,17 @@ namespace agx
 		}
 
 		/* ---------------- per-game solver state in LDS ---------------- */
-		struct Frame
-		{
-				int base, size, i, depth_remaining;
+		struct alignas(16) Frame
+		{ // 32 bytes, 16-byte aligned: a frame moves between registers and LDS as two 128-bit accesses
+				int base;
+				uint16_t size, i; // an action list never exceeds the number of cells
 				uint16_t alpha, beta, original_alpha, best_score;
 				uint16_t best_move, move, baseline;
+				int16_t depth_remaining;
 				uint8_t must_defend, has_initiative, fully_expanded, pad;
+				uint32_t pad2;
 		};
+		static_assert(sizeof(Frame) == 32, "frame layout");
 		enum Cmd : int { CMD_NONE = 0, CMD_ADD = 1, CMD_UNDO = 2, CMD_DONE = 3 };
 		constexpr int ACT_LDS = 2048;
 
