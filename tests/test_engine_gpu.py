@@ -520,6 +520,47 @@ def test_pool_step_with_device_network_is_deterministic_and_consistent(agx_lib):
     net.close()
 
 
+def test_full_size_pool_matches_a_small_pool_game_by_game(agx_lib):
+    """BASELINE configs[1] size (1024 games, 6x128 network, 400 playouts, batch 8, yielding on): games are independent, so every
+    game of the big pool must play exactly what the same opening plays in a 12-game pool without yielding (whose behaviour the
+    other tests pin to the oracle step by step) — a size-independent property checked at full size."""
+    from alphagomoku_amd import selfplay
+    from alphagomoku_amd.networks import AGNetwork
+    d = synthetic.net_desc(blocks=6, filters=128)
+    blob, _ = synthetic.make_weights(d)
+    net = AGNetwork(d)
+    net.loadWeights(blob)
+    openings = synthetic.make_openings(N, 1024, seed0=900)
+
+    def run(games, steps, yield_fraction):
+        pool = selfplay.GeneratorPool(selfplay.default_config(n_games=games, max_batch_size=8, max_simulations=400, tss_table_entries=1 << 16,
+                                                              node_capacity=4096, edge_capacity=131072, solver_yield_fraction=yield_fraction))
+        pool.begin(selfplay.pack_openings(openings[:games]))   # no spare openings: a finished game stays finished
+        for _ in range(steps):
+            pool.step(net)
+        st = pool.stats()
+        recs, edges = pool.records()
+        per_game = {}
+        for r in recs:
+            per_game.setdefault(r.game_serial, []).append((r.move_number, r.move, r.root_visits, r.n_edges,
+                                                           tuple((e.move, e.visits, e.score) for e in edges[r.edge_offset:r.edge_offset + r.n_edges])))
+        pool.close()
+        return st, {g: sorted(v) for g, v in per_game.items()}
+    big_stats, big = run(1024, 160, 0.75)
+    small_stats, small = run(12, 260, 0.0)
+    assert big_stats["first_error"] == 0 and small_stats["first_error"] == 0
+    assert big_stats["moves_played"] > 1024 and big_stats["evaluated_nodes"] > 1024 * 400
+    compared = 0
+    for g in range(12):
+        a, b = big.get(g, []), small.get(g, [])
+        k = min(len(a), len(b))
+        assert k >= 1, g
+        assert a[:k] == b[:k], g           # same moves, same root visit counts, same edge visits and scores
+        compared += k
+    assert compared >= 24
+    net.close()
+
+
 def test_engine_error_paths(agx_lib):
     from alphagomoku_amd import selfplay, AgxError
     with pytest.raises(AgxError):
