@@ -1,6 +1,7 @@
 """The CPU oracle against the known-answer cases of the reference's own unit tests (restated as data in
 tests/golden/ref_*_cases.json by tests/golden/extract_reference_fixtures.py): game rules incl. renju fouls, NN input
 bit layout, staged move generator (37 test functions)."""
+import ctypes
 import json
 import os
 
@@ -87,3 +88,36 @@ def test_move_generator(lib, case):
         other = run_movegen(lib, [c for c in MOVEGEN if c["name"] == case["equals"]][0])
         assert sorted(other["moves"]) == sorted(got["moves"])
         assert (other["must_defend"], other["has_initiative"], other["fully_expanded"]) == (got["must_defend"], got["has_initiative"], got["fully_expanded"])
+
+
+@pytest.mark.parametrize("rules", ["FREESTYLE", "STANDARD", "RENJU", "CARO5"])
+def test_augment_equals_encode_of_the_symmetric_board(lib, rules):
+    """The property test/networks/test_NNInputFeatures.cpp:234-279 checks for the reference: augmenting the features of a board
+    with symmetry s (cell permutation + direction-bit shuffle) gives the features of the symmetric board.  This is what pins the
+    direction shuffle of oracle/agoracle.hpp (its TU needs MinML, so it cannot be compiled) to the pinned feature encoder."""
+    rng = np.random.default_rng(11)
+    lib.ago_apply_symmetry.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    seen_directional = 0
+    for n in (12, 15):
+        for trial in range(12):
+            b = np.zeros((n, n), np.uint32)
+            # clustered stones so that threes and fours (the per-direction bits) actually occur
+            r, c = n // 2, n // 2
+            for k in range(int(rng.integers(6, 40))):
+                for _ in range(50):
+                    rr, cc = r + int(rng.integers(-2, 3)), c + int(rng.integers(-2, 3))
+                    if 0 <= rr < n and 0 <= cc < n and b[rr, cc] == 0:
+                        b[rr, cc] = 1 + (k & 1)
+                        r, c = rr, cc
+                        break
+            sign = 1 if int((b != 0).sum()) % 2 == 0 else 2
+            f = np.ascontiguousarray(ol.encode_features(lib, ol.RULES[rules], b.tolist(), sign).reshape(-1), dtype=np.uint32)
+            for s in range(8):
+                bs = np.zeros(n * n, np.uint32)
+                lib.ago_apply_symmetry(n, s, 0, ol.ptr(np.ascontiguousarray(b.reshape(-1))), ol.ptr(bs))
+                want = ol.encode_features(lib, ol.RULES[rules], bs.reshape(n, n).tolist(), sign).reshape(-1)
+                got = np.zeros(n * n, np.uint32)
+                lib.ago_apply_symmetry(n, s, 1, ol.ptr(f), ol.ptr(got))
+                assert np.array_equal(got, want), (rules, n, trial, s)
+                seen_directional += int(np.count_nonzero(want & 0x0FF0FF00))
+    assert seen_directional > 200   # the boards do carry per-direction threat bits, so the shuffle is exercised
