@@ -227,35 +227,6 @@ namespace agx
 		__device__ __forceinline__ uint32_t narrow(uint32_t x) { return (x & 1023u) | ((x & 4190208u) >> 2); }
 		__device__ __forceinline__ uint32_t threat_index(const uint8_t *pt) { return pt[0] | (pt[1] << 3) | (pt[2] << 6) | (pt[3] << 9); }
 
-		__device__ __forceinline__ void list_add(SolverShared &sh, int s, int t, int cell, int lane)
-		{ // ThreatHistogram::add (ThreatHistogram.hpp:101-111)
-			if (t != 0 && lane == 0)
-			{
-				const int cnt = sh.count[s][t];
-				sh.lists[s][t][cnt] = static_cast<uint16_t>(cell);
-				sh.count[s][t] = static_cast<uint16_t>(cnt + 1);
-			}
-		}
-		__device__ __forceinline__ void list_remove(SolverShared &sh, int s, int t, int cell, int lane)
-		{ // ThreatHistogram::remove (:39-99): first match is overwritten by the last element
-			if (t == 0)
-				return;
-			const int cnt = sh.count[s][t];
-			int found = -1;
-			for (int base = 0; base < cnt && found < 0; base += 64)
-			{
-				const int j = base + lane;
-				const u64 m = __ballot(j < cnt && sh.lists[s][t][j] == cell);
-				if (m != 0)
-					found = base + __ffsll(static_cast<long long>(m)) - 1;
-			}
-			if (found >= 0 && lane == 0)
-			{
-				sh.lists[s][t][found] = sh.lists[s][t][cnt - 1];
-				sh.count[s][t] = static_cast<uint16_t>(cnt - 1);
-			}
-		}
-
 		/* ThreatTable (4096 x 2 threat types < 16) packed to one byte per index: 4 KB of LDS instead of a second dependent L2 access
 		 * for every re-classified cell.  Once per launch, before the first solver_set_board. */
 		__device__ __forceinline__ void solver_load_threat_table(SolverShared &sh, const EngineDev &E, int lane)
@@ -349,7 +320,10 @@ namespace agx
 					{
 						const int cnt = sh.count[0][t];
 						if (t0 == t)
+						{
 							sh.lists[0][t][cnt + __popcll(m0 & lower)] = static_cast<uint16_t>(cell);
+							sh.lists[0][0][cell] = static_cast<uint16_t>(cnt + __popcll(m0 & lower));
+						}
 						wave_sync();
 						if (lane == 0)
 							sh.count[0][t] = static_cast<uint16_t>(cnt + __popcll(m0));
@@ -360,7 +334,10 @@ namespace agx
 					{
 						const int cnt = sh.count[1][t];
 						if (t1 == t)
+						{
 							sh.lists[1][t][cnt + __popcll(m1 & lower)] = static_cast<uint16_t>(cell);
+							sh.lists[1][0][cell] = static_cast<uint16_t>(cnt + __popcll(m1 & lower));
+						}
 						wave_sync();
 						if (lane == 0)
 							sh.count[1][t] = static_cast<uint16_t>(cnt + __popcll(m1));
@@ -380,10 +357,8 @@ namespace agx
 		/* PatternCalculator::update_around (PatternCalculator.cpp:278-367): the centre cell, then the +-5 cells in the four
 		 * directions in the order k = -5..5 (k != 0), direction 0..3 — one lane per (k, direction); lanes 40-43 re-classify the four
 		 * directions of the centre when a stone is removed.
-		 * The threat lists must end up in the reference's order (push-back add, swap-with-last remove, applied cell by cell), so the
-		 * list edits are applied one after the other — but with the 20 list sizes cached one per lane and the element to move taken
-		 * from the search's own registers, one edit costs a single LDS round trip.  LDS executes a wave's instructions in issue order,
-		 * so an edit sees the previous one without waiting for it. */
+		 * The threat lists must end up in the reference's order (push-back add, swap-with-last remove, applied cell by cell): see the
+		 * list-edit steps below. */
 		__device__ __forceinline__ void solver_update_around(SolverShared &sh, const EngineDev &E, int r, int c, bool added, int lane)
 		{
 			const int n = E.n;
@@ -398,22 +373,29 @@ namespace agx
 				const int ki = lane >> 2, d = lane & 3;
 				const int k = (ki < 5) ? ki - 5 : ki - 4;
 				const int rr = r + k * row_step(d), cc = c + k * col_step(d);
-				if (rr >= 0 && rr < n && cc >= 0 && cc < n && sh.board[rr * n + cc] == 0)
-				{
-					cell = rr * n + cc;
-					old0 = sh.threat[cell][0];
-					old1 = sh.threat[cell][1];
-					uint32_t w0 = *reinterpret_cast<const uint32_t*>(&sh.ptype[cell][0]); // cross, one byte per direction
-					uint32_t w1 = *reinterpret_cast<const uint32_t*>(&sh.ptype[cell][4]); // circle
-					const uint32_t e = E.t_pattern[narrow(normal_pattern(sh, n, rr, cc, d))];
-					w0 = (w0 & ~(255u << (8 * d))) | ((e & 15u) << (8 * d));
-					w1 = (w1 & ~(255u << (8 * d))) | ((e >> 4) << (8 * d));
-					sh.ptype[cell][d] = static_cast<uint8_t>(e & 15u);
-					sh.ptype[cell][4 + d] = static_cast<uint8_t>(e >> 4);
-					new0 = sh.threat_lut[(w0 & 7u) | (((w0 >> 8) & 7u) << 3) | (((w0 >> 16) & 7u) << 6) | (((w0 >> 24) & 7u) << 9)] & 15;
-					new1 = sh.threat_lut[(w1 & 7u) | (((w1 >> 8) & 7u) << 3) | (((w1 >> 16) & 7u) << 6) | (((w1 >> 24) & 7u) << 9)] >> 4;
-					sh.threat[cell][0] = static_cast<uint8_t>(new0);
-					sh.threat[cell][1] = static_cast<uint8_t>(new1);
+				if (rr >= 0 && rr < n && cc >= 0 && cc < n)
+				{ // every operand is requested before the first is looked at: one LDS round trip ahead of the table access, not two
+					const int at = rr * n + cc;
+					const int stone = sh.board[at];
+					const int t0 = sh.threat[at][0], t1 = sh.threat[at][1];
+					uint32_t w0 = *reinterpret_cast<const uint32_t*>(&sh.ptype[at][0]); // cross, one byte per direction
+					uint32_t w1 = *reinterpret_cast<const uint32_t*>(&sh.ptype[at][4]); // circle
+					const uint32_t raw = narrow(normal_pattern(sh, n, rr, cc, d));
+					if (stone == 0)
+					{
+						cell = at;
+						old0 = t0;
+						old1 = t1;
+						const uint32_t e = E.t_pattern[raw];
+						w0 = (w0 & ~(255u << (8 * d))) | ((e & 15u) << (8 * d));
+						w1 = (w1 & ~(255u << (8 * d))) | ((e >> 4) << (8 * d));
+						sh.ptype[cell][d] = static_cast<uint8_t>(e & 15u);
+						sh.ptype[cell][4 + d] = static_cast<uint8_t>(e >> 4);
+						new0 = sh.threat_lut[(w0 & 7u) | (((w0 >> 8) & 7u) << 3) | (((w0 >> 16) & 7u) << 6) | (((w0 >> 24) & 7u) << 9)] & 15;
+						new1 = sh.threat_lut[(w1 & 7u) | (((w1 >> 8) & 7u) << 3) | (((w1 >> 16) & 7u) << 6) | (((w1 >> 24) & 7u) << 9)] >> 4;
+						sh.threat[cell][0] = static_cast<uint8_t>(new0);
+						sh.threat[cell][1] = static_cast<uint8_t>(new1);
+					}
 				}
 			}
 			else if (lane < 44 && !added)
@@ -453,65 +435,60 @@ namespace agx
 			AGX_PROF_COUNT(sh, 13, __popcll(changed0) + __popcll(changed1));
 			AGX_PROF_COUNT(sh, 14, 1);
 
-			auto list_take = [&](int s, int t, int what)
-			{ // ThreatHistogram::remove (ThreatHistogram.hpp:39-99): the first match is overwritten by the last element
-				if (t == 0)
-					return;
-				const int size = __builtin_amdgcn_readlane(cnt, __builtin_amdgcn_readfirstlane(10 * s + t)); // v_readlane: the index is wave-uniform
-				for (int base = 0; base < size; base += 64)
+			/*
+			 * List edits.  ThreatHistogram::remove overwrites the first match with the last element, ThreatHistogram::add pushes back
+			 * (ThreatHistogram.hpp:39-111).  A cell sits in at most one list per side, so its index is kept in lists[side][0][cell]
+			 * (the list of type NONE does not exist) and a removal needs no search.  Lane 10 s + t owns list (s, t) and its size: one
+			 * step applies one cell's removal and insertion for BOTH sides at once (four different lists, four different lanes), in the
+			 * reference's order per list.  LDS executes a wave's instructions in issue order, so a step sees the previous one.
+			 */
+			const int my_s = (lane >= 10) ? 1 : 0;
+			const int my_t = (lane < 20) ? lane - 10 * my_s : -1;
+			auto edit = [&](int cell0, int o0, int n0, int cell1, int o1, int n1)
+			{
+				const int cl = my_s ? cell1 : cell0;
+				const int o = my_s ? o1 : o0, nw = my_s ? n1 : n0;
+				const bool take = (my_t == o) && (o != 0);
+				const bool put = (my_t == nw) && (nw != 0);
+				int idx = 0, last = 0;
+				if (take)
 				{
-					const int j = base + lane;
-					const int v = (j < size) ? sh.lists[s][t][j] : -1;
-					const u64 m = __ballot(v == what);
-					if (m != 0)
-					{
-						const int found = base + __ffsll(static_cast<long long>(m)) - 1;
-						const int last = (size - 1 >= base && size - 1 < base + 64) ? __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane((size - 1) & 63)) : static_cast<int>(sh.lists[s][t][size - 1]);
-						if (lane == 0)
-							sh.lists[s][t][found] = static_cast<uint16_t>(last);
-						if (lane == 10 * s + t)
-							cnt--;
-						break;
-					}
+					idx = sh.lists[my_s][0][cl];
+					last = sh.lists[my_s][my_t][cnt - 1];
+				}
+				if (take || put)
+				{
+					sh.lists[my_s][my_t][take ? idx : cnt] = static_cast<uint16_t>(take ? last : cl);
+					if (put || last != cl)
+						sh.lists[my_s][0][take ? last : cl] = static_cast<uint16_t>(take ? idx : cnt);
+					cnt += put ? 1 : -1;
 				}
 				__builtin_amdgcn_wave_barrier();
 			};
-			auto list_put = [&](int s, int t, int what)
-			{ // ThreatHistogram::add (:101-111)
-				if (t == 0)
-					return;
-				const int size = __builtin_amdgcn_readlane(cnt, __builtin_amdgcn_readfirstlane(10 * s + t)); // v_readlane: the index is wave-uniform
-				if (lane == 0)
-					sh.lists[s][t][size] = static_cast<uint16_t>(what);
-				if (lane == 10 * s + t)
-					cnt++;
-				__builtin_amdgcn_wave_barrier();
-			};
 			if (added)
-			{
-				list_take(0, c0, center);
-				list_take(1, c1, center);
-			}
+				edit(center, c0, 0, center, c1, 0);
 			else
+				edit(center, 0, c0, center, 0, c1);
+			while ((changed0 | changed1) != 0)
 			{
-				list_put(0, c0, center);
-				list_put(1, c1, center);
-			}
-			while (changed0 != 0)
-			{
-				const int src = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(changed0)) - 1);
-				changed0 &= changed0 - 1;
-				const int cc = __builtin_amdgcn_readlane(cell, src), o = __builtin_amdgcn_readlane(old0, src), nw = __builtin_amdgcn_readlane(new0, src);
-				list_take(0, o, cc);
-				list_put(0, nw, cc);
-			}
-			while (changed1 != 0)
-			{
-				const int src = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(changed1)) - 1);
-				changed1 &= changed1 - 1;
-				const int cc = __builtin_amdgcn_readlane(cell, src), o = __builtin_amdgcn_readlane(old1, src), nw = __builtin_amdgcn_readlane(new1, src);
-				list_take(1, o, cc);
-				list_put(1, nw, cc);
+				int cell0 = 0, o0 = 0, n0 = 0, cell1 = 0, o1 = 0, n1 = 0;
+				if (changed0 != 0)
+				{
+					const int src = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(changed0)) - 1);
+					changed0 &= changed0 - 1;
+					cell0 = __builtin_amdgcn_readlane(cell, src);
+					o0 = __builtin_amdgcn_readlane(old0, src);
+					n0 = __builtin_amdgcn_readlane(new0, src);
+				}
+				if (changed1 != 0)
+				{
+					const int src = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(changed1)) - 1);
+					changed1 &= changed1 - 1;
+					cell1 = __builtin_amdgcn_readlane(cell, src);
+					o1 = __builtin_amdgcn_readlane(old1, src);
+					n1 = __builtin_amdgcn_readlane(new1, src);
+				}
+				edit(cell0, o0, n0, cell1, o1, n1);
 			}
 			if (lane < 20)
 				sh.count[lane / 10][lane % 10] = static_cast<uint16_t>(cnt);
