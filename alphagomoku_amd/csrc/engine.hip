@@ -517,8 +517,8 @@ namespace
 					e_draw[i] = d;
 				}
 				__syncthreads();
-				if (path_len > 0 && s_proven(score))
-				{ // prune_weak_moves, proven branch (:55-68): keep the best-scored edges in their original order
+				if ((path_len > 0 || E.match_mode) && s_proven(score))
+				{ // the root is exempt in self-play only (forceExpandRoot: GameGenerator.cpp:183-184, Player.cpp:111); prune_weak_moves, proven branch (:55-68): keep the best-scored edges in their original order
 					uint32_t best = s_loss_in(0);
 					for (int i = lane; i < n_e; i += 64)
 						best = max(best, static_cast<uint32_t>(e_score[i]));
@@ -546,7 +546,7 @@ namespace
 					}
 					n_e = kept;
 				}
-				else if (path_len > 0 && n_e > E.max_children && (flags & TF_MUST_DEFEND) == 0)
+				else if ((path_len > 0 || E.match_mode) && n_e > E.max_children && (flags & TF_MUST_DEFEND) == 0)
 				{ // prune_weak_moves, unproven branch (:69-83): the max_children best edges by EdgeComparator<MaxPolicyPrior>
 				  // (Edge.hpp:156-172: proven scores first, then prior), then those whose prior reaches threshold * (their prior sum).
 				  // std::partial_sort leaves the order of equal keys unspecified; here (and in the oracle) equal keys keep edge order.
@@ -817,11 +817,8 @@ namespace
 		v = scratch[0] ^ scratch[1] ^ scratch[2] ^ scratch[3];
 		__syncthreads();
 	}
-	__device__ void clear_tree_and_table(const EngineDev &E, int g, int tid)
-	{ // Tree::clear + AlphaBetaSearch::clear (GameGenerator.cpp:52-53, SharedHashTable.hpp:137-140)
-		int *ht = ht_of(E, g);
-		for (int i = tid; i < E.ht_cap; i += 256)
-			ht[i] = 0;
+	__device__ void clear_solver_table(const EngineDev &E, int g, int tid)
+	{ // AlphaBetaSearch::clear (SharedHashTable.hpp:137-140)
 		ulonglong2 *tt = reinterpret_cast<ulonglong2*>(E.tt + static_cast<size_t>(g) * (E.tt_bucket_mask + 1ull) * 8ull);
 		const size_t entries = (E.tt_bucket_mask + 1ull) * 4ull;
 		ulonglong2 empty;
@@ -829,6 +826,13 @@ namespace
 		empty.y = tt_pack(0, 0, s_unknown(0), 0);
 		for (size_t i = tid; i < entries; i += 256)
 			tt[i] = empty;
+	}
+	__device__ void clear_tree_and_table(const EngineDev &E, int g, int tid)
+	{ // Tree::clear + AlphaBetaSearch::clear (GameGenerator.cpp:52-53)
+		int *ht = ht_of(E, g);
+		for (int i = tid; i < E.ht_cap; i += 256)
+			ht[i] = 0;
+		clear_solver_table(E, g, tid);
 	}
 	/* loads opening `id` into game g: Game::loadOpening + prepare_search on an empty tree (GameGenerator.cpp:48-77,174-185) */
 	__device__ void begin_game(const EngineDev &E, int g, int id, int tid, u64 *scratch)
@@ -881,6 +885,95 @@ namespace
 		__syncthreads();
 	}
 
+	/*
+	 * prepare_search / Player::setBoard for tree t on the position in its GameState (GameGenerator.cpp:174-185, Player.cpp:98-110):
+	 * NodeCache::cleanup (NodeCache.cpp:221-249) as keep-test + prefix sum + copy to the other arena, Search::setBoard
+	 * (increaseGeneration), Tree::setBoard (root = seek(new board), Tree.cpp:146-149).  Whole 256-thread workgroup.
+	 */
+	__device__ void rebase_tree(const EngineDev &E, int t, int tid, u64 *scratch, int *scan_nodes, int *scan_edges)
+	{
+		GameState &gs = E.games[t];
+		const int lane = tid & 63, wave = tid >> 6;
+		DNode *nodes = nodes_of(E, t, gs.arena);
+		DEdge *edges = edges_of(E, t, gs.arena);
+		DNode *dst_nodes = nodes_of(E, t, gs.arena ^ 1);
+		DEdge *dst_edges = edges_of(E, t, gs.arena ^ 1);
+		int *ht = ht_of(E, t);
+		for (int i = tid; i < E.ht_cap; i += 256)
+			ht[i] = 0;
+		const int total = gs.n_nodes;
+		int node_base = 0, edge_base = 0;
+		__syncthreads();
+		for (int base = 0; base < total; base += 256)
+		{
+			const int i = base + tid;
+			int keep = 0, ne = 0;
+			if (i < total)
+			{
+				keep = 1;
+				for (int w = 0; w < BWORDS; w++)
+				{ // isTransitionPossibleFrom (NodeCache.cpp:95-115): every stone of the new position must be present
+					const u64 from = gs.cboard[w], to = nodes[i].cboard[w];
+					if (((from ^ to) & from) != 0)
+						keep = 0;
+				}
+				ne = keep ? nodes[i].n_edges : 0;
+			}
+			scan_nodes[tid] = keep;
+			scan_edges[tid] = ne;
+			__syncthreads();
+			for (int o = 1; o < 256; o <<= 1)
+			{ // inclusive Hillis-Steele scan
+				const int a = (tid >= o) ? scan_nodes[tid - o] : 0, b = (tid >= o) ? scan_edges[tid - o] : 0;
+				__syncthreads();
+				scan_nodes[tid] += a;
+				scan_edges[tid] += b;
+				__syncthreads();
+			}
+			if (keep)
+			{
+				const int ni = node_base + scan_nodes[tid] - 1, eb = edge_base + scan_edges[tid] - ne;
+				DNode nd = nodes[i];
+				for (int j = 0; j < nd.n_edges; j++)
+					dst_edges[eb + j] = edges[nd.edge_begin + j];
+				nd.edge_begin = eb;
+				dst_nodes[ni] = nd;
+				// re-insert (atomic linear probing; slot order is irrelevant to lookups)
+				const int mask = E.ht_cap - 1;
+				int slot = static_cast<int>(nd.hash & static_cast<u64>(mask));
+				while (atomicCAS(&ht[slot], 0, ni + 1) != 0)
+					slot = (slot + 1) & mask;
+			}
+			node_base += scan_nodes[255];
+			edge_base += scan_edges[255];
+			__syncthreads();
+		}
+		u64 h = 0;
+		for (int i = tid; i < E.hw; i += 256)
+			h ^= E.nc_keys[3 + 3 * i + gs.board[i]];
+		block_reduce_xor(h, scratch, tid);
+		if (tid == 0)
+		{
+			gs.root_hash = h ^ E.nc_keys[gs.sign_to_move];
+			gs.n_nodes = node_base;
+			gs.n_edges = edge_base;
+			gs.arena ^= 1;
+			gs.generation = (gs.generation + 1) % 64;
+		}
+		__syncthreads();
+		if (wave == 0)
+		{ // Tree::setBoard: root = seek(new board) (Tree.cpp:146-149)
+			const int found = cache_seek(E, dst_nodes, ht, gs.root_hash, gs.cboard, gs.sign_to_move, lane);
+			if (lane == 0)
+			{
+				gs.root = found;
+				if (found >= 0)
+					dst_nodes[found].flags |= 2;
+			}
+		}
+		__syncthreads();
+	}
+
 	__global__ __launch_bounds__(256) void k_begin(EngineDev E)
 	{
 		__shared__ u64 scratch[4];
@@ -898,7 +991,25 @@ namespace
 				gs.stats[i] = 0;
 		}
 		__syncthreads();
-		if (sh_id < E.n_openings)
+		if (E.match_mode)
+		{ // every pair starts through k_assign_openings / k_match_restart: empty trees, the first players' trees ask for openings
+			clear_tree_and_table(E, g, tid);
+			if (tid == 0)
+			{
+				gs.active = 0;
+				gs.root = -1;
+				gs.n_nodes = 0;
+				gs.n_edges = 0;
+				gs.n_tasks = 0;
+				gs.need_move = 0;
+				gs.solve_pos = 0;
+				gs.solve_pending = 0;
+				gs.outcome = 0;
+				gs.n_moves = 0;
+				gs.restart_id = (g < E.n_games / 2) ? -1 : 0;
+			}
+		}
+		else if (sh_id < E.n_openings)
 			begin_game(E, g, sh_id, tid, scratch);
 		else if (tid == 0)
 		{
@@ -1092,84 +1203,47 @@ namespace
 			}
 		}
 		__syncthreads();
+		if (E.match_mode)
+		{ // EvaluationGame.cpp:126-143: the move goes into the shared game, the OTHER player gets setBoard; this tree is left as it
+		  // is until its player's next turn (two plies on)
+			const int p = (g + E.n_games / 2) % E.n_games;
+			GameState &ps = E.games[p];
+			for (int i = tid; i < E.hw; i += 256)
+				ps.board[i] = gs.board[i];
+			if (tid < BWORDS)
+				ps.cboard[tid] = gs.cboard[tid];
+			if (tid == 0)
+			{
+				ps.moves[gs.n_moves - 1] = static_cast<uint16_t>(mv);
+				ps.n_moves = gs.n_moves;
+				ps.sign_to_move = gs.sign_to_move;
+				ps.outcome = sh_int[2];
+				gs.active = 0;
+				if (sh_int[2] != 0)
+				{ // both trees wait; the first player's tree carries the restart request of the pair
+					ps.games_done++;
+					GameState &lead = E.games[min(g, p)];
+					GameState &part = E.games[max(g, p)];
+					part.restart_id = 0;
+					// a match is two games on one opening with the colours swapped (EvaluationGame.cpp:44-71): after the first game the
+					// pair starts again from the same opening, after the second it waits for a new one
+					lead.restart_id = (lead.games_done % 2 == 1) ? lead.opening_id + 1 : -1;
+				}
+				else
+				{
+					ps.active = 1;
+					ps.need_move = 0;
+					ps.noise_ready = 0;
+				}
+			}
+			__syncthreads();
+			if (sh_int[2] == 0)
+				rebase_tree(E, p, tid, scratch, scan_nodes, scan_edges);
+			return;
+		}
 		if (sh_int[2] != 0)
 			return;
-
-		// ---- prepare_search: NodeCache::cleanup (NodeCache.cpp:221-249) as keep-test + prefix sum + copy to the other arena ----
-		DNode *dst_nodes = nodes_of(E, g, gs.arena ^ 1);
-		DEdge *dst_edges = edges_of(E, g, gs.arena ^ 1);
-		int *ht = ht_of(E, g);
-		for (int i = tid; i < E.ht_cap; i += 256)
-			ht[i] = 0;
-		const int total = gs.n_nodes;
-		int node_base = 0, edge_base = 0;
-		for (int base = 0; base < total; base += 256)
-		{
-			const int i = base + tid;
-			int keep = 0, ne = 0;
-			if (i < total)
-			{
-				keep = 1;
-				for (int w = 0; w < BWORDS; w++)
-				{ // isTransitionPossibleFrom (NodeCache.cpp:95-115): every stone of the new position must be present
-					const u64 from = gs.cboard[w], to = nodes[i].cboard[w];
-					if (((from ^ to) & from) != 0)
-						keep = 0;
-				}
-				ne = keep ? nodes[i].n_edges : 0;
-			}
-			scan_nodes[tid] = keep;
-			scan_edges[tid] = ne;
-			__syncthreads();
-			for (int o = 1; o < 256; o <<= 1)
-			{ // inclusive Hillis-Steele scan
-				const int a = (tid >= o) ? scan_nodes[tid - o] : 0, b = (tid >= o) ? scan_edges[tid - o] : 0;
-				__syncthreads();
-				scan_nodes[tid] += a;
-				scan_edges[tid] += b;
-				__syncthreads();
-			}
-			if (keep)
-			{
-				const int ni = node_base + scan_nodes[tid] - 1, eb = edge_base + scan_edges[tid] - ne;
-				DNode nd = nodes[i];
-				for (int j = 0; j < nd.n_edges; j++)
-					dst_edges[eb + j] = edges[nd.edge_begin + j];
-				nd.edge_begin = eb;
-				dst_nodes[ni] = nd;
-				// re-insert (atomic linear probing; slot order is irrelevant to lookups)
-				const int mask = E.ht_cap - 1;
-				int slot = static_cast<int>(nd.hash & static_cast<u64>(mask));
-				while (atomicCAS(&ht[slot], 0, ni + 1) != 0)
-					slot = (slot + 1) & mask;
-			}
-			node_base += scan_nodes[255];
-			edge_base += scan_edges[255];
-			__syncthreads();
-		}
-		u64 h = 0;
-		for (int i = tid; i < E.hw; i += 256)
-			h ^= E.nc_keys[3 + 3 * i + gs.board[i]];
-		block_reduce_xor(h, scratch, tid);
-		if (tid == 0)
-		{
-			gs.root_hash = h ^ E.nc_keys[gs.sign_to_move];
-			gs.n_nodes = node_base;
-			gs.n_edges = edge_base;
-			gs.arena ^= 1;
-			gs.generation = (gs.generation + 1) % 64;
-		}
-		__syncthreads();
-		if (wave == 0)
-		{ // Tree::setBoard: root = seek(new board) (Tree.cpp:146-149)
-			const int found = cache_seek(E, dst_nodes, ht, gs.root_hash, gs.cboard, gs.sign_to_move, lane);
-			if (lane == 0)
-			{
-				gs.root = found;
-				if (found >= 0)
-					dst_nodes[found].flags |= 2;
-			}
-		}
+		rebase_tree(E, g, tid, scratch, scan_nodes, scan_edges);
 	}
 
 	/*
@@ -1253,6 +1327,68 @@ namespace
 			return;
 		__syncthreads();
 		begin_game(E, g, id - 1, tid, scratch);
+	}
+
+	/*
+	 * Match mode: one workgroup per pair.  EvaluationGame.cpp:77-106: both solvers are cleared, the opening is loaded into the
+	 * shared game, the first player takes cross in the first game of a match and circle in the second, and only the player to
+	 * move gets setBoard — on a tree that still holds its previous game (Player keeps its Tree; what the new position cannot reach
+	 * is dropped by the cleanup inside setBoard).
+	 */
+	__global__ __launch_bounds__(256) void k_match_restart(EngineDev E)
+	{
+		__shared__ u64 scratch[4];
+		__shared__ int scan_nodes[256], scan_edges[256];
+		const int lead = blockIdx.x, part = lead + E.n_games / 2, tid = threadIdx.x;
+		const int id = E.games[lead].restart_id - 1;
+		if (id < 0)
+			return;
+		__syncthreads();
+		const uint16_t *op = E.openings + static_cast<size_t>(id) * OPENING_CAP;
+		const int count = op[0];
+		for (int k = 0; k < 2; k++)
+		{
+			const int t = k ? part : lead;
+			GameState &gs = E.games[t];
+			clear_solver_table(E, t, tid);
+			for (int i = tid; i < E.hw; i += 256)
+				gs.board[i] = 0;
+			if (tid < BWORDS)
+				gs.cboard[tid] = 0;
+			__syncthreads();
+			if (tid == 0)
+			{
+				int sign = 1;
+				for (int i = 0; i < count; i++)
+				{
+					const uint32_t mv = op[1 + i];
+					const int cell = ((mv >> 2) & 127) * E.n + ((mv >> 9) & 127);
+					gs.board[cell] = static_cast<uint8_t>(mv & 3);
+					gs.cboard[cell >> 5] |= static_cast<u64>(mv & 3) << (2 * (cell & 31));
+					gs.moves[i] = static_cast<uint16_t>(mv);
+					sign = 3 - static_cast<int>(mv & 3);
+				}
+				gs.sign_to_move = sign;
+				gs.n_moves = count;
+				gs.outcome = 0;
+				gs.n_tasks = 0;
+				gs.need_move = 0;
+				gs.solve_pos = 0;
+				gs.solve_pending = 0;
+				gs.nn_queued = 0;
+				gs.restart_id = 0;
+				gs.noise_ready = 0;
+				gs.opening_id = id;
+				gs.active = 0;
+				const int lead_sign = (E.games[lead].games_done % 2 == 0) ? 1 : 2;
+				gs.my_sign = k ? 3 - lead_sign : lead_sign;
+			}
+			__syncthreads();
+		}
+		const int mover = (E.games[lead].sign_to_move == E.games[lead].my_sign) ? lead : part;
+		rebase_tree(E, mover, tid, scratch, scan_nodes, scan_edges);
+		if (tid == 0)
+			E.games[mover].active = 1;
 	}
 
 	__global__ void k_reset_counter(int *counter, int *second)
@@ -1470,6 +1606,7 @@ int agx_engine_default_config(AgxEngineConfig *cfg)
 	cfg->use_symmetries = 0;
 	cfg->symmetry_seed = 0x5DEECE66Dull;
 	cfg->action_values = 0;
+	cfg->match_mode = 0;
 	cfg->noise_type = 0;
 	cfg->noise_weight = 0.0f;
 	cfg->noise_seed = 0x2545F4914F6CDD1Dull;
@@ -1487,6 +1624,7 @@ int agx_engine_create(const AgxEngineConfig *cfg, AgxEngine **out)
 	AGX_REQUIRE(cfg->solver_yield_fraction >= 0.0f && cfg->solver_yield_fraction <= 1.0f, AGX_ERR_INVALID, "agx_engine_create: solver_yield_fraction must be in [0, 1]");
 	AGX_REQUIRE(cfg->final_selector >= 0 && cfg->final_selector <= 5, AGX_ERR_INVALID, "agx_engine_create: final_selector must be 0..5");
 	AGX_REQUIRE(cfg->noise_type >= 0 && cfg->noise_type <= 3, AGX_ERR_INVALID, "agx_engine_create: noise_type must be 0 (none), 1 (custom), 2 (dirichlet) or 3 (gumbel)");
+	AGX_REQUIRE(!cfg->match_mode || cfg->n_games % 2 == 0, AGX_ERR_INVALID, "agx_engine_create: match_mode pairs the trees, n_games must be even");
 	AGX_REQUIRE(cfg->noise_weight >= 0.0f && cfg->noise_weight <= 1.0f, AGX_ERR_INVALID, "agx_engine_create: noise_weight must be in [0, 1]");
 
 	AgxEngine *e = new AgxEngine();
@@ -1556,6 +1694,7 @@ int agx_engine_create(const AgxEngineConfig *cfg, AgxEngine **out)
 	AGX_TRY(dev_alloc(e, &d.nn_policy, G * d.batch * d.hw));
 	AGX_TRY(dev_alloc(e, &d.nn_value, G * d.batch * 3));
 	d.has_q = cfg->action_values ? 1 : 0;
+	d.match_mode = cfg->match_mode ? 1 : 0;
 	AGX_TRY(dev_alloc(e, &d.nn_q, d.has_q ? G * d.batch * d.hw * 2 : 1));
 	AGX_TRY(dev_alloc(e, &d.noise, d.noise_type ? G * d.hw : 1));
 	AGX_TRY(dev_alloc(e, &d.nn_list, G * d.batch));
@@ -1612,10 +1751,17 @@ int agx_engine_begin(AgxEngine *e, const uint16_t *h_openings, int n_openings, v
 	e->dev.openings = d_op;
 	e->dev.n_openings = n_openings;
 	int counters[64] = { 0 };
-	counters[1] = e->dev.n_games;
+	counters[1] = e->dev.match_mode ? 0 : e->dev.n_games;
 	AGX_HIP_CHECK(hipMemcpy(e->dev.counters, counters, sizeof(counters), hipMemcpyHostToDevice));
 	hipStream_t s = static_cast<hipStream_t>(stream);
 	hipLaunchKernelGGL(k_begin, dim3(e->dev.n_games), dim3(256), 0, s, e->dev);
+	if (e->dev.match_mode)
+	{ // the pairs take openings 0 .. n_games/2 - 1 in order, exactly as they will after finished matches
+		EngineDev d = e->dev;
+		d.g0 = 0;
+		hipLaunchKernelGGL(k_assign_openings, dim3(1), dim3(1024), 0, s, d, d.n_games / 2);
+		hipLaunchKernelGGL(k_match_restart, dim3(d.n_games / 2), dim3(256), 0, s, d);
+	}
 	AGX_HIP_CHECK(hipGetLastError());
 	e->begun = true;
 	return AGX_OK;
@@ -1730,6 +1876,7 @@ int agx_engine_expand_backup_group(AgxEngine *e, int group, int n_groups, void *
 	const int st = group_range(e, group, n_groups, d, count);
 	if (st != AGX_OK)
 		return st;
+	AGX_REQUIRE(!d.match_mode || n_groups == 2, AGX_ERR_INVALID, "agx_engine_expand_backup: a match-mode engine is stepped as two groups (first players, second players)");
 	hipStream_t s = static_cast<hipStream_t>(stream);
 	{
 		KernelTimer t(e, s, 2);
@@ -1738,8 +1885,16 @@ int agx_engine_expand_backup_group(AgxEngine *e, int group, int n_groups, void *
 	{
 		KernelTimer t(e, s, 3);
 		hipLaunchKernelGGL(k_advance, dim3(count), dim3(256), 0, s, d);
-		hipLaunchKernelGGL(k_assign_openings, dim3(1), dim3(1024), 0, s, d, count);
-		hipLaunchKernelGGL(k_restart, dim3(count), dim3(256), 0, s, d);
+		if (!d.match_mode)
+		{
+			hipLaunchKernelGGL(k_assign_openings, dim3(1), dim3(1024), 0, s, d, count);
+			hipLaunchKernelGGL(k_restart, dim3(count), dim3(256), 0, s, d);
+		}
+		else if (group == 0)
+		{ // restarts go by pair, requested through the first players' trees (= group 0)
+			hipLaunchKernelGGL(k_assign_openings, dim3(1), dim3(1024), 0, s, d, count);
+			hipLaunchKernelGGL(k_match_restart, dim3(count), dim3(256), 0, s, d);
+		}
 	}
 	AGX_HIP_CHECK(hipGetLastError());
 	return AGX_OK;

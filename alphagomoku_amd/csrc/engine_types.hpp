@@ -103,7 +103,7 @@ namespace agx
 			int32_t solve_pending; // 1 while the batch is only partly solved: the game sits out select / network / expand until it is done
 			int32_t nn_queued;     // positions handed to the network so far in this game (index of the symmetry hash)
 			int32_t noise_ready;   // 1 once the root noise of the current move has been drawn (a fresh selector per move in the reference)
-			int32_t pad;
+			int32_t my_sign;       // match mode: the colour this tree's player has in the current game (evaluation/EvaluationGame.cpp:59-71)
 			int32_t restart_id;    // 0: playing; -1: the game is over and waits for an opening; k > 0: it starts again from opening k - 1 in k_restart
 			uint64_t root_hash;
 			uint64_t cboard[BWORDS];
@@ -180,6 +180,7 @@ namespace agx
 			float *nn_value;       // [game*batch][3]
 			float *nn_q;           // [game*batch][hw][2] action values (win, draw) per cell, 'pvq' networks only
 			int has_q;
+			int match_mode;  // evaluation matches: tree g (first player) and tree g + n_games / 2 (second player) share one game
 			int *nn_list;          // compacted slots to evaluate
 			int *counters;         // [0] (unused), [1] next opening, [2] finished games, [3] records used, [4] record edges used, [5] total moves, [16 + group] positions scheduled for the network by that group
 			// output records

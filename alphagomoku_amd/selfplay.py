@@ -86,6 +86,21 @@ class GeneratorPool:
         slots = slots[:n]
         return slots, feats[slots]
 
+    def scheduled_group(self, group, n_groups):
+        """scheduled() for one group of a pool stepped in groups (slot numbers are pool-wide)"""
+        check(lib.agx_device_synchronize())
+        per = (self.cfg.n_games + n_groups - 1) // n_groups
+        count = np.zeros(1, np.int32)
+        check(lib.agx_memcpy_d2h(count.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(self.buffers.d_nn_count + 4 * group), 4))
+        n = int(count[0])
+        slots = np.zeros(max(n, 1), np.int32)
+        first = group * per * self.cfg.max_batch_size
+        check(lib.agx_memcpy_d2h(slots.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(self.buffers.d_nn_list + 4 * first), 4 * max(n, 1)))
+        feats = np.zeros((self.slots, self.cells), np.uint32)
+        check(lib.agx_memcpy_d2h(feats.ctypes.data_as(ctypes.c_void_p), self.buffers.d_nn_features, feats.nbytes))
+        slots = slots[:n]
+        return slots, feats[slots]
+
     def provide(self, slots, policy, value3, action_values=None):
         """writes policy [n][cells] and value (win, draw, loss) [n][3] of the given slots (and, for a pool configured with
         action_values, q (win, draw) [n][cells][2])"""

@@ -148,6 +148,13 @@ typedef struct AgxEngineConfig
 	                                     action-values head and new edges start from those values (initialize_edges, EdgeGenerator.cpp:
 	                                     119-124) — what the default init_to = "q_head" selector reads.  0: 'pv' network, edges start
 	                                     at (0, 0) exactly as the reference's zero-filled 'q' tensor gives (NetworkDataPack.cpp:122-126). */
+	int match_mode;                   /* 1: evaluation matches (evaluation/EvaluationGame.cpp, evaluation/Player.cpp).  n_games must be even:
+	                                     tree g < n_games/2 belongs to the first player of match g, tree g + n_games/2 to the second player;
+	                                     both see one game and a tree searches only on its own player's turns (Player::setBoard jumps two
+	                                     plies; trees persist across games, the solver table is cleared per game; the root is pruned like
+	                                     any other node, UnifiedGenerator's forceExpandRoot = false).  Every opening is played twice with
+	                                     the colours swapped.  Drive it with two groups on ONE stream, each with its own network:
+	                                     agx_engine_step_group(e, first_net, 0, 2, s); agx_engine_step_group(e, second_net, 1, 2, s). */
 } AgxEngineConfig;
 
 typedef struct AgxEngine AgxEngine; /* opaque */

@@ -453,6 +453,38 @@ void ago_game_begin(void *h, const uint16_t *opening, int n)
 		o.push_back(Move::from_short(opening[i]));
 	static_cast<GameHandle*>(h)->game.begin(o);
 }
+/* ---- evaluation match: one handle per Player (own tree + solver), the game is mirrored by external moves ---- */
+void ago_game_set_force_expand_root(void *h, int value)
+{ // UnifiedGenerator's forceExpandRoot: 1 self-play (default), 0 evaluation Player (Player.cpp:111)
+	GameHandle *g = static_cast<GameHandle*>(h);
+	g->game.scfg.force_expand_root = value;
+	g->game.tree.scfg.force_expand_root = value;
+	g->game.search.scfg.force_expand_root = value;
+}
+void ago_game_match_begin(void *h, const uint16_t *opening, int n)
+{
+	std::vector<Move> o;
+	for (int i = 0; i < n; i++)
+		o.push_back(Move::from_short(opening[i]));
+	static_cast<GameHandle*>(h)->game.match_begin(o);
+}
+void ago_game_take_turn(void *h)
+{
+	static_cast<GameHandle*>(h)->game.take_turn();
+}
+void ago_game_external_move(void *h, int move)
+{
+	static_cast<GameHandle*>(h)->game.external_move(Move::from_short(static_cast<uint16_t>(move)));
+}
+int ago_game_last_move(void *h)
+{
+	const Game &g = static_cast<GameHandle*>(h)->game;
+	return g.moves.empty() ? -1 : static_cast<int>(g.moves.back().to_short());
+}
+int ago_game_sign_to_move(void *h)
+{
+	return static_cast<int>(static_cast<GameHandle*>(h)->game.sign_to_move);
+}
 /* returns number of positions to evaluate; features copied to out (capacity in positions) */
 int ago_game_step_select(void *h, uint32_t *features_out, int capacity)
 {

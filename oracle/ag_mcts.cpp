@@ -326,7 +326,7 @@ namespace ago
 			e.value = t.action_values[i];
 			e.score = t.action_scores[i];
 		}
-		const bool expand_fully = t.path.empty(); // relative depth 0 and force_expand_root == true (GameGenerator.cpp:183-184)
+		const bool expand_fully = t.path.empty() && scfg.force_expand_root != 0; // relative depth 0 and force_expand_root == true (GameGenerator.cpp:183-184)
 		if (!expand_fully)
 		{ // prune_weak_moves (:49-86)
 			size_t idx = 0;
@@ -688,11 +688,43 @@ namespace ago
 		if (tree.simulation_count() > simulations || tree.root_proven())
 		{
 			make_move();
-			if (outcome == O_UNKNOWN)
+			if (external_opponent)
+				awaiting = true; // EvaluationGame.cpp:126-143: the OTHER player's setBoard follows, this one waits for its next turn
+			else if (outcome == O_UNKNOWN)
 				prepare_search();
 			return 1;
 		}
 		return 0;
+	}
+	void Game::match_begin(const std::vector<Move> &opening)
+	{ // EvaluationGame.cpp:77-106: getSolver().clear(), newGame(), loadOpening; only the player to move gets setBoard (take_turn)
+		external_opponent = true;
+		awaiting = true;
+		std::fill(board.begin(), board.end(), NONE);
+		moves.clear();
+		records.clear();
+		outcome = O_UNKNOWN;
+		queued = 0;
+		search.solver.clear();
+		for (const Move &m : opening)
+		{
+			board[m.row * cfg.cols + m.col] = m.sign;
+			moves.push_back(m);
+		}
+		sign_to_move = moves.empty() ? CROSS : invert_sign(moves.back().sign);
+	}
+	void Game::take_turn()
+	{ // Player::setBoard (Player.cpp:98-110): cleanup, Tree::setBoard on the current board (two plies ahead of this player's last
+	  // search), Search::setBoard -> increaseGeneration, fresh selector
+		prepare_search();
+		awaiting = false;
+	}
+	void Game::external_move(Move m)
+	{ // Game::makeMove (game/Game.cpp:104-122) by the other player
+		board[m.row * cfg.cols + m.col] = m.sign;
+		moves.push_back(m);
+		sign_to_move = invert_sign(m.sign);
+		outcome = get_outcome(cfg.rules, board.data(), cfg.rows, cfg.cols, m, cfg.draw_after);
 	}
 	void Game::make_move()
 	{ // GameGenerator.cpp:145-173

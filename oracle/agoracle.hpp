@@ -380,6 +380,8 @@ namespace ago
 			int noise_type = 0;              // EdgeSelectorConfig::noise_type: 0 "none", 1 "custom", 2 "dirichlet", 3 "gumbel" (EdgeSelector.cpp:602-623; oracle/ag_noise.hpp)
 			float noise_weight = 0.0f;
 			uint64_t noise_seed = 0x2545F4914F6CDD1Dull;
+			int force_expand_root = 1;       // UnifiedGenerator's 4th argument: true in self-play (GameGenerator.cpp:183-184), default false for an
+			                                 // evaluation Player (Player.cpp:111, EdgeGenerator.hpp:59)
 	};
 
 	bool is_straight_four_at(const Calc &pc, int r, int c, Direction d); // RawPatternCalculator.hpp:142-178
@@ -533,6 +535,13 @@ namespace ago
 			int serial = 0;      // identifies the game in the symmetry hash (the device uses the opening id)
 			int queued = 0;      // positions handed to the network so far in this game
 			void begin(const std::vector<Move> &opening);
+			/* evaluation match (evaluation/EvaluationGame.cpp:77-146, evaluation/Player.cpp:98-110,210-216): the game is shared by two
+			 * Players, each with its own tree and solver; a Player searches only on its own turns */
+			bool external_opponent = false; // after its own move the player waits for the opponent's instead of searching on
+			bool awaiting = false;
+			void match_begin(const std::vector<Move> &opening); // GAME_NOT_STARTED + loadOpening: the solver is cleared, the tree is NOT
+			void take_turn();                                   // Player::setBoard
+			void external_move(Move m);                         // the opponent's Game::makeMove, seen by this player's copy of the game
 			/* phase 1: select + solve; returns the number of tasks that need evaluation and their features */
 			int step_select(std::vector<uint32_t> &features_out);
 			/* phase 2: policy [n][HW], value (win, draw) [n][2] for the scheduled tasks, in schedule order; returns 1 if a move was made */

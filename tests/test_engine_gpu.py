@@ -664,3 +664,154 @@ def test_wave_reduction_helpers(agx_lib, tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0
     assert out.stdout.strip().splitlines()[-1] == "bad: umax 0 add 0 xor 0 scan 0 argmax value 0 index 0", out.stdout
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# evaluation matches: two players, two networks, one game per pair of trees
+
+
+def _second_evaluator(olib, hw=HW):
+    """a different deterministic 'network' for the second player: sharper policy, shifted value"""
+    base = _stand_in_evaluator(olib, hw)
+
+    def f(feats):
+        pol, val = base(feats)
+        pol = (pol * pol).astype(np.float32)
+        s = pol.sum(1, keepdims=True, dtype=np.float32)
+        pol = np.where(s > 0, pol / np.where(s > 0, s, 1), np.float32(1.0 / hw)).astype(np.float32)
+        val = np.stack([np.float32(0.9) * val[:, 0] + np.float32(0.05), np.float32(0.5) * val[:, 1]], 1).astype(np.float32)
+        return pol, val
+    return f
+
+
+def _play_matches_and_compare(olib, rules, pairs, n_openings, batch, sims, max_steps, max_children=0, n=N, draw_after=0):
+    from alphagomoku_amd import selfplay
+    N, HW = n, n * n   # noqa: N806
+    cfg = selfplay.default_config(rules=rules, board_size=n, draw_after=draw_after if draw_after > 0 else n * n, n_games=2 * pairs, max_batch_size=batch,
+                                  max_simulations=sims, tss_table_entries=1 << 16, node_capacity=4096, edge_capacity=65536, match_mode=1,
+                                  max_children=max_children)
+    pool = selfplay.GeneratorPool(cfg)
+    ocfg = ol.default_search_config(max_batch_size=batch, max_simulations=sims, table_entries=1 << 16)
+    if max_children > 0:
+        ocfg.max_children = max_children
+    evaluators = [_stand_in_evaluator(olib, HW), _second_evaluator(olib, HW)]
+    openings = []
+    for g in range(n_openings):
+        op = np.zeros(64, np.uint16)
+        k = olib.ago_prepare_opening(rules, N, N, 500 + g, ol.ptr(op))
+        openings.append([int(x) for x in op[:k]])
+    players = []   # [pair][0 first / 1 second player]
+    for m in range(pairs):
+        hs = []
+        for _ in range(2):
+            h = olib.ago_game_create_ex(rules, N, N, draw_after, ctypes.byref(ocfg))
+            olib.ago_game_set_force_expand_root(h, 0)   # Player::setBoard builds UnifiedGenerator without forceExpandRoot
+            hs.append(h)
+        players.append(hs)
+    games_done = [0] * pairs
+    mover = [None] * pairs       # 0 / 1: whose turn; None: the pair waits for an opening
+    opening_of = [None] * pairs
+    next_opening = [0]
+    results = []
+
+    def start_game(m, oid):
+        opening_of[m] = oid
+        op = np.array(openings[oid] + [0], np.uint16)
+        first_sign = 1 if games_done[m] % 2 == 0 else 2      # EvaluationGame.cpp:59-71
+        for h in players[m]:
+            olib.ago_game_set_serial(h, oid)
+            olib.ago_game_match_begin(h, ol.ptr(op), len(openings[oid]))
+        mover[m] = 0 if olib.ago_game_sign_to_move(players[m][0]) == first_sign else 1
+        olib.ago_game_take_turn(players[m][mover[m]])
+
+    def restart_waiting():   # what k_assign_openings + k_match_restart do at the end of the first players' phase
+        for m in range(pairs):
+            if mover[m] is None:
+                if games_done[m] % 2 == 1:
+                    start_game(m, opening_of[m])
+                elif next_opening[0] < n_openings:
+                    start_game(m, next_opening[0])
+                    next_opening[0] += 1
+
+    pool.begin(selfplay.pack_openings(openings))
+    restart_waiting()
+    compared = 0
+    for step in range(max_steps):
+        for phase in range(2):
+            pool.select_solve_group(phase, 2)
+            slots, feats = pool.scheduled_group(phase, 2)
+            pol, val = evaluators[phase](feats) if len(slots) else (np.zeros((0, HW), np.float32), np.zeros((0, 2), np.float32))
+            v3 = np.concatenate([val, 1 - val.sum(1, keepdims=True)], 1).astype(np.float32)
+            pool.provide(slots, pol, v3)
+            by_slot = {int(s): i for i, s in enumerate(slots)}
+            seen = 0
+            for m in range(pairs):
+                if mover[m] != phase:
+                    continue
+                tree = m + phase * pairs
+                h = players[m][phase]
+                f = np.zeros((batch, HW), np.uint32)
+                c = olib.ago_game_step_select(h, ol.ptr(f), batch)
+                mine = sorted(s for s in by_slot if s // batch == tree)
+                assert c == len(mine), (step, phase, m)
+                idx = [by_slot[s] for s in mine]
+                assert np.array_equal(feats[idx], f[:c]), (step, phase, m)
+                seen += c
+                moved = olib.ago_game_step_expand(h, ol.ptr(np.ascontiguousarray(pol[idx])), ol.ptr(np.ascontiguousarray(val[idx])))
+                if moved:
+                    other = players[m][1 - phase]
+                    olib.ago_game_external_move(other, olib.ago_game_last_move(h))
+                    assert olib.ago_game_outcome(other) == olib.ago_game_outcome(h)
+                    if olib.ago_game_outcome(h) != 0:
+                        results.append((m, opening_of[m], games_done[m] % 2, olib.ago_game_outcome(h)))
+                        games_done[m] += 1
+                        mover[m] = None
+                    else:
+                        olib.ago_game_take_turn(other)
+                        mover[m] = 1 - phase
+            assert seen == len(slots), (step, phase)      # idle trees schedule nothing
+            pool.expand_backup_group(phase, 2)
+            if phase == 0:
+                restart_waiting()
+            for m in range(pairs):
+                infos = [pool.game_info(m), pool.game_info(m + pairs)]
+                assert infos[0]["error"] == 0 and infos[1]["error"] == 0
+                if mover[m] is None:
+                    assert not infos[0]["active"] and not infos[1]["active"], (step, phase, m)
+                    continue
+                info = infos[mover[m]]
+                assert info["active"] and not infos[1 - mover[m]]["active"], (step, phase, m)   # exactly the player to move searches
+                assert info["opening_id"] == opening_of[m] and info["games_done"] == games_done[m], (step, phase, m)
+                r = _oracle_root(olib, players[m][mover[m]])
+                e = info["edges"]
+                assert r["n"] == info["root_edges"] and r["visits"] == info["root_visits"], (step, phase, m)
+                assert np.array_equal(np.array([x["move"] for x in e], np.uint16), r["moves"]), (step, phase, m)
+                assert np.array_equal(np.array([x["visits"] for x in e], np.int32), r["ev"]), (step, phase, m)
+                assert np.array_equal(np.array([x["score"] for x in e], np.uint16), r["es"]), (step, phase, m)
+                assert np.array_equal(np.array([x["prior"] for x in e], np.float32), r["prior"]), (step, phase, m)
+                assert np.array_equal(np.array([[x["win"], x["draw"]] for x in e], np.float32).reshape(-1), r["val"]), (step, phase, m)
+                compared += 1
+        if all(x is None for x in mover) and next_opening[0] >= n_openings and all(d % 2 == 0 for d in games_done):
+            break
+    stats = pool.stats()
+    pool.close()
+    for hs in players:
+        for h in hs:
+            olib.ago_game_destroy(h)
+    return compared, stats, results
+
+
+@pytest.mark.parametrize("rules,batch,sims,max_children", [(0, 4, 60, 0), (1, 8, 80, 20), (2, 4, 60, 0)])
+def test_evaluation_matches_bit_exact(agx_lib, olib, rules, batch, sims, max_children):
+    """match_mode: EvaluationGame + Player (evaluation/EvaluationGame.cpp:77-146, evaluation/Player.cpp:98-216): two players with
+    their own trees, solvers and networks share a game; every opening is played twice with the colours swapped; a player's tree
+    jumps two plies per setBoard and survives from game to game; the root is pruned like any node.  Device vs oracle after
+    every half-step (features of every scheduled leaf, root edges of the searching tree), for three pairs playing two matches."""
+    compared, stats, results = _play_matches_and_compare(olib, rules, pairs=3, n_openings=6, batch=batch, sims=sims, max_steps=6000, max_children=max_children,
+                                                         draw_after=80)
+    assert len(results) == 12 and compared > 300                     # 6 openings x 2 games
+    assert stats["games_finished"] == 12
+    by_opening = {}
+    for m, oid, k, outcome in results:
+        by_opening.setdefault(oid, []).append(k)
+    assert all(sorted(v) == [0, 1] for v in by_opening.values())     # each opening once per colour assignment
