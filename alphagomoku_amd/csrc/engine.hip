@@ -367,7 +367,9 @@ namespace
 		 * yield_fraction of the launch's games have finished: it keeps its position in the batch, sits out this step's network /
 		 * expand stages and resumes in the next launch.  Each game still sees exactly the same sequence of operations.
 		 */
-		const int threshold = (E.yield_fraction > 0.0f) ? static_cast<int>(E.yield_fraction * gridDim.x) : 0x7FFFFFFF;
+		// (match mode: about half of a group's trees wait for their opponents and count as done at once)
+		const float fraction = E.match_mode ? 0.5f + 0.5f * E.yield_fraction : E.yield_fraction;
+		const int threshold = (E.yield_fraction > 0.0f) ? static_cast<int>(fraction * gridDim.x) : 0x7FFFFFFF;
 		int k = idle ? 0 : gs.solve_pos;
 		bool yielded = false;
 		for (; k < n_tasks; k++)
@@ -1007,6 +1009,7 @@ namespace
 				gs.outcome = 0;
 				gs.n_moves = 0;
 				gs.restart_id = (g < E.n_games / 2) ? -1 : 0;
+				gs.match_score[0] = gs.match_score[1] = gs.match_score[2] = gs.match_score[3] = 0;
 			}
 		}
 		else if (sh_id < E.n_openings)
@@ -1228,6 +1231,8 @@ namespace
 					// a match is two games on one opening with the colours swapped (EvaluationGame.cpp:44-71): after the first game the
 					// pair starts again from the same opening, after the second it waits for a new one
 					lead.restart_id = (lead.games_done % 2 == 1) ? lead.opening_id + 1 : -1;
+					const int first_won = (sh_int[2] == 2 && lead.my_sign == 1) || (sh_int[2] == 3 && lead.my_sign == 2);
+					lead.match_score[(sh_int[2] == 1) ? 1 : (first_won ? 0 : 2)]++;
 				}
 				else
 				{
@@ -1926,6 +1931,25 @@ int agx_engine_buffers(AgxEngine *e, AgxEngineBuffers *out)
 	out->d_nn_count = e->dev.counters + 16; /* group 0 of 1 */
 	out->slots = e->dev.n_games * e->dev.batch;
 	out->cells = e->dev.hw;
+	return AGX_OK;
+}
+
+int agx_engine_match_results(AgxEngine *e, int *h_results, int pair_capacity)
+{
+	AGX_REQUIRE(e != nullptr && h_results != nullptr, AGX_ERR_INVALID, "agx_engine_match_results: null argument");
+	AGX_REQUIRE(e->dev.match_mode, AGX_ERR_STATE, "agx_engine_match_results: the engine was not created with match_mode");
+	const int pairs = e->dev.n_games / 2;
+	AGX_REQUIRE(pair_capacity >= pairs, AGX_ERR_INVALID, "agx_engine_match_results: %d pairs do not fit into %d", pairs, pair_capacity);
+	AGX_HIP_CHECK(hipDeviceSynchronize());
+	std::vector<GameState> games(pairs);
+	AGX_HIP_CHECK(hipMemcpy(games.data(), e->dev.games, games.size() * sizeof(GameState), hipMemcpyDeviceToHost));
+	for (int i = 0; i < pairs; i++)
+	{
+		h_results[4 * i + 0] = games[i].match_score[0];
+		h_results[4 * i + 1] = games[i].match_score[1];
+		h_results[4 * i + 2] = games[i].match_score[2];
+		h_results[4 * i + 3] = games[i].games_done;
+	}
 	return AGX_OK;
 }
 

@@ -105,6 +105,7 @@ namespace agx
 			int32_t noise_ready;   // 1 once the root noise of the current move has been drawn (a fresh selector per move in the reference)
 			int32_t my_sign;       // match mode: the colour this tree's player has in the current game (evaluation/EvaluationGame.cpp:59-71)
 			int32_t restart_id;    // 0: playing; -1: the game is over and waits for an opening; k > 0: it starts again from opening k - 1 in k_restart
+			int32_t match_score[4]; // match mode, first players' trees: games won / drawn / lost by the first player of this pair (+ pad)
 			uint64_t root_hash;
 			uint64_t cboard[BWORDS];
 			unsigned long long prof[8];   // optional cycle counters (AGX_SOLVER_PROFILE builds only)

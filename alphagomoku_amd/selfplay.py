@@ -161,6 +161,17 @@ class GeneratorPool:
                  ctypes.byref(nr), ctypes.byref(ne)))
         return recs[:nr.value], edges[:ne.value]
 
+    def step_match(self, first_net, second_net, stream=None):
+        """one step of a match_mode pool: the first players' trees with their network, then the second players' (one stream)"""
+        check(lib.agx_engine_step_group(self._h, first_net._net, 0, 2, stream))
+        check(lib.agx_engine_step_group(self._h, second_net._net, 1, 2, stream))
+
+    def match_results(self):
+        """int [pairs][4]: games won / drawn / lost by the first player of each pair, games finished by the pair"""
+        out = np.zeros((self.cfg.n_games // 2, 4), np.int32)
+        check(lib.agx_engine_match_results(self._h, out.ctypes.data_as(ctypes.c_void_p), out.shape[0]))
+        return out
+
     def add_openings(self, packed_openings):
         """appends openings (pack_openings layout) for the games that finish from now on"""
         a = np.ascontiguousarray(packed_openings, dtype=np.uint16)

@@ -272,6 +272,9 @@ int agx_engine_records(AgxEngine* engine, AgxMoveRecord* h_records, int record_c
 /* Same, then empties the device-side record pools (what GeneratorManager::addToBuffer's hand-over does, GeneratorManager.cpp:
  * 160-164): a long-running loop calls this every few hundred steps so that record_capacity is never exhausted. */
 int agx_engine_drain_records(AgxEngine* engine, AgxMoveRecord* h_records, int record_capacity, AgxEdgeView* h_edges, int edge_capacity, int* n_records, int* n_edges);
+/* Match mode: h_results int[n_games / 2][4] = games won / drawn / lost by the FIRST player of each pair and the games the pair has
+ * finished (what EvaluationManager sums per player, evaluation/EvaluationManager.cpp); the moves of every game are in the records. */
+int agx_engine_match_results(AgxEngine* engine, int* h_results, int pair_capacity);
 /* Appends openings to the pool's list.  Finished games take the next unused opening in game order after every step; games that
  * found none left wait and pick one up here (the reference's generators produce openings on demand, GameGenerator.cpp:54-77). */
 int agx_engine_add_openings(AgxEngine* engine, const uint16_t* h_openings, int n_openings);

@@ -135,14 +135,17 @@ namespace agx
 			AgxEngine *m_engine = nullptr;
 			AgxEngineBuffers m_buffers { };
 		public:
-			GeneratorPool(const GameConfig &game, const SelfplayConfig &selfplay)
+			/* evaluationMatches: the pool plays EvaluationGames instead (evaluation/EvaluationGame.cpp): games_per_thread pairs of Players,
+			 * one tree per Player, every opening twice with the colours swapped; drive it with generate(first, second) */
+			GeneratorPool(const GameConfig &game, const SelfplayConfig &selfplay, bool evaluationMatches = false)
 			{
 				AgxEngineConfig c;
 				check(agx_engine_default_config(&c));
 				c.rules = game.rules;
 				c.board_size = game.rows;
 				c.draw_after = game.draw_after;
-				c.n_games = selfplay.games_per_thread;
+				c.n_games = evaluationMatches ? 2 * selfplay.games_per_thread : selfplay.games_per_thread;
+				c.match_mode = evaluationMatches ? 1 : 0;
 				c.max_batch_size = selfplay.search_config.max_batch_size;
 				c.max_simulations = selfplay.max_simulations;
 				c.exploration_constant = selfplay.search_config.exploration_constant;
@@ -191,6 +194,19 @@ namespace agx
 			void generate(AGNetwork &network, void *stream = nullptr)
 			{
 				check(agx_engine_step(m_engine, network.handle(), stream));
+			}
+			/* EvaluationGame::generate for every pair: the first players' trees with their network, then the second players' */
+			void generate(AGNetwork &first, AGNetwork &second, void *stream = nullptr)
+			{
+				check(agx_engine_step_group(m_engine, first.handle(), 0, 2, stream));
+				check(agx_engine_step_group(m_engine, second.handle(), 1, 2, stream));
+			}
+			/* per pair: games won / drawn / lost by the first player, games finished */
+			std::vector<int> getMatchResults() const
+			{
+				std::vector<int> out(static_cast<size_t>(m_buffers.slots) * 4);
+				check(agx_engine_match_results(m_engine, out.data(), static_cast<int>(out.size() / 4)));
+				return out;
 			}
 			/* the three stages separately (Search::select+solve+scheduleToNN / NNEvaluator::evaluateGraph / generateEdges+expand+backup) */
 			void selectSolveSchedule(void *stream = nullptr)

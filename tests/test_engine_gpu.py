@@ -815,3 +815,50 @@ def test_evaluation_matches_bit_exact(agx_lib, olib, rules, batch, sims, max_chi
     for m, oid, k, outcome in results:
         by_opening.setdefault(oid, []).append(k)
     assert all(sorted(v) == [0, 1] for v in by_opening.values())     # each opening once per colour assignment
+
+
+def test_evaluation_matches_with_two_networks(agx_lib):
+    """match_mode end to end on the device: two HIP networks of different weights, 32 pairs; every pair plays whole matches, the
+    per-pair scores add up and each finished game was recorded move by move"""
+    from alphagomoku_amd import selfplay, networks, synthetic
+    pairs, n_openings = 32, 48
+    cfg = selfplay.default_config(rules=0, board_size=N, draw_after=60, n_games=2 * pairs, max_batch_size=8, max_simulations=50, tss_table_entries=1 << 16,
+                                  node_capacity=4096, edge_capacity=65536, match_mode=1, solver_yield_fraction=0.75,
+                                  record_capacity=2 * n_openings * 64, record_edge_capacity=2 * n_openings * 64 * 230)
+    pool = selfplay.GeneratorPool(cfg)
+    nets = []
+    for seed in (1234, 4321):
+        d = synthetic.net_desc(blocks=2, filters=64)
+        net = networks.AGNetwork(d)
+        net.loadWeights(synthetic.make_weights(d, seed=seed)[0])
+        nets.append(net)
+    openings = []
+    for g in range(n_openings):
+        op = np.zeros(selfplay.OPENING_CAP, np.uint16)
+        agx_lib.agx_make_opening(0, N, 900 + g, op.ctypes.data_as(ctypes.c_void_p))
+        openings.append([int(x) for x in op[1:1 + int(op[0])]])
+    pool.begin(selfplay.pack_openings(openings))
+    for step in range(6000):
+        pool.step_match(nets[0], nets[1])
+        if step % 50 == 49:
+            res = pool.match_results()
+            if int(res[:, 3].sum()) == 2 * n_openings:
+                break
+    res = pool.match_results()
+    stats = pool.stats()
+    assert int(res[:, 3].sum()) == 2 * n_openings == stats["games_finished"]
+    assert np.array_equal(res[:, :3].sum(1), res[:, 3]) and np.all(res[:, 3] % 2 == 0)
+    recs, _ = pool.records()
+    assert len(recs) == stats["moves_played"]
+    per_opening = {}
+    for r in recs:
+        per_opening.setdefault(r.game_serial, []).append(r.move_number)
+    assert sorted(per_opening) == list(range(n_openings))
+    for oid, numbers in per_opening.items():   # two games per opening, each recorded from the opening's length on without gaps
+        first = len(openings[oid])
+        assert numbers.count(first) == 2 and max(numbers) <= 60
+    for g in range(2 * pairs):
+        assert pool.game_info(g, with_edges=False)["error"] == 0
+    pool.close()
+    for net in nets:
+        net.close()
