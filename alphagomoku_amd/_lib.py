@@ -147,6 +147,9 @@ def _declare(c):  # noqa: F811
     c.agx_engine_kernel_timing.argtypes = [vp, ci, vp, vp]
     c.agx_engine_add_openings.argtypes = [vp, vp, ci]
     c.agx_engine_match_results.argtypes = [vp, vp, ci]
+    c.agx_engine_step_match.argtypes = [vp, vp, vp, vp]
+    c.agx_engine_select_solve_match.argtypes = [vp, vp]
+    c.agx_engine_expand_backup_match.argtypes = [vp, vp]
     c.agx_engine_drain_records.argtypes = [vp, vp, ci, vp, ci, vp, vp]
     c.agx_engine_generate_openings.argtypes = [vp, vp, ci, ctypes.c_uint32, vp, vp]
     c.agx_engine_game_info.argtypes = [vp, ci, ctypes.POINTER(AgxGameInfo), vp, vp, ci]

@@ -435,8 +435,11 @@ namespace
 				t.symmetry = symmetry;
 				if (needs)
 				{
-					const int idx = atomicAdd(&E.counters[E.nn_counter], 1);
-					E.nn_list[static_cast<size_t>(E.g0) * E.batch + idx] = g * E.batch + j; // each group owns the list segment of its games
+					// each group owns the list segment of its games; a merged match launch fills the two players' lists (= groups 0 and 1 of 2)
+					const int half = (E.match_merged && g >= E.n_games / 2) ? 1 : 0;
+					const int first = E.match_merged ? half * (E.n_games / 2) : E.g0;
+					const int idx = atomicAdd(&E.counters[E.nn_counter + half], 1);
+					E.nn_list[static_cast<size_t>(first) * E.batch + idx] = g * E.batch + j;
 					scheduled++;
 				}
 			}
@@ -1848,6 +1851,73 @@ int agx_engine_select_solve_group(AgxEngine *e, int group, int n_groups, void *s
 	}
 	AGX_HIP_CHECK(hipGetLastError());
 	return AGX_OK;
+}
+
+/* match mode, both players' trees in one launch per stage: about half of the trees search at any time, so one launch over all of
+ * them keeps the GPU as busy as a self-play pool of n_games / 2; only the network stage is split (one slot list per player) */
+static int match_launch(AgxEngine *e, EngineDev &d)
+{
+	AGX_REQUIRE(e != nullptr, AGX_ERR_INVALID, "agx_engine_*_match: null engine");
+	AGX_REQUIRE(e->begun, AGX_ERR_STATE, "agx_engine_*_match: agx_engine_begin has not been called");
+	AGX_REQUIRE(e->dev.match_mode, AGX_ERR_STATE, "agx_engine_*_match: the engine was not created with match_mode");
+	d = e->dev;
+	d.g0 = 0;
+	d.nn_counter = 16;
+	d.yield_counter = 32;
+	d.match_merged = 1;
+	return AGX_OK;
+}
+int agx_engine_select_solve_match(AgxEngine *e, void *stream)
+{
+	EngineDev d;
+	const int st = match_launch(e, d);
+	if (st != AGX_OK)
+		return st;
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	hipLaunchKernelGGL(k_reset_counter, dim3(1), dim3(1), 0, s, d.counters + 16, d.counters + 32);
+	hipLaunchKernelGGL(k_reset_counter, dim3(1), dim3(1), 0, s, d.counters + 17, static_cast<int*>(nullptr));
+	{
+		KernelTimer t(e, s, 0);
+		hipLaunchKernelGGL(k_select, dim3(d.n_games), dim3(64), 0, s, d);
+	}
+	{
+		KernelTimer t(e, s, 1);
+		launch_solve(d, d.n_games, s);
+	}
+	AGX_HIP_CHECK(hipGetLastError());
+	return AGX_OK;
+}
+int agx_engine_expand_backup_match(AgxEngine *e, void *stream)
+{
+	EngineDev d;
+	const int st = match_launch(e, d);
+	if (st != AGX_OK)
+		return st;
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	{
+		KernelTimer t(e, s, 2);
+		hipLaunchKernelGGL(k_expand, dim3(d.n_games), dim3(64), 0, s, d);
+	}
+	{
+		KernelTimer t(e, s, 3);
+		// a moving tree's workgroup also rebases its partner's tree; the partner's own workgroup has nothing to do (it is not searching)
+		hipLaunchKernelGGL(k_advance, dim3(d.n_games), dim3(256), 0, s, d);
+		hipLaunchKernelGGL(k_assign_openings, dim3(1), dim3(1024), 0, s, d, d.n_games / 2);
+		hipLaunchKernelGGL(k_match_restart, dim3(d.n_games / 2), dim3(256), 0, s, d);
+	}
+	AGX_HIP_CHECK(hipGetLastError());
+	return AGX_OK;
+}
+int agx_engine_step_match(AgxEngine *e, AgxNet *first_net, AgxNet *second_net, void *stream)
+{
+	int st = agx_engine_select_solve_match(e, stream);
+	if (st == AGX_OK)
+		st = agx_engine_evaluate_group(e, first_net, 0, 2, stream);
+	if (st == AGX_OK)
+		st = agx_engine_evaluate_group(e, second_net, 1, 2, stream);
+	if (st == AGX_OK)
+		st = agx_engine_expand_backup_match(e, stream);
+	return st;
 }
 
 int agx_engine_evaluate_group(AgxEngine *e, AgxNet *net, int group, int n_groups, void *stream)

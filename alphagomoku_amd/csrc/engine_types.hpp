@@ -181,6 +181,7 @@ namespace agx
 			float *nn_value;       // [game*batch][3]
 			float *nn_q;           // [game*batch][hw][2] action values (win, draw) per cell, 'pvq' networks only
 			int has_q;
+			int match_merged; // this launch covers both players' trees: network slot lists by half of the pool, not by launch
 			int match_mode;  // evaluation matches: tree g (first player) and tree g + n_games / 2 (second player) share one game
 			int *nn_list;          // compacted slots to evaluate
 			int *counters;         // [0] (unused), [1] next opening, [2] finished games, [3] records used, [4] record edges used, [5] total moves, [16 + group] positions scheduled for the network by that group

@@ -162,9 +162,19 @@ class GeneratorPool:
         return recs[:nr.value], edges[:ne.value]
 
     def step_match(self, first_net, second_net, stream=None):
-        """one step of a match_mode pool: the first players' trees with their network, then the second players' (one stream)"""
+        """one step of a match_mode pool: every stage one launch over both players' trees, the network stage per player"""
+        check(lib.agx_engine_step_match(self._h, first_net._net, second_net._net, stream))
+
+    def step_match_groups(self, first_net, second_net, stream=None):
+        """the same as two group steps: the first players' trees with their network, then the second players' (one stream)"""
         check(lib.agx_engine_step_group(self._h, first_net._net, 0, 2, stream))
         check(lib.agx_engine_step_group(self._h, second_net._net, 1, 2, stream))
+
+    def select_solve_match(self, stream=None):
+        check(lib.agx_engine_select_solve_match(self._h, stream))
+
+    def expand_backup_match(self, stream=None):
+        check(lib.agx_engine_expand_backup_match(self._h, stream))
 
     def match_results(self):
         """int [pairs][4]: games won / drawn / lost by the first player of each pair, games finished by the pair"""

@@ -153,8 +153,8 @@ typedef struct AgxEngineConfig
 	                                     both see one game and a tree searches only on its own player's turns (Player::setBoard jumps two
 	                                     plies; trees persist across games, the solver table is cleared per game; the root is pruned like
 	                                     any other node, UnifiedGenerator's forceExpandRoot = false).  Every opening is played twice with
-	                                     the colours swapped.  Drive it with two groups on ONE stream, each with its own network:
-	                                     agx_engine_step_group(e, first_net, 0, 2, s); agx_engine_step_group(e, second_net, 1, 2, s). */
+	                                     the colours swapped.  Drive it with agx_engine_step_match(e, first_net, second_net, s), or with two
+	                                     groups on ONE stream: agx_engine_step_group(e, first_net, 0, 2, s); ..._group(e, second_net, 1, 2, s). */
 } AgxEngineConfig;
 
 typedef struct AgxEngine AgxEngine; /* opaque */
@@ -272,6 +272,13 @@ int agx_engine_records(AgxEngine* engine, AgxMoveRecord* h_records, int record_c
 /* Same, then empties the device-side record pools (what GeneratorManager::addToBuffer's hand-over does, GeneratorManager.cpp:
  * 160-164): a long-running loop calls this every few hundred steps so that record_capacity is never exhausted. */
 int agx_engine_drain_records(AgxEngine* engine, AgxMoveRecord* h_records, int record_capacity, AgxEdgeView* h_edges, int edge_capacity, int* n_records, int* n_edges);
+/* Match mode, the efficient way to step: every stage is ONE launch over both players' trees (about half of them search at any time),
+ * only the network stage runs per player: select/solve for all, first_net on the first players' leaves, second_net on the second
+ * players', expand/backup/move for all.  A tree that gets the move in this step starts searching in the next one; per-tree
+ * results are the same as with two agx_engine_step_group calls (each tree performs the same sequence of operations). */
+int agx_engine_step_match(AgxEngine* engine, AgxNet* first_net, AgxNet* second_net, void* stream);
+int agx_engine_select_solve_match(AgxEngine* engine, void* stream);  /* the stages separately: this, then                        */
+int agx_engine_expand_backup_match(AgxEngine* engine, void* stream); /* agx_engine_evaluate_group(e, net, 0 / 1, 2, s), then this */
 /* Match mode: h_results int[n_games / 2][4] = games won / drawn / lost by the FIRST player of each pair and the games the pair has
  * finished (what EvaluationManager sums per player, evaluation/EvaluationManager.cpp); the moves of every game are in the records. */
 int agx_engine_match_results(AgxEngine* engine, int* h_results, int pair_capacity);

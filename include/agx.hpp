@@ -198,8 +198,7 @@ namespace agx
 			/* EvaluationGame::generate for every pair: the first players' trees with their network, then the second players' */
 			void generate(AGNetwork &first, AGNetwork &second, void *stream = nullptr)
 			{
-				check(agx_engine_step_group(m_engine, first.handle(), 0, 2, stream));
-				check(agx_engine_step_group(m_engine, second.handle(), 1, 2, stream));
+				check(agx_engine_step_match(m_engine, first.handle(), second.handle(), stream));
 			}
 			/* per pair: games won / drawn / lost by the first player, games finished */
 			std::vector<int> getMatchResults() const

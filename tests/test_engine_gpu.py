@@ -684,7 +684,7 @@ def _second_evaluator(olib, hw=HW):
     return f
 
 
-def _play_matches_and_compare(olib, rules, pairs, n_openings, batch, sims, max_steps, max_children=0, n=N, draw_after=0):
+def _play_matches_and_compare(olib, rules, pairs, n_openings, batch, sims, max_steps, max_children=0, n=N, draw_after=0, merged=False):
     from alphagomoku_amd import selfplay
     N, HW = n, n * n   # noqa: N806
     cfg = selfplay.default_config(rules=rules, board_size=n, draw_after=draw_after if draw_after > 0 else n * n, n_games=2 * pairs, max_batch_size=batch,
@@ -736,30 +736,49 @@ def _play_matches_and_compare(olib, rules, pairs, n_openings, batch, sims, max_s
     pool.begin(selfplay.pack_openings(openings))
     restart_waiting()
     compared = 0
+    # merged: every stage one launch over both players' trees (agx_engine_step_match); else two group steps one after the other
+    phases = [(0, 1)] if merged else [(0,), (1,)]
     for step in range(max_steps):
-        for phase in range(2):
-            pool.select_solve_group(phase, 2)
-            slots, feats = pool.scheduled_group(phase, 2)
-            pol, val = evaluators[phase](feats) if len(slots) else (np.zeros((0, HW), np.float32), np.zeros((0, 2), np.float32))
+        for phase in phases:
+            if merged:
+                pool.select_solve_match()
+            else:
+                pool.select_solve_group(phase[0], 2)
+            by_slot, pol_of, val_of, feat_of = {}, {}, {}, {}
+            all_slots, all_pol, all_val = [], [], []
+            for player in phase:
+                slots, feats = pool.scheduled_group(player, 2)
+                pol, val = evaluators[player](feats) if len(slots) else (np.zeros((0, HW), np.float32), np.zeros((0, 2), np.float32))
+                for i, sl in enumerate(slots):
+                    assert (int(sl) // batch >= pairs) == (player == 1)      # each player's list holds only its own trees' leaves
+                    by_slot[int(sl)] = (feats[i], pol[i], val[i])
+                all_slots.append(slots)
+                all_pol.append(pol)
+                all_val.append(val)
+            slots = np.concatenate(all_slots)
+            pol = np.concatenate(all_pol)
+            val = np.concatenate(all_val)
             v3 = np.concatenate([val, 1 - val.sum(1, keepdims=True)], 1).astype(np.float32)
             pool.provide(slots, pol, v3)
-            by_slot = {int(s): i for i, s in enumerate(slots)}
             seen = 0
+            movers_now = list(mover)
             for m in range(pairs):
-                if mover[m] != phase:
+                who = movers_now[m]
+                if who is None or who not in phase:
                     continue
-                tree = m + phase * pairs
-                h = players[m][phase]
+                tree = m + who * pairs
+                h = players[m][who]
                 f = np.zeros((batch, HW), np.uint32)
                 c = olib.ago_game_step_select(h, ol.ptr(f), batch)
-                mine = sorted(s for s in by_slot if s // batch == tree)
+                mine = sorted(sl for sl in by_slot if sl // batch == tree)
                 assert c == len(mine), (step, phase, m)
-                idx = [by_slot[s] for s in mine]
-                assert np.array_equal(feats[idx], f[:c]), (step, phase, m)
+                assert np.array_equal(np.array([by_slot[sl][0] for sl in mine], np.uint32).reshape(c, HW), f[:c]), (step, phase, m)
                 seen += c
-                moved = olib.ago_game_step_expand(h, ol.ptr(np.ascontiguousarray(pol[idx])), ol.ptr(np.ascontiguousarray(val[idx])))
+                p_in = np.ascontiguousarray(np.array([by_slot[sl][1] for sl in mine], np.float32).reshape(c, HW))
+                v_in = np.ascontiguousarray(np.array([by_slot[sl][2] for sl in mine], np.float32).reshape(c, 2))
+                moved = olib.ago_game_step_expand(h, ol.ptr(p_in), ol.ptr(v_in))
                 if moved:
-                    other = players[m][1 - phase]
+                    other = players[m][1 - who]
                     olib.ago_game_external_move(other, olib.ago_game_last_move(h))
                     assert olib.ago_game_outcome(other) == olib.ago_game_outcome(h)
                     if olib.ago_game_outcome(h) != 0:
@@ -768,10 +787,13 @@ def _play_matches_and_compare(olib, rules, pairs, n_openings, batch, sims, max_s
                         mover[m] = None
                     else:
                         olib.ago_game_take_turn(other)
-                        mover[m] = 1 - phase
+                        mover[m] = 1 - who
             assert seen == len(slots), (step, phase)      # idle trees schedule nothing
-            pool.expand_backup_group(phase, 2)
-            if phase == 0:
+            if merged:
+                pool.expand_backup_match()
+            else:
+                pool.expand_backup_group(phase[0], 2)
+            if merged or phase[0] == 0:
                 restart_waiting()
             for m in range(pairs):
                 infos = [pool.game_info(m), pool.game_info(m + pairs)]
@@ -801,14 +823,16 @@ def _play_matches_and_compare(olib, rules, pairs, n_openings, batch, sims, max_s
     return compared, stats, results
 
 
-@pytest.mark.parametrize("rules,batch,sims,max_children", [(0, 4, 60, 0), (1, 8, 80, 20), (2, 4, 60, 0)])
-def test_evaluation_matches_bit_exact(agx_lib, olib, rules, batch, sims, max_children):
+@pytest.mark.parametrize("rules,batch,sims,max_children,merged", [(0, 4, 60, 0, False), (1, 8, 80, 20, False), (2, 4, 60, 0, False),
+                                                                   (0, 8, 60, 0, True), (1, 4, 80, 20, True), (2, 4, 60, 0, True)])
+def test_evaluation_matches_bit_exact(agx_lib, olib, rules, batch, sims, max_children, merged):
     """match_mode: EvaluationGame + Player (evaluation/EvaluationGame.cpp:77-146, evaluation/Player.cpp:98-216): two players with
     their own trees, solvers and networks share a game; every opening is played twice with the colours swapped; a player's tree
     jumps two plies per setBoard and survives from game to game; the root is pruned like any node.  Device vs oracle after
-    every half-step (features of every scheduled leaf, root edges of the searching tree), for three pairs playing two matches."""
+    every half-step (features of every scheduled leaf, root edges of the searching tree), for three pairs playing two matches;
+    stepped as two groups and as merged launches over both players' trees (agx_engine_step_match)."""
     compared, stats, results = _play_matches_and_compare(olib, rules, pairs=3, n_openings=6, batch=batch, sims=sims, max_steps=6000, max_children=max_children,
-                                                         draw_after=80)
+                                                         draw_after=80, merged=merged)
     assert len(results) == 12 and compared > 300                     # 6 openings x 2 games
     assert stats["games_finished"] == 12
     by_opening = {}
