@@ -354,13 +354,39 @@ namespace agx
 			wave_sync();
 		}
 
+		/*
+		 * The pattern-table entries solver_update_around will need for placing (add) or removing the stone `mv`, requested while the
+		 * frame machine still does its bookkeeping: lane (k, d) asks for the entry of the cell k steps from the stone in direction d
+		 * with the stone already put into / taken out of that cell's 11-cell window (window index 5 - k), lanes 40-43 for the centre's
+		 * own four windows when the stone is removed.  The L2 round trip then overlaps the descend / return work instead of standing
+		 * between the stone and the list edits.
+		 */
+		__device__ __forceinline__ uint8_t pattern_prefetch(const SolverShared &sh, const EngineDev &E, int n, uint32_t mv, bool add, int lane)
+		{ // branch-free on purpose: ONE load instruction for the whole wave (idle lanes read entry 0), so that nothing has to wait for
+		  // it before solver_update_around consumes it
+			const int s = mv & 3, r = (mv >> 2) & 127, c = (mv >> 9) & 127;
+			const bool around = lane < 40;
+			const int ki = lane >> 2, d = around ? (lane & 3) : ((lane - 40) & 3);
+			const int k = around ? ((ki < 5) ? ki - 5 : ki - 4) : 0;
+			const int r1 = r + k * row_step(d), c1 = c + k * col_step(d);
+			const bool inside = r1 >= 0 && r1 < n && c1 >= 0 && c1 < n;
+			const bool wanted = around ? inside : (lane < 44 && !add);
+			const int rr = inside ? r1 : r, cc = inside ? c1 : c;
+			uint32_t x = normal_pattern(sh, n, rr, cc, d);
+			const int shift = 2 * (5 - k);
+			const uint32_t with_stone = add ? (x | (static_cast<uint32_t>(s) << shift)) : (x & ~(3u << shift));
+			x = around ? with_stone : x; // the centre's own windows do not contain the centre
+			return E.t_pattern[wanted ? narrow(x) : 0u];
+		}
+
 		/* PatternCalculator::update_around (PatternCalculator.cpp:278-367): the centre cell, then the +-5 cells in the four
 		 * directions in the order k = -5..5 (k != 0), direction 0..3 — one lane per (k, direction); lanes 40-43 re-classify the four
 		 * directions of the centre when a stone is removed.
 		 * The threat lists must end up in the reference's order (push-back add, swap-with-last remove, applied cell by cell): see the
 		 * list-edit steps below. */
-		__device__ __forceinline__ void solver_update_around(SolverShared &sh, const EngineDev &E, int r, int c, bool added, int lane)
-		{
+		__device__ __forceinline__ void solver_update_around(SolverShared &sh, const EngineDev &E, int r, int c, bool added, int lane, bool prefetched = false,
+				uint8_t pf_e = 0)
+		{ // prefetched: pf_e holds this lane's pattern_prefetch() result for exactly this stone
 			const int n = E.n;
 			const int center = r * n + c;
 			AGX_PROF_BEGIN();
@@ -380,13 +406,15 @@ namespace agx
 					const int t0 = sh.threat[at][0], t1 = sh.threat[at][1];
 					uint32_t w0 = *reinterpret_cast<const uint32_t*>(&sh.ptype[at][0]); // cross, one byte per direction
 					uint32_t w1 = *reinterpret_cast<const uint32_t*>(&sh.ptype[at][4]); // circle
-					const uint32_t raw = narrow(normal_pattern(sh, n, rr, cc, d));
+					uint32_t raw = 0;
+					if (!prefetched)
+						raw = narrow(normal_pattern(sh, n, rr, cc, d));
 					if (stone == 0)
 					{
 						cell = at;
 						old0 = t0;
 						old1 = t1;
-						const uint32_t e = E.t_pattern[raw];
+						const uint32_t e = prefetched ? pf_e : E.t_pattern[raw]; // (the byte is widened HERE, not where it was requested)
 						w0 = (w0 & ~(255u << (8 * d))) | ((e & 15u) << (8 * d));
 						w1 = (w1 & ~(255u << (8 * d))) | ((e >> 4) << (8 * d));
 						sh.ptype[cell][d] = static_cast<uint8_t>(e & 15u);
@@ -401,7 +429,7 @@ namespace agx
 			else if (lane < 44 && !added)
 			{
 				const int d = lane - 40;
-				const uint32_t e = E.t_pattern[narrow(normal_pattern(sh, n, r, c, d))];
+				const uint32_t e = prefetched ? pf_e : E.t_pattern[narrow(normal_pattern(sh, n, r, c, d))];
 				sh.ptype[center][d] = static_cast<uint8_t>(e & 15u);
 				sh.ptype[center][4 + d] = static_cast<uint8_t>(e >> 4);
 				centre_bits = ((e & 15u) << (3 * d)) | ((e >> 4) << (16 + 3 * d));
@@ -495,7 +523,8 @@ namespace agx
 			wave_sync();
 			AGX_PROF_MARK(sh, 12);
 		}
-		__device__ __forceinline__ void solver_place(SolverShared &sh, const EngineDev &E, uint32_t move, bool add, int lane)
+		__device__ __forceinline__ void solver_place(SolverShared &sh, const EngineDev &E, uint32_t move, bool add, int lane, bool prefetched = false,
+				uint8_t pf_e = 0)
 		{ // PatternCalculator::addMove / undoMove (PatternCalculator.cpp:68-105)
 			const int n = E.n;
 			const int s = move & 3, r = (move >> 2) & 127, c = (move >> 9) & 127;
@@ -517,7 +546,7 @@ namespace agx
 					sh.legal[r] |= (1u << c);
 			}
 			wave_sync();
-			solver_update_around(sh, E, r, c, add, lane);
+			solver_update_around(sh, E, r, c, add, lane, prefetched, pf_e);
 			if (lane == 0)
 			{
 				sh.sign_to_move = 3 - sh.sign_to_move;
@@ -1755,7 +1784,8 @@ namespace agx
 		 * phase: 0 = enter frame `level`, 1 = resume frame `level` after its child returned sh.pending_value.
 		 */
 		template<bool RENJU>
-		__device__ __forceinline__ int solver_run(SolverShared &sh, const EngineDev &E, uint32_t *act, u64 *tt, int generation, int lane, u64 &pf_word)
+		__device__ __forceinline__ int solver_run(SolverShared &sh, const EngineDev &E, uint32_t *act, u64 *tt, int generation, int lane, u64 &pf_word,
+				uint8_t &pf_pattern, int &pf_pattern_tag)
 		{ // executed by ALL lanes with identical (wave-uniform) state: stores are same-address / same-value, scans are lane-parallel.
 		  // The scalars of the machine and the current frame are held in registers and written back to LDS only when the machine yields.
 			AGX_PROF_BEGIN();
@@ -1932,6 +1962,8 @@ namespace agx
 							else
 							{
 								const uint32_t mv = a & 0xFFFFu;
+								pf_pattern = pattern_prefetch(sh, E, n, mv, true, lane); // consumed by the solver_place this yield asks for
+								pf_pattern_tag = static_cast<int>(mv) | 0x10000;
 								const int cell = ((mv >> 2) & 127) * n + ((mv >> 9) & 127);
 								const uint32_t zi = __builtin_amdgcn_readfirstlane(2 * (2 * cell + ((mv & 3) - 1)));
 								hash_lo ^= zobrist_word(zseed, zi);
@@ -2002,6 +2034,12 @@ namespace agx
 					uint32_t best = f.best_score;
 					if (f.size == 0 || (s_loss(best) && !f.fully_expanded))
 						best = solver_evaluate(sh);
+					if (level > 0)
+					{ // the stone of the parent's move comes off next: its pattern entries travel while the table is updated
+						const uint32_t umv = sh.frames[level - 1].move;
+						pf_pattern = pattern_prefetch(sh, E, n, umv, false, lane);
+						pf_pattern_tag = static_cast<int>(umv);
+					}
 					int bound;
 					if (best <= f.original_alpha)
 						bound = 2;

@@ -242,6 +242,8 @@ namespace
 		wave_sync();
 		uint32_t result = s_unknown(0);
 		u64 pf_word = 0; // lanes 0-7: the transposition-table bucket prefetched for the frame about to be entered
+		uint8_t pf_pattern = 0; // pattern-table entries prefetched for the stone about to be placed / removed (dev_solver.hpp:pattern_prefetch)
+		int pf_pattern_tag = -1; // move | add << 16 they belong to
 		for (int depth = 0; depth <= E.tss_max_depth; depth += 4)
 		{
 			int stack_before = 0;
@@ -263,7 +265,8 @@ namespace
 #ifdef AGX_SOLVER_PROFILE
 				const unsigned long long r0 = wall_clock64();
 #endif
-				const int cmd_now = solver_run<RENJU>(sh, E, act, tt, generation, lane, pf_word);
+				pf_pattern_tag = -1;
+				const int cmd_now = solver_run<RENJU>(sh, E, act, tt, generation, lane, pf_word, pf_pattern, pf_pattern_tag);
 				if (lane == 0)
 					sh.cmd = cmd_now;
 				wave_sync();
@@ -273,9 +276,9 @@ namespace
 #endif
 				const int cmd = sh.cmd;
 				if (cmd == CMD_ADD)
-					solver_place(sh, E, static_cast<uint32_t>(sh.cmd_move), true, lane);
+					solver_place(sh, E, static_cast<uint32_t>(sh.cmd_move), true, lane, pf_pattern_tag == (sh.cmd_move | 0x10000), pf_pattern);
 				else if (cmd == CMD_UNDO)
-					solver_place(sh, E, static_cast<uint32_t>(sh.cmd_move), false, lane);
+					solver_place(sh, E, static_cast<uint32_t>(sh.cmd_move), false, lane, pf_pattern_tag == sh.cmd_move, pf_pattern);
 				else
 					break;
 #ifdef AGX_SOLVER_PROFILE
