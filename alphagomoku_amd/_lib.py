@@ -84,7 +84,7 @@ class AgxEngineConfig(ctypes.Structure):
                 ("edge_capacity", ctypes.c_int), ("record_capacity", ctypes.c_int), ("record_edge_capacity", ctypes.c_int),
                 ("solver_yield_fraction", ctypes.c_float), ("final_selector", ctypes.c_int), ("use_symmetries", ctypes.c_int),
                 ("symmetry_seed", ctypes.c_uint64), ("max_children", ctypes.c_int), ("noise_type", ctypes.c_int), ("noise_weight", ctypes.c_float),
-                ("noise_seed", ctypes.c_uint64), ("action_values", ctypes.c_int), ("match_mode", ctypes.c_int)]
+                ("noise_seed", ctypes.c_uint64), ("action_values", ctypes.c_int), ("match_mode", ctypes.c_int), ("policy_temperature", ctypes.c_float)]
 
 
 class AgxEngineBuffers(ctypes.Structure):

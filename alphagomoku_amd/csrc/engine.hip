@@ -524,6 +524,28 @@ namespace
 					e_win[i] = w;
 					e_draw[i] = d;
 				}
+				if (E.policy_temperature != 1.0f)
+				{ // initialize_edges with a temperature (:90-118)
+					if (E.policy_temperature == 0.0f)
+					{ // prior 1 where the policy holds its maximum over the WHOLE plane (maxValue(task.getPolicy())), 0 elsewhere
+						uint32_t mx = 0; // non-negative floats order like their bit patterns
+						if (by_network)
+							for (int i = lane; i < hw; i += 64)
+								mx = max(mx, __float_as_uint(E.nn_policy[static_cast<size_t>(slot) * hw + i]));
+						mx = wave_max_u32(mx);
+						for (int i = lane; i < n_e; i += 64)
+							e_prior[i] = (__float_as_uint(e_prior[i]) == mx) ? 1.0f : 0.0f;
+					}
+					else
+					{
+						const float inv_t = 1.0f / E.policy_temperature;
+						for (int i = lane; i < n_e; i += 64)
+						{
+							const float p = e_prior[i];
+							e_prior[i] = (p > 0.0f) ? static_cast<float>(det_exp(det_log(static_cast<double>(p)) * static_cast<double>(inv_t))) : 0.0f;
+						}
+					}
+				}
 				__syncthreads();
 				if ((path_len > 0 || E.match_mode) && s_proven(score))
 				{ // the root is exempt in self-play only (forceExpandRoot: GameGenerator.cpp:183-184, Player.cpp:111); prune_weak_moves, proven branch (:55-68): keep the best-scored edges in their original order
@@ -1618,6 +1640,7 @@ int agx_engine_default_config(AgxEngineConfig *cfg)
 	cfg->symmetry_seed = 0x5DEECE66Dull;
 	cfg->action_values = 0;
 	cfg->match_mode = 0;
+	cfg->policy_temperature = 1.0f;
 	cfg->noise_type = 0;
 	cfg->noise_weight = 0.0f;
 	cfg->noise_seed = 0x2545F4914F6CDD1Dull;
@@ -1635,6 +1658,7 @@ int agx_engine_create(const AgxEngineConfig *cfg, AgxEngine **out)
 	AGX_REQUIRE(cfg->solver_yield_fraction >= 0.0f && cfg->solver_yield_fraction <= 1.0f, AGX_ERR_INVALID, "agx_engine_create: solver_yield_fraction must be in [0, 1]");
 	AGX_REQUIRE(cfg->final_selector >= 0 && cfg->final_selector <= 5, AGX_ERR_INVALID, "agx_engine_create: final_selector must be 0..5");
 	AGX_REQUIRE(cfg->noise_type >= 0 && cfg->noise_type <= 3, AGX_ERR_INVALID, "agx_engine_create: noise_type must be 0 (none), 1 (custom), 2 (dirichlet) or 3 (gumbel)");
+	AGX_REQUIRE(cfg->policy_temperature >= 0.0f, AGX_ERR_INVALID, "agx_engine_create: policy_temperature must not be negative");
 	AGX_REQUIRE(!cfg->match_mode || cfg->n_games % 2 == 0, AGX_ERR_INVALID, "agx_engine_create: match_mode pairs the trees, n_games must be even");
 	AGX_REQUIRE(cfg->noise_weight >= 0.0f && cfg->noise_weight <= 1.0f, AGX_ERR_INVALID, "agx_engine_create: noise_weight must be in [0, 1]");
 
@@ -1706,6 +1730,7 @@ int agx_engine_create(const AgxEngineConfig *cfg, AgxEngine **out)
 	AGX_TRY(dev_alloc(e, &d.nn_value, G * d.batch * 3));
 	d.has_q = cfg->action_values ? 1 : 0;
 	d.match_mode = cfg->match_mode ? 1 : 0;
+	d.policy_temperature = cfg->policy_temperature;
 	AGX_TRY(dev_alloc(e, &d.nn_q, d.has_q ? G * d.batch * d.hw * 2 : 1));
 	AGX_TRY(dev_alloc(e, &d.noise, d.noise_type ? G * d.hw : 1));
 	AGX_TRY(dev_alloc(e, &d.nn_list, G * d.batch));

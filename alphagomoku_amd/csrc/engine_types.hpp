@@ -143,6 +143,7 @@ namespace agx
 			int init_to;
 			float leak_threshold, expansion_threshold;
 			int max_children;
+			float policy_temperature; // MCTSConfig::policy_temperature (initialize_edges, EdgeGenerator.cpp:88-127)
 			int tss_max_nodes, tss_max_depth;
 			unsigned long long zobrist_seed;
 			unsigned long long tt_bucket_mask; // buckets - 1 (4 entries of 16 bytes per bucket)

@@ -155,6 +155,10 @@ typedef struct AgxEngineConfig
 	                                     any other node, UnifiedGenerator's forceExpandRoot = false).  Every opening is played twice with
 	                                     the colours swapped.  Drive it with agx_engine_step_match(e, first_net, second_net, s), or with two
 	                                     groups on ONE stream: agx_engine_step_group(e, first_net, 0, 2, s); ..._group(e, second_net, 1, 2, s). */
+	float policy_temperature;         /* MCTSConfig::policy_temperature (initialize_edges, EdgeGenerator.cpp:88-127): 1 = priors are the policy
+	                                     (reference default); 0 = prior 1 for the cells that hold the policy maximum, 0 elsewhere; otherwise
+	                                     policy^(1/T), evaluated as exp(log(p)/T) with the fixed double-precision series of csrc/root_noise.hpp
+	                                     (the reference calls std::pow), so device and oracle agree bit for bit. */
 } AgxEngineConfig;
 
 typedef struct AgxEngine AgxEngine; /* opaque */

@@ -104,6 +104,7 @@ namespace agx
 			std::string noise_type = "none";      // EdgeSelectorConfig::noise_type: "none", "custom", "dirichlet", "gumbel"
 			float noise_weight = 0.0f;
 			float policy_expansion_threshold = 1.0e-4f;
+			float policy_temperature = 1.0f; // MCTSConfig::policy_temperature
 			int max_children = 0;                 // MCTSConfig::max_children, 0 = unlimited
 			float information_leak_threshold = 0.01f;
 			int tss_max_positions = 100;
@@ -154,6 +155,7 @@ namespace agx
 				c.init_to = (init == "q_head") ? 0 : (init == "parent") ? 1 : (init == "draw") ? 2 : 3; // EdgeSelector.cpp:1140-1165
 				c.policy_expansion_threshold = selfplay.search_config.policy_expansion_threshold;
 				c.max_children = selfplay.search_config.max_children;
+				c.policy_temperature = selfplay.search_config.policy_temperature;
 				c.information_leak_threshold = selfplay.search_config.information_leak_threshold;
 				c.tss_max_positions = selfplay.search_config.tss_max_positions;
 				c.tss_table_entries = selfplay.search_config.tss_table_entries;

@@ -461,6 +461,13 @@ void ago_game_set_force_expand_root(void *h, int value)
 	g->game.tree.scfg.force_expand_root = value;
 	g->game.search.scfg.force_expand_root = value;
 }
+void ago_game_set_policy_temperature(void *h, float value)
+{
+	GameHandle *g = static_cast<GameHandle*>(h);
+	g->game.scfg.policy_temperature = value;
+	g->game.tree.scfg.policy_temperature = value;
+	g->game.search.scfg.policy_temperature = value;
+}
 void ago_game_match_begin(void *h, const uint16_t *opening, int n)
 {
 	std::vector<Move> o;

@@ -326,6 +326,21 @@ namespace ago
 			e.value = t.action_values[i];
 			e.score = t.action_scores[i];
 		}
+		if (scfg.policy_temperature == 0.0f)
+		{ // :90-100: prior 1 where the policy holds its maximum over the whole plane
+			float max_p = t.policy[0];
+			for (float p : t.policy)
+				max_p = std::max(max_p, p);
+			for (Edge &e : t.edges)
+				e.prior = (e.prior == max_p) ? 1.0f : 0.0f;
+		}
+		else if (scfg.policy_temperature != 1.0f)
+		{ // :111-117: std::pow(p, 1 / T) — evaluated here (and on the device) as exp(log(p) / T) with the fixed series of
+		  // oracle/ag_noise.hpp, so both sides agree bit for bit; libm's powf differs in the last bits
+			const float inv_t = 1.0f / scfg.policy_temperature;
+			for (Edge &e : t.edges)
+				e.prior = (e.prior > 0.0f) ? static_cast<float>(det_exp(det_log(static_cast<double>(e.prior)) * static_cast<double>(inv_t))) : 0.0f;
+		}
 		const bool expand_fully = t.path.empty() && scfg.force_expand_root != 0; // relative depth 0 and force_expand_root == true (GameGenerator.cpp:183-184)
 		if (!expand_fully)
 		{ // prune_weak_moves (:49-86)

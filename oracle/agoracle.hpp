@@ -380,6 +380,7 @@ namespace ago
 			int noise_type = 0;              // EdgeSelectorConfig::noise_type: 0 "none", 1 "custom", 2 "dirichlet", 3 "gumbel" (EdgeSelector.cpp:602-623; oracle/ag_noise.hpp)
 			float noise_weight = 0.0f;
 			uint64_t noise_seed = 0x2545F4914F6CDD1Dull;
+			float policy_temperature = 1.0f; // MCTSConfig::policy_temperature (initialize_edges, EdgeGenerator.cpp:88-127)
 			int force_expand_root = 1;       // UnifiedGenerator's 4th argument: true in self-play (GameGenerator.cpp:183-184), default false for an
 			                                 // evaluation Player (Player.cpp:111, EdgeGenerator.hpp:59)
 	};

@@ -143,7 +143,7 @@ def _oracle_root(olib, h):
 
 
 def _play_and_compare(olib, rules, games, batch, sims, max_steps, evaluator, table_entries=1 << 16, n=N, final_selector=0, use_symmetries=0,
-                      action_values=0, noise_weight=0.0, noise_type=1, exploration_scaling=0.0, draw_after=0, max_children=0):
+                      action_values=0, noise_weight=0.0, noise_type=1, exploration_scaling=0.0, draw_after=0, max_children=0, policy_temperature=1.0):
     """evaluator(features uint32 [n][HW]) -> (policy [n][HW] f32, value [n][2] f32 (win, draw)[, q [n][HW][2]]); used for BOTH sides"""
     from alphagomoku_amd import selfplay
     N, HW = n, n * n   # noqa: N806 (shadow the 15x15 module defaults)
@@ -151,7 +151,7 @@ def _play_and_compare(olib, rules, games, batch, sims, max_steps, evaluator, tab
                                   tss_table_entries=table_entries, node_capacity=4096, edge_capacity=65536 if n <= 15 else 131072,
                                   final_selector=final_selector, use_symmetries=use_symmetries, action_values=action_values,
                                   noise_type=noise_type if noise_weight > 0 else 0, noise_weight=noise_weight,
-                                  exploration_scaling=exploration_scaling, max_children=max_children)
+                                  exploration_scaling=exploration_scaling, max_children=max_children, policy_temperature=policy_temperature)
     pool = selfplay.GeneratorPool(cfg)
     ocfg = ol.default_search_config(max_batch_size=batch, max_simulations=sims, table_entries=table_entries, final_selector=final_selector,
                                     use_symmetries=use_symmetries, noise_type=noise_type if noise_weight > 0 else 0, noise_weight=noise_weight)
@@ -165,6 +165,7 @@ def _play_and_compare(olib, rules, games, batch, sims, max_steps, evaluator, tab
         openings.append([int(x) for x in op[:k]])
         h = olib.ago_game_create_ex(rules, N, N, draw_after, ctypes.byref(ocfg))
         olib.ago_game_set_serial(h, g)   # the device keys the symmetry hash by the opening id
+        olib.ago_game_set_policy_temperature(h, policy_temperature)
         olib.ago_game_begin(h, ol.ptr(op), k)
         handles.append(h)
     pool.begin(selfplay.pack_openings(openings))
@@ -289,6 +290,17 @@ def test_max_children_pruning(agx_lib, olib, rules, max_children):
     assert compared > 200 and stats["games_finished"] == 4
     _, plain = _play_and_compare(olib, rules, games=4, batch=4, sims=80, max_steps=4000, evaluator=_stand_in_evaluator(olib))
     assert plain["peak_edges"] > stats["peak_edges"]      # pruned trees are smaller
+
+
+@pytest.mark.parametrize("rules,temperature", [(0, 0.5), (1, 2.0), (0, 0.0)])
+def test_policy_temperature(agx_lib, olib, rules, temperature):
+    """MCTSConfig::policy_temperature (initialize_edges, EdgeGenerator.cpp:88-127): priors policy^(1/T), or the arg-max indicator for
+    T = 0; the power is exp(log(p)/T) with the fixed series on both sides, so the games match the oracle bit for bit"""
+    compared, stats = _play_and_compare(olib, rules, games=4, batch=4, sims=60, max_steps=4000, evaluator=_stand_in_evaluator(olib),
+                                        policy_temperature=temperature, draw_after=90)
+    assert compared > 150 and stats["games_finished"] == 4
+    _, plain = _play_and_compare(olib, rules, games=4, batch=4, sims=60, max_steps=4000, evaluator=_stand_in_evaluator(olib), draw_after=90)
+    assert (plain["moves_played"], plain["evaluated_nodes"]) != (stats["moves_played"], stats["evaluated_nodes"])
 
 
 def test_exploration_scaling(agx_lib, olib):
