@@ -117,7 +117,7 @@ class AgxGameInfo(ctypes.Structure):
 class AgxMoveRecord(ctypes.Structure):
     _fields_ = [("game_serial", ctypes.c_int), ("move_number", ctypes.c_int), ("move", ctypes.c_uint16), ("root_score", ctypes.c_uint16),
                 ("root_visits", ctypes.c_int), ("root_win", ctypes.c_float), ("root_draw", ctypes.c_float), ("n_edges", ctypes.c_int),
-                ("edge_offset", ctypes.c_int)]
+                ("edge_offset", ctypes.c_int), ("root_flags", ctypes.c_int)]
 
 
 _declare_nn = _declare

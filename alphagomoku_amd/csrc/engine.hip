@@ -1180,6 +1180,7 @@ namespace
 				h.root_draw = root.draw;
 				h.n_edges = root.n_edges;
 				h.edge_offset = eoff;
+				h.root_flags = (root.flags >> 3) & 7; // DNode flags 8 / 16 / 32
 				E.records[rec] = h;
 			}
 		}
@@ -2191,6 +2192,7 @@ int agx_engine_records(AgxEngine *e, AgxMoveRecord *h_records, int record_capaci
 		h_records[i].root_visits = headers[i].root_visits;
 		h_records[i].root_win = headers[i].root_win;
 		h_records[i].root_draw = headers[i].root_draw;
+		h_records[i].root_flags = headers[i].root_flags;
 		h_records[i].n_edges = headers[i].n_edges;
 		h_records[i].edge_offset = headers[i].edge_offset;
 	}

@@ -127,6 +127,7 @@ namespace agx
 			float root_draw;
 			int32_t n_edges;
 			int32_t edge_offset; // into the record edge pool
+			int32_t root_flags;  // bit 0 statically solved, 1 recursively solved, 2 must defend (SearchDataPack::flags, data_packs.cpp:40-42)
 	};
 
 	enum EngineError : int32_t

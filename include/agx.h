@@ -223,6 +223,7 @@ typedef struct AgxMoveRecord
 	int root_visits;
 	float root_win, root_draw;
 	int n_edges, edge_offset;
+	int root_flags; /* SearchDataPack::flags: bit 0 root statically solved, 1 recursively solved, 2 must defend (data_packs.cpp:40-42) */
 } AgxMoveRecord;
 
 #define AGX_OPENING_CAP 32 /* uint16 per opening: [0] = number of stones, [1..] = Move::toShort */

@@ -461,6 +461,10 @@ void ago_game_set_force_expand_root(void *h, int value)
 	g->game.tree.scfg.force_expand_root = value;
 	g->game.search.scfg.force_expand_root = value;
 }
+int ago_game_record_flags(void *h, int index)
+{
+	return static_cast<GameHandle*>(h)->game.records[index].root_flags;
+}
 void ago_game_set_policy_temperature(void *h, float value)
 {
 	GameHandle *g = static_cast<GameHandle*>(h);

@@ -555,6 +555,7 @@ namespace ago
 					std::vector<Edge> root_edges;
 					Value root_value;
 					Score root_score;
+					int root_flags = 0; // SearchDataPack::flags (data_packs.cpp:40-42)
 			};
 			std::vector<MoveRecord> records;
 			bool is_over() const { return outcome != O_UNKNOWN; }

@@ -54,6 +54,7 @@ def load():
         lib.ago_game_set_serial.argtypes = [ctypes.c_void_p, ctypes.c_int]
         lib.ago_apply_symmetry.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         lib.ago_game_set_force_expand_root.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        lib.ago_game_record_flags.argtypes = [ctypes.c_void_p, ctypes.c_int]
         lib.ago_game_set_policy_temperature.argtypes = [ctypes.c_void_p, ctypes.c_float]
         lib.ago_game_match_begin.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
         lib.ago_game_take_turn.argtypes = [ctypes.c_void_p]

@@ -218,6 +218,7 @@ def _play_and_compare(olib, rules, games, batch, sims, max_steps, evaluator, tab
     for g in range(games):
         dev_moves = [r.move for r in recs if r.game_serial == g]
         n = olib.ago_game_num_records(handles[g])
+        assert [r.root_flags for r in recs if r.game_serial == g] == [olib.ago_game_record_flags(handles[g], i) for i in range(n)], g
         om = []
         for i in range(n):
             mv, rv, rs = ctypes.c_uint16(), ctypes.c_int(), ctypes.c_uint16()
