@@ -865,10 +865,11 @@ namespace
 		clear_solver_table(E, g, tid);
 	}
 	/* loads opening `id` into game g: Game::loadOpening + prepare_search on an empty tree (GameGenerator.cpp:48-77,174-185) */
-	__device__ void begin_game(const EngineDev &E, int g, int id, int tid, u64 *scratch)
+	__device__ void begin_game(const EngineDev &E, int g, int id, int tid, u64 *scratch, bool tables_cleared = false)
 	{
 		GameState &gs = E.games[g];
-		clear_tree_and_table(E, g, tid);
+		if (!tables_cleared)
+			clear_tree_and_table(E, g, tid);
 		for (int i = tid; i < E.hw; i += 256)
 			gs.board[i] = 0;
 		if (tid < BWORDS)
@@ -1352,6 +1353,34 @@ namespace
 			__syncthreads();
 		}
 	}
+	/*
+	 * Tree::clear + AlphaBetaSearch::clear for the games about to restart, spread over `parts` workgroups per game: a 4 Mi-entry
+	 * solver table is 64 MB, which one workgroup takes a millisecond to fill — longer than every other kernel of the step but two.
+	 * Match mode: both trees of a pair whose first player's tree carries the restart request; the node tables stay (Player keeps
+	 * its tree).
+	 */
+	__global__ __launch_bounds__(256) void k_clear_tables(EngineDev E, int parts)
+	{
+		const int g = E.g0 + blockIdx.x / parts, part = blockIdx.x % parts, tid = threadIdx.x;
+		const int asks = E.match_mode ? g % (E.n_games / 2) : g;
+		if (E.games[asks].restart_id <= 0)
+			return;
+		ulonglong2 *tt = reinterpret_cast<ulonglong2*>(E.tt + static_cast<size_t>(g) * (E.tt_bucket_mask + 1ull) * 8ull);
+		const size_t entries = (E.tt_bucket_mask + 1ull) * 4ull;
+		const size_t per = (entries + parts - 1) / parts;
+		const size_t end = (per * (part + 1) < entries) ? per * (part + 1) : entries;
+		ulonglong2 empty;
+		empty.x = 0ull;
+		empty.y = tt_pack(0, 0, s_unknown(0), 0);
+		for (size_t i = per * part + tid; i < end; i += 256)
+			tt[i] = empty;
+		if (!E.match_mode)
+		{
+			int *ht = ht_of(E, g);
+			for (int i = part * 256 + tid; i < E.ht_cap; i += parts * 256)
+				ht[i] = 0;
+		}
+	}
 	__global__ __launch_bounds__(256) void k_restart(EngineDev E)
 	{
 		__shared__ u64 scratch[4];
@@ -1360,7 +1389,7 @@ namespace
 		if (id <= 0)
 			return;
 		__syncthreads();
-		begin_game(E, g, id - 1, tid, scratch);
+		begin_game(E, g, id - 1, tid, scratch, true); // k_clear_tables ran just before
 	}
 
 	/*
@@ -1383,8 +1412,7 @@ namespace
 		for (int k = 0; k < 2; k++)
 		{
 			const int t = k ? part : lead;
-			GameState &gs = E.games[t];
-			clear_solver_table(E, t, tid);
+			GameState &gs = E.games[t]; // (both solver tables were emptied by k_clear_tables just before)
 			for (int i = tid; i < E.hw; i += 256)
 				gs.board[i] = 0;
 			if (tid < BWORDS)
@@ -1841,6 +1869,8 @@ static int group_range(const AgxEngine *e, int group, int n_groups, EngineDev &d
 	return AGX_OK;
 }
 
+static constexpr int CLEAR_PARTS = 16; // workgroups per restarting game in k_clear_tables
+
 static void launch_solve(const EngineDev &d, int count, hipStream_t s)
 {
 	const dim3 grid(count), block(64);
@@ -1932,6 +1962,7 @@ int agx_engine_expand_backup_match(AgxEngine *e, void *stream)
 		// a moving tree's workgroup also rebases its partner's tree; the partner's own workgroup has nothing to do (it is not searching)
 		hipLaunchKernelGGL(k_advance, dim3(d.n_games), dim3(256), 0, s, d);
 		hipLaunchKernelGGL(k_assign_openings, dim3(1), dim3(1024), 0, s, d, d.n_games / 2);
+		hipLaunchKernelGGL(k_clear_tables, dim3(d.n_games * CLEAR_PARTS), dim3(256), 0, s, d, CLEAR_PARTS);
 		hipLaunchKernelGGL(k_match_restart, dim3(d.n_games / 2), dim3(256), 0, s, d);
 	}
 	AGX_HIP_CHECK(hipGetLastError());
@@ -1992,11 +2023,17 @@ int agx_engine_expand_backup_group(AgxEngine *e, int group, int n_groups, void *
 		if (!d.match_mode)
 		{
 			hipLaunchKernelGGL(k_assign_openings, dim3(1), dim3(1024), 0, s, d, count);
+			hipLaunchKernelGGL(k_clear_tables, dim3(count * CLEAR_PARTS), dim3(256), 0, s, d, CLEAR_PARTS);
 			hipLaunchKernelGGL(k_restart, dim3(count), dim3(256), 0, s, d);
 		}
 		else if (group == 0)
 		{ // restarts go by pair, requested through the first players' trees (= group 0)
 			hipLaunchKernelGGL(k_assign_openings, dim3(1), dim3(1024), 0, s, d, count);
+			{
+				EngineDev all = d; // both players' trees
+				all.g0 = 0;
+				hipLaunchKernelGGL(k_clear_tables, dim3(all.n_games * CLEAR_PARTS), dim3(256), 0, s, all, CLEAR_PARTS);
+			}
 			hipLaunchKernelGGL(k_match_restart, dim3(count), dim3(256), 0, s, d);
 		}
 	}
