@@ -47,6 +47,52 @@ namespace agx
 			}
 			return -1;
 		}
+		/* the fields of a node record that the descent reads (everything but the compressed board), as one group of loads */
+		__device__ __forceinline__ void node_head(DNode &dst, const DNode &src)
+		{
+			dst.edge_begin = src.edge_begin;
+			dst.win = src.win;
+			dst.draw = src.draw;
+			dst.moves_left = src.moves_left;
+			dst.visits = src.visits;
+			dst.score = src.score;
+			dst.n_edges = src.n_edges;
+			dst.depth = src.depth;
+			dst.vl = src.vl;
+			dst.sign_to_move = src.sign_to_move;
+			dst.flags = src.flags;
+			dst.hash = src.hash;
+		}
+		/* cache_seek for the descent: the candidate's head is requested together with its board words, so the node found costs no
+		 * further round trip (the leak test and the next level's selection read `head`) */
+		__device__ inline int cache_seek_head(const EngineDev &E, const DNode *nodes, const int *ht, u64 hash, const u64 *cboard, int sign, int lane, DNode &head)
+		{
+			const int mask = E.ht_cap - 1;
+			int slot = static_cast<int>(hash & static_cast<u64>(mask));
+			for (int probes = 0; probes < E.ht_cap; probes++)
+			{
+				const int idx = ht[slot];
+				if (idx == 0)
+					return -1;
+				const DNode &nd = nodes[idx - 1];
+				DNode h;
+				node_head(h, nd);
+				const u64 word = (lane < BWORDS) ? nd.cboard[lane] : 0ull;
+				bool same = (h.hash == hash) && (h.sign_to_move == sign);
+				if (same)
+				{
+					const bool word_ok = (lane < BWORDS) ? (word == cboard[lane]) : true;
+					same = (__ballot(!word_ok) == 0);
+				}
+				if (same)
+				{
+					head = h;
+					return idx - 1;
+				}
+				slot = (slot + 1) & mask;
+			}
+			return -1;
+		}
 		__device__ inline void cache_insert(const EngineDev &E, int *ht, u64 hash, int node)
 		{ // single lane
 			const int mask = E.ht_cap - 1;
@@ -57,14 +103,14 @@ namespace agx
 		}
 
 		/* has_information_leak (Tree.cpp:75-85) */
-		__device__ inline bool has_leak(const EngineDev &E, const DEdge &e, const DNode *node)
+		__device__ inline bool has_leak(const EngineDev &E, const DEdge &e, bool node_found, uint32_t node_score, float node_win, float node_draw)
 		{
-			if (node == nullptr || E.leak_threshold >= 1.0f)
+			if (!node_found || E.leak_threshold >= 1.0f)
 				return false;
-			if (e.score != s_invert_up(node->score))
+			if (e.score != s_invert_up(node_score))
 				return true;
-			const float inv_win = 1.0f - (node->win + node->draw);
-			const float dw = e.win - inv_win, dd = e.draw - node->draw;
+			const float inv_win = 1.0f - (node_win + node_draw);
+			const float dw = e.win - inv_win, dd = e.draw - node_draw;
 			return (fabsf(dw) + fabsf(dd)) > E.leak_threshold;
 		}
 

@@ -37,10 +37,13 @@ namespace
 	{
 		__shared__ uint8_t sh_board[MAXHW];
 		__shared__ u64 sh_cboard[BWORDS];
+		__shared__ u64 sh_keys[3 * (1 + MAXHW)]; // FullZobristHashing keys of the node cache: four per level, from LDS instead of L2
 		const int g = E.g0 + blockIdx.x, lane = threadIdx.x;
 		GameState &gs = E.games[g];
 		if (!gs.active || gs.error != 0 || gs.outcome != 0 || gs.solve_pending)
 			return;
+		for (int i = lane; i < 3 * (1 + E.hw); i += 64)
+			sh_keys[i] = E.nc_keys[i];
 		DNode *nodes = nodes_of(E, g, gs.arena);
 		DEdge *edges = edges_of(E, g, gs.arena);
 		const int *ht = ht_of(E, g);
@@ -80,6 +83,11 @@ namespace
 			u64 hash = gs.root_hash;
 			int last_edge = -1;
 			int node = root;
+			// One dependent chain per level: edges of the node -> the chosen edge -> table slot -> the child's record.  The node
+			// record is read ONCE (by the seek that found it), the chosen edge once, and the hash keys come from LDS.
+			DNode nd;
+			if (node >= 0)
+				node_head(nd, nodes[node]);
 			while (node >= 0)
 			{
 				if (path_len >= PATH_CAP)
@@ -88,11 +96,12 @@ namespace
 						gs.error = ERR_PATH_CAPACITY;
 					break;
 				}
-				const DNode nd = nodes[node];
 				const int e = select_edge(E, nd, edges, lane, st_edges, (node == root && gs.noise_ready) ? E.noise + static_cast<size_t>(g) * E.hw : nullptr);
 				st_levels++;
-				const uint32_t mv = edges[e].move;
+				const DEdge ee = edges[e]; // as it was before this visit's virtual loss (what the leak test compares, Tree.cpp:75-85)
+				const uint32_t mv = ee.move;
 				const int s = mv & 3, cell = ((mv >> 2) & 127) * n + ((mv >> 9) & 127);
+				const uint16_t flag_vl = static_cast<uint16_t>((ee.flag_vl & 0x8000u) | (((ee.flag_vl & 0x7FFF) + 1) & 0x7FFF));
 				if (lane == 0)
 				{ // SearchTask::append (SearchTask.cpp:52-60) + virtual loss (Tree.cpp:235-236)
 					sh_board[cell] = static_cast<uint8_t>(s);
@@ -100,28 +109,29 @@ namespace
 					t.path_node[path_len] = node;
 					t.path_edge[path_len] = e;
 					nodes[node].vl = static_cast<int16_t>(nd.vl + 1);
-					edges[e].flag_vl = static_cast<uint16_t>((edges[e].flag_vl & 0x8000u) | (((edges[e].flag_vl & 0x7FFF) + 1) & 0x7FFF));
+					edges[e].flag_vl = flag_vl;
 				}
-				hash ^= E.nc_keys[3 + 3 * cell] ^ E.nc_keys[3 + 3 * cell + s] ^ E.nc_keys[sign] ^ E.nc_keys[3 - s];
+				hash ^= sh_keys[3 + 3 * cell] ^ sh_keys[3 + 3 * cell + s] ^ sh_keys[sign] ^ sh_keys[3 - s];
 				sign = 3 - s;
 				path_len++;
 				last_edge = e;
 				__syncthreads();
-				if (s_proven(edges[e].score))
+				if (s_proven(ee.score))
 				{
 					out = 2;
 					break;
 				}
-				node = cache_seek(E, nodes, ht, hash, sh_cboard, sign, lane);
+				DNode child;
+				node = cache_seek_head(E, nodes, ht, hash, sh_cboard, sign, lane, child);
 				final_node = node;
 				if (node < 0 && lane == 0)
-					edges[e].flag_vl |= 0x8000u;
-				const DEdge ee = edges[e];
-				if (has_leak(E, ee, (node >= 0) ? &nodes[node] : nullptr))
+					edges[e].flag_vl = static_cast<uint16_t>(flag_vl | 0x8000u);
+				if (has_leak(E, ee, node >= 0, child.score, child.win, child.draw))
 				{
 					out = 1;
 					break;
 				}
+				nd = child;
 			}
 			// publish the task
 			for (int i = lane; i < E.hw; i += 64)
@@ -754,7 +764,7 @@ namespace
 					if (path_len > 0)
 					{
 						const DEdge le = edges[t.path_edge[path_len - 1]];
-						if (has_leak(E, le, &nodes[found]))
+						if (has_leak(E, le, true, nodes[found].score, nodes[found].win, nodes[found].draw))
 							correct_information_leak(nodes, edges, t, path_len, final_node, lane);
 					}
 				}
