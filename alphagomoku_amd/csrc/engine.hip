@@ -787,43 +787,59 @@ namespace
 			const float win = t.win, draw = t.draw;
 			const int path_len = t.path_len, sign = t.sign_to_move, final_node = t.final_node;
 			// ---- Tree::backup (Tree.cpp:299-351) ----
+			// Every lane carries the same arithmetic (lane 0 stores it): a level costs one round trip for its node head + edge and one
+			// for the score scan; the child's score travels up in a register instead of being read back.
 			float ml = t.moves_left;
+			bool have_child = final_node >= 0;
+			uint32_t child_score = have_child ? nodes[final_node].score : 0u;
 			for (int i = path_len - 1; i >= 0; i--)
 			{
 				const int node = t.path_node[i], e = t.path_edge[i];
-				const int next = (i == path_len - 1) ? final_node : t.path_node[i + 1];
-				uint32_t new_score = 0;
+				DNode nd;
+				node_head(nd, nodes[node]);
+				DEdge ed = edges[e];
+				float vw = win, vd = draw;
+				if (nd.sign_to_move != sign)
+				{
+					vw = 1.0f - (win + draw);
+					vd = draw;
+				}
+				nd.visits++;
+				const float tn = static_cast<float>(1.0 / nd.visits); // Node::updateValue: reciprocal in double, narrowed
+				nd.win = fmaxf(0.0f, fminf(1.0f, nd.win + (vw - nd.win) * tn));
+				nd.draw = fmaxf(0.0f, fminf(1.0f, nd.draw + (vd - nd.draw) * tn));
+				ed.visits++;
+				const float te = 1.0f / ed.visits; // Edge::updateValue: fp32 reciprocal
+				ed.win = fmaxf(0.0f, fminf(1.0f, ed.win + (vw - ed.win) * te));
+				ed.draw = fmaxf(0.0f, fminf(1.0f, ed.draw + (vd - ed.draw) * te));
+				nd.moves_left += (ml - nd.moves_left) / nd.visits;
+				uint32_t new_score = ed.score;
+				if (have_child)
+					new_score = s_invert_up(child_score);
+				ed.score = static_cast<uint16_t>(new_score);
+				nd.vl--;
+				ed.flag_vl = static_cast<uint16_t>(((ed.flag_vl & 0x7FFF) - 1) & 0x7FFF);
+				// update_score(Node*) (Tree.cpp:93-104) on the registers
+				uint32_t result = 0;
+				for (int j = lane; j < nd.n_edges; j += 64)
+					result = max(result, (nd.edge_begin + j == e) ? new_score : static_cast<uint32_t>(edges[nd.edge_begin + j].score));
+				result = wave_max_u32(result);
+				if (((nd.flags & 4) != 0) || s_win(result) || s_unproven(result))
+					nd.score = static_cast<uint16_t>(result);
 				if (lane == 0)
 				{
-					DNode &nd = nodes[node];
-					DEdge &ed = edges[e];
-					float vw = win, vd = draw;
-					if (nd.sign_to_move != sign)
-					{
-						vw = 1.0f - (win + draw);
-						vd = draw;
-					}
-					nd.visits++;
-					const float tn = static_cast<float>(1.0 / nd.visits); // Node::updateValue: reciprocal in double, narrowed
-					nd.win = fmaxf(0.0f, fminf(1.0f, nd.win + (vw - nd.win) * tn));
-					nd.draw = fmaxf(0.0f, fminf(1.0f, nd.draw + (vd - nd.draw) * tn));
-					ed.visits++;
-					const float te = 1.0f / ed.visits; // Edge::updateValue: fp32 reciprocal
-					ed.win = fmaxf(0.0f, fminf(1.0f, ed.win + (vw - ed.win) * te));
-					ed.draw = fmaxf(0.0f, fminf(1.0f, ed.draw + (vd - ed.draw) * te));
-					nd.moves_left += (ml - nd.moves_left) / nd.visits;
-					new_score = ed.score;
-					if (next >= 0)
-					{
-						new_score = s_invert_up(nodes[next].score);
-						ed.score = static_cast<uint16_t>(new_score);
-					}
-					nd.vl--;
-					ed.flag_vl = static_cast<uint16_t>(((ed.flag_vl & 0x7FFF) - 1) & 0x7FFF);
+					DNode &dn = nodes[node];
+					dn.visits = nd.visits;
+					dn.win = nd.win;
+					dn.draw = nd.draw;
+					dn.moves_left = nd.moves_left;
+					dn.vl = nd.vl;
+					dn.score = nd.score;
+					edges[e] = ed;
 				}
+				child_score = nd.score;
+				have_child = true;
 				ml += 1.0f;
-				new_score = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(new_score)));
-				update_node_score(nodes, edges, node, e, new_score, lane);
 			}
 			__syncthreads();
 		}
