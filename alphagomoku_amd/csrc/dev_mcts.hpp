@@ -241,53 +241,58 @@ namespace agx
 			return nd.edge_begin + best;
 		}
 
-		/* update_score(Node*) (Tree.cpp:93-104); `changed_edge` (absolute index, or -1) carries a score still held in a register */
-		__device__ inline void update_node_score(DNode *nodes, const DEdge *edges, int node, int changed_edge, uint32_t changed_score, int lane)
-		{
-			const int begin = nodes[node].edge_begin, cnt = nodes[node].n_edges;
-			uint32_t result = 0;
-			for (int i = lane; i < cnt; i += 64)
-				result = max(result, (begin + i == changed_edge) ? changed_score : static_cast<uint32_t>(edges[begin + i].score));
-			result = wave_max_u32(result);
-			if (lane == 0 && (((nodes[node].flags & 4) != 0) || s_win(result) || s_unproven(result)))
-				nodes[node].score = static_cast<uint16_t>(result);
-		}
-
-		/* Tree::correctInformationLeak (Tree.cpp:352-376) */
+		/* Tree::correctInformationLeak (Tree.cpp:352-376).  Every lane carries the same arithmetic (lane 0 stores it); a level reads
+		 * its node head and edge once and the child's value / score travel up in registers.  final_node exists (a leak needs one). */
 		__device__ inline void correct_information_leak(DNode *nodes, DEdge *edges, const DTask &t, int path_len, int final_node, int lane)
 		{
+			float child_win = nodes[final_node].win, child_draw = nodes[final_node].draw;
+			uint32_t child_score = nodes[final_node].score;
 			for (int i = path_len - 1; i >= 0; i--)
 			{
 				const int node = t.path_node[i], e = t.path_edge[i];
-				const int next = (i == path_len - 1) ? final_node : t.path_node[i + 1];
-				uint32_t new_score = 0;
+				DNode nd;
+				node_head(nd, nodes[node]);
+				DEdge ed = edges[e];
+				const float cw = ed.win, cd = ed.draw;
+				const float tw = 1.0f - (child_win + child_draw), td = child_draw;
+				const float scale = static_cast<float>(ed.visits) / static_cast<float>(nd.visits);
+				const float nw = nd.win + (tw - cw) * scale, ndr = nd.draw + (td - cd) * scale;
+				ed.win = tw;
+				ed.draw = td;
+				nd.win = nw;
+				nd.draw = ndr;
+				const uint32_t new_score = s_invert_up(child_score);
+				ed.score = static_cast<uint16_t>(new_score);
+				// update_score(Node*) (Tree.cpp:93-104)
+				uint32_t result = 0;
+				for (int j = lane; j < nd.n_edges; j += 64)
+					result = max(result, (nd.edge_begin + j == e) ? new_score : static_cast<uint32_t>(edges[nd.edge_begin + j].score));
+				result = wave_max_u32(result);
+				if (((nd.flags & 4) != 0) || s_win(result) || s_unproven(result))
+					nd.score = static_cast<uint16_t>(result);
 				if (lane == 0)
 				{
-					const float cw = edges[e].win, cd = edges[e].draw;
-					const float tw = 1.0f - (nodes[next].win + nodes[next].draw), td = nodes[next].draw;
-					const float scale = static_cast<float>(edges[e].visits) / static_cast<float>(nodes[node].visits);
-					const float nw = nodes[node].win + (tw - cw) * scale, ndr = nodes[node].draw + (td - cd) * scale;
-					edges[e].win = tw;
-					edges[e].draw = td;
-					nodes[node].win = nw;
-					nodes[node].draw = ndr;
-					new_score = s_invert_up(nodes[next].score);
-					edges[e].score = static_cast<uint16_t>(new_score);
+					nodes[node].win = nd.win;
+					nodes[node].draw = nd.draw;
+					nodes[node].score = nd.score;
+					edges[e].win = ed.win;
+					edges[e].draw = ed.draw;
+					edges[e].score = ed.score;
 				}
-				new_score = __builtin_amdgcn_readfirstlane(static_cast<int>(new_score));
-				update_node_score(nodes, edges, node, e, new_score, lane);
+				child_win = nd.win;
+				child_draw = nd.draw;
+				child_score = nd.score;
 			}
 		}
-		/* Tree::cancelVirtualLoss (Tree.cpp:377-384) */
+		/* Tree::cancelVirtualLoss (Tree.cpp:377-384): one level per lane (the nodes and edges of a path are all different) */
 		__device__ inline void cancel_virtual_loss(DNode *nodes, DEdge *edges, const DTask &t, int path_len, int lane)
 		{
-			if (lane == 0)
-				for (int i = 0; i < path_len; i++)
-				{
-					nodes[t.path_node[i]].vl--;
-					DEdge &e = edges[t.path_edge[i]];
-					e.flag_vl = static_cast<uint16_t>((e.flag_vl & 0x8000u) | (((e.flag_vl & 0x7FFF) - 1) & 0x7FFF));
-				}
+			for (int i = lane; i < path_len; i += 64)
+			{
+				nodes[t.path_node[i]].vl--;
+				DEdge &e = edges[t.path_edge[i]];
+				e.flag_vl = static_cast<uint16_t>((e.flag_vl & 0x8000u) | (((e.flag_vl & 0x7FFF) - 1) & 0x7FFF));
+			}
 		}
 
 		__device__ inline u64 full_hash(const EngineDev &E, const uint8_t *board, int sign, int lane)
