@@ -991,8 +991,17 @@ namespace
 			{
 				const int ni = node_base + scan_nodes[tid] - 1, eb = edge_base + scan_edges[tid] - ne;
 				DNode nd = nodes[i];
-				for (int j = 0; j < nd.n_edges; j++)
-					dst_edges[eb + j] = edges[nd.edge_begin + j];
+				for (int j = 0; j < nd.n_edges; j += 8)
+				{ // eight records requested before the first is stored: a node's edges cost n/8 round trips, not n
+					DEdge tmp[8];
+#pragma unroll
+					for (int u = 0; u < 8; u++)
+						tmp[u] = edges[nd.edge_begin + min(j + u, nd.n_edges - 1)];
+#pragma unroll
+					for (int u = 0; u < 8; u++)
+						if (j + u < nd.n_edges)
+							dst_edges[eb + j + u] = tmp[u];
+				}
 				nd.edge_begin = eb;
 				dst_nodes[ni] = nd;
 				// re-insert (atomic linear probing; slot order is irrelevant to lookups)
