@@ -35,7 +35,7 @@ def _fake(lib, f, c):
 def test_match_of_two_players_colours_swap_and_copies_agree(lib):
     """EvaluationGame (evaluation/EvaluationGame.cpp:44-146): one opening, two games with the colours swapped; each player searches
     only on its own turns and both copies of the game always agree"""
-    cfg = ol.default_search_config(max_batch_size=4, max_simulations=40, table_entries=1 << 14)
+    cfg = ol.default_search_config(max_batch_size=4, max_simulations=60, table_entries=1 << 14)   # (>= 50: the draw-rate rule of misc.cpp:171-179 assumes it)
     players = []
     for _ in range(2):
         h = lib.ago_game_create_ex(0, N, N, 40, ctypes.byref(cfg))
