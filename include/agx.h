@@ -108,7 +108,9 @@ typedef struct AgxEngineConfig
 	int draw_after;                   /* GameConfig::draw_after, <= 0 means rows*cols */
 	int n_games;                      /* games resident on this GPU (SelfplayConfig::games_per_thread) */
 	int max_batch_size;               /* SearchConfig::max_batch_size: simulations selected per game per step */
-	int max_simulations;              /* SelfplayConfig::constraints.max_simulations (playouts per move) */
+	int max_simulations;              /* SelfplayConfig::constraints.max_simulations (playouts per move).  Keep it >= 50: with a drawish root the
+	                                     move rule asks for max - clamp((draw - 0.75) / 0.25) * (max - 50) visits (utils/misc.cpp:171-179), which
+	                                     EXCEEDS max below 50 while select stops at max — such a game never moves, here as in the reference. */
 	float exploration_constant;       /* EdgeSelectorConfig */
 	float exploration_scaling;
 	int init_to;                      /* 0 "q_head", 1 "parent", 2 "draw", 3 "loss" */
