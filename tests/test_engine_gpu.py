@@ -617,6 +617,12 @@ def test_native_cpp_driver_over_the_c_abi(agx_lib):
     assert out.returncode == 0, out.stderr
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["samples_drained"] > 50 and line["games_finished"] > 4 and line["opening_refills"] >= 1
+    # evaluation matches from the same loop: 8 pairs of players, two networks
+    out = subprocess.run([exe, "--match", "1", "--games", "8", "--steps", "2500", "--warmup", "2", "--sims", "50", "--batch", "8", "--blocks", "2",
+                          "--filters", "64"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["games_finished"] > 0 and sum(line["first_player_won_drawn_lost"]) >= line["games_finished"]   # (the score also counts warm-up games)
     bad = subprocess.run([exe, "--filters", "96", "--steps", "1"], capture_output=True, text=True, timeout=300)
     assert bad.returncode == 1 and "unsupported network" in bad.stderr   # errors surface as exceptions with the library's message
 
