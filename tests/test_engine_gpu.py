@@ -703,14 +703,14 @@ def _second_evaluator(olib, hw=HW):
     return f
 
 
-def _play_matches_and_compare(olib, rules, pairs, n_openings, batch, sims, max_steps, max_children=0, n=N, draw_after=0, merged=False):
+def _play_matches_and_compare(olib, rules, pairs, n_openings, batch, sims, max_steps, max_children=0, n=N, draw_after=0, merged=False, use_symmetries=0):
     from alphagomoku_amd import selfplay
     N, HW = n, n * n   # noqa: N806
     cfg = selfplay.default_config(rules=rules, board_size=n, draw_after=draw_after if draw_after > 0 else n * n, n_games=2 * pairs, max_batch_size=batch,
                                   max_simulations=sims, tss_table_entries=1 << 16, node_capacity=4096, edge_capacity=65536, match_mode=1,
-                                  max_children=max_children)
+                                  max_children=max_children, use_symmetries=use_symmetries)
     pool = selfplay.GeneratorPool(cfg)
-    ocfg = ol.default_search_config(max_batch_size=batch, max_simulations=sims, table_entries=1 << 16)
+    ocfg = ol.default_search_config(max_batch_size=batch, max_simulations=sims, table_entries=1 << 16, use_symmetries=use_symmetries)
     if max_children > 0:
         ocfg.max_children = max_children
     evaluators = [_stand_in_evaluator(olib, HW), _second_evaluator(olib, HW)]
@@ -842,16 +842,16 @@ def _play_matches_and_compare(olib, rules, pairs, n_openings, batch, sims, max_s
     return compared, stats, results
 
 
-@pytest.mark.parametrize("rules,batch,sims,max_children,merged", [(0, 4, 60, 0, False), (1, 8, 80, 20, False), (2, 4, 60, 0, False),
-                                                                   (0, 8, 60, 0, True), (1, 4, 80, 20, True), (2, 4, 60, 0, True)])
-def test_evaluation_matches_bit_exact(agx_lib, olib, rules, batch, sims, max_children, merged):
+@pytest.mark.parametrize("rules,batch,sims,max_children,merged,symmetries", [(0, 4, 60, 0, False, 0), (1, 8, 80, 20, False, 0), (2, 4, 60, 0, False, 0),
+                                                                              (0, 8, 60, 0, True, 0), (1, 4, 80, 20, True, 1), (2, 4, 60, 0, True, 0)])
+def test_evaluation_matches_bit_exact(agx_lib, olib, rules, batch, sims, max_children, merged, symmetries):
     """match_mode: EvaluationGame + Player (evaluation/EvaluationGame.cpp:77-146, evaluation/Player.cpp:98-216): two players with
     their own trees, solvers and networks share a game; every opening is played twice with the colours swapped; a player's tree
     jumps two plies per setBoard and survives from game to game; the root is pruned like any node.  Device vs oracle after
     every half-step (features of every scheduled leaf, root edges of the searching tree), for three pairs playing two matches;
     stepped as two groups and as merged launches over both players' trees (agx_engine_step_match)."""
     compared, stats, results = _play_matches_and_compare(olib, rules, pairs=3, n_openings=6, batch=batch, sims=sims, max_steps=6000, max_children=max_children,
-                                                         draw_after=80, merged=merged)
+                                                         draw_after=80, merged=merged, use_symmetries=symmetries)
     assert len(results) == 12 and compared > 300                     # 6 openings x 2 games
     assert stats["games_finished"] == 12
     by_opening = {}
