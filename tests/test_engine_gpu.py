@@ -905,3 +905,31 @@ def test_evaluation_matches_with_two_networks(agx_lib):
     pool.close()
     for net in nets:
         net.close()
+
+
+def test_configuration_errors_are_reported(agx_lib):
+    """the boundary's error behaviour: invalid configurations fail with a status and a message, nothing is launched"""
+    from alphagomoku_amd import selfplay, synthetic
+    from alphagomoku_amd._lib import AgxError
+    from alphagomoku_amd.networks import AGNetwork
+    with pytest.raises(AgxError, match="n_games must be even"):
+        selfplay.GeneratorPool(selfplay.default_config(n_games=7, match_mode=1, tss_table_entries=1 << 12))
+    with pytest.raises(AgxError, match="policy_temperature"):
+        selfplay.GeneratorPool(selfplay.default_config(n_games=4, policy_temperature=-1.0, tss_table_entries=1 << 12))
+    with pytest.raises(AgxError, match="final_selector"):
+        selfplay.GeneratorPool(selfplay.default_config(n_games=4, final_selector=9, tss_table_entries=1 << 12))
+    pool = selfplay.GeneratorPool(selfplay.default_config(n_games=4, max_simulations=50, tss_table_entries=1 << 12, node_capacity=1024, edge_capacity=16384))
+    d = synthetic.net_desc(blocks=2, filters=64)
+    net = AGNetwork(d)
+    net.loadWeights(synthetic.make_weights(d)[0])
+    with pytest.raises(AgxError, match="agx_engine_begin has not been called"):
+        pool.step(net)
+    pool.begin(selfplay.pack_openings([[], [], [], []]))
+    with pytest.raises(AgxError, match="match_mode"):
+        pool.step_match(net, net)                       # a self-play pool has no pairs
+    with pytest.raises(AgxError, match="match_mode"):
+        pool.match_results()
+    pool.step(net)                                      # and still works afterwards
+    assert pool.stats()["first_error"] == 0
+    pool.close()
+    net.close()
