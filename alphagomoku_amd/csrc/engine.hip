@@ -1695,7 +1695,7 @@ int agx_engine_default_config(AgxEngineConfig *cfg)
 	cfg->tss_table_entries = 4ull * 1024ull * 1024ull;
 	cfg->zobrist_seed = 0x9E3779B97F4A7C15ull;
 	cfg->node_capacity = 8192;
-	cfg->edge_capacity = 262144;
+	cfg->edge_capacity = 524288; // whole freestyle games at 400 playouts peak at ~250 k edges per game with an untrained (flat) policy
 	cfg->record_capacity = 0;
 	cfg->record_edge_capacity = 0;
 	cfg->solver_yield_fraction = 0.0f;
@@ -1756,7 +1756,7 @@ int agx_engine_create(const AgxEngineConfig *cfg, AgxEngine **out)
 	d.tt_bucket_mask = buckets - 1;
 	d.zobrist_seed = cfg->zobrist_seed;
 	d.node_cap = cfg->node_capacity > 0 ? cfg->node_capacity : 8192;
-	d.edge_cap = cfg->edge_capacity > 0 ? cfg->edge_capacity : 262144;
+	d.edge_cap = cfg->edge_capacity > 0 ? cfg->edge_capacity : 524288;
 	d.ht_cap = static_cast<int>(round_pow2(4 * static_cast<size_t>(d.node_cap)));
 	d.act_cap = d.hw * (d.hw + 1) / 2 + 64;
 	d.record_cap = cfg->record_capacity > 0 ? cfg->record_capacity : d.n_games * d.hw;

@@ -92,9 +92,13 @@ def main():
     blob, _ = synthetic.make_weights(desc)
     net = AGNetwork(desc)
     net.loadWeights(blob)
+    # per-game arenas sized for whole games at this playout budget (the reference's node cache and edge pool grow on demand; here they
+    # are fixed: a tree that outgrows them stops its game with an error, and the run below would report it)
+    node_capacity = max(8192, 16 * args.sims)
+    edge_capacity = max(262144, 1536 * args.sims)
     cfg = selfplay.default_config(rules=args.rules, board_size=args.board, n_games=args.games, max_batch_size=args.batch,
                                   max_simulations=args.sims, tss_table_entries=args.table_entries, solver_yield_fraction=args.yield_fraction,
-                                  action_values=args.action_values)
+                                  action_values=args.action_values, node_capacity=node_capacity, edge_capacity=edge_capacity)
     pool = selfplay.GeneratorPool(cfg)
     # enough openings for every game that can finish during the run; seeds are disjoint across ranks
     n_openings = args.games * 3
@@ -217,6 +221,8 @@ def main():
             "stage_ms_per_step": {"select_solve": ms_sel / args.steps, "network": ms_nn / args.steps, "expand_backup_advance": ms_exp / args.steps},
             "kernel_ms_per_step": {"k_select": kernel_ms[0] / args.steps, "k_solve": kernel_ms[1] / args.steps, "nn_tower": ms_nn / args.steps,
                                    "k_expand": kernel_ms[2] / args.steps, "k_advance": kernel_ms[3] / args.steps},
+            "peak_tree_per_game": {"nodes": int(s1["peak_nodes"]), "edges": int(s1["peak_edges"]), "node_capacity": node_capacity,
+                                   "edge_capacity": edge_capacity},
             "shape": {"mean_select_depth": depth, "mean_edges_per_level": edges_per_level,
                       "solver_nodes_per_simulation": solver_nodes / max(1, s1["evaluated_nodes"] - s0["evaluated_nodes"]),
                       "nn_evals_per_simulation": local_evals / max(1, s1["evaluated_nodes"] - s0["evaluated_nodes"])},

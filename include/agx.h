@@ -120,7 +120,9 @@ typedef struct AgxEngineConfig
 	uint64_t tss_table_entries;       /* AlphaBetaSearch's SharedHashTable size per game (reference: 4 Mi) */
 	uint64_t zobrist_seed;            /* seed of the solver / node-cache Zobrist keys (the reference draws them from a time-seeded RNG) */
 	int node_capacity;                /* per game, per arena (TreeConfig::node_bucket_size analogue) */
-	int edge_capacity;                /* per game, per arena (TreeConfig::edge_bucket_size analogue) */
+	int edge_capacity;                /* per game, per arena (TreeConfig::edge_bucket_size analogue).  Fixed, unlike the reference's pools: a tree
+	                                     that outgrows an arena stops its game (agx_engine_stats.first_error); size them for the playout
+	                                     budget (bench.py: 16 x and 1536 x max_simulations; measured peaks in DESIGN.md section 5) */
 	int record_capacity;              /* move records kept on the device, 0 = n_games * cells */
 	int record_edge_capacity;         /* root-edge snapshots kept on the device, 0 = 64 per record */
 	float solver_yield_fraction;      /* 0 = off.  A pool step lasts as long as its slowest game's solver batch; with f in (0,1] a game
