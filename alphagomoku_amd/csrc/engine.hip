@@ -987,21 +987,13 @@ namespace
 				scan_edges[tid] += b;
 				__syncthreads();
 			}
+			int cp_src = 0, cp_dst = 0;
 			if (keep)
 			{
 				const int ni = node_base + scan_nodes[tid] - 1, eb = edge_base + scan_edges[tid] - ne;
 				DNode nd = nodes[i];
-				for (int j = 0; j < nd.n_edges; j += 8)
-				{ // eight records requested before the first is stored: a node's edges cost n/8 round trips, not n
-					DEdge tmp[8];
-#pragma unroll
-					for (int u = 0; u < 8; u++)
-						tmp[u] = edges[nd.edge_begin + min(j + u, nd.n_edges - 1)];
-#pragma unroll
-					for (int u = 0; u < 8; u++)
-						if (j + u < nd.n_edges)
-							dst_edges[eb + j + u] = tmp[u];
-				}
+				cp_src = nd.edge_begin;
+				cp_dst = eb;
 				nd.edge_begin = eb;
 				dst_nodes[ni] = nd;
 				// re-insert (atomic linear probing; slot order is irrelevant to lookups)
@@ -1009,6 +1001,34 @@ namespace
 				int slot = static_cast<int>(nd.hash & static_cast<u64>(mask));
 				while (atomicCAS(&ht[slot], 0, ni + 1) != 0)
 					slot = (slot + 1) & mask;
+			}
+			// the edges: one node per wave at a time, its records copied by 64 lanes as 8-byte words (coalesced; 24-byte records of
+			// per-thread copies touch three times the cache lines).  The node's (source, destination, count) come from its thread by
+			// v_readlane — node k of the chunk belongs to lane k % 64 of wave k / 64.
+			{
+				const u64 *src64 = reinterpret_cast<const u64*>(edges);
+				u64 *dst64 = reinterpret_cast<u64*>(dst_edges);
+				for (int k = 0; k < 64; k++)
+				{
+					const int words = 3 * __builtin_amdgcn_readlane(ne, k);
+					if (words == 0)
+						continue;
+					const size_t so = 3 * static_cast<size_t>(__builtin_amdgcn_readlane(cp_src, k)), dof = 3 * static_cast<size_t>(__builtin_amdgcn_readlane(cp_dst, k));
+					for (int d = lane; d < words; d += 256)
+					{
+						const u64 w0 = src64[so + d];
+						const u64 w1 = (d + 64 < words) ? src64[so + d + 64] : 0ull;
+						const u64 w2 = (d + 128 < words) ? src64[so + d + 128] : 0ull;
+						const u64 w3 = (d + 192 < words) ? src64[so + d + 192] : 0ull;
+						dst64[dof + d] = w0;
+						if (d + 64 < words)
+							dst64[dof + d + 64] = w1;
+						if (d + 128 < words)
+							dst64[dof + d + 128] = w2;
+						if (d + 192 < words)
+							dst64[dof + d + 192] = w3;
+					}
+				}
 			}
 			node_base += scan_nodes[255];
 			edge_base += scan_edges[255];
