@@ -84,7 +84,8 @@ class AgxEngineConfig(ctypes.Structure):
                 ("edge_capacity", ctypes.c_int), ("record_capacity", ctypes.c_int), ("record_edge_capacity", ctypes.c_int),
                 ("solver_yield_fraction", ctypes.c_float), ("final_selector", ctypes.c_int), ("use_symmetries", ctypes.c_int),
                 ("symmetry_seed", ctypes.c_uint64), ("max_children", ctypes.c_int), ("noise_type", ctypes.c_int), ("noise_weight", ctypes.c_float),
-                ("noise_seed", ctypes.c_uint64), ("action_values", ctypes.c_int), ("match_mode", ctypes.c_int), ("policy_temperature", ctypes.c_float)]
+                ("noise_seed", ctypes.c_uint64), ("action_values", ctypes.c_int), ("match_mode", ctypes.c_int), ("policy_temperature", ctypes.c_float),
+                ("record_format", ctypes.c_int), ("record_sample_capacity", ctypes.c_int), ("game_end_capacity", ctypes.c_int)]
 
 
 class AgxEngineBuffers(ctypes.Structure):
@@ -117,7 +118,21 @@ class AgxGameInfo(ctypes.Structure):
 class AgxMoveRecord(ctypes.Structure):
     _fields_ = [("game_serial", ctypes.c_int), ("move_number", ctypes.c_int), ("move", ctypes.c_uint16), ("root_score", ctypes.c_uint16),
                 ("root_visits", ctypes.c_int), ("root_win", ctypes.c_float), ("root_draw", ctypes.c_float), ("n_edges", ctypes.c_int),
-                ("edge_offset", ctypes.c_int), ("root_flags", ctypes.c_int)]
+                ("edge_offset", ctypes.c_int), ("root_flags", ctypes.c_int), ("game_slot", ctypes.c_int), ("game_index", ctypes.c_int),
+                ("sample_offset", ctypes.c_int), ("sample_bytes", ctypes.c_int), ("outcome", ctypes.c_int)]
+
+
+class AgxGameEnd(ctypes.Structure):
+    _fields_ = [("game_serial", ctypes.c_int), ("game_slot", ctypes.c_int), ("game_index", ctypes.c_int), ("outcome", ctypes.c_int),
+                ("n_moves", ctypes.c_int), ("moves", ctypes.c_uint16 * 400)]
+
+
+class AgxRecordCounts(ctypes.Structure):
+    _fields_ = [("records", ctypes.c_int), ("edges", ctypes.c_int), ("sample_bytes", ctypes.c_int), ("game_ends", ctypes.c_int)]
+
+
+class AgxGameBufferStats(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int) for n in ["games", "samples", "cross_win", "draws", "circle_win", "game_length"]]
 
 
 _declare_nn = _declare
@@ -155,6 +170,15 @@ def _declare(c):  # noqa: F811
     c.agx_engine_game_info.argtypes = [vp, ci, ctypes.POINTER(AgxGameInfo), vp, vp, ci]
     c.agx_engine_records.argtypes = [vp, vp, ci, vp, ci, ctypes.POINTER(ci), ctypes.POINTER(ci)]
     c.agx_engine_zobrist.argtypes = [vp, vp, sz]
+    c.agx_engine_fetch_records.argtypes = [vp, vp, ci, vp, ci, vp, ci, vp, ci, ctypes.POINTER(AgxRecordCounts), ci]
+    c.agx_game_buffer_create.argtypes = [ci, ci, ci, ci, ctypes.POINTER(vp)]
+    c.agx_game_buffer_destroy.argtypes = [vp]
+    c.agx_game_buffer_clear.argtypes = [vp]
+    c.agx_game_buffer_collect.argtypes = [vp, vp, ctypes.POINTER(ci)]
+    c.agx_game_buffer_stats.argtypes = [vp, ctypes.POINTER(AgxGameBufferStats)]
+    c.agx_game_buffer_game.argtypes = [vp, ci, vp, sz, ctypes.POINTER(sz)]
+    c.agx_game_buffer_save.argtypes = [vp, ctypes.c_char_p, ci]
+    c.agx_sample_v201_unpack.argtypes = [vp, sz, ci, ci, vp, vp, vp, vp, vp, vp, ctypes.POINTER(sz)]
     c.agx_debug_solve.argtypes = [vp, vp, vp, ci, vp, vp, vp, vp, vp, vp]
     c.agx_debug_new_generation.argtypes = [vp]
     c.agx_debug_pattern_state.argtypes = [vp, vp, vp, vp, ci, ci, vp, vp, vp, ci]

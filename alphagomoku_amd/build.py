@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libagx.so")
 
-SOURCES = ["agx_api.hip", "nn_forward.hip", "engine.hip", "tables_host.cpp", "host_util.cpp"]
+SOURCES = ["agx_api.hip", "nn_forward.hip", "engine.hip", "tables_host.cpp", "host_util.cpp", "game_buffer.cpp"]
 DRIVER = os.path.join(HERE, "agx_selfplay")
 
 
@@ -52,7 +52,7 @@ def build(force=False, verbose=True):
     for p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed")
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lz"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

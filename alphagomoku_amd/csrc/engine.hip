@@ -23,6 +23,7 @@
 #include "tables_host.hpp"
 #include "renju_static.hpp"
 #include "root_noise.hpp"
+#include "sample_v201.hpp"
 
 #include <vector>
 #include <cstring>
@@ -1112,6 +1113,8 @@ namespace
 		__shared__ int red_i[4];
 		__shared__ int sh_int[8];
 		__shared__ int scan_nodes[256], scan_edges[256];
+		__shared__ uint16_t cell_edge[MAXHW], entry_cell[MAXHW]; // format-201 sample: edge of a cell (+1, bit 15 = visited or proven), cells with an entry
+		__shared__ uint32_t sh_max[3];
 		const int g = E.g0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 		GameState &gs = E.games[g];
 		if (!gs.active || gs.error != 0 || !gs.need_move || gs.solve_pending)
@@ -1211,36 +1214,127 @@ namespace
 					red_v[0] = red_v[w];
 					red_i[0] = red_i[w];
 				}
-			// ---- sample record (GameGenerator.cpp:166-171) ----
-			const int rec = atomicAdd(&E.counters[3], 1);
-			const int eoff = atomicAdd(&E.counters[4], static_cast<int>(root.n_edges));
-			sh_int[0] = (rec < E.record_cap && eoff + root.n_edges <= E.record_edge_cap) ? rec : -1;
-			sh_int[1] = eoff;
+			sh_int[4] = red_i[0];
 		}
 		__syncthreads();
-		const uint32_t mv = edges[root.edge_begin + red_i[0]].move;
-		const int rec = sh_int[0], eoff = sh_int[1];
-		if (rec >= 0)
+		const int best_edge = sh_int[4];
+		const uint32_t mv = edges[root.edge_begin + best_edge].move;
+
+		// ---- the sample in dataset format 201 (SearchDataPack of the root -> SearchDataStorage_v201::loadFrom + serialize,
+		//      dataset/data_packs.cpp:24-43, dataset/SearchDataStorage.cpp:326-374,410-419), quantised here so that 6 bytes per visited
+		//      cell leave the device instead of 24 per root edge ----
+		int n_entries = 0;
+		if (E.record_format & 2)
 		{
+			for (int i = tid; i < E.hw; i += 256)
+				cell_edge[i] = 0;
+			if (tid < 3)
+				sh_max[tid] = 0u;
+			__syncthreads();
+			for (int i = tid; i < root.n_edges; i += 256)
+			{ // scatter the edges over the board; the maxima that become the three scales (non-negative floats order like their bits)
+				const DEdge e = edges[root.edge_begin + i];
+				const int cell = ((e.move >> 2) & 127) * n + ((e.move >> 9) & 127);
+				const bool natural = e.visits > 0 || s_proven(e.score);
+				cell_edge[cell] = static_cast<uint16_t>((i + 1) | (natural ? 0x8000 : 0));
+				const float wd = fmaxf(e.win, e.draw);
+				atomicMax(&sh_max[0], __float_as_uint((e.prior > 0.0f) ? e.prior : 0.0f));
+				atomicMax(&sh_max[1], __float_as_uint((wd > 0.0f) ? wd : 0.0f));
+				atomicMax(&sh_max[2], static_cast<uint32_t>(max(e.visits, 0)));
+			}
+			__syncthreads();
+			if (tid == 0)
+			{ // which cells get an entry: visited or proven ones, and any cell 255 or more past the previous entry (:333-337, in cell order)
+				int last = 0, count = 0;
+				for (int i = 0; i < E.hw; i++)
+					if ((cell_edge[i] & 0x8000) || (i - last) >= 255)
+					{
+						entry_cell[count++] = static_cast<uint16_t>(i);
+						last = i;
+					}
+				sh_int[5] = count;
+			}
+			__syncthreads();
+			n_entries = sh_int[5];
+		}
+		if (tid == 0)
+		{
+			// ---- sample record (GameGenerator.cpp:166-171): the header is written whenever its slot exists, so that the host never
+			//      reads a slot that was reserved but not filled; a part that does not fit is left out and stops the game with ERR_RECORDS ----
+			const int rec = atomicAdd(&E.counters[3], 1);
+			int eoff = -1, soff = -1;
+			const int sbytes = v201::HEADER_BYTES + v201::ENTRY_BYTES * n_entries;
+			bool fits = rec < E.record_cap;
+			if (E.record_format & 1)
+			{
+				eoff = atomicAdd(&E.counters[4], static_cast<int>(root.n_edges));
+				if (eoff + root.n_edges > E.record_edge_cap)
+				{
+					eoff = -1;
+					fits = false;
+				}
+			}
+			if (E.record_format & 2)
+			{
+				soff = atomicAdd(&E.counters[6], (sbytes + 3) & ~3);
+				if (soff + sbytes > E.sample_cap)
+				{
+					soff = -1;
+					fits = false;
+				}
+			}
+			sh_int[0] = (rec < E.record_cap) ? rec : -1;
+			sh_int[1] = eoff;
+			sh_int[6] = soff;
+			sh_int[7] = fits ? 1 : 0;
+		}
+		__syncthreads();
+		const int rec = sh_int[0], eoff = sh_int[1], soff = sh_int[6];
+		if (eoff >= 0)
 			for (int i = tid; i < root.n_edges; i += 256)
 				E.record_edges[eoff + i] = edges[root.edge_begin + i];
+		if (soff >= 0)
+		{
+			const float prior_scale = v201::prior_scale(__uint_as_float(sh_max[0])), value_scale = v201::value_scale(__uint_as_float(sh_max[1]));
+			const float visit_scale = v201::visit_scale(fmaxf(1.0f, static_cast<float>(sh_max[2])));
+			uint8_t *out = E.samples + soff;
 			if (tid == 0)
 			{
-				MoveRecordHeader h;
-				h.game_serial = gs.opening_id;
-				h.move_number = gs.n_moves;
-				h.move = static_cast<uint16_t>(mv);
-				h.root_score = root.score;
-				h.root_visits = root.visits;
-				h.root_win = root.win;
-				h.root_draw = root.draw;
-				h.n_edges = root.n_edges;
-				h.edge_offset = eoff;
-				h.root_flags = (root.flags >> 3) & 7; // DNode flags 8 / 16 / 32
-				E.records[rec] = h;
+				uint16_t *h16 = reinterpret_cast<uint16_t*>(out);
+				h16[0] = static_cast<uint16_t>(v201::ScaleFormat::encode(value_scale));
+				h16[1] = static_cast<uint16_t>(v201::ScaleFormat::encode(prior_scale));
+				h16[2] = static_cast<uint16_t>(v201::ScaleFormat::encode(visit_scale));
+				h16[3] = root.score;
+				h16[4] = static_cast<uint16_t>(gs.n_moves); // stones on the board the root stands for
+				h16[5] = static_cast<uint16_t>((root.flags >> 3) & 7);
+				*reinterpret_cast<uint32_t*>(out + 12) = static_cast<uint32_t>(n_entries);
+			}
+			for (int k = tid; k < n_entries; k += 256)
+			{
+				const int cell = entry_cell[k], previous = (k > 0) ? entry_cell[k - 1] : 0;
+				const int ei = (cell_edge[cell] & 0x7FFF) - 1;
+				int visits = 0;
+				float prior = 0.0f, win = 0.0f, draw = 0.0f;
+				uint32_t score = s_unknown(0); // a filler cell without an edge: the SearchDataPack defaults (Score(), Value())
+				if (ei >= 0)
+				{
+					const DEdge e = edges[root.edge_begin + ei];
+					visits = e.visits;
+					prior = e.prior;
+					win = e.win;
+					draw = e.draw;
+					score = e.score;
+				}
+				uint8_t *q = out + v201::HEADER_BYTES + v201::ENTRY_BYTES * k;
+				q[0] = static_cast<uint8_t>(cell - previous);
+				q[1] = static_cast<uint8_t>(v201::VisitFormat::encode(static_cast<float>(visits) / visit_scale));
+				q[2] = static_cast<uint8_t>(v201::PriorFormat::encode(prior / prior_scale));
+				q[3] = static_cast<uint8_t>(v201::score_code(score));
+				q[4] = static_cast<uint8_t>(v201::PriorFormat::encode(win / value_scale));
+				q[5] = static_cast<uint8_t>(v201::PriorFormat::encode(draw / value_scale));
 			}
 		}
-		else if (tid == 0)
+		if (tid == 0 && !sh_int[7])
 			gs.error = ERR_RECORDS;
 
 		// ---- Game::makeMove + getOutcome (Game.cpp:104-122, rules.cpp:110-133) ----
@@ -1282,8 +1376,42 @@ namespace
 			gs.outcome = outcome;
 			sh_int[2] = outcome;
 			sh_int[3] = -1;
+			if (rec >= 0)
+			{
+				MoveRecordHeader h;
+				h.game_serial = gs.opening_id;
+				h.move_number = gs.n_moves - 1;
+				h.move = static_cast<uint16_t>(mv);
+				h.root_score = root.score;
+				h.root_visits = root.visits;
+				h.root_win = root.win;
+				h.root_draw = root.draw;
+				h.n_edges = (eoff >= 0) ? root.n_edges : 0;
+				h.edge_offset = eoff;
+				h.root_flags = (root.flags >> 3) & 7; // DNode flags 8 / 16 / 32
+				h.game_slot = g;
+				h.game_index = gs.games_done;
+				h.sample_offset = soff;
+				h.sample_bytes = (soff >= 0) ? v201::HEADER_BYTES + v201::ENTRY_BYTES * n_entries : 0;
+				h.outcome = outcome;
+				E.records[rec] = h;
+			}
 			if (outcome != 0)
 			{ // game over (GameGenerator.cpp:104-114 -> GAME_NOT_STARTED): k_assign_openings / k_restart give the slot its next opening
+				const int ge = atomicAdd(&E.counters[7], 1);
+				if (ge < E.game_end_cap)
+				{ // setOutcome + addMoves(game.getMoves()) (:107-108)
+					GameEndRecord &r = E.game_ends[ge];
+					r.game_serial = gs.opening_id;
+					r.game_slot = g;
+					r.game_index = gs.games_done;
+					r.outcome = outcome;
+					r.n_moves = gs.n_moves;
+					for (int i = 0; i < gs.n_moves; i++)
+						r.moves[i] = gs.moves[i];
+				}
+				else
+					gs.error = ERR_RECORDS;
 				gs.games_done++;
 				atomicAdd(&E.counters[2], 1);
 				gs.active = 0;
@@ -1725,6 +1853,9 @@ int agx_engine_default_config(AgxEngineConfig *cfg)
 	cfg->action_values = 0;
 	cfg->match_mode = 0;
 	cfg->policy_temperature = 1.0f;
+	cfg->record_format = 1;
+	cfg->record_sample_capacity = 0;
+	cfg->game_end_capacity = 0;
 	cfg->noise_type = 0;
 	cfg->noise_weight = 0.0f;
 	cfg->noise_seed = 0x2545F4914F6CDD1Dull;
@@ -1745,6 +1876,7 @@ int agx_engine_create(const AgxEngineConfig *cfg, AgxEngine **out)
 	AGX_REQUIRE(cfg->policy_temperature >= 0.0f, AGX_ERR_INVALID, "agx_engine_create: policy_temperature must not be negative");
 	AGX_REQUIRE(!cfg->match_mode || cfg->n_games % 2 == 0, AGX_ERR_INVALID, "agx_engine_create: match_mode pairs the trees, n_games must be even");
 	AGX_REQUIRE(cfg->noise_weight >= 0.0f && cfg->noise_weight <= 1.0f, AGX_ERR_INVALID, "agx_engine_create: noise_weight must be in [0, 1]");
+	AGX_REQUIRE(cfg->record_format >= 0 && cfg->record_format <= 3, AGX_ERR_INVALID, "agx_engine_create: record_format must be 0..3 (bit 0 edge snapshots, bit 1 format-201 samples)");
 
 	AgxEngine *e = new AgxEngine();
 	e->cfg = *cfg;
@@ -1781,6 +1913,10 @@ int agx_engine_create(const AgxEngineConfig *cfg, AgxEngine **out)
 	d.act_cap = d.hw * (d.hw + 1) / 2 + 64;
 	d.record_cap = cfg->record_capacity > 0 ? cfg->record_capacity : d.n_games * d.hw;
 	d.record_edge_cap = cfg->record_edge_capacity > 0 ? cfg->record_edge_capacity : d.record_cap * 64;
+	d.record_format = cfg->record_format;
+	d.sample_cap = cfg->record_sample_capacity > 0 ? cfg->record_sample_capacity
+			: static_cast<int>(std::min<size_t>(static_cast<size_t>(d.record_cap) * 400, 0x7FFFFFF0u));
+	d.game_end_cap = cfg->game_end_capacity > 0 ? cfg->game_end_capacity : 2 * d.n_games;
 
 	HostTables tables;
 	build_host_tables(cfg->rules, tables);
@@ -1820,7 +1956,9 @@ int agx_engine_create(const AgxEngineConfig *cfg, AgxEngine **out)
 	AGX_TRY(dev_alloc(e, &d.nn_list, G * d.batch));
 	AGX_TRY(dev_alloc(e, &d.counters, 64));
 	AGX_TRY(dev_alloc(e, &d.records, static_cast<size_t>(d.record_cap)));
-	AGX_TRY(dev_alloc(e, &d.record_edges, static_cast<size_t>(d.record_edge_cap)));
+	AGX_TRY(dev_alloc(e, &d.record_edges, (d.record_format & 1) ? static_cast<size_t>(d.record_edge_cap) : 1));
+	AGX_TRY(dev_alloc(e, &d.samples, (d.record_format & 2) ? static_cast<size_t>(d.sample_cap) : 4));
+	AGX_TRY(dev_alloc(e, &d.game_ends, static_cast<size_t>(d.game_end_cap)));
 #undef AGX_TRY
 	if (status == AGX_OK)
 	{
@@ -1913,7 +2051,8 @@ int agx_engine_add_openings(AgxEngine *e, const uint16_t *h_openings, int n_open
 /* games [first, first + count) of group `group` out of `n_groups` equal parts of the pool */
 static int group_range(const AgxEngine *e, int group, int n_groups, EngineDev &d, int &count)
 {
-	AGX_REQUIRE(n_groups >= 1 && n_groups <= 32 && group >= 0 && group < n_groups, AGX_ERR_INVALID, "group %d of %d is not valid (1..32 groups)", group, n_groups);
+	// counters[16 + g] / counters[32 + g] are group g's network count and yield count: at most 16 groups
+	AGX_REQUIRE(n_groups >= 1 && n_groups <= 16 && group >= 0 && group < n_groups, AGX_ERR_INVALID, "group %d of %d is not valid (1..16 groups)", group, n_groups);
 	const int per = (e->dev.n_games + n_groups - 1) / n_groups;
 	d = e->dev;
 	d.g0 = group * per;
@@ -2043,12 +2182,16 @@ int agx_engine_evaluate_group(AgxEngine *e, AgxNet *net, int group, int n_groups
 	const int st = group_range(e, group, n_groups, d, count);
 	if (st != AGX_OK)
 		return st;
+	AgxNetDesc desc;
+	const int ds = agx_net_description(net, &desc);
+	if (ds != AGX_OK)
+		return ds;
+	// the exchange buffers are laid out with the ENGINE's board (hw cells per slot): a network of another geometry would index them with
+	// the wrong stride
+	AGX_REQUIRE(desc.rows == d.n && desc.cols == d.n, AGX_ERR_INVALID, "agx_engine_evaluate: the network is built for %dx%d boards, the engine plays on %dx%d",
+			desc.rows, desc.cols, d.n, d.n);
 	if (d.has_q)
 	{
-		AgxNetDesc desc;
-		const int ds = agx_net_description(net, &desc);
-		if (ds != AGX_OK)
-			return ds;
 		AGX_REQUIRE(desc.action_values, AGX_ERR_INVALID, "agx_engine_evaluate: the engine was configured for a 'pvq' network but this one has no action-values head");
 		return agx_nn_forward_indirect_pvq(net, d.nn_features, d.nn_list + static_cast<size_t>(d.g0) * d.batch, d.counters + d.nn_counter, count * d.batch,
 				d.nn_policy, d.nn_value, d.nn_q, stream);
@@ -2259,56 +2402,112 @@ int agx_engine_game_info(AgxEngine *e, int game, AgxGameInfo *info, uint8_t *h_b
 	return AGX_OK;
 }
 
-int agx_engine_records(AgxEngine *e, AgxMoveRecord *h_records, int record_capacity, AgxEdgeView *h_edges, int edge_capacity, int *n_records, int *n_edges)
+int agx_engine_fetch_records(AgxEngine *e, AgxMoveRecord *h_records, int record_capacity, AgxEdgeView *h_edges, int edge_capacity, uint8_t *h_samples,
+		int sample_capacity, AgxGameEnd *h_game_ends, int game_end_capacity, AgxRecordCounts *counts, int drain)
 {
-	AGX_REQUIRE(e != nullptr && n_records != nullptr && n_edges != nullptr, AGX_ERR_INVALID, "agx_engine_records: null argument");
+	AGX_REQUIRE(e != nullptr && counts != nullptr, AGX_ERR_INVALID, "agx_engine_fetch_records: null argument");
 	AGX_HIP_CHECK(hipDeviceSynchronize());
 	int counters[16];
 	AGX_HIP_CHECK(hipMemcpy(counters, e->dev.counters, sizeof(counters), hipMemcpyDeviceToHost));
-	const int nr = std::min(counters[3], e->dev.record_cap), ne = std::min(counters[4], e->dev.record_edge_cap);
-	*n_records = nr;
-	*n_edges = ne;
-	if (h_records == nullptr || h_edges == nullptr)
-		return AGX_OK;
-	AGX_REQUIRE(nr <= record_capacity && ne <= edge_capacity, AGX_ERR_INVALID, "agx_engine_records: buffers too small (%d records, %d edges)", nr, ne);
-	std::vector<MoveRecordHeader> headers(nr);
-	std::vector<DEdge> edges(ne);
-	AGX_HIP_CHECK(hipMemcpy(headers.data(), e->dev.records, headers.size() * sizeof(MoveRecordHeader), hipMemcpyDeviceToHost));
-	AGX_HIP_CHECK(hipMemcpy(edges.data(), e->dev.record_edges, edges.size() * sizeof(DEdge), hipMemcpyDeviceToHost));
-	for (int i = 0; i < nr; i++)
+	const int nr = std::min(counters[3], e->dev.record_cap), ne = (e->dev.record_format & 1) ? std::min(counters[4], e->dev.record_edge_cap) : 0;
+	const int ns = (e->dev.record_format & 2) ? std::min(counters[6], e->dev.sample_cap) : 0, ng = std::min(counters[7], e->dev.game_end_cap);
+	counts->records = nr;
+	counts->edges = ne;
+	counts->sample_bytes = ns;
+	counts->game_ends = ng;
+	if (h_records != nullptr)
 	{
-		h_records[i].game_serial = headers[i].game_serial;
-		h_records[i].move_number = headers[i].move_number;
-		h_records[i].move = headers[i].move;
-		h_records[i].root_score = headers[i].root_score;
-		h_records[i].root_visits = headers[i].root_visits;
-		h_records[i].root_win = headers[i].root_win;
-		h_records[i].root_draw = headers[i].root_draw;
-		h_records[i].root_flags = headers[i].root_flags;
-		h_records[i].n_edges = headers[i].n_edges;
-		h_records[i].edge_offset = headers[i].edge_offset;
+		AGX_REQUIRE(nr <= record_capacity, AGX_ERR_INVALID, "agx_engine_fetch_records: %d records do not fit into %d", nr, record_capacity);
+		std::vector<MoveRecordHeader> headers(nr);
+		AGX_HIP_CHECK(hipMemcpy(headers.data(), e->dev.records, headers.size() * sizeof(MoveRecordHeader), hipMemcpyDeviceToHost));
+		for (int i = 0; i < nr; i++)
+		{
+			h_records[i].game_serial = headers[i].game_serial;
+			h_records[i].move_number = headers[i].move_number;
+			h_records[i].move = headers[i].move;
+			h_records[i].root_score = headers[i].root_score;
+			h_records[i].root_visits = headers[i].root_visits;
+			h_records[i].root_win = headers[i].root_win;
+			h_records[i].root_draw = headers[i].root_draw;
+			h_records[i].root_flags = headers[i].root_flags;
+			h_records[i].n_edges = headers[i].n_edges;
+			h_records[i].edge_offset = headers[i].edge_offset;
+			h_records[i].game_slot = headers[i].game_slot;
+			h_records[i].game_index = headers[i].game_index;
+			h_records[i].sample_offset = headers[i].sample_offset;
+			h_records[i].sample_bytes = headers[i].sample_bytes;
+			h_records[i].outcome = headers[i].outcome;
+		}
 	}
-	for (int i = 0; i < ne; i++)
+	if (h_edges != nullptr && ne > 0)
 	{
-		h_edges[i].prior = edges[i].prior;
-		h_edges[i].win = edges[i].win;
-		h_edges[i].draw = edges[i].draw;
-		h_edges[i].visits = edges[i].visits;
-		h_edges[i].move = edges[i].move;
-		h_edges[i].score = edges[i].score;
-		h_edges[i].flag_and_virtual_loss = edges[i].flag_vl;
+		AGX_REQUIRE(ne <= edge_capacity, AGX_ERR_INVALID, "agx_engine_fetch_records: %d edges do not fit into %d", ne, edge_capacity);
+		std::vector<DEdge> edges(ne);
+		AGX_HIP_CHECK(hipMemcpy(edges.data(), e->dev.record_edges, edges.size() * sizeof(DEdge), hipMemcpyDeviceToHost));
+		for (int i = 0; i < ne; i++)
+		{
+			h_edges[i].prior = edges[i].prior;
+			h_edges[i].win = edges[i].win;
+			h_edges[i].draw = edges[i].draw;
+			h_edges[i].visits = edges[i].visits;
+			h_edges[i].move = edges[i].move;
+			h_edges[i].score = edges[i].score;
+			h_edges[i].flag_and_virtual_loss = edges[i].flag_vl;
+			h_edges[i].reserved = 0;
+		}
 	}
+	if (h_samples != nullptr && ns > 0)
+	{
+		AGX_REQUIRE(ns <= sample_capacity, AGX_ERR_INVALID, "agx_engine_fetch_records: %d sample bytes do not fit into %d", ns, sample_capacity);
+		AGX_HIP_CHECK(hipMemcpy(h_samples, e->dev.samples, static_cast<size_t>(ns), hipMemcpyDeviceToHost));
+	}
+	if (h_game_ends != nullptr && ng > 0)
+	{
+		AGX_REQUIRE(ng <= game_end_capacity, AGX_ERR_INVALID, "agx_engine_fetch_records: %d finished games do not fit into %d", ng, game_end_capacity);
+		std::vector<GameEndRecord> ends(ng);
+		AGX_HIP_CHECK(hipMemcpy(ends.data(), e->dev.game_ends, ends.size() * sizeof(GameEndRecord), hipMemcpyDeviceToHost));
+		for (int i = 0; i < ng; i++)
+		{
+			h_game_ends[i].game_serial = ends[i].game_serial;
+			h_game_ends[i].game_slot = ends[i].game_slot;
+			h_game_ends[i].game_index = ends[i].game_index;
+			h_game_ends[i].outcome = ends[i].outcome;
+			h_game_ends[i].n_moves = ends[i].n_moves;
+			std::memcpy(h_game_ends[i].moves, ends[i].moves, sizeof(ends[i].moves));
+		}
+	}
+	if (drain)
+	{ // the device is synchronised: the pools start empty again (game serials / indices keep counting)
+		AGX_HIP_CHECK(hipMemset(e->dev.counters + 3, 0, 2 * sizeof(int)));
+		AGX_HIP_CHECK(hipMemset(e->dev.counters + 6, 0, 2 * sizeof(int)));
+	}
+	return AGX_OK;
+}
+
+int agx_engine_records(AgxEngine *e, AgxMoveRecord *h_records, int record_capacity, AgxEdgeView *h_edges, int edge_capacity, int *n_records, int *n_edges)
+{
+	AGX_REQUIRE(e != nullptr && n_records != nullptr && n_edges != nullptr, AGX_ERR_INVALID, "agx_engine_records: null argument");
+	AgxRecordCounts counts;
+	const bool sizes_only = (h_records == nullptr || h_edges == nullptr);
+	const int st = agx_engine_fetch_records(e, sizes_only ? nullptr : h_records, record_capacity, sizes_only ? nullptr : h_edges, edge_capacity, nullptr, 0, nullptr, 0,
+			&counts, 0);
+	if (st != AGX_OK)
+		return st;
+	*n_records = counts.records;
+	*n_edges = counts.edges;
 	return AGX_OK;
 }
 
 int agx_engine_drain_records(AgxEngine *e, AgxMoveRecord *h_records, int record_capacity, AgxEdgeView *h_edges, int edge_capacity, int *n_records, int *n_edges)
 {
-	AGX_REQUIRE(h_records != nullptr && h_edges != nullptr, AGX_ERR_INVALID, "agx_engine_drain_records: null buffer (query the sizes with agx_engine_records)");
-	const int st = agx_engine_records(e, h_records, record_capacity, h_edges, edge_capacity, n_records, n_edges);
+	AGX_REQUIRE(h_records != nullptr && h_edges != nullptr && n_records != nullptr && n_edges != nullptr, AGX_ERR_INVALID,
+			"agx_engine_drain_records: null buffer (query the sizes with agx_engine_records)");
+	AgxRecordCounts counts;
+	const int st = agx_engine_fetch_records(e, h_records, record_capacity, h_edges, edge_capacity, nullptr, 0, nullptr, 0, &counts, 1);
 	if (st != AGX_OK)
 		return st;
-	// the device is synchronised (agx_engine_records): the record pools start empty again; game_serial keeps counting
-	AGX_HIP_CHECK(hipMemset(e->dev.counters + 3, 0, 2 * sizeof(int)));
+	*n_records = counts.records;
+	*n_edges = counts.edges;
 	return AGX_OK;
 }
 

@@ -128,6 +128,20 @@ namespace agx
 			int32_t n_edges;
 			int32_t edge_offset; // into the record edge pool
 			int32_t root_flags;  // bit 0 statically solved, 1 recursively solved, 2 must defend (SearchDataPack::flags, data_packs.cpp:40-42)
+			int32_t game_slot;   // the pool slot (tree) that produced the sample
+			int32_t game_index;  // how many games that slot had finished before this one: (slot, index) identifies a game
+			int32_t sample_offset; // the sample in dataset format 201 (sample_v201.hpp) inside the sample byte pool, -1 = not recorded
+			int32_t sample_bytes;
+			int32_t outcome;     // GameOutcome after this move: 0 = the game goes on, else this was its last move
+	};
+	/* One record per finished game: what GameGenerator::generate hands over when Game::isOver (GameGenerator.cpp:104-114): the outcome
+	 * and ALL moves of the game, opening included (Game::getMoves). */
+	struct GameEndRecord
+	{
+			int32_t game_serial, game_slot, game_index;
+			int32_t outcome;
+			int32_t n_moves;
+			uint16_t moves[MAXHW];
 	};
 
 	enum EngineError : int32_t
@@ -150,6 +164,9 @@ namespace agx
 			unsigned long long tt_bucket_mask; // buckets - 1 (4 entries of 16 bytes per bucket)
 			int node_cap, edge_cap, ht_cap, act_cap;
 			int record_cap, record_edge_cap;
+			int record_format;   // bit 0: root-edge snapshots (24-byte edges), bit 1: samples in dataset format 201 (6 bytes per entry)
+			int sample_cap;      // bytes of the format-201 sample pool
+			int game_end_cap;    // finished-game records
 			int n_openings;
 			float yield_fraction; // 0 = never; else a game yields between two solves once this fraction of the launch's games is done
 			int yield_counter;    // index into counters[] of the launch's "games done" count
@@ -186,10 +203,12 @@ namespace agx
 			int match_merged; // this launch covers both players' trees: network slot lists by half of the pool, not by launch
 			int match_mode;  // evaluation matches: tree g (first player) and tree g + n_games / 2 (second player) share one game
 			int *nn_list;          // compacted slots to evaluate
-			int *counters;         // [0] (unused), [1] next opening, [2] finished games, [3] records used, [4] record edges used, [5] total moves, [16 + group] positions scheduled for the network by that group
+			int *counters;         // [0] (unused), [1] next opening, [2] finished games, [3] records used, [4] record edges used, [5] total moves, [6] sample bytes used, [7] game-end records used, [16 + group] positions scheduled for the network by that group, [32 + group] games of that group done with their solver batch
 			// output records
 			MoveRecordHeader *records;
 			DEdge *record_edges;
+			uint8_t *samples;      // format-201 bytes, one 4-byte aligned block per recorded move
+			GameEndRecord *game_ends;
 	};
 }
 

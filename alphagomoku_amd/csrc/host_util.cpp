@@ -79,10 +79,14 @@ extern "C" int agx_make_opening(int rules, int board_size, uint32_t seed, uint16
 		for (int k = 0; k < count; k++)
 		{
 			if (moves.empty())
-			{
+			{ // generateOpeningMap on an empty board (misc.cpp:111-120) ACCUMULATES into the map, and prepareOpening does not clear the
+			  // map between attempts (:144): after a rejected attempt the first stone is drawn from the previous map plus the centre map
 				for (int i = 0; i < n; i++)
 					for (int j = 0; j < n; j++)
-						dist[i * n + j] = static_cast<float>(std::pow(1.5, -(std::hypot(0.5 + i - 0.5 * n, 0.5 + j - 0.5 * n) - 1.0)));
+					{
+						const float d = static_cast<float>(std::hypot(0.5 + i - 0.5 * n, 0.5 + j - 0.5 * n) - 1);
+						dist[i * n + j] += static_cast<float>(std::pow(1.5f, -d));
+					}
 			}
 			else
 			{
@@ -95,31 +99,33 @@ extern "C" int agx_make_opening(int rules, int board_size, uint32_t seed, uint16
 							for (int i = 0; i < n; i++)
 								for (int j = 0; j < n; j++)
 									if (board[i * n + j] == 0)
-										dist[i * n + j] += static_cast<float>(std::pow(t, -(std::hypot(static_cast<double>(i - p), static_cast<double>(j - q)) - 1.0)));
+									{
+										const float d = static_cast<float>(std::hypot(static_cast<double>(i - p), static_cast<double>(j - q)) - 1);
+										dist[i * n + j] += static_cast<float>(std::pow(t, -d));
+									}
 			}
+			// randomizeMove (misc.cpp:84-103)
 			float total = 0.0f;
 			for (int i = 0; i < hw; i++)
 				total += dist[i];
-			const float pick = total * rand_float();
-			float acc = 0.0f;
-			int cell = -1;
-			for (int i = 0; i < hw; i++)
+			int cell;
+			if (total == 0.0f)
+				cell = rand_int(hw);
+			else
 			{
-				acc += dist[i];
-				if (pick < acc)
+				const float pick = total * rand_float();
+				float acc = 0.0f;
+				cell = 0;
+				for (; cell < hw; cell++)
 				{
-					cell = i;
-					break;
-				}
-			}
-			if (cell < 0 || board[cell] != 0)
-			{ // rounding tail: take the last empty cell
-				for (int i = hw - 1; i >= 0; i--)
-					if (board[i] == 0)
-					{
-						cell = i;
+					acc += dist[cell];
+					if (pick < acc)
 						break;
-					}
+				}
+				if (cell >= hw)
+					cell = hw - 1;
+				while (board[cell] != 0 && cell > 0)
+					cell--; // unreachable in exact arithmetic; guards the rounding tail
 			}
 			board[cell] = static_cast<uint8_t>(sign);
 			last_r = cell / n;

@@ -33,6 +33,8 @@
 #include "agx_internal.hpp"
 
 #include <vector>
+#include <mutex>
+#include <utility>
 #include <cstring>
 #include <cmath>
 #include <cstdlib>
@@ -802,7 +804,12 @@ struct AgxNet
 		void *d_wv3 = nullptr;
 		void *d_wq2 = nullptr;  // action-values head 1x1 weights [F][4] (padded), only with desc.action_values
 		float bq2[3] = { 0, 0, 0 };
-		void *d_skip = nullptr; // single-plane variant: residual scratch, one slice per workgroup of the persistent grid
+		// single-plane variant: residual scratch, one slice per workgroup of the persistent grid.  Launches on DIFFERENT streams may run
+		// concurrently (pool slices driven from several streams share one network), so every stream gets its own scratch; launches on
+		// one stream are ordered and share theirs.
+		std::mutex skip_mutex;
+		std::vector<std::pair<hipStream_t, void*>> skip_by_stream;
+		size_t skip_bytes = 0;
 		bool inplace = false;
 		float bp2 = 0.0f;
 		float bv1[4] = { 0, 0, 0, 0 };
@@ -819,13 +826,17 @@ namespace
 	}
 	void free_net_buffers(AgxNet *net)
 	{
-		void **ptrs[] = { &net->d_w_in, &net->d_w_tower, &net->d_bias, &net->d_wp2, &net->d_wv1, &net->d_wv2, &net->d_bv2, &net->d_wv3, &net->d_skip, &net->d_wq2 };
+		void **ptrs[] = { &net->d_w_in, &net->d_w_tower, &net->d_bias, &net->d_wp2, &net->d_wv1, &net->d_wv2, &net->d_bv2, &net->d_wv3, &net->d_wq2 };
 		for (void **p : ptrs)
 		{
 			if (*p != nullptr)
 				(void) hipFree(*p);
 			*p = nullptr;
 		}
+		std::lock_guard<std::mutex> lock(net->skip_mutex);
+		for (auto &slice : net->skip_by_stream)
+			(void) hipFree(slice.second);
+		net->skip_by_stream.clear();
 	}
 	template<typename T>
 	int upload(void **dst, const std::vector<T> &src)
@@ -934,7 +945,7 @@ int agx_net_load_weights(AgxNet *net, const float *h_blob, size_t n_floats)
 	{
 		const size_t per_wg = (net->desc.rows == 20) ? ((F == 128) ? Geometry<128, 20, 20>::SKIP_PER_WG : Geometry<64, 20, 20>::SKIP_PER_WG)
 				: ((F == 128) ? Geometry<128, 15, 15>::SKIP_PER_WG : Geometry<64, 15, 15>::SKIP_PER_WG);
-		AGX_HIP_CHECK(hipMalloc(&net->d_skip, per_wg * 8 * static_cast<size_t>(net->num_cus)));
+		net->skip_bytes = per_wg * 8 * static_cast<size_t>(net->num_cus);
 	}
 	int status = AGX_OK;
 	if ((status = upload(&net->d_w_in, w_in)) != AGX_OK || (status = upload(&net->d_w_tower, w_tower)) != AGX_OK
@@ -986,7 +997,21 @@ static int launch_forward(AgxNet *net, const uint32_t *d_features, const int *d_
 
 	const int grid = (batch < net->num_cus) ? batch : net->num_cus;
 	hipStream_t s = static_cast<hipStream_t>(stream);
-	p.skip = static_cast<half4*>(net->d_skip);
+	p.skip = nullptr;
+	if (net->inplace)
+	{
+		std::lock_guard<std::mutex> lock(net->skip_mutex);
+		for (const auto &slice : net->skip_by_stream)
+			if (slice.first == s)
+				p.skip = static_cast<half4*>(slice.second);
+		if (p.skip == nullptr)
+		{
+			void *mem = nullptr;
+			AGX_HIP_CHECK(hipMalloc(&mem, net->skip_bytes));
+			net->skip_by_stream.emplace_back(s, mem);
+			p.skip = static_cast<half4*>(mem);
+		}
+	}
 	const bool big = (net->desc.rows == 20), wide = (net->desc.filters == 128), qhead = (p.q != nullptr);
 	const dim3 g(grid), t(512);
 #define AGX_LAUNCH_TOWER(FF, NN, IP, QH) hipLaunchKernelGGL((nn_tower_kernel<FF, NN, NN, IP, QH>), g, t, 0, s, p, d_features, d_policy, d_value)

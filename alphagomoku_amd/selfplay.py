@@ -7,7 +7,8 @@ import ctypes
 
 import numpy as np
 
-from ._lib import (lib, check, AgxEngineConfig, AgxEngineBuffers, AgxEngineStats, AgxGameInfo, AgxEdgeView, AgxMoveRecord)
+from ._lib import (lib, check, AgxEngineConfig, AgxEngineBuffers, AgxEngineStats, AgxGameInfo, AgxEdgeView, AgxMoveRecord, AgxGameEnd,
+                   AgxRecordCounts, AgxGameBufferStats)
 
 OPENING_CAP = 32
 
@@ -161,6 +162,20 @@ class GeneratorPool:
                  ctypes.byref(nr), ctypes.byref(ne)))
         return recs[:nr.value], edges[:ne.value]
 
+    def fetch_records(self, drain=False):
+        """everything the record pools hold: (move records, root-edge snapshots, format-201 sample bytes as uint8 array, finished games);
+        a record's sample is samples[r.sample_offset : r.sample_offset + r.sample_bytes]"""
+        counts = AgxRecordCounts()
+        check(lib.agx_engine_fetch_records(self._h, None, 0, None, 0, None, 0, None, 0, ctypes.byref(counts), 0))
+        recs = (AgxMoveRecord * max(counts.records, 1))()
+        edges = (AgxEdgeView * max(counts.edges, 1))()
+        samples = np.zeros(max(counts.sample_bytes, 4), np.uint8)
+        ends = (AgxGameEnd * max(counts.game_ends, 1))()
+        check(lib.agx_engine_fetch_records(self._h, ctypes.cast(recs, ctypes.c_void_p), len(recs), ctypes.cast(edges, ctypes.c_void_p), len(edges),
+                                           samples.ctypes.data_as(ctypes.c_void_p), samples.size, ctypes.cast(ends, ctypes.c_void_p), len(ends),
+                                           ctypes.byref(counts), 1 if drain else 0))
+        return recs[:counts.records], edges[:counts.edges], samples[:counts.sample_bytes], ends[:counts.game_ends]
+
     def step_match(self, first_net, second_net, stream=None):
         """one step of a match_mode pool: every stage one launch over both players' trees, the network stage per player"""
         check(lib.agx_engine_step_match(self._h, first_net._net, second_net._net, stream))
@@ -223,4 +238,40 @@ class GeneratorPool:
     def close(self):
         if self._h:
             lib.agx_engine_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+
+class GameBuffer:
+    """GameDataBuffer + GeneratorManager::addToBuffer (src/dataset/GameDataBuffer.cpp, src/selfplay/GeneratorManager.cpp:160-164): finished games in
+    the reference's dataset format 201; the samples are quantised on the device (record_format bit 1)"""
+
+    def __init__(self, rules, rows, cols, draw_after=0):
+        self._h = ctypes.c_void_p()
+        check(lib.agx_game_buffer_create(rules, rows, cols, draw_after, ctypes.byref(self._h)))
+
+    def collect(self, pool):
+        """drains the pool's records and appends the games that have finished; returns how many were added"""
+        added = ctypes.c_int()
+        check(lib.agx_game_buffer_collect(self._h, pool._h, ctypes.byref(added)))
+        return added.value
+
+    def stats(self):
+        s = AgxGameBufferStats()
+        check(lib.agx_game_buffer_stats(self._h, ctypes.byref(s)))
+        return {name: getattr(s, name) for name, _ in s._fields_}
+
+    def game(self, index):
+        """GameDataStorage::serialize bytes of one game"""
+        size = ctypes.c_size_t()
+        check(lib.agx_game_buffer_game(self._h, index, None, 0, ctypes.byref(size)))
+        out = np.zeros(size.value, np.uint8)
+        check(lib.agx_game_buffer_game(self._h, index, out.ctypes.data_as(ctypes.c_void_p), out.size, ctypes.byref(size)))
+        return out
+
+    def save(self, path, compress=True):
+        check(lib.agx_game_buffer_save(self._h, str(path).encode(), 1 if compress else 0))
+
+    def close(self):
+        if self._h:
+            lib.agx_game_buffer_destroy(self._h)
             self._h = ctypes.c_void_p()

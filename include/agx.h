@@ -103,7 +103,7 @@ int agx_nn_forward_indirect_pvq(AgxNet* net, const uint32_t* d_features, const i
  * ---------------------------------------------------------------------------------------------- */
 typedef struct AgxEngineConfig
 {
-	int rules;                        /* AgxRules; AGX_RENJU is rejected (not supported on the device yet) */
+	int rules;                        /* AgxRules (all five rule sets run on the device) */
 	int board_size;                   /* square boards, <= 20 */
 	int draw_after;                   /* GameConfig::draw_after, <= 0 means rows*cols */
 	int n_games;                      /* games resident on this GPU (SelfplayConfig::games_per_thread) */
@@ -163,6 +163,14 @@ typedef struct AgxEngineConfig
 	                                     (reference default); 0 = prior 1 for the cells that hold the policy maximum, 0 elsewhere; otherwise
 	                                     policy^(1/T), evaluated as exp(log(p)/T) with the fixed double-precision series of csrc/root_noise.hpp
 	                                     (the reference calls std::pow), so device and oracle agree bit for bit. */
+	int record_format;                /* what k_advance keeps of every played move's root (SearchDataPack, dataset/data_packs.cpp:24-43):
+	                                     bit 0 (value 1, the default): the root edges as 24-byte AgxEdgeView snapshots;
+	                                     bit 1 (value 2): the sample quantised on the device to dataset format 201
+	                                     (SearchDataStorage_v201::loadFrom + serialize, dataset/SearchDataStorage.cpp:326-374,410-419:
+	                                     16-byte header + 6 bytes per visited / proven cell) — a quarter of the bytes to keep and copy;
+	                                     3 = both.  Finished games are always reported (AgxGameEnd). */
+	int record_sample_capacity;       /* bytes of the format-201 sample pool, 0 = 400 per record */
+	int game_end_capacity;            /* finished-game records kept on the device, 0 = 2 * n_games */
 } AgxEngineConfig;
 
 typedef struct AgxEngine AgxEngine; /* opaque */
@@ -228,7 +236,26 @@ typedef struct AgxMoveRecord
 	float root_win, root_draw;
 	int n_edges, edge_offset;
 	int root_flags; /* SearchDataPack::flags: bit 0 root statically solved, 1 recursively solved, 2 must defend (data_packs.cpp:40-42) */
+	int game_slot;      /* the pool slot (tree) that produced the sample */
+	int game_index;     /* games that slot had finished before this one: (game_slot, game_index) identifies a game; game_serial is the
+	                       opening id, which the two colour-swapped games of a match share */
+	int sample_offset;  /* record_format bit 1: the format-201 bytes of this sample inside the sample pool (-1 = not recorded) */
+	int sample_bytes;
+	int outcome;        /* GameOutcome after this move (0 unknown / 1 draw / 2 cross win / 3 circle win): non-zero on a game's last move */
 } AgxMoveRecord;
+
+typedef struct AgxGameEnd
+{ /* one finished game: what GameGenerator::generate passes on when Game::isOver (GameGenerator.cpp:104-114) */
+	int game_serial, game_slot, game_index;
+	int outcome;         /* GameOutcome (game/rules.hpp:29-35) */
+	int n_moves;         /* Game::getMoves(): opening stones included */
+	uint16_t moves[400]; /* Move::toShort */
+} AgxGameEnd;
+
+typedef struct AgxRecordCounts
+{
+	int records, edges, sample_bytes, game_ends;
+} AgxRecordCounts;
 
 #define AGX_OPENING_CAP 32 /* uint16 per opening: [0] = number of stones, [1..] = Move::toShort */
 
@@ -260,7 +287,8 @@ int agx_engine_expand_backup(AgxEngine* engine, void* stream);
 int agx_engine_step(AgxEngine* engine, AgxNet* net, void* stream);
 /* The same stages restricted to group `group` of `n_groups` equal slices of the pool.  Games are independent, so slices can be
  * driven from different streams and drift apart: while one slice waits for its slowest solver wave, the others use the CUs
- * (this is how bench.py runs the pool).  Results per game do not depend on the grouping. */
+ * (at most 16 groups).  Results per game do not depend on the grouping.  A network may be shared by the slices: the single-plane
+ * kernels keep their scratch per stream. */
 int agx_engine_select_solve_group(AgxEngine* engine, int group, int n_groups, void* stream);
 int agx_engine_evaluate_group(AgxEngine* engine, AgxNet* net, int group, int n_groups, void* stream);
 int agx_engine_expand_backup_group(AgxEngine* engine, int group, int n_groups, void* stream);
@@ -281,6 +309,11 @@ int agx_engine_records(AgxEngine* engine, AgxMoveRecord* h_records, int record_c
 /* Same, then empties the device-side record pools (what GeneratorManager::addToBuffer's hand-over does, GeneratorManager.cpp:
  * 160-164): a long-running loop calls this every few hundred steps so that record_capacity is never exhausted. */
 int agx_engine_drain_records(AgxEngine* engine, AgxMoveRecord* h_records, int record_capacity, AgxEdgeView* h_edges, int edge_capacity, int* n_records, int* n_edges);
+/* Everything the record pools hold: move records, root-edge snapshots (record_format bit 0), format-201 sample bytes (bit 1) and
+ * finished games.  Any buffer may be NULL (with capacity 0) to skip that part; `counts` receives what the device holds.  drain != 0
+ * empties all four pools afterwards (GeneratorManager::addToBuffer's hand-over, GeneratorManager.cpp:160-164). */
+int agx_engine_fetch_records(AgxEngine* engine, AgxMoveRecord* h_records, int record_capacity, AgxEdgeView* h_edges, int edge_capacity,
+		uint8_t* h_samples, int sample_capacity, AgxGameEnd* h_game_ends, int game_end_capacity, AgxRecordCounts* counts, int drain);
 /* Match mode, the efficient way to step: every stage is ONE launch over both players' trees (about half of them search at any time),
  * only the network stage runs per player: select/solve for all, first_net on the first players' leaves, second_net on the second
  * players', expand/backup/move for all.  A tree that gets the move in this step starts searching in the next one; per-tree
@@ -306,6 +339,38 @@ int agx_debug_pattern_state(AgxEngine* engine, const uint8_t* h_boards, const in
 /* Host-only: the lookup tables the engine uploads (pattern uint8[1<<20], half-open-three uint8[1<<20], threat uint8[4096][2],
  * defence uint16[15][256][2]) for verification against the reference tables. */
 int agx_host_tables(int rules, uint8_t* h_pattern, uint8_t* h_half_open_three, uint8_t* h_threat, uint16_t* h_defense);
+
+/* ------------------------------------------------------------------------------------------------
+ * Self-play record sink: finished games in the reference's dataset format 201.
+ * Replaces GameDataStorage / GameDataBuffer on the producing side (src/dataset/GameDataStorage.cpp:217-250,
+ * src/dataset/GameDataBuffer.cpp:97-113) and GeneratorManager::addToBuffer (src/selfplay/GeneratorManager.cpp:160-164).
+ * The samples themselves are quantised on the device (AgxEngineConfig.record_format bit 1).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct AgxGameBuffer AgxGameBuffer; /* opaque; every call locks the buffer's mutex, so one buffer may serve the generator threads of several GPUs */
+
+typedef struct AgxGameBufferStats
+{ /* GameDataBufferStats (dataset/GameDataBuffer.hpp) */
+	int games, samples, cross_win, draws, circle_win, game_length;
+} AgxGameBufferStats;
+
+int agx_game_buffer_create(int rules, int rows, int cols, int draw_after, AgxGameBuffer** out);
+int agx_game_buffer_destroy(AgxGameBuffer* buffer);
+int agx_game_buffer_clear(AgxGameBuffer* buffer);
+/* Drains the engine's record pools (synchronises its device) and appends every game that has finished: samples by move number, all
+ * moves of the game, outcome, rows, cols = the bytes of GameDataStorage::serialize.  Samples of games still running are kept until
+ * their game ends.  The engine must record format-201 samples.  games_added may be NULL. */
+int agx_game_buffer_collect(AgxGameBuffer* buffer, AgxEngine* engine, int* games_added);
+int agx_game_buffer_stats(const AgxGameBuffer* buffer, AgxGameBufferStats* out);
+/* GameDataStorage::serialize bytes of game `index`; h_bytes == NULL only queries *size. */
+int agx_game_buffer_game(const AgxGameBuffer* buffer, int index, uint8_t* h_bytes, size_t capacity, size_t* size);
+/* GameDataBuffer::save: {"format": 201, "config": {...}, "offsets": [...]} + newline + the games' bytes; compress != 0 wraps the file in
+ * a zlib stream (the reference compresses with MinML's ZipWrapper, whose format is not in the reference tree). */
+int agx_game_buffer_save(const AgxGameBuffer* buffer, const char* path, int compress);
+/* Host-only reader of one format-201 sample (SearchDataStorage_v201's parsing constructor + storeTo, dataset/SearchDataStorage.cpp:
+ * 300-320,375-409): per cell visits int32[rows*cols], prior float[rows*cols], value float[rows*cols][2] = (win, draw), score
+ * uint16[rows*cols]; header int[3] = (minimax score raw bits, move number, flags); minimax_value float[2].  consumed may be NULL. */
+int agx_sample_v201_unpack(const uint8_t* h_bytes, size_t size, int rows, int cols, int32_t* visits, float* prior, float* value, uint16_t* score,
+		int* header, float* minimax_value, size_t* consumed);
 
 /* Raw device-memory helpers so that non-HIP hosts (ctypes, cgo) can stage buffers. */
 int agx_malloc(void** d_ptr, size_t bytes);

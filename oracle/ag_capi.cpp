@@ -3,6 +3,7 @@
  * the cpu_baseline leg of bench.py).
  */
 #include "agoracle.hpp"
+#include "ag_dataset.hpp"
 #include "ag_noise.hpp"
 
 #include <chrono>
@@ -545,6 +546,153 @@ int ago_game_record(void *h, int index, uint16_t *move, int *root_visits, float 
 		edge_score[i] = r.root_edges[i].score.d;
 	}
 	return n;
+}
+/* ---- self-play record sink (ag_dataset.hpp) ---- */
+} /* extern "C" */
+namespace
+{
+	template<typename F>
+	uint32_t lowfp_dispatch(int format, F f)
+	{
+		switch (format)
+		{
+			case 0: return f(score_format());
+			case 1: return f(visit_format());
+			case 2: return f(policy_format());
+			default: return f(fp16_format());
+		}
+	}
+	/* SearchDataPack(const Node&, board) (data_packs.cpp:24-43) from a root snapshot; only the NUMBER of stones of the board matters to format 201 */
+	SearchDataPack make_pack(int rows, int cols, int stones, int n_edges, const uint16_t *edge_moves, const int32_t *edge_visits, const float *edge_prior,
+			const float *edge_value, const uint16_t *edge_score, uint16_t root_score, int root_flags)
+	{
+		SearchDataPack pack(rows, cols);
+		for (int i = 0; i < stones && i < rows * cols; i++)
+			pack.board[i] = CROSS;
+		for (int i = 0; i < n_edges; i++)
+		{
+			const Move m = Move::from_short(edge_moves[i]);
+			const int cell = m.row * cols + m.col;
+			pack.policy_prior[cell] = edge_prior[i];
+			pack.visit_count[cell] = edge_visits[i];
+			pack.action_values[cell] = Value(edge_value[2 * i], edge_value[2 * i + 1]);
+			pack.action_scores[cell] = Score::raw(edge_score[i]);
+		}
+		pack.minimax_score = Score::raw(root_score);
+		pack.flags = static_cast<uint16_t>(root_flags);
+		return pack;
+	}
+	SearchDataStorage_v201 storage_of_record(const Game &g, const Game::MoveRecord &r)
+	{
+		SearchDataPack pack(g.cfg.rows, g.cfg.cols);
+		for (int i = 0; i < r.stones; i++)
+			pack.board[i] = CROSS;
+		for (const Edge &e : r.root_edges)
+		{
+			const int cell = e.move.row * g.cfg.cols + e.move.col;
+			pack.policy_prior[cell] = e.prior;
+			pack.visit_count[cell] = e.visits;
+			pack.action_values[cell] = e.value;
+			pack.action_scores[cell] = e.score;
+		}
+		pack.minimax_value = r.root_value;
+		pack.minimax_score = r.root_score;
+		pack.flags = static_cast<uint16_t>(r.root_flags);
+		SearchDataStorage_v201 s;
+		s.load_from(pack);
+		return s;
+	}
+}
+extern "C" {
+uint32_t ago_lowfp_to_lowp(int format, float x)
+{
+	return lowfp_dispatch(format, [x](auto f) { return decltype(f)::to_lowp(x); });
+}
+float ago_lowfp_to_fp32(int format, uint32_t code)
+{
+	float out = 0.0f;
+	lowfp_dispatch(format, [&](auto f) { out = decltype(f)::to_fp32(code); return 0u; });
+	return out;
+}
+float ago_lowfp_max(int format)
+{
+	float out = 0.0f;
+	lowfp_dispatch(format, [&](auto f) { out = decltype(f)::max(); return 0u; });
+	return out;
+}
+int ago_score_to_int8(uint16_t raw)
+{
+	return score_to_int8(Score::raw(raw));
+}
+uint16_t ago_int8_to_score(int code)
+{
+	return int8_to_score(static_cast<uint8_t>(code)).d;
+}
+/* SearchDataStorage_v201::loadFrom + serialize of one root snapshot; returns the number of bytes (-1: does not fit) */
+int ago_sample_v201_pack(int rows, int cols, int stones, int n_edges, const uint16_t *edge_moves, const int32_t *edge_visits, const float *edge_prior,
+		const float *edge_value, const uint16_t *edge_score, uint16_t root_score, int root_flags, uint8_t *out, int capacity)
+{
+	const SearchDataPack pack = make_pack(rows, cols, stones, n_edges, edge_moves, edge_visits, edge_prior, edge_value, edge_score, root_score, root_flags);
+	SearchDataStorage_v201 s;
+	s.load_from(pack);
+	std::vector<uint8_t> bytes;
+	s.serialize(bytes);
+	if (static_cast<int>(bytes.size()) > capacity)
+		return -1;
+	std::memcpy(out, bytes.data(), bytes.size());
+	return static_cast<int>(bytes.size());
+}
+/* parse + storeTo: visits int[hw], prior float[hw], value float[hw][2], score u16[hw], header int[3] = (minimax score, move number, flags),
+ * minimax value float[2]; returns the number of bytes consumed */
+int ago_sample_v201_unpack(const uint8_t *bytes, int rows, int cols, int32_t *visits, float *prior, float *value, uint16_t *score, int *header, float *minimax_value)
+{
+	SearchDataStorage_v201 s;
+	const size_t used = s.parse(bytes, 0);
+	SearchDataPack pack(rows, cols);
+	s.store_to(pack);
+	for (int i = 0; i < rows * cols; i++)
+	{
+		visits[i] = pack.visit_count[i];
+		prior[i] = pack.policy_prior[i];
+		value[2 * i] = pack.action_values[i].win;
+		value[2 * i + 1] = pack.action_values[i].draw;
+		score[i] = pack.action_scores[i].d;
+	}
+	header[0] = pack.minimax_score.d;
+	header[1] = s.move_number;
+	header[2] = pack.flags;
+	minimax_value[0] = pack.minimax_value.win;
+	minimax_value[1] = pack.minimax_value.draw;
+	return static_cast<int>(used);
+}
+/* record i of the oracle game as SearchDataStorage_v201 bytes */
+int ago_game_record_v201(void *h, int index, uint8_t *out, int capacity)
+{
+	const Game &g = static_cast<GameHandle*>(h)->game;
+	std::vector<uint8_t> bytes;
+	storage_of_record(g, g.records.at(index)).serialize(bytes);
+	if (static_cast<int>(bytes.size()) > capacity)
+		return -1;
+	std::memcpy(out, bytes.data(), bytes.size());
+	return static_cast<int>(bytes.size());
+}
+/* the whole game as GameDataStorage::serialize (format 201) bytes: what GameGenerator hands to GeneratorManager::addToBuffer when the
+ * game is over (GameGenerator.cpp:104-114): samples, ALL moves of the game (opening included, Game::getMoves), outcome, rows, cols */
+int ago_game_storage_v201(void *h, uint8_t *out, int capacity)
+{
+	const Game &g = static_cast<GameHandle*>(h)->game;
+	std::vector<SearchDataStorage_v201> samples;
+	for (const Game::MoveRecord &r : g.records)
+		samples.push_back(storage_of_record(g, r));
+	std::vector<uint16_t> played;
+	for (const Move &m : g.moves)
+		played.push_back(m.to_short());
+	std::vector<uint8_t> bytes;
+	serialize_game_v201(samples, played, static_cast<int>(g.outcome), g.cfg.rows, g.cfg.cols, bytes);
+	if (static_cast<int>(bytes.size()) > capacity)
+		return -1;
+	std::memcpy(out, bytes.data(), bytes.size());
+	return static_cast<int>(bytes.size());
 }
 /* stats: nodes, nn_evals, leaks, duplicates, proven, wasted, solver_nodes, select_levels, select_edges, tree nodes, tree edges */
 void ago_game_stats(void *h, uint64_t *out)

@@ -749,6 +749,7 @@ namespace ago
 		rec.root_value = r.value;
 		rec.root_score = r.score;
 		rec.root_flags = (r.flags >> 3) & 7; // wasStaticallySolved, wasRecursivelySolved, mustDefend (Node.hpp:26-42 flag bits 8, 16, 32)
+		rec.stones = static_cast<int>(moves.size());
 		rec.root_edges.assign(tree.edges.begin() + r.edge_begin, tree.edges.begin() + r.edge_begin + r.n_edges);
 		const Move m = tree.edges[tree.select_final_edge(tree.root, scfg.final_selector)].move;
 		rec.move = m;

@@ -556,6 +556,7 @@ namespace ago
 					Value root_value;
 					Score root_score;
 					int root_flags = 0; // SearchDataPack::flags (data_packs.cpp:40-42)
+					int stones = 0;     // stones on the board the sample was taken on (SearchDataStorage_v201::move_number counts them)
 			};
 			std::vector<MoveRecord> records;
 			bool is_over() const { return outcome != O_UNKNOWN; }

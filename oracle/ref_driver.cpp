@@ -5,7 +5,9 @@
  * MinML library (no stand-in headers are written): src/patterns/{PatternTable,PatternClassifier,ThreatTable,
  * DefensiveMoveTable}.cpp, src/game/Move.cpp, src/search/{Score,Value,ZobristHashing}.cpp,
  * src/search/monte_carlo/{Edge,Node}.cpp, src/utils/random.cpp, and the header-only utils/augmentations.hpp,
- * search/alpha_beta/SharedHashTable.hpp, patterns/RawPatternCalculator.hpp, patterns/ThreatHistogram.hpp.
+ * search/alpha_beta/SharedHashTable.hpp, patterns/RawPatternCalculator.hpp, patterns/ThreatHistogram.hpp, utils/low_precision.hpp
+ * (the LowFP formats of the dataset quantiser; the quantiser itself, src/dataset/SearchDataStorage.cpp, includes
+ * <minml/utils/serialization.hpp> and is unbuildable here).
  * Built by oracle/Makefile into oracle/_ref/libagref.so straight from /root/reference; used by tests to pin the
  * restatement in oracle/ (tables, score algebra, struct layouts) and to generate tests/golden fixtures.
  * Everything that includes utils/configs.hpp (PatternCalculator, rules, MoveGenerator, AlphaBetaSearch, Tree, Search,
@@ -23,6 +25,7 @@
 #include <alphagomoku/search/alpha_beta/SharedHashTable.hpp>
 #include <alphagomoku/patterns/RawPatternCalculator.hpp>
 #include <alphagomoku/patterns/ThreatHistogram.hpp>
+#include <alphagomoku/utils/low_precision.hpp>
 #include <vector>
 
 #include <cstdint>
@@ -248,6 +251,39 @@ int ref_threat_histogram(const int *ops, int n_ops, int16_t *out)
 		}
 	}
 	return pos;
+}
+
+/* ---- LowFP (utils/low_precision.hpp): the four formats of src/dataset/SearchDataStorage.cpp:22,161-164.
+ * format 0 = score_format <1,3,2,-8>, 1 = visit_format <0,3,5,-8>, 2 = policy/value_format <0,4,4,-16>, 3 = fp16_format <0,5,11,-16> ---- */
+uint32_t ref_lowfp_to_lowp(int format, float x)
+{
+	switch (format)
+	{
+		case 0: return LowFP<1, 3, 2, -8>::to_lowp(x);
+		case 1: return LowFP<0, 3, 5, -8>::to_lowp(x);
+		case 2: return LowFP<0, 4, 4, -16>::to_lowp(x);
+		default: return LowFP<0, 5, 11, -16>::to_lowp(x);
+	}
+}
+float ref_lowfp_to_fp32(int format, uint32_t code)
+{
+	switch (format)
+	{
+		case 0: return LowFP<1, 3, 2, -8>::to_fp32(code);
+		case 1: return LowFP<0, 3, 5, -8>::to_fp32(code);
+		case 2: return LowFP<0, 4, 4, -16>::to_fp32(code);
+		default: return LowFP<0, 5, 11, -16>::to_fp32(code);
+	}
+}
+float ref_lowfp_max(int format)
+{
+	switch (format)
+	{
+		case 0: return LowFP<1, 3, 2, -8>::max();
+		case 1: return LowFP<0, 3, 5, -8>::max();
+		case 2: return LowFP<0, 4, 4, -16>::max();
+		default: return LowFP<0, 5, 11, -16>::max();
+	}
 }
 
 } /* extern "C" */

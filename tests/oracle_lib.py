@@ -71,6 +71,16 @@ def load():
         lib.ago_game_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         lib.ago_cpu_baseline.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(AgoSearchConfig), ctypes.c_int, ctypes.c_int,
                                          ctypes.c_double] + [ctypes.c_void_p] * 5
+        vp, ci = ctypes.c_void_p, ctypes.c_int
+        lib.ago_sample_v201_pack.argtypes = [ci, ci, ci, ci, vp, vp, vp, vp, vp, ctypes.c_uint16, ci, vp, ci]
+        lib.ago_sample_v201_unpack.argtypes = [vp, ci, ci, vp, vp, vp, vp, vp, vp]
+        lib.ago_game_record_v201.argtypes = [vp, ci, vp, ci]
+        lib.ago_game_storage_v201.argtypes = [vp, vp, ci]
+        lib.ago_score_to_int8.argtypes = [ctypes.c_uint16]
+        lib.ago_int8_to_score.argtypes = [ci]
+        lib.ago_int8_to_score.restype = ctypes.c_uint16
+        lib.ago_prepare_opening.argtypes = [ci, ci, ci, ctypes.c_uint32, vp]
+        lib.ago_fake_eval.argtypes = [ci, ci, vp, vp, vp]
         _lib = lib
     return _lib
 

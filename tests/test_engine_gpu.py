@@ -128,6 +128,51 @@ def test_solver_matches_oracle_per_position(agx_lib, olib, rules, max_nodes):
     pool.close()
 
 
+def _compare_record_sink(olib, pool, handles, rules, n, record_format):
+    """the samples quantised by k_advance to dataset format 201 and the finished games framed by the library
+    (GameDataStorage::serialize) must equal the oracle's restatement byte for byte"""
+    from alphagomoku_amd import selfplay
+    recs, edges, samples, ends = pool.fetch_records()
+    one = np.zeros(16 + 6 * n * n + 16, np.uint8)
+    checked = entries = 0
+    for g, h in enumerate(handles):
+        mine = sorted((r.move_number, i) for i, r in enumerate(recs) if r.game_serial == g)
+        assert len(mine) == olib.ago_game_num_records(h)
+        for k, (_, i) in enumerate(mine):
+            r = recs[i]
+            assert r.game_slot == g and r.game_index == 0 and r.sample_offset >= 0 and r.sample_offset % 4 == 0
+            size = olib.ago_game_record_v201(h, k, ol.ptr(one), one.size)
+            dev = samples[r.sample_offset:r.sample_offset + r.sample_bytes]
+            assert size == r.sample_bytes and np.array_equal(dev, one[:size]), (g, k)
+            if record_format & 1:   # ... and the same bytes from the device's own raw snapshot through the oracle's quantiser
+                e = edges[r.edge_offset:r.edge_offset + r.n_edges]
+                size2 = olib.ago_sample_v201_pack(n, n, r.move_number, len(e), ol.ptr(np.array([x.move for x in e], np.uint16)),
+                                                  ol.ptr(np.array([x.visits for x in e], np.int32)), ol.ptr(np.array([x.prior for x in e], np.float32)),
+                                                  ol.ptr(np.array([[x.win, x.draw] for x in e], np.float32).reshape(-1)),
+                                                  ol.ptr(np.array([x.score for x in e], np.uint16)), r.root_score, r.root_flags, ol.ptr(one), one.size)
+                assert size2 == r.sample_bytes and np.array_equal(dev, one[:size2]), (g, k)
+            assert (r.outcome != 0) == (k == len(mine) - 1 and olib.ago_game_outcome(h) != 0), (g, k)
+            entries += int(dev[12:16].view(np.uint32)[0])
+            checked += 1
+    finished = [g for g, h in enumerate(handles) if olib.ago_game_outcome(h) != 0]
+    assert sorted(e.game_slot for e in ends) == finished
+    buffer = selfplay.GameBuffer(rules, n, n)
+    assert buffer.collect(pool) == len(finished)
+    big = np.zeros(1 << 20, np.uint8)
+    by_first = {}
+    for i in range(len(finished)):
+        data = buffer.game(i)
+        by_first[bytes(data)] = i
+    for g in finished:
+        size = olib.ago_game_storage_v201(handles[g], ol.ptr(big), big.size)
+        assert bytes(big[:size]) in by_first, g      # GameDataStorage::serialize, byte for byte
+    st = buffer.stats()
+    assert st["games"] == len(finished) and st["samples"] == sum(olib.ago_game_num_records(handles[g]) for g in finished)
+    assert st["cross_win"] + st["draws"] + st["circle_win"] == len(finished)
+    buffer.close()
+    assert checked > 0 and entries > checked
+
+
 def _oracle_root(olib, h):
     rv, rs = ctypes.c_int(), ctypes.c_uint16()
     rval = (ctypes.c_float * 2)()
@@ -143,7 +188,8 @@ def _oracle_root(olib, h):
 
 
 def _play_and_compare(olib, rules, games, batch, sims, max_steps, evaluator, table_entries=1 << 16, n=N, final_selector=0, use_symmetries=0,
-                      action_values=0, noise_weight=0.0, noise_type=1, exploration_scaling=0.0, draw_after=0, max_children=0, policy_temperature=1.0):
+                      action_values=0, noise_weight=0.0, noise_type=1, exploration_scaling=0.0, draw_after=0, max_children=0, policy_temperature=1.0,
+                      record_format=1):
     """evaluator(features uint32 [n][HW]) -> (policy [n][HW] f32, value [n][2] f32 (win, draw)[, q [n][HW][2]]); used for BOTH sides"""
     from alphagomoku_amd import selfplay
     N, HW = n, n * n   # noqa: N806 (shadow the 15x15 module defaults)
@@ -151,7 +197,8 @@ def _play_and_compare(olib, rules, games, batch, sims, max_steps, evaluator, tab
                                   tss_table_entries=table_entries, node_capacity=4096, edge_capacity=65536 if n <= 15 else 131072,
                                   final_selector=final_selector, use_symmetries=use_symmetries, action_values=action_values,
                                   noise_type=noise_type if noise_weight > 0 else 0, noise_weight=noise_weight,
-                                  exploration_scaling=exploration_scaling, max_children=max_children, policy_temperature=policy_temperature)
+                                  exploration_scaling=exploration_scaling, max_children=max_children, policy_temperature=policy_temperature,
+                                  record_format=record_format)
     pool = selfplay.GeneratorPool(cfg)
     ocfg = ol.default_search_config(max_batch_size=batch, max_simulations=sims, table_entries=table_entries, final_selector=final_selector,
                                     use_symmetries=use_symmetries, noise_type=noise_type if noise_weight > 0 else 0, noise_weight=noise_weight)
@@ -231,6 +278,8 @@ def _play_and_compare(olib, rules, games, batch, sims, max_steps, evaluator, tab
             olib.ago_game_record(handles[g], i, ctypes.byref(mv), ctypes.byref(rv), rval, ctypes.byref(rs), ol.ptr(em), ol.ptr(ev), ol.ptr(ep), ol.ptr(evl), ol.ptr(es), 512)
             om.append(mv.value)
         assert dev_moves == om, g
+    if record_format & 2:
+        _compare_record_sink(olib, pool, handles, rules, N, record_format)
     stats = pool.stats()
     pool.close()
     for h in handles:
@@ -332,6 +381,16 @@ def test_whole_games_on_the_20x20_board(agx_lib, olib, rules, batch, sims):
     compared, stats = _play_and_compare(olib, rules, games=4, batch=batch, sims=sims, max_steps=6000, evaluator=_stand_in_evaluator(olib, 400), n=20)
     assert compared > 300
     assert stats["games_finished"] == 4
+
+
+@pytest.mark.parametrize("rules,n,record_format", [(0, 15, 3), (2, 15, 3), (3, 20, 3), (1, 15, 2), (0, 20, 2)])
+def test_record_sink_format_201(agx_lib, olib, rules, n, record_format):
+    """every played move's root quantised ON THE DEVICE to SearchDataStorage_v201 bytes (3 scales, score, move number, flags,
+    6-byte entries; 20x20 boards exercise the ">= 255 cells" filler rule) == the oracle's loadFrom + serialize; finished games framed as
+    GameDataStorage::serialize == the oracle's (dataset/SearchDataStorage.cpp:326-419, dataset/GameDataStorage.cpp:217-250)"""
+    compared, stats = _play_and_compare(olib, rules, games=5, batch=4, sims=60, max_steps=6000, evaluator=_stand_in_evaluator(olib, n * n), n=n,
+                                        record_format=record_format)
+    assert compared > 200 and stats["games_finished"] == 5
 
 
 def test_yielding_pool_gives_the_same_games(agx_lib, olib):
