@@ -40,6 +40,18 @@ def combine(dist, elapsed_seconds, counters):
     return float(t.item()), [float(x) for x in c.tolist()]
 
 
+def gather(dist, values):
+    """every rank's list of numbers, as a list of lists indexed by rank (identity wrapper for a single process)"""
+    if dist is None:
+        return [[float(v) for v in values]]
+    import torch
+    device = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    mine = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return [[float(x) for x in t.tolist()] for t in out]
+
+
 def rank_seed_base(rank):
     """disjoint opening seeds per rank so that the ranks play different games"""
     return rank * 1000003

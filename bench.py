@@ -9,12 +9,19 @@ move decision / tree compaction.  Workload at N = 1: BASELINE.json configs[1] â€
 Multi-GPU: games are independent, so each rank runs its own pool of 1024 games (weak scaling); there is no data-path
 collective, torch.distributed is only used for the barrier and the max-over-ranks timing the contract asks for.
 
-Usage: python bench.py [--gpus N] [--steps K] [--warmup W]     (N > 1: launched by torch.distributed.run, one rank per GPU)
+Usage: python bench.py [--gpus N] [--steps K] [--warmup W]
+N > 1: one rank per GPU.  Started by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (RANK / LOCAL_RANK /
+WORLD_SIZE in the environment) the ranks run as they are; started plainly (`python bench.py --gpus N`) the script launches that
+command itself BEFORE anything touches a GPU and exits with its return code.  AGX_FORCE_DEVICE=d puts every rank on device d (the
+N > 1 flow on a 1-GPU box).
 """
 import argparse
 import ctypes
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,6 +39,18 @@ def nn_flops_per_position(desc):
     return flops
 
 
+def source_hash():
+    """sha256 over the sources libagx.so is built from: ties committed PMC summaries to the build they were taken from"""
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "alphagomoku_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".hpp", ".cpp")):
+            h.update(name.encode())
+            h.update(open(os.path.join(csrc, name), "rb").read())
+    h.update(open(os.path.join(ROOT, "include", "agx.h"), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def cpu_baseline(args, max_seconds):
     """Times the CPU oracle (a scalar restatement of the reference search, oracle/) on this box's host cores with a stand-in
     evaluator (network cost = 0).  This is the ONLY place where bench.py touches oracle/."""
@@ -39,17 +58,22 @@ def cpu_baseline(args, max_seconds):
     import oracle_lib as ol
     lib = ol.load()
     cores = os.cpu_count() or 1
-    threads = max(1, min(cores, 64))
+    threads = max(1, cores if args.cpu_threads <= 0 else min(cores, args.cpu_threads))   # every host CPU: one self-play game per thread
     cfg = ol.default_search_config(max_batch_size=args.batch, max_simulations=args.sims, table_entries=4 * 1024 * 1024)
     nodes, games, moves = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
     seconds = ctypes.c_double()
     stats = (ctypes.c_uint64 * 9)()
     lib.ago_cpu_baseline(args.rules, args.board, args.board, ctypes.byref(cfg), threads, 1000, ctypes.c_double(max_seconds),
                          ctypes.byref(nodes), ctypes.byref(games), ctypes.byref(moves), ctypes.byref(seconds), stats)
-    return dict(value=nodes.value / seconds.value, unit="simulations/s", cores=threads, kind="port",
+    rate = nodes.value / seconds.value
+    return dict(value=rate, unit="simulations/s", cores=threads, kind="port",
                 sample="%d threads x 1 self-play game each (same rules/board/playouts/batch, stand-in evaluator, NN cost excluded), %.1f s wall, %d simulations, %d moves"
                        % (threads, seconds.value, nodes.value, moves.value),
-                host_cpus=cores)
+                host_cpus=cores, per_thread=rate / threads,
+                # the REAL reference search core (compiled with AVX2 intrinsics, one thread, fake evaluator) measured 10.5 k/s for this
+                # shape; the oracle is a scalar restatement (no SSE/AVX neighbourhood code) and every game owns a 64 MB solver table, so with one
+                # game per hardware thread the tables (threads x 64 MB) live in DRAM, not in cache
+                reference_core_per_thread_survey=10500.0)
 
 
 def main():
@@ -71,10 +95,23 @@ def main():
     ap.add_argument("--yield-fraction", type=float, default=0.75, help="solver straggler cut-off (0 = lock-step pool)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline, 0 = every host CPU")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher of N ranks (nothing has touched a GPU yet: no library, no torch.cuda)
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd).returncode)
 
     from alphagomoku_amd import distributed
     rank, local_rank, world = distributed.env_ranks()
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d (launch with --nproc-per-node %d, or plainly and let bench.py spawn the ranks)"
+                         % (args.gpus, world, args.gpus))
     # the ranks only exchange a barrier and two tiny reductions of host scalars -> gloo on CPU tensors keeps torch off the GPUs
     # (set AGX_DIST_BACKEND=nccl to run the same reductions over RCCL)
     dist = distributed.init(backend=os.environ.get("AGX_DIST_BACKEND", "gloo"))
@@ -170,6 +207,8 @@ def main():
     if s1["first_error"] != 0:
         raise RuntimeError("device engine stopped with error code %d" % s1["first_error"])
 
+    local_elapsed = elapsed
+    per_rank = distributed.gather(dist, [sims, local_elapsed, distributed.rank_seed_base(rank), int(os.environ.get("AGX_FORCE_DEVICE", local_rank))])
     elapsed, (sims, evals, moves, games_done) = distributed.combine(dist, elapsed, [sims, evals, moves, games_done])
 
     if rank == 0:
@@ -189,15 +228,24 @@ def main():
         tree_ms = kernel_ms[0] + kernel_ms[2] + kernel_ms[3]
         local_sims = s1["evaluated_nodes"] - s0["evaluated_nodes"]
         tree_gbs = local_sims * tree_bytes / (tree_ms * 1e-3) / 1e9 if tree_ms > 0 else 0.0
+        # PMC-derived figures cannot be sampled from inside this process (rocprofv3 --pmc passes, scripts/pmc_summary.py).  They are quoted only
+        # when the committed summary was taken from THIS build (same source hash) and this workload; otherwise null.
         traffic = None
         mfma_busy = None
-        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-        if os.path.exists(pmc_path) and args.games == 1024 and args.filters == 128 and args.blocks == 6:
-            # HBM-side bytes per network launch from the committed rocprofv3 --pmc passes of this same command (FETCH_SIZE doubled per
-            # the gfx950 correction + WRITE_SIZE); PMC counters cannot be sampled from inside this process
+        solver_issue = None
+        pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
+        src_hash = source_hash()
+        pmc_build = None
+        if os.path.exists(pmc_path):
             pmc = json.load(open(pmc_path))
-            traffic = pmc.get("nn_tower_bytes_per_launch_corrected")
-            mfma_busy = pmc.get("nn_tower_mfma_busy_fraction")
+            pmc_build = pmc.get("source_hash")
+            if pmc_build == src_hash and args.games == 1024 and args.filters == 128 and args.blocks == 6 and args.board == 15 and args.rules == 0:
+                traffic = pmc.get("nn_tower_bytes_per_launch_corrected")
+                mfma_busy = pmc.get("nn_tower_mfma_busy_fraction")
+                solver_issue = pmc.get("k_solve_issue_busy_fraction")
+        gpu_ms = kernel_ms[0] + kernel_ms[1] + kernel_ms[2] + kernel_ms[3] + ms_nn
+        per_kernel = {"k_select": kernel_ms[0], "k_solve": kernel_ms[1], "nn_tower": ms_nn, "k_expand": kernel_ms[2], "k_advance": kernel_ms[3]}
+        longest = max(per_kernel, key=per_kernel.get)
         result = {
             "metric": "MCTS simulations/sec (self-play, %dx%d %s)" % (args.board, args.board, RULE_NAMES[args.rules]),
             "value": sims / elapsed,
@@ -226,12 +274,22 @@ def main():
             "shape": {"mean_select_depth": depth, "mean_edges_per_level": edges_per_level,
                       "solver_nodes_per_simulation": solver_nodes / max(1, s1["evaluated_nodes"] - s0["evaluated_nodes"]),
                       "nn_evals_per_simulation": local_evals / max(1, s1["evaluated_nodes"] - s0["evaluated_nodes"])},
+            "ranks": [{"rank": i, "device": int(r[3]), "simulations": int(r[0]), "seconds": r[1], "opening_seed_base": int(r[2])} for i, r in enumerate(per_rank)],
+            "longest_kernel": {"name": longest, "share_of_kernel_time": per_kernel[longest] / gpu_ms if gpu_ms > 0 else None},
+            "source_hash": src_hash,
+            # the roofline object is the MFMA-bound network kernel (the only kernel of the step with a compute roof); the threat solver
+            # (roofline_solver) has neither an HBM nor an MFMA roof, see DESIGN.md
             "roofline": {"bound": "mfma", "kernel": "nn_tower_kernel<%d,%d,%d>" % (args.filters, args.board, args.board),
                          "achieved": nn_tflops, "peak": 2500.0, "unit": "TFLOP/s", "frac": nn_tflops / 2500.0, "traffic": traffic,
                          "flops_per_position": flops, "positions_per_launch": local_evals / args.steps,
                          "avg_launch_ms": ms_nn / args.steps,
                          # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) of the committed PMC passes of this command
-                         "mfma_busy_fraction_pmc": mfma_busy},
+                         "mfma_busy_fraction_pmc": mfma_busy, "pmc_summary_build": pmc_build},
+            "roofline_solver": {"bound": "none (instruction issue / dependent-chain latency: one wave per game, tasks of a game strictly ordered)",
+                                "kernel": "k_solve", "ms_per_step": kernel_ms[1] / args.steps,
+                                "share_of_kernel_time": kernel_ms[1] / gpu_ms if gpu_ms > 0 else None,
+                                "solver_nodes_per_sec": solver_nodes / elapsed, "us_per_solver_node_per_wave": (kernel_ms[1] * 1e3 * args.games / solver_nodes) if solver_nodes else None,
+                                "issue_busy_fraction_pmc": solver_issue},
             # second roof ("two kernels, two roofs"): the tree kernels are gathers/scans over the flat node/edge arrays
             "roofline_tree": {"bound": "hbm", "kernels": "k_select + k_expand + k_advance", "achieved": tree_gbs, "peak": 8000.0, "unit": "GB/s",
                               "frac": tree_gbs / 8000.0, "bytes_per_simulation": tree_bytes, "ms_per_step": tree_ms / args.steps,

@@ -1,0 +1,39 @@
+"""bench.py on the GPU box: the N > 1 flow (SURVEY row e — independent game pools, no collective) exercised on ONE GPU by putting both
+ranks on device 0 (AGX_FORCE_DEVICE), and the line's contract fields."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--games", "128", "--sims", "100", "--steps", "60", "--warmup", "5", "--table-entries", "65536", "--no-cpu-baseline"]
+
+
+def run_bench(extra, env=None):
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    e.update(env or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, env=e, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [x for x in p.stdout.splitlines() if x.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]            # rank 0 prints ONE line
+    return json.loads(lines[0])
+
+
+def test_two_ranks_on_one_gpu_report_the_whole_job(agx_lib):
+    one = run_bench(["--gpus", "1"] + SMALL)
+    two = run_bench(["--gpus", "2"] + SMALL, env={"AGX_FORCE_DEVICE": "0"})
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["scaling"] == "weak"
+    ranks = two["ranks"]
+    assert [r["rank"] for r in ranks] == [0, 1] and all(r["simulations"] > 0 for r in ranks)
+    assert ranks[0]["opening_seed_base"] != ranks[1]["opening_seed_base"]          # the pools play different games
+    total = sum(r["simulations"] for r in ranks)
+    assert abs(two["value"] * (two["ms_per_step"] * 1e-3 * two["steps"]) - total) <= 1e-6 * total   # value = all ranks' work / max time
+    assert abs(ranks[0]["simulations"] - ranks[1]["simulations"]) < 0.25 * total   # same shape of work per rank
+    # the same game pool as the single run on rank 0 (seed base 0): identical work, whatever the pacing
+    assert one["ranks"][0]["simulations"] == ranks[0]["simulations"]
+    for line in (one, two):
+        assert line["roofline"]["bound"] == "mfma" and 0 < line["roofline"]["frac"] < 1
+        assert line["roofline_solver"]["kernel"] == "k_solve" and line["longest_kernel"]["name"] in line["kernel_ms_per_step"]

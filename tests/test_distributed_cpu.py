@@ -16,8 +16,9 @@ WORKER = textwrap.dedent('''
     dist = distributed.init(backend="gloo")
     dist.barrier()
     elapsed, counters = distributed.combine(dist, 1.0 + rank, [100 * (rank + 1), 7, rank])
+    everyone = distributed.gather(dist, [rank, 10 * rank])
     dist.barrier()
-    print(json.dumps(dict(rank=rank, world=world, elapsed=elapsed, counters=counters, seed=distributed.rank_seed_base(rank))))
+    print(json.dumps(dict(rank=rank, world=world, elapsed=elapsed, counters=counters, seed=distributed.rank_seed_base(rank), everyone=everyone)))
     dist.destroy_process_group()
 ''')
 
@@ -48,9 +49,36 @@ def test_two_ranks_gloo(tmp_path):
         assert o["world"] == 2
         assert o["elapsed"] == 2.0                       # MAX over ranks
         assert o["counters"] == [300.0, 14.0, 1.0]      # SUM over ranks
+        assert o["everyone"] == [[0.0, 0.0], [1.0, 10.0]]  # per-rank values, by rank
     assert outs[0]["seed"] != outs[1]["seed"]
 
 
 def test_single_process_is_identity():
     from alphagomoku_amd import distributed
     assert distributed.combine(None, 1.5, [3, 4]) == (1.5, [3.0, 4.0])
+
+
+def test_bench_refuses_a_world_that_does_not_match_gpus():
+    """`bench.py --gpus N` under a launcher with another world size must fail loudly (before anything touches a GPU) instead of silently
+    running one pool and reporting n_gpus: 1"""
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "WORLD_SIZE is 1" in (p.stderr + p.stdout)
+
+
+def test_bench_spawns_its_ranks(tmp_path):
+    """plain `python bench.py --gpus 2` becomes the launcher: the ranks it starts see WORLD_SIZE=2 (checked with a stand-in for
+    torch.distributed.run's target: the spawned command line is bench.py itself, so here only the command construction is exercised by
+    making the child fail fast on a missing GPU library call — the rank processes must exist and report their world size)"""
+    probe = tmp_path / "sitecustomize.py"
+    probe.write_text("import os, sys\n"
+                     "if os.environ.get('WORLD_SIZE') and os.environ.get('AGX_PROBE_DIR'):\n"
+                     "    open(os.path.join(os.environ['AGX_PROBE_DIR'], 'rank%s_of_%s' % (os.environ['RANK'], os.environ['WORLD_SIZE'])), 'w').close()\n"
+                     "    if 'bench.py' in ' '.join(sys.argv): os._exit(0)\n")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env["PYTHONPATH"] = str(tmp_path) + os.pathsep + env.get("PYTHONPATH", "")
+    env["AGX_PROBE_DIR"] = str(tmp_path)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--no-cpu-baseline"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert sorted(f for f in os.listdir(tmp_path) if f.startswith("rank")) == ["rank0_of_2", "rank1_of_2"]
