@@ -9,7 +9,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SMALL = ["--games", "128", "--sims", "100", "--steps", "60", "--warmup", "5", "--table-entries", "65536", "--no-cpu-baseline"]
+SMALL = ["--games", "128", "--sims", "100", "--steps", "60", "--warmup", "5", "--table-entries", "65536", "--no-cpu-baseline", "--yield-fraction", "0"]
 
 
 def run_bench(extra, env=None):
