@@ -12,6 +12,8 @@ LIB = os.path.join(HERE, "libagx.so")
 
 SOURCES = ["agx_api.hip", "nn_forward.hip", "engine.hip", "tables_host.cpp", "host_util.cpp", "game_buffer.cpp"]
 DRIVER = os.path.join(HERE, "agx_selfplay")
+AG_LIB = os.path.join(HERE, "libagx_ag.so")               # the reference-named C++ classes (include/alphagomoku_agx/) over the C ABI
+BOUNDARY_TEST = os.path.join(HERE, "agx_boundary_test")  # tests/cpp/boundary_main.cpp: the reference's call chain on those classes
 
 
 def needs_build():
@@ -22,6 +24,14 @@ def needs_build():
         if os.path.getmtime(os.path.join(CSRC, name)) > t:
             return True
     if os.path.getmtime(os.path.join(HERE, "..", "include", "agx.h")) > t:
+        return True
+    for extra in (AG_LIB, BOUNDARY_TEST, DRIVER):
+        if not os.path.exists(extra):
+            return True
+    boundary = os.path.join(HERE, "..", "include", "alphagomoku_agx")
+    newest = max([os.path.getmtime(os.path.join(boundary, f)) for f in os.listdir(boundary)]
+                 + [os.path.getmtime(os.path.join(HERE, "..", "tests", "cpp", "boundary_main.cpp"))])
+    if newest > os.path.getmtime(BOUNDARY_TEST):
         return True
     return False
 
@@ -59,6 +69,18 @@ def build(force=False, verbose=True):
     # native C++ host driver over the C ABI (include/agx.hpp)
     cmd = [os.environ.get("CXX", "g++"), "-std=c++17", "-O2", "-o", DRIVER, os.path.join(CSRC, "selfplay_main.cpp"),
            "-L" + HERE, "-lagx", "-Wl,-rpath," + HERE]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    # the C++ boundary: plain host code (g++), no HIP types — a maintainer of the reference links it like any other library
+    cxx = os.environ.get("CXX", "g++")
+    cmd = [cxx, "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", "-o", AG_LIB, os.path.join(CSRC, "ag_classes.cpp"), "-L" + HERE, "-lagx",
+           "-Wl,-rpath," + HERE, "-lpthread"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    cmd = [cxx, "-std=c++17", "-O2", "-Wall", "-o", BOUNDARY_TEST, os.path.join(HERE, "..", "tests", "cpp", "boundary_main.cpp"), "-L" + HERE, "-lagx_ag",
+           "-lagx", "-Wl,-rpath," + HERE, "-lpthread"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -1,0 +1,1261 @@
+/*
+ * ag_classes.cpp — the reference-named C++ boundary (the headers under include/alphagomoku_agx) over the C ABI (include/agx.h).
+ * Plain host C++ (no HIP types): built by alphagomoku_amd/build.py into libagx_ag.so, linked against libagx.so.
+ * Reference lines each class follows are cited in the headers; error behaviour: a non-zero agx status becomes std::logic_error
+ * (invalid argument / state) or std::runtime_error (device failure), the exceptions the reference throws (NNEvaluator.cpp:149,185-187).
+ */
+#include "../../include/alphagomoku_agx/selfplay.hpp"
+#include "symmetry.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include <filesystem>
+#include <fstream>
+#include <iostream>
+#include <stdexcept>
+#include <thread>
+
+namespace
+{
+	void check(int status)
+	{
+		if (status == AGX_OK)
+			return;
+		const std::string msg = agx_last_error();
+		if (status == AGX_ERR_INVALID || status == AGX_ERR_STATE)
+			throw std::logic_error(msg);
+		throw std::runtime_error(msg);
+	}
+	int selector_id(const std::string &policy)
+	{ // EdgeSelector::create (EdgeSelector.cpp:680-711): the selectors GameGenerator::make_move can be configured with
+		if (policy == "best") return 0;
+		if (policy == "max_visit") return 1;
+		if (policy == "min_visit") return 2;
+		if (policy == "max_value") return 3;
+		if (policy == "max_policy") return 4;
+		if (policy == "lcb") return 5;
+		throw std::logic_error("Unknown selection policy '" + policy + "'");
+	}
+	int init_to_id(const std::string &s)
+	{ // EdgeSelector.cpp:1140-1165
+		if (s == "q_head") return 0;
+		if (s == "parent") return 1;
+		if (s == "draw") return 2;
+		if (s == "loss") return 3;
+		throw std::logic_error("Unknown init_to '" + s + "'");
+	}
+	int noise_id(const std::string &s)
+	{
+		if (s == "none") return 0;
+		if (s == "custom") return 1;
+		if (s == "dirichlet") return 2;
+		if (s == "gumbel") return 3;
+		throw std::logic_error("Unknown noise_type '" + s + "'");
+	}
+	uint64_t mix64(uint64_t z)
+	{
+		z += 0x9E3779B97F4A7C15ull;
+		z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+		z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+		return z ^ (z >> 31);
+	}
+}
+
+namespace ag
+{
+	std::string toString(GameRules rules)
+	{
+		static const char *names[] = { "FREESTYLE", "STANDARD", "RENJU", "CARO5", "CARO6" };
+		return names[static_cast<int>(rules)];
+	}
+	std::string toString(GameOutcome outcome)
+	{
+		static const char *names[] = { "UNKNOWN", "DRAW", "CROSS_WIN", "CIRCLE_WIN" };
+		return names[static_cast<int>(outcome)];
+	}
+	std::string TimedStat::toString() const
+	{
+		const double per = (m_total_count > 0) ? getTotalTime() / m_total_count : 0.0;
+		return m_name + " : " + std::to_string(getTotalTime()) + "s : " + std::to_string(m_total_count) + " : " + std::to_string(per * 1.0e6) + " us";
+	}
+
+	/* ------------------------------------------------ AGNetwork ------------------------------------------------ */
+	AGNetwork::AGNetwork(const GameConfig &gameOptions, const std::string &architecture, int blocks, int filters) :
+			game_config(gameOptions)
+	{
+		if (architecture != "ResnetPV" && architecture != "ResnetPVQ")
+			throw std::logic_error("AGNetwork: unknown architecture '" + architecture + "' (the device tower implements ResnetPV and ResnetPVQ)");
+		desc.rows = gameOptions.rows;
+		desc.cols = gameOptions.cols;
+		desc.blocks = blocks;
+		desc.filters = filters;
+		desc.in_channels = 32;
+		desc.value_hidden = std::min(256, 2 * filters);
+		desc.action_values = (architecture == "ResnetPVQ") ? 1 : 0;
+		create();
+	}
+	AGNetwork::~AGNetwork()
+	{
+		release();
+	}
+	void AGNetwork::create()
+	{
+		check(agx_net_create(&desc, &net));
+		if (!blob_copy.empty())
+			check(agx_net_load_weights(net, blob_copy.data(), blob_copy.size()));
+	}
+	void AGNetwork::release()
+	{
+		void **buffers[] = { &d_input, &d_policy, &d_value, &d_action_values };
+		for (void **p : buffers)
+		{
+			if (*p != nullptr)
+				agx_free(*p);
+			*p = nullptr;
+		}
+		if (net != nullptr)
+			agx_net_destroy(net);
+		net = nullptr;
+	}
+	std::string AGNetwork::getOutputConfig() const
+	{
+		return desc.action_values ? "pvq" : "pv";
+	}
+	std::string AGNetwork::name() const
+	{
+		return desc.action_values ? "ResnetPVQ" : "ResnetPV";
+	}
+	size_t AGNetwork::numberOfWeights() const
+	{
+		return agx_net_blob_floats(&desc);
+	}
+	void AGNetwork::loadWeights(const std::vector<float> &blob)
+	{
+		if (net == nullptr)
+			throw std::logic_error("AGNetwork::loadWeights() : the network has not been created");
+		check(agx_net_load_weights(net, blob.data(), blob.size()));
+		blob_copy = blob;
+	}
+	void AGNetwork::packInputData(int index, const uint32_t *features)
+	{
+		if (index < 0 || index >= batch_size)
+			throw std::logic_error("AGNetwork::packInputData() : index " + std::to_string(index) + " outside the batch of " + std::to_string(batch_size));
+		const int hw = desc.rows * desc.cols;
+		std::memcpy(input.data() + static_cast<size_t>(index) * hw, features, sizeof(uint32_t) * hw);
+	}
+	void AGNetwork::unpackOutput(int index, std::vector<float> &out_policy, std::vector<Value> &actionValues, Value &out_value, float &movesLeft) const
+	{ // NetworkDataPack::unpackPolicy / unpackValue / unpackActionValues (NetworkDataPack.cpp:199-236)
+		if (index < 0 || index >= batch_size)
+			throw std::logic_error("AGNetwork::unpackOutput() : index outside the batch");
+		const int hw = desc.rows * desc.cols;
+		out_policy.assign(policy.begin() + static_cast<size_t>(index) * hw, policy.begin() + static_cast<size_t>(index + 1) * hw);
+		actionValues.assign(hw, Value());
+		if (desc.action_values)
+			for (int i = 0; i < hw; i++)
+				actionValues[i] = Value(action_values[(static_cast<size_t>(index) * hw + i) * 2], action_values[(static_cast<size_t>(index) * hw + i) * 2 + 1]);
+		out_value = Value(value[3 * index], value[3 * index + 1]); // (win, draw) of the softmax over (win, draw, loss)
+		movesLeft = 0.0f;                                            // 'pv' / 'pvq' networks have no moves-left output
+	}
+	void AGNetwork::asyncForwardLaunch(int batch)
+	{
+		if (!isLoaded())
+			throw std::logic_error("AGNetwork::forward() : the network has not been loaded");
+		if (batch < 0 || batch > batch_size)
+			throw std::logic_error("AGNetwork::forward() : batch " + std::to_string(batch) + " exceeds the batch size " + std::to_string(batch_size));
+		const int hw = desc.rows * desc.cols;
+		check(agx_memcpy_h2d(d_input, input.data(), sizeof(uint32_t) * hw * batch));
+		if (desc.action_values)
+			check(agx_nn_forward_pvq(net, static_cast<const uint32_t*>(d_input), batch, static_cast<float*>(d_policy), static_cast<float*>(d_value),
+					static_cast<float*>(d_action_values), nullptr));
+		else
+			check(agx_nn_forward(net, static_cast<const uint32_t*>(d_input), batch, static_cast<float*>(d_policy), static_cast<float*>(d_value), nullptr));
+		launched = batch;
+	}
+	void AGNetwork::asyncForwardJoin()
+	{
+		const int hw = desc.rows * desc.cols;
+		check(agx_device_synchronize());
+		check(agx_memcpy_d2h(policy.data(), d_policy, sizeof(float) * hw * launched));
+		check(agx_memcpy_d2h(value.data(), d_value, sizeof(float) * 3 * launched));
+		if (desc.action_values)
+			check(agx_memcpy_d2h(action_values.data(), d_action_values, sizeof(float) * 2 * hw * launched));
+		launched = 0;
+	}
+	void AGNetwork::forward(int batch)
+	{
+		asyncForwardLaunch(batch);
+		asyncForwardJoin();
+	}
+	void AGNetwork::optimize(int)
+	{
+	}
+	void AGNetwork::convertToHalfFloats()
+	{
+	}
+	void AGNetwork::saveToFile(const std::string &path) const
+	{
+		if (blob_copy.empty())
+			throw std::logic_error("AGNetwork::saveToFile() : no weights loaded");
+		std::ofstream f(path, std::ofstream::binary);
+		if (!f.good())
+			throw std::runtime_error("AGNetwork::saveToFile() : cannot open '" + path + "'");
+		const uint64_t count = blob_copy.size();
+		f.write("AGXW", 4);
+		f.write(reinterpret_cast<const char*>(&desc), sizeof(desc));
+		f.write(reinterpret_cast<const char*>(&count), sizeof(count));
+		f.write(reinterpret_cast<const char*>(blob_copy.data()), sizeof(float) * count);
+	}
+	void AGNetwork::loadFromFile(const std::string &path)
+	{
+		std::ifstream f(path, std::ifstream::binary);
+		if (!f.good())
+			throw std::runtime_error("File '" + path + "' does not exist"); // FileLoader (file_util.cpp:58-60)
+		char magic[4];
+		uint64_t count = 0;
+		AgxNetDesc d;
+		f.read(magic, 4);
+		f.read(reinterpret_cast<char*>(&d), sizeof(d));
+		f.read(reinterpret_cast<char*>(&count), sizeof(count));
+		if (!f.good() || std::memcmp(magic, "AGXW", 4) != 0)
+			throw std::runtime_error("'" + path + "' is not a weight file of this library (MinML checkpoints cannot be imported: their format is not in the reference tree)");
+		std::vector<float> blob(count);
+		f.read(reinterpret_cast<char*>(blob.data()), sizeof(float) * count);
+		if (!f.good())
+			throw std::runtime_error("'" + path + "' is truncated");
+		release();
+		desc = d;
+		game_config.rows = d.rows;
+		game_config.cols = d.cols;
+		if (game_config.draw_after <= 0)
+			game_config.draw_after = d.rows * d.cols;
+		blob_copy.clear();
+		create();
+		loadWeights(blob);
+		if (batch_size > 0)
+		{
+			const int b = batch_size;
+			batch_size = 0;
+			setBatchSize(b);
+		}
+	}
+	void AGNetwork::unloadGraph()
+	{
+		release();
+	}
+	bool AGNetwork::isLoaded() const noexcept
+	{
+		return net != nullptr && !blob_copy.empty();
+	}
+	void AGNetwork::synchronize()
+	{
+		check(agx_device_synchronize());
+	}
+	void AGNetwork::moveTo(Device device)
+	{ // the device copy lives where it was created: re-create it on the target device
+		if (device.isCPU())
+			throw std::logic_error("AGNetwork::moveTo() : there is no CPU path");
+		const int b = batch_size;
+		release();
+		batch_size = 0;
+		check(agx_set_device(device.index()));
+		create();
+		if (b > 0)
+			setBatchSize(b);
+	}
+	int AGNetwork::getBatchSize() const noexcept
+	{
+		return batch_size;
+	}
+	void AGNetwork::setBatchSize(int batchSize)
+	{
+		if (batchSize <= 0)
+			throw std::logic_error("AGNetwork::setBatchSize() : batch size must be positive");
+		if (batchSize == batch_size && d_input != nullptr)
+			return;
+		void **buffers[] = { &d_input, &d_policy, &d_value, &d_action_values };
+		for (void **p : buffers)
+		{
+			if (*p != nullptr)
+				agx_free(*p);
+			*p = nullptr;
+		}
+		batch_size = batchSize;
+		const size_t hw = static_cast<size_t>(desc.rows) * desc.cols, n = batchSize;
+		input.assign(n * hw, 0u);
+		policy.assign(n * hw, 0.0f);
+		value.assign(n * 3, 0.0f);
+		action_values.assign(desc.action_values ? n * hw * 2 : 0, 0.0f);
+		check(agx_malloc(&d_input, sizeof(uint32_t) * n * hw));
+		check(agx_malloc(&d_policy, sizeof(float) * n * hw));
+		check(agx_malloc(&d_value, sizeof(float) * n * 3));
+		if (desc.action_values)
+			check(agx_malloc(&d_action_values, sizeof(float) * n * hw * 2));
+	}
+	GameConfig AGNetwork::getGameConfig() const noexcept
+	{
+		return game_config;
+	}
+	std::unique_ptr<AGNetwork> loadAGNetwork(const std::string &path)
+	{
+		std::unique_ptr<AGNetwork> result = std::make_unique<AGNetwork>();
+		result->loadFromFile(path);
+		return result;
+	}
+
+	NetworkLoader::NetworkLoader(const char *path) :
+			NetworkLoader(std::string(path))
+	{
+	}
+	NetworkLoader::NetworkLoader(const std::string &path) :
+			paths( { path })
+	{
+	}
+	NetworkLoader::NetworkLoader(const std::vector<std::string> &path) :
+			paths(path)
+	{
+	}
+	std::unique_ptr<AGNetwork> NetworkLoader::get(bool) const
+	{ // NetworkLoader.cpp:44-56
+		if (paths.empty())
+			return nullptr;
+		std::unique_ptr<AGNetwork> result = loadAGNetwork(paths.at(0));
+		if (paths.size() > 1)
+		{ // running average of the weights (ml::averageModelWeights(alpha, network, 1 - alpha, result))
+			std::vector<float> sum;
+			{
+				std::ifstream f(paths[0], std::ifstream::binary);
+				f.seekg(4 + sizeof(AgxNetDesc) + sizeof(uint64_t));
+				sum.resize(result->numberOfWeights());
+				f.read(reinterpret_cast<char*>(sum.data()), sizeof(float) * sum.size());
+			}
+			for (size_t i = 1; i < paths.size(); i++)
+			{
+				std::ifstream f(paths[i], std::ifstream::binary);
+				if (!f.good())
+					throw std::runtime_error("File '" + paths[i] + "' does not exist");
+				f.seekg(4 + sizeof(AgxNetDesc) + sizeof(uint64_t));
+				std::vector<float> w(sum.size());
+				f.read(reinterpret_cast<char*>(w.data()), sizeof(float) * w.size());
+				const float alpha = 1.0f / (i + 1);
+				for (size_t k = 0; k < sum.size(); k++)
+					sum[k] = alpha * w[k] + (1.0f - alpha) * sum[k];
+			}
+			result->loadWeights(sum);
+		}
+		return result;
+	}
+
+	/* ------------------------------------------------ NNEvaluator ------------------------------------------------ */
+	NNEvaluatorStats::NNEvaluatorStats() :
+			pack("pack   "), compute("compute"), unpack("unpack ")
+	{
+	}
+	std::string NNEvaluatorStats::toString() const
+	{
+		std::string result = "----NNEvaluator----\n";
+		result += "total samples = " + std::to_string(batch_sizes) + '\n';
+		result += pack.toString() + '\n' + compute.toString() + '\n' + unpack.toString() + '\n';
+		return result;
+	}
+	NNEvaluatorStats& NNEvaluatorStats::operator+=(const NNEvaluatorStats &other) noexcept
+	{
+		batch_sizes += other.batch_sizes;
+		pack += other.pack;
+		compute += other.compute;
+		unpack += other.unpack;
+		return *this;
+	}
+	NNEvaluatorStats& NNEvaluatorStats::operator/=(int i) noexcept
+	{
+		batch_sizes /= std::max(1, i);
+		return *this;
+	}
+
+	NNEvaluator::NNEvaluator(const DeviceConfig &cfg) :
+			config(cfg)
+	{
+		if (cfg.device.isCPU())
+			throw std::logic_error("NNEvaluator : the device engine has no CPU path, DeviceConfig::device must name a GPU");
+	}
+	bool NNEvaluator::isOnGPU() const noexcept
+	{
+		return true;
+	}
+	void NNEvaluator::clearStats() noexcept
+	{
+		stats = NNEvaluatorStats();
+	}
+	NNEvaluatorStats NNEvaluator::getStats() const noexcept
+	{
+		return stats;
+	}
+	bool NNEvaluator::isQueueFull() const noexcept
+	{ // NNEvaluator.cpp:99-102; a scheduled pool slice is a full launch by itself
+		return !waiting_slices.empty() || (network != nullptr && static_cast<int>(waiting_queue.size()) >= network->getBatchSize());
+	}
+	int NNEvaluator::getQueueSize() const noexcept
+	{
+		int result = static_cast<int>(waiting_queue.size());
+		for (const SliceData &s : waiting_slices)
+			result += s.positions;
+		return result;
+	}
+	void NNEvaluator::clearQueue() noexcept
+	{
+		waiting_queue.clear();
+		waiting_slices.clear();
+	}
+	void NNEvaluator::useSymmetries(bool b) noexcept
+	{
+		use_symmetries = b;
+	}
+	void NNEvaluator::loadGraph(const NetworkLoader &loader)
+	{ // NNEvaluator.cpp:121-129
+		network = loader.get();
+		if (network == nullptr)
+			throw std::logic_error("NNEvaluator::loadGraph() : the loader holds no network");
+		get_network().optimize(2);
+		get_network().moveTo(config.device);
+		// host-side staging for externally owned tasks only (pool slices never leave the device): DeviceConfig::batch_size beyond 1024
+		// positions is a slicing rule for the pool, not a staging size
+		get_network().setBatchSize(std::max(1, std::min(config.batch_size, 1024)));
+		get_network().convertToHalfFloats();
+		get_network().forward(1);
+	}
+	void NNEvaluator::unloadGraph()
+	{
+		get_network().unloadGraph();
+	}
+	void NNEvaluator::addToQueue(SearchTask &task)
+	{ // NNEvaluator.cpp:134-141; the reference draws randInt(8) from a time-seeded generator, here a counter-based hash
+		if (use_symmetries)
+			waiting_queue.push_back( { &task, static_cast<int>(mix64(0x5DEECE66Dull ^ symmetry_counter++) >> 61) });
+		else
+			waiting_queue.push_back( { &task, 0 });
+	}
+	void NNEvaluator::addToQueue(SearchTask &task, int symmetry)
+	{
+		if (symmetry < 0 || symmetry >= 8)
+			throw std::logic_error("NNEvaluator::addToQueue() : symmetry must be in [0, 8)");
+		waiting_queue.push_back( { &task, symmetry });
+	}
+	void NNEvaluator::addToQueue(AgxEngine *engine, int group, int n_groups, int max_positions, void *stream, bool *ready)
+	{
+		SliceData s;
+		s.engine = engine;
+		s.group = group;
+		s.n_groups = n_groups;
+		s.positions = max_positions;
+		s.stream = stream;
+		s.ready_flag = ready;
+		waiting_slices.push_back(s);
+	}
+	double NNEvaluator::evaluateGraph()
+	{ // NNEvaluator.cpp:147-181
+		if (!get_network().isLoaded())
+			throw std::logic_error("graph is empty - the network has not been loaded");
+		const auto t0 = std::chrono::steady_clock::now();
+		uint64_t samples = 0;
+		while (!waiting_queue.empty() || !waiting_slices.empty())
+		{
+			samples += std::min<size_t>(waiting_queue.size(), get_network().getBatchSize());
+			asyncEvaluateGraphLaunch();
+			asyncEvaluateGraphJoin();
+		}
+		const double seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+		return (samples > 0) ? seconds / samples : 0.0;
+	}
+	double NNEvaluator::asyncEvaluateGraphLaunch()
+	{ // NNEvaluator.cpp:182-206
+		if (!get_network().isLoaded())
+			throw std::logic_error("graph is empty - the network has not been loaded");
+		if (!in_progress_queue.empty() || !in_progress_slices.empty())
+			throw std::logic_error("some tasks are already being processed");
+		// pool slices: the batch is the slice's device-side queue, the launch goes onto the slice's stream behind its solver kernel
+		in_progress_slices.swap(waiting_slices);
+		for (const SliceData &s : in_progress_slices)
+			check(agx_engine_evaluate_group(s.engine, get_network().handle(), s.group, s.n_groups, s.stream));
+		// host-side tasks
+		const int batch = std::min(static_cast<int>(waiting_queue.size()), get_network().getBatchSize());
+		if (batch > 0)
+		{
+			in_progress_queue.assign(waiting_queue.begin(), waiting_queue.begin() + batch);
+			waiting_queue.erase(waiting_queue.begin(), waiting_queue.begin() + batch);
+			pack_to_network();
+			get_network().asyncForwardLaunch(batch);
+		}
+		stats.compute.startTimer();
+		return 0.0; // no host-side estimate of the end time: nothing on the host waits for it
+	}
+	void NNEvaluator::asyncEvaluateGraphJoin()
+	{ // NNEvaluator.cpp:207-228
+		if (!get_network().isLoaded())
+			throw std::logic_error("graph is empty - the network has not been loaded");
+		if (in_progress_queue.empty() && in_progress_slices.empty())
+			return;
+		const int batch = static_cast<int>(in_progress_queue.size());
+		if (batch > 0)
+		{
+			get_network().asyncForwardJoin();
+			stats.batch_sizes += batch;
+			unpack_from_network();
+			in_progress_queue.clear();
+		}
+		// a slice's expand kernel is enqueued on the same stream as its network launch, so "joined" needs no host wait
+		for (const SliceData &s : in_progress_slices)
+			if (s.ready_flag != nullptr)
+				*s.ready_flag = true;
+		stats.compute.stopTimer(static_cast<int>(in_progress_slices.size()) + (batch > 0 ? 1 : 0));
+		in_progress_slices.clear();
+	}
+	AGNetwork& NNEvaluator::get_network()
+	{
+		if (network == nullptr)
+			throw std::logic_error("NNEvaluator::get_network() : network has not been initialized");
+		return *network;
+	}
+	const AGNetwork& NNEvaluator::get_network() const
+	{
+		if (network == nullptr)
+			throw std::logic_error("NNEvaluator::get_network() : network has not been initialized");
+		return *network;
+	}
+	void NNEvaluator::pack_to_network()
+	{ // NNEvaluator.cpp:244-262: features.augment(symmetry) + packInputData
+		stats.pack.startTimer();
+		const GameConfig cfg = get_network().getGameConfig();
+		const int n = cfg.rows, hw = cfg.rows * cfg.cols;
+		std::vector<uint32_t> tmp(hw);
+		for (size_t i = 0; i < in_progress_queue.size(); i++)
+		{
+			const TaskData td = in_progress_queue[i];
+			const std::vector<uint32_t> &f = td.ptr->getFeatures();
+			if (static_cast<int>(f.size()) != hw)
+				throw std::logic_error("NNEvaluator : task of another board size");
+			for (int r = 0; r < n; r++)
+				for (int c = 0; c < n; c++)
+				{
+					int sr, sc;
+					agx::symmetry_source(td.symmetry, n, r, c, sr, sc);
+					tmp[r * n + c] = agx::shuffle_feature_directions(f[sr * n + sc], td.symmetry);
+				}
+			get_network().packInputData(static_cast<int>(i), tmp.data());
+		}
+		stats.pack.stopTimer(static_cast<int>(in_progress_queue.size()));
+	}
+	void NNEvaluator::unpack_from_network()
+	{ // NNEvaluator.cpp:263-286
+		stats.unpack.startTimer();
+		const GameConfig cfg = get_network().getGameConfig();
+		const int n = cfg.rows;
+		std::vector<float> policy;
+		std::vector<Value> action_values;
+		Value value;
+		float moves_left = 0.0f;
+		for (size_t i = 0; i < in_progress_queue.size(); i++)
+		{
+			const TaskData td = in_progress_queue[i];
+			get_network().unpackOutput(static_cast<int>(i), policy, action_values, value, moves_left);
+			const int inv = agx::inverse_symmetry(td.symmetry);
+			for (int r = 0; r < n; r++)
+				for (int c = 0; c < n; c++)
+				{
+					int sr, sc;
+					agx::symmetry_source(inv, n, r, c, sr, sc);
+					td.ptr->getPolicy()[r * n + c] = policy[sr * n + sc];
+					td.ptr->getActionValues()[r * n + c] = action_values[sr * n + sc];
+				}
+			td.ptr->setValue(value);
+			if (td.ptr->getScore().isUnproven())
+				td.ptr->setMovesLeft(moves_left);
+			td.ptr->markAsProcessedByNetwork();
+		}
+		stats.unpack.stopTimer(static_cast<int>(in_progress_queue.size()));
+	}
+
+	/* ------------------------------------------------ Search / Tree ------------------------------------------------ */
+	SearchStats::SearchStats() :
+			select("select  "), solve("solve   "), schedule("schedule"), generate("generate"), expand("expand  "), backup("backup  ")
+	{
+	}
+	std::string SearchStats::toString() const
+	{
+		std::string result = "----SearchStats----\n";
+		result += "nb_duplicate_nodes     = " + std::to_string(nb_duplicate_nodes) + '\n';
+		result += "nb_information_leaks   = " + std::to_string(nb_information_leaks) + '\n';
+		result += "nb_wasted_expansions   = " + std::to_string(nb_wasted_expansions) + '\n';
+		result += "nb_proven_states       = " + std::to_string(nb_proven_states) + '\n';
+		result += "nb_network_evaluations = " + std::to_string(nb_network_evaluations) + '\n';
+		result += "nb_node_count          = " + std::to_string(nb_node_count) + '\n';
+		result += select.toString() + '\n' + solve.toString() + '\n' + expand.toString() + '\n' + backup.toString() + '\n';
+		return result;
+	}
+	SearchStats& SearchStats::operator+=(const SearchStats &other) noexcept
+	{
+		select += other.select;
+		solve += other.solve;
+		schedule += other.schedule;
+		generate += other.generate;
+		expand += other.expand;
+		backup += other.backup;
+		nb_duplicate_nodes += other.nb_duplicate_nodes;
+		nb_information_leaks += other.nb_information_leaks;
+		nb_wasted_expansions += other.nb_wasted_expansions;
+		nb_proven_states += other.nb_proven_states;
+		nb_network_evaluations += other.nb_network_evaluations;
+		nb_node_count += other.nb_node_count;
+		return *this;
+	}
+	SearchStats& SearchStats::operator/=(int i) noexcept
+	{
+		i = std::max(1, i);
+		nb_duplicate_nodes /= i;
+		nb_information_leaks /= i;
+		nb_wasted_expansions /= i;
+		nb_proven_states /= i;
+		nb_network_evaluations /= i;
+		nb_node_count /= i;
+		return *this;
+	}
+	double SearchStats::getTotalTime() const noexcept
+	{
+		return select.getTotalTime() + solve.getTotalTime() + schedule.getTotalTime() + generate.getTotalTime() + expand.getTotalTime() + backup.getTotalTime();
+	}
+	std::string NodeCacheStats::toString() const
+	{
+		return "----NodeCacheStats----\nstored nodes (peak per game) = " + std::to_string(stored_nodes) + "\nstored edges (peak per game) = " + std::to_string(stored_edges) + '\n';
+	}
+	NodeCacheStats& NodeCacheStats::operator+=(const NodeCacheStats &other) noexcept
+	{
+		stored_nodes = std::max(stored_nodes, other.stored_nodes);
+		stored_edges = std::max(stored_edges, other.stored_edges);
+		return *this;
+	}
+	NodeCacheStats& NodeCacheStats::operator/=(int) noexcept
+	{
+		return *this;
+	}
+
+	GamePool::GamePool(const GameConfig &gameOptions, const SearchConfig &searchOptions, const EdgeSelectorConfig &finalSelector, int games, int maxSimulations,
+			bool useSymmetries, const std::string &networkOutputs) :
+			game_config(gameOptions), games(games), batch(searchOptions.max_batch_size)
+	{
+		if (gameOptions.rows != gameOptions.cols)
+			throw std::logic_error("GamePool : only square boards are supported");
+		AgxEngineConfig c;
+		check(agx_engine_default_config(&c));
+		c.rules = static_cast<int>(gameOptions.rules);
+		c.board_size = gameOptions.rows;
+		c.draw_after = gameOptions.draw_after;
+		c.n_games = games;
+		c.max_batch_size = searchOptions.max_batch_size;
+		c.max_simulations = maxSimulations;
+		const EdgeSelectorConfig &sel = searchOptions.mcts_config.edge_selector_config;
+		if (sel.policy != "puct")
+			throw std::logic_error("GamePool : the device search implements the 'puct' selector (EdgeSelectorConfig::policy = '" + sel.policy + "')");
+		c.exploration_constant = sel.exploration_constant;
+		c.exploration_scaling = sel.exploration_scaling;
+		c.init_to = init_to_id(sel.init_to);
+		c.noise_type = noise_id(sel.noise_type);
+		c.noise_weight = sel.noise_weight;
+		c.information_leak_threshold = searchOptions.tree_config.information_leak_threshold;
+		c.node_capacity = searchOptions.tree_config.node_bucket_size;
+		c.edge_capacity = searchOptions.tree_config.edge_bucket_size;
+		c.policy_expansion_threshold = searchOptions.mcts_config.policy_expansion_threshold;
+		c.policy_temperature = searchOptions.mcts_config.policy_temperature;
+		c.max_children = (searchOptions.mcts_config.max_children == std::numeric_limits<int>::max()) ? 0 : searchOptions.mcts_config.max_children;
+		c.tss_max_positions = searchOptions.tss_config.max_positions;
+		c.tss_table_entries = static_cast<uint64_t>(searchOptions.tss_config.hash_table_size);
+		c.final_selector = selector_id(finalSelector.policy);
+		c.use_symmetries = useSymmetries ? 1 : 0;
+		c.action_values = (networkOutputs == "pvq") ? 1 : 0;
+		c.record_format = 2;            // samples leave the device in dataset format 201
+		c.solver_yield_fraction = 0.75f; // pacing only: per-game results do not depend on it
+		check(agx_engine_create(&c, &engine));
+	}
+	GamePool::~GamePool()
+	{
+		agx_engine_destroy(engine);
+	}
+	void GamePool::begin(const std::vector<uint16_t> &openings)
+	{
+		if (openings.empty() || openings.size() % AGX_OPENING_CAP != 0)
+			throw std::logic_error("GamePool::begin() : openings must hold a positive multiple of AGX_OPENING_CAP words");
+		check(agx_engine_begin(engine, openings.data(), static_cast<int>(openings.size() / AGX_OPENING_CAP), nullptr));
+		check(agx_device_synchronize());
+	}
+	void GamePool::addOpenings(const std::vector<uint16_t> &openings)
+	{
+		check(agx_engine_add_openings(engine, openings.data(), static_cast<int>(openings.size() / AGX_OPENING_CAP)));
+	}
+	AgxEngineStats GamePool::getStats() const
+	{
+		AgxEngineStats s;
+		check(agx_device_synchronize());
+		check(agx_engine_stats(engine, &s));
+		return s;
+	}
+
+	Tree::Tree(GamePool &pool, int group, int n_groups, void *stream) :
+			pool(pool), group(group), n_groups(n_groups), stream(stream)
+	{
+		const int per = (pool.numberOfGames() + n_groups - 1) / n_groups;
+		first_game = group * per;
+		game_count = std::min(per, pool.numberOfGames() - first_game);
+		if (game_count <= 0)
+			throw std::logic_error("Tree : slice " + std::to_string(group) + " of " + std::to_string(n_groups) + " is empty");
+	}
+	int64_t Tree::getMemory() const noexcept
+	{
+		return 0;
+	}
+	namespace
+	{
+		AgxGameInfo game_info(const GamePool &pool, int game, std::vector<AgxEdgeView> *edges = nullptr, std::vector<uint8_t> *board = nullptr)
+		{
+			AgxGameInfo info;
+			std::vector<AgxEdgeView> e(400);
+			std::vector<uint8_t> b(400);
+			check(agx_engine_game_info(pool.handle(), game, &info, b.data(), edges ? e.data() : nullptr, 400));
+			if (edges != nullptr)
+				edges->assign(e.begin(), e.begin() + info.root_edges);
+			if (board != nullptr)
+				*board = b;
+			return info;
+		}
+	}
+	int Tree::getSimulationCount(int game) const
+	{
+		return game_info(pool, first_game + game).root_visits;
+	}
+	bool Tree::isRootProven(int game) const
+	{
+		return Score::from_short(static_cast<uint16_t>(game_info(pool, first_game + game).root_score)).isProven();
+	}
+	int Tree::getNodeCount(int game) const
+	{
+		return game_info(pool, first_game + game).n_nodes;
+	}
+	int Tree::getMoveNumber(int game) const
+	{
+		return game_info(pool, first_game + game).n_moves;
+	}
+	Value Tree::getEvaluation(int game) const
+	{
+		const AgxGameInfo info = game_info(pool, first_game + game);
+		return Value(info.root_win, info.root_draw);
+	}
+	Sign Tree::getSignToMove(int game) const
+	{
+		return static_cast<Sign>(game_info(pool, first_game + game).sign_to_move);
+	}
+	std::vector<Sign> Tree::getBoard(int game) const
+	{
+		std::vector<uint8_t> b;
+		game_info(pool, first_game + game, nullptr, &b);
+		const int hw = pool.getGameConfig().rows * pool.getGameConfig().cols;
+		std::vector<Sign> result(hw);
+		for (int i = 0; i < hw; i++)
+			result[i] = static_cast<Sign>(b[i]);
+		return result;
+	}
+	Node Tree::getInfo(int game, const std::vector<Move> &moves) const
+	{
+		if (!moves.empty())
+			throw std::logic_error("Tree::getInfo() : only the root (an empty move list) can be read from the device");
+		std::vector<AgxEdgeView> views;
+		const AgxGameInfo info = game_info(pool, first_game + game, &views);
+		std::vector<Edge> edges;
+		for (const AgxEdgeView &v : views)
+			edges.emplace_back(v);
+		return Node(std::move(edges), Value(info.root_win, info.root_draw), Score::from_short(static_cast<uint16_t>(info.root_score)), info.root_visits,
+				static_cast<Sign>(info.sign_to_move));
+	}
+	NodeCacheStats Tree::getNodeCacheStats() const noexcept
+	{
+		NodeCacheStats result;
+		try
+		{
+			const AgxEngineStats s = pool.getStats();
+			result.stored_nodes = s.peak_nodes;
+			result.stored_edges = s.peak_edges;
+		} catch (std::exception&)
+		{
+		}
+		return result;
+	}
+
+	Search::Search(GamePool &pool, int group, int n_groups, void *stream) :
+			pool(pool), group(group), n_groups(n_groups), stream(stream), batch_size(pool.getBatchSize())
+	{
+	}
+	void Search::clearStats() noexcept
+	{
+		stats = SearchStats();
+	}
+	SearchStats Search::getStats() const noexcept
+	{
+		SearchStats result = stats;
+		try
+		{
+			const AgxEngineStats s = pool.getStats();
+			result.nb_duplicate_nodes = s.duplicate_selections;
+			result.nb_information_leaks = s.information_leaks;
+			result.nb_wasted_expansions = s.wasted_expansions;
+			result.nb_proven_states = s.proven_edge_visits;
+			result.nb_network_evaluations = s.network_evaluations;
+			result.nb_node_count = s.evaluated_nodes;
+		} catch (std::exception&)
+		{
+		}
+		return result;
+	}
+	void Search::select(Tree &tree, int)
+	{ // the simulation budget is the pool's (SelfplayConfig::constraints.max_simulations, fixed at creation)
+		if (&tree.pool != &pool || tree.group != group)
+			throw std::logic_error("Search::select() : the tree belongs to another slice");
+		stats.select.startTimer();
+		check(agx_engine_select_group(pool.handle(), group, n_groups, stream));
+		stats.select.stopTimer();
+	}
+	void Search::solve(double)
+	{
+		stats.solve.startTimer();
+		check(agx_engine_solve_group(pool.handle(), group, n_groups, stream));
+		stats.solve.stopTimer();
+		scheduled = false;
+	}
+	void Search::scheduleToNN(NNEvaluator &evaluator)
+	{ // Search.cpp:184-199: the solve kernel has compacted the leaves that need the network into the slice's device-side queue
+		stats.schedule.startTimer();
+		const int per = (pool.numberOfGames() + n_groups - 1) / n_groups;
+		tasks_ready = false;
+		evaluator.addToQueue(pool.handle(), group, n_groups, per * batch_size, stream, &tasks_ready);
+		scheduled = true;
+		stats.schedule.stopTimer();
+	}
+	bool Search::areTasksReady() const noexcept
+	{
+		return tasks_ready;
+	}
+	void Search::generateEdges(const Tree&)
+	{ // first pass of the expand kernel (UnifiedGenerator::generate per leaf); nothing to enqueue separately
+		if (!tasks_ready)
+			throw std::logic_error("Search::generateEdges() : the tasks have not been evaluated yet");
+	}
+	void Search::expand(Tree&)
+	{ // one launch: generateEdges for all leaves, then Tree::expand for all, then Tree::backup for all (the order of Search.cpp:206-232)
+		if (!tasks_ready)
+			throw std::logic_error("Search::expand() : the tasks have not been evaluated yet");
+		stats.expand.startTimer();
+		check(agx_engine_expand_group(pool.handle(), group, n_groups, stream));
+		stats.expand.stopTimer();
+	}
+	void Search::backup(Tree&)
+	{ // second half of the launch enqueued by expand()
+	}
+	void Search::cleanup(Tree&)
+	{ // cancelVirtualLoss of abandoned tasks: every device step completes its batch, nothing is left to cancel
+	}
+	void Search::setBatchSize(int batchSize)
+	{
+		if (batchSize != batch_size)
+			throw std::logic_error("Search::setBatchSize() : the pool was created with max_batch_size " + std::to_string(batch_size));
+	}
+	int Search::getBatchSize() const noexcept
+	{
+		return batch_size;
+	}
+
+	/* ------------------------------------------------ dataset ------------------------------------------------ */
+	std::string GameDataBufferStats::toString() const
+	{ // GameDataBuffer.cpp:33-44
+		std::string result;
+		result += "----GameBufferStats----\n";
+		result += "games   = " + std::to_string(games) + '\n';
+		result += "samples = " + std::to_string(samples) + '\n';
+		result += "cross   = " + std::to_string(cross_win) + '\n';
+		result += "draws   = " + std::to_string(draws) + '\n';
+		result += "circle  = " + std::to_string(circle_win) + '\n';
+		result += "avg len = " + std::to_string(static_cast<float>(game_length) / std::max(1, games)) + '\n';
+		return result;
+	}
+	GameDataBuffer::GameDataBuffer(GameConfig cfg) :
+			game_config(cfg)
+	{
+		check(agx_game_buffer_create(static_cast<int>(cfg.rules), cfg.rows, cfg.cols, cfg.draw_after, &buffer));
+	}
+	GameDataBuffer::~GameDataBuffer()
+	{
+		agx_game_buffer_destroy(buffer);
+	}
+	const GameConfig& GameDataBuffer::getConfig() const noexcept
+	{
+		return game_config;
+	}
+	void GameDataBuffer::clear() noexcept
+	{
+		agx_game_buffer_clear(buffer);
+	}
+	int GameDataBuffer::numberOfGames() const noexcept
+	{
+		return getStats().games;
+	}
+	int GameDataBuffer::numberOfSamples() const noexcept
+	{
+		return getStats().samples;
+	}
+	std::vector<uint8_t> GameDataBuffer::getGameData(int index) const
+	{
+		size_t size = 0;
+		check(agx_game_buffer_game(buffer, index, nullptr, 0, &size));
+		std::vector<uint8_t> result(size);
+		check(agx_game_buffer_game(buffer, index, result.data(), result.size(), &size));
+		return result;
+	}
+	void GameDataBuffer::save(const std::string &path) const
+	{
+		check(agx_game_buffer_save(buffer, path.c_str(), 1));
+	}
+	GameDataBufferStats GameDataBuffer::getStats() const noexcept
+	{
+		AgxGameBufferStats s;
+		GameDataBufferStats result;
+		if (agx_game_buffer_stats(buffer, &s) == AGX_OK)
+		{
+			result.games = s.games;
+			result.samples = s.samples;
+			result.cross_win = s.cross_win;
+			result.draws = s.draws;
+			result.circle_win = s.circle_win;
+			result.game_length = s.game_length;
+		}
+		return result;
+	}
+
+	/* ------------------------------------------------ GameGenerator ------------------------------------------------ */
+	GameGenerator::GameGenerator(const GameConfig&, const SelfplayConfig &selfplayOptions, GeneratorManager &manager, NNEvaluator &evaluator, GamePool &pool,
+			int group, int n_groups, void *stream) :
+			manager(manager), nn_evaluator(evaluator), pool(pool), tree(pool, group, n_groups, stream), search(pool, group, n_groups, stream),
+			selfplay_config(selfplayOptions), group(group), n_groups(n_groups), stream(stream)
+	{
+	}
+	void GameGenerator::clearStats()
+	{
+		search.clearStats();
+	}
+	NodeCacheStats GameGenerator::getCacheStats() const noexcept
+	{
+		return tree.getNodeCacheStats();
+	}
+	SearchStats GameGenerator::getSearchStats() const noexcept
+	{
+		return search.getStats();
+	}
+	GameGenerator::Status GameGenerator::generate()
+	{ // GameGenerator.cpp:46-121 for every game of the slice at once
+		if (state == GAME_NOT_STARTED || state == PREPARE_OPENING)
+		{ // beginGame / loadOpening / prepare_search happen on the device when a game takes its opening (k_begin, k_restart); the thread
+		  // keeps the opening list ahead of the games (GeneratorThread::run)
+			state = GAMEPLAY_SELECT_SOLVE_EVALUATE;
+			prepare_search();
+		}
+		if (state == GAMEPLAY_SELECT_SOLVE_EVALUATE)
+		{
+			search.select(tree, selfplay_config.constraints.max_simulations);
+			search.solve();
+			search.scheduleToNN(nn_evaluator);
+			state = GAMEPLAY_EXPAND_AND_BACKUP;
+			return GameGenerator::OK;
+		}
+		if (state == GAMEPLAY_EXPAND_AND_BACKUP)
+		{
+			if (!search.areTasksReady())
+				return GameGenerator::TASKS_NOT_READY;
+			search.generateEdges(tree);
+			search.expand(tree);
+			search.backup(tree);
+			// get_simulations_for_move, the move rule, make_move, the end-of-game hand-over and prepare_search (GameGenerator.cpp:97-118) are
+			// decided per game on the device; finished games reach manager.addToBuffer through GeneratorThread::collectGames
+			make_move();
+			state = GAMEPLAY_SELECT_SOLVE_EVALUATE;
+			steps++;
+		}
+		return GameGenerator::OK;
+	}
+	void GameGenerator::make_move()
+	{ // GameGenerator.cpp:145-173 for the games whose root has its visits: final selector, sample, Game::makeMove
+		check(agx_engine_advance_group(pool.handle(), group, n_groups, stream));
+	}
+	void GameGenerator::prepare_search()
+	{ // GameGenerator.cpp:174-185: cleanup + Tree::setBoard + fresh selector / generator — part of the advance kernel on the device
+		search.cleanup(tree);
+	}
+
+	/* ------------------------------------------------ GeneratorThread ------------------------------------------------ */
+	GeneratorThread::GeneratorThread(GeneratorManager &manager, const GameConfig &gameOptions, const SelfplayConfig &selfplayOptions, int index) :
+			is_running(true), manager(manager), nn_evaluator(selfplayOptions.device_config.at(index)), game_config(gameOptions), selfplay_config(selfplayOptions),
+			index(index)
+	{
+		nn_evaluator.useSymmetries(selfplayOptions.use_symmetries);
+	}
+	GeneratorThread::~GeneratorThread()
+	{
+		if (generator_future.valid())
+			generator_future.wait();
+	}
+	void GeneratorThread::start()
+	{
+		is_running.store(true);
+		generator_future = std::async(std::launch::async, [this]()
+		{
+			try
+			{
+				this->run();
+			}
+			catch(std::exception &e)
+			{
+				std::cout << "GeneratorThread::start() threw " << e.what() << '\n';
+				exit(-1);
+			}
+		});
+	}
+	void GeneratorThread::stop()
+	{
+		is_running.store(false);
+		if (generator_future.valid())
+			generator_future.wait();
+	}
+	bool GeneratorThread::isFinished() const noexcept
+	{
+		if (generator_future.valid())
+			return generator_future.wait_for(std::chrono::milliseconds(0)) == std::future_status::ready;
+		return true;
+	}
+	void GeneratorThread::clearStats() noexcept
+	{
+		nn_evaluator.clearStats();
+	}
+	void GeneratorThread::setWorkingDirectory(const std::string &path)
+	{
+		working_directory = path;
+	}
+	NNEvaluatorStats GeneratorThread::getEvaluatorStats() const noexcept
+	{
+		std::lock_guard<std::mutex> lock(stats_mutex);
+		NNEvaluatorStats result = nn_evaluator.getStats();
+		result.batch_sizes += last_search_stats.nb_network_evaluations;
+		return result;
+	}
+	NodeCacheStats GeneratorThread::getCacheStats() const noexcept
+	{
+		std::lock_guard<std::mutex> lock(stats_mutex);
+		return last_cache_stats;
+	}
+	SearchStats GeneratorThread::getSearchStats() const noexcept
+	{
+		std::lock_guard<std::mutex> lock(stats_mutex);
+		return last_search_stats;
+	}
+	void GeneratorThread::collectGames()
+	{
+		manager.addToBuffer(pool->handle());
+		const SearchStats s = generators.front()->getSearchStats();
+		const NodeCacheStats c = generators.front()->getCacheStats();
+		std::lock_guard<std::mutex> lock(stats_mutex);
+		last_search_stats = s;
+		last_cache_stats = c;
+	}
+	void GeneratorThread::setup()
+	{
+		const DeviceConfig &device = selfplay_config.device_config.at(index);
+		check(agx_set_device(device.device.index()));
+		nn_evaluator.loadGraph(manager.getNetworkLoader());
+		const int games = selfplay_config.games_per_thread;
+		pool = std::make_unique<GamePool>(game_config, selfplay_config.search_config, selfplay_config.final_selector, games,
+				selfplay_config.constraints.max_simulations, selfplay_config.use_symmetries, nn_evaluator.get_network().getOutputConfig());
+		// slices: as many network launches as the queue capacity (games x max_batch_size) needs at DeviceConfig::batch_size positions each
+		const int slots = games * selfplay_config.search_config.max_batch_size;
+		int n_groups = (device.batch_size > 0) ? (slots + device.batch_size - 1) / device.batch_size : 1;
+		n_groups = std::max(1, std::min(std::min(16, games), n_groups));
+		for (int g = 0; g < n_groups; g++)
+		{
+			void *s = nullptr;
+			check(agx_stream_create(&s));
+			streams.push_back(s);
+			generators.push_back(std::make_unique<GameGenerator>(game_config, selfplay_config, manager, nn_evaluator, *pool, g, n_groups, s));
+		}
+	}
+	void GeneratorThread::teardown()
+	{
+		generators.clear();
+		for (void *s : streams)
+			agx_stream_destroy(s);
+		streams.clear();
+		pool.reset();
+	}
+	void GeneratorThread::run()
+	{ // GeneratorManager.cpp:124-141
+		setup();
+		const int games = selfplay_config.games_per_thread;
+		const int n = game_config.rows;
+		uint32_t next_seed = static_cast<uint32_t>(index) * 1000003u;
+		auto make_openings = [&](int count)
+		{ // OpeningGenerator (selfplay/OpeningGenerator.cpp:21-78): random openings that the solver cannot prove and the network finds balanced
+			std::vector<uint16_t> out(static_cast<size_t>(count) * AGX_OPENING_CAP, 0);
+			if (!selfplay_config.use_opening)
+				return out; // empty boards
+			AgxEngineConfig c;
+			check(agx_engine_default_config(&c));
+			c.rules = static_cast<int>(game_config.rules);
+			c.board_size = n;
+			c.draw_after = game_config.draw_after;
+			c.n_games = 64; // candidates evaluated together
+			c.max_batch_size = 1;
+			c.tss_max_positions = 1000; // OpeningGenerator.cpp:61
+			c.tss_table_entries = 1u << 18;
+			c.node_capacity = 16;
+			c.edge_capacity = 1024;
+			c.action_values = (nn_evaluator.get_network().getOutputConfig() == "pvq") ? 1 : 0;
+			AgxEngine *helper = nullptr;
+			check(agx_engine_create(&c, &helper));
+			const int st = agx_engine_generate_openings(helper, nn_evaluator.get_network().handle(), count, next_seed, out.data(), nullptr);
+			agx_engine_destroy(helper);
+			check(st);
+			next_seed += 16u * static_cast<uint32_t>(count);
+			return out;
+		};
+		int n_openings = games + games / 2;
+		pool->begin(make_openings(n_openings));
+
+		uint64_t iterations = 0;
+		while (is_running.load() and not manager.hasEnoughGames())
+		{
+			for (size_t i = 0; i < generators.size(); i++)
+			{
+				const GameGenerator::Status status = generators[i]->generate();
+				if (nn_evaluator.isQueueFull() or status == GameGenerator::TASKS_NOT_READY)
+				{
+					nn_evaluator.asyncEvaluateGraphJoin();
+					nn_evaluator.asyncEvaluateGraphLaunch();
+				}
+			}
+			if (++iterations % 256 == 0)
+			{ // hand the finished games over and keep the opening list ahead of the games
+				collectGames();
+				const AgxEngineStats st = pool->getStats();
+				if (st.first_error != 0)
+					throw std::runtime_error("the device engine stopped a game with error " + std::to_string(st.first_error));
+				if (st.openings_taken + games / 2 > n_openings)
+				{
+					pool->addOpenings(make_openings(games));
+					n_openings += games;
+				}
+			}
+		}
+		nn_evaluator.asyncEvaluateGraphJoin();
+		check(agx_device_synchronize());
+		collectGames();
+		nn_evaluator.unloadGraph();
+		teardown();
+	}
+
+	/* ------------------------------------------------ GeneratorManager ------------------------------------------------ */
+	GeneratorManager::GeneratorManager(const GameConfig &gameOptions, const SelfplayConfig &selfplayOptions) :
+			generators(selfplayOptions.device_config.size()), game_buffer(gameOptions)
+	{
+		for (size_t i = 0; i < generators.size(); i++)
+			generators[i] = std::make_unique<GeneratorThread>(*this, gameOptions, selfplayOptions, static_cast<int>(i));
+	}
+	void GeneratorManager::setWorkingDirectory(const std::string &path)
+	{
+		working_directory = path;
+		for (size_t i = 0; i < generators.size(); i++)
+			generators[i]->setWorkingDirectory(path);
+	}
+	int GeneratorManager::addToBuffer(AgxEngine *engine)
+	{ // GeneratorManager.cpp:160-164
+		std::lock_guard<std::mutex> lock(buffer_mutex);
+		int added = 0;
+		check(agx_game_buffer_collect(game_buffer.handle(), engine, &added));
+		return added;
+	}
+	const GameDataBuffer& GeneratorManager::getGameBuffer() const noexcept
+	{
+		return game_buffer;
+	}
+	GameDataBuffer& GeneratorManager::getGameBuffer() noexcept
+	{
+		return game_buffer;
+	}
+	const NetworkLoader& GeneratorManager::getNetworkLoader() const noexcept
+	{
+		return network_loader;
+	}
+	bool GeneratorManager::hasEnoughGames() const noexcept
+	{
+		std::lock_guard<std::mutex> lock(buffer_mutex);
+		return game_buffer.numberOfGames() >= games_to_generate;
+	}
+	void GeneratorManager::generate(const NetworkLoader &loader, int numberOfGames)
+	{ // GeneratorManager.cpp:182-218 (the 1 s polling sleep is 20 ms here; SIGINT handling stays with the caller)
+		games_to_generate = numberOfGames;
+		network_loader = loader;
+		for (size_t i = 0; i < generators.size(); i++)
+		{
+			generators[i]->clearStats();
+			generators[i]->start();
+		}
+		while (true)
+		{
+			std::this_thread::sleep_for(std::chrono::milliseconds(20));
+			bool is_ready = true;
+			for (size_t i = 0; i < generators.size(); i++)
+				is_ready &= generators[i]->isFinished();
+			if (is_ready)
+				break;
+		}
+	}
+	void GeneratorManager::printStats()
+	{ // GeneratorManager.cpp:219-240
+		std::cout << "Played games = " << game_buffer.numberOfGames() << "/" << games_to_generate << '\n';
+		std::cout << game_buffer.getStats().toString() << '\n';
+		NNEvaluatorStats evaluator_stats;
+		SearchStats search_stats;
+		NodeCacheStats cache_stats;
+		for (size_t i = 0; i < generators.size(); i++)
+		{
+			evaluator_stats += generators[i]->getEvaluatorStats();
+			search_stats += generators[i]->getSearchStats();
+			cache_stats += generators[i]->getCacheStats();
+		}
+		evaluator_stats /= static_cast<int>(generators.size());
+		search_stats /= static_cast<int>(generators.size());
+		cache_stats /= static_cast<int>(generators.size());
+		std::cout << evaluator_stats.toString();
+		std::cout << search_stats.toString();
+		std::cout << cache_stats.toString() << std::endl;
+	}
+	void GeneratorManager::saveState(bool saveBuffer)
+	{ // GeneratorManager.cpp:241-262; games in flight live in device trees and are not serialised: a restart begins them again
+		if (working_directory.empty())
+			return;
+		const std::string path = working_directory + "/saved_state/";
+		if (!std::filesystem::exists(path))
+			std::filesystem::create_directory(path);
+		if (saveBuffer)
+		{
+			std::cout << "Saving buffer" << std::endl;
+			game_buffer.save(path + "buffer.bin");
+		}
+	}
+	void GeneratorManager::loadState()
+	{
+		if (working_directory.empty())
+			return;
+		const std::string path = working_directory + "/saved_state/";
+		if (!std::filesystem::exists(path))
+			std::cout << "No saved state was found" << std::endl;
+	}
+} /* namespace ag */

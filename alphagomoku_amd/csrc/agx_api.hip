@@ -42,6 +42,12 @@ int agx_set_device(int device)
 	AGX_HIP_CHECK(hipSetDevice(device));
 	return AGX_OK;
 }
+int agx_device_count(int *count)
+{
+	AGX_REQUIRE(count != nullptr, AGX_ERR_INVALID, "agx_device_count: null argument");
+	AGX_HIP_CHECK(hipGetDeviceCount(count));
+	return AGX_OK;
+}
 int agx_malloc(void **d_ptr, size_t bytes)
 {
 	AGX_REQUIRE(d_ptr != nullptr, AGX_ERR_INVALID, "agx_malloc: null output pointer");

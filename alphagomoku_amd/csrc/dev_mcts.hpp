@@ -15,6 +15,7 @@
 
 #include "dev_solver.hpp"
 #include "root_noise.hpp"
+#include "symmetry.hpp"
 
 namespace agx
 {
@@ -114,42 +115,7 @@ namespace agx
 			return (fabsf(dw) + fabsf(dd)) > E.leak_threshold;
 		}
 
-		/* utils/augmentations.hpp:62-216 (square boards): source cell of destination (r, c) under symmetry s, and the inverse map */
-		__device__ __forceinline__ void symmetry_source(int s, int n, int r, int c, int &sr, int &sc)
-		{
-			const int last = n - 1;
-			switch (s)
-			{
-				default: sr = r; sc = c; break;              // IDENTITY
-				case 1: sr = last - r; sc = c; break;        // FLIP_VERTICALLY
-				case 2: sr = r; sc = last - c; break;        // FLIP_HORIZONTALLY
-				case 3: sr = last - r; sc = last - c; break; // ROTATE_180
-				case 4: sr = c; sc = r; break;               // FLIP_DIAGONALLY
-				case 5: sr = last - c; sc = last - r; break; // FLIP_ANTIDIAGONALLY
-				case 6: sr = c; sc = last - r; break;        // ROTATE_90
-				case 7: sr = last - c; sc = r; break;        // ROTATE_270
-			}
-		}
-		__device__ __forceinline__ int inverse_symmetry(int s) { return (s == 6) ? 7 : ((s == 7) ? 6 : s); }
-		/* NNInputFeatures::augment (NNInputFeatures.cpp:33-50,114-154): the per-direction feature bits follow the board symmetry */
-		__device__ __forceinline__ uint32_t shuffle_feature_directions(uint32_t data, int s)
-		{
-			int d0, d1, d2, d3;
-			switch (s)
-			{
-				case 1: case 2: d0 = 0; d1 = 1; d2 = 3; d3 = 2; break;
-				case 4: case 5: d0 = 1; d1 = 0; d2 = 2; d3 = 3; break;
-				case 6: case 7: d0 = 1; d1 = 0; d2 = 3; d3 = 2; break;
-				default: return data;
-			}
-			const uint32_t mask = (1u << 8) | (1u << 12) | (1u << 20) | (1u << 24);
-			uint32_t result = data & 0xF00F00FFu;
-			result |= ((data >> d0) & mask) << 0;
-			result |= ((data >> d1) & mask) << 1;
-			result |= ((data >> d2) & mask) << 2;
-			result |= ((data >> d3) & mask) << 3;
-			return result;
-		}
+		/* the symmetry maps themselves: symmetry.hpp (agx::symmetry_source / inverse_symmetry / shuffle_feature_directions) */
 		__device__ __forceinline__ unsigned long long symmetry_mix(unsigned long long z)
 		{
 			z += 0x9E3779B97F4A7C15ull;

@@ -1915,7 +1915,7 @@ int agx_engine_create(const AgxEngineConfig *cfg, AgxEngine **out)
 	d.record_edge_cap = cfg->record_edge_capacity > 0 ? cfg->record_edge_capacity : d.record_cap * 64;
 	d.record_format = cfg->record_format;
 	d.sample_cap = cfg->record_sample_capacity > 0 ? cfg->record_sample_capacity
-			: static_cast<int>(std::min<size_t>(static_cast<size_t>(d.record_cap) * 400, 0x7FFFFFF0u));
+			: static_cast<int>(std::min<size_t>(static_cast<size_t>(d.record_cap) * (16 + 6 * static_cast<size_t>(d.hw) + 2), 0x7FFFFFF0u)); // every cell an entry
 	d.game_end_cap = cfg->game_end_capacity > 0 ? cfg->game_end_capacity : 2 * d.n_games;
 
 	HostTables tables;
@@ -2083,10 +2083,11 @@ static void launch_solve(const EngineDev &d, int count, hipStream_t s)
 		hipLaunchKernelGGL((k_solve<false, 0>), grid, block, 0, s, d);
 }
 
-int agx_engine_select_solve_group(AgxEngine *e, int group, int n_groups, void *stream)
+/* Search::select for every game of the group (Search.cpp:117-158) */
+int agx_engine_select_group(AgxEngine *e, int group, int n_groups, void *stream)
 {
-	AGX_REQUIRE(e != nullptr, AGX_ERR_INVALID, "agx_engine_select_solve: null engine");
-	AGX_REQUIRE(e->begun, AGX_ERR_STATE, "agx_engine_select_solve: agx_engine_begin has not been called");
+	AGX_REQUIRE(e != nullptr, AGX_ERR_INVALID, "agx_engine_select: null engine");
+	AGX_REQUIRE(e->begun, AGX_ERR_STATE, "agx_engine_select: agx_engine_begin has not been called");
 	EngineDev d;
 	int count = 0;
 	const int st = group_range(e, group, n_groups, d, count);
@@ -2098,12 +2099,31 @@ int agx_engine_select_solve_group(AgxEngine *e, int group, int n_groups, void *s
 		KernelTimer t(e, s, 0);
 		hipLaunchKernelGGL(k_select, dim3(count), dim3(64), 0, s, d);
 	}
+	AGX_HIP_CHECK(hipGetLastError());
+	return AGX_OK;
+}
+/* Search::solve + Search::scheduleToNN (Search.cpp:159-199): the threat solver on the selected leaves, then the device-side queue */
+int agx_engine_solve_group(AgxEngine *e, int group, int n_groups, void *stream)
+{
+	AGX_REQUIRE(e != nullptr, AGX_ERR_INVALID, "agx_engine_solve: null engine");
+	AGX_REQUIRE(e->begun, AGX_ERR_STATE, "agx_engine_solve: agx_engine_begin has not been called");
+	EngineDev d;
+	int count = 0;
+	const int st = group_range(e, group, n_groups, d, count);
+	if (st != AGX_OK)
+		return st;
+	hipStream_t s = static_cast<hipStream_t>(stream);
 	{
 		KernelTimer t(e, s, 1);
 		launch_solve(d, count, s);
 	}
 	AGX_HIP_CHECK(hipGetLastError());
 	return AGX_OK;
+}
+int agx_engine_select_solve_group(AgxEngine *e, int group, int n_groups, void *stream)
+{
+	const int st = agx_engine_select_group(e, group, n_groups, stream);
+	return (st != AGX_OK) ? st : agx_engine_solve_group(e, group, n_groups, stream);
 }
 
 /* match mode, both players' trees in one launch per stage: about half of the trees search at any time, so one launch over all of
@@ -2200,21 +2220,38 @@ int agx_engine_evaluate_group(AgxEngine *e, AgxNet *net, int group, int n_groups
 			d.nn_value, stream);
 }
 
-int agx_engine_expand_backup_group(AgxEngine *e, int group, int n_groups, void *stream)
+/* Search::generateEdges + expand + backup for every game of the group (Search.cpp:206-232), incl. the move rule's decision */
+int agx_engine_expand_group(AgxEngine *e, int group, int n_groups, void *stream)
 {
-	AGX_REQUIRE(e != nullptr, AGX_ERR_INVALID, "agx_engine_expand_backup: null engine");
-	AGX_REQUIRE(e->begun, AGX_ERR_STATE, "agx_engine_expand_backup: agx_engine_begin has not been called");
+	AGX_REQUIRE(e != nullptr, AGX_ERR_INVALID, "agx_engine_expand: null engine");
+	AGX_REQUIRE(e->begun, AGX_ERR_STATE, "agx_engine_expand: agx_engine_begin has not been called");
 	EngineDev d;
 	int count = 0;
 	const int st = group_range(e, group, n_groups, d, count);
 	if (st != AGX_OK)
 		return st;
-	AGX_REQUIRE(!d.match_mode || n_groups == 2, AGX_ERR_INVALID, "agx_engine_expand_backup: a match-mode engine is stepped as two groups (first players, second players)");
+	AGX_REQUIRE(!d.match_mode || n_groups == 2, AGX_ERR_INVALID, "agx_engine_expand: a match-mode engine is stepped as two groups (first players, second players)");
 	hipStream_t s = static_cast<hipStream_t>(stream);
 	{
 		KernelTimer t(e, s, 2);
 		hipLaunchKernelGGL(k_expand, dim3(count), dim3(64), 0, s, d);
 	}
+	AGX_HIP_CHECK(hipGetLastError());
+	return AGX_OK;
+}
+/* GameGenerator::make_move + prepare_search for the games whose search is complete (GameGenerator.cpp:145-185), then the next openings
+ * for the games that ended */
+int agx_engine_advance_group(AgxEngine *e, int group, int n_groups, void *stream)
+{
+	AGX_REQUIRE(e != nullptr, AGX_ERR_INVALID, "agx_engine_advance: null engine");
+	AGX_REQUIRE(e->begun, AGX_ERR_STATE, "agx_engine_advance: agx_engine_begin has not been called");
+	EngineDev d;
+	int count = 0;
+	const int st = group_range(e, group, n_groups, d, count);
+	if (st != AGX_OK)
+		return st;
+	AGX_REQUIRE(!d.match_mode || n_groups == 2, AGX_ERR_INVALID, "agx_engine_advance: a match-mode engine is stepped as two groups (first players, second players)");
+	hipStream_t s = static_cast<hipStream_t>(stream);
 	{
 		KernelTimer t(e, s, 3);
 		hipLaunchKernelGGL(k_advance, dim3(count), dim3(256), 0, s, d);
@@ -2237,6 +2274,11 @@ int agx_engine_expand_backup_group(AgxEngine *e, int group, int n_groups, void *
 	}
 	AGX_HIP_CHECK(hipGetLastError());
 	return AGX_OK;
+}
+int agx_engine_expand_backup_group(AgxEngine *e, int group, int n_groups, void *stream)
+{
+	const int st = agx_engine_expand_group(e, group, n_groups, stream);
+	return (st != AGX_OK) ? st : agx_engine_advance_group(e, group, n_groups, stream);
 }
 
 int agx_engine_step_group(AgxEngine *e, AgxNet *net, int group, int n_groups, void *stream)

@@ -66,3 +66,14 @@ def make_openings(n, count, seed0=0, rules=0):
         check(lib.agx_make_opening(rules, n, seed0 + i, buf.ctypes.data_as(ctypes.c_void_p)))
         out.append([int(x) for x in buf[1:1 + int(buf[0])]])
     return out
+
+
+def save_weights(path, desc, blob):
+    """the weight container ag::AGNetwork::loadFromFile reads (include/alphagomoku_agx/networks.hpp): "AGXW", AgxNetDesc (7 ints), u64 count, fp32 blob"""
+    import struct
+    with open(path, "wb") as f:
+        f.write(b"AGXW")
+        f.write(struct.pack("<7i", desc["rows"], desc["cols"], desc["blocks"], desc["filters"], desc["in_channels"], desc["value_hidden"],
+                            desc.get("action_values", 0)))
+        f.write(struct.pack("<Q", blob.size))
+        f.write(np.ascontiguousarray(blob, dtype=np.float32).tobytes())

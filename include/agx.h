@@ -42,6 +42,7 @@ const char* agx_last_error(void);
 int agx_version(void);
 /* Selects the HIP device for the calling thread (one engine per GPU). */
 int agx_set_device(int device);
+int agx_device_count(int* count);
 
 /* ------------------------------------------------------------------------------------------------
  * Policy/value network (replaces AGNetwork::forward / asyncForwardLaunch+Join over ml::Graph,
@@ -169,7 +170,7 @@ typedef struct AgxEngineConfig
 	                                     (SearchDataStorage_v201::loadFrom + serialize, dataset/SearchDataStorage.cpp:326-374,410-419:
 	                                     16-byte header + 6 bytes per visited / proven cell) — a quarter of the bytes to keep and copy;
 	                                     3 = both.  Finished games are always reported (AgxGameEnd). */
-	int record_sample_capacity;       /* bytes of the format-201 sample pool, 0 = 400 per record */
+	int record_sample_capacity;       /* bytes of the format-201 sample pool, 0 = room for an entry on every cell of every record (capped at 2 GiB) */
 	int game_end_capacity;            /* finished-game records kept on the device, 0 = 2 * n_games */
 } AgxEngineConfig;
 
@@ -290,8 +291,15 @@ int agx_engine_step(AgxEngine* engine, AgxNet* net, void* stream);
  * (at most 16 groups).  Results per game do not depend on the grouping.  A network may be shared by the slices: the single-plane
  * kernels keep their scratch per stream. */
 int agx_engine_select_solve_group(AgxEngine* engine, int group, int n_groups, void* stream);
+/* the two halves of select_solve separately: Search::select, then Search::solve + scheduleToNN (Search.hpp:78-82) */
+int agx_engine_select_group(AgxEngine* engine, int group, int n_groups, void* stream);
+int agx_engine_solve_group(AgxEngine* engine, int group, int n_groups, void* stream);
 int agx_engine_evaluate_group(AgxEngine* engine, AgxNet* net, int group, int n_groups, void* stream);
 int agx_engine_expand_backup_group(AgxEngine* engine, int group, int n_groups, void* stream);
+/* the two halves of expand_backup separately: Search::generateEdges + expand + backup (Search.hpp:84-86), then GameGenerator::make_move +
+ * prepare_search for the games whose search is complete and the next openings for the games that ended (GameGenerator.cpp:97-118,145-185) */
+int agx_engine_expand_group(AgxEngine* engine, int group, int n_groups, void* stream);
+int agx_engine_advance_group(AgxEngine* engine, int group, int n_groups, void* stream);
 int agx_engine_step_group(AgxEngine* engine, AgxNet* net, int group, int n_groups, void* stream);
 int agx_stream_create(void** out_stream);
 int agx_stream_destroy(void* stream);

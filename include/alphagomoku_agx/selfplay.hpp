@@ -1,0 +1,171 @@
+/*
+ * alphagomoku_agx/selfplay.hpp — ag::GameDataBuffer, ag::GameGenerator, ag::GeneratorThread, ag::GeneratorManager: the objects
+ * training_launcher reaches through TrainingManager::generateGames (src/selfplay/TrainingManager.cpp:194-214):
+ *
+ *     GeneratorManager manager(gameConfig, selfplayConfig);        GeneratorManager.hpp:96-121
+ *     manager.setWorkingDirectory(path);  manager.loadState();
+ *     manager.generate(NetworkLoader(path_to_network), games);     one GeneratorThread per selfplayConfig.device_config[i]
+ *     manager.saveState(...);   manager.getGameBuffer().save(...)
+ *
+ * Same names, arguments, state machine and threading as the reference (src/selfplay/GeneratorManager.cpp:28-218,
+ * src/selfplay/GameGenerator.cpp:46-185): one host thread (std::async) per device; everything reachable from it is single-threaded; the
+ * threads meet only in GeneratorManager::addToBuffer / hasEnoughGames under buffer_mutex.  What differs is the granularity: one
+ * GameGenerator stands for a SLICE of the thread's game pool (games_per_thread games split into DeviceConfig::batch_size-sized network
+ * launches), so `generators` holds a few slices instead of games_per_thread single games, and GeneratorThread::run's loop — generate();
+ * if the evaluator's queue is full or tasks are not ready: Join, Launch — pipelines the slices on their streams exactly as the
+ * reference pipelines host search against the network (NNEvaluator.cpp:182-228).
+ */
+#ifndef ALPHAGOMOKU_AGX_SELFPLAY_HPP_
+#define ALPHAGOMOKU_AGX_SELFPLAY_HPP_
+
+#include "configs.hpp"
+#include "networks.hpp"
+#include "search.hpp"
+#include "../agx.h"
+
+#include <atomic>
+#include <future>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace ag
+{
+	struct GameDataBufferStats
+	{ // dataset/GameDataBuffer.hpp
+			int games = 0, samples = 0, cross_win = 0, draws = 0, circle_win = 0, game_length = 0;
+			std::string toString() const;
+	};
+	/* GameDataBuffer (src/dataset/GameDataBuffer.cpp) for dataset format 201, producing side: games arrive as the bytes of
+	 * GameDataStorage::serialize, their samples quantised on the device. */
+	class GameDataBuffer
+	{
+			AgxGameBuffer *buffer = nullptr;
+			GameConfig game_config;
+		public:
+			GameDataBuffer(GameConfig cfg);
+			GameDataBuffer(const GameDataBuffer&) = delete;
+			GameDataBuffer& operator=(const GameDataBuffer&) = delete;
+			~GameDataBuffer();
+			const GameConfig& getConfig() const noexcept;
+			void clear() noexcept;
+			int numberOfGames() const noexcept;
+			int numberOfSamples() const noexcept;
+			std::vector<uint8_t> getGameData(int index) const; // GameDataStorage::serialize bytes
+			void save(const std::string &path) const;
+			GameDataBufferStats getStats() const noexcept;
+			AgxGameBuffer* handle() const noexcept
+			{
+				return buffer;
+			}
+	};
+
+	class GeneratorManager;
+
+	class GameGenerator
+	{ // selfplay/GameGenerator.hpp:25-66
+		private:
+			enum GameState
+			{
+				GAME_NOT_STARTED, PREPARE_OPENING, GAMEPLAY_SELECT_SOLVE_EVALUATE, GAMEPLAY_EXPAND_AND_BACKUP
+			};
+			GeneratorManager &manager;
+			NNEvaluator &nn_evaluator;
+			GamePool &pool;
+			Tree tree;
+			Search search;
+			GameState state = GAME_NOT_STARTED;
+			SelfplayConfig selfplay_config;
+			int group, n_groups;
+			void *stream;
+			uint64_t steps = 0;
+		public:
+			enum Status
+			{
+				OK, TASKS_NOT_READY
+			};
+			/* slice `group` of `n_groups` of the thread's pool, driven on `stream` */
+			GameGenerator(const GameConfig &gameOptions, const SelfplayConfig &selfplayOptions, GeneratorManager &manager, NNEvaluator &evaluator, GamePool &pool,
+					int group, int n_groups, void *stream);
+
+			void clearStats();
+			NodeCacheStats getCacheStats() const noexcept;
+			SearchStats getSearchStats() const noexcept;
+
+			Status generate();
+		private:
+			void make_move();
+			void prepare_search();
+	};
+
+	class GeneratorThread
+	{ // selfplay/GeneratorManager.hpp:53-79
+		private:
+			std::string working_directory;
+			std::future<void> generator_future;
+			std::atomic<bool> is_running;
+
+			GeneratorManager &manager;
+			NNEvaluator nn_evaluator;
+			GameConfig game_config;
+			SelfplayConfig selfplay_config;
+			int index;
+			std::unique_ptr<GamePool> pool;
+			std::vector<void*> streams;
+			std::vector<std::unique_ptr<GameGenerator>> generators;
+			mutable std::mutex stats_mutex;
+			SearchStats last_search_stats;
+			NodeCacheStats last_cache_stats;
+		public:
+			GeneratorThread(GeneratorManager &manager, const GameConfig &gameOptions, const SelfplayConfig &selfplayOptions, int index);
+			~GeneratorThread();
+			void start();
+			void stop();
+			bool isFinished() const noexcept;
+			void clearStats() noexcept;
+			void setWorkingDirectory(const std::string &path);
+			NNEvaluatorStats getEvaluatorStats() const noexcept;
+			NodeCacheStats getCacheStats() const noexcept;
+			SearchStats getSearchStats() const noexcept;
+			/* hands the samples and finished games of this thread's pool to the manager's buffer (GeneratorManager::addToBuffer) */
+			void collectGames();
+		private:
+			void run();
+			void setup();
+			void teardown();
+	};
+
+	class GeneratorManager
+	{ // selfplay/GeneratorManager.hpp:81-121
+		private:
+			mutable std::mutex buffer_mutex;
+			std::vector<std::unique_ptr<GeneratorThread>> generators;
+			GameDataBuffer game_buffer;
+
+			int games_to_generate = 0;
+			std::string working_directory;
+			NetworkLoader network_loader;
+		public:
+			GeneratorManager(const GameConfig &gameOptions, const SelfplayConfig &selfplayOptions);
+
+			void setWorkingDirectory(const std::string &path);
+			/* the device-resident counterpart of addToBuffer(const GameDataStorage&): drains `engine`'s record pools into the buffer under
+			 * buffer_mutex; returns the number of games added */
+			int addToBuffer(AgxEngine *engine);
+
+			const GameDataBuffer& getGameBuffer() const noexcept;
+			GameDataBuffer& getGameBuffer() noexcept;
+			const NetworkLoader& getNetworkLoader() const noexcept;
+
+			void generate(const NetworkLoader &loader, int numberOfGames);
+			bool hasEnoughGames() const noexcept;
+
+			void printStats();
+
+			void saveState(bool saveBuffer);
+			void loadState();
+	};
+} /* namespace ag */
+
+#endif
