@@ -68,7 +68,7 @@ def build(force=False, verbose=True):
     subprocess.check_call(cmd)
     # native C++ host driver over the C ABI (include/agx.hpp)
     cmd = [os.environ.get("CXX", "g++"), "-std=c++17", "-O2", "-o", DRIVER, os.path.join(CSRC, "selfplay_main.cpp"),
-           "-L" + HERE, "-lagx", "-Wl,-rpath," + HERE]
+           "-L" + HERE, "-lagx", "-Wl,-rpath," + HERE, "-lpthread"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

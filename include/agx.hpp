@@ -3,11 +3,12 @@
  *
  * Same names, argument meaning and error behaviour as the reference classes it stands in for:
  *   agx::AGNetwork      <- ag::AGNetwork   (include/alphagomoku/networks/AGNetwork.hpp:60-98): loadWeights / forward / setBatchSize-free
- *   agx::NNEvaluator    <- ag::NNEvaluator (include/alphagomoku/search/monte_carlo/NNEvaluator.hpp:61-77): evaluateGraph over the engine's queue
  *   agx::GeneratorPool  <- one ag::GeneratorThread with its GameGenerators (src/selfplay/GeneratorManager.cpp:124-141,
  *                          src/selfplay/GameGenerator.cpp:46-121): generate() = one select/solve/evaluate/expand/backup/move step
  * Errors surface as std::runtime_error / std::logic_error exactly where the reference throws (NNEvaluator.cpp:149,185-187).
- * Header-only; link with -lagx.
+ * Header-only convenience layer (used by csrc/selfplay_main.cpp); link with -lagx.  The compiled, reference-NAMED classes — ag::NNEvaluator,
+ * ag::Search, ag::Tree, ag::GameGenerator, ag::GeneratorThread, ag::GeneratorManager, ag::GameDataBuffer — live in
+ * include/alphagomoku_agx/ (libagx_ag.so).
  */
 #ifndef AGX_HPP_
 #define AGX_HPP_
@@ -128,6 +129,7 @@ namespace agx
 			bool use_symmetries = false;         // SelfplayConfig::use_symmetries -> NNEvaluator::useSymmetries
 			std::string network_outputs = "pv";  // AGNetwork::getOutputConfig of the network that will evaluate: "pv" or "pvq"
 			std::string final_selector = "best"; // SelfplayConfig::final_selector.policy
+			int record_format = 1;               // AgxEngineConfig::record_format: 1 root-edge snapshots, 2 format-201 samples, 3 both
 			SearchConfig search_config;
 	};
 
@@ -167,6 +169,7 @@ namespace agx
 				c.final_selector = final_selector_id(selfplay.final_selector);
 				c.use_symmetries = selfplay.use_symmetries ? 1 : 0;
 				c.action_values = (selfplay.network_outputs == "pvq") ? 1 : 0;
+				c.record_format = selfplay.record_format;
 				if (game.rows != game.cols)
 					throw std::logic_error("GeneratorPool: only square boards are supported");
 				check(agx_engine_create(&c, &m_engine));

@@ -198,7 +198,7 @@ def _play_and_compare(olib, rules, games, batch, sims, max_steps, evaluator, tab
                                   final_selector=final_selector, use_symmetries=use_symmetries, action_values=action_values,
                                   noise_type=noise_type if noise_weight > 0 else 0, noise_weight=noise_weight,
                                   exploration_scaling=exploration_scaling, max_children=max_children, policy_temperature=policy_temperature,
-                                  record_format=record_format)
+                                  record_format=record_format, record_edge_capacity=games * HW * HW)   # a root edge per empty cell at worst
     pool = selfplay.GeneratorPool(cfg)
     ocfg = ol.default_search_config(max_batch_size=batch, max_simulations=sims, table_entries=table_entries, final_selector=final_selector,
                                     use_symmetries=use_symmetries, noise_type=noise_type if noise_weight > 0 else 0, noise_weight=noise_weight)
