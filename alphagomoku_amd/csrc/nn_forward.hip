@@ -39,6 +39,16 @@
 #include <cmath>
 #include <cstdlib>
 
+#ifndef AGX_NN_ROW_STATIONARY
+#define AGX_NN_ROW_STATIONARY 1 // 0: the tap-major k-loop for every board (A/B builds)
+#endif
+#ifndef AGX_NN_SCHED_GROUPS
+#define AGX_NN_SCHED_GROUPS 2
+#endif
+#ifndef AGX_NN_AHEAD
+#define AGX_NN_AHEAD 3 // activation fragments in flight per wave in the row-stationary k-loop
+#endif
+
 namespace
 {
 	typedef _Float16 half_t;
@@ -68,6 +78,35 @@ namespace
 			float *q;             // action values out: float[slots][HW][2] = (win, draw) per cell, null = head not evaluated
 			half4 *skip;          // single-plane variant only: residual inputs in accumulator layout, [workgroup][wave][MT][NTW][lane]
 	};
+
+#ifdef AGX_NN_PROFILE
+	// profile builds only: shader cycles per phase, waves 0 and 4 of every workgroup
+	__device__ unsigned long long g_nn_prof[2][16];
+	struct NnStamp
+	{
+			unsigned long long last;
+			bool on;
+			int row;
+			__device__ NnStamp(int wave, int lane) :
+					last(clock64()), on(lane == 0 && (wave & 3) == 0), row(wave >> 2)
+			{
+			}
+			__device__ void mark(int k)
+			{
+				const unsigned long long now = clock64();
+				if (on)
+					atomicAdd(&g_nn_prof[row][k], now - last);
+				last = now;
+			}
+	};
+#define AGX_NN_MARK(K) stamp.mark(K)
+#define AGX_NN_STAMP_PARAM , NnStamp &stamp
+#define AGX_NN_STAMP_ARG , stamp
+#else
+#define AGX_NN_MARK(K) do { } while (0)
+#define AGX_NN_STAMP_PARAM
+#define AGX_NN_STAMP_ARG
+#endif
 
 	template<int F, int ROWS, int COLS>
 	struct Geometry
@@ -106,7 +145,112 @@ namespace
 	 * src, dst: activation planes; if SKIP the residual input is read from (and the result written to) dst.
 	 */
 	template<int F, int ROWS, int COLS>
-	__device__ __forceinline__ void conv3x3_mac(const char *src, const half8 *__restrict__ wpk, int wave, int lane,
+	__device__ __forceinline__ void conv3x3_rows_stage(const char *src, const half8 *__restrict__ wnext, int kc, int dxi, int index_base, int q4,
+			int my_tiles, int lane, const half8 (&a_cur)[3][Geometry<F, ROWS, COLS>::MT], half8 (&a_next)[3][Geometry<F, ROWS, COLS>::MT],
+			floatx4 (&acc)[Geometry<F, ROWS, COLS>::MT][Geometry<F, ROWS, COLS>::NTW])
+	{
+		typedef Geometry<F, ROWS, COLS> G;
+		// the next stage's 3 * MT weight fragments: contiguous for this wave (pack_conv_rows), one scalar base + small offsets
+#pragma unroll
+		for (int dyi = 0; dyi < 3; dyi++)
+#pragma unroll
+			for (int i = 0; i < G::MT; i++)
+				a_next[dyi][i] = wnext[(dyi * G::MT + i) * 64 + lane];
+		const int index0 = index_base + (dxi - 1);
+		const int swz0 = (index0 / G::PPR) % G::CH; // invariant over rows: 16 positions == whole bank rows
+		const char *src0 = src + index0 * G::CH * 16 + (((kc * 4 + q4) ^ swz0) * 16);
+		// input rows j = -1 .. NTW, each fragment used by its own three taps only: a window of AHEAD fragments in flight
+		constexpr int AHEAD = AGX_NN_AHEAD;
+		half8 b[AHEAD];
+#pragma unroll
+		for (int u = 0; u < AHEAD - 1; u++)
+			b[u] = *reinterpret_cast<const half8*>(src0 + (u - 1) * (16 * G::CH * 16));
+#pragma unroll
+		for (int j = -1; j <= G::NTW; j++)
+		{
+			const int jn = j + AHEAD - 1; // the row requested now
+			if (jn <= G::NTW)
+				b[(jn + 1) % AHEAD] = *reinterpret_cast<const half8*>(src0 + ((jn <= my_tiles) ? jn : 0) * (16 * G::CH * 16));
+#pragma unroll
+			for (int dyi = 0; dyi < 3; dyi++)
+			{
+				const int o = j - (dyi - 1); // output row fed by input row j through the tap dy = dyi - 1
+				if (o >= 0 && o < G::NTW && o < my_tiles)
+				{
+#pragma unroll
+					for (int i = 0; i < G::MT; i++)
+						acc[i][o] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_cur[dyi][i], b[(j + 1) % AHEAD], acc[i][o], 0, 0, 0);
+				}
+			}
+#if AGX_NN_SCHED_GROUPS == 1
+			// one ds_read (0x100) per 3 * MT MFMAs (0x008), in this order
+			__builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+			__builtin_amdgcn_sched_group_barrier(0x008, 3 * G::MT, 0);
+#elif AGX_NN_SCHED_GROUPS == 2
+			// nothing crosses a row boundary: the fragment requested in this turn is the one used AHEAD - 1 turns later, so the wait in
+			// front of a turn's MFMAs leaves the younger requests in flight (left to itself the scheduler sinks every request to just
+			// before its use and a wave running alone on its SIMD stalls on each one)
+			__builtin_amdgcn_sched_barrier(0);
+#endif
+		}
+	}
+
+	/*
+	 * The k-loop of a 3x3 convolution when a 16-position tile IS a board row (row stride S = 16, i.e. 15-column boards).
+	 *
+	 * The straightforward loop (conv3x3_mac_taps) walks the 9 taps and reads, per tap and 32-channel chunk, one activation
+	 * fragment per output tile from LDS: every fragment feeds only MT MFMAs (8 KB of ds_read per 16 MFMAs per wave).  Here the loop is
+	 * input-row stationary: for a 32-channel chunk and a column shift dx the fragment of INPUT row j (shifted by dx) is read once and
+	 * multiplied by the three taps (dy = -1, 0, +1) of that column, accumulating into OUTPUT rows j + 1, j, j - 1.  A wave that owns 8
+	 * output rows reads 10 input rows x 3 shifts = 30 fragments per chunk instead of 72: LDS traffic / 2.4, the same MFMAs.  Weight
+	 * fragments are packed in consumption order (pack_conv_rows: stage = (chunk, dx), then channel group, dy, tile), so a stage's
+	 * fragments are 3 * MT consecutive KB behind one scalar base.
+	 */
+	template<int F, int ROWS, int COLS, bool ZERO = true>
+	__device__ __forceinline__ void conv3x3_mac_rows(const char *src, const half8 *__restrict__ wpk, int wave, int lane,
+			floatx4 (&acc)[Geometry<F, ROWS, COLS>::MT][Geometry<F, ROWS, COLS>::NTW])
+	{
+		typedef Geometry<F, ROWS, COLS> G;
+		static_assert(G::S == 16, "a position tile must be a board row");
+		const int r = lane & 15;
+		const int q4 = lane >> 4;
+		const int mg = wave & 3;
+		const int n0 = (wave >> 2) * G::NTW;
+		const int my_tiles = (wave >> 2) ? (G::NT - G::NTW) : G::NTW;
+
+		if (ZERO)
+		{
+#pragma unroll
+			for (int i = 0; i < G::MT; i++)
+#pragma unroll
+				for (int n = 0; n < G::NTW; n++)
+					acc[i][n] = floatx4 { 0.0f, 0.0f, 0.0f, 0.0f };
+		}
+
+		constexpr int STAGES = 3 * G::KC;               // stage = (32-channel chunk kc, column shift dx)
+		constexpr int STAGE_FRAGS = 4 * 3 * G::MT * 64; // half8 elements of one stage: 4 channel groups x 3 taps x MT tiles x 64 lanes
+		static_assert(STAGES % 2 == 0, "two stages per loop turn (static ring index)");
+		const half8 *wl = wpk + __builtin_amdgcn_readfirstlane(mg * 3 * G::MT * 64); // wave-uniform: scalar base + lane offset
+		half8 a0[3][G::MT], a1[3][G::MT];
+#pragma unroll
+		for (int dyi = 0; dyi < 3; dyi++)
+#pragma unroll
+			for (int i = 0; i < G::MT; i++)
+				a0[dyi][i] = wl[(dyi * G::MT + i) * 64 + lane];
+		const int index_base = 1 + G::S + n0 * 16 + r; // stored index of this lane's position in the wave's first output row
+#pragma unroll 1
+		for (int s = 0; s < STAGES; s += 2)
+		{
+			conv3x3_rows_stage<F, ROWS, COLS>(src, wl + (s + 1) * STAGE_FRAGS, s / 3, s % 3, index_base, q4, my_tiles, lane, a0, a1, acc);
+			// the last turn fetches stage 0 again instead of branching around the fetch: with a conditional fetch the wait for THIS stage's
+			// fragments has to assume the newer loads were never issued (vmcnt(0)), which serialises fetch and MFMAs in every turn
+			conv3x3_rows_stage<F, ROWS, COLS>(src, wl + ((s + 2 < STAGES) ? (s + 2) : 0) * STAGE_FRAGS, (s + 1) / 3, (s + 1) % 3, index_base, q4, my_tiles, lane, a1,
+					a0, acc);
+		}
+	}
+
+	template<int F, int ROWS, int COLS, bool ZERO = true>
+	__device__ __forceinline__ void conv3x3_mac_taps(const char *src, const half8 *__restrict__ wpk, int wave, int lane,
 			floatx4 (&acc)[Geometry<F, ROWS, COLS>::MT][Geometry<F, ROWS, COLS>::NTW])
 	{
 		typedef Geometry<F, ROWS, COLS> G;
@@ -116,11 +260,14 @@ namespace
 		const int n0 = (wave >> 2) * G::NTW;           // first position tile of this wave
 		const int my_tiles = (wave >> 2) ? (G::NT - G::NTW) : G::NTW;
 
+		if (ZERO)
+		{
 #pragma unroll
-		for (int i = 0; i < G::MT; i++)
+			for (int i = 0; i < G::MT; i++)
 #pragma unroll
-			for (int n = 0; n < G::NTW; n++)
-				acc[i][n] = floatx4 { 0.0f, 0.0f, 0.0f, 0.0f };
+				for (int n = 0; n < G::NTW; n++)
+					acc[i][n] = floatx4 { 0.0f, 0.0f, 0.0f, 0.0f };
+		}
 
 		/*
 		 * 9*KC k-steps (one k-step = 32 input channels of one tap).  Two waves share a SIMD, so while one waits for its LDS /
@@ -182,6 +329,16 @@ namespace
 		}
 	}
 
+	template<int F, int ROWS, int COLS, bool ZERO = true>
+	__device__ __forceinline__ void conv3x3_mac(const char *src, const half8 *__restrict__ wpk, int wave, int lane,
+			floatx4 (&acc)[Geometry<F, ROWS, COLS>::MT][Geometry<F, ROWS, COLS>::NTW])
+	{
+		if constexpr (Geometry<F, ROWS, COLS>::S == 16 && AGX_NN_ROW_STATIONARY)
+			conv3x3_mac_rows<F, ROWS, COLS, ZERO>(src, wpk, wave, lane, acc);
+		else
+			conv3x3_mac_taps<F, ROWS, COLS, ZERO>(src, wpk, wave, lane, acc);
+	}
+
 	template<bool TANH>
 	__device__ __forceinline__ float activation(float x)
 	{ // ReLU of the tower / policy head, tanh of the action-values head (blocks.cpp:119-127)
@@ -190,7 +347,7 @@ namespace
 
 	template<int F, int ROWS, int COLS, bool SKIP, bool TANH = false>
 	__device__ __forceinline__ void conv3x3(const char *src, char *dst, const half8 *__restrict__ wpk, const float *__restrict__ bias, int wave,
-			int lane)
+			int lane AGX_NN_STAMP_PARAM)
 	{
 		typedef Geometry<F, ROWS, COLS> G;
 		const int r = lane & 15;
@@ -198,15 +355,40 @@ namespace
 		const int mg = wave & 3;
 		const int n0 = (wave >> 2) * G::NTW;
 		const int my_tiles = (wave >> 2) ? (G::NT - G::NTW) : G::NTW;
+		// The accumulators START from bias (+ residual input): the adds of the epilogue move to the layer's beginning, where they run in
+		// the shadow of the first weight fetch, and the epilogue — which both waves of a SIMD reach with no MFMAs left to hide behind —
+		// shrinks to ReLU, convert, mask, store.
 		floatx4 acc[G::MT][G::NTW];
-		conv3x3_mac<F, ROWS, COLS>(src, wpk, wave, lane, acc);
+#pragma unroll
+		for (int i = 0; i < G::MT; i++)
+		{
+			const int ch = (mg * G::MT + i) * 16 + 4 * q4;
+			const floatx4 bv = *reinterpret_cast<const floatx4*>(bias + ch);
+#pragma unroll
+			for (int n = 0; n < G::NTW; n++)
+			{
+				floatx4 v = bv;
+				if (SKIP && n < my_tiles)
+				{
+					const int pos = G::S + (n0 + n) * 16 + r;
+					const half4 sk = *reinterpret_cast<const half4*>(dst + plane_offset<G>(pos + 1, ch / 8) + (ch % 8) * 2);
+					v[0] += static_cast<float>(sk[0]);
+					v[1] += static_cast<float>(sk[1]);
+					v[2] += static_cast<float>(sk[2]);
+					v[3] += static_cast<float>(sk[3]);
+				}
+				acc[i][n] = v;
+			}
+		}
+		AGX_NN_MARK(2);
+		conv3x3_mac<F, ROWS, COLS, false>(src, wpk, wave, lane, acc);
+		AGX_NN_MARK(3);
 
 		// epilogue: lane holds out-channels 4*q4 .. 4*q4+3 of tile i for position r of tile n
 #pragma unroll
 		for (int i = 0; i < G::MT; i++)
 		{
 			const int ch = (mg * G::MT + i) * 16 + 4 * q4;
-			const floatx4 bv = *reinterpret_cast<const floatx4*>(bias + ch);
 #pragma unroll
 			for (int n = 0; n < G::NTW; n++)
 				if (n < my_tiles)
@@ -216,15 +398,7 @@ namespace
 					const int y = pos / G::S - 1;
 					const bool valid = (x < COLS) && (y < ROWS);
 					char *ptr = dst + plane_offset<G>(pos + 1, ch / 8) + (ch % 8) * 2;
-					floatx4 v = acc[i][n] + bv;
-					if (SKIP)
-					{
-						const half4 sk = *reinterpret_cast<const half4*>(ptr);
-						v[0] += static_cast<float>(sk[0]);
-						v[1] += static_cast<float>(sk[1]);
-						v[2] += static_cast<float>(sk[2]);
-						v[3] += static_cast<float>(sk[3]);
-					}
+					const floatx4 v = acc[i][n];
 					half4 o;
 					o[0] = static_cast<half_t>(valid ? activation<TANH>(v[0]) : 0.0f);
 					o[1] = static_cast<half_t>(valid ? activation<TANH>(v[1]) : 0.0f);
@@ -233,6 +407,7 @@ namespace
 					*reinterpret_cast<half4*>(ptr) = o;
 				}
 		}
+		AGX_NN_MARK(4);
 	}
 
 	/*
@@ -430,6 +605,10 @@ namespace
 		}
 
 		const half8 *wp = wpk + (mg * G::MT) * 64 + lane;
+		half8 a_next[G::MT]; // the next tap's weight fragments are requested one tap ahead (an L2 round trip is longer than a tap's MFMAs)
+#pragma unroll
+		for (int i = 0; i < G::MT; i++)
+			a_next[i] = wp[i * 64];
 #pragma unroll 1
 		for (int t = 0; t < 25; t++)
 		{
@@ -437,7 +616,11 @@ namespace
 			half8 a[G::MT];
 #pragma unroll
 			for (int i = 0; i < G::MT; i++)
-				a[i] = wp[(t * G::MTILES + i) * 64];
+				a[i] = a_next[i];
+			const int tn = (t + 1 < 25) ? (t + 1) : 0;
+#pragma unroll
+			for (int i = 0; i < G::MT; i++)
+				a_next[i] = wp[(tn * G::MTILES + i) * 64];
 #pragma unroll
 			for (int n = 0; n < G::NTW; n++)
 				if (n < my_tiles)
@@ -547,6 +730,9 @@ namespace
 				s_wq2[i] = p.wq2[i];
 
 		const int batch = (p.count_ptr != nullptr) ? min(*p.count_ptr, p.batch) : p.batch;
+#ifdef AGX_NN_PROFILE
+		NnStamp stamp(wave, lane);
+#endif
 		for (int bi = blockIdx.x; bi < batch; bi += gridDim.x)
 		{
 			const int b = (p.slot_list != nullptr) ? p.slot_list[bi] : bi;
@@ -572,8 +758,10 @@ namespace
 				}
 			}
 			__syncthreads();
+			AGX_NN_MARK(0);
 			conv5x5_input<F, ROWS, COLS, INPLACE>(plane_t, plane_x, p.w_in, p.bias, skip, wave, lane);
 			__syncthreads();
+			AGX_NN_MARK(1);
 			if (!INPLACE)
 			{
 				for (int i = tid; i < G::PLANE_BYTES / 16; i += G::THREADS)
@@ -581,6 +769,7 @@ namespace
 				__syncthreads();
 			}
 
+			AGX_NN_MARK(9);
 			// ---- residual tower ----
 			for (int blk = 0; blk < p.blocks; blk++)
 			{
@@ -594,10 +783,12 @@ namespace
 				}
 				else
 				{
-					conv3x3<F, ROWS, COLS, false>(plane_x, plane_t, p.w_tower + (2 * blk) * layer_halves8, p.bias + (1 + 2 * blk) * F, wave, lane);
+					conv3x3<F, ROWS, COLS, false>(plane_x, plane_t, p.w_tower + (2 * blk) * layer_halves8, p.bias + (1 + 2 * blk) * F, wave, lane AGX_NN_STAMP_ARG);
 					__syncthreads();
-					conv3x3<F, ROWS, COLS, true>(plane_t, plane_x, p.w_tower + (2 * blk + 1) * layer_halves8, p.bias + (2 + 2 * blk) * F, wave, lane);
+					AGX_NN_MARK(5);
+					conv3x3<F, ROWS, COLS, true>(plane_t, plane_x, p.w_tower + (2 * blk + 1) * layer_halves8, p.bias + (2 + 2 * blk) * F, wave, lane AGX_NN_STAMP_ARG);
 					__syncthreads();
+					AGX_NN_MARK(5);
 				}
 			}
 
@@ -625,13 +816,15 @@ namespace
 				vbuf[c * 4 + 2] = fmaxf(s2, 0.0f);
 				vbuf[c * 4 + 3] = fmaxf(s3, 0.0f);
 			}
+			AGX_NN_MARK(6);
 			// ---- policy head: conv3x3 + ReLU into plane_t ----
 			if (INPLACE)
 				conv3x3_inplace<F, ROWS, COLS, 2>(plane_x, p.w_tower + (2 * p.blocks) * layer_halves8, p.bias + (1 + 2 * p.blocks) * F, nullptr, s_wp2, ppart,
 						wave, lane);
 			else
-				conv3x3<F, ROWS, COLS, false>(plane_x, plane_t, p.w_tower + (2 * p.blocks) * layer_halves8, p.bias + (1 + 2 * p.blocks) * F, wave, lane);
+				conv3x3<F, ROWS, COLS, false>(plane_x, plane_t, p.w_tower + (2 * p.blocks) * layer_halves8, p.bias + (1 + 2 * p.blocks) * F, wave, lane AGX_NN_STAMP_ARG);
 			__syncthreads();
+			AGX_NN_MARK(7);
 
 			// ---- policy head: conv1x1 F->1 + bias, softmax over the board ----
 			{
@@ -723,7 +916,7 @@ namespace
 					conv3x3_inplace<F, ROWS, COLS, 3>(plane_x, wq1, bq1, nullptr, s_wq2, qpart, wave, lane);
 				else
 				{
-					conv3x3<F, ROWS, COLS, false, true>(plane_x, plane_t, wq1, bq1, wave, lane);
+					conv3x3<F, ROWS, COLS, false, true>(plane_x, plane_t, wq1, bq1, wave, lane AGX_NN_STAMP_ARG);
 					__syncthreads();
 				}
 				const int c = tid;
@@ -762,6 +955,7 @@ namespace
 					out[1] = e1 * inv; // draw
 				}
 			}
+			AGX_NN_MARK(8);
 		}
 	}
 
@@ -787,6 +981,35 @@ namespace
 							const float v = w[(static_cast<size_t>(t) * cin + ic) * cout + oc];
 							out[(((static_cast<size_t>(t) * kcs + kc) * mtiles + mt) * 64 + lane) * 8 + j] = static_cast<half_t>(v);
 						}
+	}
+}
+
+namespace
+{
+	/*
+	 * The same fragments in the order the row-stationary k-loop consumes them (conv3x3_mac_rows): [kc][dx][channel group][dy][tile][lane][8],
+	 * so the 3 * MT fragments a wave needs for one stage are consecutive.  3x3 kernels only; MT = cout / 64 tiles per channel group.
+	 */
+	void pack_conv_rows(const float *w, int cin, int cout, std::vector<half_t> &dst)
+	{
+		const int kcs = cin / 32, mt_per_group = cout / 64;
+		const size_t base = dst.size();
+		dst.resize(base + static_cast<size_t>(9) * kcs * (cout / 16) * 512);
+		half_t *out = dst.data() + base;
+		size_t frag = 0;
+		for (int kc = 0; kc < kcs; kc++)
+			for (int dx = 0; dx < 3; dx++)
+				for (int mg = 0; mg < 4; mg++)
+					for (int dy = 0; dy < 3; dy++)
+						for (int i = 0; i < mt_per_group; i++, frag++)
+							for (int lane = 0; lane < 64; lane++)
+								for (int j = 0; j < 8; j++)
+								{
+									const int t = dy * 3 + dx;
+									const int oc = (mg * mt_per_group + i) * 16 + (lane & 15);
+									const int ic = kc * 32 + 8 * (lane >> 4) + j;
+									out[(frag * 64 + lane) * 8 + j] = static_cast<half_t>(w[(static_cast<size_t>(t) * cin + ic) * cout + oc]);
+								}
 	}
 }
 
@@ -898,9 +1121,18 @@ int agx_net_load_weights(AgxNet *net, const float *h_blob, size_t n_floats)
 	ptr += 25 * C * F;
 	bias.insert(bias.end(), ptr, ptr + F);
 	ptr += F;
+	// 15-column boards (row stride 16 = one MFMA tile) run the row-stationary k-loop, which reads the fragments in its own order
+	const bool row_order = (net->desc.cols + 1 == 16) && (AGX_NN_ROW_STATIONARY != 0);
+	auto pack3x3 = [&](const float *w)
+	{
+		if (row_order)
+			pack_conv_rows(w, F, F, w_tower);
+		else
+			pack_conv(w, 9, F, F, w_tower);
+	};
 	for (int l = 0; l < 2 * blocks + 1; l++)
 	{
-		pack_conv(ptr, 9, F, F, w_tower);
+		pack3x3(ptr);
 		ptr += 9 * F * F;
 		bias.insert(bias.end(), ptr, ptr + F);
 		ptr += F;
@@ -925,7 +1157,7 @@ int agx_net_load_weights(AgxNet *net, const float *h_blob, size_t n_floats)
 	std::vector<float> wq2;
 	if (net->desc.action_values)
 	{ // createActionValuesHead (blocks.cpp:119-127): the 3x3 conv joins the packed tower layers, the 1x1 conv is kept in fp32
-		pack_conv(ptr, 9, F, F, w_tower);
+		pack3x3(ptr);
 		ptr += 9 * F * F;
 		bias.insert(bias.end(), ptr, ptr + F);
 		ptr += F;
@@ -1057,6 +1289,18 @@ int agx_nn_forward_indirect_pvq(AgxNet *net, const uint32_t *d_features, const i
 	AGX_REQUIRE(d_slot_list != nullptr && d_count != nullptr, AGX_ERR_INVALID, "agx_nn_forward_indirect_pvq: null list");
 	return launch_forward(net, d_features, d_slot_list, d_count, max_batch, d_policy, d_value, d_action_values, stream);
 }
+
+#ifdef AGX_NN_PROFILE
+/* profile builds only: shader cycles per phase summed over the workgroups (waves 0 and 4), then reset.  out[2][16] */
+int agx_debug_nn_profile(unsigned long long *out)
+{
+	AGX_HIP_CHECK(hipDeviceSynchronize());
+	AGX_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_nn_prof), sizeof(unsigned long long) * 32));
+	unsigned long long zero[32] = { 0 };
+	AGX_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_nn_prof), zero, sizeof(zero)));
+	return AGX_OK;
+}
+#endif
 
 int agx_net_description(const AgxNet *net, AgxNetDesc *out)
 {
