@@ -45,8 +45,11 @@
 #ifndef AGX_NN_SCHED_GROUPS
 #define AGX_NN_SCHED_GROUPS 2
 #endif
+#ifndef AGX_NN_PROGRESS_PRIORITY
+#define AGX_NN_PROGRESS_PRIORITY 1
+#endif
 #ifndef AGX_NN_AHEAD
-#define AGX_NN_AHEAD 3 // activation fragments in flight per wave in the row-stationary k-loop
+#define AGX_NN_AHEAD 4 // activation fragments in flight per wave in the row-stationary k-loop
 #endif
 
 namespace
@@ -63,7 +66,8 @@ namespace
 			const float *bias;      // [1 + 2*blocks + 1][F]
 			const float *wp2;       // [F]
 			const float *wv1;       // [F][4]
-			const half_t *wv2;      // [HW*4][D]
+			const half_t *wv2;      // value-head dense weights in MFMA A-fragment order [KPAD/32][D/16][lane][8] (value_head_kernel)
+			half_t *vhead_x;        // [batch][KPAD]: the value head's conv1x1 output of every board of the launch, input of value_head_kernel
 			const float *bv2;       // [D]
 			const float *wv3;       // [D][3]
 			float bp2;
@@ -126,6 +130,7 @@ namespace
 			static constexpr int NPOS5 = (ROWS + 4) * S5 + 4;
 			static constexpr int HW = ROWS * COLS;
 			static constexpr int D = (2 * F < 256) ? 2 * F : 256;
+			static constexpr int KPAD = (HW * 4 + 31) / 32 * 32;                 // value-head dense input length, padded to whole MFMA k-steps
 			static constexpr int SCRATCH_FLOATS = HW * 4 + D + 8 + 256 + 8 + F * 4 + F + F * 4;
 			static constexpr int LDS_BYTES = 2 * PLANE_BYTES + SCRATCH_FLOATS * 4;
 			// single-plane variant (boards whose two planes do not fit): one plane + scratch + policy partial sums [4][NT*16]
@@ -155,7 +160,11 @@ namespace
 		for (int dyi = 0; dyi < 3; dyi++)
 #pragma unroll
 			for (int i = 0; i < G::MT; i++)
+#ifdef AGX_NN_EXPERIMENT_NO_WEIGHT_FETCH
+				a_next[dyi][i] = a_cur[dyi][i]; // experiment: no L2 traffic in the loop (results are garbage)
+#else
 				a_next[dyi][i] = wnext[(dyi * G::MT + i) * 64 + lane];
+#endif
 		const int index0 = index_base + (dxi - 1);
 		const int swz0 = (index0 / G::PPR) % G::CH; // invariant over rows: 16 positions == whole bank rows
 		const char *src0 = src + index0 * G::CH * 16 + (((kc * 4 + q4) ^ swz0) * 16);
@@ -241,12 +250,26 @@ namespace
 #pragma unroll 1
 		for (int s = 0; s < STAGES; s += 2)
 		{
+#if AGX_NN_PROGRESS_PRIORITY
+			// The two waves of a SIMD are issued oldest-first: left alone, the older one runs ahead, finishes its k-loop early and waits at
+			// the layer barrier while the younger one finishes ALONE (a lone wave hides none of its LDS / L2 latencies: measured 2.1 x its
+			// MFMA time).  Priority by remaining work — the wave that is behind goes first — keeps the pair together to the end.
+			if (3 * s < STAGES)
+				__builtin_amdgcn_s_setprio(3);
+			else if (3 * s < 2 * STAGES)
+				__builtin_amdgcn_s_setprio(2);
+			else
+				__builtin_amdgcn_s_setprio(1);
+#endif
 			conv3x3_rows_stage<F, ROWS, COLS>(src, wl + (s + 1) * STAGE_FRAGS, s / 3, s % 3, index_base, q4, my_tiles, lane, a0, a1, acc);
 			// the last turn fetches stage 0 again instead of branching around the fetch: with a conditional fetch the wait for THIS stage's
 			// fragments has to assume the newer loads were never issued (vmcnt(0)), which serialises fetch and MFMAs in every turn
 			conv3x3_rows_stage<F, ROWS, COLS>(src, wl + ((s + 2 < STAGES) ? (s + 2) : 0) * STAGE_FRAGS, (s + 1) / 3, (s + 1) % 3, index_base, q4, my_tiles, lane, a1,
 					a0, acc);
 		}
+#if AGX_NN_PROGRESS_PRIORITY
+		__builtin_amdgcn_s_setprio(0);
+#endif
 	}
 
 	template<int F, int ROWS, int COLS, bool ZERO = true>
@@ -381,6 +404,9 @@ namespace
 			}
 		}
 		AGX_NN_MARK(2);
+#ifdef AGX_NN_EXPERIMENT_SKIP_UPPER
+		if (wave < 4) // experiment: the lower waves run their k-loop ALONE on their SIMDs (results are garbage)
+#endif
 		conv3x3_mac<F, ROWS, COLS, false>(src, wpk, wave, lane, acc);
 		AGX_NN_MARK(3);
 
@@ -792,7 +818,9 @@ namespace
 				}
 			}
 
-			// ---- value head, stage 1: conv1x1 F->4 + ReLU into vbuf (NHWC flatten order) ----
+			// ---- value head, stage 1: conv1x1 F->4 + ReLU (NHWC flatten order).  The dense layers behind it run for ALL boards of the launch in
+			//      value_head_kernel: inside this kernel every board streamed the 0.46 MB of dense weights through one dependent chain per
+			//      thread (measured: 9 % of a board's time), batched they are one small GEMM on the matrix cores ----
 			for (int c = tid; c < G::HW; c += G::THREADS)
 			{
 				const int index = 1 + G::S + (c / COLS) * G::S + (c % COLS);
@@ -811,10 +839,12 @@ namespace
 						s3 += xf * w[3];
 					}
 				}
-				vbuf[c * 4 + 0] = fmaxf(s0, 0.0f);
-				vbuf[c * 4 + 1] = fmaxf(s1, 0.0f);
-				vbuf[c * 4 + 2] = fmaxf(s2, 0.0f);
-				vbuf[c * 4 + 3] = fmaxf(s3, 0.0f);
+				half4 o;
+				o[0] = static_cast<half_t>(fmaxf(s0, 0.0f));
+				o[1] = static_cast<half_t>(fmaxf(s1, 0.0f));
+				o[2] = static_cast<half_t>(fmaxf(s2, 0.0f));
+				o[3] = static_cast<half_t>(fmaxf(s3, 0.0f));
+				*reinterpret_cast<half4*>(p.vhead_x + static_cast<size_t>(bi) * G::KPAD + c * 4) = o;
 			}
 			AGX_NN_MARK(6);
 			// ---- policy head: conv3x3 + ReLU into plane_t ----
@@ -857,53 +887,6 @@ namespace
 				const float sum = block_reduce_sum(e, red, tid);
 				if (c < G::HW)
 					policy[static_cast<size_t>(b) * G::HW + c] = e / sum;
-			}
-
-			// ---- value head, stage 2: dense HW*4 -> D + ReLU, dense D -> 3, softmax ----
-			{ // every thread owns one hidden unit and one half of the 4*HW inputs; the halves meet in LDS
-				static_assert(2 * G::D <= G::THREADS, "value head assumes two threads per hidden unit");
-				constexpr int HALF = (G::HW * 4) / 2;
-				const int j = tid % G::D, part = tid / G::D;
-				float s0 = 0.0f, s1 = 0.0f;
-				if (part < 2)
-				{
-					const half_t *w = p.wv2 + static_cast<size_t>(part * HALF) * G::D + j;
-					const float *x = vbuf + part * HALF;
-#pragma unroll 10
-					for (int i = 0; i < HALF; i += 2)
-					{
-						s0 += x[i] * static_cast<float>(w[static_cast<size_t>(i) * G::D]);
-						s1 += x[i + 1] * static_cast<float>(w[static_cast<size_t>(i + 1) * G::D]);
-					}
-				}
-				if (part == 1)
-					red[8 + j] = s0 + s1; // red[8 .. 8 + D) is free here (D <= 248 is not guaranteed, so use the tail of the scratch area)
-				__syncthreads();
-				if (part == 0)
-					hid[j] = fmaxf((s0 + s1) + red[8 + j] + p.bv2[j], 0.0f);
-			}
-			__syncthreads();
-			if (wave < 3)
-			{ // wave k reduces output k
-				float s = 0.0f;
-				for (int j = lane; j < G::D; j += 64)
-					s += hid[j] * p.wv3[j * 3 + wave];
-#pragma unroll
-				for (int o = 32; o > 0; o >>= 1)
-					s += __shfl_xor(s, o);
-				if (lane == 0)
-					red[264 + wave] = s + p.bv3[wave];
-			}
-			__syncthreads();
-			if (tid == 0)
-			{
-				const float z0 = red[264], z1 = red[265], z2 = red[266];
-				const float m = fmaxf(z0, fmaxf(z1, z2));
-				const float e0 = __expf(z0 - m), e1 = __expf(z1 - m), e2 = __expf(z2 - m);
-				const float inv = 1.0f / (e0 + e1 + e2);
-				value[static_cast<size_t>(b) * 3 + 0] = e0 * inv;
-				value[static_cast<size_t>(b) * 3 + 1] = e1 * inv;
-				value[static_cast<size_t>(b) * 3 + 2] = e2 * inv;
 			}
 
 			// ---- action-values head (blocks.cpp:119-127): conv3x3 + tanh, conv1x1 F -> 3 + bias, softmax over the 3 per cell ----
@@ -956,6 +939,74 @@ namespace
 				}
 			}
 			AGX_NN_MARK(8);
+		}
+	}
+
+	/*
+	 * Value head behind the tower, for every board of a launch: hidden = ReLU(W2^T x + b2) (4 HW -> D), out = softmax(W3^T hidden + b3)
+	 * (createValueHead, blocks.cpp:108-118).  One workgroup = 16 boards (one MFMA position tile) x all D hidden units: wave w owns the
+	 * 16-unit tiles w * D/64 .. and walks K in 32-input steps (weights pre-packed in A-fragment order, the boards' inputs are rows of
+	 * KPAD halves).  3.1 GFLOP for a whole self-play batch — microseconds.
+	 */
+	template<int KPAD, int D>
+	__global__ __launch_bounds__(256) void value_head_kernel(const half_t *__restrict__ x, const half8 *__restrict__ w2, const float *__restrict__ b2,
+			const float *__restrict__ w3, float b30, float b31, float b32, const int *__restrict__ slot_list, const int *__restrict__ count_ptr, int batch_cap,
+			float *__restrict__ value)
+	{
+		constexpr int MTW = D / 64; // 16-unit tiles per wave
+		__shared__ float hid[16][D + 1];
+		const int batch = (count_ptr != nullptr) ? min(*count_ptr, batch_cap) : batch_cap;
+		const int b0 = blockIdx.x * 16;
+		if (b0 >= batch)
+			return;
+		const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 15, q4 = lane >> 4;
+		const int board = min(b0 + r, batch - 1); // the tail tile repeats the last board (never stored)
+		floatx4 acc[MTW];
+#pragma unroll
+		for (int i = 0; i < MTW; i++)
+			acc[i] = floatx4 { 0.0f, 0.0f, 0.0f, 0.0f };
+		const half8 *xb = reinterpret_cast<const half8*>(x + static_cast<size_t>(board) * KPAD) + q4;
+		const half8 *wp = w2 + (wave * MTW) * 64 + lane;
+#pragma unroll 4
+		for (int kc = 0; kc < KPAD / 32; kc++)
+		{
+			const half8 bfrag = xb[kc * 4];
+#pragma unroll
+			for (int i = 0; i < MTW; i++)
+				acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wp[(kc * (D / 16) + i) * 64], bfrag, acc[i], 0, 0, 0);
+		}
+		// lane holds hidden units 4 * q4 .. + 3 of tile i for board r
+#pragma unroll
+		for (int i = 0; i < MTW; i++)
+		{
+			const int u = (wave * MTW + i) * 16 + 4 * q4;
+#pragma unroll
+			for (int e = 0; e < 4; e++)
+				hid[r][u + e] = fmaxf(acc[i][e] + b2[u + e], 0.0f);
+		}
+		__syncthreads();
+		// 16 boards x 3 outputs: threads 0 .. 47 each reduce one (board, output) pair in a fixed order
+		__shared__ float logits[16][3];
+		if (tid < 48)
+		{
+			const int bb = tid / 3, o = tid % 3;
+			float sacc = 0.0f;
+			for (int j = 0; j < D; j++)
+				sacc += hid[bb][j] * w3[j * 3 + o];
+			logits[bb][o] = sacc + ((o == 0) ? b30 : ((o == 1) ? b31 : b32));
+		}
+		__syncthreads();
+		if (tid < 16 && b0 + tid < batch)
+		{
+			const int bi = b0 + tid;
+			const int slot = (slot_list != nullptr) ? slot_list[bi] : bi;
+			const float z0 = logits[tid][0], z1 = logits[tid][1], z2 = logits[tid][2];
+			const float m = fmaxf(z0, fmaxf(z1, z2));
+			const float e0 = __expf(z0 - m), e1 = __expf(z1 - m), e2 = __expf(z2 - m);
+			const float inv = 1.0f / (e0 + e1 + e2);
+			value[static_cast<size_t>(slot) * 3 + 0] = e0 * inv;
+			value[static_cast<size_t>(slot) * 3 + 1] = e1 * inv;
+			value[static_cast<size_t>(slot) * 3 + 2] = e2 * inv;
 		}
 	}
 
@@ -1031,7 +1082,14 @@ struct AgxNet
 		// concurrently (pool slices driven from several streams share one network), so every stream gets its own scratch; launches on
 		// one stream are ordered and share theirs.
 		std::mutex skip_mutex;
-		std::vector<std::pair<hipStream_t, void*>> skip_by_stream;
+		struct StreamScratch
+		{
+				hipStream_t stream;
+				void *skip;   // single-plane variant: residual scratch
+				void *vhead;  // value-head inputs of one launch: [boards][KPAD] halves
+				int vhead_boards;
+		};
+		std::vector<StreamScratch> scratch_by_stream;
 		size_t skip_bytes = 0;
 		bool inplace = false;
 		float bp2 = 0.0f;
@@ -1057,9 +1115,14 @@ namespace
 			*p = nullptr;
 		}
 		std::lock_guard<std::mutex> lock(net->skip_mutex);
-		for (auto &slice : net->skip_by_stream)
-			(void) hipFree(slice.second);
-		net->skip_by_stream.clear();
+		for (auto &slice : net->scratch_by_stream)
+		{
+			if (slice.skip != nullptr)
+				(void) hipFree(slice.skip);
+			if (slice.vhead != nullptr)
+				(void) hipFree(slice.vhead);
+		}
+		net->scratch_by_stream.clear();
 	}
 	template<typename T>
 	int upload(void **dst, const std::vector<T> &src)
@@ -1144,9 +1207,19 @@ int agx_net_load_weights(AgxNet *net, const float *h_blob, size_t n_floats)
 	ptr += F * 4;
 	for (int i = 0; i < 4; i++)
 		net->bv1[i] = *ptr++;
-	wv2.resize(static_cast<size_t>(HW) * 4 * D);
-	for (size_t i = 0; i < wv2.size(); i++)
-		wv2[i] = static_cast<half_t>(ptr[i]);
+	{ // dense 4 HW -> D in MFMA A-fragment order [k-step][16-unit tile][lane][8] (value_head_kernel), zero beyond the last input
+		const int kpad = (HW * 4 + 31) / 32 * 32, mtiles = D / 16;
+		wv2.assign(static_cast<size_t>(kpad) * D, static_cast<half_t>(0.0f));
+		for (int kc = 0; kc < kpad / 32; kc++)
+			for (int mt = 0; mt < mtiles; mt++)
+				for (int lane = 0; lane < 64; lane++)
+					for (int j = 0; j < 8; j++)
+					{
+						const int unit = mt * 16 + (lane & 15), k = kc * 32 + 8 * (lane >> 4) + j;
+						if (k < HW * 4)
+							wv2[((static_cast<size_t>(kc) * mtiles + mt) * 64 + lane) * 8 + j] = static_cast<half_t>(ptr[static_cast<size_t>(k) * D + unit]);
+					}
+	}
 	ptr += static_cast<size_t>(HW) * 4 * D;
 	bv2.assign(ptr, ptr + D);
 	ptr += D;
@@ -1230,19 +1303,35 @@ static int launch_forward(AgxNet *net, const uint32_t *d_features, const int *d_
 	const int grid = (batch < net->num_cus) ? batch : net->num_cus;
 	hipStream_t s = static_cast<hipStream_t>(stream);
 	p.skip = nullptr;
-	if (net->inplace)
-	{
+	const int kpad = (net->desc.rows * net->desc.cols * 4 + 31) / 32 * 32;
+	{ // per-stream scratch: launches on one stream are ordered and share it, launches on different streams may overlap
 		std::lock_guard<std::mutex> lock(net->skip_mutex);
-		for (const auto &slice : net->skip_by_stream)
-			if (slice.first == s)
-				p.skip = static_cast<half4*>(slice.second);
-		if (p.skip == nullptr)
+		AgxNet::StreamScratch *mine = nullptr;
+		for (auto &slice : net->scratch_by_stream)
+			if (slice.stream == s)
+				mine = &slice;
+		if (mine == nullptr)
 		{
-			void *mem = nullptr;
-			AGX_HIP_CHECK(hipMalloc(&mem, net->skip_bytes));
-			net->skip_by_stream.emplace_back(s, mem);
-			p.skip = static_cast<half4*>(mem);
+			net->scratch_by_stream.push_back(AgxNet::StreamScratch { s, nullptr, nullptr, 0 });
+			mine = &net->scratch_by_stream.back();
 		}
+		if (net->inplace && mine->skip == nullptr)
+			AGX_HIP_CHECK(hipMalloc(&mine->skip, net->skip_bytes));
+		if (mine->vhead_boards < batch)
+		{ // grows to the largest launch seen on this stream (a pool's launches all have the same capacity)
+			if (mine->vhead != nullptr)
+			{
+				AGX_HIP_CHECK(hipStreamSynchronize(s));
+				AGX_HIP_CHECK(hipFree(mine->vhead));
+				mine->vhead = nullptr;
+			}
+			const size_t bytes = static_cast<size_t>(batch) * kpad * sizeof(half_t);
+			AGX_HIP_CHECK(hipMalloc(&mine->vhead, bytes));
+			AGX_HIP_CHECK(hipMemsetAsync(mine->vhead, 0, bytes, s)); // the k-padding stays zero: the tower kernel only writes the first 4 HW halves of a row
+			mine->vhead_boards = batch;
+		}
+		p.skip = static_cast<half4*>(mine->skip);
+		p.vhead_x = static_cast<half_t*>(mine->vhead);
 	}
 	const bool big = (net->desc.rows == 20), wide = (net->desc.filters == 128), qhead = (p.q != nullptr);
 	const dim3 g(grid), t(512);
@@ -1265,6 +1354,20 @@ static int launch_forward(AgxNet *net, const uint32_t *d_features, const int *d_
 		AGX_LAUNCH_HEADS(64, 15, false);
 #undef AGX_LAUNCH_HEADS
 #undef AGX_LAUNCH_TOWER
+	{ // the value head's dense layers for all boards of the launch
+		const dim3 vg((batch + 15) / 16), vt(256);
+#define AGX_LAUNCH_VALUE(KP, DD) hipLaunchKernelGGL((value_head_kernel<KP, DD>), vg, vt, 0, s, p.vhead_x, reinterpret_cast<const half8*>(p.wv2), p.bv2, p.wv3, \
+		p.bv3[0], p.bv3[1], p.bv3[2], d_slot_list, d_count, batch, d_value)
+		if (big && wide)
+			AGX_LAUNCH_VALUE(1600, 256);
+		else if (big)
+			AGX_LAUNCH_VALUE(1600, 128);
+		else if (wide)
+			AGX_LAUNCH_VALUE(928, 256);
+		else
+			AGX_LAUNCH_VALUE(928, 128);
+#undef AGX_LAUNCH_VALUE
+	}
 	AGX_HIP_CHECK(hipGetLastError());
 	return AGX_OK;
 }
