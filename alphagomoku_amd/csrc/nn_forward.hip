@@ -48,6 +48,12 @@
 #ifndef AGX_NN_PROGRESS_PRIORITY
 #define AGX_NN_PROGRESS_PRIORITY 1
 #endif
+#ifndef AGX_NN_YOUNGER_BIAS
+#define AGX_NN_YOUNGER_BIAS 0 // in units of a third of a stage: > 0 lets the younger wave of a pair hold a priority level longer (measured: worse)
+#endif
+#ifndef AGX_NN_CONV5_ROWS
+#define AGX_NN_CONV5_ROWS 1
+#endif
 #ifndef AGX_NN_AHEAD
 #define AGX_NN_AHEAD 4 // activation fragments in flight per wave in the row-stationary k-loop
 #endif
@@ -57,6 +63,7 @@ namespace
 	typedef _Float16 half_t;
 	typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 	typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+	typedef _Float16 half2 __attribute__((ext_vector_type(2)));
 	typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 	struct NetParams
@@ -254,9 +261,11 @@ namespace
 			// The two waves of a SIMD are issued oldest-first: left alone, the older one runs ahead, finishes its k-loop early and waits at
 			// the layer barrier while the younger one finishes ALONE (a lone wave hides none of its LDS / L2 latencies: measured 2.1 x its
 			// MFMA time).  Priority by remaining work — the wave that is behind goes first — keeps the pair together to the end.
-			if (3 * s < STAGES)
+			// (the younger wave of a pair keeps each level one turn longer: at equal priority the hardware prefers the older one)
+			const int progress = 3 * s - ((wave >> 2) ? AGX_NN_YOUNGER_BIAS : 0);
+			if (progress < STAGES)
 				__builtin_amdgcn_s_setprio(3);
-			else if (3 * s < 2 * STAGES)
+			else if (progress < 2 * STAGES)
 				__builtin_amdgcn_s_setprio(2);
 			else
 				__builtin_amdgcn_s_setprio(1);
@@ -425,12 +434,28 @@ namespace
 					const bool valid = (x < COLS) && (y < ROWS);
 					char *ptr = dst + plane_offset<G>(pos + 1, ch / 8) + (ch % 8) * 2;
 					const floatx4 v = acc[i][n];
-					half4 o;
-					o[0] = static_cast<half_t>(valid ? activation<TANH>(v[0]) : 0.0f);
-					o[1] = static_cast<half_t>(valid ? activation<TANH>(v[1]) : 0.0f);
-					o[2] = static_cast<half_t>(valid ? activation<TANH>(v[2]) : 0.0f);
-					o[3] = static_cast<half_t>(valid ? activation<TANH>(v[3]) : 0.0f);
-					*reinterpret_cast<half4*>(ptr) = o;
+					if (TANH)
+					{
+						half4 o;
+						o[0] = static_cast<half_t>(valid ? activation<TANH>(v[0]) : 0.0f);
+						o[1] = static_cast<half_t>(valid ? activation<TANH>(v[1]) : 0.0f);
+						o[2] = static_cast<half_t>(valid ? activation<TANH>(v[2]) : 0.0f);
+						o[3] = static_cast<half_t>(valid ? activation<TANH>(v[3]) : 0.0f);
+						*reinterpret_cast<half4*>(ptr) = o;
+					}
+					else
+					{ // ReLU after the conversion (rounding is monotonic, so max(cvt(x), 0) == cvt(max(x, 0))) on packed halves, the spare
+					  // column / overhang cells masked to zero by an AND: 6 vector instructions per tile instead of 10
+						half2 lo { static_cast<half_t>(v[0]), static_cast<half_t>(v[1]) }, hi { static_cast<half_t>(v[2]), static_cast<half_t>(v[3]) };
+						const half2 zero2 { static_cast<half_t>(0.0f), static_cast<half_t>(0.0f) };
+						lo = __builtin_elementwise_max(lo, zero2);
+						hi = __builtin_elementwise_max(hi, zero2);
+						const uint32_t keep = valid ? 0xFFFFFFFFu : 0u;
+						uint2 packed;
+						packed.x = __builtin_bit_cast(uint32_t, lo) & keep;
+						packed.y = __builtin_bit_cast(uint32_t, hi) & keep;
+						*reinterpret_cast<uint2*>(ptr) = packed;
+					}
 				}
 		}
 		AGX_NN_MARK(4);
@@ -619,45 +644,106 @@ namespace
 			for (int n = 0; n < G::NTW; n++)
 				acc[i][n] = floatx4 { 0.0f, 0.0f, 0.0f, 0.0f };
 
-		// padded-plane index of the (dy = 0, dx = 0) input cell of this lane's position in every tile
-		int q0[G::NTW];
-#pragma unroll
-		for (int n = 0; n < G::NTW; n++)
+		if constexpr (G::S == 16 && AGX_NN_ROW_STATIONARY && AGX_NN_CONV5_ROWS && F == 64) // F = 128: the 2 x 10 weight fragments in flight spill, the tap loop is faster (measured)
 		{
-			const int pos = G::S + (n0 + n) * 16 + r;
-			const int x = pos % G::S;
-			const int y = pos / G::S - 1;
-			q0[n] = (y + 2) * G::S5 + (x + 2);
-		}
-
-		const half8 *wp = wpk + (mg * G::MT) * 64 + lane;
-		half8 a_next[G::MT]; // the next tap's weight fragments are requested one tap ahead (an L2 round trip is longer than a tap's MFMAs)
+			// Input-row stationary like conv3x3_mac_rows: for a column shift dx the fragment of padded input row j is read once and feeds the
+			// five taps dy = -2 .. 2 (output rows j + 2 .. j - 2): 5 x (NTW + 4) fragment reads instead of 25 x NTW, and — the padded plane being
+			// 2 cells wider than any shift on every side — no index clamping at all.
+			const half8 *wl = wpk + __builtin_amdgcn_readfirstlane(mg * G::MT * 64); // + lane; tap (dy, dx), tile i at ((dy * 5 + dx) * MTILES + i) * 64
+			half8 a_ring[2][5][G::MT];
 #pragma unroll
-		for (int i = 0; i < G::MT; i++)
-			a_next[i] = wp[i * 64];
-#pragma unroll 1
-		for (int t = 0; t < 25; t++)
-		{
-			const int off = (t / 5 - 2) * G::S5 + (t % 5 - 2);
-			half8 a[G::MT];
+			for (int dyi = 0; dyi < 5; dyi++)
 #pragma unroll
-			for (int i = 0; i < G::MT; i++)
-				a[i] = a_next[i];
-			const int tn = (t + 1 < 25) ? (t + 1) : 0;
+				for (int i = 0; i < G::MT; i++)
+					a_ring[0][dyi][i] = wl[((dyi * 5 + 0) * G::MTILES + i) * 64 + lane];
 #pragma unroll
-			for (int i = 0; i < G::MT; i++)
-				a_next[i] = wp[(tn * G::MTILES + i) * 64];
-#pragma unroll
-			for (int n = 0; n < G::NTW; n++)
-				if (n < my_tiles)
+			for (int dxi = 0; dxi < 5; dxi++)
+			{
+				if (dxi + 1 < 5)
 				{
-					int q = q0[n] + off;
-					q = (q < 0) ? 0 : ((q >= G::NPOS5) ? (G::NPOS5 - 1) : q); // only dummy (spare-column / overhang) positions can fall outside
-					const half8 b = *reinterpret_cast<const half8*>(in5 + (q * 4 + (q4 ^ ((q >> 2) & 3))) * 16);
 #pragma unroll
-					for (int i = 0; i < G::MT; i++)
-						acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b, acc[i][n], 0, 0, 0);
+					for (int dyi = 0; dyi < 5; dyi++)
+#pragma unroll
+						for (int i = 0; i < G::MT; i++)
+							a_ring[(dxi + 1) & 1][dyi][i] = wl[((dyi * 5 + dxi + 1) * G::MTILES + i) * 64 + lane];
 				}
+				// stored cell of this lane in padded row (n0 + j + 2): column r + (dxi - 2) + 2
+				auto fragment = [&](int j) -> half8
+				{
+					const int jj = (j <= my_tiles + 1) ? j : 0; // rows past the wave's last output row + 2 are not needed (and would leave the plane)
+					const int q = (n0 + jj + 2) * G::S5 + (r + dxi);
+					return *reinterpret_cast<const half8*>(in5 + (q * 4 + (q4 ^ ((q >> 2) & 3))) * 16);
+				};
+				constexpr int AHEAD = AGX_NN_AHEAD;
+				half8 b[AHEAD];
+#pragma unroll
+				for (int u = 0; u < AHEAD - 1; u++)
+					b[u] = fragment(u - 2);
+#pragma unroll
+				for (int j = -2; j <= G::NTW + 1; j++)
+				{
+					const int jn = j + AHEAD - 1;
+					if (jn <= G::NTW + 1)
+						b[(jn + 2) % AHEAD] = fragment(jn);
+#pragma unroll
+					for (int dyi = 0; dyi < 5; dyi++)
+					{
+						const int o = j - (dyi - 2);
+						if (o >= 0 && o < G::NTW && o < my_tiles)
+						{
+#pragma unroll
+							for (int i = 0; i < G::MT; i++)
+								acc[i][o] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_ring[dxi & 1][dyi][i], b[(j + 2) % AHEAD], acc[i][o], 0, 0, 0);
+						}
+					}
+#if AGX_NN_SCHED_GROUPS == 2
+					__builtin_amdgcn_sched_barrier(0);
+#endif
+				}
+			}
+		}
+		else
+		{
+			// padded-plane index of the (dy = 0, dx = 0) input cell of this lane's position in every tile
+			int q0[G::NTW];
+	#pragma unroll
+			for (int n = 0; n < G::NTW; n++)
+			{
+				const int pos = G::S + (n0 + n) * 16 + r;
+				const int x = pos % G::S;
+				const int y = pos / G::S - 1;
+				q0[n] = (y + 2) * G::S5 + (x + 2);
+			}
+
+			const half8 *wp = wpk + (mg * G::MT) * 64 + lane;
+			half8 a_next[G::MT]; // the next tap's weight fragments are requested one tap ahead (an L2 round trip is longer than a tap's MFMAs)
+	#pragma unroll
+			for (int i = 0; i < G::MT; i++)
+				a_next[i] = wp[i * 64];
+	#pragma unroll 1
+			for (int t = 0; t < 25; t++)
+			{
+				const int off = (t / 5 - 2) * G::S5 + (t % 5 - 2);
+				half8 a[G::MT];
+	#pragma unroll
+				for (int i = 0; i < G::MT; i++)
+					a[i] = a_next[i];
+				const int tn = (t + 1 < 25) ? (t + 1) : 0;
+	#pragma unroll
+				for (int i = 0; i < G::MT; i++)
+					a_next[i] = wp[(tn * G::MTILES + i) * 64];
+	#pragma unroll
+				for (int n = 0; n < G::NTW; n++)
+					if (n < my_tiles)
+					{
+						int q = q0[n] + off;
+						q = (q < 0) ? 0 : ((q >= G::NPOS5) ? (G::NPOS5 - 1) : q); // only dummy (spare-column / overhang) positions can fall outside
+						const half8 b = *reinterpret_cast<const half8*>(in5 + (q * 4 + (q4 ^ ((q >> 2) & 3))) * 16);
+	#pragma unroll
+						for (int i = 0; i < G::MT; i++)
+							acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b, acc[i][n], 0, 0, 0);
+					}
+			}
 		}
 		if (INPLACE)
 		{ // the padded input plane aliases the output plane: wait for every wave, clear the plane (zero borders), then write
@@ -729,7 +815,9 @@ namespace
 		__shared__ __attribute__((aligned(16))) char lds[LDS_TOTAL];
 		char *plane_x = lds;
 		char *plane_t = INPLACE ? lds : lds + G::PLANE_BYTES; // single-plane variant: every layer is computed in place
-		float *vbuf = reinterpret_cast<float*>(lds + (INPLACE ? 1 : 2) * G::PLANE_BYTES); // [HW*4]
+		float *vbuf = reinterpret_cast<float*>(lds + (INPLACE ? 1 : 2) * G::PLANE_BYTES); // [HW*4] + hid [D]: now the value head's conv1x1 weights as MFMA A fragments
+		half8 *s_wv1f = reinterpret_cast<half8*>(vbuf);                    // [KC][64]: lane l = unit (l & 15) (4 real, 12 zero), inputs kc*32 + 8*(l >> 4) .. + 7
+		static_assert(G::KC * 64 * 16 <= (G::HW * 4 + G::D) * 4, "value-head fragments must fit into the former vbuf + hid area");
 		float *hid = vbuf + G::HW * 4;                                     // [D]
 		float *red = hid + G::D;                                           // [8 + 256 + 8]: [0..7] wave partials, [8..8+D) value-head partials, [264..266] value logits
 		float *s_wv1 = red + 8 + 256 + 8;                                      // [F][4] value-head 1x1 weights (kept in LDS, not in registers)
@@ -747,8 +835,15 @@ namespace
 		const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
 		for (int i = tid; i < G::PLANE_BYTES / 16; i += G::THREADS)
 			reinterpret_cast<uint4*>(plane_x)[i] = zero4;
-		for (int i = tid; i < F * 4; i += G::THREADS)
-			s_wv1[i] = p.wv1[i];
+		for (int i = tid; i < G::KC * 64; i += G::THREADS)
+		{ // A fragments of the F x 4 value-head conv1x1 (p.wv1 is [F][4] fp32)
+			const int kc = i / 64, l = i % 64, unit = l & 15;
+			half8 f;
+#pragma unroll
+			for (int j = 0; j < 8; j++)
+				f[j] = static_cast<half_t>((unit < 4) ? p.wv1[(kc * 32 + 8 * (l >> 4) + j) * 4 + unit] : 0.0f);
+			s_wv1f[i] = f;
+		}
 		for (int i = tid; i < F; i += G::THREADS)
 			s_wp2[i] = p.wp2[i];
 		if (QHEAD)
@@ -821,30 +916,35 @@ namespace
 			// ---- value head, stage 1: conv1x1 F->4 + ReLU (NHWC flatten order).  The dense layers behind it run for ALL boards of the launch in
 			//      value_head_kernel: inside this kernel every board streamed the 0.46 MB of dense weights through one dependent chain per
 			//      thread (measured: 9 % of a board's time), batched they are one small GEMM on the matrix cores ----
-			for (int c = tid; c < G::HW; c += G::THREADS)
-			{
-				const int index = 1 + G::S + (c / COLS) * G::S + (c % COLS);
-				float s0 = p.bv1[0], s1 = p.bv1[1], s2 = p.bv1[2], s3 = p.bv1[3];
-				for (int k = 0; k < G::CH; k++)
+			{ // conv1x1 F -> 4 as one 16 x 16 output tile per 16 positions (4 of the 16 "channels" are real): K = F in KC steps; the 15 (NT)
+			  // position tiles are dealt round-robin to the 8 waves.  (As a per-thread dot product this stage took 4 % of a board's time with
+			  // more than half of the threads idle.)
+				const int r = lane & 15, q4 = lane >> 4;
+				for (int n = wave; n < G::NT; n += G::THREADS / 64)
 				{
-					const half8 xv = *reinterpret_cast<const half8*>(plane_x + plane_offset<G>(index, k));
+					floatx4 v { p.bv1[0], p.bv1[1], p.bv1[2], p.bv1[3] };
+					const int index0 = 1 + G::S + n * 16 + r;
+					const int swz0 = (index0 / G::PPR) % G::CH;
+					const char *src0 = plane_x + index0 * G::CH * 16;
 #pragma unroll
-					for (int j = 0; j < 8; j++)
+					for (int kc = 0; kc < G::KC; kc++)
 					{
-						const float xf = static_cast<float>(xv[j]);
-						const floatx4 w = *reinterpret_cast<const floatx4*>(s_wv1 + (k * 8 + j) * 4);
-						s0 += xf * w[0];
-						s1 += xf * w[1];
-						s2 += xf * w[2];
-						s3 += xf * w[3];
+						const half8 bfrag = *reinterpret_cast<const half8*>(src0 + (((kc * 4 + q4) ^ swz0) * 16));
+						v = __builtin_amdgcn_mfma_f32_16x16x32_f16(s_wv1f[kc * 64 + lane], bfrag, v, 0, 0, 0);
+					}
+					// lanes with q4 == 0 hold outputs 0 .. 3 of position r of tile n (the bias of the other, unused rows is irrelevant)
+					const int pos = G::S + n * 16 + r;
+					const int x = pos % G::S, y = pos / G::S - 1;
+					if (q4 == 0 && x < COLS && y < ROWS)
+					{
+						half4 o;
+						o[0] = static_cast<half_t>(fmaxf(v[0], 0.0f));
+						o[1] = static_cast<half_t>(fmaxf(v[1], 0.0f));
+						o[2] = static_cast<half_t>(fmaxf(v[2], 0.0f));
+						o[3] = static_cast<half_t>(fmaxf(v[3], 0.0f));
+						*reinterpret_cast<half4*>(p.vhead_x + static_cast<size_t>(bi) * G::KPAD + (y * COLS + x) * 4) = o;
 					}
 				}
-				half4 o;
-				o[0] = static_cast<half_t>(fmaxf(s0, 0.0f));
-				o[1] = static_cast<half_t>(fmaxf(s1, 0.0f));
-				o[2] = static_cast<half_t>(fmaxf(s2, 0.0f));
-				o[3] = static_cast<half_t>(fmaxf(s3, 0.0f));
-				*reinterpret_cast<half4*>(p.vhead_x + static_cast<size_t>(bi) * G::KPAD + c * 4) = o;
 			}
 			AGX_NN_MARK(6);
 			// ---- policy head: conv3x3 + ReLU into plane_t ----
