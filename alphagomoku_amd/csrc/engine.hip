@@ -1916,7 +1916,7 @@ int agx_engine_create(const AgxEngineConfig *cfg, AgxEngine **out)
 	d.record_format = cfg->record_format;
 	d.sample_cap = cfg->record_sample_capacity > 0 ? cfg->record_sample_capacity
 			: static_cast<int>(std::min<size_t>(static_cast<size_t>(d.record_cap) * (16 + 6 * static_cast<size_t>(d.hw) + 2), 0x7FFFFFF0u)); // every cell an entry
-	d.game_end_cap = cfg->game_end_capacity > 0 ? cfg->game_end_capacity : 2 * d.n_games;
+	d.game_end_cap = cfg->game_end_capacity > 0 ? cfg->game_end_capacity : std::max(2 * d.n_games, d.record_cap / 16); // the record pool fills first
 
 	HostTables tables;
 	build_host_tables(cfg->rules, tables);

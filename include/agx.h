@@ -171,7 +171,7 @@ typedef struct AgxEngineConfig
 	                                     16-byte header + 6 bytes per visited / proven cell) — a quarter of the bytes to keep and copy;
 	                                     3 = both.  Finished games are always reported (AgxGameEnd). */
 	int record_sample_capacity;       /* bytes of the format-201 sample pool, 0 = room for an entry on every cell of every record (capped at 2 GiB) */
-	int game_end_capacity;            /* finished-game records kept on the device, 0 = 2 * n_games */
+	int game_end_capacity;            /* finished-game records kept on the device, 0 = max(2 * n_games, record_capacity / 16) */
 } AgxEngineConfig;
 
 typedef struct AgxEngine AgxEngine; /* opaque */

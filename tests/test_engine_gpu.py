@@ -592,21 +592,36 @@ def test_pool_step_with_device_network_is_deterministic_and_consistent(agx_lib):
     net.close()
 
 
-def test_full_size_pool_matches_a_small_pool_game_by_game(agx_lib):
-    """BASELINE configs[1] size (1024 games, 6x128 network, 400 playouts, batch 8, yielding on): games are independent, so every
-    game of the big pool must play exactly what the same opening plays in a 12-game pool without yielding (whose behaviour the
-    other tests pin to the oracle step by step) — a size-independent property checked at full size."""
+FULL_SIZE = {
+    # BASELINE.json configs at bench.py's sizes: rules, board, network, playouts, steps of the big pool, steps of the small pool
+    "C2-freestyle-15x15-6x128-400": dict(rules=0, n=15, blocks=6, sims=400, big_steps=160, small_steps=260),
+    "C3-standard-15x15-10x128-800": dict(rules=1, n=15, blocks=10, sims=800, big_steps=260, small_steps=420),
+    "C4-caro5-20x20-10x128-400": dict(rules=3, n=20, blocks=10, sims=400, big_steps=160, small_steps=260),
+    "C5-renju-15x15-10x128-1600": dict(rules=2, n=15, blocks=10, sims=1600, big_steps=460, small_steps=760),
+}
+
+
+@pytest.mark.parametrize("name", list(FULL_SIZE))
+def test_full_size_pool_matches_a_small_pool_game_by_game(agx_lib, name):
+    """BASELINE configs[1..4] at FULL size — 1024 games, the config's network in the loop, its playout budget, batch 8, yielding on, the
+    reference's 4 Mi-entry solver table per game and bench.py's arena sizes: games are independent, so every game of the big pool must play
+    exactly what the same opening plays in a 12-game pool without yielding (whose behaviour the other tests pin to the oracle step by
+    step) — a size-independent property checked at full size; the arenas must hold (first_error == 0)."""
     from alphagomoku_amd import selfplay
     from alphagomoku_amd.networks import AGNetwork
-    d = synthetic.net_desc(blocks=6, filters=128)
+    c = FULL_SIZE[name]
+    n, sims = c["n"], c["sims"]
+    d = synthetic.net_desc(rows=n, cols=n, blocks=c["blocks"], filters=128)
     blob, _ = synthetic.make_weights(d)
     net = AGNetwork(d)
     net.loadWeights(blob)
-    openings = synthetic.make_openings(N, 1024, seed0=900)
+    openings = synthetic.make_openings(n, 1024, seed0=900, rules=c["rules"])
 
     def run(games, steps, yield_fraction):
-        pool = selfplay.GeneratorPool(selfplay.default_config(n_games=games, max_batch_size=8, max_simulations=400, tss_table_entries=1 << 16,
-                                                              node_capacity=4096, edge_capacity=131072, solver_yield_fraction=yield_fraction))
+        pool = selfplay.GeneratorPool(selfplay.default_config(rules=c["rules"], board_size=n, draw_after=n * n, n_games=games, max_batch_size=8, max_simulations=sims,
+                                                              tss_table_entries=4 * 1024 * 1024, node_capacity=max(8192, 16 * sims),
+                                                              edge_capacity=max(262144, 1536 * sims), solver_yield_fraction=yield_fraction,
+                                                              record_capacity=games * 64, record_edge_capacity=games * 64 * n * n))
         pool.begin(selfplay.pack_openings(openings[:games]))   # no spare openings: a finished game stays finished
         for _ in range(steps):
             pool.step(net)
@@ -618,10 +633,10 @@ def test_full_size_pool_matches_a_small_pool_game_by_game(agx_lib):
                                                            tuple((e.move, e.visits, e.score) for e in edges[r.edge_offset:r.edge_offset + r.n_edges])))
         pool.close()
         return st, {g: sorted(v) for g, v in per_game.items()}
-    big_stats, big = run(1024, 160, 0.75)
-    small_stats, small = run(12, 260, 0.0)
+    big_stats, big = run(1024, c["big_steps"], 0.75)
+    small_stats, small = run(12, c["small_steps"], 0.0)
     assert big_stats["first_error"] == 0 and small_stats["first_error"] == 0
-    assert big_stats["moves_played"] > 1024 and big_stats["evaluated_nodes"] > 1024 * 400
+    assert big_stats["moves_played"] > 1024 and big_stats["evaluated_nodes"] > 1024 * sims
     compared = 0
     for g in range(12):
         a, b = big.get(g, []), small.get(g, [])
@@ -631,6 +646,15 @@ def test_full_size_pool_matches_a_small_pool_game_by_game(agx_lib):
         compared += k
     assert compared >= 24
     net.close()
+
+
+def test_whole_games_with_the_reference_table_size(agx_lib, olib):
+    """the solver's transposition table at the reference's size (4 Mi entries = 64 MB per game, AlphaBetaSearch.cpp:59): bucket choice and
+    replacement depend on the table size, so the BASELINE size gets its own step-by-step comparison with the oracle"""
+    compared, stats = _play_and_compare(olib, 0, games=3, batch=8, sims=100, max_steps=4000, evaluator=_stand_in_evaluator(olib), table_entries=4 * 1024 * 1024)
+    assert compared > 300 and stats["games_finished"] == 3
+    compared, stats = _play_and_compare(olib, 2, games=2, batch=4, sims=100, max_steps=4000, evaluator=_stand_in_evaluator(olib), table_entries=4 * 1024 * 1024)
+    assert compared > 150 and stats["games_finished"] == 2
 
 
 def test_engine_error_paths(agx_lib):

@@ -16,6 +16,39 @@ EDGE_TOL = 5e-2
 DEEP_TOL = 3e-2
 
 
+def relative_logit_error(p, pr, floor=1.0e-7):
+    """largest |log p - log p_ref| over the cells the reference gives more than `floor`, relative to the reference's logit range:
+    a scale-free bound on the PRE-softmax outputs (softmax outputs of near one-hot policies hide or exaggerate logit errors)"""
+    worst = 0.0
+    for a, b in zip(p, pr):
+        m = b > floor
+        d = np.abs(np.log(np.maximum(a[m], 1e-30)) - np.log(b[m]))
+        span = max(1.0, float(np.log(b[m]).max() - np.log(b[m]).min()))
+        worst = max(worst, float(d.max()) / span)
+    return worst
+
+
+@pytest.mark.parametrize("rows", [15, 20])
+def test_deep_network_tolerance(agx_lib, rows):
+    """the 10-block / 128-filter tower of BASELINE configs C3-C5: (a) with activations of order one (residual branches scaled like a trained
+    tower's) the softmax outputs agree with the fp32 oracle within 1e-2 absolute — the survey's bound; (b) with plain He-init weights
+    (activations grow with depth, near one-hot policies) the pre-softmax logits still agree within 2e-2 of their range"""
+    from alphagomoku_amd.networks import AGNetwork
+    from oracle import nn_ref
+    f = synthetic.random_features(8, rows, rows, seed=31 + rows)
+    for gain, softmax_tol in [(0.5, 1.0e-2), (1.0, DEEP_TOL)]:
+        d = synthetic.net_desc(rows=rows, cols=rows, blocks=10, filters=128)
+        blob, _ = synthetic.make_weights(d, residual_gain=gain)
+        net = AGNetwork(d)
+        net.loadWeights(blob)
+        p, v = net.forward(f)
+        pr, vr = nn_ref.forward(d, blob, f)
+        assert np.abs(p - pr).max() <= softmax_tol and np.abs(v - vr).max() <= softmax_tol, gain
+        assert relative_logit_error(p, pr) <= 2.0e-2, gain
+        assert (p.argmax(1) == pr.argmax(1)).all()
+        net.close()
+
+
 @pytest.mark.parametrize("blocks,filters", [(2, 64), (6, 128), (10, 128)])
 def test_forward_matches_oracle(agx_lib, blocks, filters):
     from alphagomoku_amd.networks import AGNetwork
