@@ -85,7 +85,7 @@ class AgxEngineConfig(ctypes.Structure):
                 ("solver_yield_fraction", ctypes.c_float), ("final_selector", ctypes.c_int), ("use_symmetries", ctypes.c_int),
                 ("symmetry_seed", ctypes.c_uint64), ("max_children", ctypes.c_int), ("noise_type", ctypes.c_int), ("noise_weight", ctypes.c_float),
                 ("noise_seed", ctypes.c_uint64), ("action_values", ctypes.c_int), ("match_mode", ctypes.c_int), ("policy_temperature", ctypes.c_float),
-                ("record_format", ctypes.c_int), ("record_sample_capacity", ctypes.c_int), ("game_end_capacity", ctypes.c_int)]
+                ("arena_reserve", ctypes.c_float), ("record_format", ctypes.c_int), ("record_sample_capacity", ctypes.c_int), ("game_end_capacity", ctypes.c_int)]
 
 
 class AgxEngineBuffers(ctypes.Structure):
@@ -100,7 +100,8 @@ class AgxEngineStats(ctypes.Structure):
                  "duplicate_selections", "solver_nodes", "select_levels", "select_edge_reads", "moves_played", "peak_nodes",
                  "peak_edges"]] + [(n, ctypes.c_int) for n in
                                    ["games_finished", "openings_taken", "active_games", "records_used", "record_edges_used",
-                                    "first_error"]]
+                                    "first_error", "arena_grows", "arena_releases", "arena_failures", "arena_max_class"]] + \
+               [("arena_heap_used", ctypes.c_float)]
 
 
 class AgxEdgeView(ctypes.Structure):

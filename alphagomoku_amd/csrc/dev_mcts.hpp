@@ -21,9 +21,18 @@ namespace agx
 {
 	namespace dev
 	{
-		__device__ __forceinline__ DNode* nodes_of(const EngineDev &E, int g, int arena) { return E.nodes + (static_cast<size_t>(g) * 2 + arena) * E.node_cap; }
-		__device__ __forceinline__ DEdge* edges_of(const EngineDev &E, int g, int arena) { return E.edges + (static_cast<size_t>(g) * 2 + arena) * E.edge_cap; }
-		__device__ __forceinline__ int* ht_of(const EngineDev &E, int g) { return E.ht + static_cast<size_t>(g) * E.ht_cap; }
+		/* a game's arenas are regions of the pool-wide heaps; kernels fetch these bases once per launch.  NB E.node_cap / E.edge_cap /
+		 * E.ht_cap are the CLASS-0 capacities in the host's copy: a kernel that works on one game overrides them in its by-value copy of E
+		 * with that game's capacities (use_game_arenas) before calling anything below. */
+		__device__ __forceinline__ DNode* nodes_of(const EngineDev &E, int g, int arena) { return E.nodes + E.games[g].node_off[arena]; }
+		__device__ __forceinline__ DEdge* edges_of(const EngineDev &E, int g, int arena) { return E.edges + E.games[g].edge_off[arena]; }
+		__device__ __forceinline__ int* ht_of(const EngineDev &E, int g) { return E.ht + E.games[g].ht_off; }
+		__device__ __forceinline__ void use_game_arenas(EngineDev &E, int g)
+		{
+			E.node_cap = E.games[g].node_cap;
+			E.edge_cap = E.games[g].edge_cap;
+			E.ht_cap = E.games[g].ht_cap;
+		}
 
 		/* NodeCache::seek (NodeCache.cpp:250-264): hash, side to move and the FULL (compressed) board must match */
 		__device__ inline int cache_seek(const EngineDev &E, const DNode *nodes, const int *ht, u64 hash, const u64 *cboard, int sign, int lane)

@@ -41,8 +41,9 @@ namespace
 		__shared__ u64 sh_keys[3 * (1 + MAXHW)]; // FullZobristHashing keys of the node cache: four per level, from LDS instead of L2
 		const int g = E.g0 + blockIdx.x, lane = threadIdx.x;
 		GameState &gs = E.games[g];
-		if (!gs.active || gs.error != 0 || gs.outcome != 0 || gs.solve_pending)
-			return;
+		if (!gs.active || gs.error != 0 || gs.outcome != 0 || gs.solve_pending || gs.grow_pending)
+			return; // (grow_pending: the previous batch still waits for its expansion in larger arenas)
+		use_game_arenas(E, g);
 		for (int i = lane; i < 3 * (1 + E.hw); i += 64)
 			sh_keys[i] = E.nc_keys[i];
 		DNode *nodes = nodes_of(E, g, gs.arena);
@@ -370,7 +371,7 @@ namespace
 		__shared__ SolverShared sh;
 		const int g = E.g0 + blockIdx.x, lane = threadIdx.x;
 		GameState &gs = E.games[g];
-		const bool idle = (!gs.active || gs.error != 0 || gs.outcome != 0);
+		const bool idle = (!gs.active || gs.error != 0 || gs.outcome != 0 || gs.grow_pending != 0);
 		const int n_tasks = idle ? 0 : gs.n_tasks;
 		if (n_tasks > 0)
 			solver_load_threat_table(sh, E, lane);
@@ -483,13 +484,36 @@ namespace
 		__shared__ u64 sort_keys[512]; // prune_weak_moves with max_children: (score band, prior, original index) of every edge
 		const int g = E.g0 + blockIdx.x, lane = threadIdx.x;
 		GameState &gs = E.games[g];
-		if (!gs.active || gs.error != 0 || gs.outcome != 0 || gs.solve_pending)
+		if (!gs.active || gs.error != 0 || gs.outcome != 0 || gs.solve_pending || gs.grow_pending == 1 || gs.grow_pending == 3)
 			return;
+		use_game_arenas(E, g);
 		DNode *nodes = nodes_of(E, g, gs.arena);
 		DEdge *edges = edges_of(E, g, gs.arena);
 		int *ht = ht_of(E, g);
 		const int n = E.n, hw = E.hw;
 		const int n_tasks = gs.n_tasks;
+		{
+			/*
+			 * NodeCache::resize / ObjectPool growth (NodeCache.cpp:320-355, utils/ObjectPool.hpp:74-289) for flat arenas: BEFORE anything is
+			 * modified, the batch's worst case (a node per task, every solver edge kept) is held against the game's arenas.  If it does not
+			 * fit, the game asks for the next size class and sits this stage out with its batch untouched: k_arena_service / k_arena_copy
+			 * move the tree into larger regions, select and solve skip the game in the next step, and this kernel then expands the SAME
+			 * batch — the game performs exactly the same sequence of operations, one step later.
+			 */
+			int need_edges = gs.n_edges;
+			for (int k = 0; k < n_tasks; k++)
+				need_edges += E.tasks[static_cast<size_t>(g) * E.batch + k].n_edges;
+			const int need_nodes = gs.n_nodes + n_tasks;
+			const bool fits = need_nodes <= E.node_cap && need_edges <= E.edge_cap && 2 * need_nodes <= E.ht_cap;
+			if (!fits && gs.arena_class + 1 < ARENA_CLASSES && gs.grow_pending == 0)
+			{
+				if (lane == 0)
+					gs.grow_pending = 1;
+				return;
+			}
+			if (lane == 0)
+				gs.grow_pending = 0; // 2 -> 0: grown (or no larger class / no heap space left: the exact per-node test below decides)
+		}
 		const u64 lower = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 		unsigned long long wasted = 0;
 
@@ -887,7 +911,7 @@ namespace
 	__device__ void clear_tree_and_table(const EngineDev &E, int g, int tid)
 	{ // Tree::clear + AlphaBetaSearch::clear (GameGenerator.cpp:52-53)
 		int *ht = ht_of(E, g);
-		for (int i = tid; i < E.ht_cap; i += 256)
+		for (int i = tid; i < E.games[g].ht_cap; i += 256)
 			ht[i] = 0;
 		clear_solver_table(E, g, tid);
 	}
@@ -948,8 +972,10 @@ namespace
 	 * NodeCache::cleanup (NodeCache.cpp:221-249) as keep-test + prefix sum + copy to the other arena, Search::setBoard
 	 * (increaseGeneration), Tree::setBoard (root = seek(new board), Tree.cpp:146-149).  Whole 256-thread workgroup.
 	 */
-	__device__ void rebase_tree(const EngineDev &E, int t, int tid, u64 *scratch, int *scan_nodes, int *scan_edges)
+	__device__ void rebase_tree(const EngineDev &E0, int t, int tid, u64 *scratch, int *scan_nodes, int *scan_edges)
 	{
+		EngineDev E = E0;
+		use_game_arenas(E, t); // (in match mode t is the partner's tree, not the workgroup's own game)
 		GameState &gs = E.games[t];
 		const int lane = tid & 63, wave = tid >> 6;
 		DNode *nodes = nodes_of(E, t, gs.arena);
@@ -1117,8 +1143,9 @@ namespace
 		__shared__ uint32_t sh_max[3];
 		const int g = E.g0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 		GameState &gs = E.games[g];
-		if (!gs.active || gs.error != 0 || !gs.need_move || gs.solve_pending)
+		if (!gs.active || gs.error != 0 || !gs.need_move || gs.solve_pending || gs.grow_pending)
 			return;
+		use_game_arenas(E, g);
 		DNode *nodes = nodes_of(E, g, gs.arena);
 		DEdge *edges = edges_of(E, g, gs.arena);
 		const int n = E.n;
@@ -1560,7 +1587,7 @@ namespace
 		if (!E.match_mode)
 		{
 			int *ht = ht_of(E, g);
-			for (int i = part * 256 + tid; i < E.ht_cap; i += parts * 256)
+			for (int i = part * 256 + tid; i < E.games[g].ht_cap; i += parts * 256)
 				ht[i] = 0;
 		}
 	}
@@ -1634,6 +1661,212 @@ namespace
 		rebase_tree(E, mover, tid, scratch, scan_nodes, scan_edges);
 		if (tid == 0)
 			E.games[mover].active = 1;
+	}
+
+	/*
+	 * Arena heap service, once per step after k_advance: ONE workgroup; its thread 0 is the only allocator, so the per-class free lists
+	 * need no lock.  (1) games that ended with a grown bundle give it back and return to class 0 (self-play only: a match player keeps its
+	 * tree); (2) games whose expand asked for room get a bundle of the next class reserved (copied over by k_arena_copy).
+	 */
+	/* The heap and its free lists are shared by the whole pool, and slices of a pool may be stepped on different streams: every access goes
+	 * through agent-scope atomics under one spin lock (taken by a single thread of a workgroup, for a handful of words). */
+	template<typename T>
+	__device__ __forceinline__ T heap_load(T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+	template<typename T>
+	__device__ __forceinline__ void heap_store(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+	__device__ void heap_lock(ArenaHeap *h)
+	{
+		int expected = 0;
+		while (!__hip_atomic_compare_exchange_strong(&h->lock, &expected, 1, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+		{
+			expected = 0;
+			__builtin_amdgcn_s_sleep(2);
+		}
+	}
+	__device__ void heap_unlock(ArenaHeap *h) { __hip_atomic_store(&h->lock, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+	__device__ void bundle_store(ArenaBundle *dst, const ArenaBundle &b)
+	{
+		heap_store(&dst->node_off[0], b.node_off[0]);
+		heap_store(&dst->node_off[1], b.node_off[1]);
+		heap_store(&dst->edge_off[0], b.edge_off[0]);
+		heap_store(&dst->edge_off[1], b.edge_off[1]);
+		heap_store(&dst->ht_off, b.ht_off);
+	}
+	__device__ bool arena_alloc(const EngineDev &E, int cls, ArenaBundle &out)
+	{ // one calling thread per workgroup
+		ArenaHeap *h = E.heap;
+		bool ok = true;
+		heap_lock(h);
+		const int free_count = heap_load(&h->free_count[cls]);
+		if (free_count > 0)
+		{
+			ArenaBundle *src = E.free_bundles + static_cast<size_t>(cls) * h->free_capacity + (free_count - 1);
+			out.node_off[0] = heap_load(&src->node_off[0]);
+			out.node_off[1] = heap_load(&src->node_off[1]);
+			out.edge_off[0] = heap_load(&src->edge_off[0]);
+			out.edge_off[1] = heap_load(&src->edge_off[1]);
+			out.ht_off = heap_load(&src->ht_off);
+			heap_store(&h->free_count[cls], free_count - 1);
+		}
+		else
+		{
+			const u64 nodes = static_cast<u64>(E.node_cap) << cls, edges = static_cast<u64>(E.edge_cap) << cls, ht = static_cast<u64>(E.ht_cap) << cls;
+			const u64 nc = heap_load(&h->node_cursor), ec = heap_load(&h->edge_cursor), hc = heap_load(&h->ht_cursor);
+			if (nc + 2 * nodes > h->node_total || ec + 2 * edges > h->edge_total || hc + ht > h->ht_total)
+				ok = false;
+			else
+			{
+				out.node_off[0] = nc;
+				out.node_off[1] = nc + nodes;
+				out.edge_off[0] = ec;
+				out.edge_off[1] = ec + edges;
+				out.ht_off = hc;
+				heap_store(&h->node_cursor, nc + 2 * nodes);
+				heap_store(&h->edge_cursor, ec + 2 * edges);
+				heap_store(&h->ht_cursor, hc + ht);
+			}
+		}
+		heap_unlock(h);
+		return ok;
+	}
+	__device__ void arena_free(const EngineDev &E, int cls, const GameState &gs)
+	{ // one calling thread per workgroup
+		ArenaHeap *h = E.heap;
+		ArenaBundle b;
+		b.node_off[0] = gs.node_off[0];
+		b.node_off[1] = gs.node_off[1];
+		b.edge_off[0] = gs.edge_off[0];
+		b.edge_off[1] = gs.edge_off[1];
+		b.ht_off = gs.ht_off;
+		heap_lock(h);
+		const int free_count = heap_load(&h->free_count[cls]);
+		if (free_count < h->free_capacity)
+		{ // (the lists hold one entry per game and class: always true; a bundle that found no room would be leaked, never handed out twice)
+			bundle_store(E.free_bundles + static_cast<size_t>(cls) * h->free_capacity + free_count, b);
+			heap_store(&h->free_count[cls], free_count + 1);
+		}
+		heap_unlock(h);
+	}
+	__global__ __launch_bounds__(1024) void k_arena_service(EngineDev E, int count)
+	{
+		__shared__ int sh_list[1024];
+		__shared__ int sh_n;
+		const int tid = threadIdx.x;
+		for (int start = 0; start < count; start += 1024)
+		{
+			if (tid == 0)
+				sh_n = 0;
+			__syncthreads();
+			const int i = start + tid;
+			if (i < count)
+			{
+				const GameState &gs = E.games[E.g0 + i];
+				const bool release = !E.match_mode && gs.restart_id == -1 && gs.arena_class > 0 && gs.grow_pending == 0;
+				if (gs.grow_pending == 1 || release)
+					sh_list[atomicAdd(&sh_n, 1)] = i;
+			}
+			__syncthreads();
+			if (tid == 0)
+			{
+				// requests in game order (the lanes appended them in any order): results do not depend on it, the heap layout stays reproducible
+				for (int a = 1; a < sh_n; a++)
+					for (int b = a; b > 0 && sh_list[b - 1] > sh_list[b]; b--)
+					{
+						const int tmp = sh_list[b];
+						sh_list[b] = sh_list[b - 1];
+						sh_list[b - 1] = tmp;
+					}
+				for (int k = 0; k < sh_n; k++)
+				{
+					GameState &gs = E.games[E.g0 + sh_list[k]];
+					if (gs.grow_pending == 1)
+					{
+						ArenaBundle nb;
+						if (arena_alloc(E, gs.arena_class + 1, nb))
+						{
+							gs.new_node_off[0] = nb.node_off[0];
+							gs.new_node_off[1] = nb.node_off[1];
+							gs.new_edge_off[0] = nb.edge_off[0];
+							gs.new_edge_off[1] = nb.edge_off[1];
+							gs.new_ht_off = nb.ht_off;
+							gs.grow_pending = 3;
+							atomicAdd(&E.heap->grows, 1);
+						}
+						else
+						{ // heap exhausted: the game carries on in its arenas; if the batch really overflows them, k_expand reports it
+							gs.grow_pending = 2;
+							atomicAdd(&E.heap->failures, 1);
+						}
+					}
+					else
+					{ // a finished game hands its grown bundle back and waits for its next opening in class-0 arenas
+						ArenaBundle nb;
+						if (arena_alloc(E, 0, nb))
+						{
+							arena_free(E, gs.arena_class, gs);
+							gs.node_off[0] = nb.node_off[0];
+							gs.node_off[1] = nb.node_off[1];
+							gs.edge_off[0] = nb.edge_off[0];
+							gs.edge_off[1] = nb.edge_off[1];
+							gs.ht_off = nb.ht_off;
+							gs.arena_class = 0;
+							gs.node_cap = E.node_cap;
+							gs.edge_cap = E.edge_cap;
+							gs.ht_cap = E.ht_cap;
+							atomicAdd(&E.heap->releases, 1);
+						}
+					}
+				}
+			}
+			__syncthreads();
+		}
+	}
+	/* moves a game's tree into the bundle k_arena_service reserved for it: nodes and edges of the active arena copied as they are (indices
+	 * stay valid), the node-cache table rebuilt at its new size; then the old bundle goes onto the free list (thread 0 of the NEXT service
+	 * launch is the only other writer of the lists, and launches of one stream are ordered) */
+	__global__ __launch_bounds__(256) void k_arena_copy(EngineDev E)
+	{
+		const int g = E.g0 + blockIdx.x, tid = threadIdx.x;
+		GameState &gs = E.games[g];
+		if (gs.grow_pending != 3)
+			return;
+		const int cls = gs.arena_class + 1;
+		const int new_ht_cap = E.ht_cap << cls;
+		const DNode *src_nodes = nodes_of(E, g, gs.arena);
+		const u64 *src_edges = reinterpret_cast<const u64*>(edges_of(E, g, gs.arena));
+		DNode *dst_nodes = E.nodes + gs.new_node_off[gs.arena];
+		u64 *dst_edges = reinterpret_cast<u64*>(E.edges + gs.new_edge_off[gs.arena]);
+		int *ht = E.ht + gs.new_ht_off;
+		for (int i = tid; i < new_ht_cap; i += 256)
+			ht[i] = 0;
+		for (size_t i = tid; i < 3 * static_cast<size_t>(gs.n_edges); i += 256)
+			dst_edges[i] = src_edges[i];
+		__syncthreads();
+		const int mask = new_ht_cap - 1;
+		for (int i = tid; i < gs.n_nodes; i += 256)
+		{
+			const DNode nd = src_nodes[i];
+			dst_nodes[i] = nd;
+			int slot = static_cast<int>(nd.hash & static_cast<u64>(mask));
+			while (atomicCAS(&ht[slot], 0, i + 1) != 0)
+				slot = (slot + 1) & mask;
+		}
+		__syncthreads();
+		if (tid == 0)
+		{
+			arena_free(E, gs.arena_class, gs);
+			gs.node_off[0] = gs.new_node_off[0];
+			gs.node_off[1] = gs.new_node_off[1];
+			gs.edge_off[0] = gs.new_edge_off[0];
+			gs.edge_off[1] = gs.new_edge_off[1];
+			gs.ht_off = gs.new_ht_off;
+			gs.arena_class = cls;
+			gs.node_cap = E.node_cap << cls;
+			gs.edge_cap = E.edge_cap << cls;
+			gs.ht_cap = new_ht_cap;
+			gs.grow_count++;
+			gs.grow_pending = 2;
+		}
 	}
 
 	__global__ void k_reset_counter(int *counter, int *second)
@@ -1853,6 +2086,7 @@ int agx_engine_default_config(AgxEngineConfig *cfg)
 	cfg->action_values = 0;
 	cfg->match_mode = 0;
 	cfg->policy_temperature = 1.0f;
+	cfg->arena_reserve = 1.0f;
 	cfg->record_format = 1;
 	cfg->record_sample_capacity = 0;
 	cfg->game_end_capacity = 0;
@@ -1933,9 +2167,17 @@ int agx_engine_create(const AgxEngineConfig *cfg, AgxEngine **out)
 	const size_t G = d.n_games;
 #define AGX_TRY(expr) if (status == AGX_OK) status = (expr)
 	AGX_TRY(dev_alloc(e, &d.games, G));
-	AGX_TRY(dev_alloc(e, &d.nodes, G * 2 * d.node_cap));
-	AGX_TRY(dev_alloc(e, &d.edges, G * 2 * d.edge_cap));
-	AGX_TRY(dev_alloc(e, &d.ht, G * d.ht_cap));
+	// tree arenas: pool-wide heaps; every game starts with a class-0 bundle (2 x node_cap nodes, 2 x edge_cap edges, ht_cap table slots),
+	// the reserve behind them feeds the games that outgrow theirs (k_arena_service)
+	const double reserve = (cfg->arena_reserve >= 0.0f) ? cfg->arena_reserve : 1.0;
+	const size_t node_total = static_cast<size_t>(static_cast<double>(G * 2 * d.node_cap) * (1.0 + reserve));
+	const size_t edge_total = static_cast<size_t>(static_cast<double>(G * 2 * d.edge_cap) * (1.0 + reserve));
+	const size_t ht_total = static_cast<size_t>(static_cast<double>(G * d.ht_cap) * (1.0 + reserve));
+	AGX_TRY(dev_alloc(e, &d.nodes, node_total));
+	AGX_TRY(dev_alloc(e, &d.edges, edge_total));
+	AGX_TRY(dev_alloc(e, &d.ht, ht_total));
+	AGX_TRY(dev_alloc(e, &d.heap, 1));
+	AGX_TRY(dev_alloc(e, &d.free_bundles, static_cast<size_t>(ARENA_CLASSES) * G));
 	AGX_TRY(dev_alloc(e, &d.tasks, G * d.batch));
 	AGX_TRY(dev_alloc(e, &d.act, G * d.act_cap));
 	AGX_TRY(dev_alloc(e, &d.tt, G * buckets * 8));
@@ -1962,7 +2204,31 @@ int agx_engine_create(const AgxEngineConfig *cfg, AgxEngine **out)
 #undef AGX_TRY
 	if (status == AGX_OK)
 	{
-		hipError_t err = hipMemset(d.games, 0, G * sizeof(GameState));
+		std::vector<GameState> games(G);
+		std::memset(static_cast<void*>(games.data()), 0, G * sizeof(GameState));
+		for (size_t g = 0; g < G; g++)
+		{
+			games[g].node_off[0] = (2 * g) * d.node_cap;
+			games[g].node_off[1] = (2 * g + 1) * d.node_cap;
+			games[g].edge_off[0] = (2 * g) * static_cast<uint64_t>(d.edge_cap);
+			games[g].edge_off[1] = (2 * g + 1) * static_cast<uint64_t>(d.edge_cap);
+			games[g].ht_off = g * static_cast<uint64_t>(d.ht_cap);
+			games[g].node_cap = d.node_cap;
+			games[g].edge_cap = d.edge_cap;
+			games[g].ht_cap = d.ht_cap;
+		}
+		ArenaHeap heap;
+		std::memset(&heap, 0, sizeof(heap));
+		heap.node_cursor = G * 2 * d.node_cap;
+		heap.edge_cursor = G * 2 * static_cast<uint64_t>(d.edge_cap);
+		heap.ht_cursor = G * static_cast<uint64_t>(d.ht_cap);
+		heap.node_total = node_total;
+		heap.edge_total = edge_total;
+		heap.ht_total = ht_total;
+		heap.free_capacity = static_cast<int32_t>(G);
+		hipError_t err = hipMemcpy(d.games, games.data(), G * sizeof(GameState), hipMemcpyHostToDevice);
+		if (err == hipSuccess)
+			err = hipMemcpy(d.heap, &heap, sizeof(heap), hipMemcpyHostToDevice);
 		if (err == hipSuccess)
 			err = hipMemset(d.counters, 0, 64 * sizeof(int));
 		if (err == hipSuccess)
@@ -2175,6 +2441,8 @@ int agx_engine_expand_backup_match(AgxEngine *e, void *stream)
 		KernelTimer t(e, s, 3);
 		// a moving tree's workgroup also rebases its partner's tree; the partner's own workgroup has nothing to do (it is not searching)
 		hipLaunchKernelGGL(k_advance, dim3(d.n_games), dim3(256), 0, s, d);
+		hipLaunchKernelGGL(k_arena_service, dim3(1), dim3(1024), 0, s, d, d.n_games);
+		hipLaunchKernelGGL(k_arena_copy, dim3(d.n_games), dim3(256), 0, s, d);
 		hipLaunchKernelGGL(k_assign_openings, dim3(1), dim3(1024), 0, s, d, d.n_games / 2);
 		hipLaunchKernelGGL(k_clear_tables, dim3(d.n_games * CLEAR_PARTS), dim3(256), 0, s, d, CLEAR_PARTS);
 		hipLaunchKernelGGL(k_match_restart, dim3(d.n_games / 2), dim3(256), 0, s, d);
@@ -2255,6 +2523,8 @@ int agx_engine_advance_group(AgxEngine *e, int group, int n_groups, void *stream
 	{
 		KernelTimer t(e, s, 3);
 		hipLaunchKernelGGL(k_advance, dim3(count), dim3(256), 0, s, d);
+		hipLaunchKernelGGL(k_arena_service, dim3(1), dim3(1024), 0, s, d, count);
+		hipLaunchKernelGGL(k_arena_copy, dim3(count), dim3(256), 0, s, d);
 		if (!d.match_mode)
 		{
 			hipLaunchKernelGGL(k_assign_openings, dim3(1), dim3(1024), 0, s, d, count);
@@ -2384,6 +2654,16 @@ int agx_engine_stats(AgxEngine *e, AgxEngineStats *out)
 				dp[14] / solves, dp[13] / (dp[14] ? static_cast<double>(dp[14]) : 1.0), dp[10] / solves, dp[11] / solves, dp[12] / solves);
 	}
 #endif
+	{
+		ArenaHeap heap;
+		AGX_HIP_CHECK(hipMemcpy(&heap, e->dev.heap, sizeof(heap), hipMemcpyDeviceToHost));
+		out->arena_grows = heap.grows;
+		out->arena_releases = heap.releases;
+		out->arena_failures = heap.failures;
+		for (const GameState &g : games)
+			out->arena_max_class = std::max(out->arena_max_class, g.arena_class);
+		out->arena_heap_used = static_cast<float>(static_cast<double>(heap.edge_cursor) / static_cast<double>(heap.edge_total));
+	}
 	out->games_finished = counters[2];
 	out->openings_taken = counters[1];
 	out->records_used = counters[3];
@@ -2416,7 +2696,7 @@ int agx_engine_game_info(AgxEngine *e, int game, AgxGameInfo *info, uint8_t *h_b
 	if (gs.root >= 0)
 	{
 		DNode root;
-		const DNode *nodes = e->dev.nodes + (static_cast<size_t>(game) * 2 + gs.arena) * e->dev.node_cap;
+		const DNode *nodes = e->dev.nodes + gs.node_off[gs.arena];
 		AGX_HIP_CHECK(hipMemcpy(&root, nodes + gs.root, sizeof(DNode), hipMemcpyDeviceToHost));
 		info->root_visits = root.visits;
 		info->root_win = root.win;
@@ -2427,7 +2707,7 @@ int agx_engine_game_info(AgxEngine *e, int game, AgxGameInfo *info, uint8_t *h_b
 		{
 			AGX_REQUIRE(root.n_edges <= edge_capacity, AGX_ERR_INVALID, "agx_engine_game_info: %d root edges do not fit into %d", root.n_edges, edge_capacity);
 			std::vector<DEdge> edges(root.n_edges);
-			const DEdge *pool = e->dev.edges + (static_cast<size_t>(game) * 2 + gs.arena) * e->dev.edge_cap;
+			const DEdge *pool = e->dev.edges + gs.edge_off[gs.arena];
 			AGX_HIP_CHECK(hipMemcpy(edges.data(), pool + root.edge_begin, edges.size() * sizeof(DEdge), hipMemcpyDeviceToHost));
 			for (int i = 0; i < root.n_edges; i++)
 			{

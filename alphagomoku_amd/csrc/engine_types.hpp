@@ -106,6 +106,14 @@ namespace agx
 			int32_t my_sign;       // match mode: the colour this tree's player has in the current game (evaluation/EvaluationGame.cpp:59-71)
 			int32_t restart_id;    // 0: playing; -1: the game is over and waits for an opening; k > 0: it starts again from opening k - 1 in k_restart
 			int32_t match_score[4]; // match mode, first players' trees: games won / drawn / lost by the first player of this pair (+ pad)
+			// the game's tree arenas live in pool-wide heaps (ArenaHeap): two node regions, two edge regions (search / compaction target)
+			// and the node-cache table, all of size class `arena_class` (capacities = class-0 capacities << class)
+			int32_t arena_class;
+			int32_t grow_pending;  // 0 none; 1 k_expand found the arenas too small for this step's batch (nothing modified); 3 a larger bundle is
+			                       // reserved, copy pending; 2 grown: the batch waits for expand (select / solve sit this step out)
+			int32_t node_cap, edge_cap, ht_cap, grow_count;
+			uint64_t node_off[2], edge_off[2], ht_off;          // element offsets into EngineDev::nodes / edges / ht
+			uint64_t new_node_off[2], new_edge_off[2], new_ht_off; // the bundle reserved by k_arena_service (grow_pending == 3)
 			uint64_t root_hash;
 			uint64_t cboard[BWORDS];
 			unsigned long long prof[8];   // optional cycle counters (AGX_SOLVER_PROFILE builds only)
@@ -144,6 +152,22 @@ namespace agx
 			uint16_t moves[MAXHW];
 	};
 
+	constexpr int ARENA_CLASSES = 6; // bundle capacities: class-0 capacity << class, class < ARENA_CLASSES
+
+	/* Bump allocators over the node / edge / table heaps + one free list of bundles per size class (k_arena_service, engine.hip). */
+	struct ArenaBundle
+	{
+			uint64_t node_off[2], edge_off[2], ht_off;
+	};
+	struct ArenaHeap
+	{
+			uint64_t node_cursor, edge_cursor, ht_cursor; // first free element of each heap
+			uint64_t node_total, edge_total, ht_total;
+			int32_t free_count[ARENA_CLASSES];
+			int32_t free_capacity;                        // bundles per class list
+			int32_t grows, releases, failures, lock;
+	};
+
 	enum EngineError : int32_t
 	{
 		ERR_NONE = 0, ERR_NODE_CAPACITY = 1, ERR_EDGE_CAPACITY = 2, ERR_PATH_CAPACITY = 3, ERR_ACTION_STACK = 4, ERR_HASH_TABLE = 5, ERR_RECORDS = 6, ERR_FRAMES = 7
@@ -180,9 +204,11 @@ namespace agx
 			int nn_counter;  // index into counters[] of this group's scheduled-position count
 			// state
 			GameState *games;
-			DNode *nodes;   // [game][arena 0/1][node_cap]
-			DEdge *edges;   // [game][arena 0/1][edge_cap]
-			int *ht;        // [game][ht_cap] node index + 1, 0 = empty
+			DNode *nodes;   // node heap: a game's two regions at GameState::node_off[0/1], node_cap << class records each
+			DEdge *edges;   // edge heap (GameState::edge_off)
+			int *ht;        // node-cache tables (GameState::ht_off): node index + 1, 0 = empty
+			ArenaHeap *heap;
+			ArenaBundle *free_bundles; // [ARENA_CLASSES][heap->free_capacity]
 			DTask *tasks;   // [game][batch]
 			uint32_t *act;  // [game][act_cap] alpha-beta action stack: move | score << 16
 			uint64_t *tt;   // [game][buckets][4][2]

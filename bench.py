@@ -140,13 +140,14 @@ def main():
     blob, _ = synthetic.make_weights(desc)
     net = AGNetwork(desc)
     net.loadWeights(blob)
-    # per-game arenas sized for whole games at this playout budget (the reference's node cache and edge pool grow on demand; here they
-    # are fixed: a tree that outgrows them stops its game with an error, and the run below would report it)
-    node_capacity = max(8192, 16 * args.sims)
-    edge_capacity = max(262144, 1536 * args.sims)
+    # tree arenas: every game starts with class-0 regions (8 nodes / 192 edges per playout of the budget) in pool-wide heaps and moves into larger
+    # ones on demand (AgxEngineConfig.arena_reserve: the heaps hold 3 x the class-0 total); the measured peaks are on the line
+    node_capacity = max(4096, 8 * args.sims)
+    edge_capacity = max(65536, 192 * args.sims)
     cfg = selfplay.default_config(rules=args.rules, board_size=args.board, n_games=args.games, max_batch_size=args.batch,
                                   max_simulations=args.sims, tss_table_entries=args.table_entries, solver_yield_fraction=args.yield_fraction,
-                                  action_values=args.action_values, node_capacity=node_capacity, edge_capacity=edge_capacity)
+                                  action_values=args.action_values, node_capacity=node_capacity, edge_capacity=edge_capacity, arena_reserve=2.0,
+                                  record_format=2)
     pool = selfplay.GeneratorPool(cfg)
     # enough openings for every game that can finish during the run; seeds are disjoint across ranks
     n_openings = args.games * 3
@@ -186,7 +187,7 @@ def main():
         if (i + 1) % 256 == 0:
             # long runs only (the default 150 steps never get here): what a generator thread does every few hundred steps — hand the
             # finished samples over (GeneratorManager.cpp:160-164) and keep the opening list ahead of the games
-            pool.records(drain=True)
+            pool.fetch_records(drain=True)   # format-201 samples (6 bytes per visited cell) + finished games
             if pool.stats()["openings_taken"] + args.games > n_openings:
                 extra = synthetic.make_openings(args.board, args.games, seed0=distributed.rank_seed_base(rank) + n_openings, rules=args.rules)
                 pool.add_openings(selfplay.pack_openings(extra))
@@ -280,8 +281,10 @@ def main():
             "stage_ms_per_step": {"select_solve": ms_sel / args.steps, "network": ms_nn / args.steps, "expand_backup_advance": ms_exp / args.steps},
             "kernel_ms_per_step": {"k_select": kernel_ms[0] / args.steps, "k_solve": kernel_ms[1] / args.steps, "nn_tower": ms_nn / args.steps,
                                    "k_expand": kernel_ms[2] / args.steps, "k_advance": kernel_ms[3] / args.steps},
-            "peak_tree_per_game": {"nodes": int(s1["peak_nodes"]), "edges": int(s1["peak_edges"]), "node_capacity": node_capacity,
-                                   "edge_capacity": edge_capacity},
+            "peak_tree_per_game": {"nodes": int(s1["peak_nodes"]), "edges": int(s1["peak_edges"]), "class0_node_capacity": node_capacity,
+                                   "class0_edge_capacity": edge_capacity, "arena_grows": int(s1["arena_grows"]), "arena_releases": int(s1["arena_releases"]),
+                                   "arena_failures": int(s1["arena_failures"]), "arena_max_class": int(s1["arena_max_class"]),
+                                   "arena_heap_high_water": float(s1["arena_heap_used"])},
             "shape": {"mean_select_depth": depth, "mean_edges_per_level": edges_per_level,
                       "solver_nodes_per_simulation": solver_nodes / max(1, s1["evaluated_nodes"] - s0["evaluated_nodes"]),
                       "nn_evals_per_simulation": local_evals / max(1, s1["evaluated_nodes"] - s0["evaluated_nodes"])},

@@ -120,10 +120,9 @@ typedef struct AgxEngineConfig
 	int tss_max_positions;            /* TSSConfig::max_positions, <= 1000 (the search depth is capped at 100 plies either way) */
 	uint64_t tss_table_entries;       /* AlphaBetaSearch's SharedHashTable size per game (reference: 4 Mi) */
 	uint64_t zobrist_seed;            /* seed of the solver / node-cache Zobrist keys (the reference draws them from a time-seeded RNG) */
-	int node_capacity;                /* per game, per arena (TreeConfig::node_bucket_size analogue) */
-	int edge_capacity;                /* per game, per arena (TreeConfig::edge_bucket_size analogue).  Fixed, unlike the reference's pools: a tree
-	                                     that outgrows an arena stops its game (agx_engine_stats.first_error); size them for the playout
-	                                     budget (bench.py: 16 x and 1536 x max_simulations; measured peaks in DESIGN.md section 5) */
+	int node_capacity;                /* per game, per arena, size class 0 (TreeConfig::node_bucket_size analogue; see arena_reserve) */
+	int edge_capacity;                /* per game, per arena, size class 0 (TreeConfig::edge_bucket_size analogue).  The arenas grow on demand
+	                                     like the reference's pools (arena_reserve below) */
 	int record_capacity;              /* move records kept on the device, 0 = n_games * cells */
 	int record_edge_capacity;         /* root-edge snapshots kept on the device, 0 = 64 per record */
 	float solver_yield_fraction;      /* 0 = off.  A pool step lasts as long as its slowest game's solver batch; with f in (0,1] a game
@@ -164,6 +163,12 @@ typedef struct AgxEngineConfig
 	                                     (reference default); 0 = prior 1 for the cells that hold the policy maximum, 0 elsewhere; otherwise
 	                                     policy^(1/T), evaluated as exp(log(p)/T) with the fixed double-precision series of csrc/root_noise.hpp
 	                                     (the reference calls std::pow), so device and oracle agree bit for bit. */
+	float arena_reserve;              /* the tree arenas are regions of pool-wide heaps sized n_games x (class-0 bundle) x (1 + arena_reserve).
+	                                     node_capacity / edge_capacity are the CLASS-0 sizes every game starts with; a game whose batch would
+	                                     not fit moves into a bundle of twice the size from the reserve (NodeCache::resize x2, NodeCache.cpp:
+	                                     320-355; ObjectPool growth, utils/ObjectPool.hpp:74-289) — it sits out one expand stage, its results do
+	                                     not change — and hands it back when its game is over.  Only with the reserve exhausted (or beyond 32 x
+	                                     the class-0 size) does an overflowing tree stop its game (agx_engine_stats.first_error).  < 0 = default 1.0 */
 	int record_format;                /* what k_advance keeps of every played move's root (SearchDataPack, dataset/data_packs.cpp:24-43):
 	                                     bit 0 (value 1, the default): the root edges as 24-byte AgxEdgeView snapshots;
 	                                     bit 1 (value 2): the sample quantised on the device to dataset format 201
@@ -208,6 +213,11 @@ typedef struct AgxEngineStats
 	int records_used;
 	int record_edges_used;
 	int first_error;                          /* 0 = none; EngineError of the first game that stopped */
+	int arena_grows;                          /* bundles handed out by the arena heap to games that outgrew theirs */
+	int arena_releases;                       /* grown bundles handed back by finished games */
+	int arena_failures;                       /* growth requests the heap could not serve (reserve exhausted) */
+	int arena_max_class;                      /* largest size class in use: capacities = class-0 capacities << class */
+	float arena_heap_used;                    /* high-water mark of the edge heap, fraction of its size */
 } AgxEngineStats;
 
 typedef struct AgxEdgeView

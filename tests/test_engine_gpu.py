@@ -189,12 +189,13 @@ def _oracle_root(olib, h):
 
 def _play_and_compare(olib, rules, games, batch, sims, max_steps, evaluator, table_entries=1 << 16, n=N, final_selector=0, use_symmetries=0,
                       action_values=0, noise_weight=0.0, noise_type=1, exploration_scaling=0.0, draw_after=0, max_children=0, policy_temperature=1.0,
-                      record_format=1):
+                      record_format=1, node_capacity=4096, edge_capacity=0, arena_reserve=1.0):
     """evaluator(features uint32 [n][HW]) -> (policy [n][HW] f32, value [n][2] f32 (win, draw)[, q [n][HW][2]]); used for BOTH sides"""
     from alphagomoku_amd import selfplay
     N, HW = n, n * n   # noqa: N806 (shadow the 15x15 module defaults)
     cfg = selfplay.default_config(rules=rules, board_size=n, draw_after=draw_after if draw_after > 0 else n * n, n_games=games, max_batch_size=batch, max_simulations=sims,
-                                  tss_table_entries=table_entries, node_capacity=4096, edge_capacity=65536 if n <= 15 else 131072,
+                                  tss_table_entries=table_entries, node_capacity=node_capacity,
+                                  edge_capacity=edge_capacity if edge_capacity > 0 else (65536 if n <= 15 else 131072), arena_reserve=arena_reserve,
                                   final_selector=final_selector, use_symmetries=use_symmetries, action_values=action_values,
                                   noise_type=noise_type if noise_weight > 0 else 0, noise_weight=noise_weight,
                                   exploration_scaling=exploration_scaling, max_children=max_children, policy_temperature=policy_temperature,
@@ -391,6 +392,38 @@ def test_record_sink_format_201(agx_lib, olib, rules, n, record_format):
     compared, stats = _play_and_compare(olib, rules, games=5, batch=4, sims=60, max_steps=6000, evaluator=_stand_in_evaluator(olib, n * n), n=n,
                                         record_format=record_format)
     assert compared > 200 and stats["games_finished"] == 5
+
+
+@pytest.mark.parametrize("rules,batch", [(0, 8), (2, 4)])
+def test_arenas_grow_on_demand(agx_lib, olib, rules, batch):
+    """NodeCache::resize / ObjectPool growth (NodeCache.cpp:320-355, utils/ObjectPool.hpp:74-289): with class-0 arenas far too small for a
+    search (64 nodes, 1024 edges per game) every game has to move into larger bundles several times — the games must still be the
+    oracle's, step by step, no game may stop, and finished games hand their grown bundles back"""
+    compared, stats = _play_and_compare(olib, rules, games=6, batch=batch, sims=100, max_steps=6000, evaluator=_stand_in_evaluator(olib), node_capacity=64,
+                                        edge_capacity=1024, arena_reserve=60.0)
+    assert compared > 300 and stats["games_finished"] == 6 and stats["first_error"] == 0
+    assert stats["arena_grows"] >= 12 and stats["arena_max_class"] >= 2 and stats["arena_failures"] == 0
+    assert stats["arena_releases"] >= 1          # (a game that ends while others still play returns to class 0)
+
+
+def test_exhausted_arena_reserve_is_reported(agx_lib, olib):
+    """without a reserve the old behaviour remains: a tree that outgrows its arenas stops its game with an error code, the others play on"""
+    from alphagomoku_amd import selfplay
+    cfg = selfplay.default_config(n_games=4, max_batch_size=4, max_simulations=100, tss_table_entries=1 << 12, node_capacity=64, edge_capacity=1024,
+                                  arena_reserve=0.0)
+    pool = selfplay.GeneratorPool(cfg)
+    pool.begin(selfplay.pack_openings(synthetic.make_openings(15, 4, seed0=7)))
+    ev = _stand_in_evaluator(olib)
+    for _ in range(200):
+        pool.select_solve()
+        slots, feats = pool.scheduled()
+        if len(slots):
+            pol, val = ev(feats)
+            pool.provide(slots, pol, np.concatenate([val, 1 - val.sum(1, keepdims=True)], 1).astype(np.float32))
+        pool.expand_backup()
+    st = pool.stats()
+    assert st["first_error"] in (1, 2, 5) and st["arena_failures"] > 0 and st["arena_grows"] == 0
+    pool.close()
 
 
 def test_yielding_pool_gives_the_same_games(agx_lib, olib):
