@@ -85,7 +85,7 @@ class AgxEngineConfig(ctypes.Structure):
                 ("solver_yield_fraction", ctypes.c_float), ("final_selector", ctypes.c_int), ("use_symmetries", ctypes.c_int),
                 ("symmetry_seed", ctypes.c_uint64), ("max_children", ctypes.c_int), ("noise_type", ctypes.c_int), ("noise_weight", ctypes.c_float),
                 ("noise_seed", ctypes.c_uint64), ("action_values", ctypes.c_int), ("match_mode", ctypes.c_int), ("policy_temperature", ctypes.c_float),
-                ("arena_reserve", ctypes.c_float), ("record_format", ctypes.c_int), ("record_sample_capacity", ctypes.c_int), ("game_end_capacity", ctypes.c_int)]
+                ("arena_reserve", ctypes.c_float), ("search_threads", ctypes.c_int), ("record_format", ctypes.c_int), ("record_sample_capacity", ctypes.c_int), ("game_end_capacity", ctypes.c_int)]
 
 
 class AgxEngineBuffers(ctypes.Structure):
@@ -113,7 +113,8 @@ class AgxEdgeView(ctypes.Structure):
 class AgxGameInfo(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in ["active", "sign_to_move", "n_moves", "outcome", "error", "opening_id", "games_done",
                                             "n_nodes", "n_edges", "root_visits"]] + \
-               [("root_win", ctypes.c_float), ("root_draw", ctypes.c_float), ("root_score", ctypes.c_int), ("root_edges", ctypes.c_int)]
+               [("root_win", ctypes.c_float), ("root_draw", ctypes.c_float), ("root_score", ctypes.c_int), ("root_edges", ctypes.c_int),
+                ("grow_pending", ctypes.c_int), ("arena_class", ctypes.c_int)]
 
 
 class AgxMoveRecord(ctypes.Structure):

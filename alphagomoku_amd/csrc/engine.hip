@@ -34,24 +34,18 @@ using namespace agx::dev;
 namespace
 {
 	/* ------------------------------------------------------------------------------------------------------------ */
-	__global__ __launch_bounds__(64) void k_select(EngineDev E)
+	/* Search::select for one task buffer: `g` owns the buffer (its GameState `ls` carries the batch bookkeeping and statistics), `tg` owns
+	 * the tree (its GameState `gs`).  Self-play: tg == g.  Tournament search (shared_tree): every search thread g descends tree 0. */
+	__device__ __forceinline__ void select_batch(EngineDev &E, int tg, int g, int lane, uint8_t *sh_board, u64 *sh_cboard, const u64 *sh_keys)
 	{
-		__shared__ uint8_t sh_board[MAXHW];
-		__shared__ u64 sh_cboard[BWORDS];
-		__shared__ u64 sh_keys[3 * (1 + MAXHW)]; // FullZobristHashing keys of the node cache: four per level, from LDS instead of L2
-		const int g = E.g0 + blockIdx.x, lane = threadIdx.x;
-		GameState &gs = E.games[g];
-		if (!gs.active || gs.error != 0 || gs.outcome != 0 || gs.solve_pending || gs.grow_pending)
-			return; // (grow_pending: the previous batch still waits for its expansion in larger arenas)
-		use_game_arenas(E, g);
-		for (int i = lane; i < 3 * (1 + E.hw); i += 64)
-			sh_keys[i] = E.nc_keys[i];
-		DNode *nodes = nodes_of(E, g, gs.arena);
-		DEdge *edges = edges_of(E, g, gs.arena);
-		const int *ht = ht_of(E, g);
+		GameState &gs = E.games[tg];
+		GameState &ls = E.games[g];
+		DNode *nodes = nodes_of(E, tg, gs.arena);
+		DEdge *edges = edges_of(E, tg, gs.arena);
+		const int *ht = ht_of(E, tg);
 		const int n = E.n;
 
-		int n_tasks = gs.n_tasks;
+		int n_tasks = ls.n_tasks;
 		int trials = 2 * E.batch;
 		unsigned long long st_levels = 0, st_edges = 0, st_leaks = 0, st_proven = 0, st_dup = 0;
 		while (n_tasks < E.batch)
@@ -67,7 +61,7 @@ namespace
 					const DNode rn = nodes[root];
 					const DEdge *root_edges = edges + rn.edge_begin;
 					make_root_noise(E.noise_type, E.noise_weight, E.noise_seed, gs.opening_id, gs.n_moves, rn.n_edges, [&](int i) { return root_edges[i].prior; },
-							E.noise + static_cast<size_t>(g) * E.hw);
+							E.noise + static_cast<size_t>(tg) * E.hw);
 					gs.noise_ready = 1;
 				}
 				__threadfence_block();
@@ -95,10 +89,10 @@ namespace
 				if (path_len >= PATH_CAP)
 				{
 					if (lane == 0)
-						gs.error = ERR_PATH_CAPACITY;
+						ls.error = ERR_PATH_CAPACITY;
 					break;
 				}
-				const int e = select_edge(E, nd, edges, lane, st_edges, (node == root && gs.noise_ready) ? E.noise + static_cast<size_t>(g) * E.hw : nullptr);
+				const int e = select_edge(E, nd, edges, lane, st_edges, (node == root && gs.noise_ready) ? E.noise + static_cast<size_t>(tg) * E.hw : nullptr);
 				st_levels++;
 				const DEdge ee = edges[e]; // as it was before this visit's virtual loss (what the leak test compares, Tree.cpp:75-85)
 				const uint32_t mv = ee.move;
@@ -193,12 +187,39 @@ namespace
 		}
 		if (lane == 0)
 		{
-			gs.n_tasks = n_tasks;
-			gs.stats[2] += st_leaks;
-			gs.stats[3] += st_proven;
-			gs.stats[6] += st_levels;
-			gs.stats[7] += st_edges;
-			gs.stats[9] += st_dup;
+			ls.n_tasks = n_tasks;
+			ls.stats[2] += st_leaks;
+			ls.stats[3] += st_proven;
+			ls.stats[6] += st_levels;
+			ls.stats[7] += st_edges;
+			ls.stats[9] += st_dup;
+		}
+	}
+	__global__ __launch_bounds__(64) void k_select(EngineDev E)
+	{
+		__shared__ uint8_t sh_board[MAXHW];
+		__shared__ u64 sh_cboard[BWORDS];
+		__shared__ u64 sh_keys[3 * (1 + MAXHW)]; // FullZobristHashing keys of the node cache: four per level, from LDS instead of L2
+		const int g = E.g0 + blockIdx.x, lane = threadIdx.x;
+		const int tg = E.shared_tree ? 0 : g;
+		GameState &gs = E.games[tg];
+		if (!gs.active || gs.error != 0 || gs.outcome != 0 || gs.grow_pending)
+			return; // (grow_pending: the previous batch still waits for its expansion in larger arenas)
+		use_game_arenas(E, tg);
+		for (int i = lane; i < 3 * (1 + E.hw); i += 64)
+			sh_keys[i] = E.nc_keys[i];
+		if (!E.shared_tree)
+		{
+			if (!gs.solve_pending)
+				select_batch(E, g, g, lane, sh_board, sh_cboard, sh_keys);
+			return;
+		}
+		// tournament search: the search threads take the tree one after the other (SearchThread.cpp:124-129), in thread order
+		for (int t = 0; t < E.n_games; t++)
+		{
+			if (E.games[t].error == 0)
+				select_batch(E, 0, t, lane, sh_board, sh_cboard, sh_keys);
+			__syncthreads();
 		}
 	}
 
@@ -371,7 +392,7 @@ namespace
 		__shared__ SolverShared sh;
 		const int g = E.g0 + blockIdx.x, lane = threadIdx.x;
 		GameState &gs = E.games[g];
-		const bool idle = (!gs.active || gs.error != 0 || gs.outcome != 0 || gs.grow_pending != 0);
+		const bool idle = (!gs.active || gs.error != 0 || gs.outcome != 0 || E.games[E.shared_tree ? 0 : g].grow_pending != 0);
 		const int n_tasks = idle ? 0 : gs.n_tasks;
 		if (n_tasks > 0)
 			solver_load_threat_table(sh, E, lane);
@@ -482,16 +503,17 @@ namespace
 		__shared__ uint16_t e_move[MAXHW], e_score[MAXHW];
 		__shared__ float sh_sum;
 		__shared__ u64 sort_keys[512]; // prune_weak_moves with max_children: (score band, prior, original index) of every edge
-		const int g = E.g0 + blockIdx.x, lane = threadIdx.x;
-		GameState &gs = E.games[g];
-		if (!gs.active || gs.error != 0 || gs.outcome != 0 || gs.solve_pending || gs.grow_pending == 1 || gs.grow_pending == 3)
+		const int g0 = E.g0 + blockIdx.x, lane = threadIdx.x;
+		const int tg = E.shared_tree ? 0 : g0; // the game that owns the tree; tournament search: every search thread works on tree 0
+		GameState &gs = E.games[tg];
+		if (!gs.active || gs.error != 0 || gs.outcome != 0 || (!E.shared_tree && gs.solve_pending) || gs.grow_pending == 1 || gs.grow_pending == 3)
 			return;
-		use_game_arenas(E, g);
-		DNode *nodes = nodes_of(E, g, gs.arena);
-		DEdge *edges = edges_of(E, g, gs.arena);
-		int *ht = ht_of(E, g);
+		use_game_arenas(E, tg);
+		DNode *nodes = nodes_of(E, tg, gs.arena);
+		DEdge *edges = edges_of(E, tg, gs.arena);
+		int *ht = ht_of(E, tg);
 		const int n = E.n, hw = E.hw;
-		const int n_tasks = gs.n_tasks;
+		const int first_lane = E.shared_tree ? 0 : g0, last_lane = E.shared_tree ? E.n_games - 1 : g0;
 		{
 			/*
 			 * NodeCache::resize / ObjectPool growth (NodeCache.cpp:320-355, utils/ObjectPool.hpp:74-289) for flat arenas: BEFORE anything is
@@ -500,21 +522,31 @@ namespace
 			 * move the tree into larger regions, select and solve skip the game in the next step, and this kernel then expands the SAME
 			 * batch — the game performs exactly the same sequence of operations, one step later.
 			 */
-			int need_edges = gs.n_edges;
-			for (int k = 0; k < n_tasks; k++)
-				need_edges += E.tasks[static_cast<size_t>(g) * E.batch + k].n_edges;
-			const int need_nodes = gs.n_nodes + n_tasks;
-			const bool fits = need_nodes <= E.node_cap && need_edges <= E.edge_cap && 2 * need_nodes <= E.ht_cap;
-			if (!fits && gs.arena_class + 1 < ARENA_CLASSES && gs.grow_pending == 0)
+			int need_edges = gs.n_edges, need_nodes = gs.n_nodes;
+			for (int lg = first_lane; lg <= last_lane; lg++)
 			{
+				const int lane_tasks = E.games[lg].n_tasks;
+				need_nodes += lane_tasks;
+				for (int k = 0; k < lane_tasks; k++)
+					need_edges += E.tasks[static_cast<size_t>(lg) * E.batch + k].n_edges;
+			}
+			const bool fits = need_nodes <= E.node_cap && need_edges <= E.edge_cap && 2 * need_nodes <= E.ht_cap;
+			if (!fits && gs.arena_class + 1 < ARENA_CLASSES && gs.grow_pending != 4)
+			{ // (also straight after a growth that was not enough: one more class)
 				if (lane == 0)
 					gs.grow_pending = 1;
 				return;
 			}
 			if (lane == 0)
-				gs.grow_pending = 0; // 2 -> 0: grown (or no larger class / no heap space left: the exact per-node test below decides)
+				gs.grow_pending = 0; // 2 -> 0: grown; 4 -> 0: no heap space left (or the largest class reached): the exact per-node test below decides
 		}
 		const u64 lower = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+		// tournament search: the search threads take the tree in thread order, each expands its batch and backs it up (SearchThread.cpp:
+		// 135-141); self-play: the one buffer of the game
+		for (int g = first_lane; g <= last_lane; g++)
+		{
+		GameState &ls = E.games[g];
+		const int n_tasks = ls.n_tasks;
 		unsigned long long wasted = 0;
 
 		for (int k = 0; k < n_tasks; k++)
@@ -871,9 +903,14 @@ namespace
 
 		if (lane == 0)
 		{
-			gs.stats[0] += n_tasks;
-			gs.stats[4] += wasted;
-			gs.n_tasks = 0;
+			ls.stats[0] += n_tasks;
+			ls.stats[4] += wasted;
+			ls.n_tasks = 0;
+		}
+		__syncthreads();
+		} // search threads
+		if (lane == 0)
+		{
 			gs.stats[10] = max(gs.stats[10], static_cast<unsigned long long>(gs.n_nodes));
 			gs.stats[11] = max(gs.stats[11], static_cast<unsigned long long>(gs.n_edges));
 			// move rule (GameGenerator.cpp:97-103, utils/misc.cpp:171-179)
@@ -1095,7 +1132,8 @@ namespace
 		__shared__ int sh_id;
 		if (tid == 0)
 		{
-			sh_id = g; // the first wave of games takes openings 0..n_games-1 in order; counters[1] is preset to n_games
+			sh_id = E.shared_tree ? 0 : g; // the first wave of games takes openings 0..n_games-1 in order; counters[1] is preset to n_games
+			                               // (tournament search: every search thread starts on opening 0, counters[1] is preset to 1)
 			gs.generation = 0;
 			gs.error = 0;
 			gs.games_done = 0;
@@ -1486,6 +1524,18 @@ namespace
 				rebase_tree(E, p, tid, scratch, scan_nodes, scan_edges);
 			return;
 		}
+		if (E.shared_tree)
+		{ // every SearchThread's Search sees the move: Search::setBoard -> AlphaBetaSearch::increaseGeneration; a finished game stops them all
+			for (int t = 1 + tid; t < E.n_games; t += 256)
+			{
+				GameState &ls = E.games[t];
+				ls.generation = (ls.generation + 1) % 64;
+				ls.outcome = sh_int[2];
+				ls.n_moves = gs.n_moves;
+				if (sh_int[2] != 0)
+					ls.active = 0;
+			}
+		}
 		if (sh_int[2] != 0)
 			return;
 		rebase_tree(E, g, tid, scratch, scan_nodes, scan_edges);
@@ -1572,7 +1622,7 @@ namespace
 	__global__ __launch_bounds__(256) void k_clear_tables(EngineDev E, int parts)
 	{
 		const int g = E.g0 + blockIdx.x / parts, part = blockIdx.x % parts, tid = threadIdx.x;
-		const int asks = E.match_mode ? g % (E.n_games / 2) : g;
+		const int asks = E.shared_tree ? 0 : (E.match_mode ? g % (E.n_games / 2) : g);
 		if (E.games[asks].restart_id <= 0)
 			return;
 		ulonglong2 *tt = reinterpret_cast<ulonglong2*>(E.tt + static_cast<size_t>(g) * (E.tt_bucket_mask + 1ull) * 8ull);
@@ -1595,8 +1645,8 @@ namespace
 	{
 		__shared__ u64 scratch[4];
 		const int g = E.g0 + blockIdx.x, tid = threadIdx.x;
-		const int id = E.games[g].restart_id;
-		if (id <= 0)
+		const int id = E.games[E.shared_tree ? 0 : g].restart_id; // (tournament search: thread 0's request counts for every search thread,
+		if (id <= 0)                                              //  and thread 0 is restarted by a later launch than the others)
 			return;
 		__syncthreads();
 		begin_game(E, g, id - 1, tid, scratch, true); // k_clear_tables ran just before
@@ -1794,7 +1844,7 @@ namespace
 						}
 						else
 						{ // heap exhausted: the game carries on in its arenas; if the batch really overflows them, k_expand reports it
-							gs.grow_pending = 2;
+							gs.grow_pending = 4;
 							atomicAdd(&E.heap->failures, 1);
 						}
 					}
@@ -2087,6 +2137,7 @@ int agx_engine_default_config(AgxEngineConfig *cfg)
 	cfg->match_mode = 0;
 	cfg->policy_temperature = 1.0f;
 	cfg->arena_reserve = 1.0f;
+	cfg->search_threads = 0;
 	cfg->record_format = 1;
 	cfg->record_sample_capacity = 0;
 	cfg->game_end_capacity = 0;
@@ -2110,6 +2161,8 @@ int agx_engine_create(const AgxEngineConfig *cfg, AgxEngine **out)
 	AGX_REQUIRE(cfg->policy_temperature >= 0.0f, AGX_ERR_INVALID, "agx_engine_create: policy_temperature must not be negative");
 	AGX_REQUIRE(!cfg->match_mode || cfg->n_games % 2 == 0, AGX_ERR_INVALID, "agx_engine_create: match_mode pairs the trees, n_games must be even");
 	AGX_REQUIRE(cfg->noise_weight >= 0.0f && cfg->noise_weight <= 1.0f, AGX_ERR_INVALID, "agx_engine_create: noise_weight must be in [0, 1]");
+	AGX_REQUIRE(cfg->search_threads <= 1 || (cfg->search_threads == cfg->n_games && !cfg->match_mode && cfg->solver_yield_fraction == 0.0f), AGX_ERR_INVALID,
+			"agx_engine_create: search_threads > 1 makes the pool ONE tree searched by n_games threads: n_games must equal search_threads, no match_mode, no yielding");
 	AGX_REQUIRE(cfg->record_format >= 0 && cfg->record_format <= 3, AGX_ERR_INVALID, "agx_engine_create: record_format must be 0..3 (bit 0 edge snapshots, bit 1 format-201 samples)");
 
 	AgxEngine *e = new AgxEngine();
@@ -2192,6 +2245,7 @@ int agx_engine_create(const AgxEngineConfig *cfg, AgxEngine **out)
 	AGX_TRY(dev_alloc(e, &d.nn_value, G * d.batch * 3));
 	d.has_q = cfg->action_values ? 1 : 0;
 	d.match_mode = cfg->match_mode ? 1 : 0;
+	d.shared_tree = (cfg->search_threads > 1) ? 1 : 0;
 	d.policy_temperature = cfg->policy_temperature;
 	AGX_TRY(dev_alloc(e, &d.nn_q, d.has_q ? G * d.batch * d.hw * 2 : 1));
 	AGX_TRY(dev_alloc(e, &d.noise, d.noise_type ? G * d.hw : 1));
@@ -2275,7 +2329,7 @@ int agx_engine_begin(AgxEngine *e, const uint16_t *h_openings, int n_openings, v
 	e->dev.openings = d_op;
 	e->dev.n_openings = n_openings;
 	int counters[64] = { 0 };
-	counters[1] = e->dev.match_mode ? 0 : e->dev.n_games;
+	counters[1] = e->dev.match_mode ? 0 : (e->dev.shared_tree ? 1 : e->dev.n_games);
 	AGX_HIP_CHECK(hipMemcpy(e->dev.counters, counters, sizeof(counters), hipMemcpyHostToDevice));
 	hipStream_t s = static_cast<hipStream_t>(stream);
 	hipLaunchKernelGGL(k_begin, dim3(e->dev.n_games), dim3(256), 0, s, e->dev);
@@ -2326,6 +2380,7 @@ static int group_range(const AgxEngine *e, int group, int n_groups, EngineDev &d
 	d.nn_counter = 16 + group;
 	d.yield_counter = 32 + group;
 	AGX_REQUIRE(count > 0, AGX_ERR_INVALID, "group %d of %d is empty for %d games", group, n_groups, e->dev.n_games);
+	AGX_REQUIRE(!e->dev.shared_tree || n_groups == 1, AGX_ERR_INVALID, "a tournament-search pool (search_threads) is one tree: it cannot be stepped in groups");
 	return AGX_OK;
 }
 
@@ -2363,7 +2418,7 @@ int agx_engine_select_group(AgxEngine *e, int group, int n_groups, void *stream)
 	hipLaunchKernelGGL(k_reset_counter, dim3(1), dim3(1), 0, s, d.counters + d.nn_counter, d.counters + d.yield_counter);
 	{
 		KernelTimer t(e, s, 0);
-		hipLaunchKernelGGL(k_select, dim3(count), dim3(64), 0, s, d);
+		hipLaunchKernelGGL(k_select, dim3(d.shared_tree ? 1 : count), dim3(64), 0, s, d); // tournament search: one wave walks the threads in turn
 	}
 	AGX_HIP_CHECK(hipGetLastError());
 	return AGX_OK;
@@ -2502,7 +2557,7 @@ int agx_engine_expand_group(AgxEngine *e, int group, int n_groups, void *stream)
 	hipStream_t s = static_cast<hipStream_t>(stream);
 	{
 		KernelTimer t(e, s, 2);
-		hipLaunchKernelGGL(k_expand, dim3(count), dim3(64), 0, s, d);
+		hipLaunchKernelGGL(k_expand, dim3(d.shared_tree ? 1 : count), dim3(64), 0, s, d);
 	}
 	AGX_HIP_CHECK(hipGetLastError());
 	return AGX_OK;
@@ -2522,14 +2577,24 @@ int agx_engine_advance_group(AgxEngine *e, int group, int n_groups, void *stream
 	hipStream_t s = static_cast<hipStream_t>(stream);
 	{
 		KernelTimer t(e, s, 3);
-		hipLaunchKernelGGL(k_advance, dim3(count), dim3(256), 0, s, d);
-		hipLaunchKernelGGL(k_arena_service, dim3(1), dim3(1024), 0, s, d, count);
-		hipLaunchKernelGGL(k_arena_copy, dim3(count), dim3(256), 0, s, d);
+		const int trees = d.shared_tree ? 1 : count; // tournament search: one tree (game 0), the other records are its search threads
+		hipLaunchKernelGGL(k_advance, dim3(trees), dim3(256), 0, s, d);
+		hipLaunchKernelGGL(k_arena_service, dim3(1), dim3(1024), 0, s, d, trees);
+		hipLaunchKernelGGL(k_arena_copy, dim3(trees), dim3(256), 0, s, d);
 		if (!d.match_mode)
 		{
-			hipLaunchKernelGGL(k_assign_openings, dim3(1), dim3(1024), 0, s, d, count);
+			hipLaunchKernelGGL(k_assign_openings, dim3(1), dim3(1024), 0, s, d, trees);
 			hipLaunchKernelGGL(k_clear_tables, dim3(count * CLEAR_PARTS), dim3(256), 0, s, d, CLEAR_PARTS);
-			hipLaunchKernelGGL(k_restart, dim3(count), dim3(256), 0, s, d);
+			if (d.shared_tree)
+			{ // the search threads restart on thread 0's opening: they first (they read its request), thread 0 last (it clears the request)
+				EngineDev others = d;
+				others.g0 = 1;
+				if (count > 1)
+					hipLaunchKernelGGL(k_restart, dim3(count - 1), dim3(256), 0, s, others);
+				hipLaunchKernelGGL(k_restart, dim3(1), dim3(256), 0, s, d);
+			}
+			else
+				hipLaunchKernelGGL(k_restart, dim3(count), dim3(256), 0, s, d);
 		}
 		else if (group == 0)
 		{ // restarts go by pair, requested through the first players' trees (= group 0)
@@ -2687,6 +2752,8 @@ int agx_engine_game_info(AgxEngine *e, int game, AgxGameInfo *info, uint8_t *h_b
 	info->games_done = gs.games_done;
 	info->n_nodes = gs.n_nodes;
 	info->n_edges = gs.n_edges;
+	info->grow_pending = gs.grow_pending;
+	info->arena_class = gs.arena_class;
 	info->root_visits = 0;
 	info->root_win = info->root_draw = 0.0f;
 	info->root_score = 0;

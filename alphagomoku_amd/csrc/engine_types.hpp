@@ -110,7 +110,8 @@ namespace agx
 			// and the node-cache table, all of size class `arena_class` (capacities = class-0 capacities << class)
 			int32_t arena_class;
 			int32_t grow_pending;  // 0 none; 1 k_expand found the arenas too small for this step's batch (nothing modified); 3 a larger bundle is
-			                       // reserved, copy pending; 2 grown: the batch waits for expand (select / solve sit this step out)
+			                       // reserved, copy pending; 2 grown: the batch waits for expand (select / solve sit this step out); 4 the heap
+			                       // had no bundle left: expand proceeds in the old arenas
 			int32_t node_cap, edge_cap, ht_cap, grow_count;
 			uint64_t node_off[2], edge_off[2], ht_off;          // element offsets into EngineDev::nodes / edges / ht
 			uint64_t new_node_off[2], new_edge_off[2], new_ht_off; // the bundle reserved by k_arena_service (grow_pending == 3)
@@ -228,6 +229,7 @@ namespace agx
 			int has_q;
 			int match_merged; // this launch covers both players' trees: network slot lists by half of the pool, not by launch
 			int match_mode;  // evaluation matches: tree g (first player) and tree g + n_games / 2 (second player) share one game
+			int shared_tree; // tournament search: the n_games records are the search threads of ONE tree (game 0): own task buffer and solver each
 			int *nn_list;          // compacted slots to evaluate
 			int *counters;         // [0] (unused), [1] next opening, [2] finished games, [3] records used, [4] record edges used, [5] total moves, [6] sample bytes used, [7] game-end records used, [16 + group] positions scheduled for the network by that group, [32 + group] games of that group done with their solver batch
 			// output records

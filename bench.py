@@ -141,12 +141,12 @@ def main():
     net = AGNetwork(desc)
     net.loadWeights(blob)
     # tree arenas: every game starts with class-0 regions (8 nodes / 192 edges per playout of the budget) in pool-wide heaps and moves into larger
-    # ones on demand (AgxEngineConfig.arena_reserve: the heaps hold 3 x the class-0 total); the measured peaks are on the line
+    # ones on demand (AgxEngineConfig.arena_reserve: the heaps hold 4 x the class-0 total); the measured peaks are on the line
     node_capacity = max(4096, 8 * args.sims)
     edge_capacity = max(65536, 192 * args.sims)
     cfg = selfplay.default_config(rules=args.rules, board_size=args.board, n_games=args.games, max_batch_size=args.batch,
                                   max_simulations=args.sims, tss_table_entries=args.table_entries, solver_yield_fraction=args.yield_fraction,
-                                  action_values=args.action_values, node_capacity=node_capacity, edge_capacity=edge_capacity, arena_reserve=2.0,
+                                  action_values=args.action_values, node_capacity=node_capacity, edge_capacity=edge_capacity, arena_reserve=3.0,
                                   record_format=2)
     pool = selfplay.GeneratorPool(cfg)
     # enough openings for every game that can finish during the run; seeds are disjoint across ranks

@@ -169,6 +169,12 @@ typedef struct AgxEngineConfig
 	                                     320-355; ObjectPool growth, utils/ObjectPool.hpp:74-289) — it sits out one expand stage, its results do
 	                                     not change — and hands it back when its game is over.  Only with the reserve exhausted (or beyond 32 x
 	                                     the class-0 size) does an overflowing tree stop its game (agx_engine_stats.first_error).  < 0 = default 1.0 */
+	int search_threads;               /* > 1: tournament search (player/SearchThread.cpp:121-180): the pool is ONE game tree searched by
+	                                     `search_threads` SearchThreads, each with its own Search — own task buffer of max_batch_size leaves, own
+	                                     threat solver and table — and n_games must equal search_threads (record 0 owns the tree, the others are the
+	                                     threads).  Per step the threads take the tree in thread order for select (virtual loss makes them spread),
+	                                     solve their batches in parallel (one wave each), share one network launch, then take the tree in order
+	                                     again for expand + backup: the lock-step interleaving of SearchThread::serial_run.  0 / 1 = self-play pool. */
 	int record_format;                /* what k_advance keeps of every played move's root (SearchDataPack, dataset/data_packs.cpp:24-43):
 	                                     bit 0 (value 1, the default): the root edges as 24-byte AgxEdgeView snapshots;
 	                                     bit 1 (value 2): the sample quantised on the device to dataset format 201
@@ -237,6 +243,8 @@ typedef struct AgxGameInfo
 	float root_win, root_draw;
 	int root_score;
 	int root_edges;
+	int grow_pending; /* non-zero: the game's last batch waits for its expansion in larger arenas (one step later than a lock-step pool) */
+	int arena_class;  /* its tree arenas hold class-0 capacity << arena_class records */
 } AgxGameInfo;
 
 typedef struct AgxMoveRecord

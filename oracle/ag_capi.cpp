@@ -428,6 +428,11 @@ double ago_det_exp(double x)
 {
 	return det_exp(x);
 }
+/* tournament search on one tree: `count` search threads (Search objects with their own solver and table) in lock-step; before ago_game_begin */
+void ago_game_set_search_threads(void *h, int count)
+{
+	static_cast<GameHandle*>(h)->game.set_search_threads(count);
+}
 void ago_game_set_serial(void *h, int serial)
 {
 	static_cast<GameHandle*>(h)->game.serial = serial;

@@ -619,8 +619,11 @@ namespace ago
 		outcome = O_UNKNOWN;
 		queued = 0;
 		tree.clear();
-		search.solver.clear();
-		search.stored = 0;
+		for (int l = 0; l < lanes(); l++)
+		{
+			lane(l).solver.clear();
+			lane(l).stored = 0;
+		}
 		for (const Move &m : opening)
 		{
 			board[m.row * cfg.cols + m.col] = m.sign;
@@ -629,27 +632,49 @@ namespace ago
 		sign_to_move = moves.empty() ? CROSS : invert_sign(moves.back().sign); // Game::getSignToMove (Game.cpp:60-69)
 		prepare_search();
 	}
+	void Game::set_search_threads(int count)
+	{
+		more_searches.clear();
+		for (int i = 1; i < count; i++)
+			more_searches.push_back(std::make_unique<Search>(cfg, scfg));
+	}
 	void Game::prepare_search()
 	{ // GameGenerator.cpp:174-185
-		search.cleanup(tree);
+		for (int l = 0; l < lanes(); l++)
+			lane(l).cleanup(tree);
 		tree.set_board(board.data(), sign_to_move);
 		tree.noisy_policy.clear(); // a fresh EdgeSelector per move (GameGenerator.cpp:181-183)
 		tree.noise_serial = serial;
 		tree.noise_move = static_cast<int>(moves.size());
-		search.solver.increase_generation();
+		for (int l = 0; l < lanes(); l++)
+			lane(l).solver.increase_generation();
 	}
 	int Game::step_select(std::vector<uint32_t> &features_out)
 	{ // GameGenerator.cpp:79-86
-		search.select(tree, scfg.max_simulations);
-		search.solve();
-		const int n = search.schedule(scheduled);
-		search.stats.nn_evals += n;
+		// SearchThread::serial_run (SearchThread.cpp:121-146) of every thread in lock-step: select under the tree lock in thread order ...
+		for (int l = 0; l < lanes(); l++)
+			lane(l).select(tree, scfg.max_simulations);
+		scheduled.clear();
+		scheduled_lane.clear();
+		for (int l = 0; l < lanes(); l++)
+		{ // ... each thread's own solver on its own batch, its leaves queued for the shared evaluator
+			lane(l).solve();
+			std::vector<int> mine;
+			const int m = lane(l).schedule(mine);
+			lane(l).stats.nn_evals += m;
+			for (int idx : mine)
+			{
+				scheduled.push_back(idx);
+				scheduled_lane.push_back(l);
+			}
+		}
+		const int n = static_cast<int>(scheduled.size());
 		const int hw = cfg.rows * cfg.cols;
 		features_out.resize(static_cast<size_t>(n) * hw);
 		symmetries.assign(n, 0);
 		for (int i = 0; i < n; i++)
 		{
-			Task &t = search.tasks[scheduled[i]];
+			Task &t = lane(scheduled_lane[i]).tasks[scheduled[i]];
 			if (scfg.use_symmetries)
 			{ // NNEvaluator::addToQueue + pack_to_network: features.augment(symmetry) (NNEvaluator.cpp:134-141,244-262)
 				const int s = pick_symmetry(scfg.symmetry_seed, serial, queued);
@@ -677,7 +702,7 @@ namespace ago
 		const int hw = cfg.rows * cfg.cols;
 		for (size_t i = 0; i < scheduled.size(); i++)
 		{
-			Task &t = search.tasks[scheduled[i]];
+			Task &t = lane(scheduled_lane.empty() ? 0 : scheduled_lane[i]).tasks[scheduled[i]];
 			const int inv = inverse_symmetry(symmetries.empty() ? 0 : symmetries[i]);
 			for (int k = 0; k < hw; k++)
 			{ // apply_symmetry(task policy, network policy, inverse symmetry) (NNEvaluator.cpp:277-279)
@@ -692,9 +717,12 @@ namespace ago
 				t.moves_left = 0.0f;
 			t.by_network = true;
 		}
-		search.generate_edges(tree);
-		search.expand(tree);
-		search.backup(tree);
+		for (int l = 0; l < lanes(); l++)
+		{ // each thread in turn, under the tree lock: expand its batch, back it up (SearchThread.cpp:135-141)
+			lane(l).generate_edges(tree);
+			lane(l).expand(tree);
+			lane(l).backup(tree);
+		}
 
 		const float draw_rate = tree.nodes[tree.root].value.draw;
 		// get_simulations_for_move (utils/misc.cpp:171-179)

@@ -28,6 +28,7 @@
 #include <cassert>
 #include <cmath>
 #include <limits>
+#include <memory>
 
 namespace ago
 {
@@ -529,6 +530,13 @@ namespace ago
 			SearchConfig scfg;
 			Tree tree;
 			Search search;
+			/* tournament search (player/SearchThread.cpp:121-180): several SearchThreads, each with its own Search (own solver, own table,
+			 * own task buffer), work on ONE tree under its lock.  The threads' interleaving is not defined by the reference; the order used
+			 * here is the lock-step one: select of every thread in thread order, solve, evaluate, then per thread expand + backup. */
+			std::vector<std::unique_ptr<Search>> more_searches;
+			void set_search_threads(int count);
+			Search& lane(int i) { return (i == 0) ? search : *more_searches[i - 1]; }
+			int lanes() const { return 1 + static_cast<int>(more_searches.size()); }
 			std::vector<Sign> board;
 			std::vector<Move> moves;
 			Sign sign_to_move = CROSS;
@@ -563,6 +571,7 @@ namespace ago
 		private:
 			std::vector<int> scheduled;
 			std::vector<int> symmetries;
+			std::vector<int> scheduled_lane; // shared-tree search: which Search each scheduled task belongs to
 			void prepare_search();
 			void make_move();
 	};

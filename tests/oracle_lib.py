@@ -52,6 +52,7 @@ def load():
         lib.ago_solver_solve.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 6
         lib.ago_game_begin.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
         lib.ago_game_set_serial.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        lib.ago_game_set_search_threads.argtypes = [ctypes.c_void_p, ctypes.c_int]
         lib.ago_apply_symmetry.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         lib.ago_game_set_force_expand_root.argtypes = [ctypes.c_void_p, ctypes.c_int]
         lib.ago_game_record_flags.argtypes = [ctypes.c_void_p, ctypes.c_int]

@@ -218,6 +218,7 @@ def _play_and_compare(olib, rules, games, batch, sims, max_steps, evaluator, tab
         handles.append(h)
     pool.begin(selfplay.pack_openings(openings))
     compared = 0
+    deferred = [False] * games
     for step in range(max_steps):
         pool.select_solve()
         slots, feats = pool.scheduled()
@@ -229,6 +230,11 @@ def _play_and_compare(olib, rules, games, batch, sims, max_steps, evaluator, tab
         by_slot = {int(s): i for i, s in enumerate(slots)}
         for g in range(games):
             if olib.ago_game_outcome(handles[g]) != 0:
+                continue
+            if deferred[g]:
+                # the game's previous batch waited for larger arenas: this step the device only expands it (no select, nothing scheduled);
+                # the oracle already holds that batch's results
+                assert not any(s // batch == g for s in by_slot), (step, g)
                 continue
             f = np.zeros((batch, HW), np.uint32)
             c = olib.ago_game_step_select(handles[g], ol.ptr(f), batch)
@@ -246,6 +252,9 @@ def _play_and_compare(olib, rules, games, batch, sims, max_steps, evaluator, tab
         for g in range(games):
             info = pool.game_info(g)
             assert info["error"] == 0
+            deferred[g] = info["grow_pending"] != 0
+            if deferred[g]:
+                continue   # compared again once the batch has been expanded
             if info["opening_id"] != g or not info["active"] or olib.ago_game_outcome(handles[g]) != 0:
                 continue
             r = _oracle_root(olib, handles[g])
@@ -259,7 +268,7 @@ def _play_and_compare(olib, rules, games, batch, sims, max_steps, evaluator, tab
             assert np.array_equal(np.array([[x["win"], x["draw"]] for x in e], np.float32).reshape(-1), r["val"]), (step, g)
             assert np.float32(info["root_win"]) == r["win"] and np.float32(info["root_draw"]) == r["draw"] and info["root_score"] == r["score"], (step, g)
             compared += 1
-        if all(olib.ago_game_outcome(h) != 0 for h in handles):
+        if all(olib.ago_game_outcome(h) != 0 for h in handles) and not any(deferred):
             break
     # the played moves (the path's output records) must be identical
     recs, _ = pool.records()
@@ -424,6 +433,68 @@ def test_exhausted_arena_reserve_is_reported(agx_lib, olib):
     st = pool.stats()
     assert st["first_error"] in (1, 2, 5) and st["arena_failures"] > 0 and st["arena_grows"] == 0
     pool.close()
+
+
+@pytest.mark.parametrize("rules,threads,batch", [(0, 4, 8), (1, 8, 4), (2, 3, 4)])
+def test_tournament_search_on_one_tree(agx_lib, olib, rules, threads, batch):
+    """SURVEY row f4 (player/SearchThread.cpp:121-180): ONE tree searched by several SearchThreads, each with its own Search (task buffer,
+    threat solver, table).  The device runs the threads in lock-step — select in thread order under the tree 'lock' (one wave), the
+    solvers in parallel (one wave per thread), one network launch, expand + backup in thread order — and the oracle plays the same
+    schedule: same leaves, same features, same root after every step, same moves, for whole games."""
+    from alphagomoku_amd import selfplay
+    sims = 300
+    cfg = selfplay.default_config(rules=rules, n_games=threads, search_threads=threads, max_batch_size=batch, max_simulations=sims,
+                                  tss_table_entries=1 << 16, node_capacity=4096, edge_capacity=65536)
+    pool = selfplay.GeneratorPool(cfg)
+    ocfg = ol.default_search_config(max_batch_size=batch, max_simulations=sims, table_entries=1 << 16)
+    op = np.zeros(64, np.uint16)
+    k = olib.ago_prepare_opening(rules, N, N, 77 + rules, ol.ptr(op))
+    h = olib.ago_game_create_ex(rules, N, N, 0, ctypes.byref(ocfg))
+    olib.ago_game_set_search_threads(h, threads)
+    olib.ago_game_set_serial(h, 0)
+    olib.ago_game_begin(h, ol.ptr(op), k)
+    pool.begin(selfplay.pack_openings([[int(x) for x in op[:k]]]))
+    ev = _stand_in_evaluator(olib)
+    compared, widest = 0, 0
+    for step in range(3000):
+        pool.select_solve()
+        slots, feats = pool.scheduled()
+        order = np.argsort(slots)                       # thread-major, task order inside a thread: the oracle's queue order
+        slots, feats = slots[order], feats[order]
+        pol, val = ev(feats) if len(slots) else (np.zeros((0, HW), np.float32), np.zeros((0, 2), np.float32))
+        pool.provide(slots, pol, np.concatenate([val, 1 - val.sum(1, keepdims=True)], 1).astype(np.float32))
+        f = np.zeros((threads * batch, HW), np.uint32)
+        c = olib.ago_game_step_select(h, ol.ptr(f), threads * batch)
+        assert c == len(slots), step
+        assert np.array_equal(feats, f[:c]), step
+        widest = max(widest, len({int(s) // batch for s in slots}))
+        olib.ago_game_step_expand(h, ol.ptr(np.ascontiguousarray(pol)), ol.ptr(np.ascontiguousarray(val)))
+        pool.expand_backup()
+        info = pool.game_info(0)
+        assert info["error"] == 0 and info["grow_pending"] == 0
+        if olib.ago_game_outcome(h) != 0:
+            break
+        r = _oracle_root(olib, h)
+        e = info["edges"]
+        assert info["n_moves"] == k + olib.ago_game_num_records(h), step
+        assert r["n"] == info["root_edges"] and r["visits"] == info["root_visits"], step
+        assert np.array_equal(np.array([x["move"] for x in e], np.uint16), r["moves"]), step
+        assert np.array_equal(np.array([x["visits"] for x in e], np.int32), r["ev"]), step
+        assert np.array_equal(np.array([x["score"] for x in e], np.uint16), r["es"]), step
+        assert np.array_equal(np.array([[x["win"], x["draw"]] for x in e], np.float32).reshape(-1), r["val"]), step
+        compared += 1
+    assert olib.ago_game_outcome(h) != 0 and pool.game_info(0, with_edges=False)["outcome"] == olib.ago_game_outcome(h)
+    recs, _ = pool.records()
+    assert len(recs) == olib.ago_game_num_records(h)
+    for i, r in enumerate(sorted(recs, key=lambda x: x.move_number)):
+        mv, rv, rs = ctypes.c_uint16(), ctypes.c_int(), ctypes.c_uint16()
+        rval = (ctypes.c_float * 2)()
+        em, evv, ep, evl, es = np.zeros(512, np.uint16), np.zeros(512, np.int32), np.zeros(512, np.float32), np.zeros(1024, np.float32), np.zeros(512, np.uint16)
+        olib.ago_game_record(h, i, ctypes.byref(mv), ctypes.byref(rv), rval, ctypes.byref(rs), ol.ptr(em), ol.ptr(evv), ol.ptr(ep), ol.ptr(evl), ol.ptr(es), 512)
+        assert r.move == mv.value and r.root_visits == rv.value
+    assert compared > 100 and widest == threads      # every thread found work in some step
+    pool.close()
+    olib.ago_game_destroy(h)
 
 
 def test_yielding_pool_gives_the_same_games(agx_lib, olib):
