@@ -105,16 +105,18 @@ class GeneratorPool:
     def provide(self, slots, policy, value3, action_values=None):
         """writes policy [n][cells] and value (win, draw, loss) [n][3] of the given slots (and, for a pool configured with
         action_values, q (win, draw) [n][cells][2])"""
-        pol = np.zeros((self.slots, self.cells), np.float32)
-        val = np.zeros((self.slots, 3), np.float32)
-        pol[slots] = policy
-        val[slots] = value3
-        check(lib.agx_memcpy_h2d(self.buffers.d_nn_policy, pol.ctypes.data_as(ctypes.c_void_p), pol.nbytes))
-        check(lib.agx_memcpy_h2d(self.buffers.d_nn_value, val.ctypes.data_as(ctypes.c_void_p), val.nbytes))
+        # the other slots keep what they held: a game whose batch waits for larger arenas reads its outputs one step later
+        if not hasattr(self, "_pol"):
+            self._pol = np.zeros((self.slots, self.cells), np.float32)
+            self._val = np.zeros((self.slots, 3), np.float32)
+            self._q = np.zeros((self.slots, self.cells, 2), np.float32)
+        self._pol[slots] = policy
+        self._val[slots] = value3
+        check(lib.agx_memcpy_h2d(self.buffers.d_nn_policy, self._pol.ctypes.data_as(ctypes.c_void_p), self._pol.nbytes))
+        check(lib.agx_memcpy_h2d(self.buffers.d_nn_value, self._val.ctypes.data_as(ctypes.c_void_p), self._val.nbytes))
         if action_values is not None:
-            q = np.zeros((self.slots, self.cells, 2), np.float32)
-            q[slots] = action_values
-            check(lib.agx_memcpy_h2d(self.buffers.d_nn_action_values, q.ctypes.data_as(ctypes.c_void_p), q.nbytes))
+            self._q[slots] = action_values
+            check(lib.agx_memcpy_h2d(self.buffers.d_nn_action_values, self._q.ctypes.data_as(ctypes.c_void_p), self._q.nbytes))
 
     def generate_openings(self, net, count, seed=0):
         """OpeningGenerator::generate: `count` solver-unproven, network-balanced openings (before begin()); returns
