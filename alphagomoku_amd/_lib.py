@@ -51,6 +51,7 @@ def _declare(c):
     c.agx_net_load_weights.argtypes = [vp, vp, sz]
     c.agx_nn_forward.argtypes = [vp, vp, ci, vp, vp, vp]
     c.agx_net_description.argtypes = [vp, vp]
+    c.agx_net_set_launch_width.argtypes = [vp, ci]
     c.agx_nn_forward_pvq.argtypes = [vp, vp, ci, vp, vp, vp, vp]
     c.agx_nn_forward_indirect_pvq.argtypes = [vp, vp, vp, vp, ci, vp, vp, vp, vp]
     c.agx_net_destroy.argtypes = [vp]

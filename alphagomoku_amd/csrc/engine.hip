@@ -1308,8 +1308,27 @@ namespace
 				atomicMax(&sh_max[2], static_cast<uint32_t>(max(e.visits, 0)));
 			}
 			__syncthreads();
-			if (tid == 0)
-			{ // which cells get an entry: visited or proven ones, and any cell 255 or more past the previous entry (:333-337, in cell order)
+			// which cells get an entry: visited or proven ones, and any cell 255 or more past the previous entry (:333-337, in cell order)
+			if (E.hw <= 255)
+			{ // no cell can be 255 past anything: the entries are the flagged cells, compacted in order by the first wave
+				if (wave == 0)
+				{
+					int count = 0;
+					for (int base = 0; base < E.hw; base += 64)
+					{
+						const int i = base + lane;
+						const bool flagged = (i < E.hw) && (cell_edge[i] & 0x8000);
+						const u64 m = __ballot(flagged);
+						if (flagged)
+							entry_cell[count + __popcll(m & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))))] = static_cast<uint16_t>(i);
+						count += __popcll(m);
+					}
+					if (lane == 0)
+						sh_int[5] = count;
+				}
+			}
+			else if (tid == 0)
+			{
 				int last = 0, count = 0;
 				for (int i = 0; i < E.hw; i++)
 					if ((cell_edge[i] & 0x8000) || (i - last) >= 255)
@@ -2019,6 +2038,8 @@ struct AgxEngine
 		AgxEngineConfig cfg;
 		EngineDev dev;
 		std::vector<void*> allocations;
+		std::vector<GameState> idle_games; // the pool before agx_engine_begin: every game idle, in its class-0 arena bundle
+		ArenaHeap idle_heap;
 		std::vector<uint64_t> zobrist; // [2*hw][2]
 		bool begun = false;
 		// optional per-kernel timing (agx_engine_kernel_timing): HIP events on the launch stream around every kernel of a step
@@ -2072,7 +2093,13 @@ namespace
 	int dev_alloc(AgxEngine *e, T **ptr, size_t count)
 	{
 		void *p = nullptr;
-		AGX_HIP_CHECK(hipMalloc(&p, std::max<size_t>(count * sizeof(T), 16)));
+		const hipError_t err = hipMalloc(&p, std::max<size_t>(count * sizeof(T), 16));
+		if (err != hipSuccess)
+		{
+			(void) hipGetLastError(); // the failure must not stay behind as the "last error" of this thread's later, successful calls
+			agx::set_error("hipMalloc of %zu bytes failed: %s", count * sizeof(T), hipGetErrorString(err));
+			return AGX_ERR_HIP;
+		}
 		e->allocations.push_back(p);
 		*ptr = static_cast<T*>(p);
 		return AGX_OK;
@@ -2280,6 +2307,8 @@ int agx_engine_create(const AgxEngineConfig *cfg, AgxEngine **out)
 		heap.edge_total = edge_total;
 		heap.ht_total = ht_total;
 		heap.free_capacity = static_cast<int32_t>(G);
+		e->idle_games = games;
+		e->idle_heap = heap;
 		hipError_t err = hipMemcpy(d.games, games.data(), G * sizeof(GameState), hipMemcpyHostToDevice);
 		if (err == hipSuccess)
 			err = hipMemcpy(d.heap, &heap, sizeof(heap), hipMemcpyHostToDevice);
@@ -2996,7 +3025,7 @@ int agx_debug_solve(AgxEngine *e, const uint8_t *h_boards, const int *h_signs, i
 					hipMemcpyDeviceToHost));
 	}
 	// leave the pool idle again
-	AGX_HIP_CHECK(hipMemset(d.games, 0, static_cast<size_t>(d.n_games) * sizeof(GameState)));
+	AGX_HIP_CHECK(hipMemcpy(d.games, e->idle_games.data(), e->idle_games.size() * sizeof(GameState), hipMemcpyHostToDevice)); // idle pool, arena descriptors intact
 	(void) hipFree(d_boards);
 	(void) hipFree(d_signs);
 	return AGX_OK;
@@ -3117,7 +3146,7 @@ int agx_engine_generate_openings(AgxEngine *e, AgxNet *net, int count, uint32_t 
 		for (Entry &en : workspace)
 			en.scheduled = false; // entries not consumed because enough openings were found
 	}
-	(void) hipMemset(d.games, 0, static_cast<size_t>(d.n_games) * sizeof(GameState)); // leave the pool idle again
+	(void) hipMemcpy(d.games, e->idle_games.data(), e->idle_games.size() * sizeof(GameState), hipMemcpyHostToDevice); // leave the pool idle again
 	(void) hipFree(d_boards);
 	(void) hipFree(d_signs);
 	if (h_stats != nullptr)

@@ -54,6 +54,9 @@
 #ifndef AGX_NN_CONV5_ROWS
 #define AGX_NN_CONV5_ROWS 1
 #endif
+#ifndef AGX_NN_CONV5_ROWS_WIDE
+#define AGX_NN_CONV5_ROWS_WIDE 1 // 0: 128-filter nets keep the tap-major 5x5 loop
+#endif
 #ifndef AGX_NN_AHEAD
 #define AGX_NN_AHEAD 4 // activation fragments in flight per wave in the row-stationary k-loop
 #endif
@@ -644,29 +647,27 @@ namespace
 			for (int n = 0; n < G::NTW; n++)
 				acc[i][n] = floatx4 { 0.0f, 0.0f, 0.0f, 0.0f };
 
-		if constexpr (G::S == 16 && AGX_NN_ROW_STATIONARY && AGX_NN_CONV5_ROWS && F == 64) // F = 128: the 2 x 10 weight fragments in flight spill, the tap loop is faster (measured)
+		if constexpr (G::S == 16 && AGX_NN_ROW_STATIONARY && AGX_NN_CONV5_ROWS && (F == 64 || AGX_NN_CONV5_ROWS_WIDE))
 		{
 			// Input-row stationary like conv3x3_mac_rows: for a column shift dx the fragment of padded input row j is read once and feeds the
 			// five taps dy = -2 .. 2 (output rows j + 2 .. j - 2): 5 x (NTW + 4) fragment reads instead of 25 x NTW, and — the padded plane being
 			// 2 cells wider than any shift on every side — no index clamping at all.
 			const half8 *wl = wpk + __builtin_amdgcn_readfirstlane(mg * G::MT * 64); // + lane; tap (dy, dx), tile i at ((dy * 5 + dx) * MTILES + i) * 64
-			half8 a_ring[2][5][G::MT];
+			half8 a_cur[5][G::MT], a_next[5][G::MT];
 #pragma unroll
 			for (int dyi = 0; dyi < 5; dyi++)
 #pragma unroll
 				for (int i = 0; i < G::MT; i++)
-					a_ring[0][dyi][i] = wl[((dyi * 5 + 0) * G::MTILES + i) * 64 + lane];
-#pragma unroll
+					a_cur[dyi][i] = wl[((dyi * 5 + 0) * G::MTILES + i) * 64 + lane];
+#pragma unroll 1
 			for (int dxi = 0; dxi < 5; dxi++)
-			{
-				if (dxi + 1 < 5)
-				{
+			{ // one loop body for the five column shifts (unrolled five times the 2 x 10 weight fragments in flight spill)
+				const int dxn = (dxi + 1 < 5) ? (dxi + 1) : 0;
 #pragma unroll
-					for (int dyi = 0; dyi < 5; dyi++)
+				for (int dyi = 0; dyi < 5; dyi++)
 #pragma unroll
-						for (int i = 0; i < G::MT; i++)
-							a_ring[(dxi + 1) & 1][dyi][i] = wl[((dyi * 5 + dxi + 1) * G::MTILES + i) * 64 + lane];
-				}
+					for (int i = 0; i < G::MT; i++)
+						a_next[dyi][i] = wl[((dyi * 5 + dxn) * G::MTILES + i) * 64 + lane];
 				// stored cell of this lane in padded row (n0 + j + 2): column r + (dxi - 2) + 2
 				auto fragment = [&](int j) -> half8
 				{
@@ -693,13 +694,18 @@ namespace
 						{
 #pragma unroll
 							for (int i = 0; i < G::MT; i++)
-								acc[i][o] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_ring[dxi & 1][dyi][i], b[(j + 2) % AHEAD], acc[i][o], 0, 0, 0);
+								acc[i][o] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_cur[dyi][i], b[(j + 2) % AHEAD], acc[i][o], 0, 0, 0);
 						}
 					}
 #if AGX_NN_SCHED_GROUPS == 2
 					__builtin_amdgcn_sched_barrier(0);
 #endif
 				}
+#pragma unroll
+				for (int dyi = 0; dyi < 5; dyi++)
+#pragma unroll
+					for (int i = 0; i < G::MT; i++)
+						a_cur[dyi][i] = a_next[dyi][i];
 			}
 		}
 		else
@@ -1196,6 +1202,7 @@ struct AgxNet
 		float bv1[4] = { 0, 0, 0, 0 };
 		float bv3[3] = { 0, 0, 0 };
 		int num_cus = 256;
+		int launch_width = 0; // 0 = every CU
 };
 
 namespace
@@ -1400,7 +1407,11 @@ static int launch_forward(AgxNet *net, const uint32_t *d_features, const int *d_
 	for (int i = 0; i < 3; i++)
 		p.bq2[i] = net->bq2[i];
 
-	const int grid = (batch < net->num_cus) ? batch : net->num_cus;
+	// persistent grid: one workgroup per CU it may use.  A pool stepped as pipelined slices narrows the launch (agx_net_set_launch_width) so that
+	// the CUs it leaves free run the OTHER slice's search kernels at the same time: a tower workgroup fills its CU's LDS and registers, so
+	// the two kinds of work never share a CU, they share the chip
+	const int width = (net->launch_width > 0 && net->launch_width < net->num_cus) ? net->launch_width : net->num_cus;
+	const int grid = (batch < width) ? batch : width;
 	hipStream_t s = static_cast<hipStream_t>(stream);
 	p.skip = nullptr;
 	const int kpad = (net->desc.rows * net->desc.cols * 4 + 31) / 32 * 32;
@@ -1504,6 +1515,13 @@ int agx_debug_nn_profile(unsigned long long *out)
 	return AGX_OK;
 }
 #endif
+
+int agx_net_set_launch_width(AgxNet *net, int workgroups)
+{
+	AGX_REQUIRE(net != nullptr && workgroups >= 0, AGX_ERR_INVALID, "agx_net_set_launch_width: invalid argument");
+	net->launch_width = workgroups;
+	return AGX_OK;
+}
 
 int agx_net_description(const AgxNet *net, AgxNetDesc *out)
 {

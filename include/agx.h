@@ -81,6 +81,10 @@ int agx_nn_forward(AgxNet* net, const uint32_t* d_features, int batch, float* d_
  * NetworkDataPack::unpackActionValues keeps (NetworkDataPack.cpp:214-224).  Passing NULL skips the head. */
 int agx_nn_forward_pvq(AgxNet* net, const uint32_t* d_features, int batch, float* d_policy, float* d_value, float* d_action_values, void* stream);
 int agx_net_description(const AgxNet* net, AgxNetDesc* out);
+/* Caps the persistent grid of the tower kernel at `workgroups` CUs (0 = all of them).  A tower workgroup fills its CU (LDS, registers), so
+ * a narrowed launch leaves whole CUs to kernels running at the same time on other streams: the other slices of a pool stepped as
+ * pipelined groups (agx_engine_*_group). */
+int agx_net_set_launch_width(AgxNet* net, int workgroups);
 int agx_net_destroy(AgxNet* net);
 
 /* Same network, but the batch is a device-side list: position i is slot d_slot_list[i] of the slot-indexed buffers

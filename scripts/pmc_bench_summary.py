@@ -1,0 +1,51 @@
+"""rocprofv3 --pmc rocpd databases of bench.py (one per pass) -> the summary bench.py quotes (profiles/<tag>_pmc_summary.json).
+
+Per kernel: counter sums per launch (summed over the XCD / SE instances the tool reports).  Derived, per MI355X_MICROARCH.md:
+  * HBM-side bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (gfx950: FETCH_SIZE tallies a 128-B request as 64 B for wide coalesced reads; unit KB;
+    Infinity-Cache hits are included);
+  * MFMA busy fraction = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs);
+  * solver issue-busy fraction = SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES, parked = SQ_WAIT_ANY / SQ_WAVE_CYCLES.
+The summary carries the source hash of the build it was taken from (bench.py quotes it only when it matches the build it runs)."""
+import json
+import os
+import re
+import sqlite3
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+out_path, dbs = sys.argv[1], sys.argv[2:]
+per = {}
+for path in dbs:
+    cur = sqlite3.connect(path).cursor()
+    rows = cur.execute("select name, dispatch_id, counter_name, sum(counter_value), max(duration) from pmc_events group by name, dispatch_id, counter_name").fetchall()
+    acc = {}
+    for name, dispatch, counter, value, duration in rows:
+        name = re.sub(r"\(.*$", "", name.replace("(anonymous namespace)::", "").replace("void ", "")).replace(".kd", "").strip()
+        k = acc.setdefault(name, {})
+        k.setdefault(counter, []).append(value)
+    for name, counters in acc.items():
+        s = per.setdefault(name, {})
+        for counter, values in counters.items():
+            s[counter + "_per_launch"] = sum(values) / len(values)
+            s["launches"] = len(values)
+import bench  # noqa: E402
+summary = {"_comment": __doc__, "source_hash": bench.source_hash(), "command": "python3 bench.py --steps 40 --warmup 30 --no-cpu-baseline",
+           "per_kernel_raw": per}
+tower = next((k for k in per if k.startswith("nn_tower_kernel<128, 15, 15")), None)
+if tower:
+    t = per[tower]
+    if "FETCH_SIZE_per_launch" in t and "WRITE_SIZE_per_launch" in t:
+        summary["nn_tower_bytes_per_launch_corrected"] = (2.0 * t["FETCH_SIZE_per_launch"] + t["WRITE_SIZE_per_launch"]) * 1024.0
+    if "SQ_VALU_MFMA_BUSY_CYCLES_per_launch" in t and "GRBM_GUI_ACTIVE_per_launch" in t:
+        summary["nn_tower_mfma_busy_fraction"] = t["SQ_VALU_MFMA_BUSY_CYCLES_per_launch"] / (1024.0 * t["GRBM_GUI_ACTIVE_per_launch"] / 8.0)
+    if "SQ_LDS_BANK_CONFLICT_per_launch" in t and t.get("SQ_LDS_IDX_ACTIVE_per_launch"):
+        summary["nn_tower_lds_bank_conflict_fraction"] = t["SQ_LDS_BANK_CONFLICT_per_launch"] / t["SQ_LDS_IDX_ACTIVE_per_launch"]
+solve = next((k for k in per if k.startswith("k_solve<false, 15>")), None)
+if solve and "SQ_WAVE_CYCLES_per_launch" in per[solve]:
+    t = per[solve]
+    summary["k_solve_issue_busy_fraction"] = t["SQ_ACTIVE_INST_ANY_per_launch"] / t["SQ_WAVE_CYCLES_per_launch"]
+    summary["k_solve_parked_fraction"] = t["SQ_WAIT_ANY_per_launch"] / t["SQ_WAVE_CYCLES_per_launch"]
+    summary["k_solve_issue_stall_fraction"] = t["SQ_WAIT_INST_ANY_per_launch"] / t["SQ_WAVE_CYCLES_per_launch"]
+json.dump(summary, open(out_path, "w"), indent=1, sort_keys=True)
+print(json.dumps({k: v for k, v in summary.items() if k not in ("per_kernel_raw", "_comment")}, indent=1))

@@ -723,8 +723,8 @@ def test_full_size_pool_matches_a_small_pool_game_by_game(agx_lib, name):
 
     def run(games, steps, yield_fraction):
         pool = selfplay.GeneratorPool(selfplay.default_config(rules=c["rules"], board_size=n, draw_after=n * n, n_games=games, max_batch_size=8, max_simulations=sims,
-                                                              tss_table_entries=4 * 1024 * 1024, node_capacity=max(8192, 16 * sims),
-                                                              edge_capacity=max(262144, 1536 * sims), solver_yield_fraction=yield_fraction,
+                                                              tss_table_entries=4 * 1024 * 1024, node_capacity=max(4096, 8 * sims),
+                                                              edge_capacity=max(65536, 192 * sims), arena_reserve=3.0, solver_yield_fraction=yield_fraction,
                                                               record_capacity=games * 64, record_edge_capacity=games * 64 * n * n))
         pool.begin(selfplay.pack_openings(openings[:games]))   # no spare openings: a finished game stays finished
         for _ in range(steps):
@@ -739,7 +739,7 @@ def test_full_size_pool_matches_a_small_pool_game_by_game(agx_lib, name):
         return st, {g: sorted(v) for g, v in per_game.items()}
     big_stats, big = run(1024, c["big_steps"], 0.75)
     small_stats, small = run(12, c["small_steps"], 0.0)
-    assert big_stats["first_error"] == 0 and small_stats["first_error"] == 0
+    assert big_stats["first_error"] == 0 and small_stats["first_error"] == 0 and big_stats["arena_failures"] == 0
     assert big_stats["moves_played"] > 1024 and big_stats["evaluated_nodes"] > 1024 * sims
     compared = 0
     for g in range(12):
