@@ -1891,25 +1891,27 @@ namespace
 		}
 	}
 	/* moves a game's tree into the bundle k_arena_service reserved for it: nodes and edges of the active arena copied as they are (indices
-	 * stay valid), the node-cache table rebuilt at its new size; then the old bundle goes onto the free list (thread 0 of the NEXT service
-	 * launch is the only other writer of the lists, and launches of one stream are ordered) */
-	__global__ __launch_bounds__(256) void k_arena_copy(EngineDev E)
+	 * stay valid), the node-cache table rebuilt at its new size.  `parts` workgroups per game: the edges (a few MB for a large tree) are
+	 * split among them, part 0 also moves the nodes and rebuilds the table; k_arena_commit then switches the game over. */
+	__global__ __launch_bounds__(256) void k_arena_copy(EngineDev E, int parts)
 	{
-		const int g = E.g0 + blockIdx.x, tid = threadIdx.x;
-		GameState &gs = E.games[g];
+		const int g = E.g0 + blockIdx.x / parts, part = blockIdx.x % parts, tid = threadIdx.x;
+		const GameState &gs = E.games[g];
 		if (gs.grow_pending != 3)
 			return;
-		const int cls = gs.arena_class + 1;
-		const int new_ht_cap = E.ht_cap << cls;
-		const DNode *src_nodes = nodes_of(E, g, gs.arena);
 		const u64 *src_edges = reinterpret_cast<const u64*>(edges_of(E, g, gs.arena));
-		DNode *dst_nodes = E.nodes + gs.new_node_off[gs.arena];
 		u64 *dst_edges = reinterpret_cast<u64*>(E.edges + gs.new_edge_off[gs.arena]);
+		const size_t words = 3 * static_cast<size_t>(gs.n_edges);
+		for (size_t i = static_cast<size_t>(part) * 256 + tid; i < words; i += static_cast<size_t>(parts) * 256)
+			dst_edges[i] = src_edges[i];
+		if (part != 0)
+			return;
+		const int new_ht_cap = E.ht_cap << (gs.arena_class + 1);
+		const DNode *src_nodes = nodes_of(E, g, gs.arena);
+		DNode *dst_nodes = E.nodes + gs.new_node_off[gs.arena];
 		int *ht = E.ht + gs.new_ht_off;
 		for (int i = tid; i < new_ht_cap; i += 256)
 			ht[i] = 0;
-		for (size_t i = tid; i < 3 * static_cast<size_t>(gs.n_edges); i += 256)
-			dst_edges[i] = src_edges[i];
 		__syncthreads();
 		const int mask = new_ht_cap - 1;
 		for (int i = tid; i < gs.n_nodes; i += 256)
@@ -1920,22 +1922,28 @@ namespace
 			while (atomicCAS(&ht[slot], 0, i + 1) != 0)
 				slot = (slot + 1) & mask;
 		}
-		__syncthreads();
-		if (tid == 0)
-		{
-			arena_free(E, gs.arena_class, gs);
-			gs.node_off[0] = gs.new_node_off[0];
-			gs.node_off[1] = gs.new_node_off[1];
-			gs.edge_off[0] = gs.new_edge_off[0];
-			gs.edge_off[1] = gs.new_edge_off[1];
-			gs.ht_off = gs.new_ht_off;
-			gs.arena_class = cls;
-			gs.node_cap = E.node_cap << cls;
-			gs.edge_cap = E.edge_cap << cls;
-			gs.ht_cap = new_ht_cap;
-			gs.grow_count++;
-			gs.grow_pending = 2;
-		}
+	}
+	/* the old bundle goes onto the free list, the game continues in the new one */
+	__global__ __launch_bounds__(64) void k_arena_commit(EngineDev E)
+	{ // one workgroup per game and ONE acting thread in it: the heap lock must never be contended by lanes of one wave
+		if (threadIdx.x != 0)
+			return;
+		GameState &gs = E.games[E.g0 + blockIdx.x];
+		if (gs.grow_pending != 3)
+			return;
+		const int cls = gs.arena_class + 1;
+		arena_free(E, gs.arena_class, gs);
+		gs.node_off[0] = gs.new_node_off[0];
+		gs.node_off[1] = gs.new_node_off[1];
+		gs.edge_off[0] = gs.new_edge_off[0];
+		gs.edge_off[1] = gs.new_edge_off[1];
+		gs.ht_off = gs.new_ht_off;
+		gs.arena_class = cls;
+		gs.node_cap = E.node_cap << cls;
+		gs.edge_cap = E.edge_cap << cls;
+		gs.ht_cap = E.ht_cap << cls;
+		gs.grow_count++;
+		gs.grow_pending = 2;
 	}
 
 	__global__ void k_reset_counter(int *counter, int *second)
@@ -2526,7 +2534,8 @@ int agx_engine_expand_backup_match(AgxEngine *e, void *stream)
 		// a moving tree's workgroup also rebases its partner's tree; the partner's own workgroup has nothing to do (it is not searching)
 		hipLaunchKernelGGL(k_advance, dim3(d.n_games), dim3(256), 0, s, d);
 		hipLaunchKernelGGL(k_arena_service, dim3(1), dim3(1024), 0, s, d, d.n_games);
-		hipLaunchKernelGGL(k_arena_copy, dim3(d.n_games), dim3(256), 0, s, d);
+		hipLaunchKernelGGL(k_arena_copy, dim3(d.n_games * CLEAR_PARTS), dim3(256), 0, s, d, CLEAR_PARTS);
+		hipLaunchKernelGGL(k_arena_commit, dim3(d.n_games), dim3(64), 0, s, d);
 		hipLaunchKernelGGL(k_assign_openings, dim3(1), dim3(1024), 0, s, d, d.n_games / 2);
 		hipLaunchKernelGGL(k_clear_tables, dim3(d.n_games * CLEAR_PARTS), dim3(256), 0, s, d, CLEAR_PARTS);
 		hipLaunchKernelGGL(k_match_restart, dim3(d.n_games / 2), dim3(256), 0, s, d);
@@ -2609,7 +2618,8 @@ int agx_engine_advance_group(AgxEngine *e, int group, int n_groups, void *stream
 		const int trees = d.shared_tree ? 1 : count; // tournament search: one tree (game 0), the other records are its search threads
 		hipLaunchKernelGGL(k_advance, dim3(trees), dim3(256), 0, s, d);
 		hipLaunchKernelGGL(k_arena_service, dim3(1), dim3(1024), 0, s, d, trees);
-		hipLaunchKernelGGL(k_arena_copy, dim3(trees), dim3(256), 0, s, d);
+		hipLaunchKernelGGL(k_arena_copy, dim3(trees * CLEAR_PARTS), dim3(256), 0, s, d, CLEAR_PARTS);
+		hipLaunchKernelGGL(k_arena_commit, dim3(trees), dim3(64), 0, s, d);
 		if (!d.match_mode)
 		{
 			hipLaunchKernelGGL(k_assign_openings, dim3(1), dim3(1024), 0, s, d, trees);

@@ -74,12 +74,15 @@ def cpu_baseline(args, max_seconds):
     if args.cpu_threads > 0:
         counts = [min(cores, args.cpu_threads)]
     else:
-        counts = sorted({c for c in (cores // 4, cores // 2, cores) if c >= 1})
-    legs = [leg(c, max_seconds / len(counts)) for c in counts]
-    best = max(legs, key=lambda x: x["simulations_per_sec"])
+        counts = sorted({c for c in (cores // 8, cores // 4, cores // 2, cores) if c >= 1})
+    probes = [leg(c, 0.1 * max_seconds) for c in counts] if len(counts) > 1 else []
+    chosen = max(probes, key=lambda x: x["simulations_per_sec"])["threads"] if probes else counts[0]
+    best = leg(chosen, max_seconds - 0.1 * max_seconds * len(probes))     # the reported value: one long leg at the best thread count
+    legs = probes + [best]
     return dict(value=best["simulations_per_sec"], unit="simulations/s", cores=best["threads"], kind="port",
                 sample="%d threads x 1 self-play game each (same rules/board/playouts/batch, stand-in evaluator, NN cost excluded), %.1f s wall, %d simulations, %d moves; "
-                       "best of a sweep over %s threads" % (best["threads"], best["seconds"], best["simulations"], best["moves"], counts),
+                       "thread count chosen by short probes over %s threads (every host CPU is slower: one 64 MB solver table per game)"
+                       % (best["threads"], best["seconds"], best["simulations"], best["moves"], counts),
                 host_cpus=cores, per_thread=best["per_thread"], sweep=legs,
                 # the REAL reference search core (compiled with AVX2 intrinsics, one thread, fake evaluator) measured 10.5 k/s for this
                 # shape in the survey container; the oracle is a scalar restatement (no SSE/AVX neighbourhood code) and every game owns a 64 MB
