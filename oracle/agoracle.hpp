@@ -229,12 +229,12 @@ namespace ago
 	enum GenMode : int { G_BASIC = 0, G_THREATS = 1, G_OPTIMAL = 2, G_REDUCED = 3, G_LEGAL = 4 }; // MoveGenerator.hpp:27-34
 
 	struct ActionStack
-	{ // ActionList.hpp:42-99
+	{ // ActionList.hpp:247-315 (Action, ActionStack; the first half of the file is a commented-out older version)
 			std::vector<Action> data;
 			size_t offset = 0, max_offset = 0;
 	};
 	struct ActionList
-	{ // ActionList.hpp:101-268 (a window on the shared stack)
+	{ // ActionList.hpp:317-470 (a window on the shared stack)
 			ActionStack *stack = nullptr;
 			size_t base = 0;
 			int size = 0;
