@@ -996,7 +996,7 @@ namespace agx
 				}
 
 				__device__ __forceinline__ void push(uint32_t move, uint32_t score, int num)
-				{ // ActionList::add (ActionList.hpp:190-195)
+				{ // ActionList::add (ActionList.hpp:405-410)
 					if (f.base + f.size + 1 >= E.act_cap)
 					{
 						sh.error = ERR_ACTION_STACK;
@@ -2060,7 +2060,7 @@ namespace agx
 						sh.result_score = static_cast<int>(value);
 						return yield(CMD_DONE, 0);
 					}
-					stack_offset -= f.size; // ~ActionList (ActionList.hpp:128-131)
+					stack_offset -= f.size; // ~ActionList (ActionList.hpp:344-347)
 					level--;
 					phase = 1;
 					return yield(CMD_UNDO, sh.frames[level].move);

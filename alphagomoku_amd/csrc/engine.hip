@@ -1892,20 +1892,24 @@ namespace
 	}
 	/* moves a game's tree into the bundle k_arena_service reserved for it: nodes and edges of the active arena copied as they are (indices
 	 * stay valid), the node-cache table rebuilt at its new size.  `parts` workgroups per game: the edges (a few MB for a large tree) are
-	 * split among them, part 0 also moves the nodes and rebuilds the table; k_arena_commit then switches the game over. */
+	 * split among parts 1.., part 0 moves the nodes and rebuilds the table; k_arena_commit then switches the game over. */
 	__global__ __launch_bounds__(256) void k_arena_copy(EngineDev E, int parts)
 	{
 		const int g = E.g0 + blockIdx.x / parts, part = blockIdx.x % parts, tid = threadIdx.x;
 		const GameState &gs = E.games[g];
 		if (gs.grow_pending != 3)
 			return;
-		const u64 *src_edges = reinterpret_cast<const u64*>(edges_of(E, g, gs.arena));
-		u64 *dst_edges = reinterpret_cast<u64*>(E.edges + gs.new_edge_off[gs.arena]);
-		const size_t words = 3 * static_cast<size_t>(gs.n_edges);
-		for (size_t i = static_cast<size_t>(part) * 256 + tid; i < words; i += static_cast<size_t>(parts) * 256)
-			dst_edges[i] = src_edges[i];
 		if (part != 0)
+		{ // 24-byte edge records copied as 16-byte words (arena regions start at multiples of the even class-0 capacity: 16-byte aligned)
+			const uint4 *src_edges = reinterpret_cast<const uint4*>(edges_of(E, g, gs.arena));
+			uint4 *dst_edges = reinterpret_cast<uint4*>(E.edges + gs.new_edge_off[gs.arena]);
+			const size_t halves = 3 * static_cast<size_t>(gs.n_edges), words = halves / 2;
+			for (size_t i = static_cast<size_t>(part - 1) * 256 + tid; i < words; i += static_cast<size_t>(parts - 1) * 256)
+				dst_edges[i] = src_edges[i];
+			if ((halves & 1) != 0 && part == 1 && tid == 0)
+				reinterpret_cast<u64*>(dst_edges)[halves - 1] = reinterpret_cast<const u64*>(src_edges)[halves - 1];
 			return;
+		}
 		const int new_ht_cap = E.ht_cap << (gs.arena_class + 1);
 		const DNode *src_nodes = nodes_of(E, g, gs.arena);
 		DNode *dst_nodes = E.nodes + gs.new_node_off[gs.arena];
@@ -2231,6 +2235,7 @@ int agx_engine_create(const AgxEngineConfig *cfg, AgxEngine **out)
 	d.zobrist_seed = cfg->zobrist_seed;
 	d.node_cap = cfg->node_capacity > 0 ? cfg->node_capacity : 8192;
 	d.edge_cap = cfg->edge_capacity > 0 ? cfg->edge_capacity : 524288;
+	d.edge_cap += d.edge_cap & 1; // even: every arena region then starts on a 16-byte boundary (k_arena_copy moves edges as 16-byte words)
 	d.ht_cap = static_cast<int>(round_pow2(4 * static_cast<size_t>(d.node_cap)));
 	d.act_cap = d.hw * (d.hw + 1) / 2 + 64;
 	d.record_cap = cfg->record_capacity > 0 ? cfg->record_capacity : d.n_games * d.hw;

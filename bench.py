@@ -248,6 +248,7 @@ def main():
         traffic = None
         mfma_busy = None
         solver_issue = None
+        nn_clock = None
         pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
         src_hash = source_hash()
         pmc_build = None
@@ -258,6 +259,7 @@ def main():
                 traffic = pmc.get("nn_tower_bytes_per_launch_corrected")
                 mfma_busy = pmc.get("nn_tower_mfma_busy_fraction")
                 solver_issue = pmc.get("k_solve_issue_busy_fraction")
+                nn_clock = pmc.get("nn_tower_shader_clock_mhz")
         gpu_ms = kernel_ms[0] + kernel_ms[1] + kernel_ms[2] + kernel_ms[3] + ms_nn
         per_kernel = {"k_select": kernel_ms[0], "k_solve": kernel_ms[1], "nn_tower": ms_nn, "k_expand": kernel_ms[2], "k_advance": kernel_ms[3]}
         longest = max(per_kernel, key=per_kernel.get)
@@ -301,7 +303,12 @@ def main():
                          "flops_per_position": flops, "positions_per_launch": local_evals / args.steps,
                          "avg_launch_ms": ms_nn / args.steps,
                          # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) of the committed PMC passes of this command
-                         "mfma_busy_fraction_pmc": mfma_busy, "pmc_summary_build": pmc_build},
+                         "mfma_busy_fraction_pmc": mfma_busy,
+                         # GRBM_GUI_ACTIVE / 8 / launch duration: the tower runs power-limited below the 2.4 GHz the 2.5 PFLOP/s peak assumes
+                         # (frac keeps the nominal peak; this is the same rate against the MFMA issue rate at the clock actually held)
+                         "shader_clock_mhz_pmc": nn_clock,
+                         "frac_of_issue_rate_at_measured_clock": (nn_tflops / (2500.0 * nn_clock / 2400.0)) if nn_clock else None,
+                         "pmc_summary_build": pmc_build},
             "roofline_solver": {"bound": "none (instruction issue / dependent-chain latency: one wave per game, tasks of a game strictly ordered)",
                                 "kernel": "k_solve", "ms_per_step": kernel_ms[1] / args.steps,
                                 "share_of_kernel_time": kernel_ms[1] / gpu_ms if gpu_ms > 0 else None,

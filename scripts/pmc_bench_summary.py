@@ -4,7 +4,9 @@ Per kernel: counter sums per launch (summed over the XCD / SE instances the tool
   * HBM-side bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (gfx950: FETCH_SIZE tallies a 128-B request as 64 B for wide coalesced reads; unit KB;
     Infinity-Cache hits are included);
   * MFMA busy fraction = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs);
-  * solver issue-busy fraction = SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES, parked = SQ_WAIT_ANY / SQ_WAVE_CYCLES.
+  * solver issue-busy fraction = SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES, parked = SQ_WAIT_ANY / SQ_WAVE_CYCLES;
+  * shader clock of a kernel = (GRBM_GUI_ACTIVE / 8 XCDs) / launch duration of the same dispatch (the tower runs power-limited well below the
+    2.4 GHz the MFMA peak assumes, the solver at the full clock).
 The summary carries the source hash of the build it was taken from (bench.py quotes it only when it matches the build it runs)."""
 import json
 import os
@@ -24,8 +26,13 @@ for path in dbs:
         name = re.sub(r"\(.*$", "", name.replace("(anonymous namespace)::", "").replace("void ", "")).replace(".kd", "").strip()
         k = acc.setdefault(name, {})
         k.setdefault(counter, []).append(value)
+        if counter == "GRBM_GUI_ACTIVE" and duration:
+            k.setdefault("_clock_mhz", []).append(value / 8.0 / duration * 1e3)
     for name, counters in acc.items():
         s = per.setdefault(name, {})
+        clocks = counters.pop("_clock_mhz", None)
+        if clocks:
+            s["shader_clock_mhz"] = sum(clocks) / len(clocks)
         for counter, values in counters.items():
             s[counter + "_per_launch"] = sum(values) / len(values)
             s["launches"] = len(values)
@@ -39,6 +46,8 @@ if tower:
         summary["nn_tower_bytes_per_launch_corrected"] = (2.0 * t["FETCH_SIZE_per_launch"] + t["WRITE_SIZE_per_launch"]) * 1024.0
     if "SQ_VALU_MFMA_BUSY_CYCLES_per_launch" in t and "GRBM_GUI_ACTIVE_per_launch" in t:
         summary["nn_tower_mfma_busy_fraction"] = t["SQ_VALU_MFMA_BUSY_CYCLES_per_launch"] / (1024.0 * t["GRBM_GUI_ACTIVE_per_launch"] / 8.0)
+    if "shader_clock_mhz" in t:
+        summary["nn_tower_shader_clock_mhz"] = t["shader_clock_mhz"]
     if "SQ_LDS_BANK_CONFLICT_per_launch" in t and t.get("SQ_LDS_IDX_ACTIVE_per_launch"):
         summary["nn_tower_lds_bank_conflict_fraction"] = t["SQ_LDS_BANK_CONFLICT_per_launch"] / t["SQ_LDS_IDX_ACTIVE_per_launch"]
 solve = next((k for k in per if k.startswith("k_solve<false, 15>")), None)
@@ -46,6 +55,8 @@ if solve and "SQ_WAVE_CYCLES_per_launch" in per[solve]:
     t = per[solve]
     summary["k_solve_issue_busy_fraction"] = t["SQ_ACTIVE_INST_ANY_per_launch"] / t["SQ_WAVE_CYCLES_per_launch"]
     summary["k_solve_parked_fraction"] = t["SQ_WAIT_ANY_per_launch"] / t["SQ_WAVE_CYCLES_per_launch"]
+    if "shader_clock_mhz" in t:
+        summary["k_solve_shader_clock_mhz"] = t["shader_clock_mhz"]
     summary["k_solve_issue_stall_fraction"] = t["SQ_WAIT_INST_ANY_per_launch"] / t["SQ_WAVE_CYCLES_per_launch"]
 json.dump(summary, open(out_path, "w"), indent=1, sort_keys=True)
 print(json.dumps({k: v for k, v in summary.items() if k not in ("per_kernel_raw", "_comment")}, indent=1))
