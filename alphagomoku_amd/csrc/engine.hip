@@ -381,7 +381,12 @@ namespace
 
 	/* NFIX: board size known at compile time (15, 20) or 0 for any size.  The solver divides and takes remainders by the board size
 	 * all the time (cell <-> row, column); with a constant these are a multiply and a shift instead of ~40 instructions each. */
-	template<bool RENJU, int NFIX>
+	/* FUSED: Search::select of the game runs in the same wave right before its solver (self-play and match pools; a tournament-search pool
+	 * selects for all threads in one wave, k_select).  As two launches the select stage lasts as long as its slowest game (deep end-game
+	 * paths, leak retries: measured 2.4 x the mean wave) while the other SIMDs idle; fused, a slow descent only delays its own game's solver
+	 * and the launch ends with the yield rule as before.  The select stage's LDS (board, keys) aliases the threat lists, which the solver
+	 * initialises afterwards. */
+	template<bool RENJU, int NFIX, bool FUSED>
 	__global__ __launch_bounds__(64) void k_solve(EngineDev E)
 	{
 		if (NFIX != 0)
@@ -391,6 +396,25 @@ namespace
 		}
 		__shared__ SolverShared sh;
 		const int g = E.g0 + blockIdx.x, lane = threadIdx.x;
+		if (FUSED)
+		{
+			static_assert(offsetof(SolverShared, lists) % 8 == 0, "select-stage keys alias the threat lists as 64-bit words");
+			static_assert(sizeof(sh.lists) >= (3 * (1 + MAXHW) + BWORDS) * sizeof(u64) + MAXHW, "select-stage LDS must fit into the threat lists");
+			const GameState &sg = E.games[g];
+			if (sg.active && sg.error == 0 && sg.outcome == 0 && !sg.grow_pending)
+			{
+				use_game_arenas(E, g);
+				u64 *sel_keys = reinterpret_cast<u64*>(&sh.lists[0][0][0]);
+				u64 *sel_cboard = sel_keys + 3 * (1 + MAXHW);
+				uint8_t *sel_board = reinterpret_cast<uint8_t*>(sel_cboard + BWORDS);
+				for (int i = lane; i < 3 * (1 + E.hw); i += 64)
+					sel_keys[i] = E.nc_keys[i];
+				if (!sg.solve_pending)
+					select_batch(E, g, g, lane, sel_board, sel_cboard, sel_keys);
+			}
+			__threadfence(); // the tasks written by the select stage are read back below (other lanes, vector L1)
+			__syncthreads();
+		}
 		GameState &gs = E.games[g];
 		const bool idle = (!gs.active || gs.error != 0 || gs.outcome != 0 || E.games[E.shared_tree ? 0 : g].grow_pending != 0);
 		const int n_tasks = idle ? 0 : gs.n_tasks;
@@ -2054,6 +2078,9 @@ struct AgxEngine
 		ArenaHeap idle_heap;
 		std::vector<uint64_t> zobrist; // [2*hw][2]
 		bool begun = false;
+		// Search::select and the threat solver of a game in one launch (k_solve<.., FUSED>); AGX_FUSE_SELECT=0 keeps them as two launches
+		// (separate k_select / k_solve times in agx_engine_kernel_timing and in profiles)
+		bool fuse_select = true;
 		// optional per-kernel timing (agx_engine_kernel_timing): HIP events on the launch stream around every kernel of a step
 		bool timing = false;
 		std::vector<hipEvent_t> events;   // groups of (before, after) per kernel launch
@@ -2206,6 +2233,8 @@ int agx_engine_create(const AgxEngineConfig *cfg, AgxEngine **out)
 
 	AgxEngine *e = new AgxEngine();
 	e->cfg = *cfg;
+	if (const char *fuse = std::getenv("AGX_FUSE_SELECT"))
+		e->fuse_select = std::atoi(fuse) != 0;
 	EngineDev &d = e->dev;
 	std::memset(&d, 0, sizeof(d));
 	d.rules = cfg->rules;
@@ -2428,23 +2457,31 @@ static int group_range(const AgxEngine *e, int group, int n_groups, EngineDev &d
 
 static constexpr int CLEAR_PARTS = 16; // workgroups per restarting game in k_clear_tables
 
-static void launch_solve(const EngineDev &d, int count, hipStream_t s)
+#define AGX_LAUNCH_SOLVE(FUSED) \
+	do { \
+		if (d.rules == AGX_RENJU) \
+		{ \
+			if (d.n == 15) \
+				hipLaunchKernelGGL((k_solve<true, 15, FUSED>), grid, block, 0, s, d); \
+			else \
+				hipLaunchKernelGGL((k_solve<true, 0, FUSED>), grid, block, 0, s, d); \
+		} \
+		else if (d.n == 15) \
+			hipLaunchKernelGGL((k_solve<false, 15, FUSED>), grid, block, 0, s, d); \
+		else if (d.n == 20) \
+			hipLaunchKernelGGL((k_solve<false, 20, FUSED>), grid, block, 0, s, d); \
+		else \
+			hipLaunchKernelGGL((k_solve<false, 0, FUSED>), grid, block, 0, s, d); \
+	} while (0)
+static void launch_solve(const EngineDev &d, int count, hipStream_t s, bool with_select = false)
 {
 	const dim3 grid(count), block(64);
-	if (d.rules == AGX_RENJU)
-	{
-		if (d.n == 15)
-			hipLaunchKernelGGL((k_solve<true, 15>), grid, block, 0, s, d);
-		else
-			hipLaunchKernelGGL((k_solve<true, 0>), grid, block, 0, s, d);
-	}
-	else if (d.n == 15)
-		hipLaunchKernelGGL((k_solve<false, 15>), grid, block, 0, s, d);
-	else if (d.n == 20)
-		hipLaunchKernelGGL((k_solve<false, 20>), grid, block, 0, s, d);
+	if (with_select)
+		AGX_LAUNCH_SOLVE(true);
 	else
-		hipLaunchKernelGGL((k_solve<false, 0>), grid, block, 0, s, d);
+		AGX_LAUNCH_SOLVE(false);
 }
+#undef AGX_LAUNCH_SOLVE
 
 /* Search::select for every game of the group (Search.cpp:117-158) */
 int agx_engine_select_group(AgxEngine *e, int group, int n_groups, void *stream)
@@ -2485,6 +2522,22 @@ int agx_engine_solve_group(AgxEngine *e, int group, int n_groups, void *stream)
 }
 int agx_engine_select_solve_group(AgxEngine *e, int group, int n_groups, void *stream)
 {
+	if (e != nullptr && e->begun && e->fuse_select && !e->dev.shared_tree)
+	{ // one launch: every game selects and solves in its own wave (k_solve<.., FUSED>); timed as the solve stage
+		EngineDev d;
+		int count = 0;
+		const int st = group_range(e, group, n_groups, d, count);
+		if (st != AGX_OK)
+			return st;
+		hipStream_t s = static_cast<hipStream_t>(stream);
+		hipLaunchKernelGGL(k_reset_counter, dim3(1), dim3(1), 0, s, d.counters + d.nn_counter, d.counters + d.yield_counter);
+		{
+			KernelTimer t(e, s, 1);
+			launch_solve(d, count, s, true);
+		}
+		AGX_HIP_CHECK(hipGetLastError());
+		return AGX_OK;
+	}
 	const int st = agx_engine_select_group(e, group, n_groups, stream);
 	return (st != AGX_OK) ? st : agx_engine_solve_group(e, group, n_groups, stream);
 }
@@ -2512,13 +2565,21 @@ int agx_engine_select_solve_match(AgxEngine *e, void *stream)
 	hipStream_t s = static_cast<hipStream_t>(stream);
 	hipLaunchKernelGGL(k_reset_counter, dim3(1), dim3(1), 0, s, d.counters + 16, d.counters + 32);
 	hipLaunchKernelGGL(k_reset_counter, dim3(1), dim3(1), 0, s, d.counters + 17, static_cast<int*>(nullptr));
-	{
-		KernelTimer t(e, s, 0);
-		hipLaunchKernelGGL(k_select, dim3(d.n_games), dim3(64), 0, s, d);
-	}
+	if (e->fuse_select)
 	{
 		KernelTimer t(e, s, 1);
-		launch_solve(d, d.n_games, s);
+		launch_solve(d, d.n_games, s, true);
+	}
+	else
+	{
+		{
+			KernelTimer t(e, s, 0);
+			hipLaunchKernelGGL(k_select, dim3(d.n_games), dim3(64), 0, s, d);
+		}
+		{
+			KernelTimer t(e, s, 1);
+			launch_solve(d, d.n_games, s);
+		}
 	}
 	AGX_HIP_CHECK(hipGetLastError());
 	return AGX_OK;

@@ -286,6 +286,9 @@ def main():
             "stage_ms_per_step": {"select_solve": ms_sel / args.steps, "network": ms_nn / args.steps, "expand_backup_advance": ms_exp / args.steps},
             "kernel_ms_per_step": {"k_select": kernel_ms[0] / args.steps, "k_solve": kernel_ms[1] / args.steps, "nn_tower": ms_nn / args.steps,
                                    "k_expand": kernel_ms[2] / args.steps, "k_advance": kernel_ms[3] / args.steps},
+            # default: Search::select runs inside the solver's launch (one wave per game selects, then solves: k_solve<.., FUSED>), its time is
+            # part of k_solve and k_select is 0; AGX_FUSE_SELECT=0 launches them separately
+            "select_fused_into_solve": os.environ.get("AGX_FUSE_SELECT", "1") != "0",
             "peak_tree_per_game": {"nodes": int(s1["peak_nodes"]), "edges": int(s1["peak_edges"]), "class0_node_capacity": node_capacity,
                                    "class0_edge_capacity": edge_capacity, "arena_grows": int(s1["arena_grows"]), "arena_releases": int(s1["arena_releases"]),
                                    "arena_failures": int(s1["arena_failures"]), "arena_max_class": int(s1["arena_max_class"]),
@@ -310,7 +313,7 @@ def main():
                          "frac_of_issue_rate_at_measured_clock": (nn_tflops / (2500.0 * nn_clock / 2400.0)) if nn_clock else None,
                          "pmc_summary_build": pmc_build},
             "roofline_solver": {"bound": "none (instruction issue / dependent-chain latency: one wave per game, tasks of a game strictly ordered)",
-                                "kernel": "k_solve", "ms_per_step": kernel_ms[1] / args.steps,
+                                "kernel": "k_solve (select + threat solver of a game in one wave)" if os.environ.get("AGX_FUSE_SELECT", "1") != "0" else "k_solve", "ms_per_step": kernel_ms[1] / args.steps,
                                 "share_of_kernel_time": kernel_ms[1] / gpu_ms if gpu_ms > 0 else None,
                                 "solver_nodes_per_sec": solver_nodes / elapsed, "us_per_solver_node_per_wave": (kernel_ms[1] * 1e3 * args.games / solver_nodes) if solver_nodes else None,
                                 "issue_busy_fraction_pmc": solver_issue},
