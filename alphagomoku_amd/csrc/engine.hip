@@ -15,7 +15,7 @@
  *
  * Everything stays in HBM between steps; the host only enqueues launches.  One wavefront per game for the sequential
  * tree work (games are independent, the batch inside a game is order-dependent through virtual loss); k_advance uses a
- * 256-thread workgroup per game because compaction is data parallel.
+ * 1024-thread workgroup per game because compaction is data parallel.
  */
 #include "agx_internal.hpp"
 #include "engine_types.hpp"
@@ -949,14 +949,17 @@ namespace
 	}
 
 	/* ------------------------------------------------------------------------------------------------------------ */
+	template<int TPB = 256>
 	__device__ void block_reduce_xor(u64 &v, u64 *scratch, int tid)
-	{
+	{ // scratch: TPB / 64 words
 		v = wave_reduce_xor64(v);
 		__syncthreads();
 		if ((tid & 63) == 0)
 			scratch[tid >> 6] = v;
 		__syncthreads();
-		v = scratch[0] ^ scratch[1] ^ scratch[2] ^ scratch[3];
+		v = 0;
+		for (int w = 0; w < TPB / 64; w++)
+			v ^= scratch[w];
 		__syncthreads();
 	}
 	__device__ void clear_solver_table(const EngineDev &E, int g, int tid)
@@ -1031,8 +1034,9 @@ namespace
 	/*
 	 * prepare_search / Player::setBoard for tree t on the position in its GameState (GameGenerator.cpp:174-185, Player.cpp:98-110):
 	 * NodeCache::cleanup (NodeCache.cpp:221-249) as keep-test + prefix sum + copy to the other arena, Search::setBoard
-	 * (increaseGeneration), Tree::setBoard (root = seek(new board), Tree.cpp:146-149).  Whole 256-thread workgroup.
+	 * (increaseGeneration), Tree::setBoard (root = seek(new board), Tree.cpp:146-149).  Whole workgroup of TPB threads.
 	 */
+	template<int TPB>
 	__device__ void rebase_tree(const EngineDev &E0, int t, int tid, u64 *scratch, int *scan_nodes, int *scan_edges)
 	{
 		EngineDev E = E0;
@@ -1044,12 +1048,12 @@ namespace
 		DNode *dst_nodes = nodes_of(E, t, gs.arena ^ 1);
 		DEdge *dst_edges = edges_of(E, t, gs.arena ^ 1);
 		int *ht = ht_of(E, t);
-		for (int i = tid; i < E.ht_cap; i += 256)
+		for (int i = tid; i < E.ht_cap; i += TPB)
 			ht[i] = 0;
 		const int total = gs.n_nodes;
 		int node_base = 0, edge_base = 0;
 		__syncthreads();
-		for (int base = 0; base < total; base += 256)
+		for (int base = 0; base < total; base += TPB)
 		{
 			const int i = base + tid;
 			int keep = 0, ne = 0;
@@ -1067,7 +1071,7 @@ namespace
 			scan_nodes[tid] = keep;
 			scan_edges[tid] = ne;
 			__syncthreads();
-			for (int o = 1; o < 256; o <<= 1)
+			for (int o = 1; o < TPB; o <<= 1)
 			{ // inclusive Hillis-Steele scan
 				const int a = (tid >= o) ? scan_nodes[tid - o] : 0, b = (tid >= o) ? scan_edges[tid - o] : 0;
 				__syncthreads();
@@ -1118,14 +1122,14 @@ namespace
 					}
 				}
 			}
-			node_base += scan_nodes[255];
-			edge_base += scan_edges[255];
+			node_base += scan_nodes[TPB - 1];
+			edge_base += scan_edges[TPB - 1];
 			__syncthreads();
 		}
 		u64 h = 0;
-		for (int i = tid; i < E.hw; i += 256)
+		for (int i = tid; i < E.hw; i += TPB)
 			h ^= E.nc_keys[3 + 3 * i + gs.board[i]];
-		block_reduce_xor(h, scratch, tid);
+		block_reduce_xor<TPB>(h, scratch, tid);
 		if (tid == 0)
 		{
 			gs.root_hash = h ^ E.nc_keys[gs.sign_to_move];
@@ -1194,13 +1198,18 @@ namespace
 		}
 	}
 
-	__global__ __launch_bounds__(256) void k_advance(EngineDev E)
+	/* ADV_THREADS threads per game that must move: the compaction of a large tree (2000 nodes, 250 k edges: 6 MB) is a chain of dependent
+	 * load -> store rounds per wave, so its duration falls with the number of waves that copy (256 -> 1024 threads: k_advance 0.36 -> see
+	 * DESIGN 6.1); the other games' workgroups leave at once. */
+	constexpr int ADV_THREADS = 1024;
+	__global__ __launch_bounds__(ADV_THREADS) void k_advance(EngineDev E)
 	{
-		__shared__ u64 scratch[4];
-		__shared__ float red_v[4];
-		__shared__ int red_i[4];
+		constexpr int TPB = ADV_THREADS, WAVES = ADV_THREADS / 64;
+		__shared__ u64 scratch[WAVES];
+		__shared__ float red_v[WAVES];
+		__shared__ int red_i[WAVES];
 		__shared__ int sh_int[8];
-		__shared__ int scan_nodes[256], scan_edges[256];
+		__shared__ int scan_nodes[TPB], scan_edges[TPB];
 		__shared__ uint16_t cell_edge[MAXHW], entry_cell[MAXHW]; // format-201 sample: edge of a cell (+1, bit 15 = visited or proven), cells with an entry
 		__shared__ uint32_t sh_max[3];
 		const int g = E.g0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1216,7 +1225,7 @@ namespace
 		// ---- final selector: "best" (EdgeSelector.cpp:515-536) or max_visit / min_visit / max_value / max_policy (:476-514) ----
 		float best_value = -3.402823466e+38f;
 		int best = 0x7FFFFFFF;
-		for (int i = tid; i < root.n_edges; i += 256)
+		for (int i = tid; i < root.n_edges; i += TPB)
 		{
 			const DEdge e = edges[root.edge_begin + i];
 			float value;
@@ -1297,7 +1306,7 @@ namespace
 		__syncthreads();
 		if (tid == 0)
 		{
-			for (int w = 1; w < 4; w++)
+			for (int w = 1; w < WAVES; w++)
 				if (red_v[w] > red_v[0] || (red_v[w] == red_v[0] && red_i[w] < red_i[0]))
 				{
 					red_v[0] = red_v[w];
@@ -1315,12 +1324,12 @@ namespace
 		int n_entries = 0;
 		if (E.record_format & 2)
 		{
-			for (int i = tid; i < E.hw; i += 256)
+			for (int i = tid; i < E.hw; i += TPB)
 				cell_edge[i] = 0;
 			if (tid < 3)
 				sh_max[tid] = 0u;
 			__syncthreads();
-			for (int i = tid; i < root.n_edges; i += 256)
+			for (int i = tid; i < root.n_edges; i += TPB)
 			{ // scatter the edges over the board; the maxima that become the three scales (non-negative floats order like their bits)
 				const DEdge e = edges[root.edge_begin + i];
 				const int cell = ((e.move >> 2) & 127) * n + ((e.move >> 9) & 127);
@@ -1399,7 +1408,7 @@ namespace
 		__syncthreads();
 		const int rec = sh_int[0], eoff = sh_int[1], soff = sh_int[6];
 		if (eoff >= 0)
-			for (int i = tid; i < root.n_edges; i += 256)
+			for (int i = tid; i < root.n_edges; i += TPB)
 				E.record_edges[eoff + i] = edges[root.edge_begin + i];
 		if (soff >= 0)
 		{
@@ -1417,7 +1426,7 @@ namespace
 				h16[5] = static_cast<uint16_t>((root.flags >> 3) & 7);
 				*reinterpret_cast<uint32_t*>(out + 12) = static_cast<uint32_t>(n_entries);
 			}
-			for (int k = tid; k < n_entries; k += 256)
+			for (int k = tid; k < n_entries; k += TPB)
 			{
 				const int cell = entry_cell[k], previous = (k > 0) ? entry_cell[k - 1] : 0;
 				const int ei = (cell_edge[cell] & 0x7FFF) - 1;
@@ -1532,7 +1541,7 @@ namespace
 		  // is until its player's next turn (two plies on)
 			const int p = (g + E.n_games / 2) % E.n_games;
 			GameState &ps = E.games[p];
-			for (int i = tid; i < E.hw; i += 256)
+			for (int i = tid; i < E.hw; i += TPB)
 				ps.board[i] = gs.board[i];
 			if (tid < BWORDS)
 				ps.cboard[tid] = gs.cboard[tid];
@@ -1564,12 +1573,12 @@ namespace
 			}
 			__syncthreads();
 			if (sh_int[2] == 0)
-				rebase_tree(E, p, tid, scratch, scan_nodes, scan_edges);
+				rebase_tree<TPB>(E, p, tid, scratch, scan_nodes, scan_edges);
 			return;
 		}
 		if (E.shared_tree)
 		{ // every SearchThread's Search sees the move: Search::setBoard -> AlphaBetaSearch::increaseGeneration; a finished game stops them all
-			for (int t = 1 + tid; t < E.n_games; t += 256)
+			for (int t = 1 + tid; t < E.n_games; t += TPB)
 			{
 				GameState &ls = E.games[t];
 				ls.generation = (ls.generation + 1) % 64;
@@ -1581,7 +1590,7 @@ namespace
 		}
 		if (sh_int[2] != 0)
 			return;
-		rebase_tree(E, g, tid, scratch, scan_nodes, scan_edges);
+		rebase_tree<TPB>(E, g, tid, scratch, scan_nodes, scan_edges);
 	}
 
 	/*
@@ -1751,7 +1760,7 @@ namespace
 			__syncthreads();
 		}
 		const int mover = (E.games[lead].sign_to_move == E.games[lead].my_sign) ? lead : part;
-		rebase_tree(E, mover, tid, scratch, scan_nodes, scan_edges);
+		rebase_tree<256>(E, mover, tid, scratch, scan_nodes, scan_edges);
 		if (tid == 0)
 			E.games[mover].active = 1;
 	}
@@ -2598,7 +2607,7 @@ int agx_engine_expand_backup_match(AgxEngine *e, void *stream)
 	{
 		KernelTimer t(e, s, 3);
 		// a moving tree's workgroup also rebases its partner's tree; the partner's own workgroup has nothing to do (it is not searching)
-		hipLaunchKernelGGL(k_advance, dim3(d.n_games), dim3(256), 0, s, d);
+		hipLaunchKernelGGL(k_advance, dim3(d.n_games), dim3(ADV_THREADS), 0, s, d);
 		hipLaunchKernelGGL(k_arena_service, dim3(1), dim3(1024), 0, s, d, d.n_games);
 		hipLaunchKernelGGL(k_arena_copy, dim3(d.n_games * CLEAR_PARTS), dim3(256), 0, s, d, CLEAR_PARTS);
 		hipLaunchKernelGGL(k_arena_commit, dim3(d.n_games), dim3(64), 0, s, d);
@@ -2682,7 +2691,7 @@ int agx_engine_advance_group(AgxEngine *e, int group, int n_groups, void *stream
 	{
 		KernelTimer t(e, s, 3);
 		const int trees = d.shared_tree ? 1 : count; // tournament search: one tree (game 0), the other records are its search threads
-		hipLaunchKernelGGL(k_advance, dim3(trees), dim3(256), 0, s, d);
+		hipLaunchKernelGGL(k_advance, dim3(trees), dim3(ADV_THREADS), 0, s, d);
 		hipLaunchKernelGGL(k_arena_service, dim3(1), dim3(1024), 0, s, d, trees);
 		hipLaunchKernelGGL(k_arena_copy, dim3(trees * CLEAR_PARTS), dim3(256), 0, s, d, CLEAR_PARTS);
 		hipLaunchKernelGGL(k_arena_commit, dim3(trees), dim3(64), 0, s, d);
