@@ -16,35 +16,70 @@ AG_LIB = os.path.join(HERE, "libagx_ag.so")               # the reference-named 
 BOUNDARY_TEST = os.path.join(HERE, "agx_boundary_test")  # tests/cpp/boundary_main.cpp: the reference's call chain on those classes
 
 
+INCLUDE = os.path.join(HERE, "..", "include")
+BOUNDARY_SRC = os.path.join(HERE, "..", "tests", "cpp", "boundary_main.cpp")
+HOST_ONLY = ("ag_classes.cpp", "selfplay_main.cpp")  # plain g++ sources in csrc/ (not part of libagx.so)
+
+
+def _mtime(path):
+    return os.path.getmtime(path) if os.path.exists(path) else 0.0
+
+
+def _device_headers():
+    """every header a libagx.so object may include: csrc/*.hpp and the C ABI"""
+    return [os.path.join(CSRC, n) for n in os.listdir(CSRC) if n.endswith(".hpp")] + [os.path.join(INCLUDE, "agx.h")]
+
+
+def _stale_objects():
+    newest_header = max(_mtime(h) for h in _device_headers())
+    stale = []
+    for src in SOURCES:
+        obj = os.path.join(CSRC, src.rsplit(".", 1)[0] + ".o")
+        if _mtime(obj) < max(_mtime(os.path.join(CSRC, src)), newest_header):
+            stale.append(src)
+    return stale
+
+
+def _boundary_headers():
+    d = os.path.join(INCLUDE, "alphagomoku_agx")
+    return [os.path.join(d, f) for f in os.listdir(d)] + [os.path.join(INCLUDE, "agx.h"), os.path.join(INCLUDE, "agx.hpp")]
+
+
+def _stale_host_targets():
+    """[(target, newest input)] of the host-side binaries that are older than their inputs"""
+    headers = max(_mtime(h) for h in _boundary_headers())
+    out = []
+    if _mtime(DRIVER) < max(_mtime(os.path.join(CSRC, "selfplay_main.cpp")), headers):
+        out.append(DRIVER)
+    if _mtime(AG_LIB) < max(_mtime(os.path.join(CSRC, "ag_classes.cpp")), headers):
+        out.append(AG_LIB)
+    if _mtime(BOUNDARY_TEST) < max(_mtime(BOUNDARY_SRC), headers, _mtime(AG_LIB)) or AG_LIB in out:
+        out.append(BOUNDARY_TEST)
+    return out
+
+
 def needs_build():
-    if not os.path.exists(LIB):
+    objs = [os.path.join(CSRC, src.rsplit(".", 1)[0] + ".o") for src in SOURCES]
+    if _stale_objects() or _mtime(LIB) < max(_mtime(o) for o in objs):
         return True
-    t = os.path.getmtime(LIB)
-    for name in os.listdir(CSRC):
-        if os.path.getmtime(os.path.join(CSRC, name)) > t:
-            return True
-    if os.path.getmtime(os.path.join(HERE, "..", "include", "agx.h")) > t:
-        return True
-    for extra in (AG_LIB, BOUNDARY_TEST, DRIVER):
-        if not os.path.exists(extra):
-            return True
-    boundary = os.path.join(HERE, "..", "include", "alphagomoku_agx")
-    newest = max([os.path.getmtime(os.path.join(boundary, f)) for f in os.listdir(boundary)]
-                 + [os.path.getmtime(os.path.join(HERE, "..", "tests", "cpp", "boundary_main.cpp"))])
-    if newest > os.path.getmtime(BOUNDARY_TEST):
-        return True
-    return False
+    return bool(_stale_host_targets())
 
 
 def build(force=False, verbose=True):
-    if not force and not needs_build():
-        return LIB
+    """Incremental: an object is recompiled when its source or any device header is newer, libagx.so is linked when an object is newer,
+    the host-side binaries (driver, reference-named classes, boundary test) when their sources / headers are."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objs = []
+    cxx = os.environ.get("CXX", "g++")
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    objs = [os.path.join(CSRC, src.rsplit(".", 1)[0] + ".o") for src in SOURCES]
     procs = []
-    for src in SOURCES:
+    for src in (SOURCES if force else _stale_objects()):
         obj = os.path.join(CSRC, src.rsplit(".", 1)[0] + ".o")
-        objs.append(obj)
         # -ffp-contract=off: the tree kernels must round exactly like the CPU oracle (no fused multiply-add)
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]
         if os.environ.get("AGX_SOLVER_PROFILE"):
@@ -62,28 +97,16 @@ def build(force=False, verbose=True):
     for p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed")
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lz"]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
-    # native C++ host driver over the C ABI (include/agx.hpp)
-    cmd = [os.environ.get("CXX", "g++"), "-std=c++17", "-O2", "-o", DRIVER, os.path.join(CSRC, "selfplay_main.cpp"),
-           "-L" + HERE, "-lagx", "-Wl,-rpath," + HERE, "-lpthread"]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
-    # the C++ boundary: plain host code (g++), no HIP types — a maintainer of the reference links it like any other library
-    cxx = os.environ.get("CXX", "g++")
-    cmd = [cxx, "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", "-o", AG_LIB, os.path.join(CSRC, "ag_classes.cpp"), "-L" + HERE, "-lagx",
-           "-Wl,-rpath," + HERE, "-lpthread"]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
-    cmd = [cxx, "-std=c++17", "-O2", "-Wall", "-o", BOUNDARY_TEST, os.path.join(HERE, "..", "tests", "cpp", "boundary_main.cpp"), "-L" + HERE, "-lagx_ag",
-           "-lagx", "-Wl,-rpath," + HERE, "-lpthread"]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+    if force or _mtime(LIB) < max(_mtime(o) for o in objs):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lz"])
+    stale = [DRIVER, AG_LIB, BOUNDARY_TEST] if force else _stale_host_targets()
+    if DRIVER in stale:  # native C++ host driver over the C ABI (include/agx.hpp)
+        run([cxx, "-std=c++17", "-O2", "-o", DRIVER, os.path.join(CSRC, "selfplay_main.cpp"), "-L" + HERE, "-lagx", "-Wl,-rpath," + HERE, "-lpthread"])
+    if AG_LIB in stale:  # the C++ boundary: plain host code (g++), no HIP types — a maintainer of the reference links it like any other library
+        run([cxx, "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", "-o", AG_LIB, os.path.join(CSRC, "ag_classes.cpp"), "-L" + HERE, "-lagx",
+             "-Wl,-rpath," + HERE, "-lpthread"])
+    if BOUNDARY_TEST in stale:
+        run([cxx, "-std=c++17", "-O2", "-Wall", "-o", BOUNDARY_TEST, BOUNDARY_SRC, "-L" + HERE, "-lagx_ag", "-lagx", "-Wl,-rpath," + HERE, "-lpthread"])
     return LIB
 
 

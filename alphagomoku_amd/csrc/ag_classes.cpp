@@ -815,19 +815,38 @@ namespace ag
 	{ // the simulation budget is the pool's (SelfplayConfig::constraints.max_simulations, fixed at creation)
 		if (&tree.pool != &pool || tree.group != group)
 			throw std::logic_error("Search::select() : the tree belongs to another slice");
-		stats.select.startTimer();
-		check(agx_engine_select_group(pool.handle(), group, n_groups, stream));
-		stats.select.stopTimer();
+		// The launch is enqueued by solve(): on the device a game's wave descends the tree and then solves its leaves in ONE launch
+		// (agx_engine_select_solve_group), so a slow descent holds up only its own game.  A caller that never calls solve() gets the
+		// stand-alone select launch from the next stage it calls.
+		flush_select();
+		select_pending = true;
+	}
+	void Search::flush_select()
+	{
+		if (select_pending)
+		{
+			select_pending = false;
+			stats.select.startTimer();
+			check(agx_engine_select_group(pool.handle(), group, n_groups, stream));
+			stats.select.stopTimer();
+		}
 	}
 	void Search::solve(double)
 	{
 		stats.solve.startTimer();
-		check(agx_engine_solve_group(pool.handle(), group, n_groups, stream));
+		if (select_pending)
+		{
+			select_pending = false;
+			check(agx_engine_select_solve_group(pool.handle(), group, n_groups, stream));
+		}
+		else
+			check(agx_engine_solve_group(pool.handle(), group, n_groups, stream));
 		stats.solve.stopTimer();
 		scheduled = false;
 	}
 	void Search::scheduleToNN(NNEvaluator &evaluator)
 	{ // Search.cpp:184-199: the solve kernel has compacted the leaves that need the network into the slice's device-side queue
+		flush_select();
 		stats.schedule.startTimer();
 		const int per = (pool.numberOfGames() + n_groups - 1) / n_groups;
 		tasks_ready = false;

@@ -366,7 +366,9 @@ namespace ag
 			int batch_size;
 			bool scheduled = false;
 			bool tasks_ready = true;
+			bool select_pending = false; // select() asked for, enqueued together with solve()
 			SearchStats stats;
+			void flush_select();
 		public:
 			static constexpr int maximum_number_of_simulations = 16777216;
 			Search(GamePool &pool, int group, int n_groups, void *stream);
