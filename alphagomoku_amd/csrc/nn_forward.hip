@@ -42,21 +42,6 @@
 #ifndef AGX_NN_ROW_STATIONARY
 #define AGX_NN_ROW_STATIONARY 1 // 0: the tap-major k-loop for every board (A/B builds)
 #endif
-#ifndef AGX_NN_SCHED_GROUPS
-#define AGX_NN_SCHED_GROUPS 2
-#endif
-#ifndef AGX_NN_PROGRESS_PRIORITY
-#define AGX_NN_PROGRESS_PRIORITY 1
-#endif
-#ifndef AGX_NN_YOUNGER_BIAS
-#define AGX_NN_YOUNGER_BIAS 0 // in units of a third of a stage: > 0 lets the younger wave of a pair hold a priority level longer (measured: worse)
-#endif
-#ifndef AGX_NN_CONV5_ROWS
-#define AGX_NN_CONV5_ROWS 1
-#endif
-#ifndef AGX_NN_CONV5_ROWS_WIDE
-#define AGX_NN_CONV5_ROWS_WIDE 0 // 128-filter nets keep the tap-major 5x5 loop (measured 1 % faster: the 2 x 10 weight fragments in flight spill)
-#endif
 #ifndef AGX_NN_AHEAD
 #define AGX_NN_AHEAD 4 // activation fragments in flight per wave in the row-stationary k-loop
 #endif
@@ -170,11 +155,7 @@ namespace
 		for (int dyi = 0; dyi < 3; dyi++)
 #pragma unroll
 			for (int i = 0; i < G::MT; i++)
-#ifdef AGX_NN_EXPERIMENT_NO_WEIGHT_FETCH
-				a_next[dyi][i] = a_cur[dyi][i]; // experiment: no L2 traffic in the loop (results are garbage)
-#else
 				a_next[dyi][i] = wnext[(dyi * G::MT + i) * 64 + lane];
-#endif
 		const int index0 = index_base + (dxi - 1);
 		const int swz0 = (index0 / G::PPR) % G::CH; // invariant over rows: 16 positions == whole bank rows
 		const char *src0 = src + index0 * G::CH * 16 + (((kc * 4 + q4) ^ swz0) * 16);
@@ -201,16 +182,10 @@ namespace
 						acc[i][o] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_cur[dyi][i], b[(j + 1) % AHEAD], acc[i][o], 0, 0, 0);
 				}
 			}
-#if AGX_NN_SCHED_GROUPS == 1
-			// one ds_read (0x100) per 3 * MT MFMAs (0x008), in this order
-			__builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-			__builtin_amdgcn_sched_group_barrier(0x008, 3 * G::MT, 0);
-#elif AGX_NN_SCHED_GROUPS == 2
 			// nothing crosses a row boundary: the fragment requested in this turn is the one used AHEAD - 1 turns later, so the wait in
 			// front of a turn's MFMAs leaves the younger requests in flight (left to itself the scheduler sinks every request to just
 			// before its use and a wave running alone on its SIMD stalls on each one)
 			__builtin_amdgcn_sched_barrier(0);
-#endif
 		}
 	}
 
@@ -260,28 +235,23 @@ namespace
 #pragma unroll 1
 		for (int s = 0; s < STAGES; s += 2)
 		{
-#if AGX_NN_PROGRESS_PRIORITY
 			// The two waves of a SIMD are issued oldest-first: left alone, the older one runs ahead, finishes its k-loop early and waits at
 			// the layer barrier while the younger one finishes ALONE (a lone wave hides none of its LDS / L2 latencies: measured 2.1 x its
 			// MFMA time).  Priority by remaining work — the wave that is behind goes first — keeps the pair together to the end.
-			// (the younger wave of a pair keeps each level one turn longer: at equal priority the hardware prefers the older one)
-			const int progress = 3 * s - ((wave >> 2) ? AGX_NN_YOUNGER_BIAS : 0);
-			if (progress < STAGES)
+			// (a static bias towards the younger wave of a pair was measured worse)
+			if (3 * s < STAGES)
 				__builtin_amdgcn_s_setprio(3);
-			else if (progress < 2 * STAGES)
+			else if (3 * s < 2 * STAGES)
 				__builtin_amdgcn_s_setprio(2);
 			else
 				__builtin_amdgcn_s_setprio(1);
-#endif
 			conv3x3_rows_stage<F, ROWS, COLS>(src, wl + (s + 1) * STAGE_FRAGS, s / 3, s % 3, index_base, q4, my_tiles, lane, a0, a1, acc);
 			// the last turn fetches stage 0 again instead of branching around the fetch: with a conditional fetch the wait for THIS stage's
 			// fragments has to assume the newer loads were never issued (vmcnt(0)), which serialises fetch and MFMAs in every turn
 			conv3x3_rows_stage<F, ROWS, COLS>(src, wl + ((s + 2 < STAGES) ? (s + 2) : 0) * STAGE_FRAGS, (s + 1) / 3, (s + 1) % 3, index_base, q4, my_tiles, lane, a1,
 					a0, acc);
 		}
-#if AGX_NN_PROGRESS_PRIORITY
 		__builtin_amdgcn_s_setprio(0);
-#endif
 	}
 
 	template<int F, int ROWS, int COLS, bool ZERO = true>
@@ -416,9 +386,6 @@ namespace
 			}
 		}
 		AGX_NN_MARK(2);
-#ifdef AGX_NN_EXPERIMENT_SKIP_UPPER
-		if (wave < 4) // experiment: the lower waves run their k-loop ALONE on their SIMDs (results are garbage)
-#endif
 		conv3x3_mac<F, ROWS, COLS, false>(src, wpk, wave, lane, acc);
 		AGX_NN_MARK(3);
 
@@ -647,7 +614,7 @@ namespace
 			for (int n = 0; n < G::NTW; n++)
 				acc[i][n] = floatx4 { 0.0f, 0.0f, 0.0f, 0.0f };
 
-		if constexpr (G::S == 16 && AGX_NN_ROW_STATIONARY && AGX_NN_CONV5_ROWS && (F == 64 || AGX_NN_CONV5_ROWS_WIDE))
+		if constexpr (G::S == 16 && AGX_NN_ROW_STATIONARY && F == 64) // (128-filter nets keep the tap-major loop: measured 1 % faster, the 2 x 10 weight fragments in flight spill)
 		{
 			// Input-row stationary like conv3x3_mac_rows: for a column shift dx the fragment of padded input row j is read once and feeds the
 			// five taps dy = -2 .. 2 (output rows j + 2 .. j - 2): 5 x (NTW + 4) fragment reads instead of 25 x NTW, and — the padded plane being
@@ -697,9 +664,7 @@ namespace
 								acc[i][o] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_cur[dyi][i], b[(j + 2) % AHEAD], acc[i][o], 0, 0, 0);
 						}
 					}
-#if AGX_NN_SCHED_GROUPS == 2
 					__builtin_amdgcn_sched_barrier(0);
-#endif
 				}
 #pragma unroll
 				for (int dyi = 0; dyi < 5; dyi++)
