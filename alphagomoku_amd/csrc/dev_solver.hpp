@@ -1811,6 +1811,7 @@ namespace agx
 				sh.cmd_move = move;
 				return cmd;
 			};
+			uint32_t cur_action = 0; // the action list's entry at f.i as last written / picked (phase 3 reads it)
 			while (true)
 			{
 				bool returning = false;
@@ -1901,8 +1902,9 @@ namespace agx
 				}
 				else if (phase == 1)
 				{ // ---- child returned ----
-					const uint32_t mv = act_get(sh, act, f.base + f.i) & 0xFFFFu;
-					act_set(sh, act, f.base + f.i, mv | (s_invert_up(value) << 16));
+					const uint32_t mv = f.move; // == the move of the entry at f.i (set when the machine descended)
+					cur_action = mv | (s_invert_up(value) << 16);
+					act_set(sh, act, f.base + f.i, cur_action);
 					const int cell = ((mv >> 2) & 127) * n + ((mv >> 9) & 127);
 					{ // the key index is wave-uniform: in an SGPR the splitmix64 rounds run on the scalar unit
 						const uint32_t zi = __builtin_amdgcn_readfirstlane(2 * (2 * cell + ((mv & 3) - 1)));
@@ -1922,6 +1924,8 @@ namespace agx
 						phase = 4;
 					else
 					{
+						uint32_t picked = 0;
+						bool have_picked = false;
 						const uint32_t bm = f.best_move;
 						const bool tt_move_legal = ((bm & 3u) == static_cast<uint32_t>(sh.sign_to_move)) && sh.board[((bm >> 2) & 127) * n + ((bm >> 9) & 127)] == 0;
 						if (f.i == 0 && tt_move_legal)
@@ -1934,9 +1938,24 @@ namespace agx
 								act_set(sh, act, at, t);
 							}
 						}
+						else if (f.size - f.i <= 64)
+						{ // first maximum of the remaining actions, one per lane: the key is (score, lowest index), one DPP reduction picks the
+						  // winner, and the two entries that trade places come out of the lanes' registers (one LDS round trip, not four)
+							const int j = f.i + lane;
+							const uint32_t mine = (j < f.size) ? act_get(sh, act, f.base + j) : 0u;
+							uint32_t key = (j < f.size) ? (((mine >> 16) << 16) | static_cast<uint32_t>(0xFFFF - j)) : 0u;
+							key = wave_reduce_umax(key);
+							const int idx = 0xFFFF - static_cast<int>(key & 0xFFFFu);
+							picked = __builtin_amdgcn_readlane(mine, __builtin_amdgcn_readfirstlane(idx - f.i));
+							if (idx != f.i)
+							{
+								act_set(sh, act, f.base + f.i, picked);
+								act_set(sh, act, f.base + idx, __builtin_amdgcn_readlane(mine, 0));
+							}
+							have_picked = true;
+						}
 						else
-						{ // first maximum of the remaining actions: every lane folds its actions into one key (score, lowest index), one
-						  // DPP reduction picks the winner
+						{ // more than 64 actions left: every lane folds its actions into one key
 							uint32_t key = 0;
 							for (int j = f.i + lane; j < f.size; j += 64)
 								key = max(key, ((act_get(sh, act, f.base + j) >> 16) << 16) | static_cast<uint32_t>(0xFFFF - j));
@@ -1951,7 +1970,8 @@ namespace agx
 						}
 						AGX_PROF_MARK(sh, 16); // pick: table move or first maximum, swap to the front
 						AGX_PROF_COUNT(sh, 22, 1);
-						const uint32_t a = act_get(sh, act, f.base + f.i);
+						const uint32_t a = have_picked ? picked : act_get(sh, act, f.base + f.i);
+						cur_action = a;
 						if (s_unproven(a >> 16) && node_counter < E.tss_max_nodes)
 						{ // descend (:268-298)
 							if (level + 1 >= MAX_FRAMES)
@@ -2004,8 +2024,8 @@ namespace agx
 					}
 				}
 				if (!returning && phase == 3)
-				{ // ---- after the action has its score (:299-307) ----
-					const uint32_t a = act_get(sh, act, f.base + f.i);
+				{ // ---- after the action has its score (:299-307): the entry at f.i, still in a register from the pick or the child's return ----
+					const uint32_t a = cur_action;
 					const uint32_t sc = a >> 16;
 					f.best_score = static_cast<uint16_t>(max(static_cast<uint32_t>(f.best_score), sc));
 					if (sc > f.alpha)

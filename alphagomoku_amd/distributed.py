@@ -4,6 +4,7 @@ There is NO collective on the data path (games never talk to each other, exactly
 GeneratorManager, src/selfplay/GeneratorManager.cpp:146-152).  torch.distributed is used only for the start/stop barrier and to
 combine the per-rank measurements: wall time = MAX over ranks, work counters = SUM over ranks."""
 import os
+import sys
 
 
 def env_ranks():
@@ -23,7 +24,18 @@ def init(backend=None, device=None):
     if backend == "nccl":
         torch.cuda.set_device(local_rank)
         kwargs["device_id"] = torch.device("cuda", local_rank)
-    dist.init_process_group(backend=backend, **kwargs)
+    # gloo announces its connections on stdout ("[Gloo] Rank 0 is connected to ..."); bench.py's stdout is ONE JSON line, so the process's
+    # stdout goes to stderr while the group is being set up
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        dist.init_process_group(backend=backend, **kwargs)
+        dist.barrier()  # (gloo connects lazily: the first collective makes the announcements)
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
     return dist
 
 

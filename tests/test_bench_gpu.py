@@ -36,4 +36,4 @@ def test_two_ranks_on_one_gpu_report_the_whole_job(agx_lib):
     assert one["ranks"][0]["simulations"] == ranks[0]["simulations"]
     for line in (one, two):
         assert line["roofline"]["bound"] == "mfma" and 0 < line["roofline"]["frac"] < 1
-        assert line["roofline_solver"]["kernel"] == "k_solve" and line["longest_kernel"]["name"] in line["kernel_ms_per_step"]
+        assert line["roofline_solver"]["kernel"].startswith("k_solve") and line["longest_kernel"]["name"] in line["kernel_ms_per_step"]
