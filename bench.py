@@ -238,9 +238,13 @@ def main():
         # with the MEASURED mean select depth d and edges per level E (new-leaf edge count taken as E):
         #   select d*(40 + 24E) + virtual loss 4d + hash probe d*(8 + 104) + expand 176 + 24E + backup 128d + 2dE + encode 10*HW
         hw = args.board * args.board
-        tree_bytes = (depth * (40 + 24 * edges_per_level) + 4 * depth + depth * 112 + 176 + 24 * edges_per_level + 128 * depth
-                      + 2 * depth * edges_per_level + 10 * hw)
-        tree_ms = kernel_ms[0] + kernel_ms[2] + kernel_ms[3]
+        fused = os.environ.get("AGX_FUSE_SELECT", "1") != "0"
+        select_bytes = depth * (40 + 24 * edges_per_level) + 4 * depth + depth * 112 + 10 * hw   # descents + the feature planes (written by the solve stage)
+        update_bytes = 176 + 24 * edges_per_level + 128 * depth + 2 * depth * edges_per_level
+        # with select fused into the solver launch its time cannot be separated from the solver's: the HBM-side figure then covers the
+        # launches that are pure tree work (expand / backup / advance) with their own bytes
+        tree_bytes = update_bytes if fused else select_bytes + update_bytes
+        tree_ms = (0.0 if fused else kernel_ms[0]) + kernel_ms[2] + kernel_ms[3]
         local_sims = s1["evaluated_nodes"] - s0["evaluated_nodes"]
         tree_gbs = local_sims * tree_bytes / (tree_ms * 1e-3) / 1e9 if tree_ms > 0 else 0.0
         # PMC-derived figures cannot be sampled from inside this process (rocprofv3 --pmc passes, scripts/pmc_summary.py).  They are quoted only
@@ -318,7 +322,7 @@ def main():
                                 "solver_nodes_per_sec": solver_nodes / elapsed, "us_per_solver_node_per_wave": (kernel_ms[1] * 1e3 * args.games / solver_nodes) if solver_nodes else None,
                                 "issue_busy_fraction_pmc": solver_issue},
             # second roof ("two kernels, two roofs"): the tree kernels are gathers/scans over the flat node/edge arrays
-            "roofline_tree": {"bound": "hbm", "kernels": "k_select + k_expand + k_advance", "achieved": tree_gbs, "peak": 8000.0, "unit": "GB/s",
+            "roofline_tree": {"bound": "hbm", "kernels": "k_expand + k_advance" if fused else "k_select + k_expand + k_advance", "achieved": tree_gbs, "peak": 8000.0, "unit": "GB/s",
                               "frac": tree_gbs / 8000.0, "bytes_per_simulation": tree_bytes, "ms_per_step": tree_ms / args.steps,
                               "note": "latency-bound by one wave per game, not by bandwidth; k_solve (threat solver) has no HBM/MFMA roof"},
         }
