@@ -314,6 +314,15 @@ def test_whole_games_bit_exact_with_stand_in_evaluator(agx_lib, olib, rules, bat
     assert stats["games_finished"] == 6 and stats["information_leaks"] > 0 and stats["proven_edge_visits"] > 0
 
 
+@pytest.mark.parametrize("rules", [0, 2])
+def test_separate_select_and_solve_launches(agx_lib, olib, rules, monkeypatch):
+    """AGX_FUSE_SELECT=0: Search::select and the solver as two launches (k_select + k_solve<.., false>, what agx_engine_select_group /
+    agx_engine_solve_group and tournament pools use) play the same games as the fused launch that every other test goes through"""
+    monkeypatch.setenv("AGX_FUSE_SELECT", "0")   # read by agx_engine_create
+    compared, stats = _play_and_compare(olib, rules, games=4, batch=8, sims=80, max_steps=4000, evaluator=_stand_in_evaluator(olib))
+    assert compared > 300 and stats["games_finished"] == 4
+
+
 @pytest.mark.parametrize("selector", [1, 2, 3, 4, 5])
 def test_final_move_selectors(agx_lib, olib, selector):
     """GameGenerator::make_move with final_selector max_visit / min_visit / max_value / max_policy / lcb instead of "best" """
