@@ -50,7 +50,7 @@ if tower:
         summary["nn_tower_shader_clock_mhz"] = t["shader_clock_mhz"]
     if "SQ_LDS_BANK_CONFLICT_per_launch" in t and t.get("SQ_LDS_IDX_ACTIVE_per_launch"):
         summary["nn_tower_lds_bank_conflict_fraction"] = t["SQ_LDS_BANK_CONFLICT_per_launch"] / t["SQ_LDS_IDX_ACTIVE_per_launch"]
-solve = next((k for k in per if k.startswith("k_solve<false, 15>")), None)
+solve = next((k for k in per if k.startswith("k_solve<false, 15")), None)
 if solve and "SQ_WAVE_CYCLES_per_launch" in per[solve]:
     t = per[solve]
     summary["k_solve_issue_busy_fraction"] = t["SQ_ACTIVE_INST_ANY_per_launch"] / t["SQ_WAVE_CYCLES_per_launch"]
