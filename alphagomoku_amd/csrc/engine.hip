@@ -2,16 +2,19 @@
  * engine.hip — the device-resident self-play engine: kernels, host object and its C ABI (include/agx.h).
  *
  * One step of the pool = what GameGenerator::generate does for every game of a GeneratorThread
- * (src/selfplay/GameGenerator.cpp:79-118, src/selfplay/GeneratorManager.cpp:124-141), as five launches:
+ * (src/selfplay/GameGenerator.cpp:79-118, src/selfplay/GeneratorManager.cpp:124-141), as four launches:
  *
- *   k_select   Search::select          (Search.cpp:117-158)   up to `batch` PUCT descents per game, virtual loss
- *   k_solve    Search::solve           (Search.cpp:159-183)   threat solver on every new leaf + NN feature encode,
+ *   k_solve<.., FUSED>   one wave per game, two stages back to back (a game's stages depend on no other game):
+ *              Search::select          (Search.cpp:117-158)   up to `batch` PUCT descents per game, virtual loss
+ *              Search::solve           (Search.cpp:159-183)   threat solver on every new leaf + NN feature encode,
  *              Search::scheduleToNN    (Search.cpp:184-199)   compacts the positions that need the network
+ *              (k_select + k_solve<.., false> are the same stages as two launches: agx_engine_select_group / _solve_group, tournament pools)
  *   (network)  NNEvaluator::evaluate                         agx_nn_forward over the compacted list (nn_forward.hip)
  *   k_expand   Search::generateEdges / expand / backup (Search.cpp:206-232) and the move rule (GameGenerator.cpp:97-103)
  *   k_advance  GameGenerator::make_move + prepare_search (:145-185): final selector, sample record, outcome test (incl. renju
  *              fouls), NodeCache::cleanup as a keep-test + prefix-sum compaction into the game's other arena
  *   k_assign_openings / k_restart   finished games take the next openings in game order (GAME_NOT_STARTED -> next game)
+ *   k_arena_service / _copy / _commit   trees that outgrew their arenas move into larger ones (NodeCache::resize, ObjectPool growth)
  *
  * Everything stays in HBM between steps; the host only enqueues launches.  One wavefront per game for the sequential
  * tree work (games are independent, the batch inside a game is order-dependent through virtual loss); k_advance uses a
