@@ -116,9 +116,18 @@ namespace
 			static constexpr int CH = F / 8;                                     // 16-byte chunks per position
 			static constexpr int PPR = (16 / CH) > 0 ? (16 / CH) : 1;            // positions per 256-byte bank row
 			static constexpr int PLANE_BYTES = NPOS * F * 2;
-			static constexpr int MT = F / 64;                                    // 16-channel output tiles per wave (4 channel groups)
-			static constexpr int NTW = (NT + 1) / 2;                             // position tiles per wave (2 position halves)
-			static constexpr int THREADS = 512;                                  // 8 waves = 4 channel groups x 2 position halves, 2 per SIMD
+			// The 8 waves of a workgroup are CG channel groups x PG position groups: 4 x 2, except for 64-filter nets on boards whose tiles are
+			// not rows (20x20: the tap-major k-loop, one activation fragment read per (tap, tile)), where 4 groups would leave a wave a single
+			// 16-channel tile (MT = 1) per fragment read: 2 x 4 there (+12 % measured).  128-filter nets keep 4 x 2 on every board: with
+			// 2 x 4 (MT = 4) each weight fragment is fetched by four waves instead of two and the kernel lost 8 %.
+			static constexpr int CG = (S == 16 || F >= 128) ? 4 : 2;
+			static constexpr int PG = 8 / CG;
+			static constexpr int MT = F / (16 * CG);                             // 16-channel output tiles per wave
+			static constexpr int NTW = (NT + PG - 1) / PG;                       // position tiles per wave
+			static constexpr int THREADS = 512;                                  // 8 waves, 2 per SIMD
+			__device__ static __forceinline__ int channel_group(int wave) { return wave % CG; }
+			__device__ static __forceinline__ int first_tile(int wave) { return (wave / CG) * NTW; }
+			__device__ static __forceinline__ int tile_count(int wave) { return (NT - (wave / CG) * NTW < NTW) ? (NT - (wave / CG) * NTW) : NTW; }
 			static constexpr int MTILES = F / 16;
 			static constexpr int KC = F / 32;                                    // k-steps per tap
 			static constexpr int S5 = S + 4;                                     // row stride of the padded input plane
@@ -208,9 +217,9 @@ namespace
 		static_assert(G::S == 16, "a position tile must be a board row");
 		const int r = lane & 15;
 		const int q4 = lane >> 4;
-		const int mg = wave & 3;
-		const int n0 = (wave >> 2) * G::NTW;
-		const int my_tiles = (wave >> 2) ? (G::NT - G::NTW) : G::NTW;
+		const int mg = G::channel_group(wave);   // output channels [mg * 16 * MT, (mg + 1) * 16 * MT)
+		const int n0 = G::first_tile(wave);
+		const int my_tiles = G::tile_count(wave);
 
 		if (ZERO)
 		{
@@ -222,7 +231,8 @@ namespace
 		}
 
 		constexpr int STAGES = 3 * G::KC;               // stage = (32-channel chunk kc, column shift dx)
-		constexpr int STAGE_FRAGS = 4 * 3 * G::MT * 64; // half8 elements of one stage: 4 channel groups x 3 taps x MT tiles x 64 lanes
+		static_assert(G::CG == 4, "pack_conv_rows lays a stage out for four channel groups");
+		constexpr int STAGE_FRAGS = G::CG * 3 * G::MT * 64; // half8 elements of one stage: channel groups x 3 taps x MT tiles x 64 lanes
 		static_assert(STAGES % 2 == 0, "two stages per loop turn (static ring index)");
 		const half8 *wl = wpk + __builtin_amdgcn_readfirstlane(mg * 3 * G::MT * 64); // wave-uniform: scalar base + lane offset
 		half8 a0[3][G::MT], a1[3][G::MT];
@@ -261,9 +271,9 @@ namespace
 		typedef Geometry<F, ROWS, COLS> G;
 		const int r = lane & 15;
 		const int q4 = lane >> 4;
-		const int mg = wave & 3;                       // channel group: output channels [mg*16*MT, (mg+1)*16*MT)
-		const int n0 = (wave >> 2) * G::NTW;           // first position tile of this wave
-		const int my_tiles = (wave >> 2) ? (G::NT - G::NTW) : G::NTW;
+		const int mg = G::channel_group(wave);   // output channels [mg * 16 * MT, (mg + 1) * 16 * MT)
+		const int n0 = G::first_tile(wave);
+		const int my_tiles = G::tile_count(wave);
 
 		if (ZERO)
 		{
@@ -357,9 +367,9 @@ namespace
 		typedef Geometry<F, ROWS, COLS> G;
 		const int r = lane & 15;
 		const int q4 = lane >> 4;
-		const int mg = wave & 3;
-		const int n0 = (wave >> 2) * G::NTW;
-		const int my_tiles = (wave >> 2) ? (G::NT - G::NTW) : G::NTW;
+		const int mg = G::channel_group(wave);   // output channels [mg * 16 * MT, (mg + 1) * 16 * MT)
+		const int n0 = G::first_tile(wave);
+		const int my_tiles = G::tile_count(wave);
 		// The accumulators START from bias (+ residual input): the adds of the epilogue move to the layer's beginning, where they run in
 		// the shadow of the first weight fetch, and the epilogue — which both waves of a SIMD reach with no MFMAs left to hide behind —
 		// shrinks to ReLU, convert, mask, store.
@@ -438,8 +448,8 @@ namespace
 	 * (same accumulator layout, 8 bytes per lane and tile) in a per-workgroup scratch in global memory — written and read by the
 	 * same lane, fully coalesced, 2 x 110 KB per residual block against ~120 MFLOP of MFMA work.
 	 * MODE 0: first conv of a block (ReLU)   MODE 1: second conv (+ skip, ReLU, new skip saved)
-	 * MODE 2: policy conv + ReLU folded with the 1x1 policy conv: per-channel-group partial logits into `ppart` [4][NT*16].
-	 * MODE 3: action-values conv + tanh folded with its 1x1 conv to 3 outputs: `ppart` is [3][NT*16], the four channel groups
+	 * MODE 2: policy conv + ReLU folded with the 1x1 policy conv: per-channel-group partial logits into `ppart` [CG][NT*16].
+	 * MODE 3: action-values conv + tanh folded with its 1x1 conv to 3 outputs: `ppart` is [3][NT*16], the channel groups
 	 *         add their partial sums one after the other (fixed order, so results do not depend on wave timing).
 	 */
 	template<int F, int ROWS, int COLS, int MODE>
@@ -449,9 +459,9 @@ namespace
 		typedef Geometry<F, ROWS, COLS> G;
 		const int r = lane & 15;
 		const int q4 = lane >> 4;
-		const int mg = wave & 3;
-		const int n0 = (wave >> 2) * G::NTW;
-		const int my_tiles = (wave >> 2) ? (G::NT - G::NTW) : G::NTW;
+		const int mg = G::channel_group(wave);   // output channels [mg * 16 * MT, (mg + 1) * 16 * MT)
+		const int n0 = G::first_tile(wave);
+		const int my_tiles = G::tile_count(wave);
 		floatx4 acc[G::MT][G::NTW];
 		conv3x3_mac<F, ROWS, COLS>(plane, wpk, wave, lane, acc);
 
@@ -491,7 +501,7 @@ namespace
 					part[o][n] += __shfl_xor(part[o][n], 16);
 					part[o][n] += __shfl_xor(part[o][n], 32);
 				}
-			for (int group = 0; group < 4; group++)
+			for (int group = 0; group < G::CG; group++)
 			{
 				if (mg == group && q4 == 0)
 				{
@@ -603,9 +613,9 @@ namespace
 		typedef Geometry<F, ROWS, COLS> G;
 		const int r = lane & 15;
 		const int q4 = lane >> 4;
-		const int mg = wave & 3;
-		const int n0 = (wave >> 2) * G::NTW;
-		const int my_tiles = (wave >> 2) ? (G::NT - G::NTW) : G::NTW;
+		const int mg = G::channel_group(wave);   // output channels [mg * 16 * MT, (mg + 1) * 16 * MT)
+		const int n0 = G::first_tile(wave);
+		const int my_tiles = G::tile_count(wave);
 
 		floatx4 acc[G::MT][G::NTW];
 #pragma unroll
@@ -937,7 +947,10 @@ namespace
 					if (INPLACE)
 					{
 						const int idx = (c / COLS) * G::S + (c % COLS);
-						s += (ppart[idx] + ppart[G::NT * 16 + idx]) + (ppart[2 * G::NT * 16 + idx] + ppart[3 * G::NT * 16 + idx]);
+						if constexpr (G::CG == 4)
+							s += (ppart[idx] + ppart[G::NT * 16 + idx]) + (ppart[2 * G::NT * 16 + idx] + ppart[3 * G::NT * 16 + idx]);
+						else
+							s += ppart[idx] + ppart[G::NT * 16 + idx];
 					}
 					else
 					{
