@@ -160,3 +160,40 @@ def test_error_paths(agx_lib):
     with pytest.raises(AgxError):
         AGNetwork(synthetic.net_desc(blocks=1, filters=96))      # unsupported width
     net.close()
+
+
+@pytest.mark.parametrize("rows,blocks,filters,floor_tflops", [(15, 6, 128, 850.0), (15, 2, 64, 450.0), (20, 10, 128, 600.0)])
+def test_network_rate_floor(agx_lib, rows, blocks, filters, floor_tflops):
+    """A floor under the stand-alone rate of the BASELINE networks (about 65 % of what the pool's boxes reach: 1340-1400, 900-930 and
+    960-990 TFLOP/s).  Not a benchmark — a tripwire: a rewrite of the wave-to-tile mapping with / and % once cost the 15x15 kernels 12 %
+    (6x128) and a factor of 60 (2x64) with every numerics test green."""
+    import ctypes
+    from alphagomoku_amd import lib, check
+    from alphagomoku_amd.networks import AGNetwork, DeviceBuffer
+    d = synthetic.net_desc(rows=rows, cols=rows, blocks=blocks, filters=filters)
+    blob, _ = synthetic.make_weights(d)
+    net = AGNetwork(d)
+    net.loadWeights(blob)
+    boards, hw = 4096, rows * rows
+    fb = synthetic.random_features(boards, rows, rows, seed=5)
+    df = DeviceBuffer(fb.nbytes)
+    df.upload(fb)
+    dp, dv = DeviceBuffer(boards * hw * 4), DeviceBuffer(boards * 3 * 4)
+    t = ctypes.c_void_p()
+    check(lib.agx_timer_create(ctypes.byref(t)))
+    for _ in range(3):
+        net.forwardDevice(df.ptr, boards, dp.ptr, dv.ptr)
+    check(lib.agx_device_synchronize())
+    check(lib.agx_timer_start(t, None))
+    launches = 5
+    for _ in range(launches):
+        net.forwardDevice(df.ptr, boards, dp.ptr, dv.ptr)
+    check(lib.agx_timer_stop(t, None))
+    ms = ctypes.c_float()
+    check(lib.agx_timer_elapsed_ms(t, ctypes.byref(ms)))
+    check(lib.agx_timer_destroy(t))
+    f, dense = filters, d["value_hidden"]
+    flops = 2 * hw * (25 * 32 * f + blocks * 2 * 9 * f * f + 9 * f * f + f + 4 * f) + 2 * 4 * hw * dense + 6 * dense
+    tflops = boards * flops / (ms.value / launches * 1e-3) / 1e12
+    net.close()
+    assert tflops >= floor_tflops, "%dx%d %dx%d network: %.0f TFLOP/s" % (rows, rows, blocks, filters, tflops)
