@@ -197,3 +197,42 @@ def test_network_rate_floor(agx_lib, rows, blocks, filters, floor_tflops):
     tflops = boards * flops / (ms.value / launches * 1e-3) / 1e12
     net.close()
     assert tflops >= floor_tflops, "%dx%d %dx%d network: %.0f TFLOP/s" % (rows, rows, blocks, filters, tflops)
+
+
+def test_one_network_on_two_streams(agx_lib):
+    """The single-plane kernel (every 20x20 network) parks residual inputs in a global scratch: one AgxNet launched on two streams at
+    the same time must keep a scratch per stream (slices of a pool share a network and run on their own streams).  Two different
+    batches are evaluated concurrently, many times over; every result must equal the batch's stand-alone result."""
+    import ctypes
+    from alphagomoku_amd import lib, check
+    from alphagomoku_amd.networks import AGNetwork, DeviceBuffer
+    rows, boards = 20, 1024
+    hw = rows * rows
+    d = synthetic.net_desc(rows=rows, cols=rows, blocks=4, filters=128)
+    blob, _ = synthetic.make_weights(d)
+    net = AGNetwork(d)
+    net.loadWeights(blob)
+    batches = [synthetic.random_features(boards, rows, rows, seed=s) for s in (11, 12)]
+    expected = [net.forward(b) for b in batches]
+    streams, feats, pols, vals = [], [], [], []
+    for b in batches:
+        s = ctypes.c_void_p()
+        check(lib.agx_stream_create(ctypes.byref(s)))
+        streams.append(s)
+        df = DeviceBuffer(b.nbytes)
+        df.upload(b)
+        feats.append(df)
+        pols.append(DeviceBuffer(boards * hw * 4))
+        vals.append(DeviceBuffer(boards * 3 * 4))
+    for _ in range(6):
+        for k in range(2):
+            net.forwardDevice(feats[k].ptr, boards, pols[k].ptr, vals[k].ptr, stream=streams[k])
+    for s in streams:
+        check(lib.agx_stream_synchronize(s))
+    for k in range(2):
+        p = pols[k].download((boards, hw), np.float32)
+        v = vals[k].download((boards, 3), np.float32)
+        assert np.array_equal(p, expected[k][0]) and np.array_equal(v, expected[k][1])
+    for s in streams:
+        check(lib.agx_stream_destroy(s))
+    net.close()
