@@ -45,6 +45,7 @@ def _declare(c):
     c.agx_last_error.argtypes = []
     c.agx_version.restype = ci
     c.agx_set_device.argtypes = [ci]
+    c.agx_device_cu_count.argtypes = [ctypes.POINTER(ci)]
     c.agx_net_blob_floats.restype = sz
     c.agx_net_blob_floats.argtypes = [ctypes.POINTER(AgxNetDesc)]
     c.agx_net_create.argtypes = [ctypes.POINTER(AgxNetDesc), ctypes.POINTER(vp)]
@@ -158,6 +159,7 @@ def _declare(c):  # noqa: F811
     for name in ["agx_engine_evaluate_group", "agx_engine_step_group"]:
         getattr(c, name).argtypes = [vp, vp, ci, ci, vp]
     c.agx_stream_create.argtypes = [ctypes.POINTER(vp)]
+    c.agx_stream_create_with_cu_mask.argtypes = [ctypes.POINTER(vp), vp, ci]
     c.agx_stream_destroy.argtypes = [vp]
     c.agx_stream_synchronize.argtypes = [vp]
     c.agx_engine_buffers.argtypes = [vp, ctypes.POINTER(AgxEngineBuffers)]

@@ -1098,10 +1098,25 @@ namespace ag
 		const int slots = games * selfplay_config.search_config.max_batch_size;
 		int n_groups = (device.batch_size > 0) ? (slots + device.batch_size - 1) / device.batch_size : 1;
 		n_groups = std::max(1, std::min(std::min(16, games), n_groups));
+		// Slices own disjoint blocks of the chip's compute units (CU-masked streams, agx.h): out of phase with each other, so the
+		// power-limited network launches never cover the whole chip at once and no slice waits for another's stragglers.
+		int cus = 0;
+		check(agx_device_cu_count(&cus));
+		const bool partition = n_groups > 1 && cus >= n_groups && games % n_groups == 0;
+		if (partition)
+			check(agx_net_set_launch_width(nn_evaluator.get_network().handle(), cus / n_groups));
 		for (int g = 0; g < n_groups; g++)
 		{
 			void *s = nullptr;
-			check(agx_stream_create(&s));
+			if (partition)
+			{
+				std::vector<uint32_t> mask((cus + 31) / 32, 0u);
+				for (int c = g * (cus / n_groups); c < (g + 1) * (cus / n_groups); c++)
+					mask[c / 32] |= 1u << (c % 32);
+				check(agx_stream_create_with_cu_mask(&s, mask.data(), static_cast<int>(mask.size())));
+			}
+			else
+				check(agx_stream_create(&s));
 			streams.push_back(s);
 			generators.push_back(std::make_unique<GameGenerator>(game_config, selfplay_config, manager, nn_evaluator, *pool, g, n_groups, s));
 		}

@@ -48,6 +48,14 @@ int agx_device_count(int *count)
 	AGX_HIP_CHECK(hipGetDeviceCount(count));
 	return AGX_OK;
 }
+int agx_device_cu_count(int *count)
+{ // compute units of the current device (what a CU mask of agx_stream_create_with_cu_mask indexes)
+	AGX_REQUIRE(count != nullptr, AGX_ERR_INVALID, "agx_device_cu_count: null argument");
+	int device = 0;
+	AGX_HIP_CHECK(hipGetDevice(&device));
+	AGX_HIP_CHECK(hipDeviceGetAttribute(count, hipDeviceAttributeMultiprocessorCount, device));
+	return AGX_OK;
+}
 int agx_malloc(void **d_ptr, size_t bytes)
 {
 	AGX_REQUIRE(d_ptr != nullptr, AGX_ERR_INVALID, "agx_malloc: null output pointer");

@@ -29,6 +29,7 @@
 #include "sample_v201.hpp"
 
 #include <vector>
+#include <mutex>
 #include <cstring>
 
 using namespace agx;
@@ -3033,10 +3034,44 @@ int agx_stream_create(void **out)
 	*out = s;
 	return AGX_OK;
 }
+/* a stream whose kernels run only on the compute units whose bits are set in `mask` (bit i of word i / 32 = CU i): slices of a pool
+ * that own disjoint parts of the chip */
+namespace
+{
+	std::mutex g_masked_streams_mutex;
+	std::vector<hipStream_t> g_masked_streams; // hipStreamDestroy of a CU-masked stream hangs on ROCm 7.2: they live until the process exits
+}
+int agx_stream_create_with_cu_mask(void **out, const uint32_t *mask, int words)
+{
+	AGX_REQUIRE(out != nullptr && mask != nullptr && words > 0, AGX_ERR_INVALID, "agx_stream_create_with_cu_mask: invalid argument");
+	bool any = false;
+	for (int i = 0; i < words; i++)
+		any = any || mask[i] != 0u;
+	AGX_REQUIRE(any, AGX_ERR_INVALID, "agx_stream_create_with_cu_mask: the mask selects no compute unit");
+	hipStream_t s = nullptr;
+	AGX_HIP_CHECK(hipExtStreamCreateWithCUMask(&s, static_cast<uint32_t>(words), mask));
+	{
+		std::lock_guard<std::mutex> lock(g_masked_streams_mutex);
+		g_masked_streams.push_back(s);
+	}
+	*out = s;
+	return AGX_OK;
+}
 int agx_stream_destroy(void *stream)
 {
-	if (stream != nullptr)
-		AGX_HIP_CHECK(hipStreamDestroy(static_cast<hipStream_t>(stream)));
+	if (stream == nullptr)
+		return AGX_OK;
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	{
+		std::lock_guard<std::mutex> lock(g_masked_streams_mutex);
+		for (hipStream_t m : g_masked_streams)
+			if (m == s)
+			{ // drained, not destroyed (see above)
+				AGX_HIP_CHECK(hipStreamSynchronize(s));
+				return AGX_OK;
+			}
+	}
+	AGX_HIP_CHECK(hipStreamDestroy(s));
 	return AGX_OK;
 }
 int agx_stream_synchronize(void *stream)

@@ -23,6 +23,26 @@ def default_config(**overrides):
     return cfg
 
 
+def chip_slices(n_slices):
+    """n_slices streams that own disjoint, equal blocks of the device's compute units (agx_stream_create_with_cu_mask), for stepping a pool as
+    n_slices groups: returns (streams, compute units per slice).  The streams are never destroyed (agx.h)."""
+    cus = ctypes.c_int()
+    check(lib.agx_device_cu_count(ctypes.byref(cus)))
+    per = cus.value // n_slices
+    if per < 1:
+        raise ValueError("%d slices on %d compute units" % (n_slices, cus.value))
+    words = (cus.value + 31) // 32
+    streams = []
+    for k in range(n_slices):
+        mask = [0] * words
+        for c in range(k * per, (k + 1) * per):
+            mask[c // 32] |= 1 << (c % 32)
+        s = ctypes.c_void_p()
+        check(lib.agx_stream_create_with_cu_mask(ctypes.byref(s), (ctypes.c_uint32 * words)(*mask), words))
+        streams.append(s)
+    return streams, per
+
+
 def pack_openings(openings):
     """list of lists of Move::toShort -> uint16 [n][OPENING_CAP]"""
     out = np.zeros((len(openings), OPENING_CAP), dtype=np.uint16)

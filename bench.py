@@ -107,6 +107,8 @@ def main():
     ap.add_argument("--action-values", type=int, default=0, help="1: ResnetPVQ network (extra action-values head feeding the edge Q)")
     ap.add_argument("--table-entries", type=int, default=4 * 1024 * 1024)
     ap.add_argument("--yield-fraction", type=float, default=0.75, help="solver straggler cut-off (0 = lock-step pool)")
+    ap.add_argument("--slices", type=int, default=4,
+                    help="the pool stepped as this many slices on streams that own disjoint blocks of the chip's compute units (1 = one lock-step pool)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=24.0)
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline, 0 = every host CPU")
@@ -166,27 +168,46 @@ def main():
             out.append(t)
         return out
 
+    # The pool as `slices` groups of games, each stepped on its own stream that owns 1 / slices of the compute units (CU mask): the slices
+    # drift out of phase, so the power-limited tower launches never cover the whole chip at once (they hold a higher clock) and no slice
+    # waits for another slice's stragglers.  Same games, same results (games never interact); 1 slice = the whole pool in lock step.
+    slices = max(1, min(args.slices, 16))
+    while slices > 1 and (args.games % slices != 0 or args.games // slices < 4):
+        slices //= 2
+    streams, cus_per_slice, total_cus = [None], None, None
+    if slices > 1:
+        try:
+            streams, cus_per_slice = selfplay.chip_slices(slices)
+            total_cus = cus_per_slice * slices
+            check(lib.agx_net_set_launch_width(net._net, cus_per_slice))
+        except Exception as exc:   # no CU-mask support: one lock-step pool
+            print("bench.py: chip slices unavailable (%s), running one pool" % exc, file=sys.stderr)
+            slices, streams = 1, [None]
+
+    def step_slice(g, nn_timer=None):
+        pool.select_solve_group(g, slices, streams[g])
+        if nn_timer is not None:
+            check(lib.agx_timer_start(nn_timer, streams[g]))
+        pool.evaluate_group(net, g, slices, streams[g])
+        if nn_timer is not None:
+            check(lib.agx_timer_stop(nn_timer, streams[g]))
+        pool.expand_backup_group(g, slices, streams[g])
+
     for _ in range(args.warmup):
-        pool.step(net)
+        for g in range(slices):
+            step_slice(g)
     check(lib.agx_device_synchronize())
     s0 = pool.stats()
     pool.kernel_timing(True)   # HIP events around every engine kernel, on the launch stream
-    t_sel, t_nn, t_exp = make_timers(args.steps), make_timers(args.steps), make_timers(args.steps)
+    t_nn = [make_timers(args.steps) for _ in range(slices)]   # the network stage (tower + value head) of every slice and step
 
     if dist is not None:
         dist.barrier()
     check(lib.agx_device_synchronize())
     t0 = time.perf_counter()
     for i in range(args.steps):
-        check(lib.agx_timer_start(t_sel[i], None))
-        pool.select_solve()
-        check(lib.agx_timer_stop(t_sel[i], None))
-        check(lib.agx_timer_start(t_nn[i], None))
-        pool.evaluate(net)
-        check(lib.agx_timer_stop(t_nn[i], None))
-        check(lib.agx_timer_start(t_exp[i], None))
-        pool.expand_backup()
-        check(lib.agx_timer_stop(t_exp[i], None))
+        for g in range(slices):
+            step_slice(g, t_nn[g][i])
         if (i + 1) % 256 == 0:
             # long runs only (the default 150 steps never get here): what a generator thread does every few hundred steps — hand the
             # finished samples over (GeneratorManager.cpp:160-164) and keep the opening list ahead of the games
@@ -210,7 +231,9 @@ def main():
             acc += ms.value
         return acc
 
-    ms_sel, ms_nn, ms_exp = total_ms(t_sel), total_ms(t_nn), total_ms(t_exp)
+    ms_nn = sum(total_ms(t) for t in t_nn)                 # summed over slices (their launches overlap in time)
+    launches = args.steps * slices                          # launches of every stage
+    ms_sel, ms_exp = kernel_ms[0] + kernel_ms[1], kernel_ms[2] + kernel_ms[3]
     sims = s1["evaluated_nodes"] - s0["evaluated_nodes"]
     evals = s1["network_evaluations"] - s0["network_evaluations"]
     moves = s1["moves_played"] - s0["moves_played"]
@@ -230,7 +253,10 @@ def main():
         flops = nn_flops_per_position(desc)
         # dominant kernel: the policy/value tower (one launch per step); algorithmic FLOPs per launch = positions x FLOPs/position
         local_evals = s1["network_evaluations"] - s0["network_evaluations"]
+        # (ms_nn is the sum of all network launches' durations: with slices this is the rate of ONE launch on its slice's compute units)
         nn_tflops = (local_evals * flops) / (ms_nn * 1e-3) / 1e12 if ms_nn > 0 else 0.0
+        chip_share = (cus_per_slice / float(total_cus)) if slices > 1 else 1.0
+        nn_peak = 2500.0 * chip_share
         depth = levels / max(1, (s1["evaluated_nodes"] - s0["evaluated_nodes"]) + leaks)
         edges_per_level = edge_reads / max(1, levels)
         RULE_NAMES = ["freestyle", "standard", "renju", "caro5", "caro6"]
@@ -246,7 +272,7 @@ def main():
         tree_bytes = update_bytes if fused else select_bytes + update_bytes
         tree_ms = (0.0 if fused else kernel_ms[0]) + kernel_ms[2] + kernel_ms[3]
         local_sims = s1["evaluated_nodes"] - s0["evaluated_nodes"]
-        tree_gbs = local_sims * tree_bytes / (tree_ms * 1e-3) / 1e9 if tree_ms > 0 else 0.0
+        tree_gbs = local_sims * tree_bytes / (tree_ms / slices * 1e-3) / 1e9 if tree_ms > 0 else 0.0   # the slices' tree launches overlap
         # PMC-derived figures cannot be sampled from inside this process (rocprofv3 --pmc passes, scripts/pmc_summary.py).  They are quoted only
         # when the committed summary was taken from THIS build (same source hash) and this workload; otherwise null.
         traffic = None
@@ -259,7 +285,8 @@ def main():
         if os.path.exists(pmc_path):
             pmc = json.load(open(pmc_path))
             pmc_build = pmc.get("source_hash")
-            if pmc_build == src_hash and args.games == 1024 and args.filters == 128 and args.blocks == 6 and args.board == 15 and args.rules == 0:
+            if (pmc_build == src_hash and pmc.get("slices", 1) == slices and args.games == 1024 and args.filters == 128 and args.blocks == 6
+                    and args.board == 15 and args.rules == 0):
                 traffic = pmc.get("nn_tower_bytes_per_launch_corrected")
                 mfma_busy = pmc.get("nn_tower_mfma_busy_fraction")
                 solver_issue = pmc.get("k_solve_issue_busy_fraction")
@@ -287,9 +314,13 @@ def main():
             "moves_per_sec": moves / elapsed,
             "games_per_sec": games_done / elapsed,
             "nn_positions_per_sec": evals / elapsed,
-            "stage_ms_per_step": {"select_solve": ms_sel / args.steps, "network": ms_nn / args.steps, "expand_backup_advance": ms_exp / args.steps},
-            "kernel_ms_per_step": {"k_select": kernel_ms[0] / args.steps, "k_solve": kernel_ms[1] / args.steps, "nn_tower": ms_nn / args.steps,
-                                   "k_expand": kernel_ms[2] / args.steps, "k_advance": kernel_ms[3] / args.steps},
+            # how the pool is stepped: `count` slices of games_per_gpu / count games, each on a stream that owns cus_per_slice compute units;
+            # the slices' launches overlap in time, so the per-launch durations below add up to more than ms_per_step
+            "slices": {"count": slices, "cus_per_slice": cus_per_slice, "games_per_slice": args.games // slices},
+            "stage_ms_per_step": {"select_solve": ms_sel / launches, "network": ms_nn / launches, "expand_backup_advance": ms_exp / launches,
+                                  "of": "one slice's launches (average)"},
+            "kernel_ms_per_step": {"k_select": kernel_ms[0] / launches, "k_solve": kernel_ms[1] / launches, "nn_tower": ms_nn / launches,
+                                   "k_expand": kernel_ms[2] / launches, "k_advance": kernel_ms[3] / launches},
             # default: Search::select runs inside the solver's launch (one wave per game selects, then solves: k_solve<.., FUSED>), its time is
             # part of k_solve and k_select is 0; AGX_FUSE_SELECT=0 launches them separately
             "select_fused_into_solve": os.environ.get("AGX_FUSE_SELECT", "1") != "0",
@@ -306,24 +337,28 @@ def main():
             # the roofline object is the MFMA-bound network kernel (the only kernel of the step with a compute roof); the threat solver
             # (roofline_solver) has neither an HBM nor an MFMA roof, see DESIGN.md
             "roofline": {"bound": "mfma", "kernel": "nn_tower_kernel<%d,%d,%d>" % (args.filters, args.board, args.board),
-                         "achieved": nn_tflops, "peak": 2500.0, "unit": "TFLOP/s", "frac": nn_tflops / 2500.0, "traffic": traffic,
-                         "flops_per_position": flops, "positions_per_launch": local_evals / args.steps,
-                         "avg_launch_ms": ms_nn / args.steps,
+                         # a launch runs on its slice's compute units only (CU-masked stream): achieved and peak are per launch, i.e. per
+                         # cus_per_slice / total of the chip; `count` such launches overlap
+                         "achieved": nn_tflops, "peak": nn_peak, "unit": "TFLOP/s", "frac": nn_tflops / nn_peak, "traffic": traffic,
+                         "chip_share_of_a_launch": chip_share, "whole_chip_equivalent": nn_tflops / chip_share,
+                         "flops_per_position": flops, "positions_per_launch": local_evals / launches,
+                         "avg_launch_ms": ms_nn / launches,
                          # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) of the committed PMC passes of this command
                          "mfma_busy_fraction_pmc": mfma_busy,
                          # GRBM_GUI_ACTIVE / 8 / launch duration: the tower runs power-limited below the 2.4 GHz the 2.5 PFLOP/s peak assumes
                          # (frac keeps the nominal peak; this is the same rate against the MFMA issue rate at the clock actually held)
                          "shader_clock_mhz_pmc": nn_clock,
-                         "frac_of_issue_rate_at_measured_clock": (nn_tflops / (2500.0 * nn_clock / 2400.0)) if nn_clock else None,
+                         "frac_of_issue_rate_at_measured_clock": (nn_tflops / (nn_peak * nn_clock / 2400.0)) if nn_clock else None,
                          "pmc_summary_build": pmc_build},
             "roofline_solver": {"bound": "none (instruction issue / dependent-chain latency: one wave per game, tasks of a game strictly ordered)",
-                                "kernel": "k_solve (select + threat solver of a game in one wave)" if os.environ.get("AGX_FUSE_SELECT", "1") != "0" else "k_solve", "ms_per_step": kernel_ms[1] / args.steps,
+                                "kernel": "k_solve (select + threat solver of a game in one wave)" if os.environ.get("AGX_FUSE_SELECT", "1") != "0" else "k_solve", "ms_per_step": kernel_ms[1] / launches,
                                 "share_of_kernel_time": kernel_ms[1] / gpu_ms if gpu_ms > 0 else None,
-                                "solver_nodes_per_sec": solver_nodes / elapsed, "us_per_solver_node_per_wave": (kernel_ms[1] * 1e3 * args.games / solver_nodes) if solver_nodes else None,
+                                "solver_nodes_per_sec": solver_nodes / elapsed,
+                                "us_per_solver_node_per_wave": (kernel_ms[1] * 1e3 * (args.games // slices) / solver_nodes) if solver_nodes else None,
                                 "issue_busy_fraction_pmc": solver_issue},
             # second roof ("two kernels, two roofs"): the tree kernels are gathers/scans over the flat node/edge arrays
             "roofline_tree": {"bound": "hbm", "kernels": "k_expand + k_advance" if fused else "k_select + k_expand + k_advance", "achieved": tree_gbs, "peak": 8000.0, "unit": "GB/s",
-                              "frac": tree_gbs / 8000.0, "bytes_per_simulation": tree_bytes, "ms_per_step": tree_ms / args.steps,
+                              "frac": tree_gbs / 8000.0, "bytes_per_simulation": tree_bytes, "ms_per_step": tree_ms / launches,
                               "note": "latency-bound by one wave per game, not by bandwidth; k_solve (threat solver) has no HBM/MFMA roof"},
         }
         if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only

@@ -43,6 +43,7 @@ int agx_version(void);
 /* Selects the HIP device for the calling thread (one engine per GPU). */
 int agx_set_device(int device);
 int agx_device_count(int* count);
+int agx_device_cu_count(int* count); /* compute units of the current device */
 
 /* ------------------------------------------------------------------------------------------------
  * Policy/value network (replaces AGNetwork::forward / asyncForwardLaunch+Join over ml::Graph,
@@ -324,6 +325,13 @@ int agx_engine_expand_group(AgxEngine* engine, int group, int n_groups, void* st
 int agx_engine_advance_group(AgxEngine* engine, int group, int n_groups, void* stream);
 int agx_engine_step_group(AgxEngine* engine, AgxNet* net, int group, int n_groups, void* stream);
 int agx_stream_create(void** out_stream);
+/* A stream whose kernels run only on the compute units set in the mask (bit i = compute unit i).  A pool stepped as N slices
+ * (agx_engine_*_group) on N such streams with disjoint masks — 4 x 64 CUs on MI355X — runs its slices out of phase, each on its own part
+ * of the chip: the power-limited network launches never cover the whole chip at once and hold a higher clock, and no slice waits for
+ * another's stragglers (+10 % simulations/s).  Narrow the network's persistent grid to the slice's CU count
+ * (agx_net_set_launch_width).  Do not destroy such a stream while the process lives (hipStreamDestroy of a CU-masked stream hangs on
+ * ROCm 7.2): agx_stream_destroy leaves them to process exit. */
+int agx_stream_create_with_cu_mask(void** out_stream, const uint32_t* cu_mask, int n_words);
 int agx_stream_destroy(void* stream);
 int agx_stream_synchronize(void* stream);
 int agx_engine_buffers(AgxEngine* engine, AgxEngineBuffers* out);

@@ -3,7 +3,10 @@
 Per kernel: counter sums per launch (summed over the XCD / SE instances the tool reports).  Derived, per MI355X_MICROARCH.md:
   * HBM-side bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (gfx950: FETCH_SIZE tallies a 128-B request as 64 B for wide coalesced reads; unit KB;
     Infinity-Cache hits are included);
-  * MFMA busy fraction = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs);
+  * MFMA busy fraction = SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs the launch may use x GRBM_GUI_ACTIVE / 8 XCDs); bench.py steps the pool as
+    AGX_PROFILE_SLICES (default 4) slices on CU-masked streams, a tower launch then owns 1024 / slices SIMDs;
+  * NB rocprofv3 serialises kernels while it collects counters: in these passes the slices' launches do NOT overlap, so the tower's clock
+    here is that of a launch running alone on its part of an otherwise idle chip, not the clock it holds in the real, overlapped run;
   * solver issue-busy fraction = SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES, parked = SQ_WAIT_ANY / SQ_WAVE_CYCLES;
   * shader clock of a kernel = (GRBM_GUI_ACTIVE / 8 XCDs) / launch duration of the same dispatch (the tower runs power-limited well below the
     2.4 GHz the MFMA peak assumes, the solver at the full clock).
@@ -37,7 +40,8 @@ for path in dbs:
             s[counter + "_per_launch"] = sum(values) / len(values)
             s["launches"] = len(values)
 import bench  # noqa: E402
-summary = {"_comment": __doc__, "source_hash": bench.source_hash(), "command": "python3 bench.py --steps 40 --warmup 30 --no-cpu-baseline",
+slices = int(os.environ.get("AGX_PROFILE_SLICES", "4"))
+summary = {"_comment": __doc__, "source_hash": bench.source_hash(), "command": "python3 bench.py --steps 40 --warmup 30 --no-cpu-baseline", "slices": slices,
            "per_kernel_raw": per}
 tower = next((k for k in per if k.startswith("nn_tower_kernel<128, 15, 15")), None)
 if tower:
@@ -45,7 +49,7 @@ if tower:
     if "FETCH_SIZE_per_launch" in t and "WRITE_SIZE_per_launch" in t:
         summary["nn_tower_bytes_per_launch_corrected"] = (2.0 * t["FETCH_SIZE_per_launch"] + t["WRITE_SIZE_per_launch"]) * 1024.0
     if "SQ_VALU_MFMA_BUSY_CYCLES_per_launch" in t and "GRBM_GUI_ACTIVE_per_launch" in t:
-        summary["nn_tower_mfma_busy_fraction"] = t["SQ_VALU_MFMA_BUSY_CYCLES_per_launch"] / (1024.0 * t["GRBM_GUI_ACTIVE_per_launch"] / 8.0)
+        summary["nn_tower_mfma_busy_fraction"] = t["SQ_VALU_MFMA_BUSY_CYCLES_per_launch"] / (1024.0 / slices * t["GRBM_GUI_ACTIVE_per_launch"] / 8.0)
     if "shader_clock_mhz" in t:
         summary["nn_tower_shader_clock_mhz"] = t["shader_clock_mhz"]
     if "SQ_LDS_BANK_CONFLICT_per_launch" in t and t.get("SQ_LDS_IDX_ACTIVE_per_launch"):
