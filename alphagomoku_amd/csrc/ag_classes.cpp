@@ -1102,19 +1102,26 @@ namespace ag
 		// power-limited network launches never cover the whole chip at once and no slice waits for another's stragglers.
 		int cus = 0;
 		check(agx_device_cu_count(&cus));
-		const bool partition = n_groups > 1 && cus >= n_groups && games % n_groups == 0;
+		bool partition = n_groups > 1 && cus >= n_groups && games % n_groups == 0;
+		std::vector<void*> masked;
+		for (int g = 0; partition && g < n_groups; g++)
+		{
+			std::vector<uint32_t> mask((cus + 31) / 32, 0u);
+			for (int c = g * (cus / n_groups); c < (g + 1) * (cus / n_groups); c++)
+				mask[c / 32] |= 1u << (c % 32);
+			void *s = nullptr;
+			if (agx_stream_create_with_cu_mask(&s, mask.data(), static_cast<int>(mask.size())) == AGX_OK)
+				masked.push_back(s);
+			else
+				partition = false; // no CU masks on this device / runtime: plain streams (the slices then only pipeline host work)
+		}
 		if (partition)
 			check(agx_net_set_launch_width(nn_evaluator.get_network().handle(), cus / n_groups));
 		for (int g = 0; g < n_groups; g++)
 		{
 			void *s = nullptr;
 			if (partition)
-			{
-				std::vector<uint32_t> mask((cus + 31) / 32, 0u);
-				for (int c = g * (cus / n_groups); c < (g + 1) * (cus / n_groups); c++)
-					mask[c / 32] |= 1u << (c % 32);
-				check(agx_stream_create_with_cu_mask(&s, mask.data(), static_cast<int>(mask.size())));
-			}
+				s = masked[g];
 			else
 				check(agx_stream_create(&s));
 			streams.push_back(s);

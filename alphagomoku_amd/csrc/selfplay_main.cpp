@@ -3,7 +3,8 @@
  * Stands where GeneratorThread::run stands in the reference (src/selfplay/GeneratorManager.cpp:124-141).
  *
  *   agx_selfplay [--games 1024] [--steps 200] [--warmup 20] [--sims 400] [--batch 8] [--blocks 6] [--filters 128] [--rules 0]
- *                [--balanced-openings 0|1] [--drain-every N] [--pvq 0|1] [--symmetries 0|1] [--match 0|1]
+ *                [--balanced-openings 0|1] [--drain-every N] [--pvq 0|1] [--symmetries 0|1] [--match 0|1] [--slices N (default 4: the pool
+ *                 as N slices of the chip on CU-masked streams, 1 = one lock-step pool)]
  *                [--devices 0,1,...] [--save-buffer file]
  * --devices: one generator thread per listed device, each with its own pool of --games games (GeneratorManager.cpp:146-152, 39-53); the
  * threads share one game buffer (--save-buffer: finished games in dataset format 201, samples quantised on the device).
@@ -29,13 +30,13 @@
 struct Options
 {
 		int games = 1024, steps = 200, warmup = 20, sims = 400, batch = 8, blocks = 6, filters = 128, rules = 0;
-		int balanced = 0, drain_every = 0, pvq = 0, symmetries = 0, match = 0;
+		int balanced = 0, drain_every = 0, pvq = 0, symmetries = 0, match = 0, slices = 4;
 };
 struct DeviceResult
 {
 		double seconds = 0.0;
 		unsigned long long simulations = 0, moves = 0, evaluations = 0, samples = 0, refills = 0;
-		int games_finished = 0, openings_taken = 0;
+		int games_finished = 0, openings_taken = 0, slices = 1;
 		int first_score[3] = { 0, 0, 0 };
 		std::string error;
 };
@@ -72,6 +73,7 @@ static void run_device(int device, int thread_index, const Options &o, AgxGameBu
 		selfplay.network_outputs = network.getOutputConfig();
 		selfplay.record_format = (buffer != nullptr) ? 2 : 1; // format-201 samples when the games go to a buffer
 		agx::GeneratorPool pool(game, selfplay, o.match != 0);
+		result.slices = o.match ? 1 : pool.useChipSlices(network, o.slices); // the pool as slices of the chip (agx.hpp)
 		auto one_step = [&]() { if (o.match) pool.generate(network, second_network); else pool.generate(network); };
 		uint32_t next_seed = static_cast<uint32_t>(thread_index) * 1000003u; // disjoint openings per device thread
 		bool first_batch = true;
@@ -175,6 +177,7 @@ int main(int argc, char **argv)
 		}
 		else if (k == "--balanced-openings") o.balanced = v;
 		else if (k == "--drain-every") o.drain_every = v;
+		else if (k == "--slices") o.slices = v;
 		else if (k == "--pvq") o.pvq = v;
 		else if (k == "--symmetries") o.symmetries = v;
 		else if (k == "--match") o.match = v;
@@ -235,8 +238,9 @@ int main(int argc, char **argv)
 		agx_game_buffer_destroy(buffer);
 	}
 	std::printf("{\"devices\": %zu, \"simulations_per_sec\": %.1f, \"ms_per_step\": %.3f, \"moves_per_sec\": %.1f, \"games_finished\": %d, \"network_evaluations\": %llu, "
-			"\"samples_drained\": %llu, \"opening_refills\": %llu, \"openings_taken\": %d, \"first_player_won_drawn_lost\": [%d, %d, %d], \"buffer_games\": %d}\n",
+			"\"samples_drained\": %llu, \"opening_refills\": %llu, \"openings_taken\": %d, \"first_player_won_drawn_lost\": [%d, %d, %d], \"buffer_games\": %d, "
+			"\"slices\": %d}\n",
 			devices.size(), total.simulations / total.seconds, 1e3 * total.seconds / o.steps, total.moves / total.seconds, total.games_finished, total.evaluations,
-			total.samples, total.refills, total.openings_taken, total.first_score[0], total.first_score[1], total.first_score[2], bs.games);
+			total.samples, total.refills, total.openings_taken, total.first_score[0], total.first_score[1], total.first_score[2], bs.games, results.empty() ? 1 : results[0].slices);
 	return 0;
 }
