@@ -341,6 +341,9 @@ def main():
                          # cus_per_slice / total of the chip; `count` such launches overlap
                          "achieved": nn_tflops, "peak": nn_peak, "unit": "TFLOP/s", "frac": nn_tflops / nn_peak, "traffic": traffic,
                          "chip_share_of_a_launch": chip_share, "whole_chip_equivalent": nn_tflops / chip_share,
+                         "peak_note": ("peak = 2500 TFLOP/s (dense fp16 MFMA, whole chip) x %d/%d compute units: the launch runs on a CU-masked stream, "
+                                       "%d such launches (one per slice) overlap; achieved x %d = whole_chip_equivalent against 2500"
+                                       % (cus_per_slice, total_cus, slices, slices)) if slices > 1 else "whole chip: 2500 TFLOP/s dense fp16 MFMA",
                          "flops_per_position": flops, "positions_per_launch": local_evals / launches,
                          "avg_launch_ms": ms_nn / launches,
                          # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) of the committed PMC passes of this command
