@@ -44,6 +44,8 @@ def _declare(c):
     c.agx_last_error.restype = ctypes.c_char_p
     c.agx_last_error.argtypes = []
     c.agx_version.restype = ci
+    c.agx_build_hash.restype = ctypes.c_char_p
+    c.agx_build_hash.argtypes = []
     c.agx_set_device.argtypes = [ci]
     c.agx_device_cu_count.argtypes = [ctypes.POINTER(ci)]
     c.agx_net_blob_floats.restype = sz
@@ -72,6 +74,15 @@ def _declare(c):
 lib = _Lazy()
 
 
+def require_current_build():
+    """Raises unless libagx.so was compiled from the sources beside it (its agx_build_hash() == build.source_hash())."""
+    from . import build
+    have, want = lib.agx_build_hash().decode(), build.source_hash()
+    if have != want and not os.environ.get("AGX_NO_BUILD"):   # (AGX_NO_BUILD: developer A/B runs with swapped-in variants)
+        raise AgxError("libagx.so was built from other sources (library %s, sources %s): run `python -m alphagomoku_amd.build`" % (have, want))
+    return have
+
+
 def check(status):
     if status != 0:
         raise AgxError("agx error %d: %s" % (status, lib.agx_last_error().decode()))
@@ -87,7 +98,8 @@ class AgxEngineConfig(ctypes.Structure):
                 ("solver_yield_fraction", ctypes.c_float), ("final_selector", ctypes.c_int), ("use_symmetries", ctypes.c_int),
                 ("symmetry_seed", ctypes.c_uint64), ("max_children", ctypes.c_int), ("noise_type", ctypes.c_int), ("noise_weight", ctypes.c_float),
                 ("noise_seed", ctypes.c_uint64), ("action_values", ctypes.c_int), ("match_mode", ctypes.c_int), ("policy_temperature", ctypes.c_float),
-                ("arena_reserve", ctypes.c_float), ("search_threads", ctypes.c_int), ("record_format", ctypes.c_int), ("record_sample_capacity", ctypes.c_int), ("game_end_capacity", ctypes.c_int)]
+                ("arena_reserve", ctypes.c_float), ("search_threads", ctypes.c_int), ("record_format", ctypes.c_int), ("record_sample_capacity", ctypes.c_int), ("game_end_capacity", ctypes.c_int),
+                ("speculative_solver", ctypes.c_int), ("speculative_waves", ctypes.c_int)]
 
 
 class AgxEngineBuffers(ctypes.Structure):
@@ -103,7 +115,8 @@ class AgxEngineStats(ctypes.Structure):
                  "peak_edges"]] + [(n, ctypes.c_int) for n in
                                    ["games_finished", "openings_taken", "active_games", "records_used", "record_edges_used",
                                     "first_error", "arena_grows", "arena_releases", "arena_failures", "arena_max_class"]] + \
-               [("arena_heap_used", ctypes.c_float)]
+               [("arena_heap_used", ctypes.c_float), ("reserved0", ctypes.c_int), ("speculative_solves", ctypes.c_ulonglong),
+                ("speculative_reruns", ctypes.c_ulonglong)]
 
 
 class AgxEdgeView(ctypes.Structure):

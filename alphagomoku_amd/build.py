@@ -2,6 +2,7 @@
 
 The .so is git-ignored but travels to the GPU box with the gpurun snapshot.
 """
+import hashlib
 import os
 import subprocess
 import sys
@@ -10,15 +11,39 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libagx.so")
 
+INCLUDE = os.path.join(HERE, "..", "include")
 SOURCES = ["agx_api.hip", "nn_forward.hip", "engine.hip", "tables_host.cpp", "host_util.cpp", "game_buffer.cpp"]
 DRIVER = os.path.join(HERE, "agx_selfplay")
 AG_LIB = os.path.join(HERE, "libagx_ag.so")               # the reference-named C++ classes (include/alphagomoku_agx/) over the C ABI
 BOUNDARY_TEST = os.path.join(HERE, "agx_boundary_test")  # tests/cpp/boundary_main.cpp: the reference's call chain on those classes
 
 
-INCLUDE = os.path.join(HERE, "..", "include")
 BOUNDARY_SRC = os.path.join(HERE, "..", "tests", "cpp", "boundary_main.cpp")
 HOST_ONLY = ("ag_classes.cpp", "selfplay_main.cpp")  # plain g++ sources in csrc/ (not part of libagx.so)
+
+
+BUILD_ID_SRC = os.path.join(CSRC, "build_id.cpp")   # agx_build_hash(): the source hash below, compiled into libagx.so
+BUILD_ID_INC = os.path.join(CSRC, "build_id.inc")   # generated: the hash as a string literal (git-ignored)
+BUILD_ID_OBJ = os.path.join(CSRC, "build_id.o")
+
+
+def source_hash():
+    """sha256 over the sources libagx.so is built from (csrc/*.hip, *.hpp, *.cpp and include/agx.h).  The library carries the hash of the
+    sources it was compiled from (agx_build_hash()); bench.py, the test suite and committed PMC summaries compare against it, so a stale
+    prebuilt binary cannot pass for the current sources."""
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(CSRC)):
+        if name.endswith((".hip", ".hpp", ".cpp")):
+            h.update(name.encode())
+            h.update(open(os.path.join(CSRC, name), "rb").read())
+    h.update(open(os.path.join(INCLUDE, "agx.h"), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def _recorded_hash():
+    if not os.path.exists(BUILD_ID_INC) or not os.path.exists(BUILD_ID_OBJ):
+        return None
+    return open(BUILD_ID_INC).read().strip().strip('"')
 
 
 def _mtime(path):
@@ -60,14 +85,30 @@ def _stale_host_targets():
 
 def needs_build():
     objs = [os.path.join(CSRC, src.rsplit(".", 1)[0] + ".o") for src in SOURCES]
-    if _stale_objects() or _mtime(LIB) < max(_mtime(o) for o in objs):
+    if _stale_objects() or _mtime(LIB) < max(_mtime(o) for o in objs) or _recorded_hash() != source_hash():
         return True
     return bool(_stale_host_targets())
+
+
+def _compile_cmd(hipcc, src, obj):
+    # -ffp-contract=off: the tree kernels must round exactly like the CPU oracle (no fused multiply-add)
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]
+    if os.environ.get("AGX_SOLVER_PROFILE"):
+        cmd += ["-DAGX_SOLVER_PROFILE"]
+    if src.endswith(".hip"):
+        # the iterative-ILP machine scheduler beats the default on every kernel here (A/B on one box): k_solve 7.99 -> 7.72 ms,
+        # 20x20 network kernels +5 % (10x128) / +32 % (2x64), 15x15 network kernels unchanged (they carry an iglp_opt hint)
+        cmd += ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]
+    if src.endswith(".cpp"):
+        cmd += ["-x", "hip"]
+    return cmd + ["-c", os.path.join(CSRC, src), "-o", obj]
 
 
 def build(force=False, verbose=True):
     """Incremental: an object is recompiled when its source or any device header is newer, libagx.so is linked when an object is newer,
     the host-side binaries (driver, reference-named classes, boundary test) when their sources / headers are."""
+    if os.environ.get("AGX_NO_BUILD"):   # developer A/B runs that swap prebuilt variants of libagx.so in (scripts/ab_bench.sh)
+        return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cxx = os.environ.get("CXX", "g++")
 
@@ -80,25 +121,28 @@ def build(force=False, verbose=True):
     procs = []
     for src in (SOURCES if force else _stale_objects()):
         obj = os.path.join(CSRC, src.rsplit(".", 1)[0] + ".o")
-        # -ffp-contract=off: the tree kernels must round exactly like the CPU oracle (no fused multiply-add)
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]
-        if os.environ.get("AGX_SOLVER_PROFILE"):
-            cmd += ["-DAGX_SOLVER_PROFILE"]
-        if src.endswith(".hip"):
-            # the iterative-ILP machine scheduler beats the default on every kernel here (A/B on one box): k_solve 7.99 -> 7.72 ms,
-            # 20x20 network kernels +5 % (10x128) / +32 % (2x64), 15x15 network kernels unchanged (they carry an iglp_opt hint)
-            cmd += ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]
-        if src.endswith(".cpp"):
-            cmd += ["-x", "hip"]
-        cmd += ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = _compile_cmd(hipcc, src, obj)
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append(subprocess.Popen(cmd))
     for p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed")
-    if force or _mtime(LIB) < max(_mtime(o) for o in objs):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lz"])
+    # build identity: whenever the source hash differs from the one recorded with the last link, every object is suspect (mtimes do
+    # not survive every way of copying a tree), so a hash change without a recompiled object recompiles everything
+    current = source_hash()
+    relink = force or _mtime(LIB) < max(_mtime(o) for o in objs)
+    if _recorded_hash() != current:
+        if not procs and not force and _recorded_hash() is not None:
+            for src in SOURCES:   # sources changed but no object looked stale: do not trust the mtimes
+                obj = os.path.join(CSRC, src.rsplit(".", 1)[0] + ".o")
+                run(_compile_cmd(hipcc, src, obj))
+        with open(BUILD_ID_INC, "w") as f:
+            f.write('"%s"\n' % current)
+        run([cxx, "-std=c++17", "-O2", "-fPIC", "-c", BUILD_ID_SRC, "-o", BUILD_ID_OBJ])
+        relink = True
+    if relink:
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + [BUILD_ID_OBJ, "-lz"])
     stale = [DRIVER, AG_LIB, BOUNDARY_TEST] if force else _stale_host_targets()
     if DRIVER in stale:  # native C++ host driver over the C ABI (include/agx.hpp)
         run([cxx, "-std=c++17", "-O2", "-o", DRIVER, os.path.join(CSRC, "selfplay_main.cpp"), "-L" + HERE, "-lagx", "-Wl,-rpath," + HERE, "-lpthread"])

@@ -159,45 +159,129 @@ namespace agx
 				uint16_t best_move, move, baseline;
 				int16_t depth_remaining;
 				uint8_t must_defend, has_initiative, fully_expanded, pad;
-				uint32_t pad2;
+				uint32_t ov_slot; // speculative solves: the overlay slot of this node's table bucket (set when the frame is entered)
 		};
 		static_assert(sizeof(Frame) == 32, "frame layout");
 		enum Cmd : int { CMD_NONE = 0, CMD_ADD = 1, CMD_UNDO = 2, CMD_DONE = 3 };
-		constexpr int ACT_LDS = 2048;
+#ifndef AGX_LUT_LDS
+#define AGX_LUT_LDS 0 /* 1: a private 4 KB copy of the packed ThreatTable in every solver wave's LDS (-1.4 % solver time at one wave per SIMD); 0: read
+                         through the vector L1 / L2 — 4 KB less LDS per wave buys a third wave per SIMD, which hides far more than that latency */
+#endif
+		constexpr int LDS_FRAMES = 42;
+		constexpr int OV_CAP = 256; // overlay slots of a speculative solve (a 100-node solve touches ~100-150 buckets; more = the task is re-run serially) // alpha-beta frames kept in LDS; deeper ones (only reachable with node budgets far above 100) live in HBM
 
-		struct SolverShared
+		/*
+		 * Per-wave solver state, sized by the board (N = 15, 20, or MAXN for the any-size kernel) so that eight solver waves fit into a
+		 * CU's 160 KB of LDS at 15x15 (two per SIMD) instead of four:
+		 *  - the threat lists: a cell sits in at most one list per side, and the list of HALF_OPEN_3 cells is never read by anything on the
+		 *    path (MoveGenerator / AlphaBetaSearch::evaluate use OPEN_3 ... OVERLINE), so only its size is kept.  Lists 2-9 have a fixed LDS
+		 *    capacity (OPEN_3: CAP2, the others CAP); the rare tail beyond it lives in the game's HBM spill area (list_get / list_set),
+		 *    exactly like the action stack's tail;
+		 *  - the alpha-beta frames beyond LDS_FRAMES and the action stack beyond ACT_LDS spill the same way.
+		 */
+		template<int N>
+		struct SolverSharedT
 		{
-				u64 lines[6 * MAXN];
-				uint8_t board[MAXHW];
-				uint8_t ptype[MAXHW][8]; // [cell][0-3 cross dirs, 4-7 circle dirs]
-				uint8_t threat[MAXHW][2];
-				uint8_t threat_lut[4096]; // ThreatTable in LDS: cross | circle << 4 for the 4 x 3-bit pattern index (loaded per launch)
-				uint16_t lists[2][10][MAXHW];
-				uint16_t count[2][10];
-				uint32_t legal[MAXN];
-				uint32_t added[MAXN];
-				Frame frames[MAX_FRAMES];
+				static constexpr int DIM = N, HW = N * N;
+				static constexpr int CAP2 = (N <= 15) ? 64 : 96, CAP = 24;
+				static constexpr int LIST_ITEMS = CAP2 + 7 * CAP;
+				// the select stage of the fused kernel parks its node-cache keys in the (then idle) action stack + frames, which are
+				// contiguous, its compressed board in `lines` and its board in `board`
+				static constexpr int SELECT_KEY_BYTES = 3 * (1 + HW) * 8;
+				static constexpr int ACT_LDS = (N <= 15) ? 1024 : 2112;
+				__device__ static constexpr int list_cap(int t) { return (t == 2) ? CAP2 : CAP; }
+				__device__ static constexpr int list_off(int t) { return (t == 2) ? 0 : CAP2 + (t - 3) * CAP; }
+
+				u64 lines[6 * N];
 				uint32_t act[ACT_LDS];   // head of the action stack (the tail, if ever needed, spills to HBM)
-				uint32_t row_mask[MAXN]; // scratch row masks of the move generator
+				Frame frames[LDS_FRAMES];
+				uint8_t ptype[HW][8]; // [cell][0-3 cross dirs, 4-7 circle dirs]
+#if AGX_LUT_LDS
+				uint8_t threat_lut[4096]; // ThreatTable in LDS: cross | circle << 4 for the 4 x 3-bit pattern index (loaded per launch)
+#endif
+				uint8_t threat[HW][2];
+				uint16_t items[2][LIST_ITEMS]; // threat lists 2..9 of both sides, list t at list_off(t)
+				uint16_t pos[2][HW];     // index of a cell inside its list (ThreatHistogram::remove finds it by search)
+				uint16_t count[2][10];
+				uint32_t legal[N];
+				uint32_t added[N];
+				uint32_t row_mask[N]; // scratch row masks of the move generator
 				uint16_t sets[5][32];    // small location sets of the move generator (kept out of per-lane scratch memory)
-				uint16_t tmp_list[MAXHW]; // copy of a threat list that renju foul checks would permute while it is iterated
+				uint16_t tmp_list[HW]; // copy of a threat list that renju foul checks would permute while it is iterated
 				uint16_t foul_cell[64];  // MoveGenerator::forbidden_moves_cache (MoveGenerator.hpp:74)
 				uint8_t foul_flag[64];
+				uint8_t board[(HW + 7) / 8 * 8];
 				int foul_count;
 				int fstack[16][5];       // explicit stack of the recursive renju 3x3 check: cell, dir, i, count, promotion mask
 				u64 pf_bucket[8];        // transposition-table bucket prefetched for the child about to be entered
 				u64 pf_lo;
 				int pf_valid;
+				// speculative solves (k_search_spec): every table bucket the task touches is copied into a per-task overlay in HBM (its content at
+				// first touch + the task's own version); the game's table itself is only written when the task is committed
+				uint32_t ov_keys[OV_CAP];          // bucket index of every overlay slot
+				uint32_t ov_dirty[OV_CAP / 32];    // slots the task has written
+				u64 *ov_data;                      // [OV_CAP][16]: words 0-7 the bucket at first touch, 8-15 the task's version
+				int ov_on, ov_count, ov_overflow, pf_slot;
 #ifdef AGX_SOLVER_PROFILE
 				unsigned long long prof[8];
 				unsigned long long dprof[24];
 #endif
 				u64 hash_lo, hash_hi;
+				uint16_t *spill_lists;   // [2][10][hw] tails of the threat lists (HBM, per game)
+				Frame *spill_frames;     // [MAX_FRAMES] frames beyond LDS_FRAMES (HBM, per game)
 				int sign_to_move, depth;
 				int node_counter, stack_offset, stack_max, level;
 				int cmd, cmd_move, pending_value, error;
 				int result_score, phase;
 		};
+		typedef SolverSharedT<MAXN> SolverShared; // any board size
+
+		/* Threat-list entries: LDS below the list's capacity, the game's HBM spill area above it.  As with the action stack the two paths
+		 * stay two different instructions (inline assembly), or hipcc merges them into FLAT accesses. */
+		template<class SH>
+		__device__ __forceinline__ uint32_t list_get(const SH &sh, int s, int t, int i)
+		{
+			if (__builtin_expect(i < SH::list_cap(t), 1))
+				return sh.items[s][SH::list_off(t) + i];
+			uint32_t v;
+			asm volatile("global_load_ushort %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(sh.spill_lists + (s * 10 + t) * SH::HW + i) : "memory");
+			return v;
+		}
+		template<class SH>
+		__device__ __forceinline__ void list_set(SH &sh, int s, int t, int i, uint32_t cell)
+		{
+			if (__builtin_expect(i < SH::list_cap(t), 1))
+				sh.items[s][SH::list_off(t) + i] = static_cast<uint16_t>(cell);
+			else
+				asm volatile("global_store_short %0, %1, off\n\ts_waitcnt vmcnt(0)" : : "v"(sh.spill_lists + (s * 10 + t) * SH::HW + i), "v"(cell) : "memory");
+		}
+		template<class SH>
+		__device__ __forceinline__ Frame frame_get(const SH &sh, int level)
+		{
+			if (__builtin_expect(level < LDS_FRAMES, 1))
+				return sh.frames[level];
+			u64 w[4];
+			const Frame *p = sh.spill_frames + level;
+			asm volatile("global_load_dwordx2 %0, %4, off\n\tglobal_load_dwordx2 %1, %4, off offset:8\n\tglobal_load_dwordx2 %2, %4, off offset:16\n\t"
+					"global_load_dwordx2 %3, %4, off offset:24\n\ts_waitcnt vmcnt(0)" : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]) : "v"(p) : "memory");
+			Frame f;
+			__builtin_memcpy(&f, w, sizeof(Frame));
+			return f;
+		}
+		template<class SH>
+		__device__ __forceinline__ void frame_set(SH &sh, int level, const Frame &f)
+		{
+			if (__builtin_expect(level < LDS_FRAMES, 1))
+				sh.frames[level] = f;
+			else
+			{
+				u64 w[4];
+				__builtin_memcpy(w, &f, sizeof(Frame));
+				Frame *p = sh.spill_frames + level;
+				asm volatile("global_store_dwordx2 %4, %0, off\n\tglobal_store_dwordx2 %4, %1, off offset:8\n\tglobal_store_dwordx2 %4, %2, off offset:16\n\t"
+						"global_store_dwordx2 %4, %3, off offset:24\n\ts_waitcnt vmcnt(0)" : : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(p) : "memory");
+			}
+		}
 
 #ifdef AGX_SOLVER_PROFILE
 #define AGX_PROF_BEGIN() unsigned long long agx_pt_ = clock64()
@@ -217,30 +301,43 @@ namespace agx
 			index = (d == 0) ? r : ((d == 1) ? n + c : ((d == 2) ? i2 : i3));
 			shift = 2 * ((d == 0) ? c : ((d == 1) ? r : ((d == 2) ? s2 : s3)));
 		}
-		__device__ __forceinline__ uint32_t extended_pattern(const SolverShared &sh, int n, int r, int c, int d)
+		template<class SH>
+		__device__ __forceinline__ uint32_t extended_pattern(const SH &sh, int n, int r, int c, int d)
 		{ // 13 cells (+-6), off-board = 3 (RawPatternCalculator.hpp:196-210)
 			int index, shift;
 			line_of(n, r, c, d, index, shift);
 			return static_cast<uint32_t>((sh.lines[index] >> shift) & 0x3FFFFFFull);
 		}
-		__device__ __forceinline__ uint32_t normal_pattern(const SolverShared &sh, int n, int r, int c, int d) { return (extended_pattern(sh, n, r, c, d) >> 2) & 0x3FFFFFu; }
+		template<class SH>
+		__device__ __forceinline__ uint32_t normal_pattern(const SH &sh, int n, int r, int c, int d) { return (extended_pattern(sh, n, r, c, d) >> 2) & 0x3FFFFFu; }
 		__device__ __forceinline__ uint32_t narrow(uint32_t x) { return (x & 1023u) | ((x & 4190208u) >> 2); }
 		__device__ __forceinline__ uint32_t threat_index(const uint8_t *pt) { return pt[0] | (pt[1] << 3) | (pt[2] << 6) | (pt[3] << 9); }
 
 		/* ThreatTable (4096 x 2 threat types < 16) packed to one byte per index: 4 KB of LDS instead of a second dependent L2 access
 		 * for every re-classified cell.  Once per launch, before the first solver_set_board. */
-		__device__ __forceinline__ void solver_load_threat_table(SolverShared &sh, const EngineDev &E, int lane)
+		template<class SH>
+		__device__ __forceinline__ void solver_load_threat_table(SH &sh, const EngineDev &E, int lane)
 		{
+#if AGX_LUT_LDS
 			for (int i = lane; i < 4096; i += 64)
-			{
-				const uint16_t both = reinterpret_cast<const uint16_t*>(E.t_threat)[i];
-				sh.threat_lut[i] = static_cast<uint8_t>((both & 15u) | ((both >> 8) << 4));
-			}
+				sh.threat_lut[i] = E.t_threat_packed[i];
 			wave_sync();
+#endif
+		}
+		/* ThreatTable lookup: cross type in the low nibble, circle type in the high one (tables_host: packed once at engine creation) */
+		template<class SH>
+		__device__ __forceinline__ uint32_t threat_lookup(const SH &sh, const EngineDev &E, uint32_t index)
+		{
+#if AGX_LUT_LDS
+			return sh.threat_lut[index];
+#else
+			return E.t_threat_packed[index];
+#endif
 		}
 
 		/* PatternCalculator::setBoard (PatternCalculator.cpp:40-66, 245-277) */
-		__device__ __forceinline__ void solver_set_board(SolverShared &sh, const EngineDev &E, const uint8_t *board, int sign_to_move, int lane)
+		template<class SH>
+		__device__ __forceinline__ void solver_set_board(SH &sh, const EngineDev &E, const uint8_t *board, int sign_to_move, int lane)
 		{
 			const int n = E.n, hw = E.hw;
 			for (int i = lane; i < hw; i += 64)
@@ -299,8 +396,8 @@ namespace agx
 							sh.ptype[cell][d] = e & 15;
 							sh.ptype[cell][4 + d] = e >> 4;
 						}
-						t0 = sh.threat_lut[threat_index(sh.ptype[cell])] & 15;
-						t1 = sh.threat_lut[threat_index(sh.ptype[cell] + 4)] >> 4;
+						t0 = threat_lookup(sh, E, threat_index(sh.ptype[cell])) & 15;
+						t1 = threat_lookup(sh, E, threat_index(sh.ptype[cell] + 4)) >> 4;
 					}
 					else
 					{
@@ -319,10 +416,10 @@ namespace agx
 					if (m0 != 0)
 					{
 						const int cnt = sh.count[0][t];
-						if (t0 == t)
+						if (t0 == t && t != 1)
 						{
-							sh.lists[0][t][cnt + __popcll(m0 & lower)] = static_cast<uint16_t>(cell);
-							sh.lists[0][0][cell] = static_cast<uint16_t>(cnt + __popcll(m0 & lower));
+							list_set(sh, 0, t, cnt + __popcll(m0 & lower), cell);
+							sh.pos[0][cell] = static_cast<uint16_t>(cnt + __popcll(m0 & lower));
 						}
 						wave_sync();
 						if (lane == 0)
@@ -333,10 +430,10 @@ namespace agx
 					if (m1 != 0)
 					{
 						const int cnt = sh.count[1][t];
-						if (t1 == t)
+						if (t1 == t && t != 1)
 						{
-							sh.lists[1][t][cnt + __popcll(m1 & lower)] = static_cast<uint16_t>(cell);
-							sh.lists[1][0][cell] = static_cast<uint16_t>(cnt + __popcll(m1 & lower));
+							list_set(sh, 1, t, cnt + __popcll(m1 & lower), cell);
+							sh.pos[1][cell] = static_cast<uint16_t>(cnt + __popcll(m1 & lower));
 						}
 						wave_sync();
 						if (lane == 0)
@@ -361,7 +458,8 @@ namespace agx
 		 * own four windows when the stone is removed.  The L2 round trip then overlaps the descend / return work instead of standing
 		 * between the stone and the list edits.
 		 */
-		__device__ __forceinline__ uint8_t pattern_prefetch(const SolverShared &sh, const EngineDev &E, int n, uint32_t mv, bool add, int lane)
+		template<class SH>
+		__device__ __forceinline__ uint8_t pattern_prefetch(const SH &sh, const EngineDev &E, int n, uint32_t mv, bool add, int lane)
 		{ // branch-free on purpose: ONE load instruction for the whole wave (idle lanes read entry 0), so that nothing has to wait for
 		  // it before solver_update_around consumes it
 			const int s = mv & 3, r = (mv >> 2) & 127, c = (mv >> 9) & 127;
@@ -384,7 +482,8 @@ namespace agx
 		 * directions of the centre when a stone is removed.
 		 * The threat lists must end up in the reference's order (push-back add, swap-with-last remove, applied cell by cell): see the
 		 * list-edit steps below. */
-		__device__ __forceinline__ void solver_update_around(SolverShared &sh, const EngineDev &E, int r, int c, bool added, int lane, bool prefetched = false,
+		template<class SH>
+		__device__ __forceinline__ void solver_update_around(SH &sh, const EngineDev &E, int r, int c, bool added, int lane, bool prefetched = false,
 				uint8_t pf_e = 0)
 		{ // prefetched: pf_e holds this lane's pattern_prefetch() result for exactly this stone
 			const int n = E.n;
@@ -419,8 +518,8 @@ namespace agx
 						w1 = (w1 & ~(255u << (8 * d))) | ((e >> 4) << (8 * d));
 						sh.ptype[cell][d] = static_cast<uint8_t>(e & 15u);
 						sh.ptype[cell][4 + d] = static_cast<uint8_t>(e >> 4);
-						new0 = sh.threat_lut[(w0 & 7u) | (((w0 >> 8) & 7u) << 3) | (((w0 >> 16) & 7u) << 6) | (((w0 >> 24) & 7u) << 9)] & 15;
-						new1 = sh.threat_lut[(w1 & 7u) | (((w1 >> 8) & 7u) << 3) | (((w1 >> 16) & 7u) << 6) | (((w1 >> 24) & 7u) << 9)] >> 4;
+						new0 = threat_lookup(sh, E, (w0 & 7u) | (((w0 >> 8) & 7u) << 3) | (((w0 >> 16) & 7u) << 6) | (((w0 >> 24) & 7u) << 9)) & 15;
+						new1 = threat_lookup(sh, E, (w1 & 7u) | (((w1 >> 8) & 7u) << 3) | (((w1 >> 16) & 7u) << 6) | (((w1 >> 24) & 7u) << 9)) >> 4;
 						sh.threat[cell][0] = static_cast<uint8_t>(new0);
 						sh.threat[cell][1] = static_cast<uint8_t>(new1);
 					}
@@ -449,8 +548,8 @@ namespace agx
 			{
 				const uint32_t bits = __builtin_amdgcn_readlane(centre_bits, 40) | __builtin_amdgcn_readlane(centre_bits, 41)
 						| __builtin_amdgcn_readlane(centre_bits, 42) | __builtin_amdgcn_readlane(centre_bits, 43);
-				c0 = sh.threat_lut[bits & 4095u] & 15;
-				c1 = sh.threat_lut[(bits >> 16) & 4095u] >> 4;
+				c0 = threat_lookup(sh, E, bits & 4095u) & 15;
+				c1 = threat_lookup(sh, E, (bits >> 16) & 4095u) >> 4;
 				if (lane == 0)
 				{
 					sh.threat[center][0] = static_cast<uint8_t>(c0);
@@ -478,17 +577,21 @@ namespace agx
 				const int o = my_s ? o1 : o0, nw = my_s ? n1 : n0;
 				const bool take = (my_t == o) && (o != 0);
 				const bool put = (my_t == nw) && (nw != 0);
+				const bool stored = (my_t != 1); // the HALF_OPEN_3 list is only counted (nothing on the path reads its entries)
 				int idx = 0, last = 0;
-				if (take)
+				if (take && stored)
 				{
-					idx = sh.lists[my_s][0][cl];
-					last = sh.lists[my_s][my_t][cnt - 1];
+					idx = sh.pos[my_s][cl];
+					last = static_cast<int>(list_get(sh, my_s, my_t, cnt - 1));
 				}
 				if (take || put)
 				{
-					sh.lists[my_s][my_t][take ? idx : cnt] = static_cast<uint16_t>(take ? last : cl);
-					if (put || last != cl)
-						sh.lists[my_s][0][take ? last : cl] = static_cast<uint16_t>(take ? idx : cnt);
+					if (stored)
+					{
+						list_set(sh, my_s, my_t, take ? idx : cnt, static_cast<uint32_t>(take ? last : cl));
+						if (put || last != cl)
+							sh.pos[my_s][take ? last : cl] = static_cast<uint16_t>(take ? idx : cnt);
+					}
 					cnt += put ? 1 : -1;
 				}
 				__builtin_amdgcn_wave_barrier();
@@ -523,7 +626,8 @@ namespace agx
 			wave_sync();
 			AGX_PROF_MARK(sh, 12);
 		}
-		__device__ __forceinline__ void solver_place(SolverShared &sh, const EngineDev &E, uint32_t move, bool add, int lane, bool prefetched = false,
+		template<class SH>
+		__device__ __forceinline__ void solver_place(SH &sh, const EngineDev &E, uint32_t move, bool add, int lane, bool prefetched = false,
 				uint8_t pf_e = 0)
 		{ // PatternCalculator::addMove / undoMove (PatternCalculator.cpp:68-105)
 			const int n = E.n;
@@ -566,7 +670,8 @@ namespace agx
 					return PROMO_RESULTS[i];
 			return 0;
 		}
-		__device__ __forceinline__ bool straight_four_at(const SolverShared &sh, int n, int r, int c, int d)
+		template<class SH>
+		__device__ __forceinline__ bool straight_four_at(const SH &sh, int n, int r, int c, int d)
 		{ // RawPatternCalculator::isStraightFourAt (RawPatternCalculator.hpp:142-178) on the byte board, cross stone assumed at (r, c)
 			uint32_t line = 0;
 			for (int k = -5, shf = 0; k <= 5; k++, shf += 2)
@@ -588,7 +693,8 @@ namespace agx
 		 * explicit stack, and the stone placement is the same wave-wide incremental update as everywhere else (so the threat lists are
 		 * permuted exactly as in the reference).  Called by ALL lanes.
 		 */
-		__device__ __forceinline__ bool renju_is_forbidden(SolverShared &sh, const EngineDev &E, int cell0, int lane)
+		template<class SH>
+		__device__ __forceinline__ bool renju_is_forbidden(SH &sh, const EngineDev &E, int cell0, int lane)
 		{
 			const int n = E.n;
 			if (sh.board[cell0] != 0)
@@ -742,7 +848,8 @@ namespace agx
 		}
 
 		/* NNInputFeatures::encode (NNInputFeatures.cpp:15-32,59-113) */
-		__device__ __forceinline__ void solver_encode_features(const SolverShared &sh, const EngineDev &E, uint32_t *out, int lane)
+		template<class SH>
+		__device__ __forceinline__ void solver_encode_features(const SH &sh, const EngineDev &E, uint32_t *out, int lane)
 		{
 			const int own = sh.sign_to_move;
 			const uint32_t base = (1u << 3) | ((own == 1) ? (1u << 4) : (1u << 5));
@@ -763,7 +870,8 @@ namespace agx
 		}
 		/* the renju part of encode (NNInputFeatures.cpp:105-112): bit 6 on every cell that is a foul for cross, probed in row-major
 		 * order (the probes of 3x3 forks place and remove stones, i.e. permute the threat lists, exactly like the reference) */
-		__device__ __forceinline__ void solver_encode_forbidden(SolverShared &sh, const EngineDev &E, uint32_t *out, int lane)
+		template<class SH>
+		__device__ __forceinline__ void solver_encode_forbidden(SH &sh, const EngineDev &E, uint32_t *out, int lane)
 		{
 			if (E.rules != AGX_RENJU || sh.sign_to_move != 1)
 				return;
@@ -902,22 +1010,25 @@ namespace agx
 		/* The action stack lives in LDS; only its tail (index >= ACT_LDS, rare) spills to HBM.  The two paths must stay two different
 		 * instructions (hence the inline assembly): as plain C++ hipcc merges them into a FLAT load / store with a selected address, and a FLAT
 		 * access to LDS costs a full vector-memory round trip on every action read (2300 cycles per move pick, measured). */
-		__device__ __forceinline__ uint32_t act_get(const SolverShared &sh, const uint32_t *spill, int i)
+		template<class SH>
+		__device__ __forceinline__ uint32_t act_get(const SH &sh, const uint32_t *spill, int i)
 		{
-			if (__builtin_expect(i < ACT_LDS, 1))
+			if (__builtin_expect(i < SH::ACT_LDS, 1))
 				return sh.act[i];
 			uint32_t v;
 			asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(spill + i) : "memory");
 			return v;
 		}
-		__device__ __forceinline__ void act_set(SolverShared &sh, uint32_t *spill, int i, uint32_t v)
+		template<class SH>
+		__device__ __forceinline__ void act_set(SH &sh, uint32_t *spill, int i, uint32_t v)
 		{
-			if (__builtin_expect(i < ACT_LDS, 1))
+			if (__builtin_expect(i < SH::ACT_LDS, 1))
 				sh.act[i] = v;
 			else
 				asm volatile("global_store_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : : "v"(spill + i), "v"(v) : "memory");
 		}
-		__device__ __forceinline__ int act_find_move(const SolverShared &sh, const uint32_t *spill, int begin, int end, uint32_t move, int lane)
+		template<class SH>
+		__device__ __forceinline__ int act_find_move(const SH &sh, const uint32_t *spill, int begin, int end, uint32_t move, int lane)
 		{
 			for (int base = begin; base < end; base += 64)
 			{
@@ -929,10 +1040,10 @@ namespace agx
 			return -1;
 		}
 
-		template<bool RENJU>
+		template<bool RENJU, class SH>
 		struct MoveGen
 		{
-				SolverShared &sh;
+				SH &sh;
 				const EngineDev &E;
 				uint32_t *act;
 				Frame &f;
@@ -940,7 +1051,7 @@ namespace agx
 				int stack_offset, stack_max, board_depth;
 				int own_cnt[10], opp_cnt[10]; // list sizes, read once: the generator never changes the threat lists (non-renju)
 
-				__device__ __forceinline__ MoveGen(SolverShared &s, const EngineDev &e, uint32_t *a, Frame &fr, int ln, int offset, int maximum) :
+				__device__ __forceinline__ MoveGen(SH &s, const EngineDev &e, uint32_t *a, Frame &fr, int ln, int offset, int maximum) :
 						sh(s), E(e), act(a), f(fr), n(e.n), own(s.sign_to_move), opp(3 - s.sign_to_move), lane(ln), stack_offset(offset), stack_max(maximum), board_depth(s.depth)
 				{
 #pragma unroll
@@ -950,7 +1061,7 @@ namespace agx
 						opp_cnt[t] = s.count[opp - 1][t];
 					}
 				}
-				__device__ __forceinline__ const uint16_t* list(int sign, int t) const { return sh.lists[sign - 1][t]; }
+				__device__ __forceinline__ int item(int sign, int t, int k) const { return static_cast<int>(list_get(sh, sign - 1, t, k)); }
 				__device__ __forceinline__ int count(int sign, int t) const { return (sign == own) ? own_cnt[t] : opp_cnt[t]; }
 				__device__ __forceinline__ const uint8_t* patterns(int sign, int cell) const { return sh.ptype[cell] + 4 * (sign - 1); }
 				__device__ __forceinline__ int threat_at(int sign, int cell) const { return sh.threat[cell][sign - 1]; }
@@ -990,7 +1101,7 @@ namespace agx
 				{ // MoveGenerator::get_copy_of (:1174-1178)
 					const int cnt = count(sign, t);
 					for (int i = lane; i < cnt; i += 64)
-						sh.tmp_list[i] = list(sign, t)[i];
+						sh.tmp_list[i] = item(sign, t, i);
 					wave_sync();
 					return cnt;
 				}
@@ -1033,14 +1144,14 @@ namespace agx
 					if (override_duplicate)
 					{
 						for (int i = 0; i < cnt; i++)
-							add_move(list(sign, t)[i], score, true);
+							add_move(item(sign, t, i), score, true);
 						return;
 					}
 					// the cells of one threat list are distinct, so the not-yet-added ones can be appended in list order by all lanes at once
 					for (int base = 0; base < cnt; base += 64)
 					{
 						const int k = base + lane;
-						const int cell = (k < cnt) ? list(sign, t)[k] : 0;
+						const int cell = (k < cnt) ? item(sign, t, k) : 0;
 						const int r = cell / n, c = cell % n;
 						const bool fresh = (k < cnt) && (((sh.added[r] >> c) & 1u) == 0u);
 						const u64 m = __ballot(fresh);
@@ -1171,7 +1282,7 @@ namespace agx
 					const int cnt = count(own, 5);
 					for (int k = 0; k < cnt; k++)
 					{
-						const int cell = list(own, 5)[k];
+						const int cell = item(own, 5, k);
 						const uint32_t solution = try_solve_own_fork_4x3(cell);
 						add_move(cell, solution, true);
 						if (s_proven(solution))
@@ -1300,7 +1411,7 @@ namespace agx
 					bool initialized = false;
 					for (int k = 0; k < cnt; k++)
 					{
-						const int cell = list(opp, 8)[k];
+						const int cell = item(opp, 8, k);
 						const int dir = direction_of(patterns(opp, cell), 6);
 						get_defensive_moves(cell, dir, tmp);
 						intersect_init(dm, initialized, tmp);
@@ -1485,7 +1596,7 @@ namespace agx
 					for (int k = 0; k < n_open4; k++)
 					{
 						f.must_defend = 1;
-						const int cell = list(opp, 7)[k];
+						const int cell = item(opp, 7, k);
 						const int dir = direction_of(patterns(opp, cell), 4);
 						get_defensive_moves(cell, dir, tmp);
 						intersect_init(dm, initialized, tmp);
@@ -1500,7 +1611,7 @@ namespace agx
 					for (int k = 0; k < n_fork44; k++)
 					{
 						f.must_defend = 1;
-						const int cell = list(opp, 6)[k];
+						const int cell = item(opp, 6, k);
 						const uint8_t *group = patterns(opp, cell);
 						for (int d = 0; d < 4; d++)
 							if (group[d] == 4 || group[d] == 5)
@@ -1570,7 +1681,7 @@ namespace agx
 					SmallSet tmp(sh.sets[1]), half4(sh.sets[3]);
 					for (int k = 0; k < n43; k++)
 					{
-						const int cell = list(opp, 5)[k];
+						const int cell = item(opp, 5, k);
 						const uint8_t *group = patterns(opp, cell);
 						for (int d = 0; d < 4; d++)
 							if (group[d] == 2)
@@ -1610,7 +1721,7 @@ namespace agx
 					}
 					for (int k = 0; k < n33; k++)
 					{
-						const int cell = list(opp, 3)[k];
+						const int cell = item(opp, 3, k);
 						const uint8_t *group = patterns(opp, cell);
 						for (int d = 0; d < 4; d++)
 							if (group[d] == 2)
@@ -1723,6 +1834,46 @@ namespace agx
 				}
 		};
 
+		/* ---------------- speculative table overlay ----------------
+		 * The tasks of a game's batch share its transposition table and the reference solves them one after the other (Search.cpp:159-183).
+		 * k_search_spec solves them in parallel, each against the table as it was BEFORE the batch: a task never writes the table, it
+		 * copies every bucket it touches into its overlay (first-touch content + own version) and works on the copy.  When the whole batch
+		 * is solved the tasks are committed in batch order: a task whose first-touch copies still equal the table's buckets has seen exactly
+		 * what it would have seen in its turn, so its version of the written buckets IS the serial result; any other task is solved again,
+		 * serially, on the then-current table (solve_spec_commit, engine.hip). */
+		template<class SH>
+		__device__ __forceinline__ int ov_find(const SH &sh, uint32_t bucket, int lane)
+		{ // slot of `bucket` or -1: the keys are searched 64 per step, one per lane
+			const int cnt = sh.ov_count;
+			for (int base = 0; base < cnt; base += 64)
+			{
+				const u64 m = __ballot(base + lane < cnt && sh.ov_keys[base + lane] == bucket);
+				if (m != 0)
+					return base + __ffsll(static_cast<long long>(m)) - 1;
+			}
+			return -1;
+		}
+		/* a new slot for `bucket` whose eight words lanes 0-7 and again lanes 8-15 hold in `word`; -1 (and ov_overflow) when the overlay is full */
+		template<class SH>
+		__device__ __forceinline__ int ov_create(SH &sh, uint32_t bucket, u64 word, int lane)
+		{
+			const int p = sh.ov_count;
+			if (p >= OV_CAP)
+			{
+				sh.ov_overflow = 1;
+				return -1;
+			}
+			if (lane < 16)
+				sh.ov_data[p * 16 + lane] = word; // lanes 0-7: first-touch copy, lanes 8-15 (same words): working copy
+			if (lane == 0)
+			{
+				sh.ov_keys[p] = bucket;
+				sh.ov_count = p + 1;
+			}
+			wave_sync();
+			return p;
+		}
+
 		/* ---------------- transposition table (SharedHashTable.hpp:27-220), 4 x 16-byte entries per bucket ---------------- */
 		__device__ __forceinline__ u64 tt_pack(int bound, int depth, uint32_t score, uint32_t move)
 		{
@@ -1769,7 +1920,8 @@ namespace agx
 		}
 
 		/* AlphaBetaSearch::evaluate (AlphaBetaSearch.cpp:345-365) */
-		__device__ __forceinline__ uint32_t solver_evaluate(const SolverShared &sh)
+		template<class SH>
+		__device__ __forceinline__ uint32_t solver_evaluate(const SH &sh)
 		{
 			const int own = sh.sign_to_move - 1, opp = 1 - own;
 			int result = 12;
@@ -1783,8 +1935,8 @@ namespace agx
 		 * Runs until a stone must be placed/removed (returns CMD_ADD / CMD_UNDO with sh.cmd_move) or the root returns (CMD_DONE).
 		 * phase: 0 = enter frame `level`, 1 = resume frame `level` after its child returned sh.pending_value.
 		 */
-		template<bool RENJU>
-		__device__ __forceinline__ int solver_run(SolverShared &sh, const EngineDev &E, uint32_t *act, u64 *tt, int generation, int lane, u64 &pf_word,
+		template<bool RENJU, class SH>
+		__device__ __forceinline__ int solver_run(SH &sh, const EngineDev &E, uint32_t *act, u64 *tt, int generation, int lane, u64 &pf_word,
 				uint8_t &pf_pattern, int &pf_pattern_tag)
 		{ // executed by ALL lanes with identical (wave-uniform) state: stores are same-address / same-value, scans are lane-parallel.
 		  // The scalars of the machine and the current frame are held in registers and written back to LDS only when the machine yields.
@@ -1795,7 +1947,7 @@ namespace agx
 			int node_counter = sh.node_counter, stack_offset = sh.stack_offset, stack_max = sh.stack_max, error = sh.error;
 			u64 hash_lo = sh.hash_lo, hash_hi = sh.hash_hi;
 			uint32_t value = static_cast<uint32_t>(sh.pending_value);
-			Frame f = sh.frames[level];
+			Frame f = frame_get(sh, level);
 			AGX_PROF_MARK(sh, 15); // resume: machine state back into registers
 			auto yield = [&](int cmd, int move)
 			{
@@ -1825,8 +1977,19 @@ namespace agx
 				{ // ---- enter ----
 					f.best_move = 0;
 					u64 entry;
-					if (sh.pf_valid && sh.pf_lo == hash_lo)
+					const bool have_pf = sh.pf_valid && sh.pf_lo == hash_lo;
+					if (have_pf || sh.ov_on)
 					{ // bucket fetched while the stone was being placed (lanes 0-7 still hold its words in a register)
+						if (sh.ov_on)
+						{ // speculative solve: the bucket comes out of / goes into the task's overlay
+							const uint32_t bucket = static_cast<uint32_t>(hash_lo & E.tt_bucket_mask);
+							int slot = have_pf ? sh.pf_slot : ov_find(sh, bucket, lane);
+							if (!have_pf && lane < 16)
+								pf_word = (slot >= 0) ? sh.ov_data[slot * 16 + 8 + (lane & 7)] : tt[8 * static_cast<u64>(bucket) + (lane & 7)];
+							if (slot < 0)
+								slot = ov_create(sh, bucket, pf_word, lane);
+							f.ov_slot = static_cast<uint32_t>(slot);
+						}
 						if (lane < 8)
 							sh.pf_bucket[lane] = pf_word;
 						wave_sync();
@@ -1840,7 +2003,13 @@ namespace agx
 						entry = tt_seek(tt, E.tt_bucket_mask, hash_lo, hash_hi);
 					sh.pf_valid = 0;
 					bool early = false;
-					if ((entry & 3ull) != 0ull)
+					if (sh.ov_on && sh.ov_overflow)
+					{ // the overlay is full: the solve is abandoned (every frame returns at once) and repeated serially, straight on the table
+						error = ERR_OVERLAY;
+						value = s_unknown(0);
+						early = true;
+					}
+					else if ((entry & 3ull) != 0ull)
 					{
 						f.best_move = static_cast<uint16_t>((entry >> 32) & 65535u);
 						if (level != 0)
@@ -1868,7 +2037,7 @@ namespace agx
 						node_counter++;
 						if (f.size == 0)
 						{
-							MoveGen<RENJU> gen(sh, E, act, f, lane, stack_offset, stack_max);
+							MoveGen<RENJU, SH> gen(sh, E, act, f, lane, stack_offset, stack_max);
 							const uint32_t static_score = gen.generate(level == 0 ? 2 : 1);
 							stack_offset = gen.stack_offset;
 							stack_max = gen.stack_max;
@@ -1989,7 +2158,7 @@ namespace agx
 								hash_lo ^= zobrist_word(zseed, zi);
 								hash_hi ^= zobrist_word(zseed, zi + 1);
 								f.move = static_cast<uint16_t>(mv);
-								sh.frames[level] = f;
+								frame_set(sh, level, f);
 								Frame child;
 								child.base = f.base + f.size; // == stack offset: lists are strictly nested
 								child.size = 0;
@@ -2003,12 +2172,20 @@ namespace agx
 								child.move = 0;
 								child.baseline = static_cast<uint16_t>(s_unknown(0));
 								child.must_defend = child.has_initiative = child.fully_expanded = child.pad = 0;
-								sh.frames[level + 1] = child;
+								frame_set(sh, level + 1, child);
 								level++;
 								phase = 0;
 								// SharedHashTable::prefetch (AlphaBetaSearch.cpp:273): fetch the child's bucket now, it is consumed
 								// when the child frame is entered after the stone has been placed
-								if (lane < 8)
+								if (sh.ov_on)
+								{
+									const uint32_t bucket = static_cast<uint32_t>(hash_lo & E.tt_bucket_mask);
+									const int slot = ov_find(sh, bucket, lane);
+									if (lane < 16)
+										pf_word = (slot >= 0) ? sh.ov_data[slot * 16 + 8 + (lane & 7)] : tt[8 * static_cast<u64>(bucket) + (lane & 7)];
+									sh.pf_slot = slot;
+								}
+								else if (lane < 8)
 									pf_word = tt[8 * (hash_lo & E.tt_bucket_mask) + lane];
 								sh.pf_lo = hash_lo;
 								sh.pf_valid = 1;
@@ -2056,7 +2233,7 @@ namespace agx
 						best = solver_evaluate(sh);
 					if (level > 0)
 					{ // the stone of the parent's move comes off next: its pattern entries travel while the table is updated
-						const uint32_t umv = sh.frames[level - 1].move;
+						const uint32_t umv = frame_get(sh, level - 1).move;
 						pf_pattern = pattern_prefetch(sh, E, n, umv, false, lane);
 						pf_pattern_tag = static_cast<int>(umv);
 					}
@@ -2065,7 +2242,18 @@ namespace agx
 						bound = 2;
 					else
 						bound = (best >= f.beta) ? 1 : 3;
-					tt_insert(tt, E.tt_bucket_mask, hash_lo, hash_hi, tt_pack(bound, f.depth_remaining, best, f.best_move), generation);
+					if (sh.ov_on)
+					{ // the node's bucket is in the overlay since the frame was entered: update the task's version of it
+						if (error != ERR_OVERLAY)
+						{
+							const int slot = static_cast<int>(f.ov_slot);
+							tt_insert(sh.ov_data + slot * 16 + 8, 0ull, hash_lo, hash_hi, tt_pack(bound, f.depth_remaining, best, f.best_move), generation);
+							if (lane == 0)
+								sh.ov_dirty[slot >> 5] |= 1u << (slot & 31);
+						}
+					}
+					else
+						tt_insert(tt, E.tt_bucket_mask, hash_lo, hash_hi, tt_pack(bound, f.depth_remaining, best, f.best_move), generation);
 					value = best;
 					returning = true;
 #ifdef AGX_SOLVER_PROFILE
@@ -2083,7 +2271,7 @@ namespace agx
 					stack_offset -= f.size; // ~ActionList (ActionList.hpp:344-347)
 					level--;
 					phase = 1;
-					return yield(CMD_UNDO, sh.frames[level].move);
+					return yield(CMD_UNDO, frame_get(sh, level).move);
 				}
 			}
 		}

@@ -228,10 +228,26 @@ namespace
 	}
 
 	/* ------------------------------------------------------------------------------------------------------------ */
-	template<bool RENJU>
-	__device__ __forceinline__ void solve_task(SolverShared &sh, const EngineDev &E, int g, DTask &t, int slot, int generation, int lane, unsigned long long &solver_nodes)
+	/* Where a solve keeps what does not fit into LDS: `area` indexes the per-game spill areas (the game itself, or for speculative solves —
+	 * several tasks of one game at once — the wave's own area behind the games'); `overlay` != nullptr makes the solve speculative
+	 * (dev_solver.hpp: the table is only read, every touched bucket lives in the overlay). */
+	template<bool RENJU, class SH>
+	__device__ __forceinline__ void solve_task(SH &sh, const EngineDev &E, int g, DTask &t, int slot, int generation, int lane, unsigned long long &solver_nodes,
+			int area, u64 *overlay = nullptr)
 	{ // AlphaBetaSearch::solve (AlphaBetaSearch.cpp:77-156)
-		uint32_t *act = E.act + static_cast<size_t>(g) * E.act_cap;
+		uint32_t *act = E.act + static_cast<size_t>(area) * E.act_cap;
+		if (lane == 0)
+		{ // HBM tails of the LDS-resident threat lists and frames (dev_solver.hpp: list_get / frame_get)
+			sh.spill_lists = E.list_spill + static_cast<size_t>(area) * 20 * E.hw;
+			sh.spill_frames = reinterpret_cast<Frame*>(E.frame_spill) + static_cast<size_t>(area) * MAX_FRAMES;
+			sh.ov_on = (overlay != nullptr) ? 1 : 0;
+			sh.ov_data = overlay;
+			sh.ov_count = 0;
+			sh.ov_overflow = 0;
+			sh.pf_slot = -1;
+		}
+		if (lane < OV_CAP / 32)
+			sh.ov_dirty[lane] = 0;
 		u64 *tt = E.tt + static_cast<size_t>(g) * (E.tt_bucket_mask + 1ull) * 8ull;
 #ifdef AGX_SOLVER_PROFILE
 		unsigned long long c0 = wall_clock64(), c_run = 0, c_place = 0, n_place = 0;
@@ -360,7 +376,7 @@ namespace
 			if (sh.node_counter <= 1)
 				t.flags |= TF_STATICALLY_SOLVED;
 			t.flags |= TF_BY_SOLVER;
-			if (sh.error != 0)
+			if (sh.error != 0 && sh.error != ERR_OVERLAY)
 				E.games[g].error = sh.error;
 		}
 		solver_nodes += static_cast<unsigned long long>(sh.node_counter);
@@ -383,92 +399,13 @@ namespace
 		wave_sync();
 	}
 
-	/* NFIX: board size known at compile time (15, 20) or 0 for any size.  The solver divides and takes remainders by the board size
-	 * all the time (cell <-> row, column); with a constant these are a multiply and a shift instead of ~40 instructions each. */
-	/* FUSED: Search::select of the game runs in the same wave right before its solver (self-play and match pools; a tournament-search pool
-	 * selects for all threads in one wave, k_select).  As two launches the select stage lasts as long as its slowest game (deep end-game
-	 * paths, leak retries: measured 2.4 x the mean wave) while the other SIMDs idle; fused, a slow descent only delays its own game's solver
-	 * and the launch ends with the yield rule as before.  The select stage's LDS (board, keys) aliases the threat lists, which the solver
-	 * initialises afterwards. */
-	template<bool RENJU, int NFIX, bool FUSED>
-	__global__ __launch_bounds__(64) void k_solve(EngineDev E)
+	/* Search::scheduleToNN (Search.cpp:184-199) for one game whose whole batch has been solved: input symmetries, the device-side queue of
+	 * positions for the network.  Returns the number of positions scheduled. */
+	template<class SH>
+	__device__ __forceinline__ unsigned long long schedule_to_nn(SH &sh, const EngineDev &E, int g, GameState &gs, int n_tasks, int lane)
 	{
-		if (NFIX != 0)
-		{
-			E.n = NFIX;
-			E.hw = NFIX * NFIX;
-		}
-		__shared__ SolverShared sh;
-		const int g = E.g0 + blockIdx.x, lane = threadIdx.x;
-		if (FUSED)
-		{
-			static_assert(offsetof(SolverShared, lists) % 8 == 0, "select-stage keys alias the threat lists as 64-bit words");
-			static_assert(sizeof(sh.lists) >= (3 * (1 + MAXHW) + BWORDS) * sizeof(u64) + MAXHW, "select-stage LDS must fit into the threat lists");
-			const GameState &sg = E.games[g];
-			if (sg.active && sg.error == 0 && sg.outcome == 0 && !sg.grow_pending)
-			{
-				use_game_arenas(E, g);
-				u64 *sel_keys = reinterpret_cast<u64*>(&sh.lists[0][0][0]);
-				u64 *sel_cboard = sel_keys + 3 * (1 + MAXHW);
-				uint8_t *sel_board = reinterpret_cast<uint8_t*>(sel_cboard + BWORDS);
-				for (int i = lane; i < 3 * (1 + E.hw); i += 64)
-					sel_keys[i] = E.nc_keys[i];
-				if (!sg.solve_pending)
-					select_batch(E, g, g, lane, sel_board, sel_cboard, sel_keys);
-			}
-			__threadfence(); // the tasks written by the select stage are read back below (other lanes, vector L1)
-			__syncthreads();
-		}
-		GameState &gs = E.games[g];
-		const bool idle = (!gs.active || gs.error != 0 || gs.outcome != 0 || E.games[E.shared_tree ? 0 : g].grow_pending != 0);
-		const int n_tasks = idle ? 0 : gs.n_tasks;
-		if (n_tasks > 0)
-			solver_load_threat_table(sh, E, lane);
-		unsigned long long solver_nodes = 0, scheduled = 0;
-		/*
-		 * The tasks of a game are solved strictly in order (they share the game's transposition table), so a launch lasts as long as
-		 * its slowest game.  To keep the other CUs from idling behind stragglers a game may YIELD between two tasks once
-		 * yield_fraction of the launch's games have finished: it keeps its position in the batch, sits out this step's network /
-		 * expand stages and resumes in the next launch.  Each game still sees exactly the same sequence of operations.
-		 */
-		// (match mode: about half of a group's trees wait for their opponents and count as done at once)
-		const float fraction = E.match_mode ? 0.5f + 0.5f * E.yield_fraction : E.yield_fraction;
-		const int threshold = (E.yield_fraction > 0.0f) ? static_cast<int>(fraction * gridDim.x) : 0x7FFFFFFF;
-		int k = idle ? 0 : gs.solve_pos;
-		bool yielded = false;
-		for (; k < n_tasks; k++)
-		{
-			DTask &t = E.tasks[static_cast<size_t>(g) * E.batch + k];
-			const int slot = g * E.batch + k;
-			if ((t.flags & TF_BY_SOLVER) == 0)
-			{
-				if (threshold != 0x7FFFFFFF && k > gs.solve_pos)
-				{ // at least one task per launch is always solved, so every game makes progress
-					int done = 0;
-					if (lane == 0)
-						done = __hip_atomic_load(&E.counters[E.yield_counter], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-					done = __builtin_amdgcn_readfirstlane(done);
-					if (done >= threshold)
-					{
-						yielded = true;
-						break;
-					}
-				}
-				solve_task<RENJU>(sh, E, g, t, slot, gs.generation, lane, solver_nodes);
-			}
-		}
-		if (yielded)
-		{
-			if (lane == 0)
-			{
-				gs.solve_pos = k;
-				gs.solve_pending = 1;
-				gs.stats[5] += solver_nodes;
-			}
-			return;
-		}
-		// Search::scheduleToNN (Search.cpp:184-199), once the whole batch has been solved
-		int queued = idle ? 0 : gs.nn_queued;
+		unsigned long long scheduled = 0;
+		int queued = gs.nn_queued;
 		for (int j = 0; j < n_tasks; j++)
 		{
 			DTask &t = E.tasks[static_cast<size_t>(g) * E.batch + j];
@@ -511,16 +448,433 @@ namespace
 				queued++;
 		}
 		if (lane == 0)
+			gs.nn_queued = queued;
+		return scheduled;
+	}
+
+	/* NFIX: board size known at compile time (15, 20) or 0 for any size.  The solver divides and takes remainders by the board size
+	 * all the time (cell <-> row, column); with a constant these are a multiply and a shift instead of ~40 instructions each. */
+	/* FUSED: Search::select of the game runs in the same wave right before its solver (self-play and match pools; a tournament-search pool
+	 * selects for all threads in one wave, k_select).  As two launches the select stage lasts as long as its slowest game (deep end-game
+	 * paths, leak retries: measured 2.4 x the mean wave) while the other SIMDs idle; fused, a slow descent only delays its own game's solver
+	 * and the launch ends with the yield rule as before.  The select stage's LDS (board, keys) aliases the threat lists, which the solver
+	 * initialises afterwards. */
+#ifndef AGX_SOLVE_WAVES
+#define AGX_SOLVE_WAVES 2 /* solver waves per SIMD the register allocation must leave room for (the LDS footprint allows 2 at 15x15) */
+#endif
+	template<bool RENJU, int NFIX, bool FUSED>
+	__global__ __launch_bounds__(64, AGX_SOLVE_WAVES) void k_solve(EngineDev E)
+	{
+		if (NFIX != 0)
+		{
+			E.n = NFIX;
+			E.hw = NFIX * NFIX;
+		}
+		typedef SolverSharedT<(NFIX != 0) ? NFIX : MAXN> SH;
+		__shared__ SH sh;
+		const int g = E.g0 + blockIdx.x, lane = threadIdx.x;
+		if (FUSED)
+		{
+			static_assert(offsetof(SH, act) % 8 == 0 && offsetof(SH, frames) == offsetof(SH, act) + sizeof(sh.act), "select-stage keys: 64-bit words over act + frames");
+			static_assert(sizeof(sh.act) + sizeof(sh.frames) >= SH::SELECT_KEY_BYTES && sizeof(sh.lines) >= BWORDS * sizeof(u64), "select-stage LDS must fit");
+			const GameState &sg = E.games[g];
+			if (sg.active && sg.error == 0 && sg.outcome == 0 && !sg.grow_pending)
+			{
+				use_game_arenas(E, g);
+				u64 *sel_keys = reinterpret_cast<u64*>(&sh.act[0]);
+				u64 *sel_cboard = &sh.lines[0];
+				uint8_t *sel_board = &sh.board[0];
+				for (int i = lane; i < 3 * (1 + E.hw); i += 64)
+					sel_keys[i] = E.nc_keys[i];
+				if (!sg.solve_pending)
+					select_batch(E, g, g, lane, sel_board, sel_cboard, sel_keys);
+			}
+			__threadfence(); // the tasks written by the select stage are read back below (other lanes, vector L1)
+			__syncthreads();
+		}
+		GameState &gs = E.games[g];
+		const bool idle = (!gs.active || gs.error != 0 || gs.outcome != 0 || E.games[E.shared_tree ? 0 : g].grow_pending != 0);
+		const int n_tasks = idle ? 0 : gs.n_tasks;
+		if (n_tasks > 0)
+			solver_load_threat_table(sh, E, lane);
+		unsigned long long solver_nodes = 0;
+		/*
+		 * The tasks of a game are solved strictly in order (they share the game's transposition table), so a launch lasts as long as
+		 * its slowest game.  To keep the other CUs from idling behind stragglers a game may YIELD between two tasks once
+		 * yield_fraction of the launch's games have finished: it keeps its position in the batch, sits out this step's network /
+		 * expand stages and resumes in the next launch.  Each game still sees exactly the same sequence of operations.
+		 */
+		// (match mode: about half of a group's trees wait for their opponents and count as done at once)
+		const float fraction = E.match_mode ? 0.5f + 0.5f * E.yield_fraction : E.yield_fraction;
+		const int threshold = (E.yield_fraction > 0.0f) ? static_cast<int>(fraction * gridDim.x) : 0x7FFFFFFF;
+		int k = idle ? 0 : gs.solve_pos;
+		bool yielded = false;
+		for (; k < n_tasks; k++)
+		{
+			DTask &t = E.tasks[static_cast<size_t>(g) * E.batch + k];
+			const int slot = g * E.batch + k;
+			if ((t.flags & TF_BY_SOLVER) == 0)
+			{
+				if (threshold != 0x7FFFFFFF && k > gs.solve_pos)
+				{ // at least one task per launch is always solved, so every game makes progress
+					int done = 0;
+					if (lane == 0)
+						done = __hip_atomic_load(&E.counters[E.yield_counter], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					done = __builtin_amdgcn_readfirstlane(done);
+					if (done >= threshold)
+					{
+						yielded = true;
+						break;
+					}
+				}
+				solve_task<RENJU>(sh, E, g, t, slot, gs.generation, lane, solver_nodes, g);
+			}
+		}
+		if (yielded)
+		{
+			if (lane == 0)
+			{
+				gs.solve_pos = k;
+				gs.solve_pending = 1;
+				gs.stats[5] += solver_nodes;
+			}
+			return;
+		}
+		// Search::scheduleToNN (Search.cpp:184-199), once the whole batch has been solved
+		const unsigned long long scheduled = idle ? 0ull : schedule_to_nn(sh, E, g, gs, n_tasks, lane);
+		if (lane == 0)
 		{
 			if (!idle)
 			{
 				gs.solve_pos = 0;
 				gs.solve_pending = 0;
-				gs.nn_queued = queued;
 				gs.stats[5] += solver_nodes;
 				gs.stats[1] += scheduled;
 			}
 			atomicAdd(&E.counters[E.yield_counter], 1);
+		}
+	}
+
+
+	/* ------------------------------------------------------------------------------------------------------------ */
+	/*
+	 * k_search_spec — Search::select + Search::solve + Search::scheduleToNN of a group of games as ONE launch of persistent waves
+	 * (AgxEngineConfig.speculative_solver).
+	 *
+	 * Why: a game's leaves share its transposition table, so Search::solve (Search.cpp:159-183) handles them one after the other and
+	 * k_solve gives a game one wave — 1024 waves on 1024 SIMDs, each a dependent chain that waits on LDS / L2 about half of the time with
+	 * nobody to fill the gaps.  Measured on MI355X (profiles/r03_solver_occupancy.txt): the same solver code with three waves per SIMD
+	 * delivers 2.6 x the solver nodes per second.  A pool of 1024 games only has that many waves if the ~6.6 leaves of a batch are solved at
+	 * the same time, which is what this kernel does without changing any result:
+	 *   1. every wave first takes games off a cursor and runs their select stage (select_batch, exactly as k_solve<.., FUSED>), then
+	 *      queues one work item per leaf the solver has to look at;
+	 *   2. the waves take items off the queue and solve them against the game's table AS IT WAS BEFORE THE BATCH: the table is only
+	 *      read, every bucket a task touches is copied into the task's overlay (dev_solver.hpp) and modified there;
+	 *   3. the wave that finishes a game's last leaf commits the batch in order: a task whose first-touch bucket copies still equal the
+	 *      table has seen exactly what it would have seen in its turn, so its versions of the buckets it wrote are stored; otherwise (an
+	 *      earlier leaf of the same batch changed a bucket it read: 3-5 % of the leaves) it is solved again right there, serially,
+	 *      on the table itself.  Then the game's positions go to the network queue.
+	 * No wave ever waits for another wave's result (the commit is done by whoever arrives last), the only spinning is on an empty queue
+	 * while other waves are still selecting, and selects are themselves taken off a cursor by resident waves — so the launch cannot
+	 * deadlock whatever the grid size.
+	 */
+	template<class SH>
+	__device__ __forceinline__ void spec_flush(const SH &sh, SpecTask &h, int nodes, uint32_t flags0, int lane)
+	{
+		const int cnt = sh.ov_count;
+		for (int i = lane; i < cnt; i += 64)
+			h.keys[i] = sh.ov_keys[i];
+		if (lane < OV_CAP / 32)
+			h.dirty[lane] = sh.ov_dirty[lane];
+		if (lane == 0)
+		{
+			h.count = cnt;
+			h.overflow = (sh.ov_overflow || sh.error == ERR_OVERLAY) ? 1 : 0;
+			h.nodes = nodes;
+			h.flags0 = flags0;
+			h.solved = 1;
+		}
+	}
+	template<bool RENJU, class SH>
+	__device__ __forceinline__ void spec_commit_game(SH &sh, const EngineDev &E, int g, int area, int lane)
+	{
+		GameState &gs = E.games[g];
+		const int n_tasks = gs.n_tasks;
+		u64 *tt = E.tt + static_cast<size_t>(g) * (E.tt_bucket_mask + 1ull) * 8ull;
+		bool table_changed = false;
+		unsigned long long nodes = 0, solved = 0, reruns = 0;
+		for (int k = 0; k < n_tasks; k++)
+		{
+			const int slot = g * E.batch + k;
+			SpecTask &h = E.spec_tasks[slot];
+			if (h.solved == 0)
+				continue; // a proven edge: the solver never saw this task
+			DTask &t = E.tasks[slot];
+			const u64 *ov = E.spec_overlay + static_cast<size_t>(slot) * (SPEC_OV_CAP * 16);
+			const int cnt = h.count;
+			bool valid = (h.overflow == 0);
+			{ // a header that does not describe an overlay (count or a bucket index out of range) can only mean that the solving wave's stores were
+			  // not visible here: stop the game with an error instead of following a wild index
+				bool bad = (cnt < 0 || cnt > SPEC_OV_CAP);
+				for (int i = lane; !bad && i < cnt; i += 64)
+					bad = static_cast<u64>(h.keys[i]) > E.tt_bucket_mask;
+				if (__ballot(bad) != 0ull)
+				{
+					if (lane == 0)
+					{
+						gs.error = ERR_SPEC_STATE;
+						h.solved = 0;
+					}
+					continue;
+				}
+			}
+			if (valid && table_changed)
+			{ // has any bucket this task looked at changed since the batch began?  Eight lanes per bucket.
+				bool mismatch = false;
+				for (int base = 0; base < cnt; base += 8)
+				{
+					const int p = base + (lane >> 3), w = lane & 7;
+					if (p < cnt)
+						mismatch = mismatch || (ov[p * 16 + w] != tt[8 * static_cast<u64>(h.keys[p]) + w]);
+				}
+				valid = (__ballot(mismatch) == 0ull);
+			}
+			solved++;
+			if (E.spec_debug == 8)
+				continue;
+			if (!valid)
+			{ // Search::solve's own order: this task again, on the table as the earlier tasks of the batch left it
+				if (lane == 0)
+				{
+					t.flags = h.flags0;
+					t.win = 0.0f;
+					t.draw = 0.0f;
+					t.moves_left = 0.0f;
+				}
+				wave_sync();
+				unsigned long long n2 = 0;
+				solve_task<RENJU>(sh, E, g, t, slot, gs.generation, lane, n2, area);
+				nodes += n2;
+				reruns++;
+				table_changed = true;
+			}
+			else
+			{
+				bool any = false;
+				for (int base = 0; base < cnt; base += 8)
+				{
+					const int p = base + (lane >> 3), w = lane & 7;
+					if (p < cnt && ((h.dirty[p >> 5] >> (p & 31)) & 1u))
+					{
+						tt[8 * static_cast<u64>(h.keys[p]) + w] = ov[p * 16 + 8 + w];
+						any = true;
+					}
+				}
+				table_changed = table_changed || (__ballot(any) != 0ull);
+				nodes += static_cast<unsigned long long>(h.nodes);
+			}
+			if (lane == 0)
+				h.solved = 0;
+			wave_sync();
+		}
+		if (E.spec_debug == 7)
+			return;
+		const unsigned long long scheduled = schedule_to_nn(sh, E, g, gs, n_tasks, lane);
+		if (lane == 0)
+		{
+			gs.stats[5] += nodes;
+			gs.stats[1] += scheduled;
+			gs.spec_stats[0] += solved;
+			gs.spec_stats[1] += reruns;
+#ifdef AGX_SPEC_PROFILE
+			E.spec_trace[4 * g + 3] = reruns * 16 + solved;
+#endif
+		}
+	}
+
+#ifdef AGX_SPEC_PROFILE /* developer builds: where the waves of k_search_spec spend their time (100 MHz wall clock ticks, summed over waves) */
+#define SPEC_T(var) const unsigned long long var = wall_clock64()
+#define SPEC_ADD(k, v) do { if (lane == 0) atomicAdd(&E.spec_prof[k], static_cast<unsigned long long>(v)); } while (0)
+#define SPEC_MAX(k, v) do { if (lane == 0) atomicMax(&E.spec_prof[k], static_cast<unsigned long long>(v)); } while (0)
+#else
+#define SPEC_T(var) do { } while (0)
+#define SPEC_ADD(k, v) do { } while (0)
+#define SPEC_MAX(k, v) do { } while (0)
+#endif
+#ifndef AGX_SPEC_WAVES
+#define AGX_SPEC_WAVES 3 /* waves per SIMD the register allocation of k_search_spec leaves room for (LDS: 12 waves per compute unit at 15x15) */
+#endif
+	template<bool RENJU, int NFIX>
+	__global__ __launch_bounds__(64, AGX_SPEC_WAVES) void k_search_spec(EngineDev E, int count)
+	{
+		if (NFIX != 0)
+		{
+			E.n = NFIX;
+			E.hw = NFIX * NFIX;
+		}
+		typedef SolverSharedT<(NFIX != 0) ? NFIX : MAXN> SH;
+		__shared__ SH sh;
+		const int lane = threadIdx.x;
+		int *const c_select = E.counters + SPEC_COUNTER0 + 4 * E.spec_group, *const c_head = c_select + 1, *const c_tail = c_select + 2, *const c_selected = c_select + 3;
+		int *const items = E.spec_items + static_cast<size_t>(E.g0) * E.batch + static_cast<size_t>(E.spec_group) * SPEC_QUEUE_SLACK;
+		const int item_cap = count * E.batch + SPEC_QUEUE_SLACK;
+		const int area = E.n_games + E.spec_group * E.spec_waves + blockIdx.x; // this wave's spill areas (action stack, list / frame tails)
+
+		/* ---- 1. select: games off a cursor ---- */
+		static_assert(offsetof(SH, act) % 8 == 0 && offsetof(SH, frames) == offsetof(SH, act) + sizeof(sh.act), "select-stage keys: 64-bit words over act + frames");
+		static_assert(sizeof(sh.act) + sizeof(sh.frames) >= SH::SELECT_KEY_BYTES && sizeof(sh.lines) >= BWORDS * sizeof(u64), "select-stage LDS must fit");
+		u64 *sel_keys = reinterpret_cast<u64*>(&sh.act[0]);
+		bool keys_loaded = false;
+		SPEC_T(t_begin);
+		while (true)
+		{
+			int s = 0;
+			if (lane == 0)
+				s = atomicAdd(c_select, 1);
+			s = __builtin_amdgcn_readfirstlane(s);
+			if (s >= count)
+				break;
+			const int g = E.g0 + s;
+			GameState &gs = E.games[g];
+			const bool idle = (!gs.active || gs.error != 0 || gs.outcome != 0 || gs.grow_pending != 0);
+			if (!idle)
+			{
+				if (!keys_loaded)
+				{
+					for (int i = lane; i < 3 * (1 + E.hw); i += 64)
+						sel_keys[i] = E.nc_keys[i];
+					keys_loaded = true;
+				}
+				use_game_arenas(E, g);
+				select_batch(E, g, g, lane, &sh.board[0], &sh.lines[0], sel_keys);
+				__threadfence(); // the tasks are read by other waves
+				__syncthreads();
+				const int n_tasks = gs.n_tasks;
+				int n_items = 0;
+				for (int k = 0; k < n_tasks; k++)
+					if ((E.tasks[static_cast<size_t>(g) * E.batch + k].flags & TF_BY_SOLVER) == 0)
+						n_items++;
+				if (n_items == 0)
+				{ // nothing for the solver (proven edges only): the batch goes to the network queue at once
+					const unsigned long long scheduled = schedule_to_nn(sh, E, g, gs, n_tasks, lane);
+					if (lane == 0)
+						gs.stats[1] += scheduled;
+					keys_loaded = keys_loaded && !E.use_symmetries; // (symmetric features pass through sh.act, where the keys are)
+				}
+				else
+				{
+					if (lane == 0)
+					{
+						__hip_atomic_store(&E.spec_left[g], n_items, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+						__threadfence();
+						const int base = atomicAdd(c_tail, n_items);
+						int j = 0;
+						for (int k = 0; k < n_tasks; k++)
+							if ((E.tasks[static_cast<size_t>(g) * E.batch + k].flags & TF_BY_SOLVER) == 0)
+								__hip_atomic_store(&items[base + j++], (g * 16 + k) + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+					}
+				}
+			}
+#ifdef AGX_SPEC_PROFILE
+			if (lane == 0)
+			{
+				E.spec_trace[4 * g + 0] = wall_clock64();
+				E.spec_trace[4 * g + 3] = 0;
+			}
+#endif
+			if (lane == 0)
+			{
+				__threadfence();
+				atomicAdd(c_selected, 1);
+			}
+			__syncthreads();
+		}
+		__syncthreads();
+
+		SPEC_T(t_selected);
+		SPEC_ADD(0, t_selected - t_begin); // select phase, all waves (incl. the ones that found the cursor exhausted at once)
+		SPEC_MAX(1, t_selected - t_begin); // the slowest wave's select phase
+		if (E.spec_debug == 1)
+			return;
+		/* ---- 2. + 3. solve the queued leaves, commit a game's batch when its last leaf is done ---- */
+		solver_load_threat_table(sh, E, lane);
+		while (true)
+		{
+			SPEC_T(t_pop);
+			int i = 0;
+			if (lane == 0)
+				i = atomicAdd(c_head, 1);
+			i = __builtin_amdgcn_readfirstlane(i);
+			if (i >= item_cap)
+				return;
+			int v = 0;
+			if (lane == 0)
+			{
+				while (true)
+				{
+					v = __hip_atomic_load(&items[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+					if (v != 0)
+						break;
+					if (__hip_atomic_load(c_selected, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= count)
+					{ // every game has queued its leaves: the queue's length is final
+						if (i >= __hip_atomic_load(c_tail, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT))
+						{
+							v = -1;
+							break;
+						}
+					}
+					else
+						__builtin_amdgcn_s_sleep(16);
+				}
+				if (v > 0)
+					__hip_atomic_store(&items[i], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // empty again for the next launch
+			}
+			v = __builtin_amdgcn_readfirstlane(v);
+			SPEC_T(t_got);
+			SPEC_ADD(2, t_got - t_pop); // waiting for an item
+			if (v < 0)
+			{
+				SPEC_MAX(7, t_got - t_begin); // the last wave's exit = the launch
+				return;
+			}
+			__threadfence(); // (acquire: the task as its selecting wave wrote it)
+			const int g = (v - 1) >> 4, k = (v - 1) & 15;
+			const int slot = g * E.batch + k;
+			DTask &t = E.tasks[slot];
+			const uint32_t flags0 = t.flags;
+			unsigned long long n1 = 0;
+			if (E.spec_debug == 2)
+				continue;
+			solve_task<RENJU>(sh, E, g, t, slot, E.games[g].generation, lane, n1, area, (E.spec_debug == 3) ? nullptr : E.spec_overlay + static_cast<size_t>(slot) * (SPEC_OV_CAP * 16));
+			if (E.spec_debug == 3 || E.spec_debug == 4)
+				continue;
+			spec_flush(sh, E.spec_tasks[slot], static_cast<int>(n1), flags0, lane);
+			if (E.spec_debug == 5)
+				continue;
+			SPEC_T(t_solved);
+			SPEC_ADD(3, t_solved - t_got); // speculative solves
+			SPEC_ADD(6, 1);
+			__threadfence(); // release: task results, features, overlay and its header
+			int left = 0;
+			if (lane == 0)
+				left = __hip_atomic_fetch_add(&E.spec_left[g], -1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+			left = __builtin_amdgcn_readfirstlane(left);
+			if (left == 1 && E.spec_debug != 6)
+			{ // the last leaf of this game's batch: commit in batch order
+				__threadfence();
+				SPEC_T(t_c0);
+				spec_commit_game<RENJU>(sh, E, g, area, lane);
+				SPEC_T(t_c1);
+#ifdef AGX_SPEC_PROFILE
+				if (lane == 0)
+				{
+					E.spec_trace[4 * g + 1] = t_c0;
+					E.spec_trace[4 * g + 2] = t_c1;
+				}
+#endif
+				SPEC_ADD(4, t_c1 - t_c0); // commits incl. serial re-runs
+				SPEC_MAX(5, t_c1 - t_c0);
+			}
 		}
 	}
 
@@ -2028,6 +2382,11 @@ namespace
 	{
 		__shared__ SolverShared sh;
 		const int g = blockIdx.x, lane = threadIdx.x;
+		if (lane == 0)
+		{
+			sh.spill_lists = E.list_spill + static_cast<size_t>(g) * 20 * E.hw;
+			sh.spill_frames = reinterpret_cast<Frame*>(E.frame_spill) + static_cast<size_t>(g) * MAX_FRAMES;
+		}
 		solver_load_threat_table(sh, E, lane);
 		solver_set_board(sh, E, boards + static_cast<size_t>(g) * E.hw, signs[g], lane);
 		__shared__ uint16_t done[512];
@@ -2070,10 +2429,21 @@ namespace
 				for (int t = 0; t < 10; t++)
 				{
 					out[pos++] = static_cast<int16_t>(sh.count[s][t]);
+					if (t == 1)
+					{ // HALF_OPEN_3: only the size is kept on the device; the cells are listed in row-major order (the caller compares them as a set)
+						for (int cell = 0; cell < E.hw; cell++)
+							if (sh.threat[cell][s] == 1)
+							{
+								out[pos++] = static_cast<int16_t>(cell / E.n);
+								out[pos++] = static_cast<int16_t>(cell % E.n);
+							}
+						continue;
+					}
 					for (int k = 0; k < sh.count[s][t]; k++)
 					{
-						out[pos++] = static_cast<int16_t>(sh.lists[s][t][k] / E.n);
-						out[pos++] = static_cast<int16_t>(sh.lists[s][t][k] % E.n);
+						const int cell = (t == 0) ? 0 : static_cast<int>(list_get(sh, s, t, k));
+						out[pos++] = static_cast<int16_t>(cell / E.n);
+						out[pos++] = static_cast<int16_t>(cell % E.n);
 					}
 				}
 			out[lists_stride - 1] = static_cast<int16_t>(pos);
@@ -2094,6 +2464,9 @@ struct AgxEngine
 		// Search::select and the threat solver of a game in one launch (k_solve<.., FUSED>); AGX_FUSE_SELECT=0 keeps them as two launches
 		// (separate k_select / k_solve times in agx_engine_kernel_timing and in profiles)
 		bool fuse_select = true;
+		// AgxEngineConfig.speculative_solver: select + solver as one persistent launch with the leaves of a batch solved in parallel (k_search_spec)
+		bool speculative = false;
+		int spec_waves = 0; // waves of that launch over the whole pool
 		// optional per-kernel timing (agx_engine_kernel_timing): HIP events on the launch stream around every kernel of a step
 		bool timing = false;
 		std::vector<hipEvent_t> events;   // groups of (before, after) per kernel launch
@@ -2220,6 +2593,8 @@ int agx_engine_default_config(AgxEngineConfig *cfg)
 	cfg->record_format = 1;
 	cfg->record_sample_capacity = 0;
 	cfg->game_end_capacity = 0;
+	cfg->speculative_solver = 0;
+	cfg->speculative_waves = 0;
 	cfg->noise_type = 0;
 	cfg->noise_weight = 0.0f;
 	cfg->noise_seed = 0x2545F4914F6CDD1Dull;
@@ -2314,11 +2689,41 @@ int agx_engine_create(const AgxEngineConfig *cfg, AgxEngine **out)
 	AGX_TRY(dev_alloc(e, &d.heap, 1));
 	AGX_TRY(dev_alloc(e, &d.free_bundles, static_cast<size_t>(ARENA_CLASSES) * G));
 	AGX_TRY(dev_alloc(e, &d.tasks, G * d.batch));
-	AGX_TRY(dev_alloc(e, &d.act, G * d.act_cap));
+	// speculative solver: its waves solve several leaves of one game at once, so each wave brings its own spill areas (behind the games')
+	e->speculative = cfg->speculative_solver != 0 && cfg->search_threads <= 1 && cfg->tss_max_positions <= 250 && cfg->max_batch_size <= 16;
+	if (e->speculative)
+	{
+		int cus = 0, device_of_engine = 0;
+		(void) hipGetDevice(&device_of_engine);
+		(void) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_of_engine);
+		e->spec_waves = (cfg->speculative_waves > 0) ? cfg->speculative_waves : 12 * std::max(1, cus);
+		e->spec_waves = std::min(e->spec_waves, SPEC_QUEUE_SLACK);
+	}
+	const size_t areas = G + static_cast<size_t>(e->spec_waves);
+	AGX_TRY(dev_alloc(e, &d.act, areas * d.act_cap));
+	AGX_TRY(dev_alloc(e, &d.list_spill, areas * 20 * static_cast<size_t>(d.hw)));
+	AGX_TRY(dev_alloc(e, &d.frame_spill, areas * MAX_FRAMES));
+	d.spec_group = 0;
+	d.spec_waves = e->spec_waves;
+	d.spec_debug = getenv("AGX_SPEC_DEBUG") ? atoi(getenv("AGX_SPEC_DEBUG")) : 0;
+	AGX_TRY(dev_alloc(e, &d.spec_prof, 16));
+	AGX_TRY(dev_alloc(e, &d.spec_trace, 4 * G));
+	(void) hipMemset(d.spec_trace, 0, 4 * G * sizeof(unsigned long long));
+	(void) hipMemset(d.spec_prof, 0, 16 * sizeof(unsigned long long));
+	AGX_TRY(dev_alloc(e, &d.spec_items, e->speculative ? G * d.batch + 16 * static_cast<size_t>(SPEC_QUEUE_SLACK) : 1));
+	AGX_TRY(dev_alloc(e, &d.spec_left, e->speculative ? G : 1));
+	AGX_TRY(dev_alloc(e, &d.spec_tasks, e->speculative ? G * d.batch : 1));
+	AGX_TRY(dev_alloc(e, &d.spec_overlay, e->speculative ? G * d.batch * (SPEC_OV_CAP * 16) : 1));
 	AGX_TRY(dev_alloc(e, &d.tt, G * buckets * 8));
 	AGX_TRY(dev_upload(e, &d.t_pattern, tables.pattern));
 	AGX_TRY(dev_upload(e, &d.t_ho3, tables.half_open_three));
 	AGX_TRY(dev_upload(e, &d.t_threat, tables.threat));
+	{ // the solver's form of the same table: cross type | circle type << 4 in one byte (dev_solver.hpp:threat_lookup)
+		std::vector<uint8_t> packed(4096);
+		for (int i = 0; i < 4096; i++)
+			packed[i] = static_cast<uint8_t>((tables.threat[2 * i] & 15u) | ((tables.threat[2 * i + 1] & 15u) << 4));
+		AGX_TRY(dev_upload(e, &d.t_threat_packed, packed));
+	}
 	AGX_TRY(dev_upload(e, &d.t_defense, tables.defense));
 	AGX_TRY(dev_upload(e, &d.nc_keys, nc_keys));
 	AGX_TRY(dev_upload(e, &d.zob, e->zobrist));
@@ -2332,7 +2737,7 @@ int agx_engine_create(const AgxEngineConfig *cfg, AgxEngine **out)
 	AGX_TRY(dev_alloc(e, &d.nn_q, d.has_q ? G * d.batch * d.hw * 2 : 1));
 	AGX_TRY(dev_alloc(e, &d.noise, d.noise_type ? G * d.hw : 1));
 	AGX_TRY(dev_alloc(e, &d.nn_list, G * d.batch));
-	AGX_TRY(dev_alloc(e, &d.counters, 64));
+	AGX_TRY(dev_alloc(e, &d.counters, N_COUNTERS));
 	AGX_TRY(dev_alloc(e, &d.records, static_cast<size_t>(d.record_cap)));
 	AGX_TRY(dev_alloc(e, &d.record_edges, (d.record_format & 1) ? static_cast<size_t>(d.record_edge_cap) : 1));
 	AGX_TRY(dev_alloc(e, &d.samples, (d.record_format & 2) ? static_cast<size_t>(d.sample_cap) : 4));
@@ -2368,9 +2773,15 @@ int agx_engine_create(const AgxEngineConfig *cfg, AgxEngine **out)
 		if (err == hipSuccess)
 			err = hipMemcpy(d.heap, &heap, sizeof(heap), hipMemcpyHostToDevice);
 		if (err == hipSuccess)
-			err = hipMemset(d.counters, 0, 64 * sizeof(int));
+			err = hipMemset(d.counters, 0, N_COUNTERS * sizeof(int));
 		if (err == hipSuccess)
 			err = hipMemset(d.tasks, 0, G * d.batch * sizeof(DTask));
+		if (err == hipSuccess && e->speculative)
+			err = hipMemset(d.spec_items, 0, (G * d.batch + 16 * static_cast<size_t>(SPEC_QUEUE_SLACK)) * sizeof(int));
+		if (err == hipSuccess && e->speculative)
+			err = hipMemset(d.spec_tasks, 0, G * d.batch * sizeof(SpecTask));
+		if (err == hipSuccess && e->speculative)
+			err = hipMemset(d.spec_left, 0, G * sizeof(int));
 		if (err != hipSuccess)
 		{
 			agx::set_error("hipMemset failed: %s", hipGetErrorString(err));
@@ -2412,7 +2823,7 @@ int agx_engine_begin(AgxEngine *e, const uint16_t *h_openings, int n_openings, v
 	AGX_HIP_CHECK(hipMemcpy(d_op, h_openings, static_cast<size_t>(n_openings) * OPENING_CAP * sizeof(uint16_t), hipMemcpyHostToDevice));
 	e->dev.openings = d_op;
 	e->dev.n_openings = n_openings;
-	int counters[64] = { 0 };
+	int counters[N_COUNTERS] = { 0 };
 	counters[1] = e->dev.match_mode ? 0 : (e->dev.shared_tree ? 1 : e->dev.n_games);
 	AGX_HIP_CHECK(hipMemcpy(e->dev.counters, counters, sizeof(counters), hipMemcpyHostToDevice));
 	hipStream_t s = static_cast<hipStream_t>(stream);
@@ -2470,6 +2881,9 @@ static int group_range(const AgxEngine *e, int group, int n_groups, EngineDev &d
 
 static constexpr int CLEAR_PARTS = 16; // workgroups per restarting game in k_clear_tables
 
+#ifdef AGX_QUICK /* developer builds: only the 15x15 non-renju solver is instantiated (a fifth of the compile time) */
+#define AGX_LAUNCH_SOLVE(FUSED) hipLaunchKernelGGL((k_solve<false, 15, FUSED>), grid, block, 0, s, d)
+#else
 #define AGX_LAUNCH_SOLVE(FUSED) \
 	do { \
 		if (d.rules == AGX_RENJU) \
@@ -2486,6 +2900,39 @@ static constexpr int CLEAR_PARTS = 16; // workgroups per restarting game in k_cl
 		else \
 			hipLaunchKernelGGL((k_solve<false, 0, FUSED>), grid, block, 0, s, d); \
 	} while (0)
+#endif
+__global__ void k_reset_spec(int *nn_counter, int *nn_second, int *spec_counters)
+{
+	*nn_counter = 0;
+	if (nn_second != nullptr)
+		*nn_second = 0;
+	for (int i = 0; i < 4; i++)
+		spec_counters[i] = 0;
+}
+/* select + speculative solve + scheduleToNN of `count` games from d.g0 as one persistent launch of `waves` waves (k_search_spec) */
+static void launch_search_spec(EngineDev d, int count, int group, int waves, hipStream_t s)
+{
+	d.spec_group = group;
+	d.spec_waves = waves;
+	const dim3 grid(waves), block(64);
+#ifdef AGX_QUICK
+	hipLaunchKernelGGL((k_search_spec<false, 15>), grid, block, 0, s, d, count);
+#else
+	if (d.rules == AGX_RENJU)
+	{
+		if (d.n == 15)
+			hipLaunchKernelGGL((k_search_spec<true, 15>), grid, block, 0, s, d, count);
+		else
+			hipLaunchKernelGGL((k_search_spec<true, 0>), grid, block, 0, s, d, count);
+	}
+	else if (d.n == 15)
+		hipLaunchKernelGGL((k_search_spec<false, 15>), grid, block, 0, s, d, count);
+	else if (d.n == 20)
+		hipLaunchKernelGGL((k_search_spec<false, 20>), grid, block, 0, s, d, count);
+	else
+		hipLaunchKernelGGL((k_search_spec<false, 0>), grid, block, 0, s, d, count);
+#endif
+}
 static void launch_solve(const EngineDev &d, int count, hipStream_t s, bool with_select = false)
 {
 	const dim3 grid(count), block(64);
@@ -2535,6 +2982,22 @@ int agx_engine_solve_group(AgxEngine *e, int group, int n_groups, void *stream)
 }
 int agx_engine_select_solve_group(AgxEngine *e, int group, int n_groups, void *stream)
 {
+	if (e != nullptr && e->begun && e->speculative)
+	{ // one persistent launch: games select off a cursor, their leaves are solved in parallel against overlays, committed in batch order
+		EngineDev d;
+		int count = 0;
+		const int st = group_range(e, group, n_groups, d, count);
+		if (st != AGX_OK)
+			return st;
+		hipStream_t s = static_cast<hipStream_t>(stream);
+		hipLaunchKernelGGL(k_reset_spec, dim3(1), dim3(1), 0, s, d.counters + d.nn_counter, static_cast<int*>(nullptr), d.counters + SPEC_COUNTER0 + 4 * group);
+		{
+			KernelTimer t(e, s, 1);
+			launch_search_spec(d, count, group, std::max(1, e->spec_waves / n_groups), s);
+		}
+		AGX_HIP_CHECK(hipGetLastError());
+		return AGX_OK;
+	}
 	if (e != nullptr && e->begun && e->fuse_select && !e->dev.shared_tree)
 	{ // one launch: every game selects and solves in its own wave (k_solve<.., FUSED>); timed as the solve stage
 		EngineDev d;
@@ -2578,7 +3041,13 @@ int agx_engine_select_solve_match(AgxEngine *e, void *stream)
 	hipStream_t s = static_cast<hipStream_t>(stream);
 	hipLaunchKernelGGL(k_reset_counter, dim3(1), dim3(1), 0, s, d.counters + 16, d.counters + 32);
 	hipLaunchKernelGGL(k_reset_counter, dim3(1), dim3(1), 0, s, d.counters + 17, static_cast<int*>(nullptr));
-	if (e->fuse_select)
+	if (e->speculative)
+	{
+		hipLaunchKernelGGL(k_reset_spec, dim3(1), dim3(1), 0, s, d.counters + 16, d.counters + 17, d.counters + SPEC_COUNTER0);
+		KernelTimer t(e, s, 1);
+		launch_search_spec(d, d.n_games, 0, e->spec_waves, s);
+	}
+	else if (e->fuse_select)
 	{
 		KernelTimer t(e, s, 1);
 		launch_solve(d, d.n_games, s, true);
@@ -2802,12 +3271,35 @@ int agx_engine_stats(AgxEngine *e, AgxEngineStats *out)
 		out->select_edge_reads += g.stats[7];
 		out->moves_played += g.stats[8];
 		out->duplicate_selections += g.stats[9];
+		out->speculative_solves += g.spec_stats[0];
+		out->speculative_reruns += g.spec_stats[1];
 		out->peak_nodes = std::max<unsigned long long>(out->peak_nodes, g.stats[10]);
 		out->peak_edges = std::max<unsigned long long>(out->peak_edges, g.stats[11]);
 		out->active_games += g.active ? 1 : 0;
 		if (g.error != 0 && out->first_error == 0)
 			out->first_error = g.error;
 	}
+#ifdef AGX_SPEC_PROFILE
+	if (getenv("AGX_SPEC_TRACE"))
+	{ // per game of the LAST launch: select done, commit begin, commit end (100 MHz ticks), re-runs * 16 + leaves
+		std::vector<unsigned long long> tr(4 * games.size());
+		AGX_HIP_CHECK(hipMemcpy(tr.data(), e->dev.spec_trace, tr.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+		FILE *f = fopen(getenv("AGX_SPEC_TRACE"), "w");
+		if (f != nullptr)
+		{
+			for (size_t g = 0; g < games.size(); g++)
+				fprintf(f, "%llu %llu %llu %llu\n", tr[4 * g], tr[4 * g + 1], tr[4 * g + 2], tr[4 * g + 3]);
+			fclose(f);
+		}
+	}
+	{
+		unsigned long long p[16];
+		AGX_HIP_CHECK(hipMemcpy(p, e->dev.spec_prof, sizeof(p), hipMemcpyDeviceToHost));
+		fprintf(stderr, "[k_search_spec profile, wave-ms summed] select phase %.1f (slowest wave, max over launches %.3f ms), waiting for items %.1f, speculative solves %.1f (%llu, %.1f us each), "
+				"commits + re-runs %.1f (longest %.3f ms), longest launch %.3f ms\n", p[0] / 1e5, p[1] / 1e5, p[2] / 1e5, p[3] / 1e5, p[6], p[3] / 1e2 / (p[6] ? p[6] : 1), p[4] / 1e5, p[5] / 1e5,
+				p[7] / 1e5);
+	}
+#endif
 #ifdef AGX_SOLVER_PROFILE
 	{
 		unsigned long long p[10] = { 0 };

@@ -23,6 +23,8 @@ namespace agx
 	constexpr int MAX_FRAMES = 104; // alpha-beta recursion depth is bounded by the iterative-deepening limit (100 plies) + root
 	constexpr int OPENING_CAP = 32;
 
+	struct alignas(16) FrameBytes { uint32_t w[8]; }; // storage of one dev::Frame (dev_solver.hpp)
+
 	struct DEdge
 	{
 			float prior;
@@ -119,6 +121,7 @@ namespace agx
 			uint64_t cboard[BWORDS];
 			unsigned long long prof[8];   // optional cycle counters (AGX_SOLVER_PROFILE builds only)
 			unsigned long long dprof[24]; // finer stage stamps of the same builds (shader cycles)
+			unsigned long long spec_stats[2]; // speculative solver: leaves solved against the pre-batch table, of which re-run serially
 			unsigned long long stats[12]; // nodes, nn, leaks, proven, wasted, solver nodes, select levels, select edges, moves, duplicates, max nodes, max edges
 			uint8_t board[MAXHW];
 			uint16_t moves[MAXHW];
@@ -153,6 +156,23 @@ namespace agx
 			uint16_t moves[MAXHW];
 	};
 
+	/* speculative solver (k_search_spec): what a task's solving wave leaves for the wave that commits the game's batch */
+	constexpr int SPEC_OV_CAP = 256;    // overlay slots per task (== dev::OV_CAP)
+	constexpr int SPEC_COUNTER0 = 64;   // counters[SPEC_COUNTER0 + 4 * group + {0 select cursor, 1 item cursor, 2 items queued, 3 games selected}]
+	constexpr int SPEC_QUEUE_SLACK = 8192; // extra queue slots per group: item cursors run past the end by one per wave
+	constexpr int N_COUNTERS = 192;
+	struct SpecTask
+	{
+			int32_t solved;     // 1: solved speculatively in this launch (cleared by the commit)
+			int32_t count;      // overlay slots in use
+			int32_t overflow;   // the overlay was full: the result is void
+			int32_t nodes;      // solver positions of the speculative run
+			uint32_t flags0;    // the task's flags before the solve (a discarded run must not leave its own behind)
+			uint32_t pad[3];
+			uint32_t dirty[SPEC_OV_CAP / 32];
+			uint32_t keys[SPEC_OV_CAP]; // table bucket of every slot
+	};
+
 	constexpr int ARENA_CLASSES = 6; // bundle capacities: class-0 capacity << class, class < ARENA_CLASSES
 
 	/* Bump allocators over the node / edge / table heaps + one free list of bundles per size class (k_arena_service, engine.hip). */
@@ -171,7 +191,8 @@ namespace agx
 
 	enum EngineError : int32_t
 	{
-		ERR_NONE = 0, ERR_NODE_CAPACITY = 1, ERR_EDGE_CAPACITY = 2, ERR_PATH_CAPACITY = 3, ERR_ACTION_STACK = 4, ERR_HASH_TABLE = 5, ERR_RECORDS = 6, ERR_FRAMES = 7
+		ERR_NONE = 0, ERR_NODE_CAPACITY = 1, ERR_EDGE_CAPACITY = 2, ERR_PATH_CAPACITY = 3, ERR_ACTION_STACK = 4, ERR_HASH_TABLE = 5, ERR_RECORDS = 6, ERR_FRAMES = 7, ERR_SPEC_STATE = 8,
+		ERR_OVERLAY = 100 // internal to speculative solves (overlay full): never reported, the task is solved again serially
 	};
 
 	struct EngineDev
@@ -212,11 +233,14 @@ namespace agx
 			ArenaBundle *free_bundles; // [ARENA_CLASSES][heap->free_capacity]
 			DTask *tasks;   // [game][batch]
 			uint32_t *act;  // [game][act_cap] alpha-beta action stack: move | score << 16
+			uint16_t *list_spill;       // [game][2][10][hw] tails of the solver's threat lists beyond their LDS capacity (dev_solver.hpp)
+			FrameBytes *frame_spill;    // [game][MAX_FRAMES] alpha-beta frames (dev::Frame, 32 bytes) beyond the LDS-resident ones
 			uint64_t *tt;   // [game][buckets][4][2]
 			// read-only tables
 			const uint8_t *t_pattern;
 			const uint8_t *t_ho3;
 			const uint8_t *t_threat;
+			const uint8_t *t_threat_packed; // [4096] cross | circle << 4
 			const uint16_t *t_defense;
 			const uint64_t *nc_keys; // node-cache Zobrist keys [3 + 3*hw]
 			const uint64_t *zob;     // solver Zobrist keys [2*hw][2] (lo, hi)
@@ -230,6 +254,16 @@ namespace agx
 			int match_merged; // this launch covers both players' trees: network slot lists by half of the pool, not by launch
 			int match_mode;  // evaluation matches: tree g (first player) and tree g + n_games / 2 (second player) share one game
 			int shared_tree; // tournament search: the n_games records are the search threads of ONE tree (game 0): own task buffer and solver each
+			// speculative solver
+			int spec_group;        // index of this launch's group (its queue segment and counters)
+			unsigned long long *spec_trace; // AGX_SPEC_PROFILE builds: [game][4] time stamps of the last launch
+			unsigned long long *spec_prof; // AGX_SPEC_PROFILE builds: time sums of k_search_spec
+			int spec_debug;        // developer switch: stop the launch after a stage
+			int spec_waves;        // waves of this launch (its spill areas start at area n_games + spec_group * spec_waves)
+			int *spec_items;       // [n_games * batch + 16 * SPEC_QUEUE_SLACK] work queue: (game * 16 + task) + 1, 0 = empty
+			int *spec_left;        // [game] tasks of the batch still being solved
+			SpecTask *spec_tasks;  // [game * batch]
+			uint64_t *spec_overlay; // [game * batch][SPEC_OV_CAP][16]
 			int *nn_list;          // compacted slots to evaluate
 			int *counters;         // [0] (unused), [1] next opening, [2] finished games, [3] records used, [4] record edges used, [5] total moves, [6] sample bytes used, [7] game-end records used, [16 + group] positions scheduled for the network by that group, [32 + group] games of that group done with their solver batch
 			// output records

@@ -40,15 +40,10 @@ def nn_flops_per_position(desc):
 
 
 def source_hash():
-    """sha256 over the sources libagx.so is built from: ties committed PMC summaries to the build they were taken from"""
-    h = hashlib.sha256()
-    csrc = os.path.join(ROOT, "alphagomoku_amd", "csrc")
-    for name in sorted(os.listdir(csrc)):
-        if name.endswith((".hip", ".hpp", ".cpp")):
-            h.update(name.encode())
-            h.update(open(os.path.join(csrc, name), "rb").read())
-    h.update(open(os.path.join(ROOT, "include", "agx.h"), "rb").read())
-    return h.hexdigest()[:16]
+    """sha256 over the sources libagx.so is built from (alphagomoku_amd/build.py): the library reports the hash it was compiled from
+    (agx_build_hash) and committed PMC summaries carry the hash of the build they were taken from"""
+    from alphagomoku_amd import build
+    return build.source_hash()
 
 
 def cpu_baseline(args, max_seconds):
@@ -109,6 +104,9 @@ def main():
     ap.add_argument("--yield-fraction", type=float, default=0.75, help="solver straggler cut-off (0 = lock-step pool)")
     ap.add_argument("--slices", type=int, default=4,
                     help="the pool stepped as this many slices on streams that own disjoint blocks of the chip's compute units (1 = one lock-step pool)")
+    ap.add_argument("--speculative", type=int, default=1,
+                    help="1: select + threat solver as one persistent launch with the leaves of a batch solved in parallel (AgxEngineConfig.speculative_solver)")
+    ap.add_argument("--speculative-waves", type=int, default=0, help="waves of that launch over the whole pool, 0 = 12 per compute unit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=24.0)
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline, 0 = every host CPU")
@@ -137,8 +135,9 @@ def main():
         build.build(verbose=False)
     if dist is not None:
         dist.barrier()
-    from alphagomoku_amd import lib, check, synthetic, selfplay
+    from alphagomoku_amd import lib, check, synthetic, selfplay, _lib
     from alphagomoku_amd.networks import AGNetwork
+    build_hash = _lib.require_current_build()   # refuses a stale prebuilt libagx.so (its compiled-in hash != the sources beside it)
 
     check(lib.agx_set_device(int(os.environ.get("AGX_FORCE_DEVICE", local_rank))))  # AGX_FORCE_DEVICE: test the N > 1 flow on a 1-GPU box
     desc = synthetic.net_desc(rows=args.board, cols=args.board, blocks=args.blocks, filters=args.filters, action_values=args.action_values)
@@ -152,7 +151,7 @@ def main():
     cfg = selfplay.default_config(rules=args.rules, board_size=args.board, n_games=args.games, max_batch_size=args.batch,
                                   max_simulations=args.sims, tss_table_entries=args.table_entries, solver_yield_fraction=args.yield_fraction,
                                   action_values=args.action_values, node_capacity=node_capacity, edge_capacity=edge_capacity, arena_reserve=3.0,
-                                  record_format=2)
+                                  record_format=2, speculative_solver=args.speculative, speculative_waves=args.speculative_waves)
     pool = selfplay.GeneratorPool(cfg)
     # enough openings for every game that can finish during the run; seeds are disjoint across ranks
     n_openings = args.games * 3
@@ -324,6 +323,8 @@ def main():
             # default: Search::select runs inside the solver's launch (one wave per game selects, then solves: k_solve<.., FUSED>), its time is
             # part of k_solve and k_select is 0; AGX_FUSE_SELECT=0 launches them separately
             "select_fused_into_solve": os.environ.get("AGX_FUSE_SELECT", "1") != "0",
+            "speculative_solver": {"enabled": bool(args.speculative), "leaves_solved": int(s1["speculative_solves"] - s0["speculative_solves"]),
+                                   "rerun_serially": int(s1["speculative_reruns"] - s0["speculative_reruns"])},
             "peak_tree_per_game": {"nodes": int(s1["peak_nodes"]), "edges": int(s1["peak_edges"]), "class0_node_capacity": node_capacity,
                                    "class0_edge_capacity": edge_capacity, "arena_grows": int(s1["arena_grows"]), "arena_releases": int(s1["arena_releases"]),
                                    "arena_failures": int(s1["arena_failures"]), "arena_max_class": int(s1["arena_max_class"]),
@@ -333,7 +334,7 @@ def main():
                       "nn_evals_per_simulation": local_evals / max(1, s1["evaluated_nodes"] - s0["evaluated_nodes"])},
             "ranks": [{"rank": i, "device": int(r[3]), "simulations": int(r[0]), "seconds": r[1], "opening_seed_base": int(r[2])} for i, r in enumerate(per_rank)],
             "longest_kernel": {"name": longest, "share_of_kernel_time": per_kernel[longest] / gpu_ms if gpu_ms > 0 else None},
-            "source_hash": src_hash,
+            "source_hash": src_hash, "library_build_hash": build_hash,
             # the roofline object is the MFMA-bound network kernel (the only kernel of the step with a compute roof); the threat solver
             # (roofline_solver) has neither an HBM nor an MFMA roof, see DESIGN.md
             "roofline": {"bound": "mfma", "kernel": "nn_tower_kernel<%d,%d,%d>" % (args.filters, args.board, args.board),

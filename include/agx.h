@@ -40,6 +40,8 @@ enum AgxSign { AGX_NONE = 0, AGX_CROSS = 1, AGX_CIRCLE = 2, AGX_ILLEGAL = 3 };
 
 const char* agx_last_error(void);
 int agx_version(void);
+/* sha256[:16] of the sources this library was compiled from (csrc + this header; alphagomoku_amd/build.py:source_hash) */
+const char* agx_build_hash(void);
 /* Selects the HIP device for the calling thread (one engine per GPU). */
 int agx_set_device(int device);
 int agx_device_count(int* count);
@@ -188,6 +190,14 @@ typedef struct AgxEngineConfig
 	                                     3 = both.  Finished games are always reported (AgxGameEnd). */
 	int record_sample_capacity;       /* bytes of the format-201 sample pool, 0 = room for an entry on every cell of every record (capped at 2 GiB) */
 	int game_end_capacity;            /* finished-game records kept on the device, 0 = max(2 * n_games, record_capacity / 16) */
+	int speculative_solver;           /* 1: agx_engine_select_solve* runs select + threat solver as ONE persistent launch (k_search_spec) in which the
+	                                     leaves of a game's batch are solved in PARALLEL, each wave against the game's transposition table as it was
+	                                     before the batch (every touched bucket copied into a per-task overlay), and committed in batch order; a task
+	                                     that saw a bucket an earlier task of the batch changed is solved again serially — results are bit-identical
+	                                     to the serial order of Search::solve (Search.cpp:159-183), the solver runs with 3 waves per SIMD instead of
+	                                     one wave per game.  0 (default): one wave per game, tasks in order.  Ignored by tournament-search pools and for
+	                                     solver budgets above 250 positions (the overlay holds 256 buckets). */
+	int speculative_waves;            /* waves of that launch over the whole pool, 0 = 12 per compute unit of the device */
 } AgxEngineConfig;
 
 typedef struct AgxEngine AgxEngine; /* opaque */
@@ -229,6 +239,9 @@ typedef struct AgxEngineStats
 	int arena_failures;                       /* growth requests the heap could not serve (reserve exhausted) */
 	int arena_max_class;                      /* largest size class in use: capacities = class-0 capacities << class */
 	float arena_heap_used;                    /* high-water mark of the edge heap, fraction of its size */
+	int reserved0;
+	unsigned long long speculative_solves;    /* speculative_solver: leaves solved against the pre-batch table ... */
+	unsigned long long speculative_reruns;    /* ... and how many of them had to be solved again serially (conflict or full overlay) */
 } AgxEngineStats;
 
 typedef struct AgxEdgeView

@@ -16,5 +16,6 @@ def pytest_configure(config):
 def agx_lib():
     from alphagomoku_amd import build
     build.build(verbose=False)
-    from alphagomoku_amd import lib
+    from alphagomoku_amd import lib, _lib
+    _lib.require_current_build()   # a prebuilt library from other sources must not pass for this tree
     return lib

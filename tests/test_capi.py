@@ -28,6 +28,18 @@ def test_library_exports_every_declared_symbol(agx_lib):
     assert missing == []
 
 
+def test_library_carries_the_hash_of_its_sources(agx_lib, monkeypatch):
+    from alphagomoku_amd import _lib, build
+    assert agx_lib.agx_build_hash().decode() == build.source_hash()
+    monkeypatch.setattr(build, "source_hash", lambda: "0" * 16)
+    try:
+        _lib.require_current_build()
+    except _lib.AgxError as e:
+        assert "other sources" in str(e)
+    else:
+        raise AssertionError("a library built from other sources must be refused")
+
+
 def test_blob_size_matches_layout(agx_lib):
     from alphagomoku_amd import synthetic, _lib
     for blocks, filters in [(2, 64), (6, 128), (10, 128)]:
