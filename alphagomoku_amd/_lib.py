@@ -99,7 +99,7 @@ class AgxEngineConfig(ctypes.Structure):
                 ("symmetry_seed", ctypes.c_uint64), ("max_children", ctypes.c_int), ("noise_type", ctypes.c_int), ("noise_weight", ctypes.c_float),
                 ("noise_seed", ctypes.c_uint64), ("action_values", ctypes.c_int), ("match_mode", ctypes.c_int), ("policy_temperature", ctypes.c_float),
                 ("arena_reserve", ctypes.c_float), ("search_threads", ctypes.c_int), ("record_format", ctypes.c_int), ("record_sample_capacity", ctypes.c_int), ("game_end_capacity", ctypes.c_int),
-                ("speculative_solver", ctypes.c_int), ("speculative_waves", ctypes.c_int)]
+                ("speculative_solver", ctypes.c_int), ("speculative_waves", ctypes.c_int), ("force_expand_root", ctypes.c_int)]
 
 
 class AgxEngineBuffers(ctypes.Structure):
@@ -116,7 +116,7 @@ class AgxEngineStats(ctypes.Structure):
                                    ["games_finished", "openings_taken", "active_games", "records_used", "record_edges_used",
                                     "first_error", "arena_grows", "arena_releases", "arena_failures", "arena_max_class"]] + \
                [("arena_heap_used", ctypes.c_float), ("reserved0", ctypes.c_int), ("speculative_solves", ctypes.c_ulonglong),
-                ("speculative_reruns", ctypes.c_ulonglong)]
+                ("speculative_reruns", ctypes.c_ulonglong), ("speculative_deferrals", ctypes.c_ulonglong)]
 
 
 class AgxEdgeView(ctypes.Structure):
@@ -167,14 +167,23 @@ def _declare(c):  # noqa: F811
         getattr(c, name).argtypes = [vp, vp]
     for name in ["agx_engine_evaluate", "agx_engine_step"]:
         getattr(c, name).argtypes = [vp, vp, vp]
-    for name in ["agx_engine_select_solve_group", "agx_engine_expand_backup_group"]:
+    for name in ["agx_engine_select_solve_group", "agx_engine_expand_backup_group", "agx_engine_expand_group", "agx_engine_advance_group"]:
         getattr(c, name).argtypes = [vp, ci, ci, vp]
     for name in ["agx_engine_evaluate_group", "agx_engine_step_group"]:
         getattr(c, name).argtypes = [vp, vp, ci, ci, vp]
     c.agx_stream_create.argtypes = [ctypes.POINTER(vp)]
     c.agx_stream_create_with_cu_mask.argtypes = [ctypes.POINTER(vp), vp, ci]
+    c.agx_stream_create_with_cu_mask_instance.argtypes = [ctypes.POINTER(vp), vp, ci, ci]
+    c.agx_event_create.argtypes = [ctypes.POINTER(vp)]
+    c.agx_event_record.argtypes = [vp, vp]
+    c.agx_stream_wait_event.argtypes = [vp, vp]
+    c.agx_event_destroy.argtypes = [vp]
+    c.agx_stream_masked_count.argtypes = []
     c.agx_stream_destroy.argtypes = [vp]
     c.agx_stream_synchronize.argtypes = [vp]
+    c.agx_engine_set_board.argtypes = [vp, ci, vp, ci, vp]
+    c.agx_engine_set_max_simulations.argtypes = [vp, ci]
+    c.agx_engine_set_force_expand_root.argtypes = [vp, ci]
     c.agx_engine_buffers.argtypes = [vp, ctypes.POINTER(AgxEngineBuffers)]
     c.agx_engine_stats.argtypes = [vp, ctypes.POINTER(AgxEngineStats)]
     c.agx_engine_kernel_timing.argtypes = [vp, ci, vp, vp]

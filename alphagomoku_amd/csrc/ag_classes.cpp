@@ -638,8 +638,8 @@ namespace ag
 	}
 
 	GamePool::GamePool(const GameConfig &gameOptions, const SearchConfig &searchOptions, const EdgeSelectorConfig &finalSelector, int games, int maxSimulations,
-			bool useSymmetries, const std::string &networkOutputs) :
-			game_config(gameOptions), games(games), batch(searchOptions.max_batch_size)
+			bool useSymmetries, const std::string &networkOutputs, bool forceExpandRoot) :
+			game_config(gameOptions), search_config(searchOptions), games(games), batch(searchOptions.max_batch_size)
 	{
 		if (gameOptions.rows != gameOptions.cols)
 			throw std::logic_error("GamePool : only square boards are supported");
@@ -671,7 +671,11 @@ namespace ag
 		c.use_symmetries = useSymmetries ? 1 : 0;
 		c.action_values = (networkOutputs == "pvq") ? 1 : 0;
 		c.record_format = 2;            // samples leave the device in dataset format 201
-		c.solver_yield_fraction = 0.75f; // pacing only: per-game results do not depend on it
+		c.force_expand_root = forceExpandRoot ? 1 : 0;
+		// pacing only, per-game results do not depend on either: the leaves of a batch solved in parallel (k_search_spec), stragglers of a
+		// launch put off to the next one
+		c.speculative_solver = 1;
+		c.solver_yield_fraction = (games >= 64) ? 0.9f : 0.0f;
 		check(agx_engine_create(&c, &engine));
 	}
 	GamePool::~GamePool()
@@ -697,14 +701,67 @@ namespace ag
 		return s;
 	}
 
+	Tree::Tree(const TreeConfig &treeConfig) :
+			config(treeConfig), standalone(true)
+	{ // its storage is the one-game engine of the Search it will be used with (Search::bind)
+	}
 	Tree::Tree(GamePool &pool, int group, int n_groups, void *stream) :
-			pool(pool), group(group), n_groups(n_groups), stream(stream)
+			pool(&pool), group(group), n_groups(n_groups), stream(stream)
 	{
 		const int per = (pool.numberOfGames() + n_groups - 1) / n_groups;
 		first_game = group * per;
 		game_count = std::min(per, pool.numberOfGames() - first_game);
 		if (game_count <= 0)
 			throw std::logic_error("Tree : slice " + std::to_string(group) + " of " + std::to_string(n_groups) + " is empty");
+	}
+	GamePool& Tree::bound() const
+	{
+		if (pool == nullptr)
+			throw std::logic_error("Tree : a tree made from a TreeConfig holds its nodes in the engine of a Search: pass it to that Search first (Search::cleanup / select)");
+		return *pool;
+	}
+	void Tree::setBoard(const matrix<Sign> &newBoard, Sign signToMove, bool forceRemoveRootNode)
+	{ // Tree.cpp:128-151 on the device: the cached states reachable from the new position stay, the root is the cached node of the position
+		GamePool &p = bound();
+		if (!standalone)
+			throw std::logic_error("Tree::setBoard() : the trees of a pool slice take their positions from the pool's own games");
+		if (forceRemoveRootNode)
+			throw std::logic_error("Tree::setBoard() : forceRemoveRootNode is not provided by the device tree");
+		if (newBoard.rows() != p.getGameConfig().rows || newBoard.cols() != p.getGameConfig().cols)
+			throw std::logic_error("Tree::setBoard() : the board is " + std::to_string(newBoard.rows()) + "x" + std::to_string(newBoard.cols()) + ", the search was created for "
+					+ std::to_string(p.getGameConfig().rows) + "x" + std::to_string(p.getGameConfig().cols));
+		if (signToMove != Sign::CROSS && signToMove != Sign::CIRCLE)
+			throw std::logic_error("Tree::setBoard() : signToMove must be CROSS or CIRCLE");
+		std::vector<uint8_t> cells(static_cast<size_t>(newBoard.size()));
+		for (int i = 0; i < newBoard.size(); i++)
+			cells[i] = static_cast<uint8_t>(newBoard[i]);
+		check(agx_engine_set_board(p.handle(), 0, cells.data(), static_cast<int>(signToMove), stream));
+		edge_selector.reset();  // a fresh selector / generator per position, as Player::setBoard installs them
+		edge_generator.reset();
+	}
+	void Tree::setEdgeSelector(const EdgeSelector &selector)
+	{ // the device's select stage is the PUCT selector with the parameters the engine was created with: accept exactly that
+		const EdgeSelectorConfig &want = selector.getConfig(), &have = bound().getSearchConfig().mcts_config.edge_selector_config;
+		if (want.policy != "puct")
+			throw std::logic_error("Tree::setEdgeSelector() : the device search implements the 'puct' selector, not '" + want.policy + "'");
+		if (want.init_to != have.init_to || want.noise_type != have.noise_type || want.noise_weight != have.noise_weight
+				|| want.exploration_constant != have.exploration_constant || want.exploration_scaling != have.exploration_scaling)
+			throw std::logic_error("Tree::setEdgeSelector() : the selector's parameters differ from the SearchConfig the search was created with");
+		edge_selector = selector.clone();
+	}
+	void Tree::setEdgeGenerator(const EdgeGenerator &generator)
+	{
+		const UnifiedGenerator *g = dynamic_cast<const UnifiedGenerator*>(&generator);
+		if (g == nullptr)
+			throw std::logic_error("Tree::setEdgeGenerator() : the device's expand stage implements UnifiedGenerator");
+		const MCTSConfig &have = bound().getSearchConfig().mcts_config;
+		if (g->maxEdges() != have.max_children || g->expansionThreshold() != have.policy_expansion_threshold || g->policyTemperature() != have.policy_temperature)
+			throw std::logic_error("Tree::setEdgeGenerator() : the generator's parameters differ from the SearchConfig the search was created with");
+		if (standalone)
+			check(agx_engine_set_force_expand_root(bound().handle(), g->forceExpandRoot() ? 1 : 0)); // false for a Player (Player.cpp:109), true in self-play
+		else if (!g->forceExpandRoot())
+			throw std::logic_error("Tree::setEdgeGenerator() : the trees of a self-play pool never prune the root (forceExpandRoot = true, GameGenerator.cpp:183-184)");
+		edge_generator = generator.clone();
 	}
 	int64_t Tree::getMemory() const noexcept
 	{
@@ -727,45 +784,62 @@ namespace ag
 	}
 	int Tree::getSimulationCount(int game) const
 	{
-		return game_info(pool, first_game + game).root_visits;
+		return game_info(bound(), first_game + game).root_visits;
 	}
 	bool Tree::isRootProven(int game) const
 	{
-		return Score::from_short(static_cast<uint16_t>(game_info(pool, first_game + game).root_score)).isProven();
+		return Score::from_short(static_cast<uint16_t>(game_info(bound(), first_game + game).root_score)).isProven();
 	}
 	int Tree::getNodeCount(int game) const
 	{
-		return game_info(pool, first_game + game).n_nodes;
+		return game_info(bound(), first_game + game).n_nodes;
 	}
 	int Tree::getMoveNumber(int game) const
 	{
-		return game_info(pool, first_game + game).n_moves;
+		return game_info(bound(), first_game + game).n_moves;
 	}
 	Value Tree::getEvaluation(int game) const
 	{
-		const AgxGameInfo info = game_info(pool, first_game + game);
+		const AgxGameInfo info = game_info(bound(), first_game + game);
 		return Value(info.root_win, info.root_draw);
+	}
+	float Tree::getExpectation(int game) const
+	{
+		return getEvaluation(game).getExpectation();
 	}
 	Sign Tree::getSignToMove(int game) const
 	{
-		return static_cast<Sign>(game_info(pool, first_game + game).sign_to_move);
+		return static_cast<Sign>(game_info(bound(), first_game + game).sign_to_move);
 	}
 	std::vector<Sign> Tree::getBoard(int game) const
 	{
 		std::vector<uint8_t> b;
-		game_info(pool, first_game + game, nullptr, &b);
-		const int hw = pool.getGameConfig().rows * pool.getGameConfig().cols;
+		game_info(bound(), first_game + game, nullptr, &b);
+		const int hw = bound().getGameConfig().rows * bound().getGameConfig().cols;
 		std::vector<Sign> result(hw);
 		for (int i = 0; i < hw; i++)
 			result[i] = static_cast<Sign>(b[i]);
 		return result;
+	}
+	const matrix<Sign>& Tree::getBoard() const
+	{
+		const GameConfig &gc = bound().getGameConfig();
+		const std::vector<Sign> cells = getBoard(0);
+		board_copy = matrix<Sign>(gc.rows, gc.cols);
+		for (int i = 0; i < board_copy.size(); i++)
+			board_copy[i] = cells[i];
+		return board_copy;
+	}
+	Node Tree::getInfo(const std::vector<Move> &moves) const
+	{
+		return getInfo(0, moves);
 	}
 	Node Tree::getInfo(int game, const std::vector<Move> &moves) const
 	{
 		if (!moves.empty())
 			throw std::logic_error("Tree::getInfo() : only the root (an empty move list) can be read from the device");
 		std::vector<AgxEdgeView> views;
-		const AgxGameInfo info = game_info(pool, first_game + game, &views);
+		const AgxGameInfo info = game_info(bound(), first_game + game, &views);
 		std::vector<Edge> edges;
 		for (const AgxEdgeView &v : views)
 			edges.emplace_back(v);
@@ -777,7 +851,7 @@ namespace ag
 		NodeCacheStats result;
 		try
 		{
-			const AgxEngineStats s = pool.getStats();
+			const AgxEngineStats s = bound().getStats();
 			result.stored_nodes = s.peak_nodes;
 			result.stored_edges = s.peak_edges;
 		} catch (std::exception&)
@@ -786,9 +860,57 @@ namespace ag
 		return result;
 	}
 
+	Search::Search(const GameConfig &gameOptions, const SearchConfig &searchOptions) :
+			own_pool(std::make_unique<GamePool>(gameOptions, searchOptions, EdgeSelectorConfig(), 1, maximum_number_of_simulations, false, "pv", false)),
+			pool(*own_pool), group(0), n_groups(1), stream(nullptr), batch_size(searchOptions.max_batch_size)
+	{ // the reference's constructor: a one-game engine (solver table, task buffers, the arenas of the Tree it will be used with), begun on the
+	  // empty board; Tree::setBoard gives it its positions
+		std::vector<uint16_t> empty_opening(AGX_OPENING_CAP, 0);
+		own_pool->begin(empty_opening);
+	}
 	Search::Search(GamePool &pool, int group, int n_groups, void *stream) :
 			pool(pool), group(group), n_groups(n_groups), stream(stream), batch_size(pool.getBatchSize())
 	{
+	}
+	void Search::bind(Tree &tree)
+	{
+		if (tree.standalone && tree.pool == nullptr)
+		{ // the first meeting of a stand-alone pair: the tree's nodes live in this search's engine from now on
+			if (own_pool == nullptr)
+				throw std::logic_error("Search : a tree made from a TreeConfig goes with a Search(const GameConfig&, const SearchConfig&)");
+			const TreeConfig &want = tree.config, &have = pool.getSearchConfig().tree_config;
+			if (want.information_leak_threshold != have.information_leak_threshold)
+				throw std::logic_error("Search : the tree's information_leak_threshold differs from the SearchConfig's tree_config");
+			tree.pool = &pool;
+			tree.stream = stream;
+		}
+		if (tree.pool != &pool || tree.group != group)
+			throw std::logic_error("Search : the tree belongs to another search / slice");
+	}
+	int64_t Search::getMemory() const noexcept
+	{
+		return 0;
+	}
+	const SearchConfig& Search::getConfig() const noexcept
+	{
+		return pool.getSearchConfig();
+	}
+	AlphaBetaSearch& Search::getSolver() noexcept
+	{
+		return ab_search;
+	}
+	void Search::setBoard(const matrix<Sign>&, Sign)
+	{ // Search.cpp:112-115: ab_search.increaseGeneration() — the set-board launch Tree::setBoard enqueued ages the solver table (k_set_board)
+	}
+	void Search::useBuffer(int index)
+	{
+		if (index != 0 && index != 1)
+			throw std::logic_error("Search::useBuffer() : index must be 0 or 1");
+		current_task_buffer = index;
+	}
+	void Search::switchBuffer() noexcept
+	{
+		current_task_buffer = 1 - current_task_buffer;
 	}
 	void Search::clearStats() noexcept
 	{
@@ -811,10 +933,12 @@ namespace ag
 		}
 		return result;
 	}
-	void Search::select(Tree &tree, int)
-	{ // the simulation budget is the pool's (SelfplayConfig::constraints.max_simulations, fixed at creation)
-		if (&tree.pool != &pool || tree.group != group)
-			throw std::logic_error("Search::select() : the tree belongs to another slice");
+	void Search::select(Tree &tree, int maxSimulations)
+	{ // a pool slice: the simulation budget is the pool's (SelfplayConfig::constraints.max_simulations, fixed at creation); a stand-alone
+	  // pair takes it per call like the reference
+		bind(tree);
+		if (own_pool != nullptr)
+			check(agx_engine_set_max_simulations(pool.handle(), maxSimulations));
 		// The launch is enqueued by solve(): on the device a game's wave descends the tree and then solves its leaves in ONE launch
 		// (agx_engine_select_solve_group), so a slow descent holds up only its own game.  A caller that never calls solve() gets the
 		// stand-alone select launch from the next stage it calls.
@@ -874,8 +998,15 @@ namespace ag
 	void Search::backup(Tree&)
 	{ // second half of the launch enqueued by expand()
 	}
-	void Search::cleanup(Tree&)
+	void Search::cleanup(Tree &tree)
 	{ // cancelVirtualLoss of abandoned tasks: every device step completes its batch, nothing is left to cancel
+		bind(tree);
+		if (ab_search.clear_requested && own_pool != nullptr)
+		{ // getSolver().clear() at the start of a game (EvaluationGame.cpp:81-82): an empty table — and an empty tree, which is what the cache
+		  // cleanup of the new game's first setBoard would leave of the old game's states anyway
+			pool.begin(std::vector<uint16_t>(AGX_OPENING_CAP, 0));
+			ab_search.clear_requested = false;
+		}
 	}
 	void Search::setBatchSize(int batchSize)
 	{
@@ -885,6 +1016,89 @@ namespace ag
 	int Search::getBatchSize() const noexcept
 	{
 		return batch_size;
+	}
+
+	/* ------------------------------------------------ selectors ------------------------------------------------ */
+	namespace
+	{
+		/* the search selector: its select() happens inside the device's select stage (dev_mcts.hpp:select_edge); the object only carries the
+		 * configuration from EdgeSelector::create to Tree::setEdgeSelector */
+		class DeviceSelector: public EdgeSelector
+		{
+				EdgeSelectorConfig config;
+			public:
+				explicit DeviceSelector(const EdgeSelectorConfig &cfg) :
+						config(cfg)
+				{
+				}
+				std::unique_ptr<EdgeSelector> clone() const override { return std::make_unique<DeviceSelector>(config); }
+				const Edge* select(const Node*) noexcept override { return nullptr; }
+				const EdgeSelectorConfig& getConfig() const noexcept override { return config; }
+		};
+		/* the final-move selectors on an owning copy of the root (EdgeSelector.cpp:476-536 under find_best_edge_impl :562-586): one rating
+		 * per edge, the first strictly greater one wins */
+		class FinalSelector: public EdgeSelector
+		{
+				EdgeSelectorConfig config;
+				int kind;
+			public:
+				FinalSelector(const EdgeSelectorConfig &cfg, int kind) :
+						config(cfg), kind(kind)
+				{
+				}
+				std::unique_ptr<EdgeSelector> clone() const override { return std::make_unique<FinalSelector>(config, kind); }
+				const EdgeSelectorConfig& getConfig() const noexcept override { return config; }
+				float rate(const Edge &e, int parent_visits) const noexcept
+				{
+					const ProvenValue pv = e.getScore().getProvenValue();
+					const float distance = static_cast<float>(e.getScore().getDistance());
+					switch (kind)
+					{
+						case 0: // 'best' (:515-536): proven results first, else visits + Q * N + a little of the prior
+							if (pv == ProvenValue::LOSS)
+								return -1.0e8f + distance;
+							if (pv == ProvenValue::WIN)
+								return +1.0e8f - distance;
+							return e.getVisits() + e.getValue().getExpectation() * parent_visits + 0.001f * e.getPolicyPrior();
+						case 1: // 'max_visit' (:501-507)
+							return static_cast<float>(e.getVisits());
+						case 2: // 'min_visit' (:508-514)
+							return -static_cast<float>(e.getVisits());
+						case 3: // 'max_value' (:476-493)
+							if (pv == ProvenValue::LOSS)
+								return -1000.0f + distance;
+							if (pv == ProvenValue::WIN)
+								return +1000.0f - distance;
+							return (pv == ProvenValue::DRAW) ? Value(0.0f, 1.0f).getExpectation() : e.getValue().getExpectation();
+						default: // 'max_policy' (:494-500)
+							return e.getPolicyPrior();
+					}
+				}
+				const Edge* select(const Node *node) noexcept override
+				{
+					const Edge *best = nullptr;
+					float best_rating = std::numeric_limits<float>::lowest();
+					for (const Edge *e = node->begin(); e < node->end(); e++)
+					{
+						const float r = rate(*e, node->getVisits());
+						if (r > best_rating)
+						{
+							best_rating = r;
+							best = e;
+						}
+					}
+					return best;
+				}
+		};
+	}
+	std::unique_ptr<EdgeSelector> EdgeSelector::create(const EdgeSelectorConfig &config)
+	{ // EdgeSelector.cpp:680-711
+		if (config.policy == "puct")
+			return std::make_unique<DeviceSelector>(config);
+		const int kind = selector_id(config.policy); // throws for unknown names
+		if (kind == 5)
+			throw std::logic_error("EdgeSelector::create() : 'lcb' is provided as the pool's own final selector (on the device), not on root copies");
+		return std::make_unique<FinalSelector>(config, kind);
 	}
 
 	/* ------------------------------------------------ dataset ------------------------------------------------ */
@@ -954,26 +1168,65 @@ namespace ag
 	}
 
 	/* ------------------------------------------------ GameGenerator ------------------------------------------------ */
-	GameGenerator::GameGenerator(const GameConfig&, const SelfplayConfig &selfplayOptions, GeneratorManager &manager, NNEvaluator &evaluator, GamePool &pool,
+	GameGenerator::GameGenerator(const GameConfig &gameOptions, const SelfplayConfig &selfplayOptions, GeneratorManager &manager, NNEvaluator &evaluator) :
+			manager(manager), nn_evaluator(evaluator), game_config(gameOptions), selfplay_config(selfplayOptions)
+	{ // GameGenerator.cpp:36-45: the pool of one game is created by the first generate(), when the evaluator's network (its outputs) is known
+		static std::atomic<uint32_t> generator_counter { 0 };
+		opening_seed = 7919u * (1u + generator_counter.fetch_add(1u));
+	}
+	GameGenerator::GameGenerator(const GameConfig &gameOptions, const SelfplayConfig &selfplayOptions, GeneratorManager &manager, NNEvaluator &evaluator, GamePool &pool,
 			int group, int n_groups, void *stream) :
-			manager(manager), nn_evaluator(evaluator), pool(pool), tree(pool, group, n_groups, stream), search(pool, group, n_groups, stream),
-			selfplay_config(selfplayOptions), group(group), n_groups(n_groups), stream(stream)
+			manager(manager), nn_evaluator(evaluator), game_config(gameOptions), pool(&pool), tree(std::make_unique<Tree>(pool, group, n_groups, stream)),
+			search(std::make_unique<Search>(pool, group, n_groups, stream)), selfplay_config(selfplayOptions), group(group), n_groups(n_groups), stream(stream)
 	{
+	}
+	void GameGenerator::start_own_pool()
+	{
+		own_pool = std::make_unique<GamePool>(game_config, selfplay_config.search_config, selfplay_config.final_selector, 1,
+				selfplay_config.constraints.max_simulations, selfplay_config.use_symmetries, nn_evaluator.get_network().getOutputConfig());
+		pool = own_pool.get();
+		tree = std::make_unique<Tree>(*pool, 0, 1, nullptr);
+		search = std::make_unique<Search>(*pool, 0, 1, nullptr);
+		own_openings = 0;
+		serve_own_pool();
+	}
+	void GameGenerator::serve_own_pool()
+	{ // what the generator thread does for a shared pool: finished games to the manager's buffer, the next openings into the list
+	  // (prepareOpening, utils/misc.cpp:142-170; the network-balanced OpeningGenerator is the generator thread's, GeneratorThread::run)
+		const bool first = (own_openings == 0);
+		if (!first)
+			manager.addToBuffer(pool->handle());
+		const int taken = first ? 0 : pool->getStats().openings_taken;
+		if (first || taken + 1 > own_openings)
+		{
+			const int count = 8;
+			std::vector<uint16_t> list(static_cast<size_t>(count) * AGX_OPENING_CAP, 0);
+			for (int i = 0; i < count && selfplay_config.use_opening; i++)
+				check(agx_make_opening(static_cast<int>(game_config.rules), game_config.rows, opening_seed++, list.data() + static_cast<size_t>(i) * AGX_OPENING_CAP));
+			if (first)
+				pool->begin(list);
+			else
+				pool->addOpenings(list);
+			own_openings += count;
+		}
 	}
 	void GameGenerator::clearStats()
 	{
-		search.clearStats();
+		if (search != nullptr)
+			search->clearStats();
 	}
 	NodeCacheStats GameGenerator::getCacheStats() const noexcept
 	{
-		return tree.getNodeCacheStats();
+		return (tree != nullptr) ? tree->getNodeCacheStats() : NodeCacheStats();
 	}
 	SearchStats GameGenerator::getSearchStats() const noexcept
 	{
-		return search.getStats();
+		return (search != nullptr) ? search->getStats() : SearchStats();
 	}
 	GameGenerator::Status GameGenerator::generate()
 	{ // GameGenerator.cpp:46-121 for every game of the slice at once
+		if (pool == nullptr)
+			start_own_pool();
 		if (state == GAME_NOT_STARTED || state == PREPARE_OPENING)
 		{ // beginGame / loadOpening / prepare_search happen on the device when a game takes its opening (k_begin, k_restart); the thread
 		  // keeps the opening list ahead of the games (GeneratorThread::run)
@@ -982,34 +1235,36 @@ namespace ag
 		}
 		if (state == GAMEPLAY_SELECT_SOLVE_EVALUATE)
 		{
-			search.select(tree, selfplay_config.constraints.max_simulations);
-			search.solve();
-			search.scheduleToNN(nn_evaluator);
+			search->select(*tree, selfplay_config.constraints.max_simulations);
+			search->solve();
+			search->scheduleToNN(nn_evaluator);
 			state = GAMEPLAY_EXPAND_AND_BACKUP;
 			return GameGenerator::OK;
 		}
 		if (state == GAMEPLAY_EXPAND_AND_BACKUP)
 		{
-			if (!search.areTasksReady())
+			if (!search->areTasksReady())
 				return GameGenerator::TASKS_NOT_READY;
-			search.generateEdges(tree);
-			search.expand(tree);
-			search.backup(tree);
+			search->generateEdges(*tree);
+			search->expand(*tree);
+			search->backup(*tree);
 			// get_simulations_for_move, the move rule, make_move, the end-of-game hand-over and prepare_search (GameGenerator.cpp:97-118) are
 			// decided per game on the device; finished games reach manager.addToBuffer through GeneratorThread::collectGames
 			make_move();
 			state = GAMEPLAY_SELECT_SOLVE_EVALUATE;
 			steps++;
+			if (own_pool != nullptr && steps % 64 == 0)
+				serve_own_pool();
 		}
 		return GameGenerator::OK;
 	}
 	void GameGenerator::make_move()
 	{ // GameGenerator.cpp:145-173 for the games whose root has its visits: final selector, sample, Game::makeMove
-		check(agx_engine_advance_group(pool.handle(), group, n_groups, stream));
+		check(agx_engine_advance_group(pool->handle(), group, n_groups, stream));
 	}
 	void GameGenerator::prepare_search()
 	{ // GameGenerator.cpp:174-185: cleanup + Tree::setBoard + fresh selector / generator — part of the advance kernel on the device
-		search.cleanup(tree);
+		search->cleanup(*tree);
 	}
 
 	/* ------------------------------------------------ GeneratorThread ------------------------------------------------ */
@@ -1188,8 +1443,8 @@ namespace ag
 				const AgxEngineStats st = pool->getStats();
 				if (st.first_error != 0)
 					throw std::runtime_error("the device engine stopped a game with error " + std::to_string(st.first_error));
-				if (st.openings_taken + games / 2 > n_openings)
-				{
+				if (st.openings_taken + games > n_openings)
+				{ // slot s plays openings s, s + games, s + 2 games, ...: keep a whole round beyond the furthest slot in the list
 					pool->addOpenings(make_openings(games));
 					n_openings += games;
 				}

@@ -460,7 +460,8 @@ namespace
 	 * and the launch ends with the yield rule as before.  The select stage's LDS (board, keys) aliases the threat lists, which the solver
 	 * initialises afterwards. */
 #ifndef AGX_SOLVE_WAVES
-#define AGX_SOLVE_WAVES 2 /* solver waves per SIMD the register allocation must leave room for (the LDS footprint allows 2 at 15x15) */
+#define AGX_SOLVE_WAVES 1 /* waves per SIMD the register allocation of k_solve leaves room for: a pool of n games has n solver waves, one per SIMD at the
+                             BASELINE pool size, and an uncapped allocation is the fastest single wave (k_search_spec is the kernel built for occupancy) */
 #endif
 	template<bool RENJU, int NFIX, bool FUSED>
 	__global__ __launch_bounds__(64, AGX_SOLVE_WAVES) void k_solve(EngineDev E)
@@ -595,15 +596,26 @@ namespace
 			h.solved = 1;
 		}
 	}
-	template<bool RENJU, class SH>
-	__device__ __forceinline__ void spec_commit_game(SH &sh, const EngineDev &E, int g, int area, int lane)
+	/* The commit of one game's batch, resumable: the wave that solved the game's last leaf walks the leaves in batch order from `k` on.
+	 * Returns the index of a leaf that has to be solved again serially (the caller does that, straight on the table, and calls again with
+	 * k + 1), -1 when the batch is committed and on the network queue, or -2 when the game was DEFERRED: a leaf needs its serial re-run while
+	 * all but a few games of the launch are done (the yield rule of k_solve, AgxEngineConfig.solver_yield_fraction) — the leaves before it
+	 * stay committed, the game sits out this step's network / expand stages and the next launch queues its remaining leaves again: the
+	 * same operations one step later. */
+	struct SpecCommit
 	{
+			int game, k;
+			bool table_changed;
+			unsigned long long nodes, solved, reruns;
+	};
+	template<class SH>
+	__device__ __forceinline__ int spec_commit_game(SH &sh, const EngineDev &E, SpecCommit &c, int lane, const int *c_done, int defer_threshold)
+	{
+		const int g = c.game;
 		GameState &gs = E.games[g];
 		const int n_tasks = gs.n_tasks;
 		u64 *tt = E.tt + static_cast<size_t>(g) * (E.tt_bucket_mask + 1ull) * 8ull;
-		bool table_changed = false;
-		unsigned long long nodes = 0, solved = 0, reruns = 0;
-		for (int k = 0; k < n_tasks; k++)
+		for (int k = c.k; k < n_tasks; k++)
 		{
 			const int slot = g * E.batch + k;
 			SpecTask &h = E.spec_tasks[slot];
@@ -628,7 +640,7 @@ namespace
 					continue;
 				}
 			}
-			if (valid && table_changed)
+			if (valid && c.table_changed)
 			{ // has any bucket this task looked at changed since the batch began?  Eight lanes per bucket.
 				bool mismatch = false;
 				for (int base = 0; base < cnt; base += 8)
@@ -639,61 +651,82 @@ namespace
 				}
 				valid = (__ballot(mismatch) == 0ull);
 			}
-			solved++;
-			if (E.spec_debug == 8)
-				continue;
 			if (!valid)
-			{ // Search::solve's own order: this task again, on the table as the earlier tasks of the batch left it
-				if (lane == 0)
-				{
-					t.flags = h.flags0;
-					t.win = 0.0f;
-					t.draw = 0.0f;
-					t.moves_left = 0.0f;
-				}
-				wave_sync();
-				unsigned long long n2 = 0;
-				solve_task<RENJU>(sh, E, g, t, slot, gs.generation, lane, n2, area);
-				nodes += n2;
-				reruns++;
-				table_changed = true;
-			}
-			else
 			{
-				bool any = false;
-				for (int base = 0; base < cnt; base += 8)
+				int done = 0;
+				if (lane == 0)
+					done = __hip_atomic_load(c_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				const bool defer = __builtin_amdgcn_readfirstlane(done) >= defer_threshold;
+				// forget the speculative result: of this leaf (it is solved again), or of this leaf and the ones behind it (deferred)
+				for (int j = k; j < (defer ? n_tasks : k + 1); j++)
 				{
-					const int p = base + (lane >> 3), w = lane & 7;
-					if (p < cnt && ((h.dirty[p >> 5] >> (p & 31)) & 1u))
+					SpecTask &hj = E.spec_tasks[g * E.batch + j];
+					if (hj.solved != 0 && lane == 0)
 					{
-						tt[8 * static_cast<u64>(h.keys[p]) + w] = ov[p * 16 + 8 + w];
-						any = true;
+						DTask &tj = E.tasks[g * E.batch + j];
+						tj.flags = hj.flags0;
+						tj.win = 0.0f;
+						tj.draw = 0.0f;
+						tj.moves_left = 0.0f;
+						hj.solved = 0;
 					}
 				}
-				table_changed = table_changed || (__ballot(any) != 0ull);
-				nodes += static_cast<unsigned long long>(h.nodes);
+				wave_sync();
+				if (defer)
+				{
+					if (lane == 0)
+					{
+						gs.solve_pos = k;
+						gs.solve_pending = 1;
+						gs.stats[5] += c.nodes;
+						gs.spec_stats[0] += c.solved;
+						gs.spec_stats[1] += c.reruns;
+						gs.spec_stats[2] += 1;
+					}
+					return -2;
+				}
+				// Search::solve's own order: this task again, on the table as the earlier tasks of the batch left it
+				c.solved++;
+				c.reruns++;
+				c.table_changed = true;
+				c.k = k + 1;
+				return k;
 			}
+			bool any = false;
+			for (int base = 0; base < cnt; base += 8)
+			{
+				const int p = base + (lane >> 3), w = lane & 7;
+				if (p < cnt && ((h.dirty[p >> 5] >> (p & 31)) & 1u))
+				{
+					tt[8 * static_cast<u64>(h.keys[p]) + w] = ov[p * 16 + 8 + w];
+					any = true;
+				}
+			}
+			c.table_changed = c.table_changed || (__ballot(any) != 0ull);
+			c.nodes += static_cast<unsigned long long>(h.nodes);
+			c.solved++;
 			if (lane == 0)
 				h.solved = 0;
 			wave_sync();
 		}
-		if (E.spec_debug == 7)
-			return;
 		const unsigned long long scheduled = schedule_to_nn(sh, E, g, gs, n_tasks, lane);
 		if (lane == 0)
 		{
-			gs.stats[5] += nodes;
+			gs.solve_pos = 0;
+			gs.solve_pending = 0;
+			gs.stats[5] += c.nodes;
 			gs.stats[1] += scheduled;
-			gs.spec_stats[0] += solved;
-			gs.spec_stats[1] += reruns;
+			gs.spec_stats[0] += c.solved;
+			gs.spec_stats[1] += c.reruns;
 #ifdef AGX_SPEC_PROFILE
-			E.spec_trace[4 * g + 3] = reruns * 16 + solved;
+			E.spec_trace[4 * g + 3] = c.reruns * 16 + c.solved;
 #endif
 		}
+		return -1;
 	}
 
 #ifdef AGX_SPEC_PROFILE /* developer builds: where the waves of k_search_spec spend their time (100 MHz wall clock ticks, summed over waves) */
-#define SPEC_T(var) const unsigned long long var = wall_clock64()
+#define SPEC_T(var) unsigned long long var = wall_clock64()
 #define SPEC_ADD(k, v) do { if (lane == 0) atomicAdd(&E.spec_prof[k], static_cast<unsigned long long>(v)); } while (0)
 #define SPEC_MAX(k, v) do { if (lane == 0) atomicMax(&E.spec_prof[k], static_cast<unsigned long long>(v)); } while (0)
 #else
@@ -716,6 +749,9 @@ namespace
 		__shared__ SH sh;
 		const int lane = threadIdx.x;
 		int *const c_select = E.counters + SPEC_COUNTER0 + 4 * E.spec_group, *const c_head = c_select + 1, *const c_tail = c_select + 2, *const c_selected = c_select + 3;
+		int *const c_done = E.counters + E.yield_counter; // games of this launch whose batch is on the network queue (or that had nothing to do)
+		const float fraction = E.match_mode ? 0.5f + 0.5f * E.yield_fraction : E.yield_fraction; // (match mode: half of the trees wait for their opponents)
+		const int defer_threshold = (E.yield_fraction > 0.0f) ? static_cast<int>(fraction * count) : 0x7FFFFFFF;
 		int *const items = E.spec_items + static_cast<size_t>(E.g0) * E.batch + static_cast<size_t>(E.spec_group) * SPEC_QUEUE_SLACK;
 		const int item_cap = count * E.batch + SPEC_QUEUE_SLACK;
 		const int area = E.n_games + E.spec_group * E.spec_waves + blockIdx.x; // this wave's spill areas (action stack, list / frame tails)
@@ -726,6 +762,7 @@ namespace
 		u64 *sel_keys = reinterpret_cast<u64*>(&sh.act[0]);
 		bool keys_loaded = false;
 		SPEC_T(t_begin);
+		__builtin_amdgcn_s_setprio(3); // selects (and below: commits) are the launch's critical path, the speculative solves fill the SIMDs around them
 		while (true)
 		{
 			int s = 0;
@@ -746,19 +783,26 @@ namespace
 					keys_loaded = true;
 				}
 				use_game_arenas(E, g);
-				select_batch(E, g, g, lane, &sh.board[0], &sh.lines[0], sel_keys);
+				const int first = gs.solve_pending ? gs.solve_pos : 0; // a deferred game: no new descents, its batch goes on behind the committed leaves
+				if (!gs.solve_pending)
+					select_batch(E, g, g, lane, &sh.board[0], &sh.lines[0], sel_keys);
 				__threadfence(); // the tasks are read by other waves
 				__syncthreads();
 				const int n_tasks = gs.n_tasks;
 				int n_items = 0;
-				for (int k = 0; k < n_tasks; k++)
+				for (int k = first; k < n_tasks; k++)
 					if ((E.tasks[static_cast<size_t>(g) * E.batch + k].flags & TF_BY_SOLVER) == 0)
 						n_items++;
 				if (n_items == 0)
 				{ // nothing for the solver (proven edges only): the batch goes to the network queue at once
 					const unsigned long long scheduled = schedule_to_nn(sh, E, g, gs, n_tasks, lane);
 					if (lane == 0)
+					{
 						gs.stats[1] += scheduled;
+						gs.solve_pos = 0;
+						gs.solve_pending = 0;
+						atomicAdd(c_done, 1);
+					}
 					keys_loaded = keys_loaded && !E.use_symmetries; // (symmetric features pass through sh.act, where the keys are)
 				}
 				else
@@ -769,12 +813,14 @@ namespace
 						__threadfence();
 						const int base = atomicAdd(c_tail, n_items);
 						int j = 0;
-						for (int k = 0; k < n_tasks; k++)
+						for (int k = first; k < n_tasks; k++)
 							if ((E.tasks[static_cast<size_t>(g) * E.batch + k].flags & TF_BY_SOLVER) == 0)
 								__hip_atomic_store(&items[base + j++], (g * 16 + k) + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 					}
 				}
 			}
+			if (idle && lane == 0)
+				atomicAdd(c_done, 1);
 #ifdef AGX_SPEC_PROFILE
 			if (lane == 0)
 			{
@@ -791,89 +837,122 @@ namespace
 		}
 		__syncthreads();
 
+		__builtin_amdgcn_s_setprio(0);
 		SPEC_T(t_selected);
 		SPEC_ADD(0, t_selected - t_begin); // select phase, all waves (incl. the ones that found the cursor exhausted at once)
 		SPEC_MAX(1, t_selected - t_begin); // the slowest wave's select phase
-		if (E.spec_debug == 1)
-			return;
-		/* ---- 2. + 3. solve the queued leaves, commit a game's batch when its last leaf is done ---- */
+		/* ---- 2. + 3. solve the queued leaves, commit a game's batch when its last leaf is done ----
+		 * One call site of the solver for both kinds of solves (speculative: against the task's overlay; re-run during a commit: straight on
+		 * the table) — the solver is ~25 k instructions, a second inlined copy costs registers and instruction cache. */
 		solver_load_threat_table(sh, E, lane);
+		SpecCommit commit;
+		commit.game = -1;
+		SPEC_T(t_commit0);
 		while (true)
 		{
+			int g, k;
+			bool speculative;
 			SPEC_T(t_pop);
-			int i = 0;
-			if (lane == 0)
-				i = atomicAdd(c_head, 1);
-			i = __builtin_amdgcn_readfirstlane(i);
-			if (i >= item_cap)
-				return;
-			int v = 0;
-			if (lane == 0)
-			{
-				while (true)
+			if (commit.game >= 0)
+			{ // this wave is committing a game: go on until a leaf needs its serial re-run
+				const int r = spec_commit_game(sh, E, commit, lane, c_done, defer_threshold);
+				if (r < 0)
 				{
-					v = __hip_atomic_load(&items[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-					if (v != 0)
-						break;
-					if (__hip_atomic_load(c_selected, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= count)
-					{ // every game has queued its leaves: the queue's length is final
-						if (i >= __hip_atomic_load(c_tail, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT))
-						{
-							v = -1;
-							break;
-						}
+					if (r == -1 && lane == 0)
+						atomicAdd(c_done, 1);
+#ifdef AGX_SPEC_PROFILE
+					SPEC_T(t_c1);
+					if (lane == 0)
+					{
+						E.spec_trace[4 * commit.game + 1] = t_commit0;
+						E.spec_trace[4 * commit.game + 2] = t_c1;
 					}
-					else
-						__builtin_amdgcn_s_sleep(16);
+					SPEC_ADD(4, t_c1 - t_commit0); // commits incl. serial re-runs
+					SPEC_MAX(5, t_c1 - t_commit0);
+#endif
+					commit.game = -1;
+					__builtin_amdgcn_s_setprio(0);
+					continue;
 				}
-				if (v > 0)
-					__hip_atomic_store(&items[i], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // empty again for the next launch
+				g = commit.game;
+				k = r;
+				speculative = false;
 			}
-			v = __builtin_amdgcn_readfirstlane(v);
-			SPEC_T(t_got);
-			SPEC_ADD(2, t_got - t_pop); // waiting for an item
-			if (v < 0)
+			else
 			{
-				SPEC_MAX(7, t_got - t_begin); // the last wave's exit = the launch
-				return;
+				int i = 0;
+				if (lane == 0)
+					i = atomicAdd(c_head, 1);
+				i = __builtin_amdgcn_readfirstlane(i);
+				if (i >= item_cap)
+					return;
+				int v = 0;
+				if (lane == 0)
+				{ // wait for queue slot i to be filled.  The waiting waves must not disturb the ones that still select (they are the critical path):
+				  // each polls only its OWN slot (no shared hot spot), sleeps in between, and looks at the shared counters once in 32 polls
+					for (int polls = 0;; polls++)
+					{
+						v = __hip_atomic_load(&items[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+						if (v != 0)
+							break;
+						if ((polls & 31) == 31 && __hip_atomic_load(c_selected, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= count)
+						{ // every game has queued its leaves: the queue's length is final
+							__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+							if (i >= __hip_atomic_load(c_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+							{
+								v = -1;
+								break;
+							}
+						}
+						__builtin_amdgcn_s_sleep(64);
+					}
+					if (v > 0)
+						__hip_atomic_store(&items[i], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // empty again for the next launch
+				}
+				v = __builtin_amdgcn_readfirstlane(v);
+				SPEC_T(t_got);
+				SPEC_ADD(2, t_got - t_pop); // waiting for an item
+				if (v < 0)
+				{
+					SPEC_MAX(7, t_got - t_begin); // the last wave's exit = the launch
+					return;
+				}
+				__threadfence(); // (acquire: the task as its selecting wave wrote it)
+				g = (v - 1) >> 4;
+				k = (v - 1) & 15;
+				speculative = true;
 			}
-			__threadfence(); // (acquire: the task as its selecting wave wrote it)
-			const int g = (v - 1) >> 4, k = (v - 1) & 15;
 			const int slot = g * E.batch + k;
 			DTask &t = E.tasks[slot];
 			const uint32_t flags0 = t.flags;
 			unsigned long long n1 = 0;
-			if (E.spec_debug == 2)
+			SPEC_T(t_s0);
+			solve_task<RENJU>(sh, E, g, t, slot, E.games[g].generation, lane, n1, area, speculative ? E.spec_overlay + static_cast<size_t>(slot) * (SPEC_OV_CAP * 16) : nullptr);
+			if (!speculative)
+			{ // a re-run inside a commit: its result stands
+				commit.nodes += n1;
 				continue;
-			solve_task<RENJU>(sh, E, g, t, slot, E.games[g].generation, lane, n1, area, (E.spec_debug == 3) ? nullptr : E.spec_overlay + static_cast<size_t>(slot) * (SPEC_OV_CAP * 16));
-			if (E.spec_debug == 3 || E.spec_debug == 4)
-				continue;
+			}
 			spec_flush(sh, E.spec_tasks[slot], static_cast<int>(n1), flags0, lane);
-			if (E.spec_debug == 5)
-				continue;
 			SPEC_T(t_solved);
-			SPEC_ADD(3, t_solved - t_got); // speculative solves
+			SPEC_ADD(3, t_solved - t_s0); // speculative solves
 			SPEC_ADD(6, 1);
 			__threadfence(); // release: task results, features, overlay and its header
 			int left = 0;
 			if (lane == 0)
 				left = __hip_atomic_fetch_add(&E.spec_left[g], -1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
 			left = __builtin_amdgcn_readfirstlane(left);
-			if (left == 1 && E.spec_debug != 6)
-			{ // the last leaf of this game's batch: commit in batch order
+			if (left == 1)
+			{ // the last leaf of this game's batch: this wave commits it, in batch order (the loop's next turns)
 				__threadfence();
-				SPEC_T(t_c0);
-				spec_commit_game<RENJU>(sh, E, g, area, lane);
-				SPEC_T(t_c1);
+				commit.game = g;
+				commit.k = 0;
+				commit.table_changed = false;
+				commit.nodes = commit.solved = commit.reruns = 0;
+				__builtin_amdgcn_s_setprio(3);
 #ifdef AGX_SPEC_PROFILE
-				if (lane == 0)
-				{
-					E.spec_trace[4 * g + 1] = t_c0;
-					E.spec_trace[4 * g + 2] = t_c1;
-				}
+				t_commit0 = wall_clock64();
 #endif
-				SPEC_ADD(4, t_c1 - t_c0); // commits incl. serial re-runs
-				SPEC_MAX(5, t_c1 - t_c0);
 			}
 		}
 	}
@@ -996,7 +1075,7 @@ namespace
 					}
 				}
 				__syncthreads();
-				if ((path_len > 0 || E.match_mode) && s_proven(score))
+				if ((path_len > 0 || E.prune_root) && s_proven(score))
 				{ // the root is exempt in self-play only (forceExpandRoot: GameGenerator.cpp:183-184, Player.cpp:111); prune_weak_moves, proven branch (:55-68): keep the best-scored edges in their original order
 					uint32_t best = s_loss_in(0);
 					for (int i = lane; i < n_e; i += 64)
@@ -1025,7 +1104,7 @@ namespace
 					}
 					n_e = kept;
 				}
-				else if ((path_len > 0 || E.match_mode) && n_e > E.max_children && (flags & TF_MUST_DEFEND) == 0)
+				else if ((path_len > 0 || E.prune_root) && n_e > E.max_children && (flags & TF_MUST_DEFEND) == 0)
 				{ // prune_weak_moves, unproven branch (:69-83): the max_children best edges by EdgeComparator<MaxPolicyPrior>
 				  // (Edge.hpp:156-172: proven scores first, then prior), then those whose prior reaches threshold * (their prior sum).
 				  // std::partial_sort leaves the order of equal keys unspecified; here (and in the oracle) equal keys keep edge order.
@@ -1956,71 +2035,27 @@ namespace
 	 * run is reproducible: one workgroup scans the games of the launch's range, numbers the waiting ones and reserves that many
 	 * openings; games for which none is left keep waiting (agx_engine_add_openings can supply more).
 	 */
+	/* A finished game takes its next opening.  In the reference every GameGenerator draws its own openings (OpeningGenerator per generator,
+	 * GameGenerator.cpp:46-77); here slot s of S takes openings s, s + S, s + 2 S, ... — a function of the slot and of how many games it has
+	 * played, NOT of which slot finished first, so a pool plays the same games however it is sliced into groups and however their launches
+	 * interleave on their streams.  A slot whose next opening is not in the list yet waits (agx_engine_add_openings).  counters[1] keeps the
+	 * high-water mark (openings_taken). */
 	__global__ __launch_bounds__(1024) void k_assign_openings(EngineDev E, int count)
 	{
-		__shared__ int scan[1024];
-		__shared__ int sh_base, sh_take, sh_running;
-		const int tid = threadIdx.x;
-		if (tid == 0)
-			sh_running = 0;
-		__syncthreads();
-		// pass 1: how many games wait
-		int mine = 0;
-		for (int i = tid; i < count; i += 1024)
-			mine += (E.games[E.g0 + i].restart_id == -1) ? 1 : 0;
-		scan[tid] = mine;
-		__syncthreads();
-		for (int o = 512; o > 0; o >>= 1)
+		const int slots = E.shared_tree ? 1 : (E.match_mode ? E.n_games / 2 : E.n_games);
+		for (int i = threadIdx.x; i < count; i += 1024)
 		{
-			if (tid < o)
-				scan[tid] += scan[tid + o];
-			__syncthreads();
-		}
-		if (tid == 0)
-		{
-			const int wanted = scan[0];
-			int base = 0, take = 0;
-			if (wanted > 0)
+			GameState &gs = E.games[E.g0 + i];
+			if (gs.restart_id != -1)
+				continue;
+			// (match mode: a pair plays every opening twice, colours swapped — games_done counts games, the opening changes every other one)
+			const int round = E.match_mode ? gs.games_done / 2 : gs.games_done;
+			const long long id = static_cast<long long>(E.g0 + i) + static_cast<long long>(slots) * round;
+			if (id < E.n_openings)
 			{
-				int seen = __hip_atomic_load(&E.counters[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				while (true)
-				{ // reserve min(wanted, openings left); another group's launch may be doing the same on its stream
-					take = max(0, min(wanted, E.n_openings - seen));
-					const int prev = atomicCAS(&E.counters[1], seen, seen + take);
-					if (prev == seen)
-						break;
-					seen = prev;
-				}
-				base = seen;
+				gs.restart_id = static_cast<int>(id) + 1;
+				atomicMax(&E.counters[1], static_cast<int>(id) + 1);
 			}
-			sh_base = base;
-			sh_take = take;
-		}
-		__syncthreads();
-		if (sh_take == 0)
-			return;
-		// pass 2: number the waiting games in game order, chunk by chunk
-		for (int start = 0; start < count; start += 1024)
-		{
-			const int i = start + tid;
-			const int waiting = (i < count && E.games[E.g0 + i].restart_id == -1) ? 1 : 0;
-			__syncthreads();
-			scan[tid] = waiting;
-			__syncthreads();
-			for (int o = 1; o < 1024; o <<= 1)
-			{
-				const int v = (tid >= o) ? scan[tid - o] : 0;
-				__syncthreads();
-				scan[tid] += v;
-				__syncthreads();
-			}
-			const int rank = sh_running + scan[tid] - waiting;
-			if (waiting && rank < sh_take)
-				E.games[E.g0 + i].restart_id = sh_base + rank + 1;
-			__syncthreads();
-			if (tid == 1023)
-				sh_running += scan[1023];
-			__syncthreads();
 		}
 	}
 	/*
@@ -2341,6 +2376,46 @@ namespace
 		gs.grow_pending = 2;
 	}
 
+	/* Tree::setBoard(board, signToMove) + Search::setBoard + Search::cleanup for ONE game driven from outside (evaluation/Player.cpp:100-110):
+	 * the position becomes the tree's base board, every cached state that can still be reached from it is kept (NodeCache::cleanup:
+	 * compaction into the other arena, table rebuilt), the root is whatever the cache holds for it, abandoned tasks are dropped and the
+	 * solver table ages by one generation (Tree.cpp:128-151, Search.cpp:112-115,233-242). */
+	__global__ __launch_bounds__(256) void k_set_board(EngineDev E, int g, const uint8_t *board, int sign_to_move)
+	{
+		__shared__ u64 scratch[4];
+		__shared__ int scan_nodes[256], scan_edges[256];
+		const int tid = threadIdx.x;
+		GameState &gs = E.games[g];
+		for (int i = tid; i < E.hw; i += 256)
+			gs.board[i] = board[i];
+		if (tid < BWORDS)
+			gs.cboard[tid] = 0;
+		__syncthreads();
+		if (tid == 0)
+		{
+			int stones = 0;
+			for (int cell = 0; cell < E.hw; cell++)
+				if (board[cell] != 0)
+				{
+					gs.cboard[cell >> 5] |= static_cast<u64>(board[cell] & 3) << (2 * (cell & 31));
+					stones++;
+				}
+			gs.sign_to_move = sign_to_move;
+			gs.n_moves = stones;
+			gs.outcome = 0;
+			gs.n_tasks = 0;
+			gs.need_move = 0;
+			gs.solve_pos = 0;
+			gs.solve_pending = 0;
+			gs.grow_pending = 0;
+			gs.noise_ready = 0;
+			gs.restart_id = 0;
+			gs.active = 1;
+		}
+		__syncthreads();
+		rebase_tree<256>(E, g, tid, scratch, scan_nodes, scan_edges);
+	}
+
 	__global__ void k_reset_counter(int *counter, int *second)
 	{
 		*counter = 0;
@@ -2465,6 +2540,7 @@ struct AgxEngine
 		// (separate k_select / k_solve times in agx_engine_kernel_timing and in profiles)
 		bool fuse_select = true;
 		// AgxEngineConfig.speculative_solver: select + solver as one persistent launch with the leaves of a batch solved in parallel (k_search_spec)
+		uint8_t *board_staging = nullptr; // agx_engine_set_board: the caller's board on its way to the device
 		bool speculative = false;
 		int spec_waves = 0; // waves of that launch over the whole pool
 		// optional per-kernel timing (agx_engine_kernel_timing): HIP events on the launch stream around every kernel of a step
@@ -2595,6 +2671,7 @@ int agx_engine_default_config(AgxEngineConfig *cfg)
 	cfg->game_end_capacity = 0;
 	cfg->speculative_solver = 0;
 	cfg->speculative_waves = 0;
+	cfg->force_expand_root = 1;
 	cfg->noise_type = 0;
 	cfg->noise_weight = 0.0f;
 	cfg->noise_seed = 0x2545F4914F6CDD1Dull;
@@ -2705,7 +2782,6 @@ int agx_engine_create(const AgxEngineConfig *cfg, AgxEngine **out)
 	AGX_TRY(dev_alloc(e, &d.frame_spill, areas * MAX_FRAMES));
 	d.spec_group = 0;
 	d.spec_waves = e->spec_waves;
-	d.spec_debug = getenv("AGX_SPEC_DEBUG") ? atoi(getenv("AGX_SPEC_DEBUG")) : 0;
 	AGX_TRY(dev_alloc(e, &d.spec_prof, 16));
 	AGX_TRY(dev_alloc(e, &d.spec_trace, 4 * G));
 	(void) hipMemset(d.spec_trace, 0, 4 * G * sizeof(unsigned long long));
@@ -2732,6 +2808,7 @@ int agx_engine_create(const AgxEngineConfig *cfg, AgxEngine **out)
 	AGX_TRY(dev_alloc(e, &d.nn_value, G * d.batch * 3));
 	d.has_q = cfg->action_values ? 1 : 0;
 	d.match_mode = cfg->match_mode ? 1 : 0;
+	d.prune_root = (cfg->match_mode || !cfg->force_expand_root) ? 1 : 0; // UnifiedGenerator(.., forceExpandRoot): true in self-play (GameGenerator.cpp:183-184), false for a Player (Player.cpp:109)
 	d.shared_tree = (cfg->search_threads > 1) ? 1 : 0;
 	d.policy_temperature = cfg->policy_temperature;
 	AGX_TRY(dev_alloc(e, &d.nn_q, d.has_q ? G * d.batch * d.hw * 2 : 1));
@@ -2901,9 +2978,10 @@ static constexpr int CLEAR_PARTS = 16; // workgroups per restarting game in k_cl
 			hipLaunchKernelGGL((k_solve<false, 0, FUSED>), grid, block, 0, s, d); \
 	} while (0)
 #endif
-__global__ void k_reset_spec(int *nn_counter, int *nn_second, int *spec_counters)
+__global__ void k_reset_spec(int *nn_counter, int *nn_second, int *spec_counters, int *done_counter)
 {
 	*nn_counter = 0;
+	*done_counter = 0;
 	if (nn_second != nullptr)
 		*nn_second = 0;
 	for (int i = 0; i < 4; i++)
@@ -2990,7 +3068,8 @@ int agx_engine_select_solve_group(AgxEngine *e, int group, int n_groups, void *s
 		if (st != AGX_OK)
 			return st;
 		hipStream_t s = static_cast<hipStream_t>(stream);
-		hipLaunchKernelGGL(k_reset_spec, dim3(1), dim3(1), 0, s, d.counters + d.nn_counter, static_cast<int*>(nullptr), d.counters + SPEC_COUNTER0 + 4 * group);
+		hipLaunchKernelGGL(k_reset_spec, dim3(1), dim3(1), 0, s, d.counters + d.nn_counter, static_cast<int*>(nullptr), d.counters + SPEC_COUNTER0 + 4 * group,
+				d.counters + d.yield_counter);
 		{
 			KernelTimer t(e, s, 1);
 			launch_search_spec(d, count, group, std::max(1, e->spec_waves / n_groups), s);
@@ -3043,7 +3122,7 @@ int agx_engine_select_solve_match(AgxEngine *e, void *stream)
 	hipLaunchKernelGGL(k_reset_counter, dim3(1), dim3(1), 0, s, d.counters + 17, static_cast<int*>(nullptr));
 	if (e->speculative)
 	{
-		hipLaunchKernelGGL(k_reset_spec, dim3(1), dim3(1), 0, s, d.counters + 16, d.counters + 17, d.counters + SPEC_COUNTER0);
+		hipLaunchKernelGGL(k_reset_spec, dim3(1), dim3(1), 0, s, d.counters + 16, d.counters + 17, d.counters + SPEC_COUNTER0, d.counters + 32);
 		KernelTimer t(e, s, 1);
 		launch_search_spec(d, d.n_games, 0, e->spec_waves, s);
 	}
@@ -3251,6 +3330,42 @@ int agx_engine_match_results(AgxEngine *e, int *h_results, int pair_capacity)
 	return AGX_OK;
 }
 
+int agx_engine_set_board(AgxEngine *e, int game, const uint8_t *h_board, int sign_to_move, void *stream)
+{
+	AGX_REQUIRE(e != nullptr && h_board != nullptr, AGX_ERR_INVALID, "agx_engine_set_board: null argument");
+	AGX_REQUIRE(e->begun, AGX_ERR_STATE, "agx_engine_set_board: agx_engine_begin has not been called");
+	AGX_REQUIRE(game >= 0 && game < e->dev.n_games, AGX_ERR_INVALID, "agx_engine_set_board: game %d of %d", game, e->dev.n_games);
+	AGX_REQUIRE(sign_to_move == 1 || sign_to_move == 2, AGX_ERR_INVALID, "agx_engine_set_board: sign_to_move must be 1 (cross) or 2 (circle)");
+	AGX_REQUIRE(!e->dev.match_mode && !e->dev.shared_tree, AGX_ERR_STATE, "agx_engine_set_board: the engine plays its own games (match_mode / search_threads)");
+	for (int i = 0; i < e->dev.hw; i++)
+		AGX_REQUIRE(h_board[i] <= 2, AGX_ERR_INVALID, "agx_engine_set_board: cell %d holds %d (0 empty, 1 cross, 2 circle)", i, h_board[i]);
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	if (e->board_staging == nullptr)
+	{
+		AGX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e->board_staging), MAXHW));
+		e->allocations.push_back(e->board_staging);
+	}
+	AGX_HIP_CHECK(hipStreamSynchronize(s)); // (the staging buffer of the previous call may still be read)
+	AGX_HIP_CHECK(hipMemcpy(e->board_staging, h_board, e->dev.hw, hipMemcpyHostToDevice));
+	hipLaunchKernelGGL(k_set_board, dim3(1), dim3(256), 0, s, e->dev, game, e->board_staging, sign_to_move);
+	AGX_HIP_CHECK(hipGetLastError());
+	return AGX_OK;
+}
+int agx_engine_set_force_expand_root(AgxEngine *e, int force_expand_root)
+{
+	AGX_REQUIRE(e != nullptr, AGX_ERR_INVALID, "agx_engine_set_force_expand_root: null engine");
+	AGX_REQUIRE(!e->dev.match_mode, AGX_ERR_STATE, "agx_engine_set_force_expand_root: a match-mode engine always prunes the root");
+	e->dev.prune_root = force_expand_root ? 0 : 1;
+	e->cfg.force_expand_root = force_expand_root ? 1 : 0;
+	return AGX_OK;
+}
+int agx_engine_set_max_simulations(AgxEngine *e, int max_simulations)
+{
+	AGX_REQUIRE(e != nullptr && max_simulations > 0, AGX_ERR_INVALID, "agx_engine_set_max_simulations: invalid argument");
+	e->dev.max_sims = max_simulations;
+	e->cfg.max_simulations = max_simulations;
+	return AGX_OK;
+}
 int agx_engine_stats(AgxEngine *e, AgxEngineStats *out)
 {
 	AGX_REQUIRE(e != nullptr && out != nullptr, AGX_ERR_INVALID, "agx_engine_stats: null argument");
@@ -3273,6 +3388,7 @@ int agx_engine_stats(AgxEngine *e, AgxEngineStats *out)
 		out->duplicate_selections += g.stats[9];
 		out->speculative_solves += g.spec_stats[0];
 		out->speculative_reruns += g.spec_stats[1];
+		out->speculative_deferrals += g.spec_stats[2];
 		out->peak_nodes = std::max<unsigned long long>(out->peak_nodes, g.stats[10]);
 		out->peak_edges = std::max<unsigned long long>(out->peak_edges, g.stats[11]);
 		out->active_games += g.active ? 1 : 0;
@@ -3530,40 +3646,98 @@ int agx_stream_create(void **out)
  * that own disjoint parts of the chip */
 namespace
 {
+	/* hipStreamDestroy of a CU-masked stream hangs on ROCm 7.2, so such a stream lives until the process exits — and therefore must not be
+	 * created twice: the streams are cached process-wide by (device, mask).  A generator thread that sets its slices up again for every
+	 * training iteration (GeneratorManager::generate, once per iteration in the reference) gets the same streams back instead of leaking a
+	 * hardware queue per slice and iteration. */
+	struct MaskedStream
+	{
+			int device, instance;
+			std::vector<uint32_t> mask;
+			hipStream_t stream;
+	};
 	std::mutex g_masked_streams_mutex;
-	std::vector<hipStream_t> g_masked_streams; // hipStreamDestroy of a CU-masked stream hangs on ROCm 7.2: they live until the process exits
+	std::vector<MaskedStream> g_masked_streams;
 }
 int agx_stream_create_with_cu_mask(void **out, const uint32_t *mask, int words)
+{
+	return agx_stream_create_with_cu_mask_instance(out, mask, words, 0);
+}
+int agx_stream_create_with_cu_mask_instance(void **out, const uint32_t *mask, int words, int instance)
 {
 	AGX_REQUIRE(out != nullptr && mask != nullptr && words > 0, AGX_ERR_INVALID, "agx_stream_create_with_cu_mask: invalid argument");
 	bool any = false;
 	for (int i = 0; i < words; i++)
 		any = any || mask[i] != 0u;
 	AGX_REQUIRE(any, AGX_ERR_INVALID, "agx_stream_create_with_cu_mask: the mask selects no compute unit");
+	int device = 0;
+	AGX_HIP_CHECK(hipGetDevice(&device));
+	std::vector<uint32_t> key(mask, mask + words);
+	while (key.size() > 1 && key.back() == 0u)
+		key.pop_back(); // (trailing zero words select nothing: the same mask)
+	std::lock_guard<std::mutex> lock(g_masked_streams_mutex);
+	for (const MaskedStream &m : g_masked_streams)
+		if (m.device == device && m.instance == instance && m.mask == key)
+		{
+			*out = m.stream;
+			return AGX_OK;
+		}
 	hipStream_t s = nullptr;
 	AGX_HIP_CHECK(hipExtStreamCreateWithCUMask(&s, static_cast<uint32_t>(words), mask));
-	{
-		std::lock_guard<std::mutex> lock(g_masked_streams_mutex);
-		g_masked_streams.push_back(s);
-	}
+	g_masked_streams.push_back(MaskedStream { device, instance, key, s });
 	*out = s;
 	return AGX_OK;
+}
+int agx_stream_masked_count(void)
+{
+	std::lock_guard<std::mutex> lock(g_masked_streams_mutex);
+	return static_cast<int>(g_masked_streams.size());
 }
 int agx_stream_destroy(void *stream)
 {
 	if (stream == nullptr)
 		return AGX_OK;
 	hipStream_t s = static_cast<hipStream_t>(stream);
+	bool masked = false;
 	{
 		std::lock_guard<std::mutex> lock(g_masked_streams_mutex);
-		for (hipStream_t m : g_masked_streams)
-			if (m == s)
-			{ // drained, not destroyed (see above)
-				AGX_HIP_CHECK(hipStreamSynchronize(s));
-				return AGX_OK;
-			}
+		for (const MaskedStream &m : g_masked_streams)
+			masked = masked || (m.stream == s);
+	}
+	if (masked)
+	{ // drained (outside the lock), not destroyed: it stays in the cache for the next caller
+		AGX_HIP_CHECK(hipStreamSynchronize(s));
+		return AGX_OK;
 	}
 	AGX_HIP_CHECK(hipStreamDestroy(s));
+	return AGX_OK;
+}
+/* events: ordering between streams without the host (a slice's tower launch on the network partition waits for its search launch on the
+ * search partition and the other way round) */
+int agx_event_create(void **out)
+{
+	AGX_REQUIRE(out != nullptr, AGX_ERR_INVALID, "agx_event_create: null argument");
+	hipEvent_t ev = nullptr;
+	AGX_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+	*out = ev;
+	return AGX_OK;
+}
+int agx_event_record(void *event, void *stream)
+{
+	AGX_REQUIRE(event != nullptr, AGX_ERR_INVALID, "agx_event_record: null event");
+	AGX_HIP_CHECK(hipEventRecord(static_cast<hipEvent_t>(event), static_cast<hipStream_t>(stream)));
+	return AGX_OK;
+}
+int agx_stream_wait_event(void *stream, void *event)
+{
+	AGX_REQUIRE(event != nullptr, AGX_ERR_INVALID, "agx_stream_wait_event: null event");
+	AGX_HIP_CHECK(hipStreamWaitEvent(static_cast<hipStream_t>(stream), static_cast<hipEvent_t>(event), 0));
+	return AGX_OK;
+}
+int agx_event_destroy(void *event)
+{
+	if (event != nullptr)
+		AGX_HIP_CHECK(hipEventDestroy(static_cast<hipEvent_t>(event)));
 	return AGX_OK;
 }
 int agx_stream_synchronize(void *stream)

@@ -121,7 +121,7 @@ namespace agx
 			uint64_t cboard[BWORDS];
 			unsigned long long prof[8];   // optional cycle counters (AGX_SOLVER_PROFILE builds only)
 			unsigned long long dprof[24]; // finer stage stamps of the same builds (shader cycles)
-			unsigned long long spec_stats[2]; // speculative solver: leaves solved against the pre-batch table, of which re-run serially
+			unsigned long long spec_stats[4]; // speculative solver: leaves solved against the pre-batch table, of which re-run serially, batches deferred, pad
 			unsigned long long stats[12]; // nodes, nn, leaks, proven, wasted, solver nodes, select levels, select edges, moves, duplicates, max nodes, max edges
 			uint8_t board[MAXHW];
 			uint16_t moves[MAXHW];
@@ -252,13 +252,13 @@ namespace agx
 			float *nn_q;           // [game*batch][hw][2] action values (win, draw) per cell, 'pvq' networks only
 			int has_q;
 			int match_merged; // this launch covers both players' trees: network slot lists by half of the pool, not by launch
+			int prune_root;  // the root is pruned like any node (UnifiedGenerator without forceExpandRoot: evaluation players)
 			int match_mode;  // evaluation matches: tree g (first player) and tree g + n_games / 2 (second player) share one game
 			int shared_tree; // tournament search: the n_games records are the search threads of ONE tree (game 0): own task buffer and solver each
 			// speculative solver
 			int spec_group;        // index of this launch's group (its queue segment and counters)
 			unsigned long long *spec_trace; // AGX_SPEC_PROFILE builds: [game][4] time stamps of the last launch
 			unsigned long long *spec_prof; // AGX_SPEC_PROFILE builds: time sums of k_search_spec
-			int spec_debug;        // developer switch: stop the launch after a stage
 			int spec_waves;        // waves of this launch (its spill areas start at area n_games + spec_group * spec_waves)
 			int *spec_items;       // [n_games * batch + 16 * SPEC_QUEUE_SLACK] work queue: (game * 16 + task) + 1, 0 = empty
 			int *spec_left;        // [game] tasks of the batch still being solved

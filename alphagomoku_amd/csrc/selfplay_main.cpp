@@ -112,7 +112,7 @@ static void run_device(int device, int thread_index, const Options &o, AgxGameBu
 					result.samples += records.size();
 				}
 				const AgxEngineStats st = pool.getStats();
-				if (st.openings_taken + o.games / 2 > n_openings)
+				if (st.openings_taken + o.games > n_openings) // (slot s plays openings s, s + games, ...: a whole round ahead of the furthest slot)
 				{
 					pool.addOpenings(make_openings(o.games));
 					n_openings += o.games;

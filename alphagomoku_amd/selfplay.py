@@ -43,6 +43,35 @@ def chip_slices(n_slices):
     return streams, per
 
 
+def cu_mask_stream(first_cu, n_cus, instance=0):
+    """a stream whose kernels run on compute units [first_cu, first_cu + n_cus); `instance` distinguishes several streams on one mask"""
+    total = ctypes.c_int()
+    check(lib.agx_device_cu_count(ctypes.byref(total)))
+    if first_cu < 0 or n_cus < 1 or first_cu + n_cus > total.value:
+        raise ValueError("compute units [%d, %d) of %d" % (first_cu, first_cu + n_cus, total.value))
+    words = (total.value + 31) // 32
+    mask = [0] * words
+    for c in range(first_cu, first_cu + n_cus):
+        mask[c // 32] |= 1 << (c % 32)
+    s = ctypes.c_void_p()
+    check(lib.agx_stream_create_with_cu_mask_instance(ctypes.byref(s), (ctypes.c_uint32 * words)(*mask), words, instance))
+    return s
+
+
+def chip_partitions(n_slices, network_cus):
+    """The chip as TWO partitions shared by all slices of a pool: the first `network_cus` compute units run every slice's network launches,
+    the rest every slice's search / tree launches (one stream per slice on each partition, ordered by events).  Slices in different phases
+    fill each other's gaps on the search partition, and the matrix cores of the network partition always have a slice to work for.
+    Returns (search_streams, network_streams, search_cus, network_cus)."""
+    total = ctypes.c_int()
+    check(lib.agx_device_cu_count(ctypes.byref(total)))
+    if not 0 < network_cus < total.value:
+        raise ValueError("network partition of %d compute units on a device with %d" % (network_cus, total.value))
+    search = [cu_mask_stream(network_cus, total.value - network_cus, instance=k) for k in range(n_slices)]
+    network = [cu_mask_stream(0, network_cus, instance=k) for k in range(n_slices)]
+    return search, network, total.value - network_cus, network_cus
+
+
 def pack_openings(openings):
     """list of lists of Move::toShort -> uint16 [n][OPENING_CAP]"""
     out = np.zeros((len(openings), OPENING_CAP), dtype=np.uint16)
@@ -83,6 +112,18 @@ class GeneratorPool:
 
     def step_group(self, net, group, n_groups, stream=None):
         check(lib.agx_engine_step_group(self._h, net._net, group, n_groups, stream))
+
+    def expand_only(self, stream=None):
+        """Search::generateEdges + expand + backup without the engine's own move rule (a game driven from outside: set_board)"""
+        check(lib.agx_engine_expand_group(self._h, 0, 1, stream))
+
+    def set_board(self, game, board, sign_to_move, stream=None):
+        """Search::cleanup + Tree::setBoard(board, signToMove) + Search::setBoard for one game (evaluation/Player.cpp:100-110)"""
+        b = np.ascontiguousarray(board, dtype=np.uint8).reshape(-1)
+        check(lib.agx_engine_set_board(self._h, game, b.ctypes.data_as(ctypes.c_void_p), int(sign_to_move), stream))
+
+    def set_max_simulations(self, n):
+        check(lib.agx_engine_set_max_simulations(self._h, int(n)))
 
     def select_solve_group(self, group, n_groups, stream=None):
         check(lib.agx_engine_select_solve_group(self._h, group, n_groups, stream))

@@ -52,7 +52,8 @@ def cpu_baseline(args, max_seconds):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as ol
     lib = ol.load()
-    cores = os.cpu_count() or 1
+    # the CPUs this process may run on (affinity / cgroup view), not the machine's total
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     cfg = ol.default_search_config(max_batch_size=args.batch, max_simulations=args.sims, table_entries=4 * 1024 * 1024)
 
     def leg(threads, seconds):
@@ -78,7 +79,10 @@ def cpu_baseline(args, max_seconds):
                 sample="%d threads x 1 self-play game each (same rules/board/playouts/batch, stand-in evaluator, NN cost excluded), %.1f s wall, %d simulations, %d moves; "
                        "thread count chosen by short probes over %s threads (every host CPU is slower: one 64 MB solver table per game)"
                        % (best["threads"], best["seconds"], best["simulations"], best["moves"], counts),
-                host_cpus=cores, per_thread=best["per_thread"], sweep=legs,
+                host_cpus=cores, host_cpus_total=os.cpu_count(), per_thread=best["per_thread"], sweep=legs,
+                # why more threads are slower: every thread owns a 64 MB solver table (the reference's size) and touches it at random, so n threads
+                # keep n x 64 MB hot — beyond the last-level cache the threads queue on DRAM, and past the physical cores they also share them
+                scaling_note="one 64 MB transposition table per game thread, randomly accessed: the working set leaves the last-level cache",
                 # the REAL reference search core (compiled with AVX2 intrinsics, one thread, fake evaluator) measured 10.5 k/s for this
                 # shape in the survey container; the oracle is a scalar restatement (no SSE/AVX neighbourhood code) and every game owns a 64 MB
                 # solver table, so with many games per socket the tables live in DRAM, not in cache
@@ -101,16 +105,33 @@ def main():
     ap.add_argument("--rules", type=int, default=0)
     ap.add_argument("--action-values", type=int, default=0, help="1: ResnetPVQ network (extra action-values head feeding the edge Q)")
     ap.add_argument("--table-entries", type=int, default=4 * 1024 * 1024)
-    ap.add_argument("--yield-fraction", type=float, default=0.75, help="solver straggler cut-off (0 = lock-step pool)")
+    ap.add_argument("--yield-fraction", type=float, default=0.9,
+                    help="straggler cut-off of the search launch: once this fraction of its games is done, a game whose batch still needs a serial re-run\n"
+                         "(speculative solver) or another serial solve sits this step out (0 = never)")
     ap.add_argument("--slices", type=int, default=4,
                     help="the pool stepped as this many slices on streams that own disjoint blocks of the chip's compute units (1 = one lock-step pool)")
     ap.add_argument("--speculative", type=int, default=1,
                     help="1: select + threat solver as one persistent launch with the leaves of a batch solved in parallel (AgxEngineConfig.speculative_solver)")
     ap.add_argument("--speculative-waves", type=int, default=0, help="waves of that launch over the whole pool, 0 = 12 per compute unit")
+    ap.add_argument("--config", default="", help="BASELINE.json preset: C2 (the default), C3 (standard, 10x128, 800 playouts: with --gpus 8 = configs[2]), "
+                                                 "C4 (caro5 20x20, 10x128), C5 (renju, 10x128, 1600 playouts)")
+    ap.add_argument("--age-steps", type=int, default=-1,
+                    help="untimed pool steps before the timed region so that a short run measures the steady state (trees of ~2 k nodes, slices out of "
+                         "phase) instead of the opening phase; -1 = 3000 when --steps < 3000, else 0")
+    ap.add_argument("--network-cus", type=int, default=0,
+                    help="> 0: the chip as two partitions shared by all slices — this many compute units run every slice's network launches, the rest "
+                         "every slice's search launches (streams ordered by events); 0: every slice owns 1 / slices of the chip for all its stages")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=24.0)
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline, 0 = every host CPU")
     args = ap.parse_args()
+    presets = {"": {}, "C2": {}, "C3": dict(rules=1, blocks=10, sims=800), "C4": dict(rules=3, board=20, blocks=10), "C5": dict(rules=2, blocks=10, sims=1600)}
+    if args.config.upper() not in presets:
+        raise SystemExit("bench.py: unknown --config %s (C2, C3, C4, C5)" % args.config)
+    for key, value in presets[args.config.upper()].items():
+        setattr(args, key, value)
+    if args.age_steps < 0:
+        args.age_steps = 3000 if args.steps < 3000 else 0
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: become the launcher of N ranks (nothing has touched a GPU yet: no library, no torch.cuda)
@@ -174,7 +195,17 @@ def main():
     while slices > 1 and (args.games % slices != 0 or args.games // slices < 4):
         slices //= 2
     streams, cus_per_slice, total_cus = [None], None, None
-    if slices > 1:
+    net_streams, events = None, None
+    if slices > 1 and args.network_cus > 0:
+        streams, net_streams, search_cus, cus_per_slice = selfplay.chip_partitions(slices, args.network_cus)
+        total_cus = search_cus + cus_per_slice
+        check(lib.agx_net_set_launch_width(net._net, cus_per_slice))
+        events = []
+        for _ in range(2 * slices):
+            ev = ctypes.c_void_p()
+            check(lib.agx_event_create(ctypes.byref(ev)))
+            events.append(ev)
+    elif slices > 1:
         try:
             streams, cus_per_slice = selfplay.chip_slices(slices)
             total_cus = cus_per_slice * slices
@@ -185,16 +216,38 @@ def main():
 
     def step_slice(g, nn_timer=None):
         pool.select_solve_group(g, slices, streams[g])
+        ns = streams[g]
+        if net_streams is not None:   # the tower runs on the network partition: its stream waits for the search launch, and the search stream for it
+            ns = net_streams[g]
+            check(lib.agx_event_record(events[2 * g], streams[g]))
+            check(lib.agx_stream_wait_event(ns, events[2 * g]))
         if nn_timer is not None:
-            check(lib.agx_timer_start(nn_timer, streams[g]))
-        pool.evaluate_group(net, g, slices, streams[g])
+            check(lib.agx_timer_start(nn_timer, ns))
+        pool.evaluate_group(net, g, slices, ns)
         if nn_timer is not None:
-            check(lib.agx_timer_stop(nn_timer, streams[g]))
+            check(lib.agx_timer_stop(nn_timer, ns))
+        if net_streams is not None:
+            check(lib.agx_event_record(events[2 * g + 1], ns))
+            check(lib.agx_stream_wait_event(streams[g], events[2 * g + 1]))
         pool.expand_backup_group(g, slices, streams[g])
 
-    for _ in range(args.warmup):
+    def keep_going(i):
+        # what a generator thread does every few hundred steps — hand the finished samples over (GeneratorManager.cpp:160-164) and keep the
+        # opening list ahead of the games
+        nonlocal n_openings
+        if (i + 1) % 256 == 0:
+            pool.fetch_records(drain=True)   # format-201 samples (6 bytes per visited cell) + finished games
+            if pool.stats()["openings_taken"] + args.games > n_openings:
+                extra = synthetic.make_openings(args.board, args.games, seed0=distributed.rank_seed_base(rank) + n_openings, rules=args.rules)
+                pool.add_openings(selfplay.pack_openings(extra))
+                n_openings += args.games
+
+    # untimed: warm-up launches, then the pool is AGED so that a short timed region sees what a long run sees — games in every phase, trees of a
+    # couple of thousand nodes, arenas that have grown, slices out of phase (fresh games alone are the opening phase: small trees, no game ends)
+    for i in range(args.warmup + args.age_steps):
         for g in range(slices):
             step_slice(g)
+        keep_going(i)
     check(lib.agx_device_synchronize())
     s0 = pool.stats()
     pool.kernel_timing(True)   # HIP events around every engine kernel, on the launch stream
@@ -207,14 +260,7 @@ def main():
     for i in range(args.steps):
         for g in range(slices):
             step_slice(g, t_nn[g][i])
-        if (i + 1) % 256 == 0:
-            # long runs only (the default 150 steps never get here): what a generator thread does every few hundred steps — hand the
-            # finished samples over (GeneratorManager.cpp:160-164) and keep the opening list ahead of the games
-            pool.fetch_records(drain=True)   # format-201 samples (6 bytes per visited cell) + finished games
-            if pool.stats()["openings_taken"] + args.games > n_openings:
-                extra = synthetic.make_openings(args.board, args.games, seed0=distributed.rank_seed_base(rank) + n_openings, rules=args.rules)
-                pool.add_openings(selfplay.pack_openings(extra))
-                n_openings += args.games
+        keep_going(i)
     check(lib.agx_device_synchronize())
     if dist is not None:
         dist.barrier()
@@ -241,12 +287,16 @@ def main():
     edge_reads = s1["select_edge_reads"] - s0["select_edge_reads"]
     solver_nodes = s1["solver_nodes"] - s0["solver_nodes"]
     leaks = s1["information_leaks"] - s0["information_leaks"]
-    if s1["first_error"] != 0:
-        raise RuntimeError("device engine stopped with error code %d" % s1["first_error"])
-
     local_elapsed = elapsed
-    per_rank = distributed.gather(dist, [sims, local_elapsed, distributed.rank_seed_base(rank), int(os.environ.get("AGX_FORCE_DEVICE", local_rank))])
+    per_rank = distributed.gather(dist, [sims, local_elapsed, distributed.rank_seed_base(rank), int(os.environ.get("AGX_FORCE_DEVICE", local_rank)),
+                                         s1["first_error"]])
     elapsed, (sims, evals, moves, games_done) = distributed.combine(dist, elapsed, [sims, evals, moves, games_done])
+    # an engine error on ANY rank fails every rank, after the collectives (a rank that raised before them would leave the others waiting)
+    failed = [(i, int(r[4])) for i, r in enumerate(per_rank) if int(r[4]) != 0]
+    if failed:
+        if dist is not None:
+            dist.destroy_process_group()
+        raise RuntimeError("device engine stopped: %s" % ", ".join("rank %d error code %d" % f for f in failed))
 
     if rank == 0:
         flops = nn_flops_per_position(desc)
@@ -271,14 +321,14 @@ def main():
         tree_bytes = update_bytes if fused else select_bytes + update_bytes
         tree_ms = (0.0 if fused else kernel_ms[0]) + kernel_ms[2] + kernel_ms[3]
         local_sims = s1["evaluated_nodes"] - s0["evaluated_nodes"]
-        tree_gbs = local_sims * tree_bytes / (tree_ms / slices * 1e-3) / 1e9 if tree_ms > 0 else 0.0   # the slices' tree launches overlap
+        tree_gbs = local_sims * tree_bytes / (tree_ms * 1e-3) / 1e9 * slices if tree_ms > 0 else 0.0   # per launch x slices (a slice's launches own their CUs)
         # PMC-derived figures cannot be sampled from inside this process (rocprofv3 --pmc passes, scripts/pmc_summary.py).  They are quoted only
         # when the committed summary was taken from THIS build (same source hash) and this workload; otherwise null.
         traffic = None
         mfma_busy = None
         solver_issue = None
         nn_clock = None
-        pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
+        pmc_path = os.path.join(ROOT, "profiles", "r03_pmc_summary.json")
         src_hash = source_hash()
         pmc_build = None
         if os.path.exists(pmc_path):
@@ -300,6 +350,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "aged_steps": args.age_steps,   # untimed pool steps before the timed region (steady state: see peak_tree_per_game)
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
             "scaling": "weak",
@@ -315,7 +366,8 @@ def main():
             "nn_positions_per_sec": evals / elapsed,
             # how the pool is stepped: `count` slices of games_per_gpu / count games, each on a stream that owns cus_per_slice compute units;
             # the slices' launches overlap in time, so the per-launch durations below add up to more than ms_per_step
-            "slices": {"count": slices, "cus_per_slice": cus_per_slice, "games_per_slice": args.games // slices},
+            "slices": {"count": slices, "cus_per_slice": cus_per_slice, "games_per_slice": args.games // slices,
+                       "partitions": ({"network_cus": cus_per_slice, "search_cus": total_cus - cus_per_slice} if net_streams is not None else None)},
             "stage_ms_per_step": {"select_solve": ms_sel / launches, "network": ms_nn / launches, "expand_backup_advance": ms_exp / launches,
                                   "of": "one slice's launches (average)"},
             "kernel_ms_per_step": {"k_select": kernel_ms[0] / launches, "k_solve": kernel_ms[1] / launches, "nn_tower": ms_nn / launches,
@@ -324,7 +376,8 @@ def main():
             # part of k_solve and k_select is 0; AGX_FUSE_SELECT=0 launches them separately
             "select_fused_into_solve": os.environ.get("AGX_FUSE_SELECT", "1") != "0",
             "speculative_solver": {"enabled": bool(args.speculative), "leaves_solved": int(s1["speculative_solves"] - s0["speculative_solves"]),
-                                   "rerun_serially": int(s1["speculative_reruns"] - s0["speculative_reruns"])},
+                                   "rerun_serially": int(s1["speculative_reruns"] - s0["speculative_reruns"]),
+                                   "batches_deferred": int(s1["speculative_deferrals"] - s0["speculative_deferrals"])},
             "peak_tree_per_game": {"nodes": int(s1["peak_nodes"]), "edges": int(s1["peak_edges"]), "class0_node_capacity": node_capacity,
                                    "class0_edge_capacity": edge_capacity, "arena_grows": int(s1["arena_grows"]), "arena_releases": int(s1["arena_releases"]),
                                    "arena_failures": int(s1["arena_failures"]), "arena_max_class": int(s1["arena_max_class"]),
@@ -351,8 +404,11 @@ def main():
                          "mfma_busy_fraction_pmc": mfma_busy,
                          # GRBM_GUI_ACTIVE / 8 / launch duration: the tower runs power-limited below the 2.4 GHz the 2.5 PFLOP/s peak assumes
                          # (frac keeps the nominal peak; this is the same rate against the MFMA issue rate at the clock actually held)
-                         "shader_clock_mhz_pmc": nn_clock,
-                         "frac_of_issue_rate_at_measured_clock": (nn_tflops / (nn_peak * nn_clock / 2400.0)) if nn_clock else None,
+                         # the clock of a launch of the (serialising) PMC passes, i.e. of a tower alone on an idle chip — not of the overlapped run
+                         "shader_clock_mhz_serialised_pmc_pass": nn_clock,
+                         # what the matrix cores deliver over the whole step, all slices: evaluated positions/s x FLOPs / 2.5 PFLOP/s (the tower
+                         # only runs part of each slice's cycle; the search kernels use no MFMA)
+                         "time_averaged_whole_chip_frac": (evals / elapsed) * flops / 2.5e15 / world,
                          "pmc_summary_build": pmc_build},
             "roofline_solver": {"bound": "none (instruction issue / dependent-chain latency: one wave per game, tasks of a game strictly ordered)",
                                 "kernel": "k_solve (select + threat solver of a game in one wave)" if os.environ.get("AGX_FUSE_SELECT", "1") != "0" else "k_solve", "ms_per_step": kernel_ms[1] / launches,

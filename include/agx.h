@@ -198,6 +198,9 @@ typedef struct AgxEngineConfig
 	                                     one wave per game.  0 (default): one wave per game, tasks in order.  Ignored by tournament-search pools and for
 	                                     solver budgets above 250 positions (the overlay holds 256 buckets). */
 	int speculative_waves;            /* waves of that launch over the whole pool, 0 = 12 per compute unit of the device */
+	int force_expand_root;            /* UnifiedGenerator's forceExpandRoot (EdgeGenerator.cpp:283-285): 1 (default, self-play: GameGenerator.cpp:183-184)
+	                                     never prunes the root's edges; 0 prunes the root like any node (evaluation Player, Player.cpp:109; match_mode
+	                                     engines always do) */
 } AgxEngineConfig;
 
 typedef struct AgxEngine AgxEngine; /* opaque */
@@ -242,6 +245,7 @@ typedef struct AgxEngineStats
 	int reserved0;
 	unsigned long long speculative_solves;    /* speculative_solver: leaves solved against the pre-batch table ... */
 	unsigned long long speculative_reruns;    /* ... and how many of them had to be solved again serially (conflict or full overlay) */
+	unsigned long long speculative_deferrals; /* batches whose commit was put off to the next launch (solver_yield_fraction) */
 } AgxEngineStats;
 
 typedef struct AgxEdgeView
@@ -345,8 +349,27 @@ int agx_stream_create(void** out_stream);
  * (agx_net_set_launch_width).  Do not destroy such a stream while the process lives (hipStreamDestroy of a CU-masked stream hangs on
  * ROCm 7.2): agx_stream_destroy leaves them to process exit. */
 int agx_stream_create_with_cu_mask(void** out_stream, const uint32_t* cu_mask, int n_words);
+/* the same, for callers that need several streams on one mask (the slices of a pool sharing the search partition of the chip): streams are
+ * cached by (device, mask, instance); instance 0 is what agx_stream_create_with_cu_mask returns */
+int agx_stream_create_with_cu_mask_instance(void** out_stream, const uint32_t* cu_mask, int n_words, int instance);
+/* events order launches across streams on the device (hipStreamWaitEvent): record on one stream, make another wait for it */
+int agx_event_create(void** out_event);
+int agx_event_record(void* event, void* stream);
+int agx_stream_wait_event(void* stream, void* event);
+int agx_event_destroy(void* event);
+/* streams agx_stream_create_with_cu_mask has created in this process: they are cached by (device, mask) and handed out again, never destroyed */
+int agx_stream_masked_count(void);
 int agx_stream_destroy(void* stream);
 int agx_stream_synchronize(void* stream);
+/* One game driven from OUTSIDE, the way evaluation/Player.cpp:100-129 drives a Tree / Search pair: agx_engine_set_board is
+ * Search::cleanup + Tree::setBoard(board, signToMove) + Search::setBoard (Tree.cpp:128-151: the cached states still reachable from the new
+ * position are kept, the root is the cached node of the position if there is one; the solver table ages by a generation); the caller then
+ * steps select_solve / evaluate / expand (agx_engine_expand_group: no move is played by the engine) until ITS stopping rule says so, reads the
+ * root (agx_engine_game_info) and decides the move.  h_board: one byte per cell, 0 empty / 1 cross / 2 circle.  forceRemoveRootNode is not
+ * provided.  agx_engine_set_max_simulations: the budget Search::select(tree, maxSimulations) takes per call. */
+int agx_engine_set_board(AgxEngine* engine, int game, const uint8_t* h_board, int sign_to_move, void* stream);
+int agx_engine_set_max_simulations(AgxEngine* engine, int max_simulations);
+int agx_engine_set_force_expand_root(AgxEngine* engine, int force_expand_root); /* AgxEngineConfig.force_expand_root, for the launches that follow */
 int agx_engine_buffers(AgxEngine* engine, AgxEngineBuffers* out);
 int agx_engine_stats(AgxEngine* engine, AgxEngineStats* out);
 /* Per-kernel timing of the engine's own launches, by HIP events recorded on the launch stream around every kernel (the role of

@@ -27,6 +27,28 @@ namespace ag
 	{ // game/Move.hpp:17-23
 		NONE, CROSS, CIRCLE, ILLEGAL
 	};
+	template<typename T>
+	class matrix
+	{ // utils/matrix.hpp: row-major rows x cols (the part of the interface the path's callers use)
+			std::vector<T> m_data;
+			int m_rows = 0, m_cols = 0;
+		public:
+			matrix() = default;
+			matrix(int rows, int cols) :
+					m_data(static_cast<size_t>(rows) * cols), m_rows(rows), m_cols(cols)
+			{
+			}
+			int rows() const noexcept { return m_rows; }
+			int cols() const noexcept { return m_cols; }
+			int size() const noexcept { return m_rows * m_cols; }
+			T* data() noexcept { return m_data.data(); }
+			const T* data() const noexcept { return m_data.data(); }
+			T& at(int r, int c) { return m_data.at(static_cast<size_t>(r) * m_cols + c); }
+			const T& at(int r, int c) const { return m_data.at(static_cast<size_t>(r) * m_cols + c); }
+			T& operator[](int i) noexcept { return m_data[i]; }
+			const T& operator[](int i) const noexcept { return m_data[i]; }
+			void fill(T value) { m_data.assign(m_data.size(), value); }
+	};
 	struct Move
 	{ // game/Move.hpp:92-174
 			Sign sign = Sign::NONE;
@@ -224,6 +246,47 @@ namespace ag
 			NNEvaluatorStats& operator/=(int i) noexcept;
 	};
 
+	/* EdgeSelector (monte_carlo/EdgeSelector.hpp:31-45).  The SEARCH selector ('puct') runs inside the device's select stage — an object of it
+	 * carries its configuration to Tree::setEdgeSelector, which accepts what the engine implements; the FINAL-move selectors ('best',
+	 * 'max_visit', 'min_visit', 'max_value', 'max_policy') run here, on the owning copy of the root Tree::getInfo returns (Player.cpp:205-212,
+	 * GameGenerator.cpp:161-163). */
+	class EdgeSelector
+	{
+		public:
+			EdgeSelector() noexcept = default;
+			EdgeSelector(const EdgeSelector &other) = delete;
+			EdgeSelector& operator=(const EdgeSelector &other) = delete;
+			virtual ~EdgeSelector() = default;
+			virtual std::unique_ptr<EdgeSelector> clone() const = 0;
+			virtual const Edge* select(const Node *node) noexcept = 0;
+			virtual const EdgeSelectorConfig& getConfig() const noexcept = 0;
+			static std::unique_ptr<EdgeSelector> create(const EdgeSelectorConfig &config);
+	};
+	/* EdgeGenerator / UnifiedGenerator (monte_carlo/EdgeGenerator.hpp:51-62): pruning and prior temperature of new nodes' edges; the work is
+	 * the first pass of the device's expand stage, the object carries the parameters to Tree::setEdgeGenerator */
+	class EdgeGenerator
+	{
+		public:
+			virtual ~EdgeGenerator() = default;
+			virtual std::unique_ptr<EdgeGenerator> clone() const = 0;
+	};
+	class UnifiedGenerator: public EdgeGenerator
+	{
+			int max_edges;
+			float expansion_threshold, temperature;
+			bool force_expand_root;
+		public:
+			UnifiedGenerator(int maxEdges, float expansionThreshold, float temperature, bool forceExpandRoot = false) :
+					max_edges(maxEdges), expansion_threshold(expansionThreshold), temperature(temperature), force_expand_root(forceExpandRoot)
+			{
+			}
+			std::unique_ptr<EdgeGenerator> clone() const { return std::make_unique<UnifiedGenerator>(max_edges, expansion_threshold, temperature, force_expand_root); }
+			int maxEdges() const noexcept { return max_edges; }
+			float expansionThreshold() const noexcept { return expansion_threshold; }
+			float policyTemperature() const noexcept { return temperature; }
+			bool forceExpandRoot() const noexcept { return force_expand_root; }
+	};
+
 	class Tree;
 	class NNEvaluator
 	{ // NNEvaluator.hpp:42-83
@@ -318,10 +381,11 @@ namespace ag
 	{
 			AgxEngine *engine = nullptr;
 			GameConfig game_config;
+			SearchConfig search_config;
 			int games = 0, batch = 0;
 		public:
 			GamePool(const GameConfig &gameOptions, const SearchConfig &searchOptions, const EdgeSelectorConfig &finalSelector, int games, int maxSimulations,
-					bool useSymmetries, const std::string &networkOutputs);
+					bool useSymmetries, const std::string &networkOutputs, bool forceExpandRoot = true);
 			GamePool(const GamePool&) = delete;
 			GamePool& operator=(const GamePool&) = delete;
 			~GamePool();
@@ -329,37 +393,76 @@ namespace ag
 			const GameConfig& getGameConfig() const noexcept { return game_config; }
 			int numberOfGames() const noexcept { return games; }
 			int getBatchSize() const noexcept { return batch; }
+			const SearchConfig& getSearchConfig() const noexcept { return search_config; }
 			void begin(const std::vector<uint16_t> &openings);
 			void addOpenings(const std::vector<uint16_t> &openings);
 			AgxEngineStats getStats() const;
 	};
 
+	/* Tree (Tree.hpp:68-104).  Two ways to get one, as in the header comment:
+	 *  - Tree(const TreeConfig&) — the reference's constructor: ONE game, driven from outside (evaluation/Player.cpp:64-75).  The tree's
+	 *    storage lives in the one-game engine of the Search it is used with; the first Search method that receives the tree binds them
+	 *    (Player::setBoard starts with search.cleanup(tree)).
+	 *  - Tree(GamePool&, group, n_groups, stream) — the trees of a slice of a generator thread's pool; the per-game accessors take the game's
+	 *    index within the slice. */
 	class Tree
-	{ // Tree.hpp:68-104 for the games of one slice
-			GamePool &pool;
-			int group, n_groups;
-			void *stream;
-			int first_game, game_count;
+	{
+			GamePool *pool = nullptr;
+			int group = 0, n_groups = 1;
+			void *stream = nullptr;
+			int first_game = 0, game_count = 1;
+			TreeConfig config;
+			bool standalone = false;
+			std::unique_ptr<EdgeSelector> edge_selector;
+			std::unique_ptr<EdgeGenerator> edge_generator;
+			mutable matrix<Sign> board_copy;
 			friend class Search;
+			GamePool& bound() const;
 		public:
+			Tree(const TreeConfig &treeConfig);
 			Tree(GamePool &pool, int group, int n_groups, void *stream);
 			int64_t getMemory() const noexcept;
 			int numberOfGames() const noexcept { return game_count; }
 			int firstGame() const noexcept { return first_game; }
-			/* per game (index within the slice); these read the game's state back and therefore wait for the device */
-			int getSimulationCount(int game) const;
-			bool isRootProven(int game) const;
-			int getNodeCount(int game) const;
-			int getMoveNumber(int game) const;
-			Value getEvaluation(int game) const;
-			Sign getSignToMove(int game) const;
+
+			/* Tree.hpp:72-74 (a stand-alone tree) */
+			void setBoard(const matrix<Sign> &newBoard, Sign signToMove, bool forceRemoveRootNode = false);
+			void setEdgeSelector(const EdgeSelector &selector);
+			void setEdgeGenerator(const EdgeGenerator &generator);
+
+			/* Tree.hpp:76-104: the game of a stand-alone tree, or game `game` of the slice.  These read the game's state back and therefore wait
+			 * for the device */
+			int getSimulationCount(int game = 0) const;
+			bool isRootProven(int game = 0) const;
+			int getNodeCount(int game = 0) const;
+			int getMoveNumber(int game = 0) const;
+			Value getEvaluation(int game = 0) const;
+			float getExpectation(int game = 0) const;
+			Sign getSignToMove(int game = 0) const;
+			const matrix<Sign>& getBoard() const;
 			std::vector<Sign> getBoard(int game) const;
-			Node getInfo(int game, const std::vector<Move> &moves = { }) const; // Tree::getInfo({}) (Tree.cpp:403-424): the root
+			Node getInfo(const std::vector<Move> &moves) const; // Tree::getInfo({}) (Tree.cpp:403-424): an owning copy of the root
+			Node getInfo(int game, const std::vector<Move> &moves = { }) const;
 			NodeCacheStats getNodeCacheStats() const noexcept;
 	};
 
+	/* stand-in for the solver handle Search::getSolver returns (Search.hpp:74): the alpha-beta solver lives inside the device's solve stage; what
+	 * callers do with the handle is clear() it at the start of a game (EvaluationGame.cpp:81-82) */
+	class AlphaBetaSearch
+	{
+			friend class Search;
+			bool clear_requested = false;
+		public:
+			void clear() noexcept { clear_requested = true; }
+			void increaseGeneration() noexcept { }
+	};
+
+	/* Search (Search.hpp:56-101): Search(const GameConfig&, const SearchConfig&) is the reference's constructor — it owns a one-game engine
+	 * (the AlphaBetaSearch with its table, the task buffers) and works on a Tree(const TreeConfig&); Search(GamePool&, ...) steps a slice of a
+	 * generator thread's pool.  The solver (AlphaBetaSearch) lives inside the solve stage. */
 	class Search
-	{ // Search.hpp:56-101 for the games of one slice; the solver (AlphaBetaSearch) lives inside the solve stage
+	{
+			std::unique_ptr<GamePool> own_pool; // stand-alone: the engine of this Search / Tree pair
 			GamePool &pool;
 			int group, n_groups;
 			void *stream;
@@ -367,15 +470,23 @@ namespace ag
 			bool scheduled = false;
 			bool tasks_ready = true;
 			bool select_pending = false; // select() asked for, enqueued together with solve()
+			int current_task_buffer = 0;
 			SearchStats stats;
+			AlphaBetaSearch ab_search;
 			void flush_select();
+			void bind(Tree &tree);
 		public:
 			static constexpr int maximum_number_of_simulations = 16777216;
+			Search(const GameConfig &gameOptions, const SearchConfig &searchOptions);
 			Search(GamePool &pool, int group, int n_groups, void *stream);
 
+			int64_t getMemory() const noexcept;
+			const SearchConfig& getConfig() const noexcept;
+			AlphaBetaSearch& getSolver() noexcept;
 			void clearStats() noexcept;
 			SearchStats getStats() const noexcept;  // counters of the whole pool (the device keeps them per game, not per slice)
 
+			void setBoard(const matrix<Sign> &board, Sign signToMove);
 			void select(Tree &tree, int maxSimulations = maximum_number_of_simulations);
 			void solve(double endTime = -1.0);
 			void scheduleToNN(NNEvaluator &evaluator);
@@ -385,6 +496,10 @@ namespace ag
 			void backup(Tree &tree);
 			void cleanup(Tree &tree);
 
+			/* Search.hpp:88-89: the two task buffers of the tournament engine's double-buffered loop (player/SearchThread.cpp:148-180).  A device
+			 * step always completes its batch before the next select, so both indices name the same (empty between steps) buffer. */
+			void useBuffer(int index);
+			void switchBuffer() noexcept;
 			void setBatchSize(int batchSize);
 			int getBatchSize() const noexcept;
 	};

@@ -72,19 +72,28 @@ namespace ag
 			};
 			GeneratorManager &manager;
 			NNEvaluator &nn_evaluator;
-			GamePool &pool;
-			Tree tree;
-			Search search;
+			GameConfig game_config;
+			std::unique_ptr<GamePool> own_pool; // the 4-argument form: this generator's own one-game pool (created by the first generate())
+			GamePool *pool = nullptr;
+			std::unique_ptr<Tree> tree;
+			std::unique_ptr<Search> search;
 			GameState state = GAME_NOT_STARTED;
 			SelfplayConfig selfplay_config;
-			int group, n_groups;
-			void *stream;
+			int group = 0, n_groups = 1;
+			void *stream = nullptr;
 			uint64_t steps = 0;
+			int own_openings = 0;
+			uint32_t opening_seed = 0;
+			void start_own_pool();
+			void serve_own_pool();
 		public:
 			enum Status
 			{
 				OK, TASKS_NOT_READY
 			};
+			/* the reference's constructor (GameGenerator.hpp:54): ONE game with its own Tree and Search.  A generator thread that wants the
+			 * device filled gives its generators slices of one pool instead (below). */
+			GameGenerator(const GameConfig &gameOptions, const SelfplayConfig &selfplayOptions, GeneratorManager &manager, NNEvaluator &evaluator);
 			/* slice `group` of `n_groups` of the thread's pool, driven on `stream` */
 			GameGenerator(const GameConfig &gameOptions, const SelfplayConfig &selfplayOptions, GeneratorManager &manager, NNEvaluator &evaluator, GamePool &pool,
 					int group, int n_groups, void *stream);

@@ -5,6 +5,10 @@
  *               GeneratorManager(gameConfig, selfplayConfig) -> setWorkingDirectory -> loadState -> generate(NetworkLoader, games) ->
  *               saveState -> getGameBuffer().save(...), with one GeneratorThread per entry of selfplayConfig.device_config
  *   evaluator : NNEvaluator with host-side SearchTasks (addToQueue(task, symmetry), evaluateGraph, asyncEvaluateGraphLaunch / Join)
+ *   player    : two evaluation Players (evaluation/Player.cpp:64-129,205-212), each with a Tree(const TreeConfig&) and a
+ *               Search(const GameConfig&, const SearchConfig&) of its own, played against each other the way EvaluationGame::generate
+ *               (evaluation/EvaluationGame.cpp:77-143) does it; prints the moves
+ *   generator : GameGenerator's own four-argument constructor (selfplay/GameGenerator.hpp:54): one game, its own tree and search
  *   errors    : the exceptions the reference throws at this boundary
  * Prints one JSON line per mode; tests/test_boundary_gpu.py runs it on the GPU box and checks the results.
  */
@@ -143,6 +147,181 @@ static int mode_evaluator(const std::map<std::string, std::string> &a)
 	return 0;
 }
 
+/* evaluation/Player.cpp:64-129,152-160,205-212 call for call (simulation-count constraint; the time-controlled variant reads wall clocks) */
+class Player
+{
+		NNEvaluator &nn_evaluator;
+		GameConfig game_config;
+		EdgeSelectorConfig final_move_selection_config;
+		Tree tree;
+		Search search;
+		Constraints constraints;
+		Sign sign = Sign::NONE;
+	public:
+		Player(const GameConfig &gameOptions, const SelfplayConfig &options, NNEvaluator &evaluator) :
+				nn_evaluator(evaluator), game_config(gameOptions), final_move_selection_config(options.final_selector), tree(options.search_config.tree_config),
+				search(gameOptions, options.search_config), constraints(options.constraints)
+		{
+			search.setBatchSize(options.search_config.max_batch_size);
+		}
+		void setSign(Sign s) noexcept { sign = s; }
+		Sign getSign() const noexcept { return sign; }
+		AlphaBetaSearch& getSolver() noexcept { return search.getSolver(); }
+		void setBoard(const matrix<Sign> &board, Sign signToMove)
+		{ // Player.cpp:98-110
+			search.cleanup(tree);
+			tree.setBoard(board, signToMove);
+			search.setBoard(board, signToMove);
+
+			const MCTSConfig &mcts_config = search.getConfig().mcts_config;
+			std::unique_ptr<EdgeSelector> tmp = EdgeSelector::create(mcts_config.edge_selector_config);
+			tree.setEdgeSelector(*tmp);
+			tree.setEdgeGenerator(UnifiedGenerator(mcts_config.max_children, mcts_config.policy_expansion_threshold, mcts_config.policy_temperature));
+		}
+		void selectSolveEvaluate()
+		{ // Player.cpp:111-122
+			search.select(tree, constraints.max_simulations);
+			search.solve();
+			search.scheduleToNN(nn_evaluator);
+		}
+		void expandBackup()
+		{ // Player.cpp:123-131
+			search.generateEdges(tree);
+			search.expand(tree);
+			search.backup(tree);
+		}
+		bool isSearchOver()
+		{ // Player.cpp:152-160 + get_simulations_for_move (utils/misc.cpp:171-179)
+			if (tree.isRootProven())
+				return true;
+			const Value root_eval = tree.getInfo( { }).getValue();
+			const float reduction = std::max(0.0f, std::min(1.0f, (root_eval.draw_rate - 0.75f) / (1.0f - 0.75f)));
+			const int sims = static_cast<int>(constraints.max_simulations - reduction * (constraints.max_simulations - 50));
+			return tree.getSimulationCount() > sims;
+		}
+		Move getMove()
+		{ // Player.cpp:205-212
+			search.cleanup(tree);
+			std::unique_ptr<EdgeSelector> selector = EdgeSelector::create(final_move_selection_config);
+			const Node root_node = tree.getInfo( { });
+			return selector->select(&root_node)->getMove();
+		}
+};
+
+static int mode_player(const std::map<std::string, std::string> &a)
+{
+	const int n = geti(a, "--board", 15);
+	GameConfig game_config(static_cast<GameRules>(geti(a, "--rules", 0)), n);
+	SelfplayConfig options;
+	options.constraints = Constraints::simulations(geti(a, "--sims", 100));
+	options.final_selector.policy = "best";
+	options.search_config.max_batch_size = geti(a, "--batch", 8);
+	options.search_config.tss_config.hash_table_size = geti(a, "--table-entries", 1 << 16);
+	options.search_config.tree_config.node_bucket_size = 4096;
+	options.search_config.tree_config.edge_bucket_size = 65536;
+	DeviceConfig device;
+	device.batch_size = 64;
+	NNEvaluator first_evaluator(device), second_evaluator(device);
+	first_evaluator.loadGraph(NetworkLoader(a.at("--network")));
+	second_evaluator.loadGraph(NetworkLoader(a.count("--network2") ? a.at("--network2") : a.at("--network")));
+	first_evaluator.useSymmetries(false);
+	second_evaluator.useSymmetries(false);
+	Player first(game_config, options, first_evaluator), second(game_config, options, second_evaluator);
+	first.setSign(Sign::CROSS);
+	second.setSign(Sign::CIRCLE);
+
+	// EvaluationGame::generate (EvaluationGame.cpp:77-143) for one game: opening, then the player to move searches until its search is over
+	matrix<Sign> board(n, n);
+	board.fill(Sign::NONE);
+	std::vector<uint16_t> opening(AGX_OPENING_CAP, 0);
+	if (agx_make_opening(static_cast<int>(game_config.rules), n, static_cast<uint32_t>(geti(a, "--opening-seed", 1)), opening.data()) != AGX_OK)
+		throw std::runtime_error(agx_last_error());
+	Sign sign_to_move = Sign::CROSS;
+	std::vector<uint8_t> cells(static_cast<size_t>(n) * n, 0);
+	for (int i = 0; i < opening[0]; i++)
+	{
+		const Move m(opening[1 + i]);
+		board.at(m.row, m.col) = m.sign;
+		cells[m.row * n + m.col] = static_cast<uint8_t>(m.sign);
+		sign_to_move = (m.sign == Sign::CROSS) ? Sign::CIRCLE : Sign::CROSS;
+	}
+	first.getSolver().clear();
+	second.getSolver().clear();
+	std::vector<Move> played;
+	int outcome = 0, steps = 0;
+	auto current = [&]() -> Player& { return (sign_to_move == first.getSign()) ? first : second; };
+	auto evaluator_of = [&](Player &p) -> NNEvaluator& { return (&p == &first) ? first_evaluator : second_evaluator; };
+	current().setBoard(board, sign_to_move);
+	const int max_plies = geti(a, "--plies", n * n);
+	while (outcome == 0 && static_cast<int>(played.size()) < max_plies)
+	{
+		Player &p = current();
+		p.selectSolveEvaluate();
+		evaluator_of(p).evaluateGraph();
+		p.expandBackup();
+		steps++;
+		if (p.isSearchOver())
+		{
+			const Move m = p.getMove();
+			played.push_back(m);
+			board.at(m.row, m.col) = m.sign;
+			cells[m.row * n + m.col] = static_cast<uint8_t>(m.sign);
+			sign_to_move = (m.sign == Sign::CROSS) ? Sign::CIRCLE : Sign::CROSS;
+			if (agx_get_outcome(static_cast<int>(game_config.rules), n, cells.data(), static_cast<int>(m.sign), m.row, m.col, game_config.draw_after, &outcome) != AGX_OK)
+				throw std::runtime_error(agx_last_error());
+			if (outcome == 0)
+				current().setBoard(board, sign_to_move);
+		}
+	}
+	std::printf("{\"mode\": \"player\", \"opening_stones\": %d, \"outcome\": %d, \"steps\": %d, \"moves\": [", static_cast<int>(opening[0]), outcome, steps);
+	for (size_t i = 0; i < played.size(); i++)
+		std::printf("%s%d", i ? ", " : "", static_cast<int>(played[i].toShort()));
+	std::printf("]}\n");
+	return 0;
+}
+
+static int mode_generator(const std::map<std::string, std::string> &a)
+{ // GameGenerator(gameOptions, selfplayOptions, manager, evaluator) as GeneratorThread constructs its generators in the reference
+  // (GeneratorManager.cpp:107-110): one game per generator, each with its own tree and search
+	const int n = geti(a, "--board", 15);
+	GameConfig game_config(static_cast<GameRules>(geti(a, "--rules", 0)), n);
+	SelfplayConfig options;
+	options.games_per_iteration = geti(a, "--games", 2);
+	options.constraints = Constraints::simulations(geti(a, "--sims", 40));
+	options.final_selector.policy = "best";
+	options.use_symmetries = false;
+	options.search_config.max_batch_size = geti(a, "--batch", 8);
+	options.search_config.tss_config.hash_table_size = 1 << 14;
+	options.search_config.tree_config.node_bucket_size = 2048;
+	options.search_config.tree_config.edge_bucket_size = 32768;
+	GeneratorManager manager(game_config, options);
+	DeviceConfig device;
+	device.batch_size = 64;
+	NNEvaluator evaluator(device);
+	evaluator.loadGraph(NetworkLoader(a.at("--network")));
+	std::vector<std::unique_ptr<GameGenerator>> generators;
+	for (int i = 0; i < geti(a, "--generators", 3); i++)
+		generators.push_back(std::make_unique<GameGenerator>(game_config, options, manager, evaluator));
+	int iterations = 0;
+	while (manager.getGameBuffer().numberOfGames() < options.games_per_iteration && iterations < geti(a, "--max-iterations", 20000))
+	{ // GeneratorThread::run's loop (GeneratorManager.cpp:124-141)
+		for (size_t i = 0; i < generators.size(); i++)
+		{
+			const GameGenerator::Status status = generators[i]->generate();
+			if (evaluator.isQueueFull() or status == GameGenerator::TASKS_NOT_READY)
+			{
+				evaluator.asyncEvaluateGraphJoin();
+				evaluator.asyncEvaluateGraphLaunch();
+			}
+		}
+		iterations++;
+	}
+	evaluator.asyncEvaluateGraphJoin();
+	const GameDataBufferStats st = manager.getGameBuffer().getStats();
+	std::printf("{\"mode\": \"generator\", \"generators\": %zu, \"iterations\": %d, \"games\": %d, \"samples\": %d}\n", generators.size(), iterations, st.games, st.samples);
+	return 0;
+}
+
 static int mode_errors(const std::map<std::string, std::string> &a)
 {
 	int caught = 0;
@@ -214,7 +393,7 @@ int main(int argc, char **argv)
 {
 	if (argc < 2)
 	{
-		std::fprintf(stderr, "usage: agx_boundary_test generate|evaluator|errors [--key value ...]\n");
+		std::fprintf(stderr, "usage: agx_boundary_test generate|evaluator|player|generator|errors [--key value ...]\n");
 		return 2;
 	}
 	try
@@ -225,6 +404,10 @@ int main(int argc, char **argv)
 			return mode_generate(args);
 		if (mode == "evaluator")
 			return mode_evaluator(args);
+		if (mode == "player")
+			return mode_player(args);
+		if (mode == "generator")
+			return mode_generator(args);
 		if (mode == "errors")
 			return mode_errors(args);
 		std::fprintf(stderr, "unknown mode %s\n", mode.c_str());

@@ -131,6 +131,53 @@ def test_nn_evaluator_with_host_tasks(network_file, agx_lib, tmp_path):
     net.close()
 
 
+def test_players_with_the_reference_constructors(network_file, agx_lib, tmp_path):
+    """evaluation/Player.cpp:64-129,205-212 compiled against include/alphagomoku_agx/ as written — Tree(const TreeConfig&),
+    Search(const GameConfig&, const SearchConfig&), cleanup / setBoard / setEdgeSelector / setEdgeGenerator / select / solve / scheduleToNN /
+    generateEdges / expand / backup, Tree::getInfo({}), EdgeSelector::create(final)->select(&root) — two such players play a game against each
+    other (EvaluationGame.cpp:77-143).  The same opening, networks and budgets on the match-mode pool (whose every step the engine tests
+    compare with the oracle) must give the same moves."""
+    from alphagomoku_amd import selfplay
+    from alphagomoku_amd.networks import AGNetwork
+    path, d, blob = network_file
+    blob2, _ = synthetic.make_weights(d, seed=77)
+    path2 = tmp_path / "second.agxw"
+    synthetic.save_weights(path2, d, blob2)
+    seed, sims, batch = 11, 60, 4
+    line, _ = run("player", "--network", path, "--network2", path2, "--sims", sims, "--batch", batch, "--opening-seed", seed, "--table-entries", 1 << 16)
+    assert line["outcome"] in (1, 2, 3) and len(line["moves"]) >= 20
+    # the same game on the match-mode engine
+    nets = []
+    for b in (blob, blob2):
+        net = AGNetwork(d)
+        net.loadWeights(b)
+        nets.append(net)
+    opening = synthetic.make_openings(15, 1, seed0=seed)
+    assert len(opening[0]) == line["opening_stones"]
+    cfg = selfplay.default_config(n_games=2, max_batch_size=batch, max_simulations=sims, tss_table_entries=1 << 16, node_capacity=4096, edge_capacity=65536,
+                                  match_mode=1)
+    pool = selfplay.GeneratorPool(cfg)
+    pool.begin(selfplay.pack_openings(opening))
+    for _ in range(20000):
+        pool.step_match(nets[0], nets[1])
+        if pool.stats()["games_finished"] >= 1:
+            break
+    recs, _ = pool.records()
+    first_game = sorted((r.move_number, r.move) for r in recs if r.game_index == 0)
+    pool.close()
+    for net in nets:
+        net.close()
+    assert [m for _, m in first_game] == line["moves"]
+
+
+def test_game_generators_with_the_reference_constructor(network_file, agx_lib):
+    """GameGenerator(gameOptions, selfplayOptions, manager, evaluator) (selfplay/GameGenerator.hpp:54): generators of one game each, driven by
+    the reference's generator-thread loop, hand their finished games to the manager's buffer"""
+    path, _, _ = network_file
+    line, _ = run("generator", "--network", path, "--generators", 3, "--games", 2, "--sims", 40)
+    assert line["generators"] == 3 and line["games"] >= 2 and line["samples"] > line["games"]
+
+
 def test_boundary_error_behaviour(agx_lib):
     line, _ = run("errors")
     assert line["caught"] == 31

@@ -208,7 +208,7 @@ def _oracle_root(olib, h):
 
 def _play_and_compare(olib, rules, games, batch, sims, max_steps, evaluator, table_entries=1 << 16, n=N, final_selector=0, use_symmetries=0,
                       action_values=0, noise_weight=0.0, noise_type=1, exploration_scaling=0.0, draw_after=0, max_children=0, policy_temperature=1.0,
-                      record_format=1, node_capacity=4096, edge_capacity=0, arena_reserve=1.0, **engine_options):
+                      record_format=1, node_capacity=4096, edge_capacity=0, arena_reserve=1.0, groups=1, **engine_options):
     """evaluator(features uint32 [n][HW]) -> (policy [n][HW] f32, value [n][2] f32 (win, draw)[, q [n][HW][2]]); used for BOTH sides"""
     from alphagomoku_amd import selfplay
     N, HW = n, n * n   # noqa: N806 (shadow the 15x15 module defaults)
@@ -241,9 +241,17 @@ def _play_and_compare(olib, rules, games, batch, sims, max_steps, evaluator, tab
     pool.begin(selfplay.pack_openings(openings))
     compared = 0
     deferred = [False] * games
+    # groups > 1: the pool stepped as slices on CU-masked streams, the way bench.py and ag::GeneratorThread run it
+    streams = selfplay.chip_slices(groups)[0] if groups > 1 else [None]
     for step in range(max_steps):
-        pool.select_solve()
-        slots, feats = pool.scheduled()
+        if groups > 1:
+            for k in range(groups):
+                pool.select_solve_group(k, groups, streams[k])
+            parts = [pool.scheduled_group(k, groups) for k in range(groups)]
+            slots, feats = np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
+        else:
+            pool.select_solve()
+            slots, feats = pool.scheduled()
         out = evaluator(feats) if len(slots) else (np.zeros((0, HW), np.float32), np.zeros((0, 2), np.float32), np.zeros((0, HW, 2), np.float32))
         pol, val = out[0], out[1]
         qv = np.ascontiguousarray(out[2], dtype=np.float32) if action_values else None
@@ -270,7 +278,11 @@ def _play_and_compare(olib, rules, games, batch, sims, max_steps, evaluator, tab
                 olib.ago_game_step_expand_q(handles[g], ol.ptr(p), ol.ptr(v), ol.ptr(np.ascontiguousarray(qv[idx])))
             else:
                 olib.ago_game_step_expand(handles[g], ol.ptr(p), ol.ptr(v))
-        pool.expand_backup()
+        if groups > 1:
+            for k in range(groups):
+                pool.expand_backup_group(k, groups, streams[k])
+        else:
+            pool.expand_backup()
         for g in range(games):
             info = pool.game_info(g)
             assert info["error"] == 0
@@ -349,6 +361,14 @@ def test_speculative_solver_plays_the_same_games(agx_lib, olib, rules, n, batch,
     assert stats["speculative_solves"] > 0
     if table_entries <= 1 << 10:
         assert stats["speculative_reruns"] > 0   # the re-run path was exercised
+
+
+@pytest.mark.parametrize("rules,speculative", [(0, 1), (2, 0)])
+def test_sliced_pool_matches_the_oracle(agx_lib, olib, rules, speculative):
+    """the pool stepped as 4 slices on CU-masked streams (bench.py's default) against the ORACLE, step by step"""
+    compared, stats = _play_and_compare(olib, rules, games=16, batch=8, sims=60, max_steps=300, evaluator=_stand_in_evaluator(olib), groups=4,
+                                        speculative_solver=speculative, speculative_waves=192, record_format=3)
+    assert compared > 100 and stats["first_error"] == 0
 
 
 def test_speculative_solver_with_a_full_overlay(agx_lib, olib):
@@ -551,15 +571,17 @@ def test_tournament_search_on_one_tree(agx_lib, olib, rules, threads, batch):
     olib.ago_game_destroy(h)
 
 
-def test_yielding_pool_gives_the_same_games(agx_lib, olib):
+@pytest.mark.parametrize("fraction,speculative,table_bits", [(0.5, 0, 16), (0.5, 1, 16), (0.25, 1, 10), (0.9, 1, 22)])
+def test_yielding_pool_gives_the_same_games(agx_lib, olib, fraction, speculative, table_bits):
     """solver_yield_fraction only changes the pacing (stragglers sit out a step): every game must still produce exactly the
-    oracle's moves and root visit counts.  Compared through the output records, game by game."""
+    oracle's moves and root visit counts.  Compared through the output records, game by game.  With the speculative solver the rule
+    defers a batch whose commit needs a serial re-run while the rest of the launch is done (small tables provoke those)."""
     from alphagomoku_amd import selfplay
     games, batch, sims = 12, 8, 60
-    cfg = selfplay.default_config(n_games=games, max_batch_size=batch, max_simulations=sims, tss_table_entries=1 << 16, node_capacity=4096,
-                                  edge_capacity=65536, solver_yield_fraction=0.5)
+    cfg = selfplay.default_config(n_games=games, max_batch_size=batch, max_simulations=sims, tss_table_entries=1 << table_bits, node_capacity=4096,
+                                  edge_capacity=65536, solver_yield_fraction=fraction, speculative_solver=speculative, speculative_waves=48)
     pool = selfplay.GeneratorPool(cfg)
-    ocfg = ol.default_search_config(max_batch_size=batch, max_simulations=sims, table_entries=1 << 16)
+    ocfg = ol.default_search_config(max_batch_size=batch, max_simulations=sims, table_entries=1 << table_bits)
     ev = _stand_in_evaluator(olib)
     openings = []
     for g in range(games):
@@ -578,6 +600,8 @@ def test_yielding_pool_gives_the_same_games(agx_lib, olib):
             break
     st = pool.stats()
     assert st["first_error"] == 0 and st["games_finished"] == games
+    if speculative:
+        assert st["speculative_solves"] > 0 and (st["speculative_deferrals"] > 0 or table_bits > 16)   # the deferral path ran
     recs, edges = pool.records()
     for g in range(games):
         h = olib.ago_game_create(0, N, N, ctypes.byref(ocfg))
@@ -815,9 +839,9 @@ FULL_SIZE = {
 def test_full_size_pool_matches_a_small_pool_game_by_game(agx_lib, name):
     """BASELINE configs[1..4] at FULL size — 1024 games, the config's network in the loop, its playout budget, batch 8, yielding on, the
     reference's 4 Mi-entry solver table per game and bench.py's arena sizes: games are independent, so every game of the big pool must play
-    exactly what the same opening plays in a 12-game pool without yielding (whose behaviour the other tests pin to the oracle step by
-    step) — a size-independent property checked at full size; the arenas must hold (first_error == 0)."""
-    from alphagomoku_amd import selfplay
+    exactly what the same opening plays in a 64-game pool stepped in one piece, serial solver, no yielding (whose behaviour the other tests pin
+    to the oracle step by step) — a size-independent property checked at full size, on the path bench.py times; the arenas must hold."""
+    from alphagomoku_amd import selfplay, lib, check
     from alphagomoku_amd.networks import AGNetwork
     c = FULL_SIZE[name]
     n, sims = c["n"], c["sims"]
@@ -827,34 +851,52 @@ def test_full_size_pool_matches_a_small_pool_game_by_game(agx_lib, name):
     net.loadWeights(blob)
     openings = synthetic.make_openings(n, 1024, seed0=900, rules=c["rules"])
 
-    def run(games, steps, yield_fraction):
+    def run(games, steps, as_bench):
+        # as_bench: exactly bench.py's way of running the pool — 4 chip slices on CU-masked streams, the speculative solver, yielding at 0.9,
+        # format-201 samples on (record_format 3 = samples + the raw root edges this test compares), records drained as it goes
         pool = selfplay.GeneratorPool(selfplay.default_config(rules=c["rules"], board_size=n, draw_after=n * n, n_games=games, max_batch_size=8, max_simulations=sims,
                                                               tss_table_entries=4 * 1024 * 1024, node_capacity=max(4096, 8 * sims),
-                                                              edge_capacity=max(65536, 192 * sims), arena_reserve=3.0, solver_yield_fraction=yield_fraction,
+                                                              edge_capacity=max(65536, 192 * sims), arena_reserve=3.0, solver_yield_fraction=0.9 if as_bench else 0.0,
+                                                              speculative_solver=1 if as_bench else 0, record_format=3 if as_bench else 1,
                                                               record_capacity=games * 64, record_edge_capacity=games * 64 * n * n))
         pool.begin(selfplay.pack_openings(openings[:games]))   # no spare openings: a finished game stays finished
-        for _ in range(steps):
-            pool.step(net)
-        st = pool.stats()
-        recs, edges = pool.records()
+        slices = 4 if as_bench else 1
+        if as_bench:
+            streams, per = selfplay.chip_slices(slices)
+            check(lib.agx_net_set_launch_width(net._net, per))
+        else:
+            streams = [None]
+            check(lib.agx_net_set_launch_width(net._net, 0))
         per_game = {}
-        for r in recs:
-            per_game.setdefault(r.game_serial, []).append((r.move_number, r.move, r.root_visits, r.n_edges,
-                                                           tuple((e.move, e.visits, e.score) for e in edges[r.edge_offset:r.edge_offset + r.n_edges])))
+
+        def collect(drain):
+            recs, edges = pool.records(drain=drain)
+            for r in recs:
+                per_game.setdefault(r.game_serial, []).append((r.move_number, r.move, r.root_visits, r.n_edges,
+                                                               tuple((e.move, e.visits, e.score) for e in edges[r.edge_offset:r.edge_offset + r.n_edges])))
+        for i in range(steps):
+            for g in range(slices):
+                pool.step_group(net, g, slices, streams[g])
+            if as_bench and i % 64 == 63:
+                collect(True)
+        check(lib.agx_device_synchronize())
+        st = pool.stats()
+        collect(False)
         pool.close()
         return st, {g: sorted(v) for g, v in per_game.items()}
-    big_stats, big = run(1024, c["big_steps"], 0.75)
-    small_stats, small = run(12, c["small_steps"], 0.0)
+    big_stats, big = run(1024, c["big_steps"], True)
+    small_stats, small = run(64, c["small_steps"], False)
+    check(lib.agx_net_set_launch_width(net._net, 0))
     assert big_stats["first_error"] == 0 and small_stats["first_error"] == 0 and big_stats["arena_failures"] == 0
-    assert big_stats["moves_played"] > 1024 and big_stats["evaluated_nodes"] > 1024 * sims
+    assert big_stats["moves_played"] > 1024 and big_stats["evaluated_nodes"] > 1024 * sims and big_stats["speculative_solves"] > 0
     compared = 0
-    for g in range(12):
+    for g in range(64):
         a, b = big.get(g, []), small.get(g, [])
         k = min(len(a), len(b))
         assert k >= 1, g
         assert a[:k] == b[:k], g           # same moves, same root visit counts, same edge visits and scores
         compared += k
-    assert compared >= 24
+    assert compared >= 128
     net.close()
 
 
@@ -947,8 +989,10 @@ def test_long_running_loop_drains_records_and_refills_openings(agx_lib):
                 st = pool.stats()
                 assert st["records_used"] == 0 and st["first_error"] == 0
                 history.append((st["games_finished"], st["openings_taken"], tuple(pool.game_info(g)["opening_id"] for g in range(8))))
-                if st["openings_taken"] >= 12 and not added:
-                    assert not all(pool.game_info(g)["active"] for g in range(8)) or st["games_finished"] <= 4
+                if st["games_finished"] >= 6 and not added:
+                    # slot s plays openings s, s + 8, s + 16, ...: with 12 openings in the list the slots 4-7 wait after their first game
+                    waiting = [g for g in range(8) if not pool.game_info(g)["active"]]
+                    assert all(g >= 4 for g in waiting)
                     pool.add_openings(selfplay.pack_openings(more))
                     added = True
                 if st["games_finished"] >= 30:
@@ -980,6 +1024,99 @@ def test_wave_reduction_helpers(agx_lib, tmp_path):
 
 # ---------------------------------------------------------------------------------------------------------------------------------
 # evaluation matches: two players, two networks, one game per pair of trees
+
+
+def _best_edge(root_visits, edges):
+    """BestEdgeSelector (EdgeSelector.cpp:515-536) on a root snapshot, in float32 like the reference: first maximum wins"""
+    best, best_value = -1, np.float32(-3.0e38)
+    for i, e in enumerate(edges):
+        pv, raw_eval = (e["score"] >> 13) & 3, (e["score"] & 8191) - 4000
+        if pv == 0:
+            value = np.float32(-1.0e8) + np.float32(raw_eval)
+        elif pv == 3:
+            value = np.float32(1.0e8) - np.float32(-raw_eval)
+        else:
+            expectation = np.float32(e["win"]) + np.float32(0.5) * np.float32(e["draw"])
+            value = np.float32(e["visits"]) + expectation * np.float32(root_visits) + np.float32(0.001) * np.float32(e["prior"])
+        if value > best_value:
+            best, best_value = i, value
+    return best
+
+
+@pytest.mark.parametrize("rules,sims,speculative", [(0, 100, 0), (1, 80, 1), (2, 80, 0)])
+def test_player_api_drives_a_game_from_outside(agx_lib, olib, rules, sims, speculative):
+    """Two evaluation Players, each a Tree / Search pair of its own (a one-game engine), driven exactly like evaluation/Player.cpp:100-129 and
+    EvaluationGame.cpp:100-143 drive them: setBoard (cleanup + Tree::setBoard + Search::setBoard) for the player to move, then select / solve /
+    evaluate / expand / backup until isSearchOver, the move by the final selector on a copy of the root.  Every leaf, every root and every move
+    must equal the oracle's two players (Game::match_begin / take_turn / external_move), for a whole game."""
+    from alphagomoku_amd import selfplay
+    batch = 8
+    evaluators = [_stand_in_evaluator(olib), _second_evaluator(olib)]
+    ocfg = ol.default_search_config(max_batch_size=batch, max_simulations=sims, table_entries=1 << 16)
+    op = np.zeros(64, np.uint16)
+    k = olib.ago_prepare_opening(rules, N, N, 4242, ol.ptr(op))
+    opening = [int(x) for x in op[:k]]
+    pools, handles = [], []
+    for _ in range(2):
+        cfg = selfplay.default_config(rules=rules, n_games=1, max_batch_size=batch, max_simulations=1 << 24, tss_table_entries=1 << 16, node_capacity=4096,
+                                      edge_capacity=65536, force_expand_root=0, speculative_solver=speculative, speculative_waves=16)
+        pool = selfplay.GeneratorPool(cfg)
+        pool.begin(selfplay.pack_openings([[]]))     # an engine has to be begun; the first set_board replaces the empty position
+        pool.set_max_simulations(sims)               # Search::select(tree, constraints.max_simulations)
+        pools.append(pool)
+        h = olib.ago_game_create_ex(rules, N, N, 0, ctypes.byref(ocfg))
+        olib.ago_game_set_force_expand_root(h, 0)
+        olib.ago_game_match_begin(h, ol.ptr(np.array(opening + [0], np.uint16)), len(opening))
+        handles.append(h)
+    board = np.zeros(HW, np.uint8)
+    for m in opening:
+        board[(m >> 2 & 127) * N + (m >> 9 & 127)] = m & 3
+    sign = 1 if not opening else 3 - (opening[-1] & 3)
+    who = 0 if sign == 1 else 1     # the first player holds cross
+    plies = compared = 0
+    while True:
+        pool, h = pools[who], handles[who]
+        pool.set_board(0, board, sign)               # Player::setBoard
+        olib.ago_game_take_turn(h)
+        while True:                                  # EvaluationGame: selectSolveEvaluate, expandBackup, isSearchOver
+            pool.select_solve()
+            slots, feats = pool.scheduled()
+            f = np.zeros((batch, HW), np.uint32)
+            c = olib.ago_game_step_select(h, ol.ptr(f), batch)
+            assert c == len(slots) and np.array_equal(feats, f[:c]), plies
+            pol, val = evaluators[who](feats) if c else (np.zeros((0, HW), np.float32), np.zeros((0, 2), np.float32))
+            pool.provide(slots, pol, np.concatenate([val, 1 - val.sum(1, keepdims=True)], 1).astype(np.float32))
+            pool.expand_only()
+            moved = olib.ago_game_step_expand(h, ol.ptr(np.ascontiguousarray(pol)), ol.ptr(np.ascontiguousarray(val)))
+            info = pool.game_info(0)
+            assert info["error"] == 0
+            proven = ((info["root_score"] >> 13) & 3) != 2 and info["root_score"] not in (0, 0xFFFF)
+            reduction = np.float32(max(0.0, min(1.0, (np.float32(info["root_draw"]) - np.float32(0.75)) / np.float32(0.25))))
+            budget = int(np.float32(sims) - reduction * np.float32(sims - 50))      # get_simulations_for_move (utils/misc.cpp:171-179)
+            over = proven or info["root_visits"] > budget                           # Player::isSearchOver (Player.cpp:152-160)
+            assert over == bool(moved), plies
+            if not over:
+                r = _oracle_root(olib, h)
+                assert r["n"] == info["root_edges"] and r["visits"] == info["root_visits"], plies
+                assert np.array_equal(np.array([x["visits"] for x in info["edges"]], np.int32), r["ev"]), plies
+                compared += 1
+                continue
+            mv = info["edges"][_best_edge(info["root_visits"], info["edges"])]["move"]     # Player::getMove
+            assert mv == olib.ago_game_last_move(h), plies
+            break
+        board[(mv >> 2 & 127) * N + (mv >> 9 & 127)] = mv & 3
+        sign = 3 - (mv & 3)
+        olib.ago_game_external_move(handles[1 - who], mv)
+        plies += 1
+        if olib.ago_game_outcome(h) != 0:
+            assert olib.ago_game_outcome(handles[1 - who]) == olib.ago_game_outcome(h)
+            break
+        who = 1 - who
+    assert plies >= 20 and compared > 100
+    for pool in pools:
+        pool.close()
+    for h in handles:
+        olib.ago_game_destroy(h)
 
 
 def _second_evaluator(olib, hw=HW):
@@ -1023,7 +1160,6 @@ def _play_matches_and_compare(olib, rules, pairs, n_openings, batch, sims, max_s
     games_done = [0] * pairs
     mover = [None] * pairs       # 0 / 1: whose turn; None: the pair waits for an opening
     opening_of = [None] * pairs
-    next_opening = [0]
     results = []
 
     def start_game(m, oid):
@@ -1041,9 +1177,10 @@ def _play_matches_and_compare(olib, rules, pairs, n_openings, batch, sims, max_s
             if mover[m] is None:
                 if games_done[m] % 2 == 1:
                     start_game(m, opening_of[m])
-                elif next_opening[0] < n_openings:
-                    start_game(m, next_opening[0])
-                    next_opening[0] += 1
+                elif m + pairs * (games_done[m] // 2) < n_openings:
+                    # pair m plays openings m, m + pairs, m + 2 pairs, ...: a function of the pair and of how many matches it has played, not of
+                    # which pair finished first (k_assign_openings)
+                    start_game(m, m + pairs * (games_done[m] // 2))
 
     pool.begin(selfplay.pack_openings(openings))
     restart_waiting()
@@ -1125,7 +1262,7 @@ def _play_matches_and_compare(olib, rules, pairs, n_openings, batch, sims, max_s
                 assert np.array_equal(np.array([x["prior"] for x in e], np.float32), r["prior"]), (step, phase, m)
                 assert np.array_equal(np.array([[x["win"], x["draw"]] for x in e], np.float32).reshape(-1), r["val"]), (step, phase, m)
                 compared += 1
-        if all(x is None for x in mover) and next_opening[0] >= n_openings and all(d % 2 == 0 for d in games_done):
+        if all(x is None for x in mover) and all(d % 2 == 0 and m + pairs * (d // 2) >= n_openings for m, d in enumerate(games_done)):
             break
     stats = pool.stats()
     pool.close()
