@@ -118,8 +118,14 @@ def build(force=False, verbose=True):
         subprocess.check_call(cmd)
 
     objs = [os.path.join(CSRC, src.rsplit(".", 1)[0] + ".o") for src in SOURCES]
+    # build identity: whenever the source hash differs from the one recorded with the last link and no object looks stale by its mtime, the
+    # mtimes cannot be trusted (they do not survive every way of copying a tree): everything is compiled again
+    current = source_hash()
+    stale = list(SOURCES) if force else _stale_objects()
+    if not stale and _recorded_hash() is not None and _recorded_hash() != current:
+        stale = list(SOURCES)
     procs = []
-    for src in (SOURCES if force else _stale_objects()):
+    for src in stale:   # in parallel: engine.hip alone takes minutes
         obj = os.path.join(CSRC, src.rsplit(".", 1)[0] + ".o")
         cmd = _compile_cmd(hipcc, src, obj)
         if verbose:
@@ -128,15 +134,8 @@ def build(force=False, verbose=True):
     for p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed")
-    # build identity: whenever the source hash differs from the one recorded with the last link, every object is suspect (mtimes do
-    # not survive every way of copying a tree), so a hash change without a recompiled object recompiles everything
-    current = source_hash()
     relink = force or _mtime(LIB) < max(_mtime(o) for o in objs)
     if _recorded_hash() != current:
-        if not procs and not force and _recorded_hash() is not None:
-            for src in SOURCES:   # sources changed but no object looked stale: do not trust the mtimes
-                obj = os.path.join(CSRC, src.rsplit(".", 1)[0] + ".o")
-                run(_compile_cmd(hipcc, src, obj))
         with open(BUILD_ID_INC, "w") as f:
             f.write('"%s"\n' % current)
         run([cxx, "-std=c++17", "-O2", "-fPIC", "-c", BUILD_ID_SRC, "-o", BUILD_ID_OBJ])

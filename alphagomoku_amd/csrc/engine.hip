@@ -904,6 +904,19 @@ namespace
 								break;
 							}
 						}
+						if (polls > (1 << 22))
+						{ // watchdog (seconds): a queue slot that never fills would hang the launch — report instead
+							E.spec_watchdog[0] = 1;
+							E.spec_watchdog[1] = i;
+							E.spec_watchdog[2] = __hip_atomic_load(c_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+							E.spec_watchdog[3] = __hip_atomic_load(c_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+							E.spec_watchdog[4] = __hip_atomic_load(c_selected, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+							E.spec_watchdog[5] = count;
+							E.spec_watchdog[6] = __hip_atomic_load(c_select, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+							E.games[E.g0].error = ERR_SPEC_STATE;
+							v = -1;
+							break;
+						}
 						__builtin_amdgcn_s_sleep(64);
 					}
 					if (v > 0)
@@ -2782,6 +2795,8 @@ int agx_engine_create(const AgxEngineConfig *cfg, AgxEngine **out)
 	AGX_TRY(dev_alloc(e, &d.frame_spill, areas * MAX_FRAMES));
 	d.spec_group = 0;
 	d.spec_waves = e->spec_waves;
+	AGX_TRY(dev_alloc(e, &d.spec_watchdog, 16));
+	(void) hipMemset(d.spec_watchdog, 0, 16 * sizeof(int));
 	AGX_TRY(dev_alloc(e, &d.spec_prof, 16));
 	AGX_TRY(dev_alloc(e, &d.spec_trace, 4 * G));
 	(void) hipMemset(d.spec_trace, 0, 4 * G * sizeof(unsigned long long));
@@ -3394,6 +3409,14 @@ int agx_engine_stats(AgxEngine *e, AgxEngineStats *out)
 		out->active_games += g.active ? 1 : 0;
 		if (g.error != 0 && out->first_error == 0)
 			out->first_error = g.error;
+	}
+	if (e->speculative)
+	{
+		int w[16];
+		AGX_HIP_CHECK(hipMemcpy(w, e->dev.spec_watchdog, sizeof(w), hipMemcpyDeviceToHost));
+		if (w[0] != 0)
+			fprintf(stderr, "[k_search_spec watchdog] a wave waited in vain for queue slot %d: head %d, tail %d, games selected %d of %d, select cursor %d\n", w[1], w[2], w[3], w[4],
+					w[5], w[6]);
 	}
 #ifdef AGX_SPEC_PROFILE
 	if (getenv("AGX_SPEC_TRACE"))

@@ -257,6 +257,7 @@ namespace agx
 			int shared_tree; // tournament search: the n_games records are the search threads of ONE tree (game 0): own task buffer and solver each
 			// speculative solver
 			int spec_group;        // index of this launch's group (its queue segment and counters)
+			int *spec_watchdog;            // [16] what a wave that gave up waiting for a queue slot saw
 			unsigned long long *spec_trace; // AGX_SPEC_PROFILE builds: [game][4] time stamps of the last launch
 			unsigned long long *spec_prof; // AGX_SPEC_PROFILE builds: time sums of k_search_spec
 			int spec_waves;        // waves of this launch (its spill areas start at area n_games + spec_group * spec_waves)

@@ -11,11 +11,14 @@ def net_desc(rows=15, cols=15, blocks=6, filters=128, in_channels=32, action_val
                 value_hidden=min(256, 2 * filters), action_values=action_values)
 
 
-def make_weights(desc, seed=1234, residual_gain=1.0):
+def make_weights(desc, seed=1234, residual_gain=1.0, policy_gain=1.0):
     """Returns (blob, parts): the canonical fp32 blob of include/agx.h and the list of named arrays in blob order.
     residual_gain scales the second convolution of every residual block: 1.0 is plain He-init, under which the un-normalised residual
     sums double their variance per block (a 10-block tower ends with near one-hot policies); a gain < 1 keeps activations of order one
-    like a trained tower's (used by the deep-network tolerance test)."""
+    like a trained tower's (used by the deep-network tolerance test).
+    policy_gain scales the policy head's final 1x1 convolution, i.e. the logits: under plain He-init (1.0) a 6x128 net gives ~170 of ~215 legal
+    cells a prior above the expansion threshold (1e-4 of the total), so trees are six times wider than the reference's self-play trees; 2.5
+    leaves ~30 — the edges per stored node a TRAINED network's peaked policy gives (22-67) — a "trained-like" tree shape."""
     rng = np.random.default_rng(seed)
     F, C, HW, D = desc["filters"], desc["in_channels"], desc["rows"] * desc["cols"], desc["value_hidden"]
 
@@ -30,7 +33,7 @@ def make_weights(desc, seed=1234, residual_gain=1.0):
         parts += [("block%d.w1" % i, he((3, 3, F, F), 9 * F)), ("block%d.b1" % i, shift(F)),
                   ("block%d.w2" % i, he((3, 3, F, F), 9 * F) * np.float32(residual_gain)), ("block%d.b2" % i, shift(F))]
     parts += [("policy.w1", he((3, 3, F, F), 9 * F)), ("policy.b1", shift(F)),
-              ("policy.w2", he((F,), F)), ("policy.b2", shift(1))]
+              ("policy.w2", he((F,), F) * np.float32(policy_gain)), ("policy.b2", shift(1))]
     parts += [("value.w1", he((F, 4), F)), ("value.b1", shift(4)),
               ("value.w2", he((HW * 4, D), HW * 4)), ("value.b2", shift(D)),
               ("value.w3", he((D, 3), D)), ("value.b3", shift(3))]

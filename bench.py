@@ -118,6 +118,9 @@ def main():
     ap.add_argument("--age-steps", type=int, default=-1,
                     help="untimed pool steps before the timed region so that a short run measures the steady state (trees of ~2 k nodes, slices out of "
                          "phase) instead of the opening phase; -1 = 3000 when --steps < 3000, else 0")
+    ap.add_argument("--policy-gain", type=float, default=1.0,
+                    help="scale of the synthetic network's policy logits: 1.0 = plain He-init (near-flat priors, trees ~6x wider than self-play with a "
+                         "trained network), 2.5 = peaked priors pruning to ~30 edges per node like a trained network's (a second, realistic tree shape)")
     ap.add_argument("--network-cus", type=int, default=0,
                     help="> 0: the chip as two partitions shared by all slices — this many compute units run every slice's network launches, the rest "
                          "every slice's search launches (streams ordered by events); 0: every slice owns 1 / slices of the chip for all its stages")
@@ -162,7 +165,7 @@ def main():
 
     check(lib.agx_set_device(int(os.environ.get("AGX_FORCE_DEVICE", local_rank))))  # AGX_FORCE_DEVICE: test the N > 1 flow on a 1-GPU box
     desc = synthetic.net_desc(rows=args.board, cols=args.board, blocks=args.blocks, filters=args.filters, action_values=args.action_values)
-    blob, _ = synthetic.make_weights(desc)
+    blob, _ = synthetic.make_weights(desc, policy_gain=args.policy_gain)
     net = AGNetwork(desc)
     net.loadWeights(blob)
     # tree arenas: every game starts with class-0 regions (8 nodes / 192 edges per playout of the budget) in pool-wide heaps and moves into larger
@@ -356,7 +359,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f16 (network, fp32 accumulate) + int/fp32 (tree)",
-            "data": "synthetic (random openings, He-init weights seed 1234)",
+            "data": "synthetic (random openings, He-init weights seed 1234%s)" % ("" if args.policy_gain == 1.0 else ", policy logits x %g: trained-like peaked priors" % args.policy_gain),
             "config": {"workload": "%s %dx%d, %d-block/%d-filter net%s, %d playouts/move, %d parallel self-play games per GPU, max_batch_size %d"
                                    % (RULE_NAMES[args.rules], args.board, args.board, args.blocks, args.filters, " (pvq)" if args.action_values else "", args.sims,
                                       args.games, args.batch),
