@@ -860,8 +860,17 @@ namespace ag
 		return result;
 	}
 
+	namespace
+	{
+		EdgeSelectorConfig unused_final_selector()
+		{ // a stand-alone pair never lets the engine pick the move (no advance stage): any valid final selector
+			EdgeSelectorConfig c;
+			c.policy = "best";
+			return c;
+		}
+	}
 	Search::Search(const GameConfig &gameOptions, const SearchConfig &searchOptions) :
-			own_pool(std::make_unique<GamePool>(gameOptions, searchOptions, EdgeSelectorConfig(), 1, maximum_number_of_simulations, false, "pv", false)),
+			own_pool(std::make_unique<GamePool>(gameOptions, searchOptions, unused_final_selector(), 1, maximum_number_of_simulations, false, "pv", false)),
 			pool(*own_pool), group(0), n_groups(1), stream(nullptr), batch_size(searchOptions.max_batch_size)
 	{ // the reference's constructor: a one-game engine (solver table, task buffers, the arenas of the Tree it will be used with), begun on the
 	  // empty board; Tree::setBoard gives it its positions

@@ -114,11 +114,15 @@ int agx_game_buffer_collect(AgxGameBuffer *b, AgxEngine *engine, int *games_adde
 
 	std::lock_guard<std::mutex> lock(b->mutex); // GeneratorManager::addToBuffer
 	std::map<std::pair<int, int>, PendingGame> &mine = b->pending[engine];
+	int missing_samples = 0;
 	for (int i = 0; i < counts.records; i++)
 	{ // GameDataStorage::addSample (GameGenerator.cpp:170)
 		const AgxMoveRecord &r = records[i];
 		if (r.sample_offset < 0)
+		{ // the sample did not fit into the device's sample pool: the game would be saved with fewer samples than moves — reported below
+			missing_samples++;
 			continue;
+		}
 		PendingSample s;
 		s.move_number = r.move_number;
 		s.bytes.assign(bytes.begin() + r.sample_offset, bytes.begin() + r.sample_offset + r.sample_bytes);
@@ -154,6 +158,22 @@ int agx_game_buffer_collect(AgxGameBuffer *b, AgxEngine *engine, int *games_adde
 	}
 	if (games_added != nullptr)
 		*games_added = added;
+	// games the engine stopped with an error never end: their samples must not stay pending for ever
+	AgxEngineStats stats;
+	if (agx_engine_stats(engine, &stats) == AGX_OK && stats.first_error != 0)
+	{
+		for (auto it = mine.begin(); it != mine.end();)
+		{
+			AgxGameInfo info;
+			if (agx_engine_game_info(engine, it->first.first, &info, nullptr, nullptr, 0) == AGX_OK && info.error != 0)
+				it = mine.erase(it);
+			else
+				++it;
+		}
+	}
+	AGX_REQUIRE(missing_samples == 0, AGX_ERR_STATE,
+			"agx_game_buffer_collect: %d move records lost their format-201 sample (sample pool full: raise AgxEngineConfig.record_sample_capacity or collect more often)",
+			missing_samples);
 	return AGX_OK;
 }
 

@@ -343,6 +343,9 @@ def main():
                 mfma_busy = pmc.get("nn_tower_mfma_busy_fraction")
                 solver_issue = pmc.get("k_solve_issue_busy_fraction")
                 nn_clock = pmc.get("nn_tower_shader_clock_mhz")
+        cu_total = ctypes.c_int()
+        check(lib.agx_device_cu_count(ctypes.byref(cu_total)))
+        spec_waves_per_launch = max(1, (args.speculative_waves if args.speculative_waves > 0 else 12 * cu_total.value) // slices)
         gpu_ms = kernel_ms[0] + kernel_ms[1] + kernel_ms[2] + kernel_ms[3] + ms_nn
         per_kernel = {"k_select": kernel_ms[0], "k_solve": kernel_ms[1], "nn_tower": ms_nn, "k_expand": kernel_ms[2], "k_advance": kernel_ms[3]}
         longest = max(per_kernel, key=per_kernel.get)
@@ -413,11 +416,18 @@ def main():
                          # only runs part of each slice's cycle; the search kernels use no MFMA)
                          "time_averaged_whole_chip_frac": (evals / elapsed) * flops / 2.5e15 / world,
                          "pmc_summary_build": pmc_build},
-            "roofline_solver": {"bound": "none (instruction issue / dependent-chain latency: one wave per game, tasks of a game strictly ordered)",
-                                "kernel": "k_solve (select + threat solver of a game in one wave)" if os.environ.get("AGX_FUSE_SELECT", "1") != "0" else "k_solve", "ms_per_step": kernel_ms[1] / launches,
+            "roofline_solver": {"bound": ("none (instruction issue of the solver waves: 3 per SIMD, the leaves of a batch in parallel)" if args.speculative
+                                          else "none (instruction issue / dependent-chain latency: one wave per game, tasks of a game strictly ordered)"),
+                                "kernel": ("k_search_spec (select + speculative threat solver + commit, one persistent launch)" if args.speculative else
+                                           ("k_solve (select + threat solver of a game in one wave)" if os.environ.get("AGX_FUSE_SELECT", "1") != "0" else "k_solve")),
+                                "ms_per_step": kernel_ms[1] / launches,
                                 "share_of_kernel_time": kernel_ms[1] / gpu_ms if gpu_ms > 0 else None,
                                 "solver_nodes_per_sec": solver_nodes / elapsed,
-                                "us_per_solver_node_per_wave": (kernel_ms[1] * 1e3 * (args.games // slices) / solver_nodes) if solver_nodes else None,
+                                # wave-time per solver node: launch time x the waves of the launch / nodes (an upper bound on the work per node:
+                                # it counts the waves' idle tail of the launch as well)
+                                "us_per_solver_node_per_wave": (kernel_ms[1] * 1e3 * (spec_waves_per_launch if args.speculative else args.games // slices) / solver_nodes)
+                                if solver_nodes else None,
+                                "waves_per_launch": spec_waves_per_launch if args.speculative else args.games // slices,
                                 "issue_busy_fraction_pmc": solver_issue},
             # second roof ("two kernels, two roofs"): the tree kernels are gathers/scans over the flat node/edge arrays
             "roofline_tree": {"bound": "hbm", "kernels": "k_expand + k_advance" if fused else "k_select + k_expand + k_advance", "achieved": tree_gbs, "peak": 8000.0, "unit": "GB/s",

@@ -818,4 +818,91 @@ void ago_cpu_baseline(int rules, int rows, int cols, const AgoSearchConfig *cfg,
 	}
 }
 
+
+/* ---- the hashing formulas and the action-list mechanics with CALLER-SUPPLIED keys / scripts: tests feed them what the compiled
+ * reference produced (oracle/ref_driver.cpp: ref_full_zobrist, ref_fast_zobrist, ref_action_list_script) ---- */
+uint64_t ago_full_zobrist_with_keys(const uint64_t *keys, int cells, const uint8_t *board, int sign_to_move)
+{
+	std::vector<Sign> b(cells);
+	for (int i = 0; i < cells; i++)
+		b[i] = static_cast<Sign>(board[i]);
+	return full_zobrist_hash(keys, b.data(), cells, static_cast<Sign>(sign_to_move));
+}
+/* keys: [2 * cells][2] (lo, hi); out: the hash of the board (2 words), then the hash after every move of `moves` (2 words each) */
+void ago_fast_zobrist_with_keys(const uint64_t *keys, int rows, int cols, const uint8_t *board, const uint16_t *moves, int n_moves, uint64_t *out)
+{
+	const int cells = rows * cols;
+	std::vector<Key128> k(2 * cells);
+	for (int i = 0; i < 2 * cells; i++)
+	{
+		k[i].lo = keys[2 * i];
+		k[i].hi = keys[2 * i + 1];
+	}
+	std::vector<Sign> b(cells);
+	for (int i = 0; i < cells; i++)
+		b[i] = static_cast<Sign>(board[i]);
+	Key128 h = fast_zobrist_hash(k.data(), b.data(), cells);
+	out[0] = h.lo;
+	out[1] = h.hi;
+	for (int i = 0; i < n_moves; i++)
+	{
+		fast_zobrist_update(k.data(), cols, h, Move::from_short(moves[i]));
+		out[2 * (1 + i)] = h.lo;
+		out[2 * (1 + i) + 1] = h.hi;
+	}
+}
+/* the script format of ref_action_list_script */
+int ago_action_list_script(const int *ops, int n_ops, int *out, int capacity)
+{
+	ActionStack stack;
+	stack.data.resize(4096);
+	std::vector<ActionList> lists(1);
+	lists[0].stack = &stack;
+	lists[0].base = 0;
+	int pos = 0, at = 0;
+	for (int k = 0; k < n_ops; k++)
+	{
+		const int op = ops[at++];
+		ActionList &top = lists.back();
+		if (op == 1)
+		{
+			top.add(Move::from_short(static_cast<uint16_t>(ops[at])), Score::raw(static_cast<uint16_t>(ops[at + 1])), ops[at + 2]);
+			at += 3;
+		}
+		else if (op == 2)
+		{ // ActionList(stack, parent, i) (ActionList.hpp:337-343), as Solver::recursive_solve opens a child
+			at++;
+			ActionList next;
+			next.stack = &stack;
+			next.base = stack.offset;
+			next.distance_from_root = top.distance_from_root + 1;
+			lists.push_back(next);
+		}
+		else if (op == 3)
+		{
+			lists.back().release();
+			lists.pop_back();
+		}
+		else
+		{
+			move_closer_to_front(top, Move::from_short(static_cast<uint16_t>(ops[at])), ops[at + 1]);
+			at += 2;
+		}
+		if (pos + 4 > capacity)
+			return -1;
+		out[pos++] = static_cast<int>(stack.offset);
+		out[pos++] = static_cast<int>(stack.max_offset);
+		out[pos++] = lists.back().size;
+		out[pos++] = lists.back().distance_from_root;
+	}
+	for (const ActionList &l : lists)
+		for (int i = 0; i < l.size; i++)
+		{
+			if (pos + 2 > capacity)
+				return -1;
+			out[pos++] = l[i].move.to_short();
+			out[pos++] = l[i].score.d;
+		}
+	return pos;
+}
 } /* extern "C" */

@@ -33,12 +33,16 @@ namespace ago
 			b.clear();
 		root = -1;
 	}
-	uint64_t Tree::hash_of(const Sign *board, Sign to_move) const
-	{
+	uint64_t full_zobrist_hash(const uint64_t *keys, const Sign *board, int cells, Sign to_move)
+	{ // FullZobristHashing::getHash (ZobristHashing.cpp:21-33): the key of the side to move, then one key per cell and content
 		uint64_t h = keys[to_move];
-		for (int i = 0, k = 3; i < cfg.rows * cfg.cols; i++, k += 3)
+		for (int i = 0, k = 3; i < cells; i++, k += 3)
 			h ^= keys[k + board[i]];
 		return h;
+	}
+	uint64_t Tree::hash_of(const Sign *board, Sign to_move) const
+	{
+		return full_zobrist_hash(keys.data(), board, cfg.rows * cfg.cols, to_move);
 	}
 	int Tree::seek(const Sign *board, Sign to_move) const
 	{ // NodeCache.cpp:250-264

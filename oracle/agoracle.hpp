@@ -287,6 +287,11 @@ namespace ago
 	struct Key128 { uint64_t lo = 0, hi = 0; };
 	struct TTEntry { uint64_t key_hi = 0; uint64_t data = 0; };
 
+	Key128 fast_zobrist_hash(const Key128 *keys, const Sign *board, int cells);                 // FastZobristHashing::getHash
+	void fast_zobrist_update(const Key128 *keys, int cols, Key128 &hash, Move move);          // FastZobristHashing::updateHash
+	uint64_t full_zobrist_hash(const uint64_t *keys, const Sign *board, int cells, Sign to_move); // FullZobristHashing::getHash
+	bool move_closer_to_front(ActionList &actions, Move move, int offset);                    // ActionList::moveCloserToFront
+
 	class Solver
 	{
 		public:

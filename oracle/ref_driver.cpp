@@ -5,7 +5,8 @@
  * MinML library (no stand-in headers are written): src/patterns/{PatternTable,PatternClassifier,ThreatTable,
  * DefensiveMoveTable}.cpp, src/game/Move.cpp, src/search/{Score,Value,ZobristHashing}.cpp,
  * src/search/monte_carlo/{Edge,Node}.cpp, src/utils/random.cpp, and the header-only utils/augmentations.hpp,
- * search/alpha_beta/SharedHashTable.hpp, patterns/RawPatternCalculator.hpp, patterns/ThreatHistogram.hpp, utils/low_precision.hpp
+ * search/alpha_beta/SharedHashTable.hpp, search/alpha_beta/ActionList.hpp, patterns/RawPatternCalculator.hpp, patterns/ThreatHistogram.hpp,
+ * utils/low_precision.hpp
  * (the LowFP formats of the dataset quantiser; the quantiser itself, src/dataset/SearchDataStorage.cpp, includes
  * <minml/utils/serialization.hpp> and is unbuildable here).
  * Built by oracle/Makefile into oracle/_ref/libagref.so straight from /root/reference; used by tests to pin the
@@ -26,6 +27,10 @@
 #include <alphagomoku/patterns/RawPatternCalculator.hpp>
 #include <alphagomoku/patterns/ThreatHistogram.hpp>
 #include <alphagomoku/utils/low_precision.hpp>
+#include <alphagomoku/search/ZobristHashing.hpp>
+#include <alphagomoku/search/alpha_beta/ActionList.hpp>
+#include <alphagomoku/utils/matrix.hpp>
+#include <memory>
 #include <vector>
 
 #include <cstdint>
@@ -286,4 +291,88 @@ float ref_lowfp_max(int format)
 	}
 }
 
+
+/* ---- FullZobristHashing / FastZobristHashing (search/ZobristHashing.cpp:15-68): ONE hashing object per call (its keys are random), the
+ * hashes of `n` boards; tests derive the keys from single-stone boards and check that the oracle's formulas reproduce every other hash ---- */
+static matrix<Sign> to_matrix(int rows, int cols, const uint8_t *cells)
+{
+	matrix<Sign> m(rows, cols);
+	for (int i = 0; i < rows * cols; i++)
+		m[i] = static_cast<Sign>(cells[i]);
+	return m;
+}
+void ref_full_zobrist(int rows, int cols, const uint8_t *boards, const int *signs, int n, uint64_t *out)
+{
+	const FullZobristHashing hashing(rows, cols);
+	for (int b = 0; b < n; b++)
+		out[b] = static_cast<uint64_t>(hashing.getHash(to_matrix(rows, cols, boards + static_cast<size_t>(b) * rows * cols), static_cast<Sign>(signs[b])));
+}
+/* out[2 b], out[2 b + 1] = low / high word of getHash(board b); then, starting from the hash of board 0, the hash after every updateHash(move)
+ * of `moves` (placing or removing: the same XOR), two words each */
+void ref_fast_zobrist(int rows, int cols, const uint8_t *boards, int n, const uint16_t *moves, int n_moves, uint64_t *out)
+{
+	const FastZobristHashing hashing(rows, cols);
+	for (int b = 0; b < n; b++)
+	{
+		const HashKey128 h = hashing.getHash(to_matrix(rows, cols, boards + static_cast<size_t>(b) * rows * cols));
+		out[2 * b] = static_cast<uint64_t>(h.getLow());
+		out[2 * b + 1] = static_cast<uint64_t>(h.getHigh());
+	}
+	HashKey128 h = hashing.getHash(to_matrix(rows, cols, boards));
+	for (int i = 0; i < n_moves; i++)
+	{
+		hashing.updateHash(h, Move(moves[i]));
+		out[2 * (n + i)] = static_cast<uint64_t>(h.getLow());
+		out[2 * (n + i) + 1] = static_cast<uint64_t>(h.getHigh());
+	}
+}
+
+/* ---- ActionStack / ActionList (search/alpha_beta/ActionList.hpp:247-470) driven by a script of operations on a stack of nested lists:
+ *   1 move score num : top.add(Move(move), Score::from_short(score), num)        2 index : open a child list of top at move `index`
+ *   3                : close the top list (its destructor releases its actions)   4 move offset : top.moveCloserToFront(Move(move), offset)
+ * After every operation out gets (stack offset, stack max_offset, size of the top list, its distance from the root); at the end the
+ * (move, score) of every action of every open list, root first.  Returns the number of ints written. ---- */
+int ref_action_list_script(const int *ops, int n_ops, int *out, int capacity)
+{
+	ActionStack stack(4096);
+	std::vector<std::unique_ptr<ActionList>> lists;
+	lists.push_back(std::make_unique<ActionList>(stack));
+	int pos = 0, at = 0;
+	for (int k = 0; k < n_ops; k++)
+	{
+		const int op = ops[at++];
+		ActionList &top = *lists.back();
+		if (op == 1)
+		{
+			top.add(Move(static_cast<uint16_t>(ops[at])), Score::from_short(static_cast<uint16_t>(ops[at + 1])), ops[at + 2]);
+			at += 3;
+		}
+		else if (op == 2)
+			lists.push_back(std::make_unique<ActionList>(stack, top, ops[at++]));
+		else if (op == 3)
+			lists.pop_back();
+		else
+		{
+			top.moveCloserToFront(Move(static_cast<uint16_t>(ops[at])), ops[at + 1]);
+			at += 2;
+		}
+		if (pos + 4 > capacity)
+			return -1;
+		out[pos++] = static_cast<int>(stack.offset());
+		out[pos++] = static_cast<int>(stack.max_offset());
+		out[pos++] = lists.back()->size();
+		out[pos++] = lists.back()->distanceFromRoot();
+	}
+	for (const auto &l : lists)
+		for (int i = 0; i < l->size(); i++)
+		{
+			if (pos + 2 > capacity)
+				return -1;
+			out[pos++] = (*l)[i].move.toShort();
+			out[pos++] = Score::to_short((*l)[i].score);
+		}
+	while (lists.size() > 1)
+		lists.pop_back(); // children before parents: each releases its own actions
+	return pos;
+}
 } /* extern "C" */

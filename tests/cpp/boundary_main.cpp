@@ -66,7 +66,11 @@ static int mode_generate(const std::map<std::string, std::string> &a)
 	GeneratorManager manager(game_config, selfplay_config);
 	manager.setWorkingDirectory(out);
 	manager.loadState();
-	manager.generate(NetworkLoader(a.at("--network")), geti(a, "--games", 32));
+	// one generate() per training iteration in the reference (TrainingManager::runIterationRL): every call sets its generator threads up again,
+	// and must get the SAME CU-masked streams back (they cannot be destroyed: agx.h)
+	const int iterations = geti(a, "--iterations", 1);
+	for (int it = 0; it < iterations; it++)
+		manager.generate(NetworkLoader(a.at("--network")), geti(a, "--games", 32) * (it + 1) / iterations);
 	manager.saveState(true);
 	manager.getGameBuffer().save(out + "/buffer_0.bin");
 	manager.printStats();
@@ -81,8 +85,9 @@ static int mode_generate(const std::map<std::string, std::string> &a)
 		raw.write(reinterpret_cast<const char*>(&size), 4);
 		raw.write(reinterpret_cast<const char*>(g.data()), g.size());
 	}
-	std::printf("{\"mode\": \"generate\", \"threads\": %zu, \"games\": %d, \"samples\": %d, \"cross_win\": %d, \"draws\": %d, \"circle_win\": %d, \"game_length\": %d}\n",
-			selfplay_config.device_config.size(), st.games, st.samples, st.cross_win, st.draws, st.circle_win, st.game_length);
+	std::printf("{\"mode\": \"generate\", \"threads\": %zu, \"games\": %d, \"samples\": %d, \"cross_win\": %d, \"draws\": %d, \"circle_win\": %d, \"game_length\": %d, "
+			"\"iterations\": %d, \"masked_streams\": %d}\n",
+			selfplay_config.device_config.size(), st.games, st.samples, st.cross_win, st.draws, st.circle_win, st.game_length, iterations, agx_stream_masked_count());
 	return 0;
 }
 

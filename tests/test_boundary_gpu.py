@@ -131,6 +131,19 @@ def test_nn_evaluator_with_host_tasks(network_file, agx_lib, tmp_path):
     net.close()
 
 
+def test_repeated_generate_calls_reuse_their_streams(network_file, tmp_path):
+    """GeneratorManager::generate once per training iteration: every call sets the generator threads (and their CU-masked slice streams) up
+    again.  Such streams cannot be destroyed (ROCm 7.2), so they are cached per (device, mask): 12 iterations end with exactly the streams
+    of one (2 slices per thread: 2 masks)."""
+    path, _, _ = network_file
+    out = tmp_path / "work"
+    out.mkdir()
+    line, _ = run("generate", "--network", path, "--games", 12, "--iterations", 12, "--games-per-thread", 16, "--devices", "0", "--sims", 30, "--batch", 4,
+                  "--out", out, "--nn-batch", 32)
+    assert line["iterations"] == 12 and line["games"] >= 12
+    assert line["masked_streams"] == 2
+
+
 def test_players_with_the_reference_constructors(network_file, agx_lib, tmp_path):
     """evaluation/Player.cpp:64-129,205-212 compiled against include/alphagomoku_agx/ as written — Tree(const TreeConfig&),
     Search(const GameConfig&, const SearchConfig&), cleanup / setBoard / setEdgeSelector / setEdgeGenerator / select / solve / scheduleToNN /

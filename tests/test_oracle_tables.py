@@ -305,3 +305,120 @@ def test_threat_lists_equal_reference(oracle, ref):
         na = oracle.ago_threat_histogram(p(arr), len(ops) // 4, p(a))
         nb = ref.ref_threat_histogram(p(arr), len(ops) // 4, p(b))
         assert na == nb and np.array_equal(a[:na], b[:nb]), trial
+
+
+# ---- round 3: hashing formulas and the solver's action lists against the compiled reference ----
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+@pytest.mark.parametrize("n", [9, 15, 20])
+def test_full_zobrist_formula_matches_compiled_reference(oracle, ref, n):
+    """FullZobristHashing::getHash (ZobristHashing.cpp:21-33).  The reference's keys are random per object, so the hashes of the empty board
+    and of every single-stone board give the key table (up to the XOR of the empty-cell keys, which is folded into the sign keys); the
+    oracle's formula (Tree::hash_of) on that table must then reproduce the reference's hash of arbitrary boards, for all three signs."""
+    rng = np.random.default_rng(n)
+    hw = n * n
+    boards, signs = [np.zeros(hw, np.uint8)] * 3, [0, 1, 2]
+    for cell in range(hw):
+        for v in (1, 2):
+            b = np.zeros(hw, np.uint8)
+            b[cell] = v
+            boards.append(b)
+            signs.append(1)
+    probes = []
+    for _ in range(60):
+        b = rng.integers(0, 3, hw).astype(np.uint8) * (rng.random(hw) < rng.random()).astype(np.uint8)
+        probes.append(b)
+        boards.append(b)
+        signs.append(int(rng.integers(0, 3)))
+    flat = np.ascontiguousarray(np.stack(boards))
+    sg = np.array(signs, np.int32)
+    out = np.zeros(len(boards), np.uint64)
+    ref.ref_full_zobrist(n, n, _ptr(flat), _ptr(sg), len(boards), _ptr(out))
+    keys = np.zeros(3 + 3 * hw, np.uint64)
+    keys[0:3] = out[0:3]                                   # sign key ^ XOR of all empty-cell keys
+    for cell in range(hw):
+        for v in (1, 2):
+            keys[3 + 3 * cell + v] = out[3 + 2 * cell + (v - 1)] ^ out[1]     # cell key relative to the empty cell's
+    oracle.ago_full_zobrist_with_keys.restype = ctypes.c_uint64
+    for k, b in enumerate(probes):
+        idx = 3 + 2 * hw + k
+        got = oracle.ago_full_zobrist_with_keys(_ptr(keys), hw, _ptr(np.ascontiguousarray(b)), int(sg[idx]))
+        assert got == int(out[idx]), k
+
+
+@pytest.mark.parametrize("n", [15, 20])
+def test_fast_zobrist_formula_matches_compiled_reference(oracle, ref, n):
+    """FastZobristHashing::getHash / updateHash (ZobristHashing.cpp:49-68, ZobristHashing.hpp:125-129): the solver's 128-bit keys"""
+    rng = np.random.default_rng(100 + n)
+    hw = n * n
+    start = (rng.integers(0, 3, hw) * (rng.random(hw) < 0.2)).astype(np.uint8)
+    boards = [start]
+    for cell in range(hw):
+        for v in (1, 2):
+            b = np.zeros(hw, np.uint8)
+            b[cell] = v
+            boards.append(b)
+    probes = [(rng.integers(0, 3, hw) * (rng.random(hw) < rng.random())).astype(np.uint8) for _ in range(40)]
+    boards += probes
+    # a sequence of placements and removals on the first board
+    moves, cur = [], start.copy()
+    for _ in range(80):
+        cell = int(rng.integers(0, hw))
+        v = int(cur[cell]) if cur[cell] else int(rng.integers(1, 3))
+        cur[cell] = 0 if cur[cell] else v
+        moves.append(v | ((cell // n) << 2) | ((cell % n) << 9))
+    mv = np.array(moves, np.uint16)
+    flat = np.ascontiguousarray(np.stack(boards))
+    out = np.zeros(2 * (len(boards) + len(moves)), np.uint64)
+    ref.ref_fast_zobrist(n, n, _ptr(flat), len(boards), _ptr(mv), len(moves), _ptr(out))
+    keys = np.zeros((2 * hw, 2), np.uint64)
+    for cell in range(hw):
+        for v in (1, 2):
+            i = 1 + 2 * cell + (v - 1)
+            keys[2 * cell + (v - 1)] = out[2 * i:2 * i + 2]          # the empty board hashes to zero: a single stone's hash IS its key
+    for k, b in enumerate(probes):
+        got = np.zeros(2, np.uint64)
+        oracle.ago_fast_zobrist_with_keys(_ptr(keys), n, n, _ptr(np.ascontiguousarray(b)), None, 0, _ptr(got))
+        i = 1 + 2 * hw + k
+        assert np.array_equal(got, out[2 * i:2 * i + 2]), k
+    got = np.zeros(2 * (1 + len(moves)), np.uint64)
+    oracle.ago_fast_zobrist_with_keys(_ptr(keys), n, n, _ptr(start), _ptr(mv), len(moves), _ptr(got))
+    assert np.array_equal(got[:2], out[:2])
+    assert np.array_equal(got[2:], out[2 * len(boards):])             # every add / undo step
+
+
+def test_action_list_mechanics_match_compiled_reference(oracle, ref):
+    """ActionStack / ActionList (search/alpha_beta/ActionList.hpp:247-470): add (incl. num = 0: the slot is written, the size is not),
+    nested child lists on the shared stack, release on close, moveCloserToFront(move, offset) — stack offsets, high-water mark, list sizes
+    and the final ORDER of every list, on random scripts."""
+    rng = np.random.default_rng(7)
+    for trial in range(200):
+        ops, n_ops, depth, sizes, seen = [], 0, 0, [0], []
+        for _ in range(int(rng.integers(5, 60))):
+            r = rng.random()
+            if r < 0.55 or sizes[-1] == 0:
+                num = 0 if rng.random() < 0.1 else 1
+                move = int(rng.integers(1, 3)) | (int(rng.integers(0, 15)) << 2) | (int(rng.integers(0, 15)) << 9)
+                seen.append(move)
+                ops += [1, move, int(rng.integers(0, 65536)), num]
+                sizes[-1] += num
+            elif r < 0.7 and depth < 6:
+                ops += [2, int(rng.integers(0, sizes[-1]))]
+                sizes.append(0)
+                depth += 1
+            elif r < 0.8 and depth > 0:
+                ops += [3]
+                sizes.pop()
+                depth -= 1
+            else:   # mostly a move that is somewhere on the stack (the table move of the solver), sometimes one that is not
+                move = seen[int(rng.integers(0, len(seen)))] if rng.random() < 0.8 else int(rng.integers(1, 3)) | (int(rng.integers(0, 15)) << 2)
+                ops += [4, move, int(rng.integers(0, max(1, sizes[-1])))]
+            n_ops += 1
+        arr = np.array(ops, np.int32)
+        a, b = np.zeros(8192, np.int32), np.zeros(8192, np.int32)
+        na = ref.ref_action_list_script(_ptr(arr), n_ops, _ptr(a), len(a))
+        nb = oracle.ago_action_list_script(_ptr(arr), n_ops, _ptr(b), len(b))
+        assert na == nb and na > 0 and np.array_equal(a[:na], b[:nb]), trial
