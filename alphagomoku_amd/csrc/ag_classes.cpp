@@ -675,7 +675,7 @@ namespace ag
 		// pacing only, per-game results do not depend on either: the leaves of a batch solved in parallel (k_search_spec), stragglers of a
 		// launch put off to the next one
 		c.speculative_solver = 1;
-		c.solver_yield_fraction = (games >= 64) ? 0.9f : 0.0f;
+		c.solver_yield_fraction = (games >= 64) ? 0.85f : 0.0f;
 		check(agx_engine_create(&c, &engine));
 	}
 	GamePool::~GamePool()

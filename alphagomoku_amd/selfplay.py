@@ -58,18 +58,21 @@ def cu_mask_stream(first_cu, n_cus, instance=0):
     return s
 
 
-def chip_partitions(n_slices, network_cus):
-    """The chip as TWO partitions shared by all slices of a pool: the first `network_cus` compute units run every slice's network launches,
-    the rest every slice's search / tree launches (one stream per slice on each partition, ordered by events).  Slices in different phases
-    fill each other's gaps on the search partition, and the matrix cores of the network partition always have a slice to work for.
-    Returns (search_streams, network_streams, search_cus, network_cus)."""
+def chip_partitions(n_slices, network_cus, tree_cus=0):
+    """The chip as partitions shared by all slices of a pool: the first `network_cus` compute units run every slice's network launches, the
+    last `tree_cus` (if any) every slice's expand / advance launches (short kernels with large workgroups, which would otherwise queue behind
+    the persistent search waves), the rest every slice's search launches — one stream per slice on each partition, ordered by events.
+    Slices in different phases fill each other's gaps on the search partition, and the matrix cores of the network partition always have a
+    slice to work for.  Returns (search_streams, network_streams, tree_streams or None, search_cus, network_cus)."""
     total = ctypes.c_int()
     check(lib.agx_device_cu_count(ctypes.byref(total)))
-    if not 0 < network_cus < total.value:
-        raise ValueError("network partition of %d compute units on a device with %d" % (network_cus, total.value))
-    search = [cu_mask_stream(network_cus, total.value - network_cus, instance=k) for k in range(n_slices)]
+    search_cus = total.value - network_cus - tree_cus
+    if network_cus <= 0 or tree_cus < 0 or search_cus <= 0:
+        raise ValueError("partitions of %d + %d compute units on a device with %d" % (network_cus, tree_cus, total.value))
     network = [cu_mask_stream(0, network_cus, instance=k) for k in range(n_slices)]
-    return search, network, total.value - network_cus, network_cus
+    search = [cu_mask_stream(network_cus, search_cus, instance=k) for k in range(n_slices)]
+    tree = [cu_mask_stream(network_cus + search_cus, tree_cus, instance=k) for k in range(n_slices)] if tree_cus > 0 else None
+    return search, network, tree, search_cus, network_cus
 
 
 def pack_openings(openings):

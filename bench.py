@@ -105,7 +105,7 @@ def main():
     ap.add_argument("--rules", type=int, default=0)
     ap.add_argument("--action-values", type=int, default=0, help="1: ResnetPVQ network (extra action-values head feeding the edge Q)")
     ap.add_argument("--table-entries", type=int, default=4 * 1024 * 1024)
-    ap.add_argument("--yield-fraction", type=float, default=0.9,
+    ap.add_argument("--yield-fraction", type=float, default=0.85,
                     help="straggler cut-off of the search launch: once this fraction of its games is done, a game whose batch still needs a serial re-run\n"
                          "(speculative solver) or another serial solve sits this step out (0 = never)")
     ap.add_argument("--slices", type=int, default=4,
@@ -124,6 +124,7 @@ def main():
     ap.add_argument("--network-cus", type=int, default=0,
                     help="> 0: the chip as two partitions shared by all slices — this many compute units run every slice's network launches, the rest "
                          "every slice's search launches (streams ordered by events); 0: every slice owns 1 / slices of the chip for all its stages")
+    ap.add_argument("--tree-cus", type=int, default=0, help="with --network-cus: compute units set aside for the expand / advance launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=24.0)
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline, 0 = every host CPU")
@@ -198,13 +199,13 @@ def main():
     while slices > 1 and (args.games % slices != 0 or args.games // slices < 4):
         slices //= 2
     streams, cus_per_slice, total_cus = [None], None, None
-    net_streams, events = None, None
+    net_streams, tree_streams, events = None, None, None
     if slices > 1 and args.network_cus > 0:
-        streams, net_streams, search_cus, cus_per_slice = selfplay.chip_partitions(slices, args.network_cus)
-        total_cus = search_cus + cus_per_slice
+        streams, net_streams, tree_streams, search_cus, cus_per_slice = selfplay.chip_partitions(slices, args.network_cus, args.tree_cus)
+        total_cus = search_cus + cus_per_slice + args.tree_cus
         check(lib.agx_net_set_launch_width(net._net, cus_per_slice))
         events = []
-        for _ in range(2 * slices):
+        for _ in range(3 * slices):
             ev = ctypes.c_void_p()
             check(lib.agx_event_create(ctypes.byref(ev)))
             events.append(ev)
@@ -222,17 +223,22 @@ def main():
         ns = streams[g]
         if net_streams is not None:   # the tower runs on the network partition: its stream waits for the search launch, and the search stream for it
             ns = net_streams[g]
-            check(lib.agx_event_record(events[2 * g], streams[g]))
-            check(lib.agx_stream_wait_event(ns, events[2 * g]))
+            check(lib.agx_event_record(events[3 * g], streams[g]))
+            check(lib.agx_stream_wait_event(ns, events[3 * g]))
         if nn_timer is not None:
             check(lib.agx_timer_start(nn_timer, ns))
         pool.evaluate_group(net, g, slices, ns)
         if nn_timer is not None:
             check(lib.agx_timer_stop(nn_timer, ns))
+        ts = streams[g]
         if net_streams is not None:
-            check(lib.agx_event_record(events[2 * g + 1], ns))
-            check(lib.agx_stream_wait_event(streams[g], events[2 * g + 1]))
-        pool.expand_backup_group(g, slices, streams[g])
+            ts = tree_streams[g] if tree_streams is not None else streams[g]
+            check(lib.agx_event_record(events[3 * g + 1], ns))
+            check(lib.agx_stream_wait_event(ts, events[3 * g + 1]))
+        pool.expand_backup_group(g, slices, ts)
+        if tree_streams is not None:   # the slice's next search launch waits for its tree launches
+            check(lib.agx_event_record(events[3 * g + 2], ts))
+            check(lib.agx_stream_wait_event(streams[g], events[3 * g + 2]))
 
     def keep_going(i):
         # what a generator thread does every few hundred steps — hand the finished samples over (GeneratorManager.cpp:160-164) and keep the
@@ -347,7 +353,8 @@ def main():
         check(lib.agx_device_cu_count(ctypes.byref(cu_total)))
         spec_waves_per_launch = max(1, (args.speculative_waves if args.speculative_waves > 0 else 12 * cu_total.value) // slices)
         gpu_ms = kernel_ms[0] + kernel_ms[1] + kernel_ms[2] + kernel_ms[3] + ms_nn
-        per_kernel = {"k_select": kernel_ms[0], "k_solve": kernel_ms[1], "nn_tower": ms_nn, "k_expand": kernel_ms[2], "k_advance": kernel_ms[3]}
+        search_kernel = "k_search_spec" if args.speculative else "k_solve"   # the launch timed as the solve stage
+        per_kernel = {"k_select": kernel_ms[0], search_kernel: kernel_ms[1], "nn_tower": ms_nn, "k_expand": kernel_ms[2], "k_advance": kernel_ms[3]}
         longest = max(per_kernel, key=per_kernel.get)
         result = {
             "metric": "MCTS simulations/sec (self-play, %dx%d %s)" % (args.board, args.board, RULE_NAMES[args.rules]),
@@ -373,10 +380,11 @@ def main():
             # how the pool is stepped: `count` slices of games_per_gpu / count games, each on a stream that owns cus_per_slice compute units;
             # the slices' launches overlap in time, so the per-launch durations below add up to more than ms_per_step
             "slices": {"count": slices, "cus_per_slice": cus_per_slice, "games_per_slice": args.games // slices,
-                       "partitions": ({"network_cus": cus_per_slice, "search_cus": total_cus - cus_per_slice} if net_streams is not None else None)},
+                       "partitions": ({"network_cus": cus_per_slice, "search_cus": total_cus - cus_per_slice - args.tree_cus, "tree_cus": args.tree_cus}
+                                      if net_streams is not None else None)},
             "stage_ms_per_step": {"select_solve": ms_sel / launches, "network": ms_nn / launches, "expand_backup_advance": ms_exp / launches,
                                   "of": "one slice's launches (average)"},
-            "kernel_ms_per_step": {"k_select": kernel_ms[0] / launches, "k_solve": kernel_ms[1] / launches, "nn_tower": ms_nn / launches,
+            "kernel_ms_per_step": {"k_select": kernel_ms[0] / launches, search_kernel: kernel_ms[1] / launches, "nn_tower": ms_nn / launches,
                                    "k_expand": kernel_ms[2] / launches, "k_advance": kernel_ms[3] / launches},
             # default: Search::select runs inside the solver's launch (one wave per game selects, then solves: k_solve<.., FUSED>), its time is
             # part of k_solve and k_select is 0; AGX_FUSE_SELECT=0 launches them separately

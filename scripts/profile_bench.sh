@@ -15,3 +15,5 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_A
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAIT_INST_LDS -d gpurun_out/${tag}_pmc_lds -o p -- python3 bench.py --steps 40 --warmup 30 --age-steps 0 --no-cpu-baseline > /dev/null 2>&1
 python3 scripts/prof_summary.py gpurun_out/${tag}_trace/t_results.db gpurun_out/${tag}_bench_kernel_stats.csv "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps $steps --warmup 30 --age-steps ${3:-1000} --no-cpu-baseline" "$(cat gpurun_out/${tag}_trace.json | head -c 400)"
 python3 scripts/pmc_bench_summary.py gpurun_out/${tag}_pmc_summary.json gpurun_out/${tag}_pmc_fetch/p_results.db gpurun_out/${tag}_pmc_write/p_results.db gpurun_out/${tag}_pmc_sq/p_results.db gpurun_out/${tag}_pmc_lds/p_results.db
+# the rocpd databases are hundreds of MB: only the summaries travel back (gpurun merges at most 64 MiB of gpurun_out/)
+rm -rf gpurun_out/${tag}_trace gpurun_out/${tag}_pmc_fetch gpurun_out/${tag}_pmc_write gpurun_out/${tag}_pmc_sq gpurun_out/${tag}_pmc_lds
