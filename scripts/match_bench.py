@@ -20,7 +20,8 @@ def main():
     ap.add_argument("--sims", type=int, default=400)
     ap.add_argument("--blocks", type=int, default=6)
     ap.add_argument("--filters", type=int, default=128)
-    ap.add_argument("--yield-fraction", type=float, default=0.75)
+    ap.add_argument("--yield-fraction", type=float, default=0.85)
+    ap.add_argument("--speculative", type=int, default=1, help="the leaves of a batch solved in parallel (AgxEngineConfig.speculative_solver)")
     ap.add_argument("--slices", type=int, default=4)
     args = ap.parse_args()
     from alphagomoku_amd import build
@@ -35,7 +36,7 @@ def main():
         net.loadWeights(synthetic.make_weights(desc, seed=seed)[0])
         nets.append(net)
     slices = args.slices if (args.slices > 1 and args.pairs % args.slices == 0) else 1
-    streams = [None]
+    streams, per = [None], 0
     if slices > 1:
         streams, per = selfplay.chip_slices(slices)
         for net in nets:
@@ -43,7 +44,8 @@ def main():
     pools = []
     for k in range(slices):
         cfg = selfplay.default_config(rules=0, board_size=15, n_games=2 * args.pairs // slices, max_batch_size=8, max_simulations=args.sims,
-                                      tss_table_entries=4 * 1024 * 1024, solver_yield_fraction=args.yield_fraction, match_mode=1)
+                                      tss_table_entries=4 * 1024 * 1024, solver_yield_fraction=args.yield_fraction, match_mode=1,
+                                      speculative_solver=args.speculative, speculative_waves=(12 * per if slices > 1 else 0))
         pool = selfplay.GeneratorPool(cfg)
         pool.begin(selfplay.pack_openings(synthetic.make_openings(15, args.pairs // slices * 3, seed0=7000 + 100000 * k, rules=0)))
         pools.append(pool)
