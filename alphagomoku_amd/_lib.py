@@ -99,7 +99,7 @@ class AgxEngineConfig(ctypes.Structure):
                 ("symmetry_seed", ctypes.c_uint64), ("max_children", ctypes.c_int), ("noise_type", ctypes.c_int), ("noise_weight", ctypes.c_float),
                 ("noise_seed", ctypes.c_uint64), ("action_values", ctypes.c_int), ("match_mode", ctypes.c_int), ("policy_temperature", ctypes.c_float),
                 ("arena_reserve", ctypes.c_float), ("search_threads", ctypes.c_int), ("record_format", ctypes.c_int), ("record_sample_capacity", ctypes.c_int), ("game_end_capacity", ctypes.c_int),
-                ("speculative_solver", ctypes.c_int), ("speculative_waves", ctypes.c_int), ("force_expand_root", ctypes.c_int)]
+                ("speculative_solver", ctypes.c_int), ("speculative_waves", ctypes.c_int), ("force_expand_root", ctypes.c_int), ("search_buffers", ctypes.c_int)]
 
 
 class AgxEngineBuffers(ctypes.Structure):

@@ -219,7 +219,8 @@ namespace
 			return;
 		}
 		// tournament search: the search threads take the tree one after the other (SearchThread.cpp:124-129), in thread order
-		for (int t = 0; t < E.n_games; t++)
+		// (double-buffered search: this launch's buffer of every thread — the other buffer's leaves keep their virtual losses meanwhile)
+		for (int t = E.grp_first; t < E.grp_first + E.grp_count; t++)
 		{
 			if (E.games[t].error == 0)
 				select_batch(E, 0, t, lane, sh_board, sh_cboard, sh_keys);
@@ -248,7 +249,7 @@ namespace
 		}
 		if (lane < OV_CAP / 32)
 			sh.ov_dirty[lane] = 0;
-		u64 *tt = E.tt + static_cast<size_t>(g) * (E.tt_bucket_mask + 1ull) * 8ull;
+		u64 *tt = E.tt + static_cast<size_t>(g % E.tt_mod) * (E.tt_bucket_mask + 1ull) * 8ull; // (double-buffered search: both buffers of a thread use its one solver)
 #ifdef AGX_SOLVER_PROFILE
 		unsigned long long c0 = wall_clock64(), c_run = 0, c_place = 0, n_place = 0;
 #endif
@@ -614,7 +615,7 @@ namespace
 		const int g = c.game;
 		GameState &gs = E.games[g];
 		const int n_tasks = gs.n_tasks;
-		u64 *tt = E.tt + static_cast<size_t>(g) * (E.tt_bucket_mask + 1ull) * 8ull;
+		u64 *tt = E.tt + static_cast<size_t>(g % E.tt_mod) * (E.tt_bucket_mask + 1ull) * 8ull; // (double-buffered search: both buffers of a thread use its one solver)
 		for (int k = c.k; k < n_tasks; k++)
 		{
 			const int slot = g * E.batch + k;
@@ -987,7 +988,9 @@ namespace
 		DEdge *edges = edges_of(E, tg, gs.arena);
 		int *ht = ht_of(E, tg);
 		const int n = E.n, hw = E.hw;
-		const int first_lane = E.shared_tree ? 0 : g0, last_lane = E.shared_tree ? E.n_games - 1 : g0;
+		const int first_lane = E.shared_tree ? E.grp_first : g0, last_lane = E.shared_tree ? E.grp_first + E.grp_count - 1 : g0;
+		if (E.shared_tree && gs.grow_pending != 0 && gs.grow_owner != E.grp_first)
+			return; // double-buffered search: the buffer whose expansion waits for larger arenas goes first, this one keeps its leaves one more turn
 		{
 			/*
 			 * NodeCache::resize / ObjectPool growth (NodeCache.cpp:320-355, utils/ObjectPool.hpp:74-289) for flat arenas: BEFORE anything is
@@ -1008,7 +1011,10 @@ namespace
 			if (!fits && gs.arena_class + 1 < ARENA_CLASSES && gs.grow_pending != 4)
 			{ // (also straight after a growth that was not enough: one more class)
 				if (lane == 0)
+				{
 					gs.grow_pending = 1;
+					gs.grow_owner = E.grp_first;
+				}
 				return;
 			}
 			if (lane == 0)
@@ -1414,7 +1420,7 @@ namespace
 	}
 	__device__ void clear_solver_table(const EngineDev &E, int g, int tid)
 	{ // AlphaBetaSearch::clear (SharedHashTable.hpp:137-140)
-		ulonglong2 *tt = reinterpret_cast<ulonglong2*>(E.tt + static_cast<size_t>(g) * (E.tt_bucket_mask + 1ull) * 8ull);
+		ulonglong2 *tt = reinterpret_cast<ulonglong2*>(E.tt + static_cast<size_t>(g % E.tt_mod) * (E.tt_bucket_mask + 1ull) * 8ull);
 		const size_t entries = (E.tt_bucket_mask + 1ull) * 4ull;
 		ulonglong2 empty;
 		empty.x = 0ull;
@@ -1670,6 +1676,28 @@ namespace
 		DNode *nodes = nodes_of(E, g, gs.arena);
 		DEdge *edges = edges_of(E, g, gs.arena);
 		const int n = E.n;
+		if (E.shared_tree && E.search_buffers > 1)
+		{ // Search::cleanup (Search.cpp:233-242) of every thread before the move: the OTHER buffer's leaves — selected, solved, in the
+		  // network or back from it — are dropped and their virtual losses taken back (SearchThread.cpp:108-109 after asynchronous_run's break)
+			if (wave == 0)
+				for (int r = 0; r < E.n_games; r++)
+				{
+					if (r >= E.grp_first && r < E.grp_first + E.grp_count)
+						continue; // this buffer was expanded and backed up by k_expand just before
+					GameState &os = E.games[r];
+					const int pending = os.n_tasks;
+					for (int k = 0; k < pending; k++)
+					{
+						const DTask &t = E.tasks[static_cast<size_t>(r) * E.batch + k];
+						cancel_virtual_loss(nodes, edges, t, t.path_len, lane);
+						wave_sync();
+					}
+					if (lane == 0)
+						os.n_tasks = 0;
+				}
+			__threadfence_block();
+			__syncthreads();
+		}
 		const DNode root = nodes[gs.root];
 
 		// ---- final selector: "best" (EdgeSelector.cpp:515-536) or max_visit / min_visit / max_value / max_policy (:476-514) ----
@@ -2083,7 +2111,7 @@ namespace
 		const int asks = E.shared_tree ? 0 : (E.match_mode ? g % (E.n_games / 2) : g);
 		if (E.games[asks].restart_id <= 0)
 			return;
-		ulonglong2 *tt = reinterpret_cast<ulonglong2*>(E.tt + static_cast<size_t>(g) * (E.tt_bucket_mask + 1ull) * 8ull);
+		ulonglong2 *tt = reinterpret_cast<ulonglong2*>(E.tt + static_cast<size_t>(g % E.tt_mod) * (E.tt_bucket_mask + 1ull) * 8ull);
 		const size_t entries = (E.tt_bucket_mask + 1ull) * 4ull;
 		const size_t per = (entries + parts - 1) / parts;
 		const size_t end = (per * (part + 1) < entries) ? per * (part + 1) : entries;
@@ -2685,6 +2713,7 @@ int agx_engine_default_config(AgxEngineConfig *cfg)
 	cfg->speculative_solver = 0;
 	cfg->speculative_waves = 0;
 	cfg->force_expand_root = 1;
+	cfg->search_buffers = 0;
 	cfg->noise_type = 0;
 	cfg->noise_weight = 0.0f;
 	cfg->noise_seed = 0x2545F4914F6CDD1Dull;
@@ -2705,8 +2734,13 @@ int agx_engine_create(const AgxEngineConfig *cfg, AgxEngine **out)
 	AGX_REQUIRE(cfg->policy_temperature >= 0.0f, AGX_ERR_INVALID, "agx_engine_create: policy_temperature must not be negative");
 	AGX_REQUIRE(!cfg->match_mode || cfg->n_games % 2 == 0, AGX_ERR_INVALID, "agx_engine_create: match_mode pairs the trees, n_games must be even");
 	AGX_REQUIRE(cfg->noise_weight >= 0.0f && cfg->noise_weight <= 1.0f, AGX_ERR_INVALID, "agx_engine_create: noise_weight must be in [0, 1]");
-	AGX_REQUIRE(cfg->search_threads <= 1 || (cfg->search_threads == cfg->n_games && !cfg->match_mode && cfg->solver_yield_fraction == 0.0f), AGX_ERR_INVALID,
-			"agx_engine_create: search_threads > 1 makes the pool ONE tree searched by n_games threads: n_games must equal search_threads, no match_mode, no yielding");
+	AGX_REQUIRE(cfg->search_buffers >= 0 && cfg->search_buffers <= 2, AGX_ERR_INVALID, "agx_engine_create: search_buffers must be 0, 1 or 2");
+	{
+		const int threads = std::max(1, cfg->search_threads), buffers = (cfg->search_buffers == 2) ? 2 : 1;
+		AGX_REQUIRE((threads == 1 && buffers == 1) || (threads * buffers == cfg->n_games && !cfg->match_mode && cfg->solver_yield_fraction == 0.0f), AGX_ERR_INVALID,
+				"agx_engine_create: search_threads > 1 / search_buffers = 2 make the pool ONE tree searched by n_games task buffers: n_games must equal "
+				"search_threads x buffers (%d x %d), no match_mode, no yielding", threads, buffers);
+	}
 	AGX_REQUIRE(cfg->record_format >= 0 && cfg->record_format <= 3, AGX_ERR_INVALID, "agx_engine_create: record_format must be 0..3 (bit 0 edge snapshots, bit 1 format-201 samples)");
 
 	AgxEngine *e = new AgxEngine();
@@ -2780,7 +2814,7 @@ int agx_engine_create(const AgxEngineConfig *cfg, AgxEngine **out)
 	AGX_TRY(dev_alloc(e, &d.free_bundles, static_cast<size_t>(ARENA_CLASSES) * G));
 	AGX_TRY(dev_alloc(e, &d.tasks, G * d.batch));
 	// speculative solver: its waves solve several leaves of one game at once, so each wave brings its own spill areas (behind the games')
-	e->speculative = cfg->speculative_solver != 0 && cfg->search_threads <= 1 && cfg->tss_max_positions <= 250 && cfg->max_batch_size <= 16;
+	e->speculative = cfg->speculative_solver != 0 && cfg->search_threads <= 1 && cfg->search_buffers != 2 && cfg->tss_max_positions <= 250 && cfg->max_batch_size <= 16;
 	if (e->speculative)
 	{
 		int cus = 0, device_of_engine = 0;
@@ -2824,7 +2858,11 @@ int agx_engine_create(const AgxEngineConfig *cfg, AgxEngine **out)
 	d.has_q = cfg->action_values ? 1 : 0;
 	d.match_mode = cfg->match_mode ? 1 : 0;
 	d.prune_root = (cfg->match_mode || !cfg->force_expand_root) ? 1 : 0; // UnifiedGenerator(.., forceExpandRoot): true in self-play (GameGenerator.cpp:183-184), false for a Player (Player.cpp:109)
-	d.shared_tree = (cfg->search_threads > 1) ? 1 : 0;
+	d.search_buffers = (cfg->search_buffers == 2) ? 2 : 1;
+	d.shared_tree = (cfg->search_threads > 1 || d.search_buffers == 2) ? 1 : 0;
+	d.tt_mod = (d.search_buffers == 2) ? std::max(1, cfg->search_threads) : static_cast<int>(G);
+	d.grp_first = 0;
+	d.grp_count = static_cast<int>(G);
 	d.policy_temperature = cfg->policy_temperature;
 	AGX_TRY(dev_alloc(e, &d.nn_q, d.has_q ? G * d.batch * d.hw * 2 : 1));
 	AGX_TRY(dev_alloc(e, &d.noise, d.noise_type ? G * d.hw : 1));
@@ -2967,7 +3005,10 @@ static int group_range(const AgxEngine *e, int group, int n_groups, EngineDev &d
 	d.nn_counter = 16 + group;
 	d.yield_counter = 32 + group;
 	AGX_REQUIRE(count > 0, AGX_ERR_INVALID, "group %d of %d is empty for %d games", group, n_groups, e->dev.n_games);
-	AGX_REQUIRE(!e->dev.shared_tree || n_groups == 1, AGX_ERR_INVALID, "a tournament-search pool (search_threads) is one tree: it cannot be stepped in groups");
+	AGX_REQUIRE(!e->dev.shared_tree || n_groups == e->dev.search_buffers, AGX_ERR_INVALID,
+			"a tournament-search pool (search_threads) is one tree: it is stepped as a whole, or buffer by buffer (2 groups) when search_buffers = 2 — not in %d groups", n_groups);
+	d.grp_first = d.g0;
+	d.grp_count = count;
 	return AGX_OK;
 }
 
@@ -3258,6 +3299,11 @@ int agx_engine_advance_group(AgxEngine *e, int group, int n_groups, void *stream
 	{
 		KernelTimer t(e, s, 3);
 		const int trees = d.shared_tree ? 1 : count; // tournament search: one tree (game 0), the other records are its search threads
+		if (d.shared_tree)
+		{ // (whichever buffer this group is: the tree, its arenas and the restart are record 0's; grp_first / grp_count keep the buffer)
+			d.g0 = 0;
+			count = d.n_games;
+		}
 		hipLaunchKernelGGL(k_advance, dim3(trees), dim3(ADV_THREADS), 0, s, d);
 		hipLaunchKernelGGL(k_arena_service, dim3(1), dim3(1024), 0, s, d, trees);
 		hipLaunchKernelGGL(k_arena_copy, dim3(trees * CLEAR_PARTS), dim3(256), 0, s, d, CLEAR_PARTS);

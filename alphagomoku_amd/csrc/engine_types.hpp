@@ -115,6 +115,7 @@ namespace agx
 			                       // reserved, copy pending; 2 grown: the batch waits for expand (select / solve sit this step out); 4 the heap
 			                       // had no bundle left: expand proceeds in the old arenas
 			int32_t node_cap, edge_cap, ht_cap, grow_count;
+			int32_t grow_owner, pad_owner; // double-buffered search: first record of the buffer whose expansion asked for the larger arenas (it goes first afterwards)
 			uint64_t node_off[2], edge_off[2], ht_off;          // element offsets into EngineDev::nodes / edges / ht
 			uint64_t new_node_off[2], new_edge_off[2], new_ht_off; // the bundle reserved by k_arena_service (grow_pending == 3)
 			uint64_t root_hash;
@@ -255,6 +256,10 @@ namespace agx
 			int prune_root;  // the root is pruned like any node (UnifiedGenerator without forceExpandRoot: evaluation players)
 			int match_mode;  // evaluation matches: tree g (first player) and tree g + n_games / 2 (second player) share one game
 			int shared_tree; // tournament search: the n_games records are the search threads of ONE tree (game 0): own task buffer and solver each
+			int search_buffers; // 2: double-buffered tournament search (Search::useBuffer / switchBuffer, Search.cpp:243-252): record b * threads + t is
+			                    // buffer b of search thread t; a group (= one launch) is one buffer of every thread
+			int tt_mod;      // solver table of record g = table g % tt_mod (n_games, or the thread count when a thread has two buffers)
+			int grp_first, grp_count; // the records of this launch's group (kept when g0 is redirected to the tree's record)
 			// speculative solver
 			int spec_group;        // index of this launch's group (its queue segment and counters)
 			int *spec_watchdog;            // [16] what a wave that gave up waiting for a queue slot saw

@@ -201,6 +201,16 @@ typedef struct AgxEngineConfig
 	int force_expand_root;            /* UnifiedGenerator's forceExpandRoot (EdgeGenerator.cpp:283-285): 1 (default, self-play: GameGenerator.cpp:183-184)
 	                                     never prunes the root's edges; 0 prunes the root like any node (evaluation Player, Player.cpp:109; match_mode
 	                                     engines always do) */
+	int search_buffers;               /* 2: the double-buffered tournament search of SearchThread::asynchronous_run (player/SearchThread.cpp:148-180,
+	                                     Search::useBuffer / switchBuffer, Search.cpp:243-252): every search thread has TWO task buffers, one solver
+	                                     and table; n_games must equal 2 x max(search_threads, 1) and record b * threads + t is buffer b of thread t.
+	                                     The pool is stepped buffer by buffer as group b of 2 (agx_engine_expand_backup_group, then
+	                                     agx_engine_select_solve_group, then the network on that group): the leaves of buffer b stay in the network
+	                                     — virtual losses applied — while buffer 1 - b is expanded, backed up, selected and solved, which is the
+	                                     overlap of tower and tree work inside ONE game that the reference gets from asyncEvaluateGraphLaunch / Join.
+	                                     When the move rule fires after a buffer's backup, the other buffer's leaves are dropped and their virtual
+	                                     losses taken back (Search::cleanup).  Also valid with search_threads 0 / 1 (one thread, two buffers — the
+	                                     reference's "1 thread per GPU" setting).  0 / 1 (default): one buffer. */
 } AgxEngineConfig;
 
 typedef struct AgxEngine AgxEngine; /* opaque */

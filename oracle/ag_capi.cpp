@@ -513,6 +513,20 @@ int ago_game_step_select(void *h, uint32_t *features_out, int capacity)
 	std::memcpy(features_out, g->features.data(), g->features.size() * sizeof(uint32_t));
 	return n;
 }
+/* double-buffered tournament search (SearchThread::asynchronous_run): one loop iteration, then the network's answer for its batch */
+int ago_game_async_step(void *h, uint32_t *features_out, int capacity)
+{
+	GameHandle *g = static_cast<GameHandle*>(h);
+	const int n = g->game.async_step(g->features);
+	if (n > capacity)
+		return -1;
+	std::memcpy(features_out, g->features.data(), g->features.size() * sizeof(uint32_t));
+	return n;
+}
+void ago_game_async_provide(void *h, const float *policy, const float *value)
+{
+	static_cast<GameHandle*>(h)->game.async_provide(policy, value);
+}
 int ago_game_step_expand(void *h, const float *policy, const float *value)
 {
 	return static_cast<GameHandle*>(h)->game.step_expand(policy, value);

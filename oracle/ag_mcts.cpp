@@ -604,10 +604,21 @@ namespace ago
 		stored = 0;
 	}
 	void Search::cleanup(Tree &tree)
-	{
-		for (int i = 0; i < stored; i++)
-			tree.cancel_virtual_loss(tasks[i]);
-		stored = 0;
+	{ // Search.cpp:233-242: both buffers
+		for (int b = 0; b < 2; b++)
+		{
+			for (int i = 0; i < stored; i++)
+				tree.cancel_virtual_loss(tasks[i]);
+			stored = 0;
+			switch_buffer();
+		}
+	}
+	void Search::switch_buffer()
+	{ // Search.cpp:248-251 (the buffers are swapped instead of indexed)
+		if (other_tasks.size() != tasks.size())
+			other_tasks.resize(tasks.size());
+		std::swap(tasks, other_tasks);
+		std::swap(stored, other_stored);
 	}
 
 	/* ------------------------------------------------ Game ------------------------------------------------ */
@@ -627,6 +638,7 @@ namespace ago
 		{
 			lane(l).solver.clear();
 			lane(l).stored = 0;
+			lane(l).other_stored = 0;
 		}
 		for (const Move &m : opening)
 		{
@@ -701,8 +713,31 @@ namespace ago
 		return n;
 	}
 	int Game::step_expand(const float *policy, const float *value, const float *action_values)
+	{
+		unpack_network(policy, value, action_values);
+		return expand_and_move();
+	}
+	int Game::async_step(std::vector<uint32_t> &features_out)
+	{ // SearchThread.cpp:152-170: generateEdges / expand / backup (current buffer), stop condition, select, solve, scheduleToNN
+		expand_and_move();
+		if (outcome != O_UNKNOWN)
+		{
+			features_out.clear();
+			scheduled.clear();
+			scheduled_lane.clear();
+			return 0;
+		}
+		return step_select(features_out);
+	}
+	void Game::async_provide(const float *policy, const float *value)
+	{ // SearchThread.cpp:171-174: the batch goes to the network (its answer is read by the expand of this buffer's next turn), switchBuffer
+		unpack_network(policy, value, nullptr);
+		for (int l = 0; l < lanes(); l++)
+			lane(l).switch_buffer();
+	}
+	void Game::unpack_network(const float *policy, const float *value, const float *action_values)
 	{ // NNEvaluator::unpack_from_network (NNEvaluator.cpp:263-286) with symmetry 0 and a 'pv' network (no 'q'/'m' heads:
-	  // those output tensors stay zero, NetworkDataPack.cpp:122-126,214-235), then GameGenerator.cpp:88-118
+	  // those output tensors stay zero, NetworkDataPack.cpp:122-126,214-235)
 		const int hw = cfg.rows * cfg.cols;
 		for (size_t i = 0; i < scheduled.size(); i++)
 		{
@@ -721,6 +756,9 @@ namespace ago
 				t.moves_left = 0.0f;
 			t.by_network = true;
 		}
+	}
+	int Game::expand_and_move()
+	{ // GameGenerator.cpp:88-118
 		for (int l = 0; l < lanes(); l++)
 		{ // each thread in turn, under the tree lock: expand its batch, back it up (SearchThread.cpp:135-141)
 			lane(l).generate_edges(tree);
@@ -728,6 +766,8 @@ namespace ago
 			lane(l).backup(tree);
 		}
 
+		if (tree.root < 0)
+			return 0; // (the first iterations of the double-buffered loop: nothing expanded yet)
 		const float draw_rate = tree.nodes[tree.root].value.draw;
 		// get_simulations_for_move (utils/misc.cpp:171-179)
 		const float reduction = std::max(0.0f, std::min(1.0f, (draw_rate - 0.75f) / (1.0f - 0.75f)));

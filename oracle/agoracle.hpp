@@ -515,8 +515,11 @@ namespace ago
 			GameConfig cfg;
 			SearchConfig scfg;
 			Solver solver;
-			std::vector<Task> tasks;
+			std::vector<Task> tasks;                      // the CURRENT task buffer (get_buffer(), Search.hpp) ...
 			int stored = 0;
+			std::vector<Task> other_tasks;                // ... and the other one of the two (Search::useBuffer / switchBuffer, :243-252)
+			int other_stored = 0;
+			void switch_buffer();                         // :248-251
 			void select(Tree &tree, int max_simulations); // :117-158
 			void solve();                                 // :159-183
 			int schedule(std::vector<int> &out) const;    // :184-199 — indices of the tasks that need the network
@@ -558,6 +561,14 @@ namespace ago
 			void external_move(Move m);                         // the opponent's Game::makeMove, seen by this player's copy of the game
 			/* phase 1: select + solve; returns the number of tasks that need evaluation and their features */
 			int step_select(std::vector<uint32_t> &features_out);
+			/* SearchThread::asynchronous_run (player/SearchThread.cpp:148-180) of every thread, one loop iteration per call: expand + backup
+			 * of the current buffer (evaluated by the network while the OTHER buffer was being worked on), the stop / move rule, select +
+			 * solve + scheduleToNN of the current buffer; async_provide hands over the network's answer for it (asyncEvaluateGraphLaunch,
+			 * joined one iteration later) and switches the buffers.  The threads take the tree in thread order inside an iteration. */
+			int async_step(std::vector<uint32_t> &features_out);
+			void async_provide(const float *policy, const float *value);
+			void unpack_network(const float *policy, const float *value, const float *action_values);
+			int expand_and_move();
 			/* phase 2: policy [n][HW], value (win, draw) [n][2] for the scheduled tasks, in schedule order; returns 1 if a move was made */
 			/* action_values: null for a 'pv' network, else (win, draw) [n][HW][2] of a 'pvq' network */
 			int step_expand(const float *policy, const float *value, const float *action_values = nullptr);

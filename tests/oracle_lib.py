@@ -64,6 +64,9 @@ def load():
         lib.ago_game_sign_to_move.argtypes = [ctypes.c_void_p]
         lib.ago_game_step_select.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
         lib.ago_game_step_expand.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        lib.ago_game_async_step.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        lib.ago_game_async_provide.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        lib.ago_game_async_provide.restype = None
         lib.ago_game_step_expand_q.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         lib.ago_game_outcome.argtypes = [ctypes.c_void_p]
         lib.ago_game_num_records.argtypes = [ctypes.c_void_p]

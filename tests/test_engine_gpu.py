@@ -571,6 +571,91 @@ def test_tournament_search_on_one_tree(agx_lib, olib, rules, threads, batch):
     olib.ago_game_destroy(h)
 
 
+@pytest.mark.parametrize("rules,threads,batch,node_capacity,seed", [(0, 1, 8, 4096, 177), (1, 4, 4, 4096, 181), (2, 3, 8, 4096, 182), (0, 2, 8, 256, 181)])
+def test_double_buffered_tournament_search(agx_lib, olib, rules, threads, batch, node_capacity, seed):
+    """SURVEY row f4, the double buffering (player/SearchThread.cpp:148-180 asynchronous_run, Search.cpp:243-252 useBuffer / switchBuffer):
+    every search thread has two task buffers; while buffer b's leaves are with the network — virtual losses applied — buffer 1 - b is
+    expanded, backed up, selected and solved.  The device steps the pool buffer by buffer (group b of 2: expand_backup, select_solve,
+    network), the oracle runs asynchronous_run's loop body per thread with the same fixed thread order: the same leaves and features in
+    every iteration, the same root after it, the same moves, for whole games.  When the move rule fires, the other buffer's leaves are
+    dropped and their virtual losses taken back (Search::cleanup).  The last case starts with small arenas: a buffer whose expansion
+    waits for larger ones must still go before the other buffer."""
+    from alphagomoku_amd import selfplay
+    sims = 300
+    cfg = selfplay.default_config(rules=rules, n_games=2 * threads, search_threads=threads, search_buffers=2, max_batch_size=batch, max_simulations=sims,
+                                  tss_table_entries=1 << 16, node_capacity=node_capacity, edge_capacity=65536 if node_capacity >= 4096 else 8192,
+                                  arena_reserve=1.0 if node_capacity >= 4096 else 8.0)
+    pool = selfplay.GeneratorPool(cfg)
+    ocfg = ol.default_search_config(max_batch_size=batch, max_simulations=sims, table_entries=1 << 16)
+    op = np.zeros(64, np.uint16)
+    k = olib.ago_prepare_opening(rules, N, N, seed, ol.ptr(op))   # (openings whose games last 120-670 iterations)
+    h = olib.ago_game_create_ex(rules, N, N, 0, ctypes.byref(ocfg))
+    olib.ago_game_set_search_threads(h, threads)
+    olib.ago_game_set_serial(h, 0)
+    olib.ago_game_begin(h, ol.ptr(op), k)
+    pool.begin(selfplay.pack_openings([[int(x) for x in op[:k]]]))
+    with pytest.raises(RuntimeError, match="buffer by buffer"):
+        pool.select_solve()                                   # a double-buffered pool is stepped as two groups
+    ev = _stand_in_evaluator(olib)
+    compared, dropped, widest, sat_out = 0, 0, 0, 0
+    for step in range(6000):
+        b = step % 2
+        before = pool.game_info(0, with_edges=False)["n_moves"]
+        pool.expand_backup_group(b, 2)
+        if pool.game_info(0, with_edges=False)["n_moves"] != before and pool.game_info(threads * (1 - b), with_edges=False)["outcome"] == 0:
+            dropped += 1                                      # a move was made with the other buffer in flight
+        growing = pool.game_info(0, with_edges=False)["grow_pending"] != 0
+        pool.select_solve_group(b, 2)
+        slots, feats = pool.scheduled_group(b, 2)
+        if growing:
+            # a buffer's expansion waits for larger arenas: the tree sits out this iteration AND the other buffer's next one (the waiting
+            # buffer must be expanded first, as in the oracle's order), nothing is selected or scheduled meanwhile
+            assert len(slots) == 0, step
+            sat_out += 1
+            continue
+        order = np.argsort(slots)                             # thread-major, task order inside a thread: the oracle's queue order
+        slots, feats = slots[order], feats[order]
+        assert all(b * threads * batch <= int(s) < (b + 1) * threads * batch for s in slots), step
+        pol, val = ev(feats) if len(slots) else (np.zeros((0, HW), np.float32), np.zeros((0, 2), np.float32))
+        pool.provide(slots, pol, np.concatenate([val, 1 - val.sum(1, keepdims=True)], 1).astype(np.float32))
+        f = np.zeros((threads * batch, HW), np.uint32)
+        c = olib.ago_game_async_step(h, ol.ptr(f), threads * batch)
+        assert c == len(slots), step
+        assert np.array_equal(feats, f[:c]), step
+        olib.ago_game_async_provide(h, ol.ptr(np.ascontiguousarray(pol)), ol.ptr(np.ascontiguousarray(val)))
+        widest = max(widest, len({int(s) // batch for s in slots}))
+        info = pool.game_info(0)
+        assert info["error"] == 0, step
+        if olib.ago_game_outcome(h) != 0:
+            break
+        if info["root_edges"] == 0:
+            continue                                          # nothing expanded yet (the first iterations of a search)
+        r = _oracle_root(olib, h)
+        e = info["edges"]
+        assert info["n_moves"] == k + olib.ago_game_num_records(h), step
+        assert r["n"] == info["root_edges"] and r["visits"] == info["root_visits"], step
+        assert np.array_equal(np.array([x["move"] for x in e], np.uint16), r["moves"]), step
+        assert np.array_equal(np.array([x["visits"] for x in e], np.int32), r["ev"]), step
+        assert np.array_equal(np.array([x["score"] for x in e], np.uint16), r["es"]), step
+        assert np.array_equal(np.array([[x["win"], x["draw"]] for x in e], np.float32).reshape(-1), r["val"]), step
+        compared += 1
+    assert olib.ago_game_outcome(h) != 0 and pool.game_info(0, with_edges=False)["outcome"] == olib.ago_game_outcome(h)
+    recs, _ = pool.records()
+    assert len(recs) == olib.ago_game_num_records(h)
+    for i, r in enumerate(sorted(recs, key=lambda x: x.move_number)):
+        mv, rv, rs = ctypes.c_uint16(), ctypes.c_int(), ctypes.c_uint16()
+        rval = (ctypes.c_float * 2)()
+        em, evv, ep, evl, es = np.zeros(512, np.uint16), np.zeros(512, np.int32), np.zeros(512, np.float32), np.zeros(1024, np.float32), np.zeros(512, np.uint16)
+        olib.ago_game_record(h, i, ctypes.byref(mv), ctypes.byref(rv), rval, ctypes.byref(rs), ol.ptr(em), ol.ptr(evv), ol.ptr(ep), ol.ptr(evl), ol.ptr(es), 512)
+        assert r.move == mv.value and r.root_visits == rv.value
+    st = pool.stats()
+    assert compared > 100 and widest == threads and dropped > 0
+    if node_capacity < 4096:
+        assert st["arena_grows"] > 0 and st["arena_failures"] == 0 and sat_out == 2 * st["arena_grows"]
+    pool.close()
+    olib.ago_game_destroy(h)
+
+
 @pytest.mark.parametrize("fraction,speculative,table_bits", [(0.5, 0, 16), (0.5, 1, 16), (0.25, 1, 10), (0.9, 1, 22)])
 def test_yielding_pool_gives_the_same_games(agx_lib, olib, fraction, speculative, table_bits):
     """solver_yield_fraction only changes the pacing (stragglers sit out a step): every game must still produce exactly the
