@@ -184,6 +184,8 @@ def _declare(c):  # noqa: F811
     c.agx_engine_set_board.argtypes = [vp, ci, vp, ci, vp]
     c.agx_engine_set_max_simulations.argtypes = [vp, ci]
     c.agx_engine_set_force_expand_root.argtypes = [vp, ci]
+    c.agx_engine_cancel_pending.argtypes = [vp, vp]
+    c.agx_engine_root_summary.argtypes = [vp, ci, vp, ctypes.POINTER(ctypes.c_int)]
     c.agx_engine_buffers.argtypes = [vp, ctypes.POINTER(AgxEngineBuffers)]
     c.agx_engine_stats.argtypes = [vp, ctypes.POINTER(AgxEngineStats)]
     c.agx_engine_kernel_timing.argtypes = [vp, ci, vp, vp]

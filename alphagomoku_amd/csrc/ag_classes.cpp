@@ -451,6 +451,41 @@ namespace ag
 		s.ready_flag = ready;
 		waiting_slices.push_back(s);
 	}
+	void NNEvaluator::addToQueueOverlapped(AgxEngine *engine, int buffer, int max_positions, void *stream, bool *ready)
+	{
+		if (own_stream == nullptr)
+		{
+			check(agx_stream_create(&own_stream));
+			for (int i = 0; i < 2; i++)
+			{
+				check(agx_event_create(&scheduled_event[i]));
+				check(agx_event_create(&done_event[i]));
+			}
+		}
+		SliceData s;
+		s.engine = engine;
+		s.group = buffer;
+		s.n_groups = 2;
+		s.positions = max_positions;
+		s.stream = stream;
+		s.ready_flag = ready;
+		s.overlap = true;
+		s.event = buffer;
+		waiting_slices.push_back(s);
+	}
+	NNEvaluator::~NNEvaluator()
+	{
+		if (own_stream != nullptr)
+		{
+			agx_stream_synchronize(own_stream);
+			for (int i = 0; i < 2; i++)
+			{
+				agx_event_destroy(scheduled_event[i]);
+				agx_event_destroy(done_event[i]);
+			}
+			agx_stream_destroy(own_stream);
+		}
+	}
 	double NNEvaluator::evaluateGraph()
 	{ // NNEvaluator.cpp:147-181
 		if (!get_network().isLoaded())
@@ -475,7 +510,15 @@ namespace ag
 		// pool slices: the batch is the slice's device-side queue, the launch goes onto the slice's stream behind its solver kernel
 		in_progress_slices.swap(waiting_slices);
 		for (const SliceData &s : in_progress_slices)
-			check(agx_engine_evaluate_group(s.engine, get_network().handle(), s.group, s.n_groups, s.stream));
+			if (s.overlap)
+			{ // behind everything the search stream holds so far (select + solve of this buffer), beside whatever it is given next
+				check(agx_event_record(scheduled_event[s.event], s.stream));
+				check(agx_stream_wait_event(own_stream, scheduled_event[s.event]));
+				check(agx_engine_evaluate_group(s.engine, get_network().handle(), s.group, s.n_groups, own_stream));
+				check(agx_event_record(done_event[s.event], own_stream));
+			}
+			else
+				check(agx_engine_evaluate_group(s.engine, get_network().handle(), s.group, s.n_groups, s.stream));
 		// host-side tasks
 		const int batch = std::min(static_cast<int>(waiting_queue.size()), get_network().getBatchSize());
 		if (batch > 0)
@@ -502,10 +545,15 @@ namespace ag
 			unpack_from_network();
 			in_progress_queue.clear();
 		}
-		// a slice's expand kernel is enqueued on the same stream as its network launch, so "joined" needs no host wait
+		// a slice's expand kernel is enqueued on the same stream as its network launch, so "joined" needs no host wait; an overlapped
+		// launch is joined on the device: the search stream waits for the network's event before what the caller enqueues next
 		for (const SliceData &s : in_progress_slices)
+		{
+			if (s.overlap)
+				check(agx_stream_wait_event(s.stream, done_event[s.event]));
 			if (s.ready_flag != nullptr)
 				*s.ready_flag = true;
+		}
 		stats.compute.stopTimer(static_cast<int>(in_progress_slices.size()) + (batch > 0 ? 1 : 0));
 		in_progress_slices.clear();
 	}
@@ -638,9 +686,11 @@ namespace ag
 	}
 
 	GamePool::GamePool(const GameConfig &gameOptions, const SearchConfig &searchOptions, const EdgeSelectorConfig &finalSelector, int games, int maxSimulations,
-			bool useSymmetries, const std::string &networkOutputs, bool forceExpandRoot) :
+			bool useSymmetries, const std::string &networkOutputs, bool forceExpandRoot, int searchBuffers) :
 			game_config(gameOptions), search_config(searchOptions), games(games), batch(searchOptions.max_batch_size)
 	{
+		if (searchBuffers == 2 && games != 1)
+			throw std::logic_error("GamePool : two task buffers are for a pool of ONE tree");
 		if (gameOptions.rows != gameOptions.cols)
 			throw std::logic_error("GamePool : only square boards are supported");
 		AgxEngineConfig c;
@@ -676,6 +726,12 @@ namespace ag
 		// launch put off to the next one
 		c.speculative_solver = 1;
 		c.solver_yield_fraction = (games >= 64) ? 0.85f : 0.0f;
+		if (searchBuffers == 2)
+		{ // records 0 and 1 are the two task buffers of the one tree (stepped as group 0 / 1 of 2)
+			c.n_games = 2;
+			c.search_buffers = 2;
+			this->games = 2;
+		}
 		check(agx_engine_create(&c, &engine));
 	}
 	GamePool::~GamePool()
@@ -736,6 +792,7 @@ namespace ag
 		for (int i = 0; i < newBoard.size(); i++)
 			cells[i] = static_cast<uint8_t>(newBoard[i]);
 		check(agx_engine_set_board(p.handle(), 0, cells.data(), static_cast<int>(signToMove), stream));
+		summary_valid = false;
 		edge_selector.reset();  // a fresh selector / generator per position, as Player::setBoard installs them
 		edge_generator.reset();
 	}
@@ -782,16 +839,34 @@ namespace ag
 			return info;
 		}
 	}
+	namespace
+	{
+	}
+	const int* Tree::root_summary() const
+	{ // one read serves the getters of a stop condition; any stage that changes the tree (Search::expand, cleanup, Tree::setBoard) drops it
+		if (!summary_valid)
+		{
+			check(agx_engine_root_summary(bound().handle(), 0, stream, summary));
+			summary_valid = true;
+		}
+		return summary;
+	}
 	int Tree::getSimulationCount(int game) const
 	{
+		if (standalone)
+			return root_summary()[0];
 		return game_info(bound(), first_game + game).root_visits;
 	}
 	bool Tree::isRootProven(int game) const
 	{
+		if (standalone)
+			return root_summary()[1] != 0;
 		return Score::from_short(static_cast<uint16_t>(game_info(bound(), first_game + game).root_score)).isProven();
 	}
 	int Tree::getNodeCount(int game) const
 	{
+		if (standalone)
+			return root_summary()[2];
 		return game_info(bound(), first_game + game).n_nodes;
 	}
 	int Tree::getMoveNumber(int game) const
@@ -870,12 +945,23 @@ namespace ag
 		}
 	}
 	Search::Search(const GameConfig &gameOptions, const SearchConfig &searchOptions) :
-			own_pool(std::make_unique<GamePool>(gameOptions, searchOptions, unused_final_selector(), 1, maximum_number_of_simulations, false, "pv", false)),
-			pool(*own_pool), group(0), n_groups(1), stream(nullptr), batch_size(searchOptions.max_batch_size)
-	{ // the reference's constructor: a one-game engine (solver table, task buffers, the arenas of the Tree it will be used with), begun on the
-	  // empty board; Tree::setBoard gives it its positions
+			own_pool(std::make_unique<GamePool>(gameOptions, searchOptions, unused_final_selector(), 1, maximum_number_of_simulations, false, "pv", false, 2)),
+			pool(*own_pool), group(0), n_groups(2), stream(nullptr), batch_size(searchOptions.max_batch_size)
+	{ // the reference's constructor: a one-tree engine (solver table, the TWO task buffers, the arenas of the Tree it will be used with), begun
+	  // on the empty board; Tree::setBoard gives it its positions.  Its launches go onto a stream of its own, so that the evaluator's
+	  // stream can run the network of one buffer beside the tree work of the other.
+		check(agx_stream_create(&own_stream));
+		stream = own_stream;
 		std::vector<uint16_t> empty_opening(AGX_OPENING_CAP, 0);
 		own_pool->begin(empty_opening);
+	}
+	Search::~Search()
+	{
+		if (own_stream != nullptr)
+		{
+			agx_stream_synchronize(own_stream);
+			agx_stream_destroy(own_stream);
+		}
 	}
 	Search::Search(GamePool &pool, int group, int n_groups, void *stream) :
 			pool(pool), group(group), n_groups(n_groups), stream(stream), batch_size(pool.getBatchSize())
@@ -893,7 +979,7 @@ namespace ag
 			tree.pool = &pool;
 			tree.stream = stream;
 		}
-		if (tree.pool != &pool || tree.group != group)
+		if (tree.pool != &pool || (own_pool == nullptr && tree.group != group))
 			throw std::logic_error("Search : the tree belongs to another search / slice");
 	}
 	int64_t Search::getMemory() const noexcept
@@ -915,11 +1001,19 @@ namespace ag
 	{
 		if (index != 0 && index != 1)
 			throw std::logic_error("Search::useBuffer() : index must be 0 or 1");
+		flush_select();
 		current_task_buffer = index;
+		if (own_pool != nullptr)
+			group = index;
 	}
 	void Search::switchBuffer() noexcept
 	{
-		current_task_buffer = 1 - current_task_buffer;
+		try
+		{
+			useBuffer(1 - current_task_buffer);
+		} catch (std::exception&)
+		{
+		}
 	}
 	void Search::clearStats() noexcept
 	{
@@ -982,34 +1076,46 @@ namespace ag
 		flush_select();
 		stats.schedule.startTimer();
 		const int per = (pool.numberOfGames() + n_groups - 1) / n_groups;
+		bool &tasks_ready = ready_flags[current_task_buffer];
 		tasks_ready = false;
-		evaluator.addToQueue(pool.handle(), group, n_groups, per * batch_size, stream, &tasks_ready);
+		if (own_pool != nullptr)
+			evaluator.addToQueueOverlapped(pool.handle(), current_task_buffer, per * batch_size, stream, &tasks_ready);
+		else
+			evaluator.addToQueue(pool.handle(), group, n_groups, per * batch_size, stream, &tasks_ready);
 		scheduled = true;
 		stats.schedule.stopTimer();
 	}
 	bool Search::areTasksReady() const noexcept
 	{
-		return tasks_ready;
+		return ready_flags[current_task_buffer];
 	}
 	void Search::generateEdges(const Tree&)
 	{ // first pass of the expand kernel (UnifiedGenerator::generate per leaf); nothing to enqueue separately
-		if (!tasks_ready)
+		if (!ready_flags[current_task_buffer])
 			throw std::logic_error("Search::generateEdges() : the tasks have not been evaluated yet");
 	}
-	void Search::expand(Tree&)
+	void Search::expand(Tree &tree)
 	{ // one launch: generateEdges for all leaves, then Tree::expand for all, then Tree::backup for all (the order of Search.cpp:206-232)
-		if (!tasks_ready)
+		if (!ready_flags[current_task_buffer])
 			throw std::logic_error("Search::expand() : the tasks have not been evaluated yet");
 		stats.expand.startTimer();
 		check(agx_engine_expand_group(pool.handle(), group, n_groups, stream));
+		tree.summary_valid = false;
 		stats.expand.stopTimer();
 	}
 	void Search::backup(Tree&)
 	{ // second half of the launch enqueued by expand()
 	}
 	void Search::cleanup(Tree &tree)
-	{ // cancelVirtualLoss of abandoned tasks: every device step completes its batch, nothing is left to cancel
+	{ // Search.cpp:233-242: cancelVirtualLoss of the abandoned tasks of both buffers (a pool slice completes its batch in every step: nothing to cancel)
 		bind(tree);
+		flush_select();
+		tree.summary_valid = false;
+		if (own_pool != nullptr)
+		{
+			check(agx_engine_cancel_pending(pool.handle(), stream));
+			ready_flags[0] = ready_flags[1] = true;
+		}
 		if (ab_search.clear_requested && own_pool != nullptr)
 		{ // getSolver().clear() at the start of a game (EvaluationGame.cpp:81-82): an empty table — and an empty tree, which is what the cache
 		  // cleanup of the new game's first setBoard would leave of the old game's states anyway

@@ -774,18 +774,20 @@ namespace
 				break;
 			const int g = E.g0 + s;
 			GameState &gs = E.games[g];
-			const bool idle = (!gs.active || gs.error != 0 || gs.outcome != 0 || gs.grow_pending != 0);
+			// (tournament search: record g is a task buffer of tree 0, already filled by k_select — the threads take the tree in turn there; here
+			//  its leaves are solved in parallel like any game's)
+			const bool idle = (!gs.active || gs.error != 0 || gs.outcome != 0 || E.games[E.shared_tree ? 0 : g].grow_pending != 0);
 			if (!idle)
 			{
-				if (!keys_loaded)
+				if (!keys_loaded && !E.shared_tree)
 				{
 					for (int i = lane; i < 3 * (1 + E.hw); i += 64)
 						sel_keys[i] = E.nc_keys[i];
 					keys_loaded = true;
 				}
-				use_game_arenas(E, g);
+				use_game_arenas(E, E.shared_tree ? 0 : g);
 				const int first = gs.solve_pending ? gs.solve_pos : 0; // a deferred game: no new descents, its batch goes on behind the committed leaves
-				if (!gs.solve_pending)
+				if (!gs.solve_pending && !E.shared_tree)
 					select_batch(E, g, g, lane, &sh.board[0], &sh.lines[0], sel_keys);
 				__threadfence(); // the tasks are read by other waves
 				__syncthreads();
@@ -2421,6 +2423,34 @@ namespace
 	 * the position becomes the tree's base board, every cached state that can still be reached from it is kept (NodeCache::cleanup:
 	 * compaction into the other arena, table rebuilt), the root is whatever the cache holds for it, abandoned tasks are dropped and the
 	 * solver table ages by one generation (Tree.cpp:128-151, Search.cpp:112-115,233-242). */
+	/* Search::cleanup (Search.cpp:233-242) from outside: the leaves selected but not expanded — of every task buffer that works on the tree —
+	 * are dropped and their virtual losses taken back (Tree::cancelVirtualLoss, Tree.cpp:377-384).  One wave per tree. */
+	__global__ __launch_bounds__(64) void k_cancel_pending(EngineDev E)
+	{
+		const int tg = E.shared_tree ? 0 : E.g0 + blockIdx.x, lane = threadIdx.x;
+		GameState &gs = E.games[tg];
+		use_game_arenas(E, tg);
+		DNode *nodes = nodes_of(E, tg, gs.arena);
+		DEdge *edges = edges_of(E, tg, gs.arena);
+		const int first = E.shared_tree ? 0 : tg, last = E.shared_tree ? E.n_games - 1 : tg;
+		for (int r = first; r <= last; r++)
+		{
+			GameState &os = E.games[r];
+			const int pending = os.n_tasks;
+			for (int k = 0; k < pending; k++)
+			{
+				const DTask &t = E.tasks[static_cast<size_t>(r) * E.batch + k];
+				cancel_virtual_loss(nodes, edges, t, t.path_len, lane);
+				wave_sync();
+			}
+			if (lane == 0)
+			{
+				os.n_tasks = 0;
+				os.solve_pos = 0;
+				os.solve_pending = 0;
+			}
+		}
+	}
 	__global__ __launch_bounds__(256) void k_set_board(EngineDev E, int g, const uint8_t *board, int sign_to_move)
 	{
 		__shared__ u64 scratch[4];
@@ -2455,8 +2485,38 @@ namespace
 		}
 		__syncthreads();
 		rebase_tree<256>(E, g, tid, scratch, scan_nodes, scan_edges);
+		if (E.shared_tree)
+		{ // every task buffer of the tree follows (its solver table ages with the tree's, Search::setBoard -> increaseGeneration)
+			__syncthreads();
+			for (int t = 1 + tid; t < E.n_games; t += 256)
+			{
+				GameState &ls = E.games[t];
+				ls.generation = (ls.generation + 1) % 64;
+				ls.outcome = 0;
+				ls.n_moves = gs.n_moves;
+				ls.n_tasks = 0;
+				ls.active = 1;
+			}
+		}
 	}
 
+	/* what a search loop asks the tree between two steps (Tree::getSimulationCount / isRootProven / getNodeCount under the tree lock,
+	 * SearchThread.cpp:181-199) */
+	__global__ void k_root_summary(EngineDev E, int g, int *out)
+	{
+		const GameState &gs = E.games[g];
+		int visits = 0, proven = 0;
+		if (gs.root >= 0)
+		{
+			const DNode &r = nodes_of(E, g, gs.arena)[gs.root];
+			visits = r.visits;
+			proven = s_proven(r.score) ? 1 : 0;
+		}
+		out[0] = visits;
+		out[1] = proven;
+		out[2] = gs.n_nodes;
+		out[3] = gs.error;
+	}
 	__global__ void k_reset_counter(int *counter, int *second)
 	{
 		*counter = 0;
@@ -2582,6 +2642,7 @@ struct AgxEngine
 		bool fuse_select = true;
 		// AgxEngineConfig.speculative_solver: select + solver as one persistent launch with the leaves of a batch solved in parallel (k_search_spec)
 		uint8_t *board_staging = nullptr; // agx_engine_set_board: the caller's board on its way to the device
+		int *summary_dev = nullptr, *summary_host = nullptr; // agx_engine_root_summary: four words on their way back (device, pinned host)
 		bool speculative = false;
 		int spec_waves = 0; // waves of that launch over the whole pool
 		// optional per-kernel timing (agx_engine_kernel_timing): HIP events on the launch stream around every kernel of a step
@@ -2814,13 +2875,14 @@ int agx_engine_create(const AgxEngineConfig *cfg, AgxEngine **out)
 	AGX_TRY(dev_alloc(e, &d.free_bundles, static_cast<size_t>(ARENA_CLASSES) * G));
 	AGX_TRY(dev_alloc(e, &d.tasks, G * d.batch));
 	// speculative solver: its waves solve several leaves of one game at once, so each wave brings its own spill areas (behind the games')
-	e->speculative = cfg->speculative_solver != 0 && cfg->search_threads <= 1 && cfg->search_buffers != 2 && cfg->tss_max_positions <= 250 && cfg->max_batch_size <= 16;
+	e->speculative = cfg->speculative_solver != 0 && cfg->tss_max_positions <= 250 && cfg->max_batch_size <= 16;
 	if (e->speculative)
 	{
 		int cus = 0, device_of_engine = 0;
 		(void) hipGetDevice(&device_of_engine);
 		(void) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_of_engine);
-		e->spec_waves = (cfg->speculative_waves > 0) ? cfg->speculative_waves : 12 * std::max(1, cus);
+		// default: 12 waves per compute unit, but no more than one per leaf of a full batch (a one-tree engine has a few dozen leaves per launch)
+		e->spec_waves = (cfg->speculative_waves > 0) ? cfg->speculative_waves : std::min<long long>(12 * std::max(1, cus), std::max<long long>(64, static_cast<long long>(G) * cfg->max_batch_size));
 		e->spec_waves = std::min(e->spec_waves, SPEC_QUEUE_SLACK);
 	}
 	const size_t areas = G + static_cast<size_t>(e->spec_waves);
@@ -2939,6 +3001,8 @@ int agx_engine_destroy(AgxEngine *e)
 		(void) hipEventDestroy(ev);
 	for (hipEvent_t ev : e->free_events)
 		(void) hipEventDestroy(ev);
+	if (e->summary_host != nullptr)
+		(void) hipHostFree(e->summary_host);
 	delete e;
 	return AGX_OK;
 }
@@ -3126,6 +3190,11 @@ int agx_engine_select_solve_group(AgxEngine *e, int group, int n_groups, void *s
 		hipStream_t s = static_cast<hipStream_t>(stream);
 		hipLaunchKernelGGL(k_reset_spec, dim3(1), dim3(1), 0, s, d.counters + d.nn_counter, static_cast<int*>(nullptr), d.counters + SPEC_COUNTER0 + 4 * group,
 				d.counters + d.yield_counter);
+		if (d.shared_tree)
+		{ // tournament search: the threads descend the one tree in turn (one wave), then their leaves are solved in parallel
+			KernelTimer t(e, s, 0);
+			hipLaunchKernelGGL(k_select, dim3(1), dim3(64), 0, s, d);
+		}
 		{
 			KernelTimer t(e, s, 1);
 			launch_search_spec(d, count, group, std::max(1, e->spec_waves / n_groups), s);
@@ -3265,7 +3334,7 @@ int agx_engine_evaluate_group(AgxEngine *e, AgxNet *net, int group, int n_groups
 }
 
 /* Search::generateEdges + expand + backup for every game of the group (Search.cpp:206-232), incl. the move rule's decision */
-int agx_engine_expand_group(AgxEngine *e, int group, int n_groups, void *stream)
+static int expand_stage(AgxEngine *e, int group, int n_groups, void *stream, bool service_arenas)
 {
 	AGX_REQUIRE(e != nullptr, AGX_ERR_INVALID, "agx_engine_expand: null engine");
 	AGX_REQUIRE(e->begun, AGX_ERR_STATE, "agx_engine_expand: agx_engine_begin has not been called");
@@ -3280,8 +3349,21 @@ int agx_engine_expand_group(AgxEngine *e, int group, int n_groups, void *stream)
 		KernelTimer t(e, s, 2);
 		hipLaunchKernelGGL(k_expand, dim3(d.shared_tree ? 1 : count), dim3(64), 0, s, d);
 	}
+	if (service_arenas && !d.match_mode)
+	{ // a caller that makes the moves itself (set_board) never runs the advance stage: the trees that asked for larger arenas get them here
+		const int trees = d.shared_tree ? 1 : count;
+		if (d.shared_tree)
+			d.g0 = 0;
+		hipLaunchKernelGGL(k_arena_service, dim3(1), dim3(1024), 0, s, d, trees);
+		hipLaunchKernelGGL(k_arena_copy, dim3(trees * CLEAR_PARTS), dim3(256), 0, s, d, CLEAR_PARTS);
+		hipLaunchKernelGGL(k_arena_commit, dim3(trees), dim3(64), 0, s, d);
+	}
 	AGX_HIP_CHECK(hipGetLastError());
 	return AGX_OK;
+}
+int agx_engine_expand_group(AgxEngine *e, int group, int n_groups, void *stream)
+{
+	return expand_stage(e, group, n_groups, stream, true);
 }
 /* GameGenerator::make_move + prepare_search for the games whose search is complete (GameGenerator.cpp:145-185), then the next openings
  * for the games that ended */
@@ -3339,7 +3421,7 @@ int agx_engine_advance_group(AgxEngine *e, int group, int n_groups, void *stream
 }
 int agx_engine_expand_backup_group(AgxEngine *e, int group, int n_groups, void *stream)
 {
-	const int st = agx_engine_expand_group(e, group, n_groups, stream);
+	const int st = expand_stage(e, group, n_groups, stream, false); // (the advance stage services the arenas)
 	return (st != AGX_OK) ? st : agx_engine_advance_group(e, group, n_groups, stream);
 }
 
@@ -3397,7 +3479,8 @@ int agx_engine_set_board(AgxEngine *e, int game, const uint8_t *h_board, int sig
 	AGX_REQUIRE(e->begun, AGX_ERR_STATE, "agx_engine_set_board: agx_engine_begin has not been called");
 	AGX_REQUIRE(game >= 0 && game < e->dev.n_games, AGX_ERR_INVALID, "agx_engine_set_board: game %d of %d", game, e->dev.n_games);
 	AGX_REQUIRE(sign_to_move == 1 || sign_to_move == 2, AGX_ERR_INVALID, "agx_engine_set_board: sign_to_move must be 1 (cross) or 2 (circle)");
-	AGX_REQUIRE(!e->dev.match_mode && !e->dev.shared_tree, AGX_ERR_STATE, "agx_engine_set_board: the engine plays its own games (match_mode / search_threads)");
+	AGX_REQUIRE(!e->dev.match_mode, AGX_ERR_STATE, "agx_engine_set_board: a match-mode engine plays its own games");
+	AGX_REQUIRE(!e->dev.shared_tree || game == 0, AGX_ERR_INVALID, "agx_engine_set_board: a tournament-search engine has one tree, game 0 (records 1.. are its task buffers)");
 	for (int i = 0; i < e->dev.hw; i++)
 		AGX_REQUIRE(h_board[i] <= 2, AGX_ERR_INVALID, "agx_engine_set_board: cell %d holds %d (0 empty, 1 cross, 2 circle)", i, h_board[i]);
 	hipStream_t s = static_cast<hipStream_t>(stream);
@@ -3408,7 +3491,44 @@ int agx_engine_set_board(AgxEngine *e, int game, const uint8_t *h_board, int sig
 	}
 	AGX_HIP_CHECK(hipStreamSynchronize(s)); // (the staging buffer of the previous call may still be read)
 	AGX_HIP_CHECK(hipMemcpy(e->board_staging, h_board, e->dev.hw, hipMemcpyHostToDevice));
+	{ // Player::setBoard begins with search.cleanup(tree) (Player.cpp:98-100): leaves still in flight give their virtual losses back first
+		EngineDev one = e->dev;
+		one.g0 = game;
+		hipLaunchKernelGGL(k_cancel_pending, dim3(1), dim3(64), 0, s, one);
+	}
 	hipLaunchKernelGGL(k_set_board, dim3(1), dim3(256), 0, s, e->dev, game, e->board_staging, sign_to_move);
+	AGX_HIP_CHECK(hipGetLastError());
+	return AGX_OK;
+}
+int agx_engine_root_summary(AgxEngine *e, int game, void *stream, int *out4)
+{
+	AGX_REQUIRE(e != nullptr && out4 != nullptr, AGX_ERR_INVALID, "agx_engine_root_summary: null argument");
+	AGX_REQUIRE(e->begun, AGX_ERR_STATE, "agx_engine_root_summary: agx_engine_begin has not been called");
+	AGX_REQUIRE(game >= 0 && game < e->dev.n_games, AGX_ERR_INVALID, "agx_engine_root_summary: game %d of %d", game, e->dev.n_games);
+	if (e->summary_dev == nullptr)
+	{
+		AGX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e->summary_dev), 4 * sizeof(int)));
+		e->allocations.push_back(e->summary_dev);
+		AGX_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&e->summary_host), 4 * sizeof(int), hipHostMallocDefault));
+	}
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	EngineDev d = e->dev;
+	{ // (k_root_summary reads the game's arenas through its own record)
+		hipLaunchKernelGGL(k_root_summary, dim3(1), dim3(1), 0, s, d, game, e->summary_dev);
+	}
+	AGX_HIP_CHECK(hipMemcpyAsync(e->summary_host, e->summary_dev, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+	AGX_HIP_CHECK(hipStreamSynchronize(s)); // THIS stream only: a network launch on another stream keeps running
+	std::memcpy(out4, e->summary_host, 4 * sizeof(int));
+	return AGX_OK;
+}
+int agx_engine_cancel_pending(AgxEngine *e, void *stream)
+{
+	AGX_REQUIRE(e != nullptr, AGX_ERR_INVALID, "agx_engine_cancel_pending: null engine");
+	AGX_REQUIRE(e->begun, AGX_ERR_STATE, "agx_engine_cancel_pending: agx_engine_begin has not been called");
+	AGX_REQUIRE(!e->dev.match_mode, AGX_ERR_STATE, "agx_engine_cancel_pending: a match-mode engine plays its own games");
+	EngineDev d = e->dev;
+	d.g0 = 0;
+	hipLaunchKernelGGL(k_cancel_pending, dim3(d.shared_tree ? 1 : d.n_games), dim3(64), 0, static_cast<hipStream_t>(stream), d);
 	AGX_HIP_CHECK(hipGetLastError());
 	return AGX_OK;
 }

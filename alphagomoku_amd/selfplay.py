@@ -125,6 +125,10 @@ class GeneratorPool:
         b = np.ascontiguousarray(board, dtype=np.uint8).reshape(-1)
         check(lib.agx_engine_set_board(self._h, game, b.ctypes.data_as(ctypes.c_void_p), int(sign_to_move), stream))
 
+    def cancel_pending(self, stream=None):
+        """Search::cleanup: leaves selected but not expanded give their virtual losses back, every task buffer is emptied"""
+        check(lib.agx_engine_cancel_pending(self._h, stream))
+
     def set_max_simulations(self, n):
         check(lib.agx_engine_set_max_simulations(self._h, int(n)))
 

@@ -379,6 +379,15 @@ int agx_stream_synchronize(void* stream);
  * provided.  agx_engine_set_max_simulations: the budget Search::select(tree, maxSimulations) takes per call. */
 int agx_engine_set_board(AgxEngine* engine, int game, const uint8_t* h_board, int sign_to_move, void* stream);
 int agx_engine_set_max_simulations(AgxEngine* engine, int max_simulations);
+/* Search::cleanup (search/monte_carlo/Search.cpp:233-242): the leaves that were selected but not expanded — in every task buffer, of every
+ * tree of the engine — are dropped and their virtual losses taken back (Tree::cancelVirtualLoss, Tree.cpp:377-384).  agx_engine_set_board does
+ * this for its game by itself; a caller that stops a double-buffered search (SearchThread.cpp:108-109) calls it before reading the tree. */
+int agx_engine_cancel_pending(AgxEngine* engine, void* stream);
+/* Tree::getSimulationCount / isRootProven / getNodeCount (Tree.hpp:86-92) as a search loop reads them between two steps (the stop condition of
+ * player/SearchThread.cpp:181-199): out4 = { root visits, root proven (0 / 1), nodes in the tree, the game's error code }, read behind the work
+ * `stream` holds and waiting for THAT stream only — agx_engine_game_info synchronises the whole device, which would also wait for a network
+ * launch running beside the search on another stream. */
+int agx_engine_root_summary(AgxEngine* engine, int game, void* stream, int* out4);
 int agx_engine_set_force_expand_root(AgxEngine* engine, int force_expand_root); /* AgxEngineConfig.force_expand_root, for the launches that follow */
 int agx_engine_buffers(AgxEngine* engine, AgxEngineBuffers* out);
 int agx_engine_stats(AgxEngine* engine, AgxEngineStats* out);

@@ -301,7 +301,11 @@ namespace ag
 					int group = 0, n_groups = 1, positions = 0;
 					void *stream = nullptr;
 					bool *ready_flag = nullptr;
+					bool overlap = false; // the network launch goes onto the evaluator's own stream, ordered against `stream` by events
+					int event = 0;        // which of the evaluator's two event pairs (= the task buffer)
 			};
+			void *own_stream = nullptr;            // asyncEvaluateGraphLaunch's stream for double-buffered searches
+			void *scheduled_event[2] = { nullptr, nullptr }, *done_event[2] = { nullptr, nullptr };
 			std::vector<TaskData> waiting_queue;
 			std::vector<TaskData> in_progress_queue;
 			std::vector<SliceData> waiting_slices;
@@ -333,6 +337,11 @@ namespace ag
 			/* the device-side queue of a pool slice (what Search::scheduleToNN adds): *ready becomes true when the launch that evaluates
 			 * it has been joined */
 			void addToQueue(AgxEngine *engine, int group, int n_groups, int max_positions, void *stream, bool *ready);
+			/* ... of one task buffer of a double-buffered Search (player/SearchThread.cpp:148-180): asyncEvaluateGraphLaunch puts the network
+			 * on the evaluator's own stream behind the search stream's work so far; the asyncEvaluateGraphJoin that follows the NEXT launch
+			 * makes the search stream wait for it (device-side, the host does not block) — the tower runs beside the other buffer's tree work */
+			void addToQueueOverlapped(AgxEngine *engine, int buffer, int max_positions, void *stream, bool *ready);
+			~NNEvaluator();
 			double evaluateGraph();
 			double asyncEvaluateGraphLaunch();
 			void asyncEvaluateGraphJoin();
@@ -384,8 +393,9 @@ namespace ag
 			SearchConfig search_config;
 			int games = 0, batch = 0;
 		public:
+			/* searchBuffers = 2: ONE tree with two task buffers (games must be 1; AgxEngineConfig.search_buffers) — a stand-alone Search's engine */
 			GamePool(const GameConfig &gameOptions, const SearchConfig &searchOptions, const EdgeSelectorConfig &finalSelector, int games, int maxSimulations,
-					bool useSymmetries, const std::string &networkOutputs, bool forceExpandRoot = true);
+					bool useSymmetries, const std::string &networkOutputs, bool forceExpandRoot = true, int searchBuffers = 1);
 			GamePool(const GamePool&) = delete;
 			GamePool& operator=(const GamePool&) = delete;
 			~GamePool();
@@ -416,6 +426,11 @@ namespace ag
 			std::unique_ptr<EdgeSelector> edge_selector;
 			std::unique_ptr<EdgeGenerator> edge_generator;
 			mutable matrix<Sign> board_copy;
+			/* stand-alone: root visits / root proven / node count / error, read behind the tree's stream and waiting for that stream only (a
+			 * network launch on the evaluator's stream runs on: the double-buffered loop, player/SearchThread.cpp:148-199) */
+			mutable int summary[4] = { 0, 0, 0, 0 };
+			mutable bool summary_valid = false;
+			const int* root_summary() const;
 			friend class Search;
 			GamePool& bound() const;
 		public:
@@ -464,11 +479,12 @@ namespace ag
 	{
 			std::unique_ptr<GamePool> own_pool; // stand-alone: the engine of this Search / Tree pair
 			GamePool &pool;
-			int group, n_groups;
+			int group, n_groups;         // stand-alone: group = the current task buffer of 2
 			void *stream;
+			void *own_stream = nullptr;  // stand-alone: created with the engine
 			int batch_size;
 			bool scheduled = false;
-			bool tasks_ready = true;
+			bool ready_flags[2] = { true, true }; // per task buffer (an empty buffer is ready)
 			bool select_pending = false; // select() asked for, enqueued together with solve()
 			int current_task_buffer = 0;
 			SearchStats stats;
@@ -479,6 +495,9 @@ namespace ag
 			static constexpr int maximum_number_of_simulations = 16777216;
 			Search(const GameConfig &gameOptions, const SearchConfig &searchOptions);
 			Search(GamePool &pool, int group, int n_groups, void *stream);
+			~Search();
+			Search(const Search&) = delete;
+			Search& operator=(const Search&) = delete;
 
 			int64_t getMemory() const noexcept;
 			const SearchConfig& getConfig() const noexcept;
@@ -496,8 +515,9 @@ namespace ag
 			void backup(Tree &tree);
 			void cleanup(Tree &tree);
 
-			/* Search.hpp:88-89: the two task buffers of the tournament engine's double-buffered loop (player/SearchThread.cpp:148-180).  A device
-			 * step always completes its batch before the next select, so both indices name the same (empty between steps) buffer. */
+			/* Search.hpp:88-89: the two task buffers of the tournament engine's double-buffered loop (player/SearchThread.cpp:148-180).  A
+			 * stand-alone Search's engine has both (AgxEngineConfig.search_buffers = 2): every stage works on the current one, the leaves of the
+			 * other keep their virtual losses meanwhile, cleanup() drops both.  A pool slice has one buffer (a device step completes its batch). */
 			void useBuffer(int index);
 			void switchBuffer() noexcept;
 			void setBatchSize(int batchSize);

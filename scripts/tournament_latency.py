@@ -5,9 +5,11 @@ the expand / backup / select / solve of buffer 1 - b (AgxEngineConfig.search_buf
   serial : expand_backup(0) -> select_solve(0) -> network(0), one stream, one buffer (serial_run's loop on the same engine and kernels)
   async  : the search stages of buffer b on the search stream, the network of buffer b on a second stream behind an event; the search
            stream waits for buffer b's network only when b's turn comes again (asynchronous_run's Join / Launch / switchBuffer)
-  pool   : the ordinary one-game self-play engine (fused select + solve launch), for reference
+  pool   : the ordinary one-game self-play engine (select + speculative solve in one launch), for reference
+each of serial / async with the buffer's leaves solved one after the other by one wave per search thread (k_solve) and in parallel
+(speculative_solver: k_search_spec behind the one-wave select) — on one tree the threat solver, not the network, is most of an iteration.
 
-usage: python scripts/tournament_latency.py [--threads 1] [--batch 8 16 32] [--iterations 2000] [--blocks 6] [--filters 128]"""
+usage: python scripts/tournament_latency.py [--threads 1 4] [--batch 8 16] [--iterations 600] [--blocks 6] [--filters 128]"""
 import argparse
 import ctypes
 import json
@@ -21,8 +23,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--threads", type=int, nargs="+", default=[1, 4])
-    ap.add_argument("--batch", type=int, nargs="+", default=[8, 16, 32])
-    ap.add_argument("--iterations", type=int, default=2000, help="loop iterations (task buffers expanded) per measurement")
+    ap.add_argument("--batch", type=int, nargs="+", default=[8, 16])
+    ap.add_argument("--iterations", type=int, default=600, help="loop iterations (task buffers expanded) per measurement")
     ap.add_argument("--blocks", type=int, default=6)
     ap.add_argument("--filters", type=int, default=128)
     ap.add_argument("--rules", type=int, default=0)
@@ -44,21 +46,21 @@ def main():
     search_stream, net_stream = streams
     opening = selfplay.pack_openings(synthetic.make_openings(15, 1, seed0=4242, rules=args.rules))
 
-    def make_pool(threads, batch, buffers):
+    def make_pool(threads, batch, buffers, speculative=1):
         cfg = selfplay.default_config(rules=args.rules, board_size=15, n_games=threads * buffers, search_threads=threads if (threads > 1 or buffers == 2) else 0,
                                       search_buffers=buffers, max_batch_size=batch, max_simulations=1 << 22,   # one long search: the move rule never fires
-                                      tss_table_entries=1 << 20, node_capacity=1 << 18, edge_capacity=1 << 23, speculative_solver=1 if (threads == 1 and buffers == 1 and batch <= 16) else 0)
+                                      tss_table_entries=1 << 20, node_capacity=1 << 18, edge_capacity=1 << 23, speculative_solver=speculative)
         pool = selfplay.GeneratorPool(cfg)
         pool.begin(opening)
         return pool
 
-    def measure(kind, threads, batch):
+    def measure(kind, threads, batch, speculative):
         if kind == "pool":
-            if threads > 1:
+            if threads > 1 or not speculative:
                 return None
             pool = make_pool(1, batch, 1)
         else:
-            pool = make_pool(threads, batch, 2)
+            pool = make_pool(threads, batch, 2, speculative)
         sched = [vp(), vp()]
         done = [vp(), vp()]
         for e in sched + done:
@@ -81,7 +83,7 @@ def main():
                 pool.evaluate_group(net, b, 2, net_stream)                        # asyncEvaluateGraphLaunch
                 check(lib.agx_event_record(done[b], net_stream))
 
-        for i in range(100):
+        for i in range(50):
             iteration(i)
         check(lib.agx_device_synchronize())
         s0 = pool.stats()
@@ -94,7 +96,7 @@ def main():
         if s1["first_error"] != 0:
             raise RuntimeError("device engine stopped with error code %d" % s1["first_error"])
         sims = s1["evaluated_nodes"] - s0["evaluated_nodes"]
-        out = dict(kind=kind, threads=threads, batch=batch, iterations=args.iterations, us_per_iteration=1e6 * dt / args.iterations, simulations=int(sims),
+        out = dict(kind=kind, threads=threads, batch=batch, parallel_leaves=speculative, iterations=args.iterations, us_per_iteration=1e6 * dt / args.iterations, simulations=int(sims),
                    simulations_per_sec=sims / dt, network_evaluations=int(s1["network_evaluations"] - s0["network_evaluations"]), moves=int(s1["moves_played"] - s0["moves_played"]),
                    tree_nodes=int(s1["peak_nodes"]))
         for e in sched + done:
@@ -106,13 +108,17 @@ def main():
     for threads in args.threads:
         for batch in args.batch:
             got = {}
-            for kind in ("pool", "serial", "async"):
-                r = measure(kind, threads, batch)
-                if r is not None:
-                    got[kind] = r
-                    rows.append(r)
-                    print(json.dumps(r), flush=True)
-            print(json.dumps(dict(threads=threads, batch=batch, async_over_serial=got["async"]["simulations_per_sec"] / got["serial"]["simulations_per_sec"])), flush=True)
+            for speculative in (0, 1):
+                for kind in ("pool", "serial", "async"):
+                    r = measure(kind, threads, batch, speculative)
+                    if r is not None:
+                        got[kind, speculative] = r
+                        rows.append(r)
+                        print(json.dumps(r), flush=True)
+            rate = {k: v["simulations_per_sec"] for k, v in got.items()}
+            print(json.dumps(dict(threads=threads, batch=batch, async_over_serial=rate["async", 0] / rate["serial", 0],
+                                  async_over_serial_parallel_leaves=rate["async", 1] / rate["serial", 1],
+                                  parallel_leaves_over_serial_leaves=rate["async", 1] / rate["async", 0])), flush=True)
     print(json.dumps(dict(workload="one game, one tree, %dx%d network, 15x15 rules %d" % (args.blocks, args.filters, args.rules), rows=len(rows))))
 
 

@@ -14,6 +14,7 @@
  */
 #include "../../include/alphagomoku_agx/selfplay.hpp"
 
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -285,6 +286,172 @@ static int mode_player(const std::map<std::string, std::string> &a)
 	return 0;
 }
 
+/* player/SearchThread.cpp:121-199 call for call, without the host threads around it (one SearchThread; the tree's PriorityMutex has nobody
+ * to keep out): serial_run, asynchronous_run with useBuffer / switchBuffer and asyncEvaluateGraphLaunch / Join, the stop condition on the
+ * simulation and node counts.  get_batch_size is the reference's (the square root of the simulation count, capped) only with --sqrt-batch:
+ * the device's buffers have the engine's fixed batch size. */
+class SearchThread
+{
+		Tree &tree;
+		Search search;
+		int max_simulations, max_nodes;
+		int iterations = 0;
+	public:
+		SearchThread(const GameConfig &gameOptions, const SearchConfig &searchOptions, Tree &tree, int maxSimulations, int maxNodes) :
+				tree(tree), search(gameOptions, searchOptions), max_simulations(maxSimulations), max_nodes(maxNodes)
+		{
+		}
+		Search& getSearch() noexcept { return search; }
+		int getIterations() const noexcept { return iterations; }
+		void setPosition(const matrix<Sign> &board, Sign signToMove)
+		{ // SearchEngine::setPosition + SearchThread::setPosition: cleanup, Tree::setBoard, Search::setBoard, a fresh selector and generator
+			search.cleanup(tree);
+			tree.setBoard(board, signToMove);
+			search.setBoard(board, signToMove);
+			const MCTSConfig &mcts_config = search.getConfig().mcts_config;
+			std::unique_ptr<EdgeSelector> tmp = EdgeSelector::create(mcts_config.edge_selector_config);
+			tree.setEdgeSelector(*tmp);
+			tree.setEdgeGenerator(UnifiedGenerator(mcts_config.max_children, mcts_config.policy_expansion_threshold, mcts_config.policy_temperature));
+		}
+		void run(NNEvaluator &evaluator, bool asynchronous)
+		{ // SearchThread.cpp:84-112
+			search.clearStats();
+			iterations = 0;
+			if (isStopConditionFulfilled())
+				return;
+			if (asynchronous)
+				asynchronous_run(evaluator);
+			else
+				serial_run(evaluator);
+			search.cleanup(tree);
+		}
+	private:
+		void serial_run(NNEvaluator &evaluator)
+		{ // SearchThread.cpp:121-146
+			while (true)
+			{
+				search.setBatchSize(search.getConfig().max_batch_size);
+				search.select(tree, max_simulations);
+				search.solve();
+				search.scheduleToNN(evaluator);
+				evaluator.evaluateGraph();
+
+				search.generateEdges(tree);
+				search.expand(tree);
+				search.backup(tree);
+				iterations++;
+				if (isStopConditionFulfilled())
+					break;
+			}
+		}
+		void asynchronous_run(NNEvaluator &evaluator)
+		{ // SearchThread.cpp:148-180
+			search.useBuffer(0);
+			double end_time = 0.0;
+			while (true)
+			{
+				search.generateEdges(tree);
+				search.expand(tree);
+				search.backup(tree);
+				iterations++;
+				if (isStopConditionFulfilled())
+					break;
+				search.setBatchSize(search.getConfig().max_batch_size);
+				search.select(tree, max_simulations);
+
+				search.solve(end_time);
+				search.scheduleToNN(evaluator);
+				evaluator.asyncEvaluateGraphJoin();
+
+				end_time = evaluator.asyncEvaluateGraphLaunch();
+				search.switchBuffer();
+			}
+			evaluator.asyncEvaluateGraphJoin();
+		}
+		bool isStopConditionFulfilled() const
+		{ // SearchThread.cpp:181-199 (the memory limit is the node limit here: flat arenas)
+			if (tree.getNodeCount() == 0)
+				return false;
+			if (tree.getSimulationCount() >= max_simulations)
+				return true;
+			if (tree.getNodeCount() >= max_nodes)
+				return true;
+			return tree.isRootProven();
+		}
+};
+
+static int mode_thread(const std::map<std::string, std::string> &a)
+{ // a game played by ONE tournament-style engine against itself: per move a search of --sims simulations (serial_run or asynchronous_run),
+  // the move by the "best" selector on the root (SearchEngine's choice), Tree::setBoard on the new position
+	const int n = geti(a, "--board", 15);
+	GameConfig game_config(static_cast<GameRules>(geti(a, "--rules", 0)), n);
+	SearchConfig search_config;
+	search_config.max_batch_size = geti(a, "--batch", 8);
+	search_config.tss_config.hash_table_size = geti(a, "--table-entries", 1 << 16);
+	search_config.tree_config.node_bucket_size = geti(a, "--nodes", 4096);
+	search_config.tree_config.edge_bucket_size = geti(a, "--edges", 65536);
+	const int sims = geti(a, "--sims", 400);
+	const bool asynchronous = geti(a, "--async", 1) != 0;
+	DeviceConfig device;
+	device.batch_size = 64;
+	NNEvaluator evaluator(device);
+	evaluator.loadGraph(NetworkLoader(a.at("--network")));
+	evaluator.useSymmetries(false);
+	Tree tree(search_config.tree_config);
+	SearchThread thread(game_config, search_config, tree, sims, 1 << 30);
+
+	matrix<Sign> board(n, n);
+	board.fill(Sign::NONE);
+	std::vector<uint16_t> opening(AGX_OPENING_CAP, 0);
+	if (agx_make_opening(static_cast<int>(game_config.rules), n, static_cast<uint32_t>(geti(a, "--opening-seed", 1)), opening.data()) != AGX_OK)
+		throw std::runtime_error(agx_last_error());
+	Sign sign_to_move = Sign::CROSS;
+	std::vector<uint8_t> cells(static_cast<size_t>(n) * n, 0);
+	for (int i = 0; i < opening[0]; i++)
+	{
+		const Move m(opening[1 + i]);
+		board.at(m.row, m.col) = m.sign;
+		cells[m.row * n + m.col] = static_cast<uint8_t>(m.sign);
+		sign_to_move = (m.sign == Sign::CROSS) ? Sign::CIRCLE : Sign::CROSS;
+	}
+	thread.getSearch().getSolver().clear();
+	EdgeSelectorConfig final_selector;
+	final_selector.policy = "best";
+	std::vector<Move> played;
+	std::vector<int> visits;
+	int outcome = 0, iterations = 0;
+	const int max_plies = geti(a, "--plies", n * n);
+	const auto t0 = std::chrono::steady_clock::now();
+	while (outcome == 0 && static_cast<int>(played.size()) < max_plies)
+	{
+		thread.setPosition(board, sign_to_move);
+		thread.run(evaluator, asynchronous);
+		iterations += thread.getIterations();
+		std::unique_ptr<EdgeSelector> selector = EdgeSelector::create(final_selector);
+		const Node root_node = tree.getInfo( { });
+		const Move m = selector->select(&root_node)->getMove();
+		played.push_back(m);
+		visits.push_back(root_node.getVisits());
+		board.at(m.row, m.col) = m.sign;
+		cells[m.row * n + m.col] = static_cast<uint8_t>(m.sign);
+		sign_to_move = (m.sign == Sign::CROSS) ? Sign::CIRCLE : Sign::CROSS;
+		if (agx_get_outcome(static_cast<int>(game_config.rules), n, cells.data(), static_cast<int>(m.sign), m.row, m.col, game_config.draw_after, &outcome) != AGX_OK)
+			throw std::runtime_error(agx_last_error());
+	}
+	const double seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+	const SearchStats stats = thread.getSearch().getStats();
+	std::printf("{\"mode\": \"thread\", \"asynchronous\": %d, \"opening_stones\": %d, \"outcome\": %d, \"iterations\": %d, \"seconds\": %.6f, \"simulations\": %llu, "
+			"\"network_evaluations\": %llu, \"moves\": [", asynchronous ? 1 : 0, static_cast<int>(opening[0]), outcome, iterations, seconds,
+			static_cast<unsigned long long>(stats.nb_node_count), static_cast<unsigned long long>(stats.nb_network_evaluations));
+	for (size_t i = 0; i < played.size(); i++)
+		std::printf("%s%d", i ? ", " : "", static_cast<int>(played[i].toShort()));
+	std::printf("], \"root_visits\": [");
+	for (size_t i = 0; i < visits.size(); i++)
+		std::printf("%s%d", i ? ", " : "", visits[i]);
+	std::printf("]}\n");
+	return 0;
+}
+
 static int mode_generator(const std::map<std::string, std::string> &a)
 { // GameGenerator(gameOptions, selfplayOptions, manager, evaluator) as GeneratorThread constructs its generators in the reference
   // (GeneratorManager.cpp:107-110): one game per generator, each with its own tree and search
@@ -398,7 +565,7 @@ int main(int argc, char **argv)
 {
 	if (argc < 2)
 	{
-		std::fprintf(stderr, "usage: agx_boundary_test generate|evaluator|player|generator|errors [--key value ...]\n");
+		std::fprintf(stderr, "usage: agx_boundary_test generate|evaluator|player|thread|generator|errors [--key value ...]\n");
 		return 2;
 	}
 	try
@@ -411,6 +578,8 @@ int main(int argc, char **argv)
 			return mode_evaluator(args);
 		if (mode == "player")
 			return mode_player(args);
+		if (mode == "thread")
+			return mode_thread(args);
 		if (mode == "generator")
 			return mode_generator(args);
 		if (mode == "errors")

@@ -183,6 +183,81 @@ def test_players_with_the_reference_constructors(network_file, agx_lib, tmp_path
     assert [m for _, m in first_game] == line["moves"]
 
 
+@pytest.mark.parametrize("asynchronous", [0, 1])
+def test_search_thread_loops_with_the_reference_constructors(network_file, agx_lib, asynchronous):
+    """player/SearchThread.cpp:121-199 compiled against include/alphagomoku_agx/ as written — serial_run, and asynchronous_run with
+    Search::useBuffer / switchBuffer, NNEvaluator::asyncEvaluateGraphLaunch / Join and the stop condition read through Tree::getNodeCount /
+    getSimulationCount / isRootProven — drives a game (tests/cpp/boundary_main.cpp, mode thread).  The same procedure through the C ABI on a
+    double-buffered engine (search_buffers = 2, whose every iteration test_double_buffered_tournament_search compares with the oracle), one
+    stream, everything in order, must give the same moves and root visit counts: the classes' two streams and events change when things run,
+    not what is computed."""
+    from alphagomoku_amd import selfplay, lib, check
+    from alphagomoku_amd.networks import AGNetwork
+    from test_engine_gpu import _best_edge
+    path, d, blob = network_file
+    seed, sims, batch, plies, n = 11, 150, 8, 14, 15
+    line, _ = run("thread", "--network", path, "--sims", sims, "--batch", batch, "--opening-seed", seed, "--table-entries", 1 << 16, "--plies", plies, "--async", asynchronous)
+    assert line["asynchronous"] == asynchronous and len(line["moves"]) >= 1
+    net = AGNetwork(d)
+    net.loadWeights(blob)
+    opening = synthetic.make_openings(n, 1, seed0=seed)[0]
+    assert len(opening) == line["opening_stones"]
+    cfg = selfplay.default_config(n_games=2, search_buffers=2, max_batch_size=batch, max_simulations=1 << 24, tss_table_entries=1 << 16, node_capacity=4096,
+                                  edge_capacity=65536, force_expand_root=0, speculative_solver=1)
+    pool = selfplay.GeneratorPool(cfg)
+    pool.begin(selfplay.pack_openings([[]]))
+    board = np.zeros(n * n, np.uint8)
+    sign = 1
+    for m in opening:
+        board[((m >> 2) & 127) * n + ((m >> 9) & 127)] = m & 3
+        sign = 3 - (m & 3)
+    out4 = (ctypes.c_int * 4)()
+
+    def stop():
+        check(lib.agx_engine_root_summary(pool._h, 0, None, out4))
+        return out4[2] != 0 and (out4[0] >= sims or out4[1] != 0)
+
+    moves, visits, outcome, iterations = [], [], 0, 0
+    while outcome == 0 and len(moves) < plies:
+        pool.set_board(0, board, sign)
+        if not stop():
+            b = 0
+            while True:
+                if asynchronous:
+                    check(lib.agx_engine_expand_group(pool._h, b, 2, None))
+                    iterations += 1
+                    if stop():
+                        break
+                pool.set_max_simulations(sims)
+                pool.select_solve_group(b, 2)
+                pool.evaluate_group(net, b, 2)
+                if asynchronous:
+                    b = 1 - b
+                else:
+                    check(lib.agx_engine_expand_group(pool._h, 0, 2, None))
+                    iterations += 1
+                    if stop():
+                        break
+        pool.cancel_pending()
+        info = pool.game_info(0)
+        e = info["edges"][_best_edge(info["root_visits"], info["edges"])]
+        mv = int(e["move"])
+        moves.append(mv)
+        visits.append(info["root_visits"])
+        row, col = (mv >> 2) & 127, (mv >> 9) & 127
+        board[row * n + col] = mv & 3
+        sign = 3 - (mv & 3)
+        res = ctypes.c_int(0)
+        check(lib.agx_get_outcome(0, n, board.ctypes.data_as(ctypes.c_void_p), mv & 3, row, col, n * n, ctypes.byref(res)))
+        outcome = res.value
+    st = pool.stats()
+    pool.close()
+    net.close()
+    assert moves == line["moves"] and visits == line["root_visits"] and outcome == line["outcome"]
+    assert iterations == line["iterations"] and st["evaluated_nodes"] == line["simulations"]
+    assert min(visits) >= sims or outcome != 0
+
+
 def test_game_generators_with_the_reference_constructor(network_file, agx_lib):
     """GameGenerator(gameOptions, selfplayOptions, manager, evaluator) (selfplay/GameGenerator.hpp:54): generators of one game each, driven by
     the reference's generator-thread loop, hand their finished games to the manager's buffer"""

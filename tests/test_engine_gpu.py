@@ -509,8 +509,8 @@ def test_exhausted_arena_reserve_is_reported(agx_lib, olib):
     pool.close()
 
 
-@pytest.mark.parametrize("rules,threads,batch", [(0, 4, 8), (1, 8, 4), (2, 3, 4)])
-def test_tournament_search_on_one_tree(agx_lib, olib, rules, threads, batch):
+@pytest.mark.parametrize("rules,threads,batch,speculative", [(0, 4, 8, 0), (1, 8, 4, 0), (2, 3, 4, 0), (0, 4, 8, 1), (2, 3, 4, 1)])
+def test_tournament_search_on_one_tree(agx_lib, olib, rules, threads, batch, speculative):
     """SURVEY row f4 (player/SearchThread.cpp:121-180): ONE tree searched by several SearchThreads, each with its own Search (task buffer,
     threat solver, table).  The device runs the threads in lock-step — select in thread order under the tree 'lock' (one wave), the
     solvers in parallel (one wave per thread), one network launch, expand + backup in thread order — and the oracle plays the same
@@ -518,7 +518,7 @@ def test_tournament_search_on_one_tree(agx_lib, olib, rules, threads, batch):
     from alphagomoku_amd import selfplay
     sims = 300
     cfg = selfplay.default_config(rules=rules, n_games=threads, search_threads=threads, max_batch_size=batch, max_simulations=sims,
-                                  tss_table_entries=1 << 16, node_capacity=4096, edge_capacity=65536)
+                                  tss_table_entries=1 << 16, node_capacity=4096, edge_capacity=65536, speculative_solver=speculative)   # (1: every thread's leaves solved in parallel)
     pool = selfplay.GeneratorPool(cfg)
     ocfg = ol.default_search_config(max_batch_size=batch, max_simulations=sims, table_entries=1 << 16)
     op = np.zeros(64, np.uint16)
@@ -571,20 +571,22 @@ def test_tournament_search_on_one_tree(agx_lib, olib, rules, threads, batch):
     olib.ago_game_destroy(h)
 
 
-@pytest.mark.parametrize("rules,threads,batch,node_capacity,seed", [(0, 1, 8, 4096, 177), (1, 4, 4, 4096, 181), (2, 3, 8, 4096, 182), (0, 2, 8, 256, 181)])
-def test_double_buffered_tournament_search(agx_lib, olib, rules, threads, batch, node_capacity, seed):
+@pytest.mark.parametrize("rules,threads,batch,node_capacity,seed,speculative", [(0, 1, 8, 4096, 177, 1), (1, 4, 4, 4096, 181, 0), (2, 3, 8, 4096, 182, 1),
+                                                                                (0, 2, 8, 256, 181, 1), (0, 1, 8, 4096, 184, 0)])
+def test_double_buffered_tournament_search(agx_lib, olib, rules, threads, batch, node_capacity, seed, speculative):
     """SURVEY row f4, the double buffering (player/SearchThread.cpp:148-180 asynchronous_run, Search.cpp:243-252 useBuffer / switchBuffer):
     every search thread has two task buffers; while buffer b's leaves are with the network — virtual losses applied — buffer 1 - b is
     expanded, backed up, selected and solved.  The device steps the pool buffer by buffer (group b of 2: expand_backup, select_solve,
     network), the oracle runs asynchronous_run's loop body per thread with the same fixed thread order: the same leaves and features in
     every iteration, the same root after it, the same moves, for whole games.  When the move rule fires, the other buffer's leaves are
     dropped and their virtual losses taken back (Search::cleanup).  The last case starts with small arenas: a buffer whose expansion
-    waits for larger ones must still go before the other buffer."""
+    waits for larger ones must still go before the other buffer.  speculative: the leaves of every buffer solved in parallel (k_search_spec
+    behind the one-wave select)."""
     from alphagomoku_amd import selfplay
     sims = 300
     cfg = selfplay.default_config(rules=rules, n_games=2 * threads, search_threads=threads, search_buffers=2, max_batch_size=batch, max_simulations=sims,
                                   tss_table_entries=1 << 16, node_capacity=node_capacity, edge_capacity=65536 if node_capacity >= 4096 else 8192,
-                                  arena_reserve=1.0 if node_capacity >= 4096 else 8.0)
+                                  arena_reserve=1.0 if node_capacity >= 4096 else 8.0, speculative_solver=speculative)
     pool = selfplay.GeneratorPool(cfg)
     ocfg = ol.default_search_config(max_batch_size=batch, max_simulations=sims, table_entries=1 << 16)
     op = np.zeros(64, np.uint16)
