@@ -865,6 +865,40 @@ void ago_fast_zobrist_with_keys(const uint64_t *keys, int rows, int cols, const 
 		out[2 * (1 + i) + 1] = h.hi;
 	}
 }
+/* the script format of ref_bitmask_script (utils/BitMask.hpp on the oracle's plain words) */
+int ago_bitmask_script(const int *ops, int n_ops, int rows, int cols, uint32_t *out, int capacity)
+{
+	uint16_t m = 0, last = 0;
+	uint32_t g[32] = { 0 }, h[32] = { 0 };
+	(void) rows;
+	(void) cols;
+	int at = 0, pos = 0;
+	for (int k = 0; k < n_ops; k++)
+	{
+		const int op = ops[at++];
+		switch (op)
+		{
+			case 1: mask_set(m, ops[at], ops[at + 1] != 0); at += 2; break;
+			case 2: m = mask_flip16(m, ops[at++]); break;
+			case 3: m = static_cast<uint16_t>(m << ops[at++]); break;
+			case 4: m = static_cast<uint16_t>(m >> ops[at++]); break;
+			case 5: last = static_cast<uint16_t>(ops[at++]); m &= last; break;
+			case 6: last = static_cast<uint16_t>(ops[at++]); m |= last; break;
+			case 7: mask_set(g[ops[at]], ops[at + 1], ops[at + 2] != 0); at += 3; break;
+			case 8: mask_set(h[ops[at]], ops[at + 1], ops[at + 2] != 0); at += 3; break;
+			case 9: for (int r = 0; r < 32; r++) g[r] &= h[r]; break;
+			case 10: for (int r = 0; r < 32; r++) g[r] |= h[r]; break;
+			default: { const uint32_t v = (ops[at++] != 0) ? 0xFFFFFFFFu : 0u; for (int r = 0; r < 32; r++) g[r] = v; } break;
+		}
+		if (pos + 34 > capacity)
+			return -1;
+		out[pos++] = m;
+		out[pos++] = (m == last) ? 1u : 0u;
+		for (int r = 0; r < 32; r++)
+			out[pos++] = g[r];
+	}
+	return pos;
+}
 /* the script format of ref_action_list_script */
 int ago_action_list_script(const int *ops, int n_ops, int *out, int capacity)
 {

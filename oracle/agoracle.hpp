@@ -32,6 +32,27 @@
 
 namespace ago
 {
+	/* utils/BitMask.hpp: the oracle keeps BitMask1D<uint16_t> / BitMask2D<uint32_t, 32> as plain words (bit = cell of a line, bit c of
+	 * word r = cell (r, c)); these are the header's operations on such words (reverse_bits :19-37, flip :112-115, at / reference :44-58,
+	 * 87-96, fill :181-187) */
+	inline uint16_t mask_reverse16(uint16_t x)
+	{
+		uint16_t r = 0;
+		for (int i = 0; i < 16; i++)
+			if ((x >> i) & 1)
+				r = static_cast<uint16_t>(r | (1u << (15 - i)));
+		return r;
+	}
+	inline uint16_t mask_flip16(uint16_t x, int length) { return static_cast<uint16_t>(mask_reverse16(x) >> (16 - length)); }
+	template<typename T>
+	inline void mask_set(T &word, int idx, bool b)
+	{
+		if (b)
+			word = static_cast<T>(word | (static_cast<T>(1) << idx));
+		else
+			word = static_cast<T>(word & ~(static_cast<T>(1) << idx));
+	}
+
 	/* ---- basic records ---- */
 	enum Rules : int { FREESTYLE = 0, STANDARD = 1, RENJU = 2, CARO5 = 3, CARO6 = 4 }; // game/rules.hpp:18-25
 	typedef uint8_t Sign;                                                             // game/Move.hpp:17-23

@@ -30,6 +30,7 @@
 #include <alphagomoku/search/ZobristHashing.hpp>
 #include <alphagomoku/search/alpha_beta/ActionList.hpp>
 #include <alphagomoku/utils/matrix.hpp>
+#include <alphagomoku/utils/BitMask.hpp>
 #include <memory>
 #include <vector>
 
@@ -332,6 +333,41 @@ void ref_fast_zobrist(int rows, int cols, const uint8_t *boards, int n, const ui
  *   3                : close the top list (its destructor releases its actions)   4 move offset : top.moveCloserToFront(Move(move), offset)
  * After every operation out gets (stack offset, stack max_offset, size of the top list, its distance from the root); at the end the
  * (move, score) of every action of every open list, root first.  Returns the number of ints written. ---- */
+/* ---- utils/BitMask.hpp: BitMask1D<uint16_t> (a line's move mask) and BitMask2D<uint32_t, 32> (a board's move mask) under a script.
+ * ops: 1 idx v : m.at(idx) = v      2 length : m.flip(length)     3 s : m = m << s      4 s : m = m >> s      5 x : m &= x      6 x : m |= x
+ *      7 r c v : g.at(r, c) = v     8 r c v : h.at(r, c) = v      9 : g &= h            10 : g |= h           11 b : g.fill(b)
+ * After every operation out gets m.raw(), m == BitMask1D(x of the last op 5 / 6), and the 32 row words of g. ---- */
+int ref_bitmask_script(const int *ops, int n_ops, int rows, int cols, uint32_t *out, int capacity)
+{
+	BitMask1D<uint16_t> m, last;
+	BitMask2D<uint32_t, 32> g(rows, cols), h(rows, cols);
+	int at = 0, pos = 0;
+	for (int k = 0; k < n_ops; k++)
+	{
+		const int op = ops[at++];
+		switch (op)
+		{
+			case 1: m.at(ops[at]) = (ops[at + 1] != 0); at += 2; break;
+			case 2: m.flip(ops[at++]); break;
+			case 3: m = m << ops[at++]; break;
+			case 4: m = m >> ops[at++]; break;
+			case 5: last = BitMask1D<uint16_t>(static_cast<uint16_t>(ops[at++])); m &= last; break;
+			case 6: last = BitMask1D<uint16_t>(static_cast<uint16_t>(ops[at++])); m |= last; break;
+			case 7: g.at(ops[at], ops[at + 1]) = (ops[at + 2] != 0); at += 3; break;
+			case 8: h.at(ops[at], ops[at + 1]) = (ops[at + 2] != 0); at += 3; break;
+			case 9: g &= h; break;
+			case 10: g |= h; break;
+			default: g.fill(ops[at++] != 0); break;
+		}
+		if (pos + 34 > capacity)
+			return -1;
+		out[pos++] = m.raw();
+		out[pos++] = (m == last) ? 1u : 0u;
+		for (int r = 0; r < 32; r++)
+			out[pos++] = g.data()[r];
+	}
+	return pos;
+}
 int ref_action_list_script(const int *ops, int n_ops, int *out, int capacity)
 {
 	ActionStack stack(4096);

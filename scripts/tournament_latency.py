@@ -119,6 +119,27 @@ def main():
             print(json.dumps(dict(threads=threads, batch=batch, async_over_serial=rate["async", 0] / rate["serial", 0],
                                   async_over_serial_parallel_leaves=rate["async", 1] / rate["serial", 1],
                                   parallel_leaves_over_serial_leaves=rate["async", 1] / rate["async", 0])), flush=True)
+    # the same two loops as compiled C++ against the reference-named classes (tests/cpp/boundary_main.cpp mode thread: SearchThread::serial_run /
+    # asynchronous_run as written, with the stop condition read from the tree in every iteration)
+    import subprocess
+    import tempfile
+    binary = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "alphagomoku_amd", "agx_boundary_test")
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "network.agxw")
+        synthetic.save_weights(path, desc, synthetic.make_weights(desc, seed=1234)[0])
+        for batch in args.batch:
+            got = {}
+            for asynchronous in (0, 1):
+                p = subprocess.run([binary, "thread", "--network", path, "--sims", "4000", "--batch", str(batch), "--opening-seed", "4242", "--plies", "3", "--async", str(asynchronous),
+                                    "--table-entries", str(1 << 20), "--nodes", str(1 << 16), "--edges", str(1 << 21)], capture_output=True, text=True, timeout=600)
+                if p.returncode != 0:
+                    raise RuntimeError(p.stderr[-2000:])
+                line = json.loads([x for x in p.stdout.splitlines() if x.startswith('{"mode"')][0])
+                r = dict(kind="SearchThread classes", asynchronous=asynchronous, batch=batch, iterations=line["iterations"], seconds=line["seconds"], simulations=line["simulations"],
+                         us_per_iteration=1e6 * line["seconds"] / line["iterations"], simulations_per_sec=line["simulations"] / line["seconds"], moves=len(line["moves"]))
+                got[asynchronous] = r
+                print(json.dumps(r), flush=True)
+            print(json.dumps(dict(kind="SearchThread classes", batch=batch, async_over_serial=got[1]["simulations_per_sec"] / got[0]["simulations_per_sec"])), flush=True)
     print(json.dumps(dict(workload="one game, one tree, %dx%d network, 15x15 rules %d" % (args.blocks, args.filters, args.rules), rows=len(rows))))
 
 

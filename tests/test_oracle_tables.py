@@ -422,3 +422,44 @@ def test_action_list_mechanics_match_compiled_reference(oracle, ref):
         na = ref.ref_action_list_script(_ptr(arr), n_ops, _ptr(a), len(a))
         nb = oracle.ago_action_list_script(_ptr(arr), n_ops, _ptr(b), len(b))
         assert na == nb and na > 0 and np.array_equal(a[:na], b[:nb]), trial
+
+
+def test_bitmask_matches_reference(ref, oracle):
+    """utils/BitMask.hpp (the compiled reference header): BitMask1D<uint16_t> — at / reference assignment, flip(length) over reverse_bits,
+    shifts, &=, |=, == — and BitMask2D<uint32_t, 32> — at(row, col), fill, &=, |= — against the oracle's plain-word restatement (the move
+    masks of a line and of a board in its move generator and defensive-move tables), on random scripts."""
+    rng = np.random.default_rng(11)
+    for trial in range(100):
+        rows, cols = int(rng.integers(5, 21)), int(rng.integers(5, 21))
+        ops, n_ops = [], 0
+        for _ in range(int(rng.integers(10, 120))):
+            op = int(rng.integers(1, 12))
+            if op == 1:
+                ops += [1, int(rng.integers(0, 16)), int(rng.integers(0, 2))]
+            elif op == 2:
+                ops += [2, int(rng.integers(1, 17))]
+            elif op in (3, 4):
+                ops += [op, int(rng.integers(0, 16))]
+            elif op in (5, 6):
+                ops += [op, int(rng.integers(0, 65536))]
+            elif op in (7, 8):
+                ops += [op, int(rng.integers(0, rows)), int(rng.integers(0, cols)), int(rng.integers(0, 2))]
+            elif op in (9, 10):
+                ops += [op]
+            else:
+                ops += [11, int(rng.integers(0, 2))]
+            n_ops += 1
+        arr = np.array(ops, np.int32)
+        a, b = np.zeros(34 * n_ops, np.uint32), np.zeros(34 * n_ops, np.uint32)
+        na = ref.ref_bitmask_script(_ptr(arr), n_ops, rows, cols, _ptr(a), len(a))
+        nb = oracle.ago_bitmask_script(_ptr(arr), n_ops, rows, cols, _ptr(b), len(b))
+        assert na == nb == 34 * n_ops and np.array_equal(a, b), trial
+    # reverse_bits itself, every 16-bit word: flip(16) of a fresh mask
+    words = np.arange(65536, dtype=np.int64)
+    expect = np.zeros(65536, np.int64)
+    for i in range(16):
+        expect |= ((words >> i) & 1) << (15 - i)
+    for x in (0, 1, 0x8000, 0x1234, 0xFFFF, 0xA5A5):
+        arr = np.array([6, x, 2, 16], np.int32)
+        a = np.zeros(68, np.uint32)
+        assert ref.ref_bitmask_script(_ptr(arr), 2, 15, 15, _ptr(a), 68) == 68 and a[34] == expect[x]
