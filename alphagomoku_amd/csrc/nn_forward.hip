@@ -42,6 +42,18 @@
 #ifndef AGX_NN_ROW_STATIONARY
 #define AGX_NN_ROW_STATIONARY 1 // 0: the tap-major k-loop for every board (A/B builds)
 #endif
+#ifndef AGX_NN_COLUMN_TILES
+#define AGX_NN_COLUMN_TILES 1 // 0: the tap-major k-loop on 20x20 boards (A/B builds)
+#endif
+#ifndef AGX_NN_COLS_AHEAD
+#define AGX_NN_COLS_AHEAD 4 // activation fragments in flight per wave in the column-tile k-loop
+#endif
+#ifndef AGX_NN_COLS_INTERLEAVE
+#define AGX_NN_COLS_INTERLEAVE 0
+#endif
+#ifndef AGX_NN_COLS_BARRIER
+#define AGX_NN_COLS_BARRIER 1
+#endif
 #ifndef AGX_NN_AHEAD
 #define AGX_NN_AHEAD 4 // activation fragments in flight per wave in the row-stationary k-loop
 #endif
@@ -123,14 +135,33 @@ namespace
 			static constexpr int CG = (S == 16 || F >= 128) ? 4 : 2;
 			static constexpr int PG = 8 / CG;
 			static constexpr int MT = F / (16 * CG);                             // 16-channel output tiles per wave
-			static constexpr int NTW = (NT + PG - 1) / PG;                       // position tiles per wave
+			// 20x20 boards with 128 filters: the tiles of rows 0..15 are COLUMNS (16 cells of one board column: lane r = row r) — the
+			// neighbouring column is the same tile shifted by one position, so one activation fragment feeds the three taps dx = -1, 0, +1 like
+			// a row's fragment feeds dy on 15x15 boards (conv3x3_mac_cols) — and rows 16..19 stay six ordinary tiles of consecutive positions
+			// (16 rows x 21 = 336 positions = 21 whole tiles lie in front of them).  A position group owns 10 columns + 3 of those.
+			static constexpr bool COLT = (ROWS == 20 && COLS == 20 && F == 128 && AGX_NN_COLUMN_TILES != 0);
+			static constexpr int COL_TILES = COLS / 2, TAIL_TILES = 3, TAIL_FIRST = 21;
+			static constexpr int NTW = COLT ? (COL_TILES + TAIL_TILES) : (NT + PG - 1) / PG; // position tiles per wave
 			static constexpr int THREADS = 512;                                  // 8 waves, 2 per SIMD
 			// (shifts and masks on purpose: written with / and % the 15x15 kernels came out 12 % (6x128) and 60 x (2x64) slower)
 			__device__ static __forceinline__ int channel_group(int wave) { return wave & (CG - 1); }
 			__device__ static __forceinline__ int first_tile(int wave) { return (wave >> (CG == 4 ? 2 : 1)) * NTW; }
+			/* row-major position (stride S, 0 = cell (0, 0)) of lane r's cell in tile n of the wave */
+			__device__ static __forceinline__ int tile_position(int wave, int n, int r)
+			{
+				if constexpr (COLT)
+				{
+					const int pg = wave >> 2;
+					return (n < COL_TILES) ? (r * S + pg * COL_TILES + n) : ((TAIL_FIRST + pg * TAIL_TILES + (n - COL_TILES)) * 16 + r);
+				}
+				else
+					return (first_tile(wave) + n) * 16 + r;
+			}
 			__device__ static __forceinline__ int tile_count(int wave)
 			{
-				if constexpr (PG == 2)
+				if constexpr (COLT)
+					return NTW;
+				else if constexpr (PG == 2)
 					return (wave >> 2) ? (NT - NTW) : NTW;
 				else
 					return ((wave >> 1) == PG - 1) ? (NT - (PG - 1) * NTW) : NTW;
@@ -149,6 +180,16 @@ namespace
 			static constexpr int SKIP_PER_WG = 8 * MT * NTW * 64;               // half4 elements of residual scratch per workgroup
 	};
 
+	/* A workgroup barrier for hand-offs through LDS only: orders (and waits for) this wave's LDS accesses, not its global stores in flight.
+	 * __syncthreads() is s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier: in the single-plane kernel every wave reaches the layer barrier right
+	 * behind the 2 * NTW global stores of its residual values (read back only by the same lane, a layer later) and would sit there for a
+	 * store round trip, twice per residual block. */
+	__device__ __forceinline__ void lds_barrier()
+	{
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+		__builtin_amdgcn_s_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+	}
 	template<typename G>
 	__device__ __forceinline__ int plane_offset(int index, int chunk)
 	{ // byte offset of a 16-byte chunk of stored position `index` (= position + 1)
@@ -351,12 +392,159 @@ namespace
 		}
 	}
 
+	/*
+	 * The k-loop of a 3x3 convolution on column tiles (Geometry::COLT: 20x20 boards, 128 filters).
+	 *
+	 * A 20-column board has row stride 21, so a 16-position tile is not a row and conv3x3_mac_rows' trick — one fragment of an input row
+	 * feeds three output rows — has nothing to hold on to; the tap-major loop reads one 1 KB fragment per (tap, tile) for MT = 2 MFMAs,
+	 * and at 14 tiles per wave the LDS reads of a k-step take as long as its MFMAs (the kernel sat at 0.39 of the launch's MFMA peak).
+	 * With tiles that are COLUMNS (lane r = row r of column x) the neighbouring column is the same tile one position on: for a 32-channel
+	 * chunk and a row shift dy the fragment of INPUT column c is read once and multiplied by the three taps dx = -1, 0, +1 of that row
+	 * shift, accumulating into OUTPUT columns c + 1, c, c - 1.  A wave owns 10 output columns (12 input fragments per stage instead of
+	 * 30) and three ordinary tiles of rows 16..19, which take their three shifted fragments from the same stage's weights: 21 fragment
+	 * reads per stage of 78 MFMAs, against 42 per 84 before.  Lanes of a fragment are 21 positions apart: 21 r mod 16 = 5 r mod 16 is a
+	 * permutation, so the chunk swizzle (position mod 16) still spreads the 16 lanes of a read over all banks.
+	 * Weight fragments in consumption order (pack_conv_rows with the roles of dx and dy exchanged): stage = (chunk, dy), then channel
+	 * group, dx, tile.
+	 */
+	template<int F, int ROWS, int COLS>
+	__device__ __forceinline__ void conv3x3_cols_stage(const char *src, const half8 *__restrict__ wnext, int kc, int dyi, int col_base, int tail_base, int q4, int lane,
+			const half8 (&a_cur)[3][Geometry<F, ROWS, COLS>::MT], half8 (&a_next)[3][Geometry<F, ROWS, COLS>::MT],
+			floatx4 (&acc)[Geometry<F, ROWS, COLS>::MT][Geometry<F, ROWS, COLS>::NTW])
+	{
+		typedef Geometry<F, ROWS, COLS> G;
+		static_assert(G::PPR == 1 && G::CH == 16, "one position per 256-byte bank row");
+#pragma unroll
+		for (int dxi = 0; dxi < 3; dxi++)
+#pragma unroll
+			for (int i = 0; i < G::MT; i++)
+#ifdef AGX_NN_DBG_NOW /* timing experiment only (wrong results): no weight fetch */
+				a_next[dxi][i] = a_cur[dxi][i];
+#else
+				a_next[dxi][i] = wnext[(dxi * G::MT + i) * 64 + lane];
+#endif
+		const int shift = (dyi - 1) * G::S;
+		const int chunk = kc * 4 + q4;
+		constexpr int NCOL = G::COL_TILES + 2;             // input columns x0 - 1 .. x0 + COL_TILES
+		constexpr int NFRAG = NCOL + 3 * G::TAIL_TILES;     // then (tail tile, dx) pairs
+		// the order of the reads: the (tail tile, dx) fragments feed MT MFMAs each, a column's 3 * MT — dealt between the columns, every
+		// stretch of the loop has the same MFMAs per read.  slot(f) < NCOL: input column slot(f); else the pair slot(f) - NCOL
+#ifdef AGX_NN_DBG_NOLDS
+		const half8 b0_dbg = *reinterpret_cast<const half8*>(src + (col_base + shift) * (G::CH * 16) + ((chunk ^ ((col_base + shift) & 15)) * 16));
+#endif
+		auto slot = [](int f) -> int
+		{
+#if AGX_NN_COLS_INTERLEAVE
+			if (f < 2)
+				return f;
+			if (f >= 2 + 2 * 3 * G::TAIL_TILES)
+				return f - 3 * G::TAIL_TILES;
+			return ((f & 1) == 0) ? (NCOL + (f - 2) / 2) : ((f + 1) / 2);
+#else
+			return f;
+#endif
+		};
+		auto fragment = [&](int f) -> half8
+		{
+			const int k = slot(f);
+#ifdef AGX_NN_DBG_NOLDS /* timing experiment only (wrong results): one fragment read per stage */
+			if (f > 0)
+				return b0_dbg;
+#endif
+			const int index = (k < NCOL) ? (col_base + shift + k) : (tail_base + shift + ((k - NCOL) / 3) * 16 + ((k - NCOL) % 3 - 1));
+			return *reinterpret_cast<const half8*>(src + index * (G::CH * 16) + ((chunk ^ (index & 15)) * 16));
+		};
+		constexpr int AHEAD = AGX_NN_COLS_AHEAD;
+		half8 b[AHEAD];
+#pragma unroll
+		for (int u = 0; u < AHEAD - 1; u++)
+			b[u] = fragment(u);
+#pragma unroll
+		for (int f = 0; f < NFRAG; f++)
+		{
+			const int fn = f + AHEAD - 1;
+			if (fn < NFRAG)
+				b[fn % AHEAD] = fragment(fn);
+			const int k = slot(f);
+			if (k < NCOL)
+			{
+#pragma unroll
+				for (int dxi = 0; dxi < 3; dxi++)
+				{
+					const int o = k - dxi; // output column (relative to the wave's first) fed by input column k - 1 through the tap dx = dxi - 1
+					if (o >= 0 && o < G::COL_TILES)
+					{
+#pragma unroll
+						for (int i = 0; i < G::MT; i++)
+							acc[i][o] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_cur[dxi][i], b[f % AHEAD], acc[i][o], 0, 0, 0);
+					}
+				}
+			}
+			else
+			{
+				const int t = (k - NCOL) / 3, dxi = (k - NCOL) % 3;
+#pragma unroll
+				for (int i = 0; i < G::MT; i++)
+					acc[i][G::COL_TILES + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_cur[dxi][i], b[f % AHEAD], acc[i][G::COL_TILES + t], 0, 0, 0);
+			}
+#if AGX_NN_COLS_BARRIER
+			__builtin_amdgcn_sched_barrier(0); // (as in conv3x3_rows_stage: keep AHEAD - 1 requests in flight behind every turn's MFMAs)
+#endif
+		}
+	}
+	template<int F, int ROWS, int COLS, bool ZERO = true>
+	__device__ __forceinline__ void conv3x3_mac_cols(const char *src, const half8 *__restrict__ wpk, int wave, int lane,
+			floatx4 (&acc)[Geometry<F, ROWS, COLS>::MT][Geometry<F, ROWS, COLS>::NTW])
+	{
+		typedef Geometry<F, ROWS, COLS> G;
+		static_assert(G::COLT && G::CG == 4 && G::PG == 2, "column tiles: four channel groups x two position groups");
+		const int r = lane & 15;
+		const int q4 = lane >> 4;
+		const int mg = G::channel_group(wave);
+		const int pg = wave >> 2;
+		if (ZERO)
+		{
+#pragma unroll
+			for (int i = 0; i < G::MT; i++)
+#pragma unroll
+				for (int n = 0; n < G::NTW; n++)
+					acc[i][n] = floatx4 { 0.0f, 0.0f, 0.0f, 0.0f };
+		}
+		constexpr int STAGES = 3 * G::KC;               // stage = (32-channel chunk kc, row shift dy)
+		constexpr int STAGE_FRAGS = G::CG * 3 * G::MT * 64;
+		static_assert(STAGES % 2 == 0, "two stages per loop turn (static ring index)");
+		const half8 *wl = wpk + __builtin_amdgcn_readfirstlane(mg * 3 * G::MT * 64);
+		half8 a0[3][G::MT], a1[3][G::MT];
+#pragma unroll
+		for (int dxi = 0; dxi < 3; dxi++)
+#pragma unroll
+			for (int i = 0; i < G::MT; i++)
+				a0[dxi][i] = wl[(dxi * G::MT + i) * 64 + lane];
+		const int col_base = 1 + G::S + r * G::S + pg * G::COL_TILES - 1;                    // stored index of (row r, column x0 - 1)
+		const int tail_base = 1 + G::S + (G::TAIL_FIRST + pg * G::TAIL_TILES) * 16 + r;      // ... of this lane's cell in the wave's first tail tile
+#pragma unroll 1
+		for (int s = 0; s < STAGES; s += 2)
+		{
+			if (3 * s < STAGES) // (priority by remaining work, as in conv3x3_mac_rows)
+				__builtin_amdgcn_s_setprio(3);
+			else if (3 * s < 2 * STAGES)
+				__builtin_amdgcn_s_setprio(2);
+			else
+				__builtin_amdgcn_s_setprio(1);
+			conv3x3_cols_stage<F, ROWS, COLS>(src, wl + (s + 1) * STAGE_FRAGS, s / 3, s % 3, col_base, tail_base, q4, lane, a0, a1, acc);
+			conv3x3_cols_stage<F, ROWS, COLS>(src, wl + ((s + 2 < STAGES) ? (s + 2) : 0) * STAGE_FRAGS, (s + 1) / 3, (s + 1) % 3, col_base, tail_base, q4, lane, a1, a0, acc);
+		}
+		__builtin_amdgcn_s_setprio(0);
+	}
+
 	template<int F, int ROWS, int COLS, bool ZERO = true>
 	__device__ __forceinline__ void conv3x3_mac(const char *src, const half8 *__restrict__ wpk, int wave, int lane,
 			floatx4 (&acc)[Geometry<F, ROWS, COLS>::MT][Geometry<F, ROWS, COLS>::NTW])
 	{
 		if constexpr (Geometry<F, ROWS, COLS>::S == 16 && AGX_NN_ROW_STATIONARY)
 			conv3x3_mac_rows<F, ROWS, COLS, ZERO>(src, wpk, wave, lane, acc);
+		else if constexpr (Geometry<F, ROWS, COLS>::COLT)
+			conv3x3_mac_cols<F, ROWS, COLS, ZERO>(src, wpk, wave, lane, acc);
 		else
 			conv3x3_mac_taps<F, ROWS, COLS, ZERO>(src, wpk, wave, lane, acc);
 	}
@@ -392,7 +580,7 @@ namespace
 				floatx4 v = bv;
 				if (SKIP && n < my_tiles)
 				{
-					const int pos = G::S + (n0 + n) * 16 + r;
+					const int pos = G::S + G::tile_position(wave, n, r);
 					const half4 sk = *reinterpret_cast<const half4*>(dst + plane_offset<G>(pos + 1, ch / 8) + (ch % 8) * 2);
 					v[0] += static_cast<float>(sk[0]);
 					v[1] += static_cast<float>(sk[1]);
@@ -415,7 +603,7 @@ namespace
 			for (int n = 0; n < G::NTW; n++)
 				if (n < my_tiles)
 				{
-					const int pos = G::S + (n0 + n) * 16 + r;
+					const int pos = G::S + G::tile_position(wave, n, r);
 					const int x = pos % G::S;
 					const int y = pos / G::S - 1;
 					const bool valid = (x < COLS) && (y < ROWS);
@@ -461,7 +649,7 @@ namespace
 	 */
 	template<int F, int ROWS, int COLS, int MODE>
 	__device__ __forceinline__ void conv3x3_inplace(char *plane, const half8 *__restrict__ wpk, const float *__restrict__ bias, half4 *skip,
-			const float *__restrict__ wp2, float *ppart, int wave, int lane)
+			const float *__restrict__ wp2, float *ppart, int wave, int lane AGX_NN_STAMP_PARAM)
 	{
 		typedef Geometry<F, ROWS, COLS> G;
 		const int r = lane & 15;
@@ -470,7 +658,40 @@ namespace
 		const int n0 = G::first_tile(wave);
 		const int my_tiles = G::tile_count(wave);
 		floatx4 acc[G::MT][G::NTW];
-		conv3x3_mac<F, ROWS, COLS>(plane, wpk, wave, lane, acc);
+		half4 *my_skip = skip + (wave * G::MT * G::NTW) * 64 + lane;
+		if (MODE == 0 || MODE == 1)
+		{ // The accumulators START from bias (+ the residual input, fetched from the workgroup's scratch): requested here, the 2 * NTW loads of a
+		  // lane are in flight together behind the layer's first weight fetch.  In the epilogue — where nothing is left to hide a global
+		  // round trip behind — they were 36 % of a 20x20 board's time (in-kernel stamps).
+#pragma unroll
+			for (int i = 0; i < G::MT; i++)
+			{
+				const int ch = (mg * G::MT + i) * 16 + 4 * q4;
+				const floatx4 bv = *reinterpret_cast<const floatx4*>(bias + ch);
+#pragma unroll
+				for (int n = 0; n < G::NTW; n++)
+				{
+					floatx4 v = bv;
+					if (MODE == 1)
+					{
+						const half4 sk = my_skip[(i * G::NTW + n) * 64];
+						v[0] += static_cast<float>(sk[0]);
+						v[1] += static_cast<float>(sk[1]);
+						v[2] += static_cast<float>(sk[2]);
+						v[3] += static_cast<float>(sk[3]);
+					}
+					acc[i][n] = v;
+				}
+			}
+			AGX_NN_MARK(2);
+			conv3x3_mac<F, ROWS, COLS, false>(plane, wpk, wave, lane, acc);
+		}
+		else
+		{
+			AGX_NN_MARK(2);
+			conv3x3_mac<F, ROWS, COLS>(plane, wpk, wave, lane, acc);
+		}
+		AGX_NN_MARK(3);
 
 		if (MODE == 3)
 		{
@@ -518,7 +739,7 @@ namespace
 						for (int n = 0; n < G::NTW; n++)
 							if (n < my_tiles)
 							{
-								float *dst = ppart + o * (G::NT * 16) + (n0 + n) * 16 + r;
+								float *dst = ppart + o * (G::NT * 16) + G::tile_position(wave, n, r);
 								*dst = (group == 0) ? part[o][n] : (*dst + part[o][n]);
 							}
 				}
@@ -556,34 +777,32 @@ namespace
 				s += __shfl_xor(s, 16);
 				s += __shfl_xor(s, 32);
 				if (q4 == 0 && n < my_tiles)
-					ppart[mg * (G::NT * 16) + (n0 + n) * 16 + r] = s;
+					ppart[mg * (G::NT * 16) + G::tile_position(wave, n, r)] = s;
 			}
 			return;
 		}
 
-		half4 *my_skip = skip + (wave * G::MT * G::NTW) * 64 + lane;
+		// The cell masks and LDS addresses below depend on the lane only, not on the layer or the board: left alone the compiler computes all
+		// 2 * MT * NTW of them once per kernel and keeps them in scratch — a reload (a global round trip, behind every store in flight) in
+		// front of every LDS write of every layer.  An opaque copy of the lane's row makes them this layer's own few VALU instructions.
+		int r_mask = r;
+		asm volatile("" : "+v"(r_mask));
 		half4 out[G::MT][G::NTW];
 #pragma unroll
 		for (int i = 0; i < G::MT; i++)
 		{
-			const int ch = (mg * G::MT + i) * 16 + 4 * q4;
-			const floatx4 bv = *reinterpret_cast<const floatx4*>(bias + ch);
 #pragma unroll
 			for (int n = 0; n < G::NTW; n++)
 			{
-				const int pos = G::S + (n0 + n) * 16 + r;
-				const int x = pos % G::S;
-				const int y = pos / G::S - 1;
-				const bool valid = (x < COLS) && (y < ROWS) && (n < my_tiles);
-				floatx4 v = acc[i][n] + bv;
-				if (MODE == 1)
-				{
-					const half4 sk = my_skip[(i * G::NTW + n) * 64];
-					v[0] += static_cast<float>(sk[0]);
-					v[1] += static_cast<float>(sk[1]);
-					v[2] += static_cast<float>(sk[2]);
-					v[3] += static_cast<float>(sk[3]);
+				bool valid = (n < my_tiles);
+				if (!(G::COLT && n < G::COL_TILES))
+				{ // (a column tile holds 16 cells of the board: nothing to mask)
+					const int pos = G::S + G::tile_position(wave, n, r_mask);
+					const int x = pos % G::S;
+					const int y = pos / G::S - 1;
+					valid = valid && (x < COLS) && (y < ROWS);
 				}
+				const floatx4 v = acc[i][n];
 				half4 o;
 				o[0] = static_cast<half_t>(valid ? fmaxf(v[0], 0.0f) : 0.0f);
 				o[1] = static_cast<half_t>(valid ? fmaxf(v[1], 0.0f) : 0.0f);
@@ -594,7 +813,11 @@ namespace
 					my_skip[(i * G::NTW + n) * 64] = o;
 			}
 		}
-		__syncthreads(); // every wave has consumed the plane: it can be overwritten now
+		AGX_NN_MARK(4);
+		lds_barrier(); // every wave has consumed the plane: it can be overwritten now
+		AGX_NN_MARK(5);
+		int r_write = r;
+		asm volatile("" : "+v"(r_write));
 #pragma unroll
 		for (int i = 0; i < G::MT; i++)
 		{
@@ -603,10 +826,11 @@ namespace
 			for (int n = 0; n < G::NTW; n++)
 				if (n < my_tiles)
 				{
-					const int pos = G::S + (n0 + n) * 16 + r;
+					const int pos = G::S + G::tile_position(wave, n, r_write);
 					*reinterpret_cast<half4*>(plane + plane_offset<G>(pos + 1, ch / 8) + (ch % 8) * 2) = out[i][n];
 				}
 		}
+		AGX_NN_MARK(4);
 	}
 
 	/*
@@ -618,7 +842,9 @@ namespace
 			half4 *skip, int wave, int lane)
 	{
 		typedef Geometry<F, ROWS, COLS> G;
-		const int r = lane & 15;
+		int r = lane & 15;
+		if (INPLACE)
+			asm volatile("" : "+v"(r)); // (per-lane cell indices and addresses are recomputed per board instead of living in scratch: conv3x3_inplace)
 		const int q4 = lane >> 4;
 		const int mg = G::channel_group(wave);   // output channels [mg * 16 * MT, (mg + 1) * 16 * MT)
 		const int n0 = G::first_tile(wave);
@@ -697,7 +923,7 @@ namespace
 	#pragma unroll
 			for (int n = 0; n < G::NTW; n++)
 			{
-				const int pos = G::S + (n0 + n) * 16 + r;
+				const int pos = G::S + G::tile_position(wave, n, r);
 				const int x = pos % G::S;
 				const int y = pos / G::S - 1;
 				q0[n] = (y + 2) * G::S5 + (x + 2);
@@ -751,7 +977,7 @@ namespace
 			for (int n = 0; n < G::NTW; n++)
 				if (n < my_tiles)
 				{
-					const int pos = G::S + (n0 + n) * 16 + r;
+					const int pos = G::S + G::tile_position(wave, n, r);
 					const int x = pos % G::S;
 					const int y = pos / G::S - 1;
 					const bool valid = (x < COLS) && (y < ROWS);
@@ -884,11 +1110,11 @@ namespace
 			{
 				if (INPLACE)
 				{
-					conv3x3_inplace<F, ROWS, COLS, 0>(plane_x, p.w_tower + (2 * blk) * layer_halves8, p.bias + (1 + 2 * blk) * F, skip, nullptr, nullptr, wave, lane);
-					__syncthreads();
+					conv3x3_inplace<F, ROWS, COLS, 0>(plane_x, p.w_tower + (2 * blk) * layer_halves8, p.bias + (1 + 2 * blk) * F, skip, nullptr, nullptr, wave, lane AGX_NN_STAMP_ARG);
+					lds_barrier();
 					conv3x3_inplace<F, ROWS, COLS, 1>(plane_x, p.w_tower + (2 * blk + 1) * layer_halves8, p.bias + (2 + 2 * blk) * F, skip, nullptr, nullptr, wave,
-							lane);
-					__syncthreads();
+							lane AGX_NN_STAMP_ARG);
+					lds_barrier();
 				}
 				else
 				{
@@ -938,7 +1164,7 @@ namespace
 			// ---- policy head: conv3x3 + ReLU into plane_t ----
 			if (INPLACE)
 				conv3x3_inplace<F, ROWS, COLS, 2>(plane_x, p.w_tower + (2 * p.blocks) * layer_halves8, p.bias + (1 + 2 * p.blocks) * F, nullptr, s_wp2, ppart,
-						wave, lane);
+						wave, lane AGX_NN_STAMP_ARG);
 			else
 				conv3x3<F, ROWS, COLS, false>(plane_x, plane_t, p.w_tower + (2 * p.blocks) * layer_halves8, p.bias + (1 + 2 * p.blocks) * F, wave, lane AGX_NN_STAMP_ARG);
 			__syncthreads();
@@ -987,7 +1213,7 @@ namespace
 				const float *bq1 = p.bias + (2 + 2 * p.blocks) * F;
 				__syncthreads(); // the policy head is done with plane_t / the partial-sum buffers
 				if (INPLACE)
-					conv3x3_inplace<F, ROWS, COLS, 3>(plane_x, wq1, bq1, nullptr, s_wq2, qpart, wave, lane);
+					conv3x3_inplace<F, ROWS, COLS, 3>(plane_x, wq1, bq1, nullptr, s_wq2, qpart, wave, lane AGX_NN_STAMP_ARG);
 				else
 				{
 					conv3x3<F, ROWS, COLS, false, true>(plane_x, plane_t, wq1, bq1, wave, lane AGX_NN_STAMP_ARG);
@@ -1132,8 +1358,8 @@ namespace
 	 * The same fragments in the order the row-stationary k-loop consumes them (conv3x3_mac_rows): [kc][dx][channel group][dy][tile][lane][8],
 	 * so the 3 * MT fragments a wave needs for one stage are consecutive.  3x3 kernels only; MT = cout / 64 tiles per channel group.
 	 */
-	void pack_conv_rows(const float *w, int cin, int cout, std::vector<half_t> &dst)
-	{
+	void pack_conv_rows(const float *w, int cin, int cout, std::vector<half_t> &dst, bool by_row_shift = false)
+	{ // by_row_shift: the column-tile loop (conv3x3_mac_cols) — stage = (chunk, dy), inside it dx: the same order with the roles exchanged
 		const int kcs = cin / 32, mt_per_group = cout / 64;
 		const size_t base = dst.size();
 		dst.resize(base + static_cast<size_t>(9) * kcs * (cout / 16) * 512);
@@ -1147,7 +1373,7 @@ namespace
 							for (int lane = 0; lane < 64; lane++)
 								for (int j = 0; j < 8; j++)
 								{
-									const int t = dy * 3 + dx;
+									const int t = by_row_shift ? (dx * 3 + dy) : (dy * 3 + dx); // (loop variable "dx" is the stage's shift)
 									const int oc = (mg * mt_per_group + i) * 16 + (lane & 15);
 									const int ic = kc * 32 + 8 * (lane >> 4) + j;
 									out[(frag * 64 + lane) * 8 + j] = static_cast<half_t>(w[(static_cast<size_t>(t) * cin + ic) * cout + oc]);
@@ -1278,10 +1504,14 @@ int agx_net_load_weights(AgxNet *net, const float *h_blob, size_t n_floats)
 	ptr += F;
 	// 15-column boards (row stride 16 = one MFMA tile) run the row-stationary k-loop, which reads the fragments in its own order
 	const bool row_order = (net->desc.cols + 1 == 16) && (AGX_NN_ROW_STATIONARY != 0);
+	// 20x20 boards with 128 filters run the column-tile k-loop (Geometry::COLT)
+	const bool column_order = (net->desc.rows == 20 && net->desc.cols == 20 && F == 128) && (AGX_NN_COLUMN_TILES != 0);
 	auto pack3x3 = [&](const float *w)
 	{
 		if (row_order)
 			pack_conv_rows(w, F, F, w_tower);
+		else if (column_order)
+			pack_conv_rows(w, F, F, w_tower, true);
 		else
 			pack_conv(w, 9, F, F, w_tower);
 	};
