@@ -51,6 +51,12 @@
 #ifndef AGX_NN_COLS_INTERLEAVE
 #define AGX_NN_COLS_INTERLEAVE 0
 #endif
+#ifndef AGX_NN_PAIR_BALANCE
+#define AGX_NN_PAIR_BALANCE 0 // 1: the two waves of a SIMD steer their priorities by each other's progress (measured: balances them, gains nothing)
+#endif
+#ifndef AGX_NN_WEIGHT_RING
+#define AGX_NN_WEIGHT_RING 2 // stages of weight fragments a wave holds in the row / column loops: 2 = fetched one stage ahead, 3 = two
+#endif
 #ifndef AGX_NN_COLS_BARRIER
 #define AGX_NN_COLS_BARRIER 1
 #endif
@@ -190,6 +196,49 @@ namespace
 		__builtin_amdgcn_s_barrier();
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 	}
+	/*
+	 * The two waves of a SIMD (wave w and w + 4: the same channel group, the two position groups) share its MFMA pipe, and the hardware
+	 * issues oldest-first: left alone the older wave runs ahead, reaches the layer barrier early and the younger one finishes ALONE — a
+	 * lone wave hides none of its LDS / L2 latencies.  In-kernel stamps: the older wave waits 9–12 % of a board's time at layer barriers.
+	 * Each wave publishes how far it is (a tick per loop turn, across layers and boards) and reads its partner's tick one turn later
+	 * (the read is requested at the end of a turn and consumed at the start of the next: it has come back with the turn's last
+	 * fragments); the wave that is ahead lowers its priority, the one behind raises it.
+	 */
+	__device__ __forceinline__ int* pair_progress()
+	{ // one word per wave of the workgroup; zeroed by the kernel before its first board
+		__shared__ int progress[8];
+		return progress;
+	}
+	struct PairBalance
+	{
+			int *mine;
+			const int *partner;
+			int tick, seen;
+			__device__ __forceinline__ PairBalance(int *progress, int wave) :
+					mine(progress + wave), partner(progress + (wave ^ 4)), tick(progress[wave]), seen(progress[wave ^ 4])
+			{
+			}
+			__device__ __forceinline__ void turn()
+			{
+#if AGX_NN_PAIR_BALANCE
+				const int ahead = __builtin_amdgcn_readfirstlane(tick - seen); // wave-uniform: a scalar compare and branch
+				if (ahead > 0)
+					__builtin_amdgcn_s_setprio(1);
+				else if (ahead == 0)
+					__builtin_amdgcn_s_setprio(2);
+				else
+					__builtin_amdgcn_s_setprio(3);
+#endif
+			}
+			__device__ __forceinline__ void done()
+			{
+#if AGX_NN_PAIR_BALANCE
+				tick++;
+				*const_cast<volatile int*>(mine) = tick;
+				seen = *const_cast<const volatile int*>(partner);
+#endif
+			}
+	};
 	template<typename G>
 	__device__ __forceinline__ int plane_offset(int index, int chunk)
 	{ // byte offset of a 16-byte chunk of stored position `index` (= position + 1)
@@ -290,6 +339,34 @@ namespace
 			for (int i = 0; i < G::MT; i++)
 				a0[dyi][i] = wl[(dyi * G::MT + i) * 64 + lane];
 		const int index_base = 1 + G::S + n0 * 16 + r; // stored index of this lane's position in the wave's first output row
+		PairBalance balance(pair_progress(), wave);
+#if AGX_NN_WEIGHT_RING == 3
+		// Three sets of weight fragments: a stage's fragments are requested TWO stages before their use.  One stage of MFMAs (~0.7 us for the
+		// two waves of a SIMD) is about an L2 round trip under load — fetched one stage ahead every stage began by waiting for its weights.
+		static_assert(STAGES % 3 == 0, "three stages per loop turn (static ring index)");
+		half8 a2[3][G::MT];
+#pragma unroll
+		for (int dyi = 0; dyi < 3; dyi++)
+#pragma unroll
+			for (int i = 0; i < G::MT; i++)
+				a1[dyi][i] = wl[STAGE_FRAGS + (dyi * G::MT + i) * 64 + lane];
+#pragma unroll 1
+		for (int s = 0; s < STAGES; s += 3)
+		{
+			if (3 * s < STAGES)
+				__builtin_amdgcn_s_setprio(3);
+			else if (3 * s < 2 * STAGES)
+				__builtin_amdgcn_s_setprio(2);
+			else
+				__builtin_amdgcn_s_setprio(1);
+			// (past the layer's last stage the requests wrap around to its first ones instead of branching: see below)
+			conv3x3_rows_stage<F, ROWS, COLS>(src, wl + ((s + 2) % STAGES) * STAGE_FRAGS, s / 3, s % 3, index_base, q4, my_tiles, lane, a0, a2, acc);
+			conv3x3_rows_stage<F, ROWS, COLS>(src, wl + ((s + 3) % STAGES) * STAGE_FRAGS, (s + 1) / 3, (s + 1) % 3, index_base, q4, my_tiles, lane, a1, a0, acc);
+			conv3x3_rows_stage<F, ROWS, COLS>(src, wl + ((s + 4) % STAGES) * STAGE_FRAGS, (s + 2) / 3, (s + 2) % 3, index_base, q4, my_tiles, lane, a2, a1, acc);
+		}
+		__builtin_amdgcn_s_setprio(0);
+		return;
+#endif
 #pragma unroll 1
 		for (int s = 0; s < STAGES; s += 2)
 		{
@@ -297,17 +374,22 @@ namespace
 			// the layer barrier while the younger one finishes ALONE (a lone wave hides none of its LDS / L2 latencies: measured 2.1 x its
 			// MFMA time).  Priority by remaining work — the wave that is behind goes first — keeps the pair together to the end.
 			// (a static bias towards the younger wave of a pair was measured worse)
+#if AGX_NN_PAIR_BALANCE
+			balance.turn();
+#else
 			if (3 * s < STAGES)
 				__builtin_amdgcn_s_setprio(3);
 			else if (3 * s < 2 * STAGES)
 				__builtin_amdgcn_s_setprio(2);
 			else
 				__builtin_amdgcn_s_setprio(1);
+#endif
 			conv3x3_rows_stage<F, ROWS, COLS>(src, wl + (s + 1) * STAGE_FRAGS, s / 3, s % 3, index_base, q4, my_tiles, lane, a0, a1, acc);
 			// the last turn fetches stage 0 again instead of branching around the fetch: with a conditional fetch the wait for THIS stage's
 			// fragments has to assume the newer loads were never issued (vmcnt(0)), which serialises fetch and MFMAs in every turn
 			conv3x3_rows_stage<F, ROWS, COLS>(src, wl + ((s + 2 < STAGES) ? (s + 2) : 0) * STAGE_FRAGS, (s + 1) / 3, (s + 1) % 3, index_base, q4, my_tiles, lane, a1,
 					a0, acc);
+			balance.done();
 		}
 		__builtin_amdgcn_s_setprio(0);
 	}
@@ -522,17 +604,47 @@ namespace
 				a0[dxi][i] = wl[(dxi * G::MT + i) * 64 + lane];
 		const int col_base = 1 + G::S + r * G::S + pg * G::COL_TILES - 1;                    // stored index of (row r, column x0 - 1)
 		const int tail_base = 1 + G::S + (G::TAIL_FIRST + pg * G::TAIL_TILES) * 16 + r;      // ... of this lane's cell in the wave's first tail tile
+		PairBalance balance(pair_progress(), wave);
+#if AGX_NN_WEIGHT_RING == 3
+		static_assert(STAGES % 3 == 0, "three stages per loop turn (static ring index)");
+		half8 a2[3][G::MT]; // (weights requested two stages ahead: conv3x3_mac_rows)
+#pragma unroll
+		for (int dxi = 0; dxi < 3; dxi++)
+#pragma unroll
+			for (int i = 0; i < G::MT; i++)
+				a1[dxi][i] = wl[STAGE_FRAGS + (dxi * G::MT + i) * 64 + lane];
 #pragma unroll 1
-		for (int s = 0; s < STAGES; s += 2)
+		for (int s = 0; s < STAGES; s += 3)
 		{
-			if (3 * s < STAGES) // (priority by remaining work, as in conv3x3_mac_rows)
+			if (3 * s < STAGES)
 				__builtin_amdgcn_s_setprio(3);
 			else if (3 * s < 2 * STAGES)
 				__builtin_amdgcn_s_setprio(2);
 			else
 				__builtin_amdgcn_s_setprio(1);
+			conv3x3_cols_stage<F, ROWS, COLS>(src, wl + ((s + 2) % STAGES) * STAGE_FRAGS, s / 3, s % 3, col_base, tail_base, q4, lane, a0, a2, acc);
+			conv3x3_cols_stage<F, ROWS, COLS>(src, wl + ((s + 3) % STAGES) * STAGE_FRAGS, (s + 1) / 3, (s + 1) % 3, col_base, tail_base, q4, lane, a1, a0, acc);
+			conv3x3_cols_stage<F, ROWS, COLS>(src, wl + ((s + 4) % STAGES) * STAGE_FRAGS, (s + 2) / 3, (s + 2) % 3, col_base, tail_base, q4, lane, a2, a1, acc);
+		}
+		__builtin_amdgcn_s_setprio(0);
+		return;
+#endif
+#pragma unroll 1
+		for (int s = 0; s < STAGES; s += 2)
+		{
+#if AGX_NN_PAIR_BALANCE
+			balance.turn();
+#else
+			if (3 * s < STAGES) // (priority by remaining work)
+				__builtin_amdgcn_s_setprio(3);
+			else if (3 * s < 2 * STAGES)
+				__builtin_amdgcn_s_setprio(2);
+			else
+				__builtin_amdgcn_s_setprio(1);
+#endif
 			conv3x3_cols_stage<F, ROWS, COLS>(src, wl + (s + 1) * STAGE_FRAGS, s / 3, s % 3, col_base, tail_base, q4, lane, a0, a1, acc);
 			conv3x3_cols_stage<F, ROWS, COLS>(src, wl + ((s + 2 < STAGES) ? (s + 2) : 0) * STAGE_FRAGS, (s + 1) / 3, (s + 1) % 3, col_base, tail_base, q4, lane, a1, a0, acc);
+			balance.done();
 		}
 		__builtin_amdgcn_s_setprio(0);
 	}
@@ -1064,6 +1176,8 @@ namespace
 			for (int i = tid; i < F * 4; i += G::THREADS)
 				s_wq2[i] = p.wq2[i];
 
+		if (tid < 8)
+			pair_progress()[tid] = 0;
 		const int batch = (p.count_ptr != nullptr) ? min(*p.count_ptr, p.batch) : p.batch;
 #ifdef AGX_NN_PROFILE
 		NnStamp stamp(wave, lane);

@@ -104,3 +104,62 @@ def test_policy_temperature_of_the_root_priors(lib, temperature):
         want = p1.astype(np.float64) ** (1.0 / temperature)
         want /= want.sum()
         assert np.allclose(pt, want, rtol=2e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("rules,threads,batch", [(0, 1, 8), (1, 3, 4)])
+def test_double_buffered_schedule_is_the_serial_loop_shifted_by_one_batch(lib, rules, threads, batch):
+    """SearchThread::asynchronous_run (player/SearchThread.cpp:148-180; Search::useBuffer / switchBuffer / cleanup, Search.cpp:233-252) in the
+    oracle: the first iteration of a search expands nothing, every later one expands the batch selected two iterations earlier — so while a
+    search lasts, two batches hold virtual losses at select time and the tree's visit count lags the serial loop's by exactly one batch;
+    a move drops the batch still in flight (the network evaluated it: positions scheduled > nodes backed up); the game ends like any game.
+    (The device's double-buffered pool is compared with this schedule leaf by leaf in tests/test_engine_gpu.py.)"""
+    sims = 120
+    cfg = ol.default_search_config(max_batch_size=batch, max_simulations=sims, table_entries=1 << 14)
+    op = np.zeros(64, np.uint16)
+    k = lib.ago_prepare_opening(rules, N, N, 181, ol.ptr(op))
+    games = []
+    for _ in range(2):
+        h = lib.ago_game_create_ex(rules, N, N, 0, ctypes.byref(cfg))
+        lib.ago_game_set_search_threads(h, threads)
+        lib.ago_game_set_serial(h, 0)
+        lib.ago_game_begin(h, ol.ptr(op), k)
+        games.append(h)
+    a, s = games   # asynchronous / serial
+    # the first search of both, iteration by iteration, until the serial one moves
+    scheduled_async, first = [], True
+    for it in range(400):
+        f = np.zeros((threads * batch, HW), np.uint32)
+        c = lib.ago_game_async_step(a, ol.ptr(f), threads * batch)
+        pol, val = _fake(lib, f, c)
+        lib.ago_game_async_provide(a, ol.ptr(pol), ol.ptr(val))
+        scheduled_async.append(c)
+        n_a, visits_a, _, _ = _root(lib, a)
+        if lib.ago_game_num_records(a) > 0:
+            break
+        if it == 0:
+            assert n_a == 0 and visits_a == 0 and c == threads    # nothing expanded yet; every thread sent the root itself to the network
+        if it == 1:
+            assert visits_a == 0 and c == threads                 # buffer 1 selected the (still unexpanded) root too: one leaf per thread
+    assert lib.ago_game_num_records(a) == 1 and it > 3
+    # the same game through the serial loop: its first move comes from a tree with at most one batch per thread less of lag
+    for it_s in range(400):
+        f = np.zeros((threads * batch, HW), np.uint32)
+        c = lib.ago_game_step_select(s, ol.ptr(f), threads * batch)
+        pol, val = _fake(lib, f, c)
+        if lib.ago_game_step_expand(s, ol.ptr(pol), ol.ptr(val)):
+            break
+    assert lib.ago_game_num_records(s) == 1
+    assert it >= it_s + 1                                         # the double-buffered loop needs at least one more iteration: its expansions lag
+    # play the asynchronous game to its end: every search stops by the same rule, the game ends, statistics stay consistent
+    for _ in range(40000):
+        if lib.ago_game_outcome(a) != 0:
+            break
+        f = np.zeros((threads * batch, HW), np.uint32)
+        c = lib.ago_game_async_step(a, ol.ptr(f), threads * batch)
+        pol, val = _fake(lib, f, c)
+        lib.ago_game_async_provide(a, ol.ptr(pol), ol.ptr(val))
+    assert lib.ago_game_outcome(a) in (1, 2, 3) and lib.ago_game_num_records(a) >= 5
+    st = np.zeros(16, np.uint64)
+    lib.ago_game_stats(a, ol.ptr(st))
+    for h in games:
+        lib.ago_game_destroy(h)
