@@ -43,7 +43,7 @@ import bench  # noqa: E402
 slices = int(os.environ.get("AGX_PROFILE_SLICES", "4"))
 summary = {"_comment": __doc__, "source_hash": bench.source_hash(), "command": "python3 bench.py --steps 40 --warmup 30 --age-steps 0 --no-cpu-baseline", "slices": slices,
            "per_kernel_raw": per}
-tower = next((k for k in per if k.startswith("nn_tower_kernel<128, 15, 15")), None)
+tower = next((k for k in per if k.startswith("nn_tower_kernel<128, 15, 15")), None) or next((k for k in per if k.startswith("nn_tower_kernel<")), None)  # (C4: <128, 20, 20, ...>)
 if tower:
     t = per[tower]
     if "FETCH_SIZE_per_launch" in t and "WRITE_SIZE_per_launch" in t:
@@ -54,7 +54,8 @@ if tower:
         summary["nn_tower_shader_clock_mhz"] = t["shader_clock_mhz"]
     if "SQ_LDS_BANK_CONFLICT_per_launch" in t and t.get("SQ_LDS_IDX_ACTIVE_per_launch"):
         summary["nn_tower_lds_bank_conflict_fraction"] = t["SQ_LDS_BANK_CONFLICT_per_launch"] / t["SQ_LDS_IDX_ACTIVE_per_launch"]
-solve = next((k for k in per if k.startswith("k_search_spec<false, 15")), None) or next((k for k in per if k.startswith("k_solve<false, 15")), None)
+solve = (next((k for k in per if k.startswith("k_search_spec<false, 15")), None) or next((k for k in per if k.startswith("k_solve<false, 15")), None)
+         or next((k for k in per if k.startswith("k_search_spec<")), None) or next((k for k in per if k.startswith("k_solve<")), None))
 summary["search_kernel"] = solve
 if solve and "SQ_WAVE_CYCLES_per_launch" in per[solve]:
     t = per[solve]
