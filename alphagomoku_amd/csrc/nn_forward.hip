@@ -358,7 +358,9 @@ namespace
 			for (int i = 0; i < G::MT; i++)
 				a0[dyi][i] = wl[(dyi * G::MT + i) * 64 + lane];
 		const int index_base = 1 + G::S + n0 * 16 + r; // stored index of this lane's position in the wave's first output row
+#if AGX_NN_PAIR_BALANCE
 		PairBalance balance(pair_progress(), wave);
+#endif
 #if AGX_NN_WEIGHT_RING == 3
 		// Three sets of weight fragments: a stage's fragments are requested TWO stages before their use.  One stage of MFMAs (~0.7 us for the
 		// two waves of a SIMD) is about an L2 round trip under load — fetched one stage ahead every stage began by waiting for its weights.
@@ -408,7 +410,9 @@ namespace
 			// fragments has to assume the newer loads were never issued (vmcnt(0)), which serialises fetch and MFMAs in every turn
 			conv3x3_rows_stage<F, ROWS, COLS>(src, wl + ((s + 2 < STAGES) ? (s + 2) : 0) * STAGE_FRAGS, (s + 1) / 3, (s + 1) % 3, index_base, q4, my_tiles, lane, a1,
 					a0, acc);
+#if AGX_NN_PAIR_BALANCE
 			balance.done();
+#endif
 		}
 		__builtin_amdgcn_s_setprio(0);
 	}
@@ -623,7 +627,9 @@ namespace
 				a0[dxi][i] = wl[(dxi * G::MT + i) * 64 + lane];
 		const int col_base = 1 + G::S + r * G::S + pg * G::COL_TILES - 1;                    // stored index of (row r, column x0 - 1)
 		const int tail_base = 1 + G::S + (G::TAIL_FIRST + pg * G::TAIL_TILES) * 16 + r;      // ... of this lane's cell in the wave's first tail tile
+#if AGX_NN_PAIR_BALANCE
 		PairBalance balance(pair_progress(), wave);
+#endif
 #if AGX_NN_WEIGHT_RING == 3
 		static_assert(STAGES % 3 == 0, "three stages per loop turn (static ring index)");
 		half8 a2[3][G::MT]; // (weights requested two stages ahead: conv3x3_mac_rows)
@@ -663,7 +669,9 @@ namespace
 #endif
 			conv3x3_cols_stage<F, ROWS, COLS>(src, wl + (s + 1) * STAGE_FRAGS, s / 3, s % 3, col_base, tail_base, q4, lane, a0, a1, acc);
 			conv3x3_cols_stage<F, ROWS, COLS>(src, wl + ((s + 2 < STAGES) ? (s + 2) : 0) * STAGE_FRAGS, (s + 1) / 3, (s + 1) % 3, col_base, tail_base, q4, lane, a1, a0, acc);
+#if AGX_NN_PAIR_BALANCE
 			balance.done();
+#endif
 		}
 		__builtin_amdgcn_s_setprio(0);
 	}
@@ -1195,8 +1203,10 @@ namespace
 			for (int i = tid; i < F * 4; i += G::THREADS)
 				s_wq2[i] = p.wq2[i];
 
+#if AGX_NN_PAIR_BALANCE
 		if (tid < 8)
 			pair_progress()[tid] = 0;
+#endif
 		const int batch = (p.count_ptr != nullptr) ? min(*p.count_ptr, p.batch) : p.batch;
 #ifdef AGX_NN_PROFILE
 		NnStamp stamp(wave, lane);

@@ -105,9 +105,10 @@ def main():
     ap.add_argument("--rules", type=int, default=0)
     ap.add_argument("--action-values", type=int, default=0, help="1: ResnetPVQ network (extra action-values head feeding the edge Q)")
     ap.add_argument("--table-entries", type=int, default=4 * 1024 * 1024)
-    ap.add_argument("--yield-fraction", type=float, default=0.85,
+    ap.add_argument("--yield-fraction", type=float, default=0.6,
                     help="straggler cut-off of the search launch: once this fraction of its games is done, a game whose batch still needs a serial re-run\n"
-                         "(speculative solver) or another serial solve sits this step out (0 = never)")
+                         "(speculative solver) or another serial solve sits this step out (0 = never).  Pacing only, the games are the same; measured on\n"
+                         "one box (profiles/r03_sweep_yield_fraction.txt): 0.3 785 k, 0.5 796 k, 0.6 796 k, 0.7 790 k, 0.8 765 k, 0.85 752 k, 0.9 744 k")
     ap.add_argument("--slices", type=int, default=4,
                     help="the pool stepped as this many slices on streams that own disjoint blocks of the chip's compute units (1 = one lock-step pool)")
     ap.add_argument("--speculative", type=int, default=1,

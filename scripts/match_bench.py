@@ -20,7 +20,7 @@ def main():
     ap.add_argument("--sims", type=int, default=400)
     ap.add_argument("--blocks", type=int, default=6)
     ap.add_argument("--filters", type=int, default=128)
-    ap.add_argument("--yield-fraction", type=float, default=0.85)
+    ap.add_argument("--yield-fraction", type=float, default=0.6)
     ap.add_argument("--speculative", type=int, default=1, help="the leaves of a batch solved in parallel (AgxEngineConfig.speculative_solver)")
     ap.add_argument("--slices", type=int, default=4)
     args = ap.parse_args()
