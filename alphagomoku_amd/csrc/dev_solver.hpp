@@ -188,13 +188,16 @@ namespace agx
 				// the select stage of the fused kernel parks its node-cache keys in the (then idle) action stack + frames, which are
 				// contiguous, its compressed board in `lines` and its board in `board`
 				static constexpr int SELECT_KEY_BYTES = 3 * (1 + HW) * 8;
-				static constexpr int ACT_LDS = (N <= 15) ? 1024 : 2112;
+				// (round 3, late: 20x20 had 2112 entries + 42 frames only to give the select stage's keys room in act + frames — 20.5 KB per wave,
+				// 7 waves per compute unit; the keys now run on over ptype / threat / items, which a select does not use either: 16.4 KB, 10 waves)
+				static constexpr int ACT_LDS = 1024;
+				static constexpr int FRAMES = (N <= 15) ? 42 : 34; // alpha-beta frames kept in LDS (LDS_FRAMES at most); deeper ones live in HBM
 				__device__ static constexpr int list_cap(int t) { return (t == 2) ? CAP2 : CAP; }
 				__device__ static constexpr int list_off(int t) { return (t == 2) ? 0 : CAP2 + (t - 3) * CAP; }
 
 				u64 lines[6 * N];
 				uint32_t act[ACT_LDS];   // head of the action stack (the tail, if ever needed, spills to HBM)
-				Frame frames[LDS_FRAMES];
+				Frame frames[FRAMES];
 				uint8_t ptype[HW][8]; // [cell][0-3 cross dirs, 4-7 circle dirs]
 #if AGX_LUT_LDS
 				uint8_t threat_lut[4096]; // ThreatTable in LDS: cross | circle << 4 for the 4 x 3-bit pattern index (loaded per launch)
@@ -258,7 +261,7 @@ namespace agx
 		template<class SH>
 		__device__ __forceinline__ Frame frame_get(const SH &sh, int level)
 		{
-			if (__builtin_expect(level < LDS_FRAMES, 1))
+			if (__builtin_expect(level < SH::FRAMES, 1))
 				return sh.frames[level];
 			u64 w[4];
 			const Frame *p = sh.spill_frames + level;
@@ -271,7 +274,7 @@ namespace agx
 		template<class SH>
 		__device__ __forceinline__ void frame_set(SH &sh, int level, const Frame &f)
 		{
-			if (__builtin_expect(level < LDS_FRAMES, 1))
+			if (__builtin_expect(level < SH::FRAMES, 1))
 				sh.frames[level] = f;
 			else
 			{

@@ -477,8 +477,11 @@ namespace
 		const int g = E.g0 + blockIdx.x, lane = threadIdx.x;
 		if (FUSED)
 		{
-			static_assert(offsetof(SH, act) % 8 == 0 && offsetof(SH, frames) == offsetof(SH, act) + sizeof(sh.act), "select-stage keys: 64-bit words over act + frames");
-			static_assert(sizeof(sh.act) + sizeof(sh.frames) >= SH::SELECT_KEY_BYTES && sizeof(sh.lines) >= BWORDS * sizeof(u64), "select-stage LDS must fit");
+			static_assert(offsetof(SH, act) % 8 == 0 && offsetof(SH, frames) == offsetof(SH, act) + sizeof(sh.act) && offsetof(SH, ptype) == offsetof(SH, frames) + sizeof(sh.frames)
+				&& offsetof(SH, threat) == offsetof(SH, ptype) + sizeof(sh.ptype) && offsetof(SH, items) == offsetof(SH, threat) + sizeof(sh.threat),
+				"select-stage keys: 64-bit words over act + frames + ptype + threat + items (contiguous)");
+			static_assert(sizeof(sh.act) + sizeof(sh.frames) + sizeof(sh.ptype) + sizeof(sh.threat) + sizeof(sh.items) >= SH::SELECT_KEY_BYTES && sizeof(sh.lines) >= BWORDS * sizeof(u64),
+				"select-stage LDS must fit");
 			const GameState &sg = E.games[g];
 			if (sg.active && sg.error == 0 && sg.outcome == 0 && !sg.grow_pending)
 			{
@@ -758,8 +761,11 @@ namespace
 		const int area = E.n_games + E.spec_group * E.spec_waves + blockIdx.x; // this wave's spill areas (action stack, list / frame tails)
 
 		/* ---- 1. select: games off a cursor ---- */
-		static_assert(offsetof(SH, act) % 8 == 0 && offsetof(SH, frames) == offsetof(SH, act) + sizeof(sh.act), "select-stage keys: 64-bit words over act + frames");
-		static_assert(sizeof(sh.act) + sizeof(sh.frames) >= SH::SELECT_KEY_BYTES && sizeof(sh.lines) >= BWORDS * sizeof(u64), "select-stage LDS must fit");
+		static_assert(offsetof(SH, act) % 8 == 0 && offsetof(SH, frames) == offsetof(SH, act) + sizeof(sh.act) && offsetof(SH, ptype) == offsetof(SH, frames) + sizeof(sh.frames)
+				&& offsetof(SH, threat) == offsetof(SH, ptype) + sizeof(sh.ptype) && offsetof(SH, items) == offsetof(SH, threat) + sizeof(sh.threat),
+				"select-stage keys: 64-bit words over act + frames + ptype + threat + items (contiguous)");
+		static_assert(sizeof(sh.act) + sizeof(sh.frames) + sizeof(sh.ptype) + sizeof(sh.threat) + sizeof(sh.items) >= SH::SELECT_KEY_BYTES && sizeof(sh.lines) >= BWORDS * sizeof(u64),
+				"select-stage LDS must fit");
 		u64 *sel_keys = reinterpret_cast<u64*>(&sh.act[0]);
 		bool keys_loaded = false;
 		SPEC_T(t_begin);
