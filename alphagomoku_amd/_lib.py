@@ -129,7 +129,7 @@ class AgxGameInfo(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in ["active", "sign_to_move", "n_moves", "outcome", "error", "opening_id", "games_done",
                                             "n_nodes", "n_edges", "root_visits"]] + \
                [("root_win", ctypes.c_float), ("root_draw", ctypes.c_float), ("root_score", ctypes.c_int), ("root_edges", ctypes.c_int),
-                ("grow_pending", ctypes.c_int), ("arena_class", ctypes.c_int)]
+                ("grow_pending", ctypes.c_int), ("arena_class", ctypes.c_int), ("root_moves_left", ctypes.c_float), ("max_depth", ctypes.c_int)]
 
 
 class AgxMoveRecord(ctypes.Structure):
@@ -142,6 +142,11 @@ class AgxMoveRecord(ctypes.Structure):
 class AgxGameEnd(ctypes.Structure):
     _fields_ = [("game_serial", ctypes.c_int), ("game_slot", ctypes.c_int), ("game_index", ctypes.c_int), ("outcome", ctypes.c_int),
                 ("n_moves", ctypes.c_int), ("moves", ctypes.c_uint16 * 400)]
+
+
+class AgxSavedGame(ctypes.Structure):
+    _fields_ = [("game_slot", ctypes.c_int), ("game_index", ctypes.c_int), ("opening_id", ctypes.c_int), ("sign_to_move", ctypes.c_int),
+                ("nn_queued", ctypes.c_int), ("n_moves", ctypes.c_int), ("moves", ctypes.c_uint16 * 400)]
 
 
 class AgxRecordCounts(ctypes.Structure):
@@ -183,6 +188,11 @@ def _declare(c):  # noqa: F811
     c.agx_stream_synchronize.argtypes = [vp]
     c.agx_engine_set_board.argtypes = [vp, ci, vp, ci, vp]
     c.agx_engine_set_max_simulations.argtypes = [vp, ci]
+    c.agx_engine_set_batch_size.argtypes = [vp, ci]
+    c.agx_engine_solve_timed_group.argtypes = [vp, ci, ci, ci, ctypes.c_double, vp]
+    c.agx_engine_select_group.argtypes = [vp, ci, ci, vp]
+    c.agx_engine_save_games.argtypes = [vp, vp, ci, ctypes.POINTER(ci)]
+    c.agx_engine_restore_game.argtypes = [vp, ctypes.POINTER(AgxSavedGame), vp]
     c.agx_engine_set_force_expand_root.argtypes = [vp, ci]
     c.agx_engine_cancel_pending.argtypes = [vp, vp]
     c.agx_engine_root_summary.argtypes = [vp, ci, vp, ctypes.POINTER(ctypes.c_int)]
@@ -207,6 +217,10 @@ def _declare(c):  # noqa: F811
     c.agx_game_buffer_stats.argtypes = [vp, ctypes.POINTER(AgxGameBufferStats)]
     c.agx_game_buffer_game.argtypes = [vp, ci, vp, sz, ctypes.POINTER(sz)]
     c.agx_game_buffer_save.argtypes = [vp, ctypes.c_char_p, ci]
+    c.agx_game_buffer_load.argtypes = [vp, ctypes.c_char_p]
+    c.agx_game_buffer_take_pending.argtypes = [vp, vp, ci, ci, vp, sz, ctypes.POINTER(sz)]
+    c.agx_game_buffer_restore_pending.argtypes = [vp, vp, ci, ci, vp, sz]
+    c.agx_game_buffer_forget_engine.argtypes = [vp, vp]
     c.agx_sample_v201_unpack.argtypes = [vp, sz, ci, ci, vp, vp, vp, vp, vp, vp, ctypes.POINTER(sz)]
     c.agx_debug_solve.argtypes = [vp, vp, vp, ci, vp, vp, vp, vp, vp, vp]
     c.agx_debug_new_generation.argtypes = [vp]

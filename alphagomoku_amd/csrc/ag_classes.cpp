@@ -13,6 +13,8 @@
 #include <filesystem>
 #include <fstream>
 #include <iostream>
+#include <iterator>
+#include <sstream>
 #include <stdexcept>
 #include <thread>
 
@@ -84,13 +86,13 @@ namespace ag
 	AGNetwork::AGNetwork(const GameConfig &gameOptions, const std::string &architecture, int blocks, int filters) :
 			game_config(gameOptions)
 	{
-		if (architecture != "ResnetPV" && architecture != "ResnetPVQ")
-			throw std::logic_error("AGNetwork: unknown architecture '" + architecture + "' (the device tower implements ResnetPV and ResnetPVQ)");
+		if (architecture != "ResnetPV" && architecture != "ResnetPVQ" && architecture != "ResnetPVraw")
+			throw std::logic_error("AGNetwork: unknown architecture '" + architecture + "' (the device tower implements ResnetPV, ResnetPVraw and ResnetPVQ)");
 		desc.rows = gameOptions.rows;
 		desc.cols = gameOptions.cols;
 		desc.blocks = blocks;
 		desc.filters = filters;
-		desc.in_channels = 32;
+		desc.in_channels = (architecture == "ResnetPVraw") ? 8 : 32; // networks.cpp:107-129: the raw network sees the 8 low bits of a feature word
 		desc.value_hidden = std::min(256, 2 * filters);
 		desc.action_values = (architecture == "ResnetPVQ") ? 1 : 0;
 		create();
@@ -124,7 +126,7 @@ namespace ag
 	}
 	std::string AGNetwork::name() const
 	{
-		return desc.action_values ? "ResnetPVQ" : "ResnetPV";
+		return desc.action_values ? "ResnetPVQ" : (desc.in_channels == 8 ? "ResnetPVraw" : "ResnetPV");
 	}
 	size_t AGNetwork::numberOfWeights() const
 	{
@@ -482,6 +484,8 @@ namespace ag
 			{
 				agx_event_destroy(scheduled_event[i]);
 				agx_event_destroy(done_event[i]);
+				if (network_timer[i] != nullptr)
+					agx_timer_destroy(network_timer[i]);
 			}
 			agx_stream_destroy(own_stream);
 		}
@@ -509,12 +513,27 @@ namespace ag
 			throw std::logic_error("some tasks are already being processed");
 		// pool slices: the batch is the slice's device-side queue, the launch goes onto the slice's stream behind its solver kernel
 		in_progress_slices.swap(waiting_slices);
+		bool timed_launch = false;
 		for (const SliceData &s : in_progress_slices)
 			if (s.overlap)
 			{ // behind everything the search stream holds so far (select + solve of this buffer), beside whatever it is given next
 				check(agx_event_record(scheduled_event[s.event], s.stream));
 				check(agx_stream_wait_event(own_stream, scheduled_event[s.event]));
+				// the estimate asyncEvaluateGraphLaunch returns (PerfEstimator in the reference, NNEvaluator.cpp:197-206): device time of this
+				// buffer's PREVIOUS network launch (long finished: the search stream has waited for it), smoothed
+				if (network_timer[s.event] == nullptr)
+					check(agx_timer_create(&network_timer[s.event]));
+				else if (network_timer_used[s.event])
+				{
+					float ms = 0.0f;
+					if (agx_timer_elapsed_ms(network_timer[s.event], &ms) == AGX_OK && ms > 0.0f)
+						network_seconds = (network_seconds > 0.0) ? 0.75 * network_seconds + 0.25 * ms * 1.0e-3 : ms * 1.0e-3;
+				}
+				check(agx_timer_start(network_timer[s.event], own_stream));
 				check(agx_engine_evaluate_group(s.engine, get_network().handle(), s.group, s.n_groups, own_stream));
+				check(agx_timer_stop(network_timer[s.event], own_stream));
+				network_timer_used[s.event] = true;
+				timed_launch = true;
 				check(agx_event_record(done_event[s.event], own_stream));
 			}
 			else
@@ -529,7 +548,11 @@ namespace ag
 			get_network().asyncForwardLaunch(batch);
 		}
 		stats.compute.startTimer();
-		return 0.0; // no host-side estimate of the end time: nothing on the host waits for it
+		// the estimated end of the launch (NNEvaluator.cpp:206; SearchThread::asynchronous_run hands it to Search::solve as its deadline); a negative
+		// value — no estimate yet, or a pool slice whose launches nobody times — makes Search::solve run its ordinary node budget
+		if (timed_launch && network_seconds > 0.0)
+			return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() + network_seconds;
+		return -1.0;
 	}
 	void NNEvaluator::asyncEvaluateGraphJoin()
 	{ // NNEvaluator.cpp:207-228
@@ -886,24 +909,73 @@ namespace ag
 	{
 		return static_cast<Sign>(game_info(bound(), first_game + game).sign_to_move);
 	}
-	std::vector<Sign> Tree::getBoard(int game) const
+	matrix<Sign> Tree::getBoard(int game) const
 	{
 		std::vector<uint8_t> b;
 		game_info(bound(), first_game + game, nullptr, &b);
-		const int hw = bound().getGameConfig().rows * bound().getGameConfig().cols;
-		std::vector<Sign> result(hw);
-		for (int i = 0; i < hw; i++)
+		const GameConfig &gc = bound().getGameConfig();
+		matrix<Sign> result(gc.rows, gc.cols);
+		for (int i = 0; i < result.size(); i++)
 			result[i] = static_cast<Sign>(b[i]);
 		return result;
 	}
 	const matrix<Sign>& Tree::getBoard() const
 	{
-		const GameConfig &gc = bound().getGameConfig();
-		const std::vector<Sign> cells = getBoard(0);
-		board_copy = matrix<Sign>(gc.rows, gc.cols);
-		for (int i = 0; i < board_copy.size(); i++)
-			board_copy[i] = cells[i];
+		board_copy = getBoard(0);
 		return board_copy;
+	}
+	void Tree::clear()
+	{ // Tree.cpp:124-127.  Both callers of the reference empty the solver's table in the same breath (GameGenerator.cpp:52-53, SearchEngine.cpp:91-96)
+	  // and give the tree its position next; the games of a pool slice restart on the device by themselves
+		if (!standalone)
+			throw std::logic_error("Tree::clear() : the trees of a pool slice are cleared on the device when their games restart");
+		if (pool == nullptr)
+			return; // not bound to a Search yet: nothing stored
+		pool->begin(std::vector<uint16_t>(AGX_OPENING_CAP, 0));
+		summary_valid = false;
+	}
+	float Tree::getMovesLeft(int game) const
+	{
+		return game_info(bound(), first_game + game).root_moves_left;
+	}
+	int Tree::getMaximumDepth(int game) const
+	{
+		return game_info(bound(), first_game + game).max_depth;
+	}
+	bool Tree::hasAllMovesProven(int game) const
+	{ // Tree.cpp:199-206 (std::all_of over the root's edges: true for a root without edges, false without a root)
+		const Node root = getInfo(game);
+		if (root.getVisits() == 0 && root.numberOfEdges() == 0)
+			return false;
+		for (const Edge *e = root.begin(); e < root.end(); e++)
+			if (!e->getScore().isProven())
+				return false;
+		return true;
+	}
+	bool Tree::hasSingleMove(int game) const
+	{ // Tree.cpp:207-213
+		return game_info(bound(), first_game + game).root_edges == 1;
+	}
+	bool Tree::hasSingleNonLosingMove(int game) const
+	{ // Tree.cpp:214-224
+		const Node root = getInfo(game);
+		int non_losing = 0;
+		for (const Edge *e = root.begin(); e < root.end(); e++)
+			non_losing += (e->getScore().getProvenValue() == ProvenValue::LOSS && e->getScore().isFinite()) ? 0 : 1;
+		return non_losing == 1;
+	}
+	LowPriorityLock Tree::low_priority_lock() const
+	{
+		return LowPriorityLock(tree_mutex);
+	}
+	HighPriorityLock Tree::high_priority_lock() const
+	{
+		return HighPriorityLock(tree_mutex);
+	}
+	void Tree::clearNodeCacheStats() noexcept
+	{
+		stats_baseline = NodeCacheStats();
+		stats_baseline = getNodeCacheStats();
 	}
 	Node Tree::getInfo(const std::vector<Move> &moves) const
 	{
@@ -927,8 +999,9 @@ namespace ag
 		try
 		{
 			const AgxEngineStats s = bound().getStats();
-			result.stored_nodes = s.peak_nodes;
-			result.stored_edges = s.peak_edges;
+			// (peaks since agx_engine_begin; after clearNodeCacheStats only what has grown beyond the peaks seen then is reported)
+			result.stored_nodes = (s.peak_nodes > stats_baseline.stored_nodes) ? s.peak_nodes : 0;
+			result.stored_edges = (s.peak_edges > stats_baseline.stored_edges) ? s.peak_edges : 0;
 		} catch (std::exception&)
 		{
 		}
@@ -1058,9 +1131,18 @@ namespace ag
 			stats.select.stopTimer();
 		}
 	}
-	void Search::solve(double)
+	void Search::solve(double endTime)
 	{
 		stats.solve.startTimer();
+		if (endTime >= 0.0)
+		{ // Search.cpp:159-183 as SearchThread::asynchronous_run calls it: node limit 10 000 and the time until endTime shared out over the leaves
+			flush_select();
+			const double now = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); // getTime() (utils/misc.hpp:52-55)
+			check(agx_engine_solve_timed_group(pool.handle(), group, n_groups, 10000, endTime - now, stream));
+			stats.solve.stopTimer();
+			scheduled = false;
+			return;
+		}
 		if (select_pending)
 		{
 			select_pending = false;
@@ -1124,8 +1206,15 @@ namespace ag
 		}
 	}
 	void Search::setBatchSize(int batchSize)
-	{
-		if (batchSize != batch_size)
+	{ // Search.cpp:252-255.  A stand-alone Search resizes its buffers (SearchThread.cpp:125-126: the batch grows with sqrt(simulations)); the slices
+	  // of a generator thread's pool share one engine and keep the size it was created with (GameGenerator.cpp:31 sets exactly that)
+		if (own_pool != nullptr)
+		{
+			if (batchSize < 1 || batchSize > batch_size)
+				throw std::logic_error("Search::setBatchSize() : " + std::to_string(batchSize) + " outside [1, max_batch_size = " + std::to_string(batch_size) + "]");
+			check(agx_engine_set_batch_size(pool.handle(), batchSize));
+		}
+		else if (batchSize != batch_size)
 			throw std::logic_error("Search::setBatchSize() : the pool was created with max_batch_size " + std::to_string(batch_size));
 	}
 	int Search::getBatchSize() const noexcept
@@ -1266,6 +1355,10 @@ namespace ag
 	{
 		check(agx_game_buffer_save(buffer, path.c_str(), 1));
 	}
+	void GameDataBuffer::load(const std::string &path)
+	{
+		check(agx_game_buffer_load(buffer, path.c_str()));
+	}
 	GameDataBufferStats GameDataBuffer::getStats() const noexcept
 	{
 		AgxGameBufferStats s;
@@ -1373,6 +1466,72 @@ namespace ag
 		}
 		return GameGenerator::OK;
 	}
+	void GameGenerator::save(std::vector<uint8_t> &binary_data)
+	{ // GameGenerator.cpp:122-130 for every game of the slice that is in flight
+		const size_t count_at = binary_data.size();
+		uint32_t count = 0;
+		binary_data.insert(binary_data.end(), sizeof(count), 0);
+		if (pool != nullptr)
+		{
+			int in_flight = 0;
+			check(agx_engine_save_games(pool->handle(), nullptr, 0, &in_flight));
+			std::vector<AgxSavedGame> games(std::max(in_flight, 1));
+			check(agx_engine_save_games(pool->handle(), games.data(), static_cast<int>(games.size()), &in_flight));
+			const int per = (pool->numberOfGames() + n_groups - 1) / n_groups;
+			for (int i = 0; i < in_flight; i++)
+			{
+				const AgxSavedGame &g = games[i];
+				if (g.game_slot / per != group)
+					continue;
+				size_t bytes = 0;
+				check(agx_game_buffer_take_pending(manager.getGameBuffer().handle(), pool->handle(), g.game_slot, g.game_index, nullptr, 0, &bytes));
+				std::vector<uint8_t> samples(std::max<size_t>(bytes, 1));
+				check(agx_game_buffer_take_pending(manager.getGameBuffer().handle(), pool->handle(), g.game_slot, g.game_index, samples.data(), samples.size(), &bytes));
+				const uint8_t *raw = reinterpret_cast<const uint8_t*>(&g);
+				binary_data.insert(binary_data.end(), raw, raw + sizeof(AgxSavedGame));
+				const uint64_t n = bytes;
+				binary_data.insert(binary_data.end(), reinterpret_cast<const uint8_t*>(&n), reinterpret_cast<const uint8_t*>(&n) + sizeof(n));
+				binary_data.insert(binary_data.end(), samples.begin(), samples.begin() + bytes);
+				count++;
+			}
+		}
+		std::memcpy(binary_data.data() + count_at, &count, sizeof(count));
+	}
+	size_t GameGenerator::load(const std::vector<uint8_t> &binary_data, size_t offset)
+	{ // GameGenerator.cpp:131-141: the Game and its samples come back, the search starts again on an empty tree (prepare_search)
+		auto need = [&](size_t n)
+		{
+			if (offset + n > binary_data.size())
+				throw std::runtime_error("GameGenerator::load() : the saved state is truncated");
+		};
+		need(sizeof(uint32_t));
+		uint32_t count = 0;
+		std::memcpy(&count, binary_data.data() + offset, sizeof(count));
+		offset += sizeof(count);
+		if (pool == nullptr && count > 0)
+			start_own_pool();
+		const int per = (pool != nullptr) ? (pool->numberOfGames() + n_groups - 1) / n_groups : 1;
+		for (uint32_t i = 0; i < count; i++)
+		{
+			need(sizeof(AgxSavedGame) + sizeof(uint64_t));
+			AgxSavedGame g;
+			std::memcpy(&g, binary_data.data() + offset, sizeof(g));
+			offset += sizeof(g);
+			uint64_t n = 0;
+			std::memcpy(&n, binary_data.data() + offset, sizeof(n));
+			offset += sizeof(n);
+			need(n);
+			if (g.game_slot >= 0 && g.game_slot < pool->numberOfGames() && g.game_slot / per == group)
+			{
+				check(agx_engine_restore_game(pool->handle(), &g, stream));
+				check(agx_game_buffer_restore_pending(manager.getGameBuffer().handle(), pool->handle(), g.game_slot, 0, binary_data.data() + offset, n));
+			}
+			offset += n;
+		}
+		if (state == GAMEPLAY_EXPAND_AND_BACKUP)
+			state = GAMEPLAY_SELECT_SOLVE_EVALUATE;
+		return offset;
+	}
 	void GameGenerator::make_move()
 	{ // GameGenerator.cpp:145-173 for the games whose root has its visits: final selector, sample, Game::makeMove
 		check(agx_engine_advance_group(pool->handle(), group, n_groups, stream));
@@ -1456,6 +1615,29 @@ namespace ag
 		last_search_stats = s;
 		last_cache_stats = c;
 	}
+	void GeneratorThread::saveGames(const std::string &path) const
+	{ // GeneratorManager.cpp:98-110.  File: "AGXS", u32 version, u32 generators, then every generator's GameGenerator::save bytes
+		if (!isFinished())
+			throw std::logic_error("GeneratorThread::saveGames() : cannot save while the generator is running");
+		std::ofstream out(path, std::ofstream::out | std::ofstream::binary);
+		if (!out.good())
+			throw std::runtime_error("GeneratorThread::saveGames() : cannot open '" + path + "'");
+		out.write(reinterpret_cast<const char*>(saved_games.data()), static_cast<std::streamsize>(saved_games.size()));
+	}
+	void GeneratorThread::loadGames(const std::string &path)
+	{ // GeneratorManager.cpp:111-122; the games continue when the thread is started next (run() hands them to its generators)
+		if (!isFinished())
+			throw std::logic_error("GeneratorThread::loadGames() : cannot load while the generator is running");
+		std::ifstream in(path, std::ifstream::in | std::ifstream::binary);
+		if (!in.good())
+			throw std::runtime_error("GeneratorThread::loadGames() : cannot open '" + path + "'");
+		saved_games.assign((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+		if (saved_games.size() < 12 || std::memcmp(saved_games.data(), "AGXS", 4) != 0)
+		{
+			saved_games.clear();
+			throw std::runtime_error("GeneratorThread::loadGames() : '" + path + "' is not a saved generator state");
+		}
+	}
 	void GeneratorThread::setup()
 	{
 		const DeviceConfig &device = selfplay_config.device_config.at(index);
@@ -1480,7 +1662,8 @@ namespace ag
 			for (int c = g * (cus / n_groups); c < (g + 1) * (cus / n_groups); c++)
 				mask[c / 32] |= 1u << (c % 32);
 			void *s = nullptr;
-			if (agx_stream_create_with_cu_mask(&s, mask.data(), static_cast<int>(mask.size())) == AGX_OK)
+			// (instance = this thread's index: two generator threads on one device — several device_config entries may name it — must not share a queue)
+			if (agx_stream_create_with_cu_mask_instance(&s, mask.data(), static_cast<int>(mask.size()), index) == AGX_OK)
 				masked.push_back(s);
 			else
 				partition = false; // no CU masks on this device / runtime: plain streams (the slices then only pipeline host work)
@@ -1539,6 +1722,19 @@ namespace ag
 		};
 		int n_openings = games + games / 2;
 		pool->begin(make_openings(n_openings));
+		if (!saved_games.empty())
+		{ // loadGames: every saved game goes to the generator whose slice holds its slot (a file written with another slicing is read by all of them)
+			uint32_t saved_generators = 0;
+			std::memcpy(&saved_generators, saved_games.data() + 8, 4);
+			size_t offset = 12;
+			for (uint32_t k = 0; k < saved_generators; k++)
+			{
+				const size_t begin = offset;
+				for (size_t i = 0; i < generators.size(); i++)
+					offset = generators[i]->load(saved_games, begin);
+			}
+			saved_games.clear();
+		}
 
 		uint64_t iterations = 0;
 		while (is_running.load() and not manager.hasEnoughGames())
@@ -1568,6 +1764,14 @@ namespace ag
 		nn_evaluator.asyncEvaluateGraphJoin();
 		check(agx_device_synchronize());
 		collectGames();
+		{ // what saveGames will write: the games still in flight, slice by slice (their samples leave the manager's buffer with them)
+			saved_games.assign({ 'A', 'G', 'X', 'S', 1, 0, 0, 0 });
+			const uint32_t count = static_cast<uint32_t>(generators.size());
+			saved_games.insert(saved_games.end(), reinterpret_cast<const uint8_t*>(&count), reinterpret_cast<const uint8_t*>(&count) + 4);
+			for (size_t i = 0; i < generators.size(); i++)
+				generators[i]->save(saved_games);
+			agx_game_buffer_forget_engine(manager.getGameBuffer().handle(), pool->handle());
+		}
 		nn_evaluator.unloadGraph();
 		teardown();
 	}
@@ -1610,63 +1814,88 @@ namespace ag
 		return game_buffer.numberOfGames() >= games_to_generate;
 	}
 	void GeneratorManager::generate(const NetworkLoader &loader, int numberOfGames)
-	{ // GeneratorManager.cpp:182-218 (the 1 s polling sleep is 20 ms here; SIGINT handling stays with the caller)
+	{ // GeneratorManager.cpp:182-218: start every device's thread, wait until all of them have seen hasEnoughGames() (SIGINT handling stays with
+	  // the caller; the polling interval is 20 ms instead of 1 s — a pool finishes games by the hundred per second)
 		games_to_generate = numberOfGames;
 		network_loader = loader;
-		for (size_t i = 0; i < generators.size(); i++)
+		for (auto &thread : generators)
 		{
-			generators[i]->clearStats();
-			generators[i]->start();
+			thread->clearStats();
+			thread->start();
 		}
-		while (true)
+		auto all_finished = [this]()
 		{
+			return std::all_of(generators.begin(), generators.end(), [](const std::unique_ptr<GeneratorThread> &t) { return t->isFinished(); });
+		};
+		while (!all_finished())
 			std::this_thread::sleep_for(std::chrono::milliseconds(20));
-			bool is_ready = true;
-			for (size_t i = 0; i < generators.size(); i++)
-				is_ready &= generators[i]->isFinished();
-			if (is_ready)
-				break;
-		}
 	}
 	void GeneratorManager::printStats()
-	{ // GeneratorManager.cpp:219-240
-		std::cout << "Played games = " << game_buffer.numberOfGames() << "/" << games_to_generate << '\n';
-		std::cout << game_buffer.getStats().toString() << '\n';
-		NNEvaluatorStats evaluator_stats;
-		SearchStats search_stats;
-		NodeCacheStats cache_stats;
-		for (size_t i = 0; i < generators.size(); i++)
+	{ // GeneratorManager.cpp:219-240: progress, the buffer's summary, then the per-thread statistics averaged over the threads
+		const int threads = static_cast<int>(generators.size());
+		NNEvaluatorStats evaluator_total;
+		SearchStats search_total;
+		NodeCacheStats cache_total;
+		for (const auto &thread : generators)
 		{
-			evaluator_stats += generators[i]->getEvaluatorStats();
-			search_stats += generators[i]->getSearchStats();
-			cache_stats += generators[i]->getCacheStats();
+			evaluator_total += thread->getEvaluatorStats();
+			search_total += thread->getSearchStats();
+			cache_total += thread->getCacheStats();
 		}
-		evaluator_stats /= static_cast<int>(generators.size());
-		search_stats /= static_cast<int>(generators.size());
-		cache_stats /= static_cast<int>(generators.size());
-		std::cout << evaluator_stats.toString();
-		std::cout << search_stats.toString();
-		std::cout << cache_stats.toString() << std::endl;
+		if (threads > 0)
+		{
+			evaluator_total /= threads;
+			search_total /= threads;
+			cache_total /= threads;
+		}
+		std::ostringstream text;
+		text << "Played games = " << game_buffer.numberOfGames() << "/" << games_to_generate << '\n' << game_buffer.getStats().toString() << '\n';
+		text << evaluator_total.toString() << search_total.toString() << cache_total.toString();
+		std::cout << text.str() << std::endl;
 	}
 	void GeneratorManager::saveState(bool saveBuffer)
-	{ // GeneratorManager.cpp:241-262; games in flight live in device trees and are not serialised: a restart begins them again
+	{ // GeneratorManager.cpp:241-262: saved_state/buffer.bin (optional) and one saved_state/thread_<i>.bin per generator thread with its games in flight
 		if (working_directory.empty())
 			return;
 		const std::string path = working_directory + "/saved_state/";
-		if (!std::filesystem::exists(path))
-			std::filesystem::create_directory(path);
+		std::filesystem::create_directories(path);
 		if (saveBuffer)
 		{
 			std::cout << "Saving buffer" << std::endl;
 			game_buffer.save(path + "buffer.bin");
 		}
+		std::cout << "Saving games" << std::endl;
+		for (size_t i = 0; i < generators.size(); i++)
+		{
+			const std::string file = path + "thread_" + std::to_string(i) + ".bin";
+			generators[i]->saveGames(file);
+			std::cout << "Saved " << file << std::endl;
+		}
 	}
 	void GeneratorManager::loadState()
-	{
+	{ // GeneratorManager.cpp:263-290: the buffer comes back (and its file is removed, as in the reference), every thread gets its games back
 		if (working_directory.empty())
 			return;
 		const std::string path = working_directory + "/saved_state/";
 		if (!std::filesystem::exists(path))
+		{
 			std::cout << "No saved state was found" << std::endl;
+			return;
+		}
+		if (std::filesystem::exists(path + "buffer.bin"))
+		{
+			game_buffer.load(path + "buffer.bin");
+			std::cout << "Loaded buffer:\n" << game_buffer.getStats().toString() << std::endl;
+			std::filesystem::remove(path + "buffer.bin");
+		}
+		for (size_t i = 0; i < generators.size(); i++)
+		{
+			const std::string file = path + "thread_" + std::to_string(i) + ".bin";
+			if (std::filesystem::exists(file))
+			{
+				generators[i]->loadGames(file);
+				std::cout << "Loaded " << file << std::endl;
+			}
+		}
 	}
 } /* namespace ag */

@@ -167,6 +167,8 @@ namespace agx
 #define AGX_LUT_LDS 0 /* 1: a private 4 KB copy of the packed ThreatTable in every solver wave's LDS (-1.4 % solver time at one wave per SIMD); 0: read
                          through the vector L1 / L2 — 4 KB less LDS per wave buys a third wave per SIMD, which hides far more than that latency */
 #endif
+		constexpr int NODE_TIME_OVER = 0x40000000; // set in the node counter when a time-limited solve runs out of time: every "nodes left" test then fails
+		constexpr int NODE_COUNT_MASK = NODE_TIME_OVER - 1;
 		constexpr int LDS_FRAMES = 42;
 		constexpr int OV_CAP = 256; // overlay slots of a speculative solve (a 100-node solve touches ~100-150 buckets; more = the task is re-run serially) // alpha-beta frames kept in LDS; deeper ones (only reachable with node budgets far above 100) live in HBM
 
@@ -230,6 +232,7 @@ namespace agx
 				unsigned long long dprof[24];
 #endif
 				u64 hash_lo, hash_hi;
+				u64 time_deadline;       // time-limited solves (E.solve_time_ticks != 0): the wall-clock tick at which this task's share of the time is over
 				uint16_t *spill_lists;   // [2][10][hw] tails of the threat lists (HBM, per game)
 				Frame *spill_frames;     // [MAX_FRAMES] frames beyond LDS_FRAMES (HBM, per game)
 				int sign_to_move, depth;
@@ -2038,6 +2041,8 @@ namespace agx
 					if (!early)
 					{
 						node_counter++;
+						if (E.solve_time_ticks != 0ull && wall_clock64() >= sh.time_deadline)
+							node_counter |= NODE_TIME_OVER; // AlphaBetaSearch.cpp:110-111,277: (getTime() - start_time) >= max_time
 						if (f.size == 0)
 						{
 							MoveGen<RENJU, SH> gen(sh, E, act, f, lane, stack_offset, stack_max);

@@ -50,9 +50,9 @@ namespace
 		const int n = E.n;
 
 		int n_tasks = ls.n_tasks;
-		int trials = 2 * E.batch;
+		int trials = 2 * E.batch_limit; // Search.cpp:119: twice the buffer's current size (Search::setBatchSize)
 		unsigned long long st_levels = 0, st_edges = 0, st_leaks = 0, st_proven = 0, st_dup = 0;
-		while (n_tasks < E.batch)
+		while (n_tasks < E.batch_limit)
 		{
 			const int root = gs.root;
 			const int sims = (root < 0) ? 0 : nodes[root].visits;
@@ -151,6 +151,8 @@ namespace
 				t.moves_left = 0.0f;
 				t.needs_nn = 0;
 				t.hash = hash;
+				if (out == 0 && path_len > gs.max_depth)
+					gs.max_depth = path_len; // Tree.cpp:249 (REACHED_LEAF only)
 			}
 			__syncthreads();
 			if (path_len == 0)
@@ -239,7 +241,7 @@ namespace
 		uint32_t *act = E.act + static_cast<size_t>(area) * E.act_cap;
 		if (lane == 0)
 		{ // HBM tails of the LDS-resident threat lists and frames (dev_solver.hpp: list_get / frame_get)
-			sh.spill_lists = E.list_spill + static_cast<size_t>(area) * 20 * E.hw;
+			sh.spill_lists = E.list_spill + static_cast<size_t>(area) * 20 * MAXHW; // (stride of list_get / list_set: SolverSharedT::HW <= MAXHW whatever the kernel instantiation)
 			sh.spill_frames = reinterpret_cast<Frame*>(E.frame_spill) + static_cast<size_t>(area) * MAX_FRAMES;
 			sh.ov_on = (overlay != nullptr) ? 1 : 0;
 			sh.ov_data = overlay;
@@ -345,6 +347,8 @@ namespace
 			{
 				const uint32_t r = static_cast<uint32_t>(sh.result_score);
 				stop = (sh.frames[0].size == 0 || s_proven(r) || sh.node_counter >= E.tss_max_nodes || sh.stack_max == stack_before || sh.error != 0) ? 1 : 0;
+				if (E.solve_time_ticks != 0ull && wall_clock64() >= sh.time_deadline)
+					stop = 1; // AlphaBetaSearch.cpp:111
 			}
 			stop = __builtin_amdgcn_readfirstlane(stop);
 			result = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(sh.result_score));
@@ -374,13 +378,13 @@ namespace
 			}
 			if (sh.frames[0].must_defend)
 				t.flags |= TF_MUST_DEFEND;
-			if (sh.node_counter <= 1)
+			if ((sh.node_counter & NODE_COUNT_MASK) <= 1)
 				t.flags |= TF_STATICALLY_SOLVED;
 			t.flags |= TF_BY_SOLVER;
 			if (sh.error != 0 && sh.error != ERR_OVERLAY)
 				E.games[g].error = sh.error;
 		}
-		solver_nodes += static_cast<unsigned long long>(sh.node_counter);
+		solver_nodes += static_cast<unsigned long long>(sh.node_counter & NODE_COUNT_MASK);
 #ifdef AGX_SOLVER_PROFILE
 		if (lane == 0)
 		{
@@ -514,12 +518,18 @@ namespace
 		const int threshold = (E.yield_fraction > 0.0f) ? static_cast<int>(fraction * gridDim.x) : 0x7FFFFFFF;
 		int k = idle ? 0 : gs.solve_pos;
 		bool yielded = false;
+		const unsigned long long t_launch = (E.solve_time_ticks != 0ull) ? wall_clock64() : 0ull;
 		for (; k < n_tasks; k++)
 		{
 			DTask &t = E.tasks[static_cast<size_t>(g) * E.batch + k];
 			const int slot = g * E.batch + k;
 			if ((t.flags & TF_BY_SOLVER) == 0)
 			{
+				if (E.solve_time_ticks != 0ull && lane == 0)
+				{ // ab_search.setTimeLimit((endTime - getTime()) / (getBatchSize() - i)) (Search.cpp:175-180): this task's share of what is left
+					const unsigned long long now = wall_clock64(), end = t_launch + E.solve_time_ticks;
+					sh.time_deadline = now + ((end > now) ? (end - now) / static_cast<unsigned long long>(max(1, n_tasks - k)) : 0ull);
+				}
 				if (threshold != 0x7FFFFFFF && k > gs.solve_pos)
 				{ // at least one task per launch is always solved, so every game makes progress
 					int done = 0;
@@ -608,7 +618,7 @@ namespace
 	 * same operations one step later. */
 	struct SpecCommit
 	{
-			int game, k;
+		int game, k, first; // first: where the game's batch began in THIS launch (0, or the solve_pos a deferred game came back with)
 			bool table_changed;
 			unsigned long long nodes, solved, reruns;
 	};
@@ -660,7 +670,9 @@ namespace
 				int done = 0;
 				if (lane == 0)
 					done = __hip_atomic_load(c_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				const bool defer = __builtin_amdgcn_readfirstlane(done) >= defer_threshold;
+				// (like k_solve's rule: the first leaf of the launch is always finished — a game whose first pending leaf needs the re-run every time,
+				//  e.g. one whose overlay overflows, would otherwise be deferred launch after launch with its speculative work thrown away)
+				const bool defer = __builtin_amdgcn_readfirstlane(done) >= defer_threshold && k > c.first;
 				// forget the speculative result: of this leaf (it is solved again), or of this leaf and the ones behind it (deferred)
 				for (int j = k; j < (defer ? n_tasks : k + 1); j++)
 				{
@@ -969,6 +981,7 @@ namespace
 				__threadfence();
 				commit.game = g;
 				commit.k = 0;
+				commit.first = E.games[g].solve_pending ? E.games[g].solve_pos : 0;
 				commit.table_changed = false;
 				commit.nodes = commit.solved = commit.reruns = 0;
 				__builtin_amdgcn_s_setprio(3);
@@ -1444,8 +1457,8 @@ namespace
 		clear_solver_table(E, g, tid);
 	}
 	/* loads opening `id` into game g: Game::loadOpening + prepare_search on an empty tree (GameGenerator.cpp:48-77,174-185) */
-	__device__ void begin_game(const EngineDev &E, int g, int id, int tid, u64 *scratch, bool tables_cleared = false)
-	{
+	__device__ void begin_game(const EngineDev &E, int g, int id, int tid, u64 *scratch, bool tables_cleared = false, const uint16_t *saved_moves = nullptr, int saved_count = 0)
+	{ // saved_moves: a game in flight restored from a checkpoint (GameGenerator::load, GameGenerator.cpp:131-141) — its moves so far instead of opening `id`
 		GameState &gs = E.games[g];
 		if (!tables_cleared)
 			clear_tree_and_table(E, g, tid);
@@ -1454,8 +1467,8 @@ namespace
 		if (tid < BWORDS)
 			gs.cboard[tid] = 0;
 		__syncthreads();
-		const uint16_t *op = E.openings + static_cast<size_t>(id) * OPENING_CAP;
-		const int count = op[0];
+		const uint16_t *op = (saved_moves != nullptr) ? saved_moves - 1 : E.openings + static_cast<size_t>(id) * OPENING_CAP;
+		const int count = (saved_moves != nullptr) ? saved_count : op[0];
 		if (tid == 0)
 		{
 			int sign = 1;
@@ -1478,6 +1491,7 @@ namespace
 			gs.need_move = 0;
 			gs.solve_pos = 0;
 			gs.solve_pending = 0;
+			gs.max_depth = 0;
 			gs.nn_queued = 0;
 			gs.restart_id = 0;
 			gs.noise_ready = 0;
@@ -1601,6 +1615,7 @@ namespace
 			gs.n_edges = edge_base;
 			gs.arena ^= 1;
 			gs.generation = (gs.generation + 1) % 64;
+			gs.max_depth = 0; // Tree.cpp:150
 		}
 		__syncthreads();
 		if (wave == 0)
@@ -2506,6 +2521,16 @@ namespace
 		}
 	}
 
+	/* GameGenerator::load (GameGenerator.cpp:131-141) for pool slot g: the saved game (its moves so far) with an EMPTY tree and solver table — the
+	 * reference's checkpoint holds the Game and the samples collected so far, the search starts again with prepare_search */
+	__global__ __launch_bounds__(256) void k_restore_game(EngineDev E, int g, const uint16_t *moves, int count, int opening_id, int nn_queued)
+	{
+		__shared__ u64 scratch[4];
+		begin_game(E, g, opening_id, threadIdx.x, scratch, false, moves, count);
+		if (threadIdx.x == 0)
+			E.games[g].nn_queued = nn_queued;
+	}
+
 	/* what a search loop asks the tree between two steps (Tree::getSimulationCount / isRootProven / getNodeCount under the tree lock,
 	 * SearchThread.cpp:181-199) */
 	__global__ void k_root_summary(EngineDev E, int g, int *out)
@@ -2566,7 +2591,7 @@ namespace
 		const int g = blockIdx.x, lane = threadIdx.x;
 		if (lane == 0)
 		{
-			sh.spill_lists = E.list_spill + static_cast<size_t>(g) * 20 * E.hw;
+			sh.spill_lists = E.list_spill + static_cast<size_t>(g) * 20 * MAXHW;
 			sh.spill_frames = reinterpret_cast<Frame*>(E.frame_spill) + static_cast<size_t>(g) * MAX_FRAMES;
 		}
 		solver_load_threat_table(sh, E, lane);
@@ -2648,8 +2673,10 @@ struct AgxEngine
 		bool fuse_select = true;
 		// AgxEngineConfig.speculative_solver: select + solver as one persistent launch with the leaves of a batch solved in parallel (k_search_spec)
 		uint8_t *board_staging = nullptr; // agx_engine_set_board: the caller's board on its way to the device
+		uint16_t *moves_staging = nullptr; // agx_engine_restore_game: the saved move list on its way to the device
 		int *summary_dev = nullptr, *summary_host = nullptr; // agx_engine_root_summary: four words on their way back (device, pinned host)
 		bool speculative = false;
+		bool external_moves = false; // agx_engine_set_board has been called: the caller makes the moves, no advance stage services the arenas
 		int spec_waves = 0; // waves of that launch over the whole pool
 		// optional per-kernel timing (agx_engine_kernel_timing): HIP events on the launch stream around every kernel of a step
 		bool timing = false;
@@ -2831,6 +2858,8 @@ int agx_engine_create(const AgxEngineConfig *cfg, AgxEngine **out)
 	d.max_children = (cfg->max_children > 0) ? cfg->max_children : 0x7FFFFFFF;
 	d.tss_max_nodes = cfg->tss_max_positions;
 	d.tss_max_depth = 100;
+	d.solve_time_ticks = 0ull;
+	d.batch_limit = d.batch;
 	d.yield_fraction = cfg->solver_yield_fraction;
 	d.final_selector = cfg->final_selector;
 	d.use_symmetries = cfg->use_symmetries;
@@ -2891,9 +2920,11 @@ int agx_engine_create(const AgxEngineConfig *cfg, AgxEngine **out)
 		e->spec_waves = (cfg->speculative_waves > 0) ? cfg->speculative_waves : std::min<long long>(12 * std::max(1, cus), std::max<long long>(64, static_cast<long long>(G) * cfg->max_batch_size));
 		e->spec_waves = std::min(e->spec_waves, SPEC_QUEUE_SLACK);
 	}
-	const size_t areas = G + static_cast<size_t>(e->spec_waves);
+	// (a group's waves take the areas n_games + group * waves + wave with waves = max(1, spec_waves / n_groups): at least one area per possible group)
+	const size_t areas = G + static_cast<size_t>(std::max(e->spec_waves, 16));
 	AGX_TRY(dev_alloc(e, &d.act, areas * d.act_cap));
-	AGX_TRY(dev_alloc(e, &d.list_spill, areas * 20 * static_cast<size_t>(d.hw)));
+	// per area 20 lists x MAXHW entries: list_get / list_set stride by the kernel's compile-time board (SolverSharedT::HW, = MAXHW in the any-size kernels)
+	AGX_TRY(dev_alloc(e, &d.list_spill, areas * 20 * static_cast<size_t>(MAXHW)));
 	AGX_TRY(dev_alloc(e, &d.frame_spill, areas * MAX_FRAMES));
 	d.spec_group = 0;
 	d.spec_waves = e->spec_waves;
@@ -3184,6 +3215,30 @@ int agx_engine_solve_group(AgxEngine *e, int group, int n_groups, void *stream)
 	AGX_HIP_CHECK(hipGetLastError());
 	return AGX_OK;
 }
+/* Search::solve(endTime >= 0) (Search.cpp:159-183, the call of SearchThread::asynchronous_run): node limit `max_nodes` (the reference sets
+ * 10 000) and a time budget of `seconds` from the moment the launch starts, shared out task by task like the reference does.  Always the
+ * serial solver (one wave per game, straight on the table): overlays of speculative solves hold 256 buckets. */
+int agx_engine_solve_timed_group(AgxEngine *e, int group, int n_groups, int max_nodes, double seconds, void *stream)
+{
+	AGX_REQUIRE(e != nullptr, AGX_ERR_INVALID, "agx_engine_solve_timed: null engine");
+	AGX_REQUIRE(e->begun, AGX_ERR_STATE, "agx_engine_solve_timed: agx_engine_begin has not been called");
+	AGX_REQUIRE(max_nodes >= 1 && max_nodes <= 100000, AGX_ERR_INVALID, "agx_engine_solve_timed: node limit %d outside [1, 100000]", max_nodes);
+	EngineDev d;
+	int count = 0;
+	const int st = group_range(e, group, n_groups, d, count);
+	if (st != AGX_OK)
+		return st;
+	d.tss_max_nodes = max_nodes;
+	d.yield_fraction = 0.0f; // every task is solved in this launch: the time limit is what bounds it
+	d.solve_time_ticks = (seconds <= 0.0) ? 1ull : static_cast<unsigned long long>(std::min(seconds, 3600.0) * 1.0e8) + 1ull;
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	{
+		KernelTimer t(e, s, 1);
+		launch_solve(d, count, s);
+	}
+	AGX_HIP_CHECK(hipGetLastError());
+	return AGX_OK;
+}
 int agx_engine_select_solve_group(AgxEngine *e, int group, int n_groups, void *stream)
 {
 	if (e != nullptr && e->begun && e->speculative)
@@ -3355,8 +3410,9 @@ static int expand_stage(AgxEngine *e, int group, int n_groups, void *stream, boo
 		KernelTimer t(e, s, 2);
 		hipLaunchKernelGGL(k_expand, dim3(d.shared_tree ? 1 : count), dim3(64), 0, s, d);
 	}
-	if (service_arenas && !d.match_mode)
+	if (service_arenas && e->external_moves && !d.match_mode)
 	{ // a caller that makes the moves itself (set_board) never runs the advance stage: the trees that asked for larger arenas get them here
+	  // (a pool stepped through expand_group + advance_group — ag::Search::expand, then GameGenerator — has them serviced ONCE, by the advance stage)
 		const int trees = d.shared_tree ? 1 : count;
 		if (d.shared_tree)
 			d.g0 = 0;
@@ -3503,7 +3559,77 @@ int agx_engine_set_board(AgxEngine *e, int game, const uint8_t *h_board, int sig
 		hipLaunchKernelGGL(k_cancel_pending, dim3(1), dim3(64), 0, s, one);
 	}
 	hipLaunchKernelGGL(k_set_board, dim3(1), dim3(256), 0, s, e->dev, game, e->board_staging, sign_to_move);
+	e->external_moves = true;
 	AGX_HIP_CHECK(hipGetLastError());
+	return AGX_OK;
+}
+/* GeneratorThread::saveGames / loadGames (GeneratorManager.cpp:98-122) on the device pool: the games in flight as their move lists */
+int agx_engine_save_games(AgxEngine *e, AgxSavedGame *h_out, int capacity, int *count)
+{
+	AGX_REQUIRE(e != nullptr && count != nullptr, AGX_ERR_INVALID, "agx_engine_save_games: null argument");
+	AGX_REQUIRE(e->begun, AGX_ERR_STATE, "agx_engine_save_games: agx_engine_begin has not been called");
+	AGX_REQUIRE(!e->dev.match_mode && !e->dev.shared_tree, AGX_ERR_UNSUPPORTED, "agx_engine_save_games: self-play pools only");
+	AGX_HIP_CHECK(hipDeviceSynchronize());
+	std::vector<GameState> games(e->dev.n_games);
+	AGX_HIP_CHECK(hipMemcpy(games.data(), e->dev.games, games.size() * sizeof(GameState), hipMemcpyDeviceToHost));
+	int n = 0;
+	for (size_t g = 0; g < games.size(); g++)
+	{
+		const GameState &gs = games[g];
+		if (!gs.active || gs.outcome != 0 || gs.error != 0)
+			continue; // waiting for an opening, finished (its record is already in the pools) or stopped
+		if (h_out != nullptr)
+		{
+			AGX_REQUIRE(n < capacity, AGX_ERR_INVALID, "agx_engine_save_games: more than %d games in flight", capacity);
+			AgxSavedGame &o = h_out[n];
+			std::memset(&o, 0, sizeof(o));
+			o.game_slot = static_cast<int>(g);
+			o.game_index = gs.games_done;
+			o.opening_id = gs.opening_id;
+			o.sign_to_move = gs.sign_to_move;
+			o.nn_queued = gs.nn_queued;
+			o.n_moves = gs.n_moves;
+			for (int i = 0; i < gs.n_moves; i++)
+				o.moves[i] = gs.moves[i];
+		}
+		n++;
+	}
+	*count = n;
+	return AGX_OK;
+}
+int agx_engine_restore_game(AgxEngine *e, const AgxSavedGame *game, void *stream)
+{
+	AGX_REQUIRE(e != nullptr && game != nullptr, AGX_ERR_INVALID, "agx_engine_restore_game: null argument");
+	AGX_REQUIRE(e->begun, AGX_ERR_STATE, "agx_engine_restore_game: agx_engine_begin has not been called");
+	AGX_REQUIRE(!e->dev.match_mode && !e->dev.shared_tree, AGX_ERR_UNSUPPORTED, "agx_engine_restore_game: self-play pools only");
+	AGX_REQUIRE(game->game_slot >= 0 && game->game_slot < e->dev.n_games, AGX_ERR_INVALID, "agx_engine_restore_game: slot %d of %d", game->game_slot, e->dev.n_games);
+	AGX_REQUIRE(game->n_moves >= 0 && game->n_moves < e->dev.hw, AGX_ERR_INVALID, "agx_engine_restore_game: %d moves on a board of %d cells", game->n_moves, e->dev.hw);
+	std::vector<uint8_t> seen(e->dev.hw, 0);
+	for (int i = 0; i < game->n_moves; i++)
+	{
+		const uint32_t mv = game->moves[i];
+		const int sg = mv & 3, r = (mv >> 2) & 127, c = (mv >> 9) & 127;
+		AGX_REQUIRE((sg == 1 || sg == 2) && r < e->dev.n && c < e->dev.n && !seen[r * e->dev.n + c], AGX_ERR_INVALID,
+				"agx_engine_restore_game: move %d (0x%x) is not a stone on an empty cell", i, mv);
+		seen[r * e->dev.n + c] = 1;
+	}
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	if (e->moves_staging == nullptr)
+	{
+		AGX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e->moves_staging), MAXHW * sizeof(uint16_t)));
+		e->allocations.push_back(e->moves_staging);
+	}
+	AGX_HIP_CHECK(hipStreamSynchronize(s)); // (the staging buffer of the previous call may still be read)
+	AGX_HIP_CHECK(hipMemcpy(e->moves_staging, game->moves, sizeof(uint16_t) * std::max(1, game->n_moves), hipMemcpyHostToDevice));
+	hipLaunchKernelGGL(k_restore_game, dim3(1), dim3(256), 0, s, e->dev, game->game_slot, e->moves_staging, game->n_moves, game->opening_id, game->nn_queued);
+	AGX_HIP_CHECK(hipGetLastError());
+	return AGX_OK;
+}
+int agx_engine_set_batch_size(AgxEngine *e, int batch_size)
+{ // Search::setBatchSize (Search.cpp:252-255): the task buffers keep their capacity (max_batch_size), the select stage fills `batch_size` of it
+	AGX_REQUIRE(e != nullptr, AGX_ERR_INVALID, "agx_engine_set_batch_size: null engine");
+	AGX_REQUIRE(batch_size >= 1 && batch_size <= e->dev.batch, AGX_ERR_INVALID, "agx_engine_set_batch_size: %d outside [1, max_batch_size = %d]", batch_size, e->dev.batch);
+	e->dev.batch_limit = batch_size;
 	return AGX_OK;
 }
 int agx_engine_root_summary(AgxEngine *e, int game, void *stream, int *out4)
@@ -3679,6 +3805,8 @@ int agx_engine_game_info(AgxEngine *e, int game, AgxGameInfo *info, uint8_t *h_b
 	info->root_win = info->root_draw = 0.0f;
 	info->root_score = 0;
 	info->root_edges = 0;
+	info->root_moves_left = 0.0f;
+	info->max_depth = gs.max_depth;
 	if (h_board != nullptr)
 		std::memcpy(h_board, gs.board, e->dev.hw);
 	if (gs.root >= 0)
@@ -3691,6 +3819,7 @@ int agx_engine_game_info(AgxEngine *e, int game, AgxGameInfo *info, uint8_t *h_b
 		info->root_draw = root.draw;
 		info->root_score = root.score;
 		info->root_edges = root.n_edges;
+		info->root_moves_left = root.moves_left;
 		if (h_root_edges != nullptr)
 		{
 			AGX_REQUIRE(root.n_edges <= edge_capacity, AGX_ERR_INVALID, "agx_engine_game_info: %d root edges do not fit into %d", root.n_edges, edge_capacity);

@@ -115,7 +115,7 @@ namespace agx
 			                       // reserved, copy pending; 2 grown: the batch waits for expand (select / solve sit this step out); 4 the heap
 			                       // had no bundle left: expand proceeds in the old arenas
 			int32_t node_cap, edge_cap, ht_cap, grow_count;
-			int32_t grow_owner, pad_owner; // double-buffered search: first record of the buffer whose expansion asked for the larger arenas (it goes first afterwards)
+			int32_t grow_owner, max_depth; // max_depth: Tree::max_depth (Tree.cpp:150,249: longest path of a select that reached a leaf since the last setBoard); grow_owner: double-buffered search: first record of the buffer whose expansion asked for the larger arenas (it goes first afterwards)
 			uint64_t node_off[2], edge_off[2], ht_off;          // element offsets into EngineDev::nodes / edges / ht
 			uint64_t new_node_off[2], new_edge_off[2], new_ht_off; // the bundle reserved by k_arena_service (grow_pending == 3)
 			uint64_t root_hash;
@@ -201,12 +201,14 @@ namespace agx
 			// configuration
 			int rules, n, hw, draw_after;
 			int n_games, batch, max_sims;
+			int batch_limit; // Search::setBatchSize: leaves a select stage takes per game (<= batch, which stays the stride of the task buffers)
 			float c_puct, c_scale;
 			int init_to;
 			float leak_threshold, expansion_threshold;
 			int max_children;
 			float policy_temperature; // MCTSConfig::policy_temperature (initialize_edges, EdgeGenerator.cpp:88-127)
 			int tss_max_nodes, tss_max_depth;
+			unsigned long long solve_time_ticks; // 0 = no time limit; else Search::solve(endTime >= 0) (Search.cpp:159-183): the launch's budget in 100 MHz wall-clock ticks
 			unsigned long long zobrist_seed;
 			unsigned long long tt_bucket_mask; // buckets - 1 (4 entries of 16 bytes per bucket)
 			int node_cap, edge_cap, ht_cap, act_cap;

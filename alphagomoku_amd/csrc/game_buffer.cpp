@@ -22,8 +22,10 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <iterator>
 #include <map>
 #include <mutex>
 #include <string>
@@ -238,6 +240,175 @@ int agx_game_buffer_save(const AgxGameBuffer *b, const char *path, int compress)
 	AGX_REQUIRE(stream.good(), AGX_ERR_STATE, "agx_game_buffer_save: cannot open '%s'", path);
 	stream.write(to_save.data(), static_cast<std::streamsize>(to_save.size()));
 	AGX_REQUIRE(stream.good(), AGX_ERR_STATE, "agx_game_buffer_save: writing '%s' failed", path);
+	return AGX_OK;
+}
+
+/* GameDataBuffer::load (GameDataBuffer.cpp:115-131) for files written by agx_game_buffer_save (zlib stream or plain): the games are APPENDED.
+ * Outcome, length and sample count of a game are read back from its GameDataStorage bytes (format 201: u32 samples, the samples — each
+ * 16 + 6 * count bytes —, u32 moves, u16 per move, int outcome, int rows, int cols). */
+int agx_game_buffer_load(AgxGameBuffer *b, const char *path)
+{
+	AGX_REQUIRE(b != nullptr && path != nullptr, AGX_ERR_INVALID, "agx_game_buffer_load: null argument");
+	std::ifstream stream(path, std::ifstream::in | std::ifstream::binary);
+	AGX_REQUIRE(stream.good(), AGX_ERR_STATE, "agx_game_buffer_load: cannot open '%s'", path);
+	std::vector<char> raw((std::istreambuf_iterator<char>(stream)), std::istreambuf_iterator<char>());
+	AGX_REQUIRE(!raw.empty(), AGX_ERR_INVALID, "agx_game_buffer_load: '%s' is empty", path);
+	if (raw[0] != '{')
+	{ // a zlib stream: inflate into a growing buffer
+		std::vector<char> plain(std::max<size_t>(raw.size() * 4, 1 << 16));
+		while (true)
+		{
+			uLongf size = static_cast<uLongf>(plain.size());
+			const int z = uncompress(reinterpret_cast<Bytef*>(plain.data()), &size, reinterpret_cast<const Bytef*>(raw.data()), static_cast<uLong>(raw.size()));
+			if (z == Z_BUF_ERROR)
+			{
+				plain.resize(plain.size() * 2);
+				continue;
+			}
+			AGX_REQUIRE(z == Z_OK, AGX_ERR_INVALID, "agx_game_buffer_load: '%s' is neither a JSON header nor a zlib stream (zlib %d)", path, z);
+			plain.resize(size);
+			break;
+		}
+		raw.swap(plain);
+	}
+	const auto newline = std::find(raw.begin(), raw.end(), '\n');
+	AGX_REQUIRE(newline != raw.end(), AGX_ERR_INVALID, "agx_game_buffer_load: '%s' has no header line", path);
+	const std::string header(raw.begin(), newline);
+	AGX_REQUIRE(header.find("\"format\": 201") != std::string::npos, AGX_ERR_UNSUPPORTED, "agx_game_buffer_load: only dataset format 201 is read");
+	auto number_after = [&](const std::string &key, long long &out)
+	{
+		const size_t at = header.find(key);
+		if (at == std::string::npos)
+			return false;
+		out = std::atoll(header.c_str() + at + key.size());
+		return true;
+	};
+	long long rows = 0, cols = 0;
+	AGX_REQUIRE(number_after("\"rows\": ", rows) && number_after("\"cols\": ", cols) && rows == b->rows && cols == b->cols, AGX_ERR_INVALID,
+			"agx_game_buffer_load: '%s' holds %lldx%lld games, the buffer %dx%d", path, rows, cols, b->rows, b->cols);
+	AGX_REQUIRE(header.find(std::string("\"rules\": \"") + rules_name(b->rules) + "\"") != std::string::npos, AGX_ERR_INVALID,
+			"agx_game_buffer_load: '%s' was saved for other rules than %s", path, rules_name(b->rules));
+	std::vector<size_t> offsets;
+	{
+		const size_t at = header.find("\"offsets\": [");
+		AGX_REQUIRE(at != std::string::npos, AGX_ERR_INVALID, "agx_game_buffer_load: no offsets in the header");
+		const char *p = header.c_str() + at + 12;
+		while (*p != ']' && *p != 0)
+		{
+			char *end = nullptr;
+			const unsigned long long v = std::strtoull(p, &end, 10);
+			if (end == p)
+				break;
+			offsets.push_back(static_cast<size_t>(v));
+			p = end;
+			while (*p == ',' || *p == ' ')
+				p++;
+		}
+	}
+	const uint8_t *blob = reinterpret_cast<const uint8_t*>(&*newline) + 1;
+	const size_t blob_size = static_cast<size_t>(raw.end() - newline) - 1;
+	std::vector<std::vector<uint8_t>> games;
+	std::vector<int> outcomes, lengths, samples;
+	for (size_t i = 0; i < offsets.size(); i++)
+	{
+		const size_t begin = offsets[i], end = (i + 1 < offsets.size()) ? offsets[i + 1] : blob_size;
+		AGX_REQUIRE(begin + 20 <= end && end <= blob_size, AGX_ERR_INVALID, "agx_game_buffer_load: game %zu lies outside the file", i);
+		const uint8_t *g = blob + begin;
+		uint32_t n_samples = 0, n_moves = 0;
+		std::memcpy(&n_samples, g, 4);
+		size_t at = 4;
+		for (uint32_t k = 0; k < n_samples; k++)
+		{
+			AGX_REQUIRE(begin + at + agx::v201::HEADER_BYTES <= end, AGX_ERR_INVALID, "agx_game_buffer_load: game %zu is truncated", i);
+			uint32_t count = 0;
+			std::memcpy(&count, g + at + 12, 4);
+			at += agx::v201::HEADER_BYTES + static_cast<size_t>(agx::v201::ENTRY_BYTES) * count;
+		}
+		AGX_REQUIRE(begin + at + 4 <= end, AGX_ERR_INVALID, "agx_game_buffer_load: game %zu is truncated", i);
+		std::memcpy(&n_moves, g + at, 4);
+		at += 4 + 2 * static_cast<size_t>(n_moves);
+		AGX_REQUIRE(begin + at + 12 == end, AGX_ERR_INVALID, "agx_game_buffer_load: game %zu has %zu bytes where its layout needs %zu", i, end - begin, at + 12);
+		int outcome = 0;
+		std::memcpy(&outcome, g + at, 4);
+		games.emplace_back(g, g + (end - begin));
+		outcomes.push_back(outcome);
+		lengths.push_back(static_cast<int>(n_moves));
+		samples.push_back(static_cast<int>(n_samples));
+	}
+	std::lock_guard<std::mutex> lock(b->mutex);
+	for (size_t i = 0; i < games.size(); i++)
+	{
+		b->games.push_back(std::move(games[i]));
+		b->outcomes.push_back(outcomes[i]);
+		b->lengths.push_back(lengths[i]);
+		b->samples.push_back(samples[i]);
+	}
+	return AGX_OK;
+}
+
+/* The samples a game in flight has collected so far (GameDataStorage::serialize of GameGenerator::save, GameGenerator.cpp:127), as
+ * { i32 move number, u32 bytes, the format-201 sample } records; they are REMOVED from the buffer's pending list: the engine that produced
+ * them is about to be destroyed.  h_bytes NULL: only the size (nothing is removed). */
+int agx_game_buffer_take_pending(AgxGameBuffer *b, const AgxEngine *engine, int game_slot, int game_index, uint8_t *h_bytes, size_t capacity, size_t *size)
+{
+	AGX_REQUIRE(b != nullptr && size != nullptr, AGX_ERR_INVALID, "agx_game_buffer_take_pending: null argument");
+	std::lock_guard<std::mutex> lock(b->mutex);
+	*size = 0;
+	auto mine = b->pending.find(engine);
+	if (mine == b->pending.end())
+		return AGX_OK;
+	auto it = mine->second.find(std::make_pair(game_slot, game_index));
+	if (it == mine->second.end())
+		return AGX_OK;
+	std::vector<uint8_t> out;
+	for (const PendingSample &s : it->second.samples)
+	{
+		put<int32_t>(out, s.move_number);
+		put<uint32_t>(out, static_cast<uint32_t>(s.bytes.size()));
+		out.insert(out.end(), s.bytes.begin(), s.bytes.end());
+	}
+	*size = out.size();
+	if (h_bytes == nullptr)
+		return AGX_OK;
+	AGX_REQUIRE(capacity >= out.size(), AGX_ERR_INVALID, "agx_game_buffer_take_pending: %zu bytes do not fit into %zu", out.size(), capacity);
+	std::memcpy(h_bytes, out.data(), out.size());
+	mine->second.erase(it);
+	if (mine->second.empty())
+		b->pending.erase(mine);
+	return AGX_OK;
+}
+/* ... and handed back for the game that continues it in another engine (GameGenerator::load, GameGenerator.cpp:131-136) */
+int agx_game_buffer_restore_pending(AgxGameBuffer *b, const AgxEngine *engine, int game_slot, int game_index, const uint8_t *h_bytes, size_t size)
+{
+	AGX_REQUIRE(b != nullptr && engine != nullptr && (h_bytes != nullptr || size == 0), AGX_ERR_INVALID, "agx_game_buffer_restore_pending: null argument");
+	PendingGame game;
+	size_t at = 0;
+	while (at < size)
+	{
+		AGX_REQUIRE(at + 8 <= size, AGX_ERR_INVALID, "agx_game_buffer_restore_pending: truncated record");
+		int32_t move_number;
+		uint32_t bytes;
+		std::memcpy(&move_number, h_bytes + at, 4);
+		std::memcpy(&bytes, h_bytes + at + 4, 4);
+		at += 8;
+		AGX_REQUIRE(bytes >= static_cast<uint32_t>(agx::v201::HEADER_BYTES) && at + bytes <= size, AGX_ERR_INVALID, "agx_game_buffer_restore_pending: truncated sample");
+		PendingSample s;
+		s.move_number = move_number;
+		s.bytes.assign(h_bytes + at, h_bytes + at + bytes);
+		game.samples.push_back(std::move(s));
+		at += bytes;
+	}
+	std::lock_guard<std::mutex> lock(b->mutex);
+	PendingGame &slot = b->pending[engine][std::make_pair(game_slot, game_index)];
+	slot.samples.insert(slot.samples.begin(), game.samples.begin(), game.samples.end());
+	return AGX_OK;
+}
+/* forgets what an engine left pending (call before agx_engine_destroy: another engine may be created at the same address) */
+int agx_game_buffer_forget_engine(AgxGameBuffer *b, const AgxEngine *engine)
+{
+	AGX_REQUIRE(b != nullptr, AGX_ERR_INVALID, "agx_game_buffer_forget_engine: null buffer");
+	std::lock_guard<std::mutex> lock(b->mutex);
+	b->pending.erase(engine);
 	return AGX_OK;
 }
 

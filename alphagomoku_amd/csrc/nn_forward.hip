@@ -975,8 +975,12 @@ namespace
 	/*
 	 * Input block: bit-unpack + 5x5 convolution (Cin = 32) + bias + ReLU.  `in5` is the padded input plane
 	 * (stride S5, 64 bytes per position, chunk-swizzled by (index >> 2) & 3).
+	 * RAW (ResnetPVraw, networks.cpp:107-129: Cin = 8, the low byte of the feature word): a position is 16 bytes (8 halves) and one
+	 * MFMA's K = 32 carries FOUR horizontal taps x 8 channels — lane group q4 reads the cell q4 columns further right — so the 25 taps
+	 * are 5 rows x 2 column groups (dx 0-3, dx 4 + three zero-weight taps) = 10 k-steps instead of 25; no chunk swizzle (16 consecutive
+	 * positions x 16 bytes already cover all 64 banks once).
 	 */
-	template<int F, int ROWS, int COLS, bool INPLACE>
+	template<int F, int ROWS, int COLS, bool INPLACE, bool RAW>
 	__device__ __forceinline__ void conv5x5_input(const char *in5, char *dst, const half8 *__restrict__ wpk, const float *__restrict__ bias,
 			half4 *skip, int wave, int lane)
 	{
@@ -996,7 +1000,46 @@ namespace
 			for (int n = 0; n < G::NTW; n++)
 				acc[i][n] = floatx4 { 0.0f, 0.0f, 0.0f, 0.0f };
 
-		if constexpr (G::S == 16 && AGX_NN_ROW_STATIONARY && F == 64) // (128-filter nets keep the tap-major loop: measured 1 % faster, the 2 x 10 weight fragments in flight spill)
+		if constexpr (RAW)
+		{
+			int q0[G::NTW];
+	#pragma unroll
+			for (int n = 0; n < G::NTW; n++)
+			{
+				const int pos = G::S + G::tile_position(wave, n, r);
+				q0[n] = (pos / G::S - 1 + 2) * G::S5 + (pos % G::S + 2) + q4; // (dy = 0, dx = 0) cell of this lane's position, q4 columns on
+			}
+			const half8 *wp = wpk + (mg * G::MT) * 64 + lane;
+			half8 a_next[G::MT];
+	#pragma unroll
+			for (int i = 0; i < G::MT; i++)
+				a_next[i] = wp[i * 64];
+	#pragma unroll 1
+			for (int t = 0; t < 10; t++)
+			{ // t = 2 * dy + column group
+				const int off = (t / 2 - 2) * G::S5 + (4 * (t % 2) - 2);
+				half8 a[G::MT];
+	#pragma unroll
+				for (int i = 0; i < G::MT; i++)
+					a[i] = a_next[i];
+				const int tn = (t + 1 < 10) ? (t + 1) : 0;
+	#pragma unroll
+				for (int i = 0; i < G::MT; i++)
+					a_next[i] = wp[(tn * G::MTILES + i) * 64];
+	#pragma unroll
+				for (int n = 0; n < G::NTW; n++)
+					if (n < my_tiles)
+					{
+						int q = q0[n] + off;
+						q = (q < 0) ? 0 : ((q >= G::NPOS5) ? (G::NPOS5 - 1) : q); // dummy positions and the zero-weight taps of column group 1 only
+						const half8 b = *reinterpret_cast<const half8*>(in5 + q * 16);
+	#pragma unroll
+						for (int i = 0; i < G::MT; i++)
+							acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b, acc[i][n], 0, 0, 0);
+					}
+			}
+		}
+		else if constexpr (G::S == 16 && AGX_NN_ROW_STATIONARY && F == 64) // (128-filter nets keep the tap-major loop: measured 1 % faster, the 2 x 10 weight fragments in flight spill)
 		{
 			// Input-row stationary like conv3x3_mac_rows: for a column shift dx the fragment of padded input row j is read once and feeds the
 			// five taps dy = -2 .. 2 (output rows j + 2 .. j - 2): 5 x (NTW + 4) fragment reads instead of 25 x NTW, and — the padded plane being
@@ -1157,7 +1200,7 @@ namespace
 		return ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
 	}
 
-	template<int F, int ROWS, int COLS, bool INPLACE, bool QHEAD>
+	template<int F, int ROWS, int COLS, bool INPLACE, bool QHEAD, bool RAW = false>
 	__global__ __launch_bounds__(512, 2) void nn_tower_kernel(NetParams p, const uint32_t *__restrict__ features, float *__restrict__ policy,
 			float *__restrict__ value)
 	{
@@ -1216,7 +1259,7 @@ namespace
 			const int b = (p.slot_list != nullptr) ? p.slot_list[bi] : bi;
 			// ---- stage the bit-unpacked input into the padded plane (aliases plane_t) ----
 			__syncthreads();
-			for (int i = tid; i < G::NPOS5 * 4; i += G::THREADS)
+			for (int i = tid; i < G::NPOS5 * (RAW ? 1 : 4); i += G::THREADS)
 				reinterpret_cast<uint4*>(plane_t)[i] = zero4;
 			__syncthreads();
 			for (int c = tid; c < G::HW; c += G::THREADS)
@@ -1224,7 +1267,7 @@ namespace
 				const uint32_t word = features[static_cast<size_t>(b) * G::HW + c];
 				const int q = (c / COLS + 2) * G::S5 + (c % COLS + 2);
 #pragma unroll
-				for (int k = 0; k < 4; k++)
+				for (int k = 0; k < (RAW ? 1 : 4); k++)
 				{
 					const uint32_t bits = (word >> (8 * k)) & 255u;
 					uint4 v;
@@ -1232,12 +1275,15 @@ namespace
 					v.y = ((bits & 4u) ? 0x3C00u : 0u) | ((bits & 8u) ? 0x3C000000u : 0u);
 					v.z = ((bits & 16u) ? 0x3C00u : 0u) | ((bits & 32u) ? 0x3C000000u : 0u);
 					v.w = ((bits & 64u) ? 0x3C00u : 0u) | ((bits & 128u) ? 0x3C000000u : 0u);
-					*reinterpret_cast<uint4*>(plane_t + (q * 4 + (k ^ ((q >> 2) & 3))) * 16) = v;
+					if (RAW) // ml::unpackInput into 8 channels (AGNetwork.cpp:249-258): the low byte of the word, 16 bytes per position
+						*reinterpret_cast<uint4*>(plane_t + q * 16) = v;
+					else
+						*reinterpret_cast<uint4*>(plane_t + (q * 4 + (k ^ ((q >> 2) & 3))) * 16) = v;
 				}
 			}
 			__syncthreads();
 			AGX_NN_MARK(0);
-			conv5x5_input<F, ROWS, COLS, INPLACE>(plane_t, plane_x, p.w_in, p.bias, skip, wave, lane);
+			conv5x5_input<F, ROWS, COLS, INPLACE, RAW>(plane_t, plane_x, p.w_in, p.bias, skip, wave, lane);
 			__syncthreads();
 			AGX_NN_MARK(1);
 			if (!INPLACE)
@@ -1524,6 +1570,27 @@ namespace
 	}
 }
 
+namespace
+{
+	/* conv5x5 of an 8-channel input (ResnetPVraw) for conv5x5_input<.., RAW>: k-step t = 2 * dy + g holds the four horizontal taps
+	 * dx = 4 g + (lane >> 4) x 8 channels (taps beyond dx = 4 are zero): [10][cout / 16][lane][8] */
+	void pack_conv5x5_raw(const float *w, int cout, std::vector<half_t> &dst)
+	{
+		const int mtiles = cout / 16;
+		dst.assign(static_cast<size_t>(10) * mtiles * 512, static_cast<half_t>(0.0f));
+		for (int t = 0; t < 10; t++)
+			for (int mt = 0; mt < mtiles; mt++)
+				for (int lane = 0; lane < 64; lane++)
+				{
+					const int dy = t / 2, dx = 4 * (t % 2) + (lane >> 4);
+					if (dx >= 5)
+						continue;
+					for (int j = 0; j < 8; j++)
+						dst[((static_cast<size_t>(t) * mtiles + mt) * 64 + lane) * 8 + j] = static_cast<half_t>(w[(static_cast<size_t>(dy * 5 + dx) * 8 + j) * cout + mt * 16 + (lane & 15)]);
+				}
+	}
+}
+
 struct AgxNet
 {
 		AgxNetDesc desc;
@@ -1563,7 +1630,8 @@ namespace
 {
 	bool is_supported(const AgxNetDesc &d)
 	{
-		return ((d.rows == 15 && d.cols == 15) || (d.rows == 20 && d.cols == 20)) && (d.filters == 64 || d.filters == 128) && d.in_channels == 32 && d.blocks >= 0
+		return ((d.rows == 15 && d.cols == 15) || (d.rows == 20 && d.cols == 20)) && (d.filters == 64 || d.filters == 128) && d.blocks >= 0
+				&& (d.in_channels == 32 || (d.in_channels == 8 && d.action_values == 0)) // 8: ResnetPVraw (networks.cpp:107-129); the raw PVQ variant is off the path
 				&& d.value_hidden == ((2 * d.filters < 256) ? 2 * d.filters : 256) && (d.action_values == 0 || d.action_values == 1);
 	}
 	void free_net_buffers(AgxNet *net)
@@ -1614,7 +1682,7 @@ int agx_net_create(const AgxNetDesc *desc, AgxNet **out)
 {
 	AGX_REQUIRE(desc != nullptr && out != nullptr, AGX_ERR_INVALID, "agx_net_create: null argument");
 	AGX_REQUIRE(is_supported(*desc), AGX_ERR_UNSUPPORTED,
-			"agx_net_create: unsupported network %dx%d blocks=%d filters=%d cin=%d hidden=%d (supported: 15x15, F in {64,128}, cin 32)", desc->rows,
+			"agx_net_create: unsupported network %dx%d blocks=%d filters=%d cin=%d hidden=%d (supported: 15x15 / 20x20, F in {64,128}, cin 32, or cin 8 without the action-values head)", desc->rows,
 			desc->cols, desc->blocks, desc->filters, desc->in_channels, desc->value_hidden);
 	AgxNet *net = new AgxNet();
 	net->desc = *desc;
@@ -1641,7 +1709,10 @@ int agx_net_load_weights(AgxNet *net, const float *h_blob, size_t n_floats)
 	std::vector<half_t> w_in, w_tower, wv2;
 	std::vector<float> bias, wp2, wv1, bv2, wv3;
 
-	pack_conv(ptr, 25, C, F, w_in);
+	if (C == 8)
+		pack_conv5x5_raw(ptr, F, w_in);
+	else
+		pack_conv(ptr, 25, C, F, w_in);
 	ptr += 25 * C * F;
 	bias.insert(bias.end(), ptr, ptr + F);
 	ptr += F;
@@ -1802,10 +1873,11 @@ static int launch_forward(AgxNet *net, const uint32_t *d_features, const int *d_
 		p.skip = static_cast<half4*>(mine->skip);
 		p.vhead_x = static_cast<half_t*>(mine->vhead);
 	}
-	const bool big = (net->desc.rows == 20), wide = (net->desc.filters == 128), qhead = (p.q != nullptr);
+	const bool big = (net->desc.rows == 20), wide = (net->desc.filters == 128), qhead = (p.q != nullptr), raw = (net->desc.in_channels == 8);
 	const dim3 g(grid), t(512);
-#define AGX_LAUNCH_TOWER(FF, NN, IP, QH) hipLaunchKernelGGL((nn_tower_kernel<FF, NN, NN, IP, QH>), g, t, 0, s, p, d_features, d_policy, d_value)
-#define AGX_LAUNCH_HEADS(FF, NN, IP) do { if (qhead) AGX_LAUNCH_TOWER(FF, NN, IP, true); else AGX_LAUNCH_TOWER(FF, NN, IP, false); } while (0)
+#define AGX_LAUNCH_TOWER(FF, NN, IP, QH, RW) hipLaunchKernelGGL((nn_tower_kernel<FF, NN, NN, IP, QH, RW>), g, t, 0, s, p, d_features, d_policy, d_value)
+#define AGX_LAUNCH_HEADS(FF, NN, IP) do { if (qhead) AGX_LAUNCH_TOWER(FF, NN, IP, true, false); else if (raw) AGX_LAUNCH_TOWER(FF, NN, IP, false, true); \
+		else AGX_LAUNCH_TOWER(FF, NN, IP, false, false); } while (0)
 	if (net->inplace)
 	{
 		if (big && wide)

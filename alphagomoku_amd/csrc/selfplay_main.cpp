@@ -73,7 +73,7 @@ static void run_device(int device, int thread_index, const Options &o, AgxGameBu
 		selfplay.network_outputs = network.getOutputConfig();
 		selfplay.record_format = (buffer != nullptr) ? 2 : 1; // format-201 samples when the games go to a buffer
 		agx::GeneratorPool pool(game, selfplay, o.match != 0);
-		result.slices = o.match ? 1 : pool.useChipSlices(network, o.slices); // the pool as slices of the chip (agx.hpp)
+		result.slices = o.match ? 1 : pool.useChipSlices(network, o.slices, thread_index); // the pool as slices of the chip (agx.hpp); masked streams of its own per device thread
 		auto one_step = [&]() { if (o.match) pool.generate(network, second_network); else pool.generate(network); };
 		uint32_t next_seed = static_cast<uint32_t>(thread_index) * 1000003u; // disjoint openings per device thread
 		bool first_batch = true;

@@ -7,7 +7,7 @@ import ctypes
 
 import numpy as np
 
-from ._lib import (lib, check, AgxEngineConfig, AgxEngineBuffers, AgxEngineStats, AgxGameInfo, AgxEdgeView, AgxMoveRecord, AgxGameEnd,
+from ._lib import (lib, check, AgxEngineConfig, AgxEngineBuffers, AgxEngineStats, AgxGameInfo, AgxEdgeView, AgxMoveRecord, AgxGameEnd, AgxSavedGame,
                    AgxRecordCounts, AgxGameBufferStats)
 
 OPENING_CAP = 32
@@ -131,6 +131,36 @@ class GeneratorPool:
 
     def set_max_simulations(self, n):
         check(lib.agx_engine_set_max_simulations(self._h, int(n)))
+
+    def set_batch_size(self, n):
+        """Search::setBatchSize: leaves the select stage takes per game from now on (1 .. max_batch_size)"""
+        check(lib.agx_engine_set_batch_size(self._h, int(n)))
+
+    def select_group(self, group, n_groups, stream=None):
+        check(lib.agx_engine_select_group(self._h, group, n_groups, stream))
+
+    def solve_timed_group(self, group, n_groups, max_nodes, seconds, stream=None):
+        """Search::solve(endTime >= 0): node limit max_nodes, `seconds` of wall clock from the launch's start shared out over the leaves"""
+        check(lib.agx_engine_solve_timed_group(self._h, group, n_groups, int(max_nodes), float(seconds), stream))
+
+    def save_games(self):
+        """the games in flight (GeneratorThread::saveGames): list of dicts with game_slot, game_index, opening_id, sign_to_move, nn_queued, moves"""
+        n = ctypes.c_int()
+        check(lib.agx_engine_save_games(self._h, None, 0, ctypes.byref(n)))
+        arr = (AgxSavedGame * max(n.value, 1))()
+        check(lib.agx_engine_save_games(self._h, ctypes.cast(arr, ctypes.c_void_p), max(n.value, 1), ctypes.byref(n)))
+        return [dict(game_slot=g.game_slot, game_index=g.game_index, opening_id=g.opening_id, sign_to_move=g.sign_to_move, nn_queued=g.nn_queued,
+                     moves=[int(m) for m in g.moves[:g.n_moves]]) for g in arr[:n.value]]
+
+    def restore_game(self, saved, slot=None, stream=None):
+        """GameGenerator::load for one pool slot: the saved game continues there with an empty tree and solver table"""
+        g = AgxSavedGame()
+        g.game_slot = saved["game_slot"] if slot is None else slot
+        g.game_index, g.opening_id, g.sign_to_move, g.nn_queued = saved["game_index"], saved["opening_id"], saved["sign_to_move"], saved["nn_queued"]
+        g.n_moves = len(saved["moves"])
+        for i, m in enumerate(saved["moves"]):
+            g.moves[i] = m
+        check(lib.agx_engine_restore_game(self._h, ctypes.byref(g), stream))
 
     def select_solve_group(self, group, n_groups, stream=None):
         check(lib.agx_engine_select_solve_group(self._h, group, n_groups, stream))

@@ -58,7 +58,8 @@ typedef struct AgxNetDesc
 	int cols;           /* board cols */
 	int blocks;         /* residual blocks */
 	int filters;        /* conv filters F (64 or 128) */
-	int in_channels;    /* 32 (bit-packed features, NNInputFeatures.cpp:59-113) */
+	int in_channels;    /* 32 (bit-packed features, NNInputFeatures.cpp:59-113) or 8 (ResnetPVraw, networks.cpp:107-129: ml::unpackInput
+	                       expands the 8 low bits of the feature word, AGNetwork.cpp:249-258; without the action-values head) */
 	int value_hidden;   /* D = min(256, 2F) (blocks.cpp:113) */
 	int action_values;  /* 0: ResnetPV (outputs "pv", networks.cpp:71-93); 1: ResnetPVQ (:143-168) with the action-values head 'q' */
 } AgxNetDesc;
@@ -277,6 +278,8 @@ typedef struct AgxGameInfo
 	int root_edges;
 	int grow_pending; /* non-zero: the game's last batch waits for its expansion in larger arenas (one step later than a lock-step pool) */
 	int arena_class;  /* its tree arenas hold class-0 capacity << arena_class records */
+	float root_moves_left; /* Tree::getMovesLeft (Tree.cpp:173-176, :350): the root's running mean of the moves-left estimates backed up through it */
+	int max_depth;         /* Tree::getMaximumDepth (Tree.cpp:188-191): longest select path that reached a leaf since the last setBoard */
 } AgxGameInfo;
 
 typedef struct AgxMoveRecord
@@ -302,6 +305,14 @@ typedef struct AgxGameEnd
 	int n_moves;         /* Game::getMoves(): opening stones included */
 	uint16_t moves[400]; /* Move::toShort */
 } AgxGameEnd;
+
+typedef struct AgxSavedGame
+{ /* one game in flight, as GameGenerator::save keeps it (selfplay/GameGenerator.cpp:122-130: Game::serialize + the samples so far — the samples
+     stay with the AgxGameBuffer, see agx_game_buffer_take_pending): search trees are not checkpointed */
+	int game_slot, game_index;   /* the pool slot and the number of games it had finished (the key of the game's pending samples) */
+	int opening_id, sign_to_move, nn_queued, n_moves;
+	uint16_t moves[400];         /* Move::toShort, opening stones included */
+} AgxSavedGame;
 
 typedef struct AgxRecordCounts
 {
@@ -379,6 +390,9 @@ int agx_stream_synchronize(void* stream);
  * provided.  agx_engine_set_max_simulations: the budget Search::select(tree, maxSimulations) takes per call. */
 int agx_engine_set_board(AgxEngine* engine, int game, const uint8_t* h_board, int sign_to_move, void* stream);
 int agx_engine_set_max_simulations(AgxEngine* engine, int max_simulations);
+/* Search::setBatchSize (search/monte_carlo/Search.cpp:252-255; SearchThread.cpp:125-126 grows it with sqrt(simulations)): the number of leaves the
+ * select stage takes per game from the next launch on, 1 .. max_batch_size (the capacity the engine was created with) */
+int agx_engine_set_batch_size(AgxEngine* engine, int batch_size);
 /* Search::cleanup (search/monte_carlo/Search.cpp:233-242): the leaves that were selected but not expanded — in every task buffer, of every
  * tree of the engine — are dropped and their virtual losses taken back (Tree::cancelVirtualLoss, Tree.cpp:377-384).  agx_engine_set_board does
  * this for its game by itself; a caller that stops a double-buffered search (SearchThread.cpp:108-109) calls it before reading the tree. */
@@ -388,6 +402,18 @@ int agx_engine_cancel_pending(AgxEngine* engine, void* stream);
  * `stream` holds and waiting for THAT stream only — agx_engine_game_info synchronises the whole device, which would also wait for a network
  * launch running beside the search on another stream. */
 int agx_engine_root_summary(AgxEngine* engine, int game, void* stream, int* out4);
+/* GeneratorThread::saveGames / loadGames (selfplay/GeneratorManager.cpp:98-122, GameGenerator::save / load, GameGenerator.cpp:122-141) for a
+ * self-play pool: agx_engine_save_games lists the games in flight (h_out NULL: only counts them); agx_engine_restore_game, after
+ * agx_engine_begin, makes pool slot game_slot continue from the saved position with an empty tree and solver table (GameGenerator::load calls
+ * prepare_search on a fresh Tree) — the slot's game index starts again at 0 in the new pool. */
+int agx_engine_save_games(AgxEngine* engine, AgxSavedGame* h_out, int capacity, int* count);
+int agx_engine_restore_game(AgxEngine* engine, const AgxSavedGame* game, void* stream);
+/* Search::solve(endTime >= 0) (search/monte_carlo/Search.cpp:159-183, called by SearchThread::asynchronous_run, player/SearchThread.cpp:150,168): the
+ * solver's node limit becomes `max_nodes` (the reference: 10 000) and the leaves of the group's batches share `seconds` of wall-clock time from
+ * the start of the launch — leaf i of a batch gets (time left) / (batch size - i), a leaf whose time is over stops after the node it is in
+ * (AlphaBetaSearch.cpp:110-111,277).  seconds <= 0: every leaf gets its first node only.  Runs the serial solver (one wave per game) behind a
+ * select stage enqueued separately (agx_engine_select_group); results depend on the clock, like the reference's. */
+int agx_engine_solve_timed_group(AgxEngine* engine, int group, int n_groups, int max_nodes, double seconds, void* stream);
 int agx_engine_set_force_expand_root(AgxEngine* engine, int force_expand_root); /* AgxEngineConfig.force_expand_root, for the launches that follow */
 int agx_engine_buffers(AgxEngine* engine, AgxEngineBuffers* out);
 int agx_engine_stats(AgxEngine* engine, AgxEngineStats* out);
@@ -459,6 +485,17 @@ int agx_game_buffer_game(const AgxGameBuffer* buffer, int index, uint8_t* h_byte
 /* GameDataBuffer::save: {"format": 201, "config": {...}, "offsets": [...]} + newline + the games' bytes; compress != 0 wraps the file in
  * a zlib stream (the reference compresses with MinML's ZipWrapper, whose format is not in the reference tree). */
 int agx_game_buffer_save(const AgxGameBuffer* buffer, const char* path, int compress);
+/* GameDataBuffer::load (dataset/GameDataBuffer.cpp:115-131; called by GeneratorManager::loadState, GeneratorManager.cpp:263-275) for files written
+ * by agx_game_buffer_save, compressed or not: the games are appended to the buffer */
+int agx_game_buffer_load(AgxGameBuffer* buffer, const char* path);
+/* Checkpoints of games in flight (GameGenerator::save / load, selfplay/GameGenerator.cpp:122-141): the format-201 samples a game has collected
+ * so far wait in the buffer, keyed by (engine, game_slot, game_index), until its AgxGameEnd arrives.  take_pending serialises and removes
+ * them ({ i32 move number, u32 bytes, sample } records; h_bytes NULL: size only, nothing removed); restore_pending hands them to the game that
+ * continues it in another engine (agx_engine_restore_game: game_index 0); forget_engine drops whatever an engine that is about to be destroyed
+ * left pending. */
+int agx_game_buffer_take_pending(AgxGameBuffer* buffer, const AgxEngine* engine, int game_slot, int game_index, uint8_t* h_bytes, size_t capacity, size_t* size);
+int agx_game_buffer_restore_pending(AgxGameBuffer* buffer, const AgxEngine* engine, int game_slot, int game_index, const uint8_t* h_bytes, size_t size);
+int agx_game_buffer_forget_engine(AgxGameBuffer* buffer, const AgxEngine* engine);
 /* Host-only reader of one format-201 sample (SearchDataStorage_v201's parsing constructor + storeTo, dataset/SearchDataStorage.cpp:
  * 300-320,375-409): per cell visits int32[rows*cols], prior float[rows*cols], value float[rows*cols][2] = (win, draw), score
  * uint16[rows*cols]; header int[3] = (minimax score raw bits, move number, flags); minimax_value float[2].  consumed may be NULL. */

@@ -19,6 +19,7 @@
 #include <cstdint>
 #include <stdexcept>
 #include <string>
+#include <atomic>
 #include <vector>
 
 namespace agx
@@ -209,8 +210,12 @@ namespace agx
 			 * (agx_stream_create_with_cu_mask), with the network's persistent grid narrowed to a slice: the slices run out of phase, the
 			 * power-limited network launches never cover the whole chip at once (+10 % simulations/s on MI355X with 4 slices).  Returns the
 			 * slice count in use (1 if the pool cannot be divided or the device offers no CU masks).  Self-play pools only. */
-			int useChipSlices(AGNetwork &network, int slices)
-			{
+			int useChipSlices(AGNetwork &network, int slices, int instance = -1)
+			{ // instance: which set of masked streams (they are cached per device, mask and instance): pools that run at the same time on one device
+			  // must not share a queue — by default every call takes a set of its own
+				static std::atomic<int> next_instance { 0 };
+				if (instance < 0)
+					instance = next_instance.fetch_add(1);
 				m_slice_streams.clear();
 				int cus = 0;
 				if (m_match || slices <= 1 || slices > 16 || m_games % slices != 0 || agx_device_cu_count(&cus) != AGX_OK || cus < slices)
@@ -222,7 +227,7 @@ namespace agx
 					for (int c = g * per; c < (g + 1) * per; c++)
 						mask[c / 32] |= 1u << (c % 32);
 					void *s = nullptr;
-					if (agx_stream_create_with_cu_mask(&s, mask.data(), static_cast<int>(mask.size())) != AGX_OK)
+					if (agx_stream_create_with_cu_mask_instance(&s, mask.data(), static_cast<int>(mask.size()), instance) != AGX_OK)
 					{
 						m_slice_streams.clear();
 						return 1;

@@ -57,7 +57,7 @@ namespace ag
 			int launched = 0;
 		public:
 			AGNetwork() noexcept = default;
-			/* architecture "ResnetPV" (outputs "pv") or "ResnetPVQ" ("pvq") */
+			/* architecture "ResnetPV" / "ResnetPVraw" (outputs "pv"; the raw network reads the 8 low bits of a feature word) or "ResnetPVQ" ("pvq") */
 			AGNetwork(const GameConfig &gameOptions, const std::string &architecture, int blocks, int filters);
 			AGNetwork(const AGNetwork &other) = delete;
 			AGNetwork& operator=(const AGNetwork &other) = delete;

@@ -18,6 +18,7 @@
 #include <chrono>
 #include <cstdint>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -306,6 +307,9 @@ namespace ag
 			};
 			void *own_stream = nullptr;            // asyncEvaluateGraphLaunch's stream for double-buffered searches
 			void *scheduled_event[2] = { nullptr, nullptr }, *done_event[2] = { nullptr, nullptr };
+			AgxTimer *network_timer[2] = { nullptr, nullptr }; // event pairs around the overlapped network launches (one per task buffer)
+			bool network_timer_used[2] = { false, false };
+			double network_seconds = 0.0;                  // smoothed device time of such a launch: the estimate asyncEvaluateGraphLaunch returns
 			std::vector<TaskData> waiting_queue;
 			std::vector<TaskData> in_progress_queue;
 			std::vector<SliceData> waiting_slices;
@@ -415,9 +419,56 @@ namespace ag
 	 *    (Player::setBoard starts with search.cleanup(tree)).
 	 *  - Tree(GamePool&, group, n_groups, stream) — the trees of a slice of a generator thread's pool; the per-game accessors take the game's
 	 *    index within the slice. */
+	/* utils/PriorityMutex.hpp:15-70: the tree lock of the tournament engine.  Search threads take it with low priority, the thread that
+	 * wants the tree for itself (SearchEngine reading the result, setting a position) with high priority: it passes every queued
+	 * low-priority waiter.  Three plain mutexes — the gate (`next`) that a high-priority locker only holds while it takes `data`, and the
+	 * queue (`low`) that lets only one low-priority locker at a time compete at the gate. */
+	class PriorityMutex
+	{
+			std::mutex data, next, low;
+		public:
+			void lockHigh()
+			{
+				std::lock_guard<std::mutex> gate(next);
+				data.lock();
+			}
+			void unlockHigh() { data.unlock(); }
+			void lockLow()
+			{
+				low.lock();
+				std::lock_guard<std::mutex> gate(next);
+				data.lock();
+			}
+			void unlockLow()
+			{
+				data.unlock();
+				low.unlock();
+			}
+	};
+	class HighPriorityLock
+	{
+			PriorityMutex *m;
+		public:
+			explicit HighPriorityLock(PriorityMutex &pm) : m(&pm) { m->lockHigh(); }
+			HighPriorityLock(HighPriorityLock &&other) noexcept : m(other.m) { other.m = nullptr; }
+			HighPriorityLock(const HighPriorityLock&) = delete;
+			HighPriorityLock& operator=(const HighPriorityLock&) = delete;
+			~HighPriorityLock() { if (m != nullptr) m->unlockHigh(); }
+	};
+	class LowPriorityLock
+	{
+			PriorityMutex *m;
+		public:
+			explicit LowPriorityLock(PriorityMutex &pm) : m(&pm) { m->lockLow(); }
+			LowPriorityLock(LowPriorityLock &&other) noexcept : m(other.m) { other.m = nullptr; }
+			LowPriorityLock(const LowPriorityLock&) = delete;
+			LowPriorityLock& operator=(const LowPriorityLock&) = delete;
+			~LowPriorityLock() { if (m != nullptr) m->unlockLow(); }
+	};
+
 	class Tree
 	{
-			GamePool *pool = nullptr;
+		GamePool *pool = nullptr;
 			int group = 0, n_groups = 1;
 			void *stream = nullptr;
 			int first_game = 0, game_count = 1;
@@ -430,6 +481,7 @@ namespace ag
 			 * network launch on the evaluator's stream runs on: the double-buffered loop, player/SearchThread.cpp:148-199) */
 			mutable int summary[4] = { 0, 0, 0, 0 };
 			mutable bool summary_valid = false;
+			mutable PriorityMutex tree_mutex; // Tree.hpp:52 (host threads that share this Tree object; the device serialises its own work per stream)
 			const int* root_summary() const;
 			friend class Search;
 			GamePool& bound() const;
@@ -440,7 +492,8 @@ namespace ag
 			int numberOfGames() const noexcept { return game_count; }
 			int firstGame() const noexcept { return first_game; }
 
-			/* Tree.hpp:72-74 (a stand-alone tree) */
+			/* Tree.hpp:70-74 (a stand-alone tree).  clear() (Tree.cpp:124-127: node_cache.clear()) empties the tree; the position stays. */
+			void clear();
 			void setBoard(const matrix<Sign> &newBoard, Sign signToMove, bool forceRemoveRootNode = false);
 			void setEdgeSelector(const EdgeSelector &selector);
 			void setEdgeGenerator(const EdgeGenerator &generator);
@@ -455,11 +508,24 @@ namespace ag
 			float getExpectation(int game = 0) const;
 			Sign getSignToMove(int game = 0) const;
 			const matrix<Sign>& getBoard() const;
-			std::vector<Sign> getBoard(int game) const;
+			matrix<Sign> getBoard(int game) const;
+			/* Tree.hpp:79,83,85-87 — getMovesLeft reads the root's running mean (the reference returns the value the last backup left, Tree.cpp:350:
+			 * the same number between a backup and the next setBoard) */
+			float getMovesLeft(int game = 0) const;
+			int getMaximumDepth(int game = 0) const;
+			bool hasAllMovesProven(int game = 0) const;
+			bool hasSingleMove(int game = 0) const;
+			bool hasSingleNonLosingMove(int game = 0) const;
 			Node getInfo(const std::vector<Move> &moves) const; // Tree::getInfo({}) (Tree.cpp:403-424): an owning copy of the root
 			Node getInfo(int game, const std::vector<Move> &moves = { }) const;
+			void clearNodeCacheStats() noexcept; // Tree.cpp:425-428: the device keeps peaks per game since agx_engine_begin; this forgets what was reported so far
 			NodeCacheStats getNodeCacheStats() const noexcept;
-	};
+			/* Tree.hpp:102-103: guards for HOST threads sharing the Tree object (player/SearchThread.cpp:94,107,126,137,155) */
+			LowPriorityLock low_priority_lock() const;
+			HighPriorityLock high_priority_lock() const;
+			private:
+			NodeCacheStats stats_baseline;
+			};
 
 	/* stand-in for the solver handle Search::getSolver returns (Search.hpp:74): the alpha-beta solver lives inside the device's solve stage; what
 	 * callers do with the handle is clear() it at the start of a game (EvaluationGame.cpp:81-82) */

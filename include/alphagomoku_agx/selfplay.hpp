@@ -54,6 +54,7 @@ namespace ag
 			int numberOfSamples() const noexcept;
 			std::vector<uint8_t> getGameData(int index) const; // GameDataStorage::serialize bytes
 			void save(const std::string &path) const;
+			void load(const std::string &path); // GameDataBuffer.cpp:115-131: appends the games of a file written by save()
 			GameDataBufferStats getStats() const noexcept;
 			AgxGameBuffer* handle() const noexcept
 			{
@@ -103,7 +104,13 @@ namespace ag
 			SearchStats getSearchStats() const noexcept;
 
 			Status generate();
-		private:
+			/* GameGenerator.cpp:122-141: the games of this generator that are in flight — their moves so far and the samples collected so far; search
+			 * trees are not saved, load() gives every restored game a fresh one (prepare_search).  The reference writes Json + SerializedObject
+			 * (MinML); here both travel in one byte vector: u32 count, then per game an AgxSavedGame, u64 n, n bytes of samples.  load() returns the
+			 * offset behind what it read; games whose slot lies outside this generator's slice are skipped. */
+			void save(std::vector<uint8_t> &binary_data);
+			size_t load(const std::vector<uint8_t> &binary_data, size_t offset = 0);
+			private:
 			void make_move();
 			void prepare_search();
 	};
@@ -126,6 +133,7 @@ namespace ag
 			mutable std::mutex stats_mutex;
 			SearchStats last_search_stats;
 			NodeCacheStats last_cache_stats;
+			std::vector<uint8_t> saved_games; // the games in flight when run() ended (GameGenerator::save of every slice), or what loadGames read
 		public:
 			GeneratorThread(GeneratorManager &manager, const GameConfig &gameOptions, const SelfplayConfig &selfplayOptions, int index);
 			~GeneratorThread();
@@ -139,6 +147,9 @@ namespace ag
 			SearchStats getSearchStats() const noexcept;
 			/* hands the samples and finished games of this thread's pool to the manager's buffer (GeneratorManager::addToBuffer) */
 			void collectGames();
+			/* GeneratorManager.cpp:98-122: the games that were in flight when the thread stopped, to / from `path`; the next start() continues them */
+			void saveGames(const std::string &path) const;
+			void loadGames(const std::string &path);
 		private:
 			void run();
 			void setup();

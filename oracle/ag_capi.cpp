@@ -759,6 +759,32 @@ int ago_game_root(void *h, int *root_visits, float *root_value, uint16_t *root_s
 	return r.n_edges;
 }
 
+/* Tree::getMovesLeft / getMaximumDepth / hasAllMovesProven / hasSingleMove / hasSingleNonLosingMove / getNodeCount (Tree.cpp:173-224):
+ * out_f[0] = moves left of the root, out_i = { max depth, all moves proven, single move, single non-losing move, stored nodes } */
+void ago_game_tree_info(void *h, float *out_f, int *out_i)
+{
+	Game &g = static_cast<GameHandle*>(h)->game;
+	out_f[0] = 0.0f;
+	out_i[0] = g.tree.max_depth;
+	out_i[1] = out_i[2] = out_i[3] = 0;
+	out_i[4] = static_cast<int>(g.tree.nodes.size());
+	if (g.tree.root < 0)
+		return;
+	const Node &r = g.tree.nodes[g.tree.root];
+	out_f[0] = r.moves_left; // Tree.cpp:350 (the root's value after the last backup; the device reads the root record)
+	bool all_proven = true;
+	int non_losing = 0;
+	for (int i = 0; i < r.n_edges; i++)
+	{
+		const Edge &e = g.tree.edges[r.edge_begin + i];
+		all_proven = all_proven && e.score.is_proven();
+		non_losing += e.score.is_loss() ? 0 : 1;
+	}
+	out_i[1] = all_proven ? 1 : 0;
+	out_i[2] = (r.n_edges == 1) ? 1 : 0;
+	out_i[3] = (non_losing == 1) ? 1 : 0;
+}
+
 /*
  * CPU baseline: plays `games_per_thread` self-play games on each of `threads` host threads with the stand-in evaluator
  * (network cost = 0), for at most `max_seconds`; returns evaluated nodes, completed games and moves made.

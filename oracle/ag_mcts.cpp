@@ -91,6 +91,7 @@ namespace ago
 		root = seek(board, to_move);
 		if (root >= 0)
 			nodes[root].flags |= 2; // markAsRoot
+		max_depth = 0; // Tree.cpp:150
 	}
 	bool Tree::has_information_leak(const Edge &e, int node) const
 	{ // Tree.cpp:75-85
@@ -319,6 +320,7 @@ namespace ago
 			if (has_information_leak(edges[e], node))
 				return 1;
 		}
+		max_depth = std::max(max_depth, static_cast<int>(t.path.size())); // Tree.cpp:249
 		return 0;
 	}
 	void Tree::generate_edges(Task &t) const

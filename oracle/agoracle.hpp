@@ -500,6 +500,7 @@ namespace ago
 			std::vector<Sign> base_board;
 			Sign sign_to_move = NONE;
 			int root = -1;
+			int max_depth = 0;                                // Tree.cpp:150,249: longest select path that reached a leaf since the last setBoard
 			void clear();
 			void set_board(const Sign *board, Sign to_move);  // Tree.cpp:128-151 + NodeCache.cpp:221-249
 			int seek(const Sign *board, Sign to_move) const;  // NodeCache.cpp:250-264

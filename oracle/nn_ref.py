@@ -1,7 +1,8 @@
 """
 oracle/nn_ref.py — TEST INFRASTRUCTURE ONLY (never imported by the product path).
 
-fp32 numpy restatement of the ResnetPV forward pass: layer definitions from the reference
+fp32 numpy restatement of the ResnetPV / ResnetPVraw (in_channels = 8, networks.cpp:107-129) / ResnetPVQ forward pass, plus an
+fp16-storage mode with the device kernel's rounding points (forward(..., storage="fp16")): layer definitions from the reference
 src/networks/blocks.cpp:32-38 (input block: conv5x5 no bias + BN(relu, no gamma)), :45-55 (residual block:
 conv3x3+BN relu, conv3x3+BN linear, Add relu), :99-107 (policy head: conv3x3+BN relu, conv1x1 F->1 with bias,
 softmax over H*W), :108-118 (value head: conv1x1 F->4 + BN relu, Dense 4HW->D + BN relu, Dense D->3 with bias,
@@ -66,32 +67,44 @@ def softmax(x, axis):
     return e / e.sum(axis=axis, keepdims=True)
 
 
-def forward(desc, blob, features):
-    """Returns (policy [B, HW], value [B, 3] = (win, draw, loss)) in float32."""
+def forward(desc, blob, features, storage="fp32"):
+    """Returns (policy [B, HW], value [B, 3] = (win, draw, loss)) in float32.
+
+    storage="fp16" restates the reference's INFERENCE precision (AGNetwork::convertToHalfFloats, AGNetwork.cpp:136-160: fp16 weights
+    and activations, fp32 accumulation) with the rounding points of the device kernel: convolution / dense weights that feed the
+    matrix cores are fp16, every activation plane is rounded to fp16 after bias (+ residual) + ReLU / tanh, accumulation and biases
+    stay fp32, the 1x1 policy / action-value convolutions and the last dense layer keep fp32 weights, softmax in fp32.  Comparing the
+    device against THIS mode separates kernel errors (order of fp32 additions only: ~1e-4) from the precision format's own rounding
+    (which the fp32 mode measures)."""
     rows, cols = desc["rows"], desc["cols"]
     parts = split_blob(desc, blob)
     it = iter(parts)
+    half = (storage == "fp16")
+    assert storage in ("fp32", "fp16")
+
+    def q(a):  # round to fp16 storage
+        return np.asarray(a, dtype=np.float32).astype(np.float16).astype(np.float32) if half else a
     x = unpack_input(features, rows, cols, desc["in_channels"])
-    x = relu(conv2d_same(x, next(it), next(it)))
+    x = q(relu(conv2d_same(x, q(next(it)), next(it))))
     for _ in range(desc["blocks"]):
-        w1, b1, w2, b2 = next(it), next(it), next(it), next(it)
-        y = relu(conv2d_same(x, w1, b1))
+        w1, b1, w2, b2 = q(next(it)), next(it), q(next(it)), next(it)
+        y = q(relu(conv2d_same(x, w1, b1)))
         y = conv2d_same(y, w2, b2)
-        x = relu(x + y)
-    wp1, bp1, wp2, bp2 = next(it), next(it), next(it), next(it)
-    p = relu(conv2d_same(x, wp1, bp1))
+        x = q(relu(x + y))
+    wp1, bp1, wp2, bp2 = q(next(it)), next(it), next(it), next(it)
+    p = q(relu(conv2d_same(x, wp1, bp1)))
     logits = np.tensordot(p, wp2, axes=([3], [0])) + bp2[0]
     policy = softmax(logits.reshape(logits.shape[0], -1), axis=1)
-    wv1, bv1, wv2, bv2, wv3, bv3 = next(it), next(it), next(it), next(it), next(it), next(it)
-    v = relu(np.tensordot(x, wv1, axes=([3], [0])) + bv1.reshape(1, 1, 1, 4))
+    wv1, bv1, wv2, bv2, wv3, bv3 = q(next(it)), next(it), q(next(it)), next(it), next(it), next(it)
+    v = q(relu(np.tensordot(x, wv1, axes=([3], [0])) + bv1.reshape(1, 1, 1, 4)))
     v = v.reshape(v.shape[0], -1)
     h = relu(v @ wv2 + bv2)
     value = softmax(h @ wv3 + bv3, axis=1)
     if desc.get("action_values", 0):
         # createActionValuesHead (blocks.cpp:119-127): conv3x3 + BN(tanh), conv1x1 F->3 with bias, softmax over the last axis;
         # the search keeps (win, draw) of every cell (NetworkDataPack::unpackActionValues, NetworkDataPack.cpp:214-224)
-        wq1, bq1, wq2, bq2 = next(it), next(it), next(it), next(it)
-        t = np.tanh(conv2d_same(x, wq1, bq1))
-        q = softmax(np.tensordot(t, wq2, axes=([3], [0])) + bq2.reshape(1, 1, 1, 3), axis=3)
-        return policy.astype(np.float32), value.astype(np.float32), q.reshape(q.shape[0], -1, 3)[:, :, :2].astype(np.float32)
+        wq1, bq1, wq2, bq2 = q(next(it)), next(it), next(it), next(it)
+        t = q(np.tanh(conv2d_same(x, wq1, bq1)))
+        qv = softmax(np.tensordot(t, wq2, axes=([3], [0])) + bq2.reshape(1, 1, 1, 3), axis=3)
+        return policy.astype(np.float32), value.astype(np.float32), qv.reshape(qv.shape[0], -1, 3)[:, :, :2].astype(np.float32)
     return policy.astype(np.float32), value.astype(np.float32)

@@ -14,14 +14,18 @@
  */
 #include "../../include/alphagomoku_agx/selfplay.hpp"
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <iostream>
+#include <cmath>
 #include <map>
+#include <mutex>
 #include <sstream>
+#include <thread>
 
 using namespace ag;
 
@@ -286,17 +290,22 @@ static int mode_player(const std::map<std::string, std::string> &a)
 	return 0;
 }
 
-/* player/SearchThread.cpp:121-199 call for call, without the host threads around it (one SearchThread; the tree's PriorityMutex has nobody
- * to keep out): serial_run, asynchronous_run with useBuffer / switchBuffer and asyncEvaluateGraphLaunch / Join, the stop condition on the
- * simulation and node counts.  get_batch_size is the reference's (the square root of the simulation count, capped) only with --sqrt-batch:
- * the device's buffers have the engine's fixed batch size. */
+/* player/SearchThread.cpp:84-199 as written: the lock scopes on the tree's PriorityMutex (Tree::low_priority_lock), get_batch_size (the square
+ * root of the simulation count, capped) into Search::setBatchSize, serial_run, asynchronous_run with useBuffer / switchBuffer,
+ * asyncEvaluateGraphLaunch / Join and the launch's estimated end time as the deadline of Search::solve, is_running under search_mutex, the stop
+ * condition on the simulation and node counts.  Two switches exist for the replayable parity run only (clock-independent results):
+ * --fixed-batch 1 and --solve-deadline 0. */
 class SearchThread
 {
 		Tree &tree;
 		Search search;
 		int max_simulations, max_nodes;
 		int iterations = 0;
+		mutable std::mutex search_mutex; // SearchThread.hpp: guards is_running
+		bool is_running = true;
 	public:
+		bool fixed_batch = false;    // --fixed-batch 1: max_batch_size in every iteration (the replayable procedure of the parity test)
+		bool solve_deadline = true;  // --solve-deadline 0: Search::solve without the end time of the network launch
 		SearchThread(const GameConfig &gameOptions, const SearchConfig &searchOptions, Tree &tree, int maxSimulations, int maxNodes) :
 				tree(tree), search(gameOptions, searchOptions), max_simulations(maxSimulations), max_nodes(maxNodes)
 		{
@@ -314,59 +323,99 @@ class SearchThread
 			tree.setEdgeGenerator(UnifiedGenerator(mcts_config.max_children, mcts_config.policy_expansion_threshold, mcts_config.policy_temperature));
 		}
 		void run(NNEvaluator &evaluator, bool asynchronous)
-		{ // SearchThread.cpp:84-112
+		{ // SearchThread.cpp:87-112
 			search.clearStats();
 			iterations = 0;
-			if (isStopConditionFulfilled())
-				return;
+			{ /* artificial scope for lock */
+				LowPriorityLock lock = tree.low_priority_lock();
+				if (isStopConditionFulfilled())
+					return;
+			}
 			if (asynchronous)
 				asynchronous_run(evaluator);
 			else
 				serial_run(evaluator);
+			LowPriorityLock lock = tree.low_priority_lock();
 			search.cleanup(tree);
 		}
+		void stop() noexcept
+		{
+			std::lock_guard<std::mutex> lock(search_mutex);
+			is_running = false;
+		}
 	private:
+		static int get_batch_size(int simulation_count, int max_batch_size) noexcept
+		{ // SearchThread.cpp:23-27: doubling the batch size for every 4x increase of the simulation count
+			const int tmp = static_cast<int>(std::sqrt(simulation_count));
+			return std::max(1, std::min(max_batch_size, tmp));
+		}
 		void serial_run(NNEvaluator &evaluator)
 		{ // SearchThread.cpp:121-146
 			while (true)
 			{
-				search.setBatchSize(search.getConfig().max_batch_size);
-				search.select(tree, max_simulations);
+				{ /* artificial scope for lock */
+					LowPriorityLock lock = tree.low_priority_lock();
+					const int batch_size = fixed_batch ? search.getConfig().max_batch_size : get_batch_size(tree.getSimulationCount(), search.getConfig().max_batch_size);
+					search.setBatchSize(batch_size);
+					search.select(tree, max_simulations);
+				}
 				search.solve();
 				search.scheduleToNN(evaluator);
 				evaluator.evaluateGraph();
 
-				search.generateEdges(tree);
-				search.expand(tree);
-				search.backup(tree);
-				iterations++;
-				if (isStopConditionFulfilled())
+				search.generateEdges(tree); // this step doesn't require locking the tree
+				{ /* artificial scope for lock */
+					LowPriorityLock lock = tree.low_priority_lock();
+					search.expand(tree);
+					search.backup(tree);
+					iterations++;
+					if (isStopConditionFulfilled())
+						break;
+				}
+				std::lock_guard<std::mutex> lock(search_mutex);
+				if (is_running == false)
 					break;
 			}
 		}
 		void asynchronous_run(NNEvaluator &evaluator)
 		{ // SearchThread.cpp:148-180
 			search.useBuffer(0);
-			double end_time = 0.0;
+			double end_time = solve_deadline ? now() + 0.1 : -1.0;
 			while (true)
 			{
-				search.generateEdges(tree);
-				search.expand(tree);
-				search.backup(tree);
-				iterations++;
-				if (isStopConditionFulfilled())
-					break;
-				search.setBatchSize(search.getConfig().max_batch_size);
-				search.select(tree, max_simulations);
+				search.generateEdges(tree); // this step doesn't require locking the tree
 
+				{ /* artificial scope for lock */
+					LowPriorityLock lock = tree.low_priority_lock();
+					search.expand(tree);
+					search.backup(tree);
+					iterations++;
+
+					if (isStopConditionFulfilled())
+						break;
+
+					const int batch_size = fixed_batch ? search.getConfig().max_batch_size : get_batch_size(tree.getSimulationCount(), search.getConfig().max_batch_size);
+					search.setBatchSize(batch_size);
+					search.select(tree, max_simulations);
+				}
 				search.solve(end_time);
 				search.scheduleToNN(evaluator);
 				evaluator.asyncEvaluateGraphJoin();
 
 				end_time = evaluator.asyncEvaluateGraphLaunch();
+				if (!solve_deadline)
+					end_time = -1.0; // --solve-deadline 0: the solver keeps its ordinary node budget, so that the run can be replayed move for move
 				search.switchBuffer();
+
+				std::lock_guard<std::mutex> lock(search_mutex);
+				if (is_running == false)
+					break;
 			}
 			evaluator.asyncEvaluateGraphJoin();
+		}
+		static double now()
+		{ // getTime() (utils/misc.hpp:52-55)
+			return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 		}
 		bool isStopConditionFulfilled() const
 		{ // SearchThread.cpp:181-199 (the memory limit is the node limit here: flat arenas)
@@ -399,6 +448,8 @@ static int mode_thread(const std::map<std::string, std::string> &a)
 	evaluator.useSymmetries(false);
 	Tree tree(search_config.tree_config);
 	SearchThread thread(game_config, search_config, tree, sims, 1 << 30);
+	thread.fixed_batch = geti(a, "--fixed-batch", 0) != 0;
+	thread.solve_deadline = geti(a, "--solve-deadline", 1) != 0;
 
 	matrix<Sign> board(n, n);
 	board.fill(Sign::NONE);
@@ -449,6 +500,102 @@ static int mode_thread(const std::map<std::string, std::string> &a)
 	for (size_t i = 0; i < visits.size(); i++)
 		std::printf("%s%d", i ? ", " : "", visits[i]);
 	std::printf("]}\n");
+	return 0;
+}
+
+static int mode_tree(const std::map<std::string, std::string> &a)
+{ // the rest of Tree's public surface (Tree.hpp:70,79-87,100-103) on a stand-alone Tree / Search pair, read after every search of a short game
+	const int n = geti(a, "--board", 15);
+	GameConfig game_config(static_cast<GameRules>(geti(a, "--rules", 0)), n);
+	SearchConfig search_config;
+	search_config.max_batch_size = geti(a, "--batch", 4);
+	search_config.tss_config.hash_table_size = 1 << 14;
+	search_config.tree_config.node_bucket_size = 2048;
+	search_config.tree_config.edge_bucket_size = 32768;
+	const int sims = geti(a, "--sims", 100);
+	DeviceConfig device;
+	device.batch_size = 64;
+	NNEvaluator evaluator(device);
+	evaluator.loadGraph(NetworkLoader(a.at("--network")));
+	evaluator.useSymmetries(false);
+	Tree tree(search_config.tree_config);
+	SearchThread thread(game_config, search_config, tree, sims, 1 << 30);
+	thread.fixed_batch = true;
+	thread.solve_deadline = false;
+	matrix<Sign> board(n, n);
+	board.fill(Sign::NONE);
+	std::vector<uint16_t> opening(AGX_OPENING_CAP, 0);
+	if (agx_make_opening(static_cast<int>(game_config.rules), n, static_cast<uint32_t>(geti(a, "--opening-seed", 1)), opening.data()) != AGX_OK)
+		throw std::runtime_error(agx_last_error());
+	Sign sign_to_move = Sign::CROSS;
+	for (int i = 0; i < opening[0]; i++)
+	{
+		const Move m(opening[1 + i]);
+		board.at(m.row, m.col) = m.sign;
+		sign_to_move = (m.sign == Sign::CROSS) ? Sign::CIRCLE : Sign::CROSS;
+	}
+	EdgeSelectorConfig final_selector;
+	final_selector.policy = "best";
+	std::vector<int> depths;
+	std::vector<float> moves_left;
+	bool single_ok = true, proven_ok = true, non_losing_ok = true;
+	int depth_after_set_board = -1;
+	const int plies = geti(a, "--plies", 6);
+	for (int ply = 0; ply < plies; ply++)
+	{
+		thread.setPosition(board, sign_to_move);
+		if (ply == 1)
+			depth_after_set_board = tree.getMaximumDepth(); // Tree::setBoard resets it (Tree.cpp:150)
+		thread.run(evaluator, false);
+		const Node root = tree.getInfo( { });
+		depths.push_back(tree.getMaximumDepth());
+		moves_left.push_back(tree.getMovesLeft());
+		int proven = 0, non_losing = 0;
+		for (const Edge *e = root.begin(); e < root.end(); e++)
+		{
+			proven += e->getScore().isProven() ? 1 : 0;
+			non_losing += (e->getScore().getProvenValue() == ProvenValue::LOSS && e->getScore().isFinite()) ? 0 : 1;
+		}
+		single_ok = single_ok && (tree.hasSingleMove() == (root.numberOfEdges() == 1));
+		proven_ok = proven_ok && (tree.hasAllMovesProven() == (proven == root.numberOfEdges()));
+		non_losing_ok = non_losing_ok && (tree.hasSingleNonLosingMove() == (non_losing == 1));
+		std::unique_ptr<EdgeSelector> selector = EdgeSelector::create(final_selector);
+		const Move m = selector->select(&root)->getMove();
+		board.at(m.row, m.col) = m.sign;
+		sign_to_move = (m.sign == Sign::CROSS) ? Sign::CIRCLE : Sign::CROSS;
+	}
+	tree.clearNodeCacheStats();
+	const NodeCacheStats after_clear_stats = tree.getNodeCacheStats();
+	// the PriorityMutex: while this thread holds the tree, a low-priority and then a high-priority locker queue up; released, the
+	// high-priority one must get the tree first (utils/PriorityMutex.hpp:15-41)
+	std::vector<int> order;
+	std::mutex order_mutex;
+	{
+		std::unique_ptr<HighPriorityLock> held = std::make_unique<HighPriorityLock>(tree.high_priority_lock());
+		std::thread low([&]() { LowPriorityLock l = tree.low_priority_lock(); std::lock_guard<std::mutex> g(order_mutex); order.push_back(0); });
+		std::this_thread::sleep_for(std::chrono::milliseconds(100));
+		std::thread high([&]() { HighPriorityLock l = tree.high_priority_lock(); std::lock_guard<std::mutex> g(order_mutex); order.push_back(1); });
+		std::thread low2([&]() { std::this_thread::sleep_for(std::chrono::milliseconds(50)); LowPriorityLock l = tree.low_priority_lock(); std::lock_guard<std::mutex> g(order_mutex); order.push_back(2); });
+		std::this_thread::sleep_for(std::chrono::milliseconds(200));
+		held.reset();
+		low.join();
+		high.join();
+		low2.join();
+	}
+	// (the first low-priority locker already stands at the gate when the high-priority one arrives: it may go first; the SECOND low-priority
+	//  locker waits in the queue behind it and must come after the high-priority one)
+	const bool high_before_second_low = std::find(order.begin(), order.end(), 1) < std::find(order.begin(), order.end(), 2);
+	tree.clear();
+	const int nodes_after_clear = tree.getNodeCount();
+	std::printf("{\"mode\": \"tree\", \"searches\": %d, \"max_depth\": [", plies);
+	for (size_t i = 0; i < depths.size(); i++)
+		std::printf("%s%d", i ? ", " : "", depths[i]);
+	std::printf("], \"moves_left\": [");
+	for (size_t i = 0; i < moves_left.size(); i++)
+		std::printf("%s%.4f", i ? ", " : "", moves_left[i]);
+	std::printf("], \"single_move_matches_edges\": %d, \"all_proven_matches_edges\": %d, \"non_losing_matches_edges\": %d, \"nodes_after_clear\": %d, "
+			"\"depth_after_set_board\": %d, \"high_priority_passed_low\": %d, \"stats_after_clear\": %llu}\n", single_ok ? 1 : 0, proven_ok ? 1 : 0, non_losing_ok ? 1 : 0,
+			nodes_after_clear, depth_after_set_board, high_before_second_low ? 1 : 0, static_cast<unsigned long long>(after_clear_stats.stored_nodes));
 	return 0;
 }
 
@@ -580,6 +727,8 @@ int main(int argc, char **argv)
 			return mode_player(args);
 		if (mode == "thread")
 			return mode_thread(args);
+		if (mode == "tree")
+			return mode_tree(args);
 		if (mode == "generator")
 			return mode_generator(args);
 		if (mode == "errors")

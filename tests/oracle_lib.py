@@ -72,6 +72,8 @@ def load():
         lib.ago_game_num_records.argtypes = [ctypes.c_void_p]
         lib.ago_game_record.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 9 + [ctypes.c_int]
         lib.ago_game_root.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 9 + [ctypes.c_int]
+        lib.ago_game_tree_info.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        lib.ago_game_tree_info.restype = None
         lib.ago_game_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         lib.ago_cpu_baseline.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(AgoSearchConfig), ctypes.c_int, ctypes.c_int,
                                          ctypes.c_double] + [ctypes.c_void_p] * 5

@@ -105,6 +105,93 @@ def test_generator_manager_call_chain(network_file, tmp_path):
     assert total_samples == line["samples"]
 
 
+def parse_saved_games(path):
+    """saved_state/thread_<i>.bin (GeneratorThread::saveGames): "AGXS", u32 version, u32 generators, per generator u32 count and per game an
+    AgxSavedGame (6 ints, 400 u16), u64 n, n bytes of { i32 move number, u32 bytes, format-201 sample } records"""
+    data = np.frombuffer(path.read_bytes(), np.uint8)
+    assert bytes(data[:4]) == b"AGXS" and int(data[4:8].view(np.uint32)[0]) == 1
+    generators = int(data[8:12].view(np.uint32)[0])
+    off, games = 12, []
+    for _ in range(generators):
+        count = int(data[off:off + 4].view(np.uint32)[0])
+        off += 4
+        for _ in range(count):
+            slot, index, opening_id, sign, nn_queued, n_moves = (int(x) for x in data[off:off + 24].view(np.int32))
+            moves = [int(m) for m in data[off + 24:off + 24 + 2 * n_moves].view(np.uint16)]
+            off += 24 + 800
+            n = int(data[off:off + 8].view(np.uint64)[0])
+            off += 8
+            rec, samples = off, []
+            while rec < off + n:
+                move_number = int(data[rec:rec + 4].view(np.int32)[0])
+                size = int(data[rec + 4:rec + 8].view(np.uint32)[0])
+                samples.append((move_number, bytes(data[rec + 8:rec + 8 + size])))
+                rec += 8 + size
+            assert rec == off + n
+            off += n
+            games.append(dict(slot=slot, index=index, sign=sign, moves=moves, samples=samples))
+    assert off == data.size
+    return games
+
+
+def read_games(out, n):
+    raw = np.frombuffer((out / "games.raw").read_bytes(), np.uint8)
+    pos, games = 0, []
+    while pos < raw.size:
+        size = int(raw[pos:pos + 4].view(np.uint32)[0])
+        games.append(parse_game(raw[pos + 4:pos + 4 + size], n))
+        pos += 4 + size
+    return games
+
+
+def test_generator_manager_restart_continues_the_games_in_flight(network_file, tmp_path):
+    """GeneratorManager::saveState / loadState (GeneratorManager.cpp:241-290) and GameGenerator::save / load (GameGenerator.cpp:122-141) across
+    two PROCESSES: the first plays 12 games and stops — its buffer goes to saved_state/buffer.bin, the games still in flight (their moves and
+    the samples collected so far) to saved_state/thread_<i>.bin; the second loads both and goes on to 30 games.  The buffer's games come back
+    byte for byte, every game that was in flight continues from its saved move prefix (trees are rebuilt, as in the reference) and, when it
+    ends, carries the samples of BOTH processes."""
+    path, d, _ = network_file
+    out = tmp_path / "work"
+    out.mkdir()
+    common = ["--network", path, "--games-per-thread", 16, "--devices", "0,0", "--sims", 50, "--batch", 4, "--out", out, "--nn-batch", 32]
+    first, _ = run("generate", "--games", 12, *common)
+    assert first["games"] >= 12
+    games_1 = read_games(out, 15)
+    state = out / "saved_state"
+    assert (state / "buffer.bin").exists() and (state / "thread_0.bin").exists() and (state / "thread_1.bin").exists()
+    in_flight = [parse_saved_games(state / ("thread_%d.bin" % t)) for t in range(2)]
+    assert sum(len(x) for x in in_flight) >= 16      # most of the 2 x 16 slots hold a game when the threads stop
+    assert any(len(g["samples"]) > 0 for t in in_flight for g in t)
+    for t in in_flight:
+        for g in t:
+            stones = len(g["moves"])
+            assert [mn for mn, _ in g["samples"]] == list(range(stones - len(g["samples"]), stones))   # one sample per move played so far
+            assert g["sign"] == (1 if stones % 2 == 0 else 2)
+
+    second, stdout = run("generate", "--games", 30, *common)
+    assert "Loaded buffer" in stdout and "thread_0.bin" in stdout and second["games"] >= 30
+    games_2 = read_games(out, 15)
+    # the loaded buffer: the first process's games, in order, byte for byte
+    for a, b in zip(games_1, games_2):
+        assert a[2] == b[2] and np.array_equal(a[1], b[1]) and len(a[0]) == len(b[0]) and all(np.array_equal(x, y) for x, y in zip(a[0], b[0]))
+    assert not (state / "buffer.bin").exists() or second["games"] == len(games_2)   # (loadState removes the file, saveState wrote a new one)
+    later = games_2[len(games_1):]
+    still = [parse_saved_games(state / ("thread_%d.bin" % t)) for t in range(2)]
+    resumed = 0
+    for t in range(2):
+        for g in in_flight[t]:
+            prefix = g["moves"]
+            ended = [x for x in later if len(x[1]) >= len(prefix) and [int(m) for m in x[1][:len(prefix)]] == prefix]
+            going = [x for x in still[t] if x["slot"] == g["slot"] and x["moves"][:len(prefix)] == prefix]
+            assert len(ended) + len(going) >= 1, (t, g["slot"])
+            for samples, moves, outcome in ended[:1]:
+                # the samples of the first process lead the game's sample list, bit for bit, and every later move added one
+                assert len(samples) == len(g["samples"]) + (len(moves) - len(prefix))
+                assert all(bytes(samples[k]) == g["samples"][k][1] for k in range(len(g["samples"])))
+                resumed += 1
+    assert resumed >= 8
+
+
 def test_nn_evaluator_with_host_tasks(network_file, agx_lib, tmp_path):
     """NNEvaluator::addToQueue(task, symmetry) / evaluateGraph / asyncEvaluateGraphLaunch + Join (NNEvaluator.cpp:134-286): the task gets the
     network's output of the AUGMENTED features mapped back by the inverse symmetry"""
@@ -196,7 +283,10 @@ def test_search_thread_loops_with_the_reference_constructors(network_file, agx_l
     from test_engine_gpu import _best_edge
     path, d, blob = network_file
     seed, sims, batch, plies, n = 11, 150, 8, 14, 15
-    line, _ = run("thread", "--network", path, "--sims", sims, "--batch", batch, "--opening-seed", seed, "--table-entries", 1 << 16, "--plies", plies, "--async", asynchronous)
+    # (--fixed-batch 1 --solve-deadline 0: the two clock-dependent pieces of the loops — sqrt batch sizes are not, but the replay below uses one
+    #  size — are switched off for THIS comparison; test_search_thread_as_written_with_deadlines runs them as written)
+    line, _ = run("thread", "--network", path, "--sims", sims, "--batch", batch, "--opening-seed", seed, "--table-entries", 1 << 16, "--plies", plies, "--async", asynchronous,
+                  "--fixed-batch", 1, "--solve-deadline", 0)
     assert line["asynchronous"] == asynchronous and len(line["moves"]) >= 1
     net = AGNetwork(d)
     net.loadWeights(blob)
@@ -256,6 +346,47 @@ def test_search_thread_loops_with_the_reference_constructors(network_file, agx_l
     assert moves == line["moves"] and visits == line["root_visits"] and outcome == line["outcome"]
     assert iterations == line["iterations"] and st["evaluated_nodes"] == line["simulations"]
     assert min(visits) >= sims or outcome != 0
+
+
+@pytest.mark.parametrize("asynchronous", [0, 1])
+def test_search_thread_as_written_with_deadlines(network_file, agx_lib, asynchronous):
+    """player/SearchThread.cpp:84-199 AS WRITTEN: the lock scopes on Tree::low_priority_lock (utils/PriorityMutex.hpp), get_batch_size =
+    sqrt(simulations) through Search::setBatchSize, and in asynchronous_run the estimated end of the network launch
+    (NNEvaluator::asyncEvaluateGraphLaunch's return value) as the deadline of Search::solve (Search.cpp:159-183: node limit 10 000, the time
+    left shared out over the leaves).  The results depend on the clock, as in the reference; what must hold: a legal game whose every search
+    reaches its simulation count (or a proven root), and with sqrt batches more iterations than the fixed-batch run needs."""
+    path, d, blob = network_file
+    seed, sims, batch, plies, n = 11, 150, 8, 10, 15
+    line, _ = run("thread", "--network", path, "--sims", sims, "--batch", batch, "--opening-seed", seed, "--table-entries", 1 << 16, "--plies", plies, "--async", asynchronous)
+    fixed, _ = run("thread", "--network", path, "--sims", sims, "--batch", batch, "--opening-seed", seed, "--table-entries", 1 << 16, "--plies", plies, "--async", asynchronous,
+                   "--fixed-batch", 1, "--solve-deadline", 0)
+    assert len(line["moves"]) == plies or line["outcome"] != 0
+    opening = synthetic.make_openings(n, 1, seed0=seed)[0]
+    board = np.zeros(n * n, np.uint8)
+    for m in opening:
+        board[((m >> 2) & 127) * n + ((m >> 9) & 127)] = m & 3
+    sign = 3 - (opening[-1] & 3) if opening else 1
+    for mv in line["moves"]:
+        cell = ((mv >> 2) & 127) * n + ((mv >> 9) & 127)
+        assert board[cell] == 0 and (mv & 3) == sign
+        board[cell] = mv & 3
+        sign = 3 - sign
+    assert all(v >= sims for v in line["root_visits"][:-1]) or line["outcome"] != 0
+    # batch sizes 1, 2, 3, ... up to 8 while the simulation count grows: more, smaller iterations than 8 leaves at a time
+    assert line["iterations"] > fixed["iterations"]
+
+
+def test_tree_accessors_of_the_reference(network_file, agx_lib):
+    """Tree::getMovesLeft / getMaximumDepth / hasAllMovesProven / hasSingleMove / hasSingleNonLosingMove / clear / clearNodeCacheStats and the
+    priority locks (Tree.hpp:70,79-87,100-103), read after every search of a short game (boundary_main.cpp, mode tree)"""
+    path, _, _ = network_file
+    line, _ = run("tree", "--network", path, "--sims", 120, "--batch", 4, "--opening-seed", 5, "--plies", 6)
+    assert line["searches"] == 6
+    assert all(1 <= d_ <= 60 for d_ in line["max_depth"])          # every search descended at least one level
+    assert all(0.0 <= m <= 225.0 for m in line["moves_left"])
+    assert line["single_move_matches_edges"] == 1 and line["all_proven_matches_edges"] == 1 and line["non_losing_matches_edges"] == 1
+    assert line["nodes_after_clear"] == 0 and line["depth_after_set_board"] == 0
+    assert line["high_priority_passed_low"] == 1                   # the PriorityMutex order: a waiting high-priority locker goes first
 
 
 def test_game_generators_with_the_reference_constructor(network_file, agx_lib):

@@ -208,7 +208,7 @@ def _oracle_root(olib, h):
 
 def _play_and_compare(olib, rules, games, batch, sims, max_steps, evaluator, table_entries=1 << 16, n=N, final_selector=0, use_symmetries=0,
                       action_values=0, noise_weight=0.0, noise_type=1, exploration_scaling=0.0, draw_after=0, max_children=0, policy_temperature=1.0,
-                      record_format=1, node_capacity=4096, edge_capacity=0, arena_reserve=1.0, groups=1, **engine_options):
+                      record_format=1, node_capacity=4096, edge_capacity=0, arena_reserve=1.0, groups=1, restore_from=None, **engine_options):
     """evaluator(features uint32 [n][HW]) -> (policy [n][HW] f32, value [n][2] f32 (win, draw)[, q [n][HW][2]]); used for BOTH sides"""
     from alphagomoku_amd import selfplay
     N, HW = n, n * n   # noqa: N806 (shadow the 15x15 module defaults)
@@ -230,15 +230,25 @@ def _play_and_compare(olib, rules, games, batch, sims, max_steps, evaluator, tab
         ocfg.max_children = max_children
     openings, handles = [], []
     for g in range(games):
-        op = np.zeros(64, np.uint16)
-        k = olib.ago_prepare_opening(rules, N, N, 100 + g, ol.ptr(op))
+        op = np.zeros(256, np.uint16)
+        if restore_from is not None:
+            # games in flight saved by another engine (agx_engine_save_games) continue here: for the oracle the saved moves are the "opening"
+            k = len(restore_from[g]["moves"])
+            op[:k] = restore_from[g]["moves"]
+        else:
+            k = olib.ago_prepare_opening(rules, N, N, 100 + g, ol.ptr(op))
         openings.append([int(x) for x in op[:k]])
         h = olib.ago_game_create_ex(rules, N, N, draw_after, ctypes.byref(ocfg))
         olib.ago_game_set_serial(h, g)   # the device keys the symmetry hash by the opening id
         olib.ago_game_set_policy_temperature(h, policy_temperature)
         olib.ago_game_begin(h, ol.ptr(op), k)
         handles.append(h)
-    pool.begin(selfplay.pack_openings(openings))
+    if restore_from is not None:
+        pool.begin(selfplay.pack_openings([[] for _ in range(games)]))
+        for g in range(games):
+            pool.restore_game(dict(restore_from[g], opening_id=g, nn_queued=0), slot=g)
+    else:
+        pool.begin(selfplay.pack_openings(openings))
     compared = 0
     deferred = [False] * games
     # groups > 1: the pool stepped as slices on CU-masked streams, the way bench.py and ag::GeneratorThread run it
@@ -301,6 +311,11 @@ def _play_and_compare(olib, rules, games, batch, sims, max_steps, evaluator, tab
             assert np.array_equal(np.array([x["prior"] for x in e], np.float32), r["prior"]), (step, g)
             assert np.array_equal(np.array([[x["win"], x["draw"]] for x in e], np.float32).reshape(-1), r["val"]), (step, g)
             assert np.float32(info["root_win"]) == r["win"] and np.float32(info["root_draw"]) == r["draw"] and info["root_score"] == r["score"], (step, g)
+            # Tree::getMovesLeft / getMaximumDepth (Tree.cpp:173-176,188-191): the root's running mean of the backed-up moves-left estimates,
+            # the longest select path that reached a leaf since the last setBoard
+            tree_f, tree_i = np.zeros(1, np.float32), np.zeros(5, np.int32)
+            olib.ago_game_tree_info(handles[g], ol.ptr(tree_f), ol.ptr(tree_i))
+            assert np.float32(info["root_moves_left"]) == tree_f[0] and info["max_depth"] == tree_i[0], (step, g, info["root_moves_left"], tree_f[0], info["max_depth"], tree_i[0])
             compared += 1
         if all(olib.ago_game_outcome(h) != 0 for h in handles) and not any(deferred):
             break
@@ -779,6 +794,125 @@ def test_games_bit_exact_with_the_hip_network_in_the_loop(agx_lib, olib):
     compared, stats = _play_and_compare(olib, 0, games=4, batch=4, sims=100, max_steps=250, evaluator=evaluator)
     assert compared > 300 and stats["moves_played"] > 0
     net.close()
+
+
+def test_games_bit_exact_with_the_raw_network_in_the_loop(agx_lib, olib):
+    """ResnetPVraw (networks.cpp:107-129) as the evaluator of a pool: the tower reads the 8 low bits of the feature words the
+    search kernels write; the pool stepped with the network on the device (GeneratorPool.step) plays the games of the oracle tree fed the
+    same network's outputs."""
+    from alphagomoku_amd.networks import AGNetwork
+    d = synthetic.net_desc(blocks=2, filters=64, in_channels=8)
+    blob, _ = synthetic.make_weights(d)
+    net = AGNetwork(d)
+    net.loadWeights(blob)
+
+    def evaluator(feats):
+        p, v = net.forward(np.ascontiguousarray(feats, dtype=np.uint32))
+        return p, np.ascontiguousarray(v[:, :2])
+    compared, stats = _play_and_compare(olib, 0, games=4, batch=4, sims=100, max_steps=250, evaluator=evaluator, speculative_solver=1, speculative_waves=48)
+    assert compared > 300 and stats["moves_played"] > 0
+    net.close()
+
+
+@pytest.mark.parametrize("rules,speculative", [(0, 1), (2, 0)])
+def test_restored_games_continue_like_the_oracle(agx_lib, olib, rules, speculative):
+    """GeneratorThread::saveGames / loadGames on the C ABI (agx_engine_save_games / agx_engine_restore_game; GameGenerator::save / load,
+    GameGenerator.cpp:122-141): a pool plays for a while, its games in flight are saved; a NEW engine gets them back and must go on exactly as
+    the oracle does from those positions with empty trees (the reference's load() calls prepare_search on a fresh Tree) — every leaf, every
+    root, every move to the end of the games."""
+    from alphagomoku_amd import selfplay
+    games = 6
+    ev = _stand_in_evaluator(olib)
+    cfg = selfplay.default_config(rules=rules, n_games=games, max_batch_size=4, max_simulations=60, tss_table_entries=1 << 14, node_capacity=4096, edge_capacity=65536)
+    first = selfplay.GeneratorPool(cfg)
+    first.begin(selfplay.pack_openings(synthetic.make_openings(15, games, seed0=40, rules=rules)))
+    for _ in range(140):
+        first.select_solve()
+        slots, feats = first.scheduled()
+        if len(slots):
+            pol, val = ev(feats)
+            first.provide(slots, pol, np.concatenate([val, 1 - val.sum(1, keepdims=True)], 1).astype(np.float32))
+        first.expand_backup()
+    saved = first.save_games()
+    infos = [first.game_info(g, with_edges=False) for g in range(games)]
+    first.close()
+    assert len(saved) >= games - 1 and all(len(g["moves"]) == infos[g["game_slot"]]["n_moves"] for g in saved)
+    assert max(len(g["moves"]) for g in saved) > 8          # the games have left their openings behind
+    by_slot = {g["game_slot"]: g for g in saved}
+    restore = [by_slot.get(g, saved[0]) for g in range(games)]   # (a slot whose game had just ended takes a copy of another game)
+    compared, stats = _play_and_compare(olib, rules, games=games, batch=4, sims=60, max_steps=2500, evaluator=ev, table_entries=1 << 14,
+                                        restore_from=restore, speculative_solver=speculative, speculative_waves=48)
+    assert compared > 200 and stats["first_error"] == 0 and stats["games_finished"] >= games
+
+
+def test_time_limited_solve(agx_lib, olib):
+    """Search::solve(endTime >= 0) (Search.cpp:159-183, SearchThread::asynchronous_run): node limit + a wall-clock budget shared out over the
+    leaves.  (a) With a generous budget and the configured node limit the launch is Search::solve(): the pool plays the oracle's games.  (b) With
+    no time left every leaf stops after its first node (AlphaBetaSearch.cpp:110-111: the check behind the first iteration).  (c) A 10 000-node
+    limit visits more nodes than the 100-node one on the same leaves."""
+    from alphagomoku_amd import selfplay
+    games, batch = 8, 4
+    ev = _stand_in_evaluator(olib)
+    openings = synthetic.make_openings(15, games, seed0=60)
+
+    def run(mode, steps):
+        pool = selfplay.GeneratorPool(selfplay.default_config(n_games=games, max_batch_size=batch, max_simulations=80, tss_table_entries=1 << 14, node_capacity=4096,
+                                                              edge_capacity=65536, speculative_solver=0, solver_yield_fraction=0.0))
+        pool.begin(selfplay.pack_openings(openings))
+        roots = []
+        for _ in range(steps):
+            if mode == "plain":
+                pool.select_solve()
+            else:
+                pool.select_group(0, 1)
+                pool.solve_timed_group(0, 1, {"generous": 100, "expired": 100, "deep": 10000}[mode], 0.0 if mode == "expired" else 30.0)
+            slots, feats = pool.scheduled()
+            if len(slots):
+                pol, val = ev(feats)
+                pool.provide(slots, pol, np.concatenate([val, 1 - val.sum(1, keepdims=True)], 1).astype(np.float32))
+            pool.expand_backup()
+            roots.append([(pool.game_info(g)["root_visits"], [(e["move"], e["visits"], e["score"]) for e in pool.game_info(g)["edges"]]) for g in range(games)])
+        st = pool.stats()
+        pool.close()
+        return roots, st
+    plain, st_plain = run("plain", 25)
+    generous, st_generous = run("generous", 25)
+    assert plain == generous and st_plain["solver_nodes"] == st_generous["solver_nodes"]
+    _, st_expired = run("expired", 6)
+    _, st_six = run("plain", 6)
+    assert 0 < st_expired["solver_nodes"] < st_six["solver_nodes"]
+    assert st_expired["solver_nodes"] <= 6 * games * batch      # one node per leaf: at most steps x games x batch
+    _, st_deep = run("deep", 6)
+    assert st_deep["solver_nodes"] > 2 * st_six["solver_nodes"] and st_deep["first_error"] == 0
+
+
+def test_select_stage_follows_set_batch_size(agx_lib, olib):
+    """Search::setBatchSize (Search.cpp:252-255; SearchThread.cpp:125-126): a pool created with max_batch_size 8 whose select stage is told to
+    take 3 leaves per game plays exactly the games of a pool created with max_batch_size 3"""
+    from alphagomoku_amd import selfplay
+    games = 6
+    ev = _stand_in_evaluator(olib)
+    openings = synthetic.make_openings(15, games, seed0=70)
+
+    def run(max_batch, limit):
+        pool = selfplay.GeneratorPool(selfplay.default_config(n_games=games, max_batch_size=max_batch, max_simulations=60, tss_table_entries=1 << 14, node_capacity=4096,
+                                                              edge_capacity=65536))
+        pool.begin(selfplay.pack_openings(openings))
+        if limit:
+            pool.set_batch_size(limit)
+        trace = []
+        for _ in range(60):
+            pool.select_solve()
+            slots, feats = pool.scheduled()
+            if len(slots):
+                pol, val = ev(feats)
+                pool.provide(slots, pol, np.concatenate([val, 1 - val.sum(1, keepdims=True)], 1).astype(np.float32))
+            pool.expand_backup()
+            trace.append([(i["root_visits"], i["n_moves"], [(e["move"], e["visits"]) for e in i["edges"]]) for i in (pool.game_info(g) for g in range(games))])
+        pool.close()
+        return trace
+    assert run(8, 3) == run(3, 0)
+    assert run(8, 3) != run(8, 0)
 
 
 @pytest.mark.parametrize("rules,symmetries", [(0, 0), (1, 1), (2, 0)])

@@ -49,6 +49,32 @@ def test_deep_network_tolerance(agx_lib, rows):
         net.close()
 
 
+FP16_ORACLE_TOL = 1.0e-3
+
+
+@pytest.mark.parametrize("rows,blocks,filters", [(15, 2, 64), (15, 6, 128), (15, 10, 128), (20, 2, 64), (20, 10, 128)])
+def test_forward_matches_the_fp16_storage_oracle(agx_lib, rows, blocks, filters):
+    """Kernel error separated from format rounding: against the oracle run with the kernel's own storage precision (fp16 weights and
+    activation planes, fp32 accumulation: nn_ref.forward(storage="fp16"), the reference's inference format, AGNetwork.cpp:136-160) what is
+    left is the order of fp32 additions and the activations that order tips across an fp16 rounding boundary.  Plain He-init weights
+    (the 10x128 towers of C3-C5 included), softmax outputs within 1e-3, arg-max identical; the fp32 comparison of the other tests
+    stays the stated end-to-end tolerance."""
+    from alphagomoku_amd.networks import AGNetwork
+    from oracle import nn_ref
+    d = synthetic.net_desc(rows=rows, cols=rows, blocks=blocks, filters=filters)
+    blob, _ = synthetic.make_weights(d)
+    net = AGNetwork(d)
+    net.loadWeights(blob)
+    f = synthetic.random_features(8, rows, rows, seed=3 * blocks + rows)
+    p, v = net.forward(f)
+    pr, vr = nn_ref.forward(d, blob, f, storage="fp16")
+    err_p, err_v = float(np.abs(p - pr).max()), float(np.abs(v - vr).max())
+    print("fp16-storage oracle %dx%d %dx%d: policy %.2e value %.2e logits %.2e" % (rows, rows, blocks, filters, err_p, err_v, relative_logit_error(p, pr)))
+    assert err_p <= FP16_ORACLE_TOL and err_v <= FP16_ORACLE_TOL
+    assert (p.argmax(1) == pr.argmax(1)).all()
+    net.close()
+
+
 @pytest.mark.parametrize("blocks,filters", [(2, 64), (6, 128), (10, 128)])
 def test_forward_matches_oracle(agx_lib, blocks, filters):
     from alphagomoku_amd.networks import AGNetwork
@@ -101,6 +127,54 @@ def test_single_plane_kernel_matches_oracle(agx_lib, monkeypatch, rows, blocks, 
     p2, v2 = net.forward(big[idx])
     assert np.array_equal(p2, pb[idx]) and np.array_equal(v2, vb[idx])
     net.close()
+
+
+@pytest.mark.parametrize("rows,blocks,filters,single", [(15, 2, 64, "0"), (15, 6, 128, "0"), (15, 6, 128, "1"), (20, 2, 64, "0"), (20, 4, 128, "0")])
+def test_raw_input_network_matches_oracle(agx_lib, monkeypatch, rows, blocks, filters, single):
+    """ResnetPVraw (networks.cpp:107-129): 8 input channels = the 8 low bits of a feature word (ml::unpackInput, AGNetwork.cpp:249-258).
+    The device kernel packs four horizontal taps x 8 channels into one K = 32 MFMA step (conv5x5_input<.., RAW>).  Same tolerance as the
+    32-channel network; the bits above the low byte must not matter."""
+    from alphagomoku_amd.networks import AGNetwork
+    from oracle import nn_ref
+    monkeypatch.setenv("AGX_NN_SINGLE_PLANE", single)
+    d = synthetic.net_desc(rows=rows, cols=rows, blocks=blocks, filters=filters, in_channels=8)
+    blob, _ = synthetic.make_weights(d)
+    assert blob.size == nn_ref_blob_floats(d)
+    net = AGNetwork(d)
+    net.loadWeights(blob)
+    f = synthetic.random_features(11, rows, rows, seed=5 + blocks)
+    p, v = net.forward(f)
+    pr, vr = nn_ref.forward(d, blob, f)
+    assert np.abs(p - pr).max() <= POLICY_TOL and np.abs(v - vr).max() <= VALUE_TOL
+    assert (p.argmax(1) == pr.argmax(1)).all()
+    p2, v2 = net.forward(f & np.uint32(0xFF))
+    assert np.array_equal(p, p2) and np.array_equal(v, v2)
+    # all-zero / all-one words and a board whose only set cells are the four corners and the border (the packed taps read across row ends)
+    e = np.zeros((3, rows * rows), np.uint32)
+    e[1, :] = 0xFFFFFFFF
+    border = np.zeros((rows, rows), np.uint32)
+    border[0, :] = border[-1, :] = border[:, 0] = border[:, -1] = 0xFF
+    e[2, :] = border.reshape(-1)
+    p, v = net.forward(e)
+    pr, vr = nn_ref.forward(d, blob, e)
+    assert np.abs(p - pr).max() <= EDGE_TOL and np.abs(v - vr).max() <= EDGE_TOL
+    assert (p.argmax(1) == pr.argmax(1)).all()
+    net.close()
+
+
+def nn_ref_blob_floats(d):
+    from oracle import nn_ref
+    n = 0
+    for a in nn_ref.split_blob(d, np.zeros(synthetic.make_weights(d)[0].size, np.float32)):
+        n += a.size
+    return n
+
+
+def test_raw_network_rejects_the_action_values_head(agx_lib):
+    from alphagomoku_amd.networks import AGNetwork
+    from alphagomoku_amd import AgxError
+    with pytest.raises(AgxError):
+        AGNetwork(synthetic.net_desc(blocks=1, filters=64, in_channels=8, action_values=1))
 
 
 @pytest.mark.parametrize("rows,blocks,filters,single", [(15, 6, 128, "0"), (15, 2, 64, "0"), (15, 6, 128, "1"), (20, 4, 128, "0")])
