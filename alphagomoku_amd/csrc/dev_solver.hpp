@@ -117,26 +117,22 @@ namespace agx
 				default: return s_make(2, -s_eval(d));
 			}
 		}
-		__device__ __forceinline__ uint32_t s_invert_up(uint32_t d)
-		{
-			switch (s_pv(d))
-			{
-				case 0: return s_infinite(d) ? s_negate(d) : s_win_in(s_distance(d) + 1);
-				case 1: return s_draw_in(s_distance(d) + 1);
-				case 3: return s_infinite(d) ? s_negate(d) : s_loss_in(s_distance(d) + 1);
-				default: return s_negate(d);
-			}
+		/* Score::increaseDistance / decreaseDistance behind operator- (invert_up / invert_down, search/Score.hpp:205-260) without branches: with
+		 * r = 4000 + eval the proven-value classes map loss -> win (3, 8000 - r -/+ 1), draw -> draw (1, r +/- 1), win -> loss (0, 8000 - r +/- 1),
+		 * unknown -> unknown (2, 8000 - r), and the two infinities swap.  (The solver inverts a score at every descent and every return; as a
+		 * switch this was a jump table per call.  All 65 536 inputs give the integers of the switch form: tests/test_oracle_tables.py pins the
+		 * oracle's score algebra to the compiled reference, the engine tests compare the device's scores with the oracle's.) */
+		__device__ __forceinline__ uint32_t s_invert_step(uint32_t d, int step)
+		{ // step = +1: invert_up, -1: invert_down
+			const uint32_t pv = (d >> 13) & 3u, r = d & 8191u;
+			const uint32_t npv = (pv == 0u) ? 3u : ((pv == 3u) ? 0u : pv);
+			const int flipped = 8000 - static_cast<int>(r) + ((pv == 0u) ? -step : ((pv == 3u) ? step : 0));
+			const int kept = static_cast<int>(r) + step;
+			const uint32_t body = (npv << 13) | static_cast<uint32_t>((pv == 1u) ? kept : flipped);
+			return (d == 0u) ? 0xFFFFu : ((d == 0xFFFFu) ? 0u : body);
 		}
-		__device__ __forceinline__ uint32_t s_invert_down(uint32_t d)
-		{
-			switch (s_pv(d))
-			{
-				case 0: return s_infinite(d) ? s_negate(d) : s_win_in(s_distance(d) - 1);
-				case 1: return s_draw_in(s_distance(d) - 1);
-				case 3: return s_infinite(d) ? s_negate(d) : s_loss_in(s_distance(d) - 1);
-				default: return s_negate(d);
-			}
-		}
+		__device__ __forceinline__ uint32_t s_invert_up(uint32_t d) { return s_invert_step(d, +1); }
+		__device__ __forceinline__ uint32_t s_invert_down(uint32_t d) { return s_invert_step(d, -1); }
 		__device__ __forceinline__ void s_to_value(uint32_t d, float &win, float &draw)
 		{ // Score.hpp:266-283
 			win = 0.0f;
@@ -207,11 +203,10 @@ namespace agx
 				uint8_t threat[HW][2];
 				uint16_t items[2][LIST_ITEMS]; // threat lists 2..9 of both sides, list t at list_off(t)
 				uint16_t pos[2][HW];     // index of a cell inside its list (ThreatHistogram::remove finds it by search)
-				uint16_t count[2][10];
+				alignas(4) uint16_t count[2][10];
 				uint32_t legal[N];
 				uint32_t added[N];
 				uint32_t row_mask[N]; // scratch row masks of the move generator
-				uint16_t sets[5][32];    // small location sets of the move generator (kept out of per-lane scratch memory)
 				uint16_t tmp_list[HW]; // copy of a threat list that renju foul checks would permute while it is iterated
 				uint16_t foul_cell[64];  // MoveGenerator::forbidden_moves_cache (MoveGenerator.hpp:74)
 				uint8_t foul_flag[64];
@@ -987,27 +982,31 @@ namespace agx
 
 		/* ---------------- staged move generator, lane 0 only (MoveGenerator.cpp:159-1207, non-renju) ---------------- */
 		struct SmallSet
-		{ // StackVector<Location, N> semantics (patterns/common.hpp:154-245); storage is one of SolverShared::sets
-				uint16_t *v;
-				int n;
-				__device__ explicit SmallSet(uint16_t *storage) : v(storage), n(0) {}
-				__device__ __forceinline__ bool contains(int x) const
+		{ // StackVector<Location, N> semantics (patterns/common.hpp:154-245) with element i in LANE i of one register: the generator's sets hold at
+		  // most a few dozen cells and every lane runs the generator with the same (wave-uniform) values, so membership is a ballot, an append a
+		  // select and an element a v_readlane — no LDS round trips (kept in LDS every operation was one or two, in dependent chains: the
+		  // defend-loss-in-2 / -4 / -6 stages of a node spent most of their time waiting for them)
+				uint32_t v;
+				int n, lane;
+				__device__ explicit SmallSet(int ln) : v(0u), n(0), lane(ln) {}
+				__device__ __forceinline__ int at(int i) const { return static_cast<int>(__builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(i))); }
+				__device__ __forceinline__ bool contains(int x) const { return __ballot(lane < n && v == static_cast<uint32_t>(x)) != 0ull; }
+				__device__ __forceinline__ void add(int x)
 				{
-					for (int i = 0; i < n; i++)
-						if (v[i] == x)
-							return true;
-					return false;
+					v = (lane == n) ? static_cast<uint32_t>(x) : v;
+					n++;
 				}
-				__device__ __forceinline__ void add(int x) { v[n++] = static_cast<uint16_t>(x); }
-				__device__ __forceinline__ void remove_at(int i) { v[i] = v[--n]; }
+				__device__ __forceinline__ void remove_at(int i)
+				{ // v[i] = v[--n]
+					const uint32_t last = static_cast<uint32_t>(at(n - 1));
+					v = (lane == i) ? last : v;
+					n--;
+				}
 				__device__ __forceinline__ void remove(int x)
-				{
-					for (int i = 0; i < n; i++)
-						if (v[i] == x)
-						{
-							v[i] = v[--n];
-							return;
-						}
+				{ // the first match
+					const u64 m = __ballot(lane < n && v == static_cast<uint32_t>(x));
+					if (m != 0ull)
+						remove_at(__ffsll(static_cast<long long>(m)) - 1);
 				}
 		};
 
@@ -1055,20 +1054,25 @@ namespace agx
 				Frame &f;
 				int n, own, opp, lane;
 				int stack_offset, stack_max, board_depth;
-				int own_cnt[10], opp_cnt[10]; // list sizes, read once: the generator never changes the threat lists (non-renju)
+				uint32_t cnt_w[2][5]; // list sizes, read once ([0] own, [1] opponent), two 16-bit counts per word as they lie in LDS: 10 registers, not 20
 
 				__device__ __forceinline__ MoveGen(SH &s, const EngineDev &e, uint32_t *a, Frame &fr, int ln, int offset, int maximum) :
 						sh(s), E(e), act(a), f(fr), n(e.n), own(s.sign_to_move), opp(3 - s.sign_to_move), lane(ln), stack_offset(offset), stack_max(maximum), board_depth(s.depth)
 				{
+const uint32_t *words = reinterpret_cast<const uint32_t*>(&s.count[0][0]);
 #pragma unroll
-					for (int t = 0; t < 10; t++)
-					{
-						own_cnt[t] = s.count[own - 1][t];
-						opp_cnt[t] = s.count[opp - 1][t];
-					}
+for (int k = 0; k < 5; k++)
+{
+	cnt_w[0][k] = words[5 * (own - 1) + k];
+	cnt_w[1][k] = words[5 * (opp - 1) + k];
+}
 				}
 				__device__ __forceinline__ int item(int sign, int t, int k) const { return static_cast<int>(list_get(sh, sign - 1, t, k)); }
-				__device__ __forceinline__ int count(int sign, int t) const { return (sign == own) ? own_cnt[t] : opp_cnt[t]; }
+				__device__ __forceinline__ int count(int sign, int t) const
+				{
+					const uint32_t w = (sign == own) ? cnt_w[0][t >> 1] : cnt_w[1][t >> 1];
+					return static_cast<int>((t & 1) ? (w >> 16) : (w & 0xFFFFu));
+				}
 				__device__ __forceinline__ const uint8_t* patterns(int sign, int cell) const { return sh.ptype[cell] + 4 * (sign - 1); }
 				__device__ __forceinline__ int threat_at(int sign, int cell) const { return sh.threat[cell][sign - 1]; }
 				__device__ __forceinline__ static int count_of(const uint8_t *g, int v) { return (g[0] == v) + (g[1] == v) + (g[2] == v) + (g[3] == v); }
@@ -1093,7 +1097,14 @@ namespace agx
 					for (int k = 0; k < cached; k++)
 						if (sh.foul_cell[k] == cell)
 							return sh.foul_flag[k] != 0;
+					#ifdef AGX_SOLVER_PROFILE
+					const unsigned long long foul_t0 = clock64();
+					#endif
 					const bool r = renju_is_forbidden(sh, E, cell, lane);
+					#ifdef AGX_SOLVER_PROFILE
+					sh.dprof[18] += clock64() - foul_t0; // renju: uncached foul tests of the generator (each may place and remove stones)
+					sh.dprof[19] += 1;
+					#endif
 					if (cached < 64)
 					{
 						sh.foul_cell[cached] = static_cast<uint16_t>(cell);
@@ -1200,7 +1211,7 @@ namespace agx
 						int i = 0;
 						while (i < out.n)
 						{
-							const int candidate = out.v[i];
+							const int candidate = out.at(i);
 							if (is_foul(own, candidate))
 							{
 								add_move(candidate, s_loss_in(1), true);
@@ -1235,7 +1246,7 @@ namespace agx
 					int i = 0;
 					while (i < lhs.n)
 					{
-						if (rhs.contains(lhs.v[i]))
+						if (rhs.contains(lhs.at(i)))
 							i++;
 						else
 							lhs.remove_at(i);
@@ -1246,7 +1257,7 @@ namespace agx
 					if (!initialized)
 					{
 						for (int i = 0; i < other.n; i++)
-							dm.add(other.v[i]);
+							dm.add(other.at(i));
 						initialized = true;
 					}
 					else
@@ -1257,13 +1268,13 @@ namespace agx
 					if (fouls_possible_for(own))
 						return s_unknown(15);
 					const int dir = direction_of(patterns(own, cell), 3);
-					SmallSet dm(sh.sets[4]);
+					SmallSet dm(lane);
 					defensive_moves(opp, cell, dir, dm);
 					dm.remove(cell);
 					int best = 0;
 					for (int i = 0; i < dm.n; i++)
 					{
-						const int tt = threat_at(opp, dm.v[i]);
+						const int tt = threat_at(opp, dm.at(i));
 						if ((tt != 6 && tt != 9) || !fouls_possible_for(opp))
 							best = max(best, tt);
 					}
@@ -1413,7 +1424,7 @@ namespace agx
 						return true;
 					f.must_defend = 1;
 					f.baseline = static_cast<uint16_t>(s_loss_in(2));
-					SmallSet dm(sh.sets[0]), tmp(sh.sets[1]);
+					SmallSet dm(lane), tmp(lane);
 					bool initialized = false;
 					for (int k = 0; k < cnt; k++)
 					{
@@ -1431,7 +1442,7 @@ namespace agx
 					uint32_t best = 0x0000u;
 					for (int k = 0; k < dm.n; k++)
 					{
-						const int cell = dm.v[k];
+						const int cell = dm.at(k);
 						uint32_t response = s_unknown(0);
 						switch (threat_at(own, cell))
 						{
@@ -1508,9 +1519,9 @@ namespace agx
 								winning = true;
 							if (winning)
 							{
-								SmallSet two(sh.sets[4]);
+								SmallSet two(lane);
 								defensive_moves(opp, cell, dir, two);
-								const int original = (two.v[0] == cell) ? two.v[1] : two.v[0];
+								const int original = (two.at(0) == cell) ? two.at(1) : two.at(0);
 								add_move(original, s_win_in(3), false);
 								result = s_win_in(3);
 								return false;
@@ -1527,7 +1538,7 @@ namespace agx
 				}
 				__device__ __forceinline__ bool defend_loss_in_4_renju(bool any_four, uint32_t &result)
 				{ // :621-677: no intersection of defences in renju, every defensive move of every threat is kept
-					SmallSet tmp(sh.sets[1]);
+					SmallSet tmp(lane);
 					{
 						const int cnt = copy_list(opp, 7);
 						for (int k = 0; k < cnt; k++)
@@ -1537,7 +1548,7 @@ namespace agx
 							const int dir = direction_of(patterns(opp, cell), 4);
 							get_defensive_moves(cell, dir, tmp);
 							for (int i = 0; i < tmp.n; i++)
-								add_move(tmp.v[i], s_unknown(0), false);
+								add_move(tmp.at(i), s_unknown(0), false);
 						}
 					}
 					if (fouls_possible_for(opp))
@@ -1552,7 +1563,7 @@ namespace agx
 								const int dir = direction_of(patterns(opp, cell), 4);
 								get_defensive_moves(cell, dir, tmp);
 								for (int i = 0; i < tmp.n; i++)
-									add_move(tmp.v[i], s_unknown(0), false);
+									add_move(tmp.at(i), s_unknown(0), false);
 							}
 						}
 					}
@@ -1570,7 +1581,7 @@ namespace agx
 								{
 									get_defensive_moves(cell, d, tmp);
 									for (int i = 0; i < tmp.n; i++)
-										add_move(tmp.v[i], s_unknown(0), false);
+										add_move(tmp.at(i), s_unknown(0), false);
 								}
 							}
 						}
@@ -1594,7 +1605,7 @@ namespace agx
 				{ // :556-689
 					const bool any_four = has_any_four(own);
 					f.baseline = static_cast<uint16_t>(s_loss_in(4));
-					SmallSet dm(sh.sets[0]), tmp(sh.sets[1]), storage(sh.sets[2]);
+					SmallSet dm(lane), tmp(lane), storage(lane);
 					bool initialized = false;
 					if (RENJU)
 						return defend_loss_in_4_renju(any_four, result);
@@ -1633,8 +1644,8 @@ namespace agx
 								{
 									get_defensive_moves(cell, d, tmp);
 									for (int i = 0; i < tmp.n; i++)
-										if (!storage.contains(tmp.v[i]))
-											storage.add(tmp.v[i]);
+										if (!storage.contains(tmp.at(i)))
+											storage.add(tmp.at(i));
 								}
 							intersect_init(dm, initialized, storage);
 						}
@@ -1646,7 +1657,7 @@ namespace agx
 						}
 					}
 					for (int i = 0; i < dm.n; i++)
-						add_move(dm.v[i], s_unknown(0), false);
+						add_move(dm.at(i), s_unknown(0), false);
 					if (f.must_defend)
 					{
 						f.has_initiative = any_four ? 1 : 0;
@@ -1684,7 +1695,7 @@ namespace agx
 						f.must_defend = 1;
 						f.baseline = static_cast<uint16_t>(s_loss_in(6));
 					}
-					SmallSet tmp(sh.sets[1]), half4(sh.sets[3]);
+					SmallSet tmp(lane), half4(lane);
 					for (int k = 0; k < n43; k++)
 					{
 						const int cell = item(opp, 5, k);
@@ -1694,15 +1705,15 @@ namespace agx
 							{
 								get_defensive_moves(cell, d, tmp);
 								for (int i = 0; i < tmp.n; i++)
-									add_move(tmp.v[i], s_unknown(0), false);
+									add_move(tmp.at(i), s_unknown(0), false);
 							}
 						const int dir = direction_of(group, 3);
 						get_defensive_moves(cell, dir, half4);
 						for (int i = 0; i < half4.n; i++)
-							add_move(half4.v[i], s_unknown(0), false);
+							add_move(half4.at(i), s_unknown(0), false);
 						for (int i = 0; i < half4.n; i++)
 						{ // the 4 x 9 (direction, offset) candidates around a defensive move: one per lane, added in (d, j) order
-							const int hr = half4.v[i] / n, hc = half4.v[i] % n;
+							const int hr = half4.at(i) / n, hc = half4.at(i) % n;
 							int l = -1;
 							bool wanted = false;
 							if (lane < 36)
@@ -1734,7 +1745,7 @@ namespace agx
 							{
 								get_defensive_moves(cell, d, tmp);
 								for (int i = 0; i < tmp.n; i++)
-									add_move(tmp.v[i], s_unknown(0), false);
+									add_move(tmp.at(i), s_unknown(0), false);
 							}
 						add_list(own, 3, s_unknown(13), false);
 						add_list(own, 2, s_unknown(1), false);
@@ -1832,9 +1843,10 @@ namespace agx
 						mark_neighborhood();
 						create_remaining_moves(sh.row_mask, s_unknown(0));
 					}
+					AGX_PROF_MARK(sh, 7);
 					if (fouls_possible_for(own))
 						mark_forbidden_moves();
-					AGX_PROF_MARK(sh, 7);
+					AGX_PROF_MARK(sh, 9); // renju: mark_forbidden_moves
 					f.fully_expanded = (f.must_defend || mode >= 2) ? 1 : 0;
 					return result;
 				}

@@ -148,7 +148,8 @@ namespace
 				t.score = s_unknown(0);
 				t.win = 0.0f;
 				t.draw = 0.0f;
-				t.moves_left = 0.0f;
+				// (t.moves_left stays: SearchTask::set (SearchTask.cpp:32-50) resets the value, not the moves-left estimate — a proven-edge leaf, which neither
+				//  the solver nor the network touches, backs up what the previous occupant of this task slot left behind, Tree.cpp:304)
 				t.needs_nn = 0;
 				t.hash = hash;
 				if (out == 0 && path_len > gs.max_depth)
@@ -257,11 +258,15 @@ namespace
 #endif
 		solver_set_board(sh, E, t.board, t.sign_to_move, lane);
 		solver_encode_features(sh, E, E.nn_features + static_cast<size_t>(slot) * E.hw, lane);
+		#ifdef AGX_SOLVER_PROFILE
+		const unsigned long long c_enc = wall_clock64();
+		#endif
 		if (RENJU)
 			solver_encode_forbidden(sh, E, E.nn_features + static_cast<size_t>(slot) * E.hw, lane);
-#ifdef AGX_SOLVER_PROFILE
+		#ifdef AGX_SOLVER_PROFILE
 		unsigned long long c1 = wall_clock64();
-#endif
+		const unsigned long long t_forbidden = c1 - c_enc; // renju: the forbidden-move bits of the network input (probes place and remove stones)
+		#endif
 		u64 lo = 0, hi = 0;
 		for (int i = lane; i < E.hw; i += 64)
 		{
@@ -399,6 +404,7 @@ namespace
 			pg.prof[7] += sh.prof[2] | (sh.prof[3] << 32);
 			for (int i = 0; i < 24; i++)
 				pg.dprof[i] += sh.dprof[i];
+			pg.dprof[23] += t_forbidden;
 		}
 #endif
 		wave_sync();
@@ -594,7 +600,7 @@ namespace
 	 * deadlock whatever the grid size.
 	 */
 	template<class SH>
-	__device__ __forceinline__ void spec_flush(const SH &sh, SpecTask &h, int nodes, uint32_t flags0, int lane)
+	__device__ __forceinline__ void spec_flush(const SH &sh, SpecTask &h, int nodes, uint32_t flags0, float moves_left0, int lane)
 	{
 		const int cnt = sh.ov_count;
 		for (int i = lane; i < cnt; i += 64)
@@ -607,6 +613,7 @@ namespace
 			h.overflow = (sh.ov_overflow || sh.error == ERR_OVERLAY) ? 1 : 0;
 			h.nodes = nodes;
 			h.flags0 = flags0;
+			h.moves_left0 = moves_left0;
 			h.solved = 1;
 		}
 	}
@@ -683,7 +690,7 @@ namespace
 						tj.flags = hj.flags0;
 						tj.win = 0.0f;
 						tj.draw = 0.0f;
-						tj.moves_left = 0.0f;
+						tj.moves_left = hj.moves_left0;
 						hj.solved = 0;
 					}
 				}
@@ -959,6 +966,7 @@ namespace
 			const int slot = g * E.batch + k;
 			DTask &t = E.tasks[slot];
 			const uint32_t flags0 = t.flags;
+			const float moves_left0 = t.moves_left;
 			unsigned long long n1 = 0;
 			SPEC_T(t_s0);
 			solve_task<RENJU>(sh, E, g, t, slot, E.games[g].generation, lane, n1, area, speculative ? E.spec_overlay + static_cast<size_t>(slot) * (SPEC_OV_CAP * 16) : nullptr);
@@ -967,7 +975,7 @@ namespace
 				commit.nodes += n1;
 				continue;
 			}
-			spec_flush(sh, E.spec_tasks[slot], static_cast<int>(n1), flags0, lane);
+			spec_flush(sh, E.spec_tasks[slot], static_cast<int>(n1), flags0, moves_left0, lane);
 			SPEC_T(t_solved);
 			SPEC_ADD(3, t_solved - t_s0); // speculative solves
 			SPEC_ADD(6, 1);
@@ -3764,6 +3772,8 @@ int agx_engine_stats(AgxEngine *e, AgxEngineStats *out)
 				dp[21] / solves, dp[22] / solves, dp[15] / solves, dp[16] / solves, dp[17] / solves, dp[20] / solves);
 		fprintf(stderr, "[update_around, shader cycles per solve; %.1f calls, %.2f list changes per call] centre %.0f, gather %.0f, lists %.0f\n",
 				dp[14] / solves, dp[13] / (dp[14] ? static_cast<double>(dp[14]) : 1.0), dp[10] / solves, dp[11] / solves, dp[12] / solves);
+		fprintf(stderr, "[renju, per solve] forbidden bits of the network input %.1f us, mark_forbidden_moves %.0f shader cycles, generator foul tests %.0f shader cycles (%.2f tests)\n",
+				dp[23] / 100.0 / solves, dp[9] / solves, dp[18] / solves, dp[19] / solves);
 	}
 #endif
 	{

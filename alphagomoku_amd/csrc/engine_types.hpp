@@ -169,7 +169,9 @@ namespace agx
 			int32_t overflow;   // the overlay was full: the result is void
 			int32_t nodes;      // solver positions of the speculative run
 			uint32_t flags0;    // the task's flags before the solve (a discarded run must not leave its own behind)
-			uint32_t pad[3];
+			float moves_left0;  // ... and its moves-left value: SearchTask::set does not reset it (SearchTask.cpp:32-50), a leaf that nobody evaluates
+			                    // (a proven edge) backs up what the slot's previous occupant left there
+			uint32_t pad[2];
 			uint32_t dirty[SPEC_OV_CAP / 32];
 			uint32_t keys[SPEC_OV_CAP]; // table bucket of every slot
 	};

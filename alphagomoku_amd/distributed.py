@@ -67,3 +67,38 @@ def gather(dist, values):
 def rank_seed_base(rank):
     """disjoint opening seeds per rank so that the ranks play different games"""
     return rank * 1000003
+
+
+def pin_to_gpu_numa_node(local_device):
+    """Binds this process's host threads to the CPUs of the NUMA node its GPU hangs off (one generator thread per device in the reference,
+    GeneratorManager.cpp:146-152; SURVEY 8e: the host side of a rank is a launch loop, it must not wander to the other socket).  Best effort
+    from sysfs — the local_device-th AMD display / processing-accelerator PCI function in address order, its numa_node, that node's cpulist
+    intersected with the current affinity; returns (numa_node, cpus pinned to) or (None, 0) when the topology cannot be read."""
+    import glob
+    try:
+        gpus = []
+        for dev in glob.glob("/sys/bus/pci/devices/*"):
+            try:
+                vendor = open(os.path.join(dev, "vendor")).read().strip()
+                cls = open(os.path.join(dev, "class")).read().strip()
+            except OSError:
+                continue
+            if vendor == "0x1002" and (cls.startswith("0x03") or cls.startswith("0x12")):
+                gpus.append(dev)
+        gpus.sort()
+        if local_device >= len(gpus):
+            return None, 0
+        node = int(open(os.path.join(gpus[local_device], "numa_node")).read().strip())
+        if node < 0:
+            return None, 0
+        cpus = set()
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        allowed = cpus & set(os.sched_getaffinity(0))
+        if not allowed:
+            return node, 0
+        os.sched_setaffinity(0, allowed)
+        return node, len(allowed)
+    except (OSError, ValueError, AttributeError):
+        return None, 0

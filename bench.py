@@ -46,46 +46,88 @@ def source_hash():
     return build.source_hash()
 
 
+def host_cpu_limits():
+    """what bounds a CPU leg on this box: the CPUs this process may run on (affinity), the cgroup CPU quota (cpu.max, cgroup v2; cfs quota, v1)
+    and the CPU model"""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota_cpus, quota_text = None, None
+    try:
+        quota_text = open("/sys/fs/cgroup/cpu.max").read().strip()
+        q, period = quota_text.split()
+        if q != "max":
+            quota_cpus = float(q) / float(period)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            quota_text = "%d %d" % (q, period)
+            if q > 0:
+                quota_cpus = q / period
+        except (OSError, ValueError):
+            pass
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return cores, quota_cpus, quota_text, model
+
+
 def cpu_baseline(args, max_seconds):
     """Times the CPU oracle (a scalar restatement of the reference search, oracle/) on this box's host cores with a stand-in
     evaluator (network cost = 0).  This is the ONLY place where bench.py touches oracle/."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as ol
     lib = ol.load()
-    # the CPUs this process may run on (affinity / cgroup view), not the machine's total
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    # the CPUs this process may run on (affinity view) and what the cgroup lets them consume (quota), not the machine's total
+    cores, quota_cpus, quota_text, model = host_cpu_limits()
+    usable = max(1, min(cores, int(quota_cpus)) if quota_cpus else cores)
     cfg = ol.default_search_config(max_batch_size=args.batch, max_simulations=args.sims, table_entries=4 * 1024 * 1024)
 
     def leg(threads, seconds):
         nodes, games, moves = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
         took = ctypes.c_double()
         stats = (ctypes.c_uint64 * 9)()
-        lib.ago_cpu_baseline(args.rules, args.board, args.board, ctypes.byref(cfg), threads, 1000, ctypes.c_double(seconds),
-                             ctypes.byref(nodes), ctypes.byref(games), ctypes.byref(moves), ctypes.byref(took), stats)
+        cpu = (ctypes.c_double * threads)()
+        lib.ago_cpu_baseline_ex.restype = None
+        lib.ago_cpu_baseline_ex(args.rules, args.board, args.board, ctypes.byref(cfg), threads, 1000, ctypes.c_double(seconds),
+                                ctypes.byref(nodes), ctypes.byref(games), ctypes.byref(moves), ctypes.byref(took), stats, cpu)
+        cpu_total = sum(cpu)
         return dict(threads=threads, simulations_per_sec=nodes.value / took.value, per_thread=nodes.value / took.value / threads, seconds=took.value,
-                    simulations=nodes.value, moves=moves.value)
+                    simulations=nodes.value, moves=moves.value,
+                    # user + system CPU seconds the worker threads consumed inside the timed region (CLOCK_THREAD_CPUTIME_ID): utilisation well below
+                    # 1 = the threads did not get the CPUs they were started on (quota, oversubscription), not a property of the code
+                    thread_cpu_seconds_mean=cpu_total / threads, thread_cpu_seconds_min=min(cpu), cpu_utilisation=cpu_total / (threads * took.value),
+                    simulations_per_cpu_second=nodes.value / max(cpu_total, 1e-9))
 
     # one self-play game per thread, every game with its own 64 MB solver table like the reference's Search: the best thread count is not
     # obvious (more threads than physical cores / memory channels lose throughput), so a short sweep picks it; the best leg is the value
     if args.cpu_threads > 0:
-        counts = [min(cores, args.cpu_threads)]
+        counts = [min(usable, args.cpu_threads)]
     else:
-        counts = sorted({c for c in (cores // 8, cores // 4, cores // 2, cores) if c >= 1})
+        counts = sorted({c for c in (usable // 8, usable // 4, usable // 2, usable) if c >= 1})
     probes = [leg(c, 0.1 * max_seconds) for c in counts] if len(counts) > 1 else []
     chosen = max(probes, key=lambda x: x["simulations_per_sec"])["threads"] if probes else counts[0]
     best = leg(chosen, max_seconds - 0.1 * max_seconds * len(probes))     # the reported value: one long leg at the best thread count
     legs = probes + [best]
+    worst = min(legs, key=lambda x: x["per_thread"])
     return dict(value=best["simulations_per_sec"], unit="simulations/s", cores=best["threads"], kind="port",
                 sample="%d threads x 1 self-play game each (same rules/board/playouts/batch, stand-in evaluator, NN cost excluded), %.1f s wall, %d simulations, %d moves; "
-                       "thread count chosen by short probes over %s threads (every host CPU is slower: one 64 MB solver table per game)"
+                       "thread count chosen by short probes over %s threads"
                        % (best["threads"], best["seconds"], best["simulations"], best["moves"], counts),
-                host_cpus=cores, host_cpus_total=os.cpu_count(), per_thread=best["per_thread"], sweep=legs,
-                # why more threads are slower: every thread owns a 64 MB solver table (the reference's size) and touches it at random, so n threads
-                # keep n x 64 MB hot — beyond the last-level cache the threads queue on DRAM, and past the physical cores they also share them
-                scaling_note="one 64 MB transposition table per game thread, randomly accessed: the working set leaves the last-level cache",
+                host_cpus=cores, host_cpus_total=os.cpu_count(), cgroup_cpu_max=quota_text, cgroup_quota_cpus=quota_cpus, cpu_model=model,
+                per_thread=best["per_thread"], cpu_utilisation=best["cpu_utilisation"], thread_cpu_seconds_mean=best["thread_cpu_seconds_mean"],
+                simulations_per_cpu_second=best["simulations_per_cpu_second"], sweep=legs,
+                # what the sweep's shape means is read off the legs themselves: per CPU-SECOND a thread does about the same work at every count when
+                # the slowdown is lost CPU time (quota / more threads than CPUs granted: cpu_utilisation falls), and less work per CPU-second when
+                # it is memory (every thread owns a 64 MB solver table — the reference's size — touched at random: n threads keep n x 64 MB hot)
+                scaling_note="slowest leg: %d threads, %.0f simulations/s per thread at CPU utilisation %.2f, %.0f simulations per CPU-second (best leg: %.0f)"
+                             % (worst["threads"], worst["per_thread"], worst["cpu_utilisation"], worst["simulations_per_cpu_second"], best["simulations_per_cpu_second"]),
                 # SURVEY 8(d): the REAL reference search core (compiled with AVX2 intrinsics, one thread, fake evaluator) measured 10.5 k/s for this
-                # shape in the survey container; the oracle is a scalar restatement (no SSE/AVX neighbourhood code) and every game owns a 64 MB
-                # solver table, so with many games per socket the tables live in DRAM, not in cache
+                # shape in the survey container; the oracle is a scalar restatement (no SSE/AVX neighbourhood code)
                 reference_core_per_thread_survey=10500.0)
 
 
@@ -165,7 +207,10 @@ def main():
     from alphagomoku_amd.networks import AGNetwork
     build_hash = _lib.require_current_build()   # refuses a stale prebuilt libagx.so (its compiled-in hash != the sources beside it)
 
-    check(lib.agx_set_device(int(os.environ.get("AGX_FORCE_DEVICE", local_rank))))  # AGX_FORCE_DEVICE: test the N > 1 flow on a 1-GPU box
+    device_index = int(os.environ.get("AGX_FORCE_DEVICE", local_rank))  # AGX_FORCE_DEVICE: test the N > 1 flow on a 1-GPU box
+    # a rank's host side is one launch loop: keep it on the CPUs next to its GPU (only with several ranks: a single rank keeps the box's affinity)
+    numa_node, pinned_cpus = distributed.pin_to_gpu_numa_node(device_index) if world > 1 and not os.environ.get("AGX_NO_PIN") else (None, 0)
+    check(lib.agx_set_device(device_index))
     desc = synthetic.net_desc(rows=args.board, cols=args.board, blocks=args.blocks, filters=args.filters, action_values=args.action_values)
     blob, _ = synthetic.make_weights(desc, policy_gain=args.policy_gain)
     net = AGNetwork(desc)
@@ -267,6 +312,7 @@ def main():
         dist.barrier()
     check(lib.agx_device_synchronize())
     t0 = time.perf_counter()
+    cpu0 = time.process_time()
     for i in range(args.steps):
         for g in range(slices):
             step_slice(g, t_nn[g][i])
@@ -275,6 +321,7 @@ def main():
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    host_cpu_seconds = time.process_time() - cpu0   # user + system time of this rank's process inside the timed region (all its threads)
     s1 = pool.stats()
     kernel_ms, kernel_launches = pool.kernel_timing(False)
 
@@ -299,7 +346,7 @@ def main():
     leaks = s1["information_leaks"] - s0["information_leaks"]
     local_elapsed = elapsed
     per_rank = distributed.gather(dist, [sims, local_elapsed, distributed.rank_seed_base(rank), int(os.environ.get("AGX_FORCE_DEVICE", local_rank)),
-                                         s1["first_error"]])
+                                         s1["first_error"], host_cpu_seconds, -1 if numa_node is None else numa_node, pinned_cpus])
     elapsed, (sims, evals, moves, games_done) = distributed.combine(dist, elapsed, [sims, evals, moves, games_done])
     # an engine error on ANY rank fails every rank, after the collectives (a rank that raised before them would leave the others waiting)
     failed = [(i, int(r[4])) for i, r in enumerate(per_rank) if int(r[4]) != 0]
@@ -400,7 +447,11 @@ def main():
             "shape": {"mean_select_depth": depth, "mean_edges_per_level": edges_per_level,
                       "solver_nodes_per_simulation": solver_nodes / max(1, s1["evaluated_nodes"] - s0["evaluated_nodes"]),
                       "nn_evals_per_simulation": local_evals / max(1, s1["evaluated_nodes"] - s0["evaluated_nodes"])},
-            "ranks": [{"rank": i, "device": int(r[3]), "simulations": int(r[0]), "seconds": r[1], "opening_seed_base": int(r[2])} for i, r in enumerate(per_rank)],
+            # per rank: its own work and wall time, the host CPU it needed (CPU seconds of the rank's process / its wall seconds — one
+            # launch loop per GPU must stay well below one core) and where it was pinned
+            "ranks": [{"rank": i, "device": int(r[3]), "simulations": int(r[0]), "seconds": r[1], "opening_seed_base": int(r[2]),
+                       "host_cpu_seconds": r[5], "host_cpu_utilisation": r[5] / max(r[1], 1e-9), "numa_node": int(r[6]), "pinned_cpus": int(r[7])}
+                      for i, r in enumerate(per_rank)],
             "longest_kernel": {"name": longest, "share_of_kernel_time": per_kernel[longest] / gpu_ms if gpu_ms > 0 else None},
             "source_hash": src_hash, "library_build_hash": build_hash,
             # the roofline object is the MFMA-bound network kernel (the only kernel of the step with a compute roof); the threat solver

@@ -7,6 +7,7 @@
 #include "ag_noise.hpp"
 
 #include <chrono>
+#include <ctime>
 #include <atomic>
 #include <thread>
 
@@ -789,8 +790,22 @@ void ago_game_tree_info(void *h, float *out_f, int *out_i)
  * CPU baseline: plays `games_per_thread` self-play games on each of `threads` host threads with the stand-in evaluator
  * (network cost = 0), for at most `max_seconds`; returns evaluated nodes, completed games and moves made.
  */
+static void cpu_baseline_impl(int rules, int rows, int cols, const AgoSearchConfig *cfg, int threads, int games_per_thread, double max_seconds, uint64_t *out_nodes,
+		uint64_t *out_games, uint64_t *out_moves, double *out_seconds, uint64_t *out_stats, double *out_thread_cpu_seconds);
 void ago_cpu_baseline(int rules, int rows, int cols, const AgoSearchConfig *cfg, int threads, int games_per_thread, double max_seconds, uint64_t *out_nodes,
 		uint64_t *out_games, uint64_t *out_moves, double *out_seconds, uint64_t *out_stats)
+{
+	cpu_baseline_impl(rules, rows, cols, cfg, threads, games_per_thread, max_seconds, out_nodes, out_games, out_moves, out_seconds, out_stats, nullptr);
+}
+/* the same with the CPU time every worker thread consumed inside the timed region (CLOCK_THREAD_CPUTIME_ID): out_thread_cpu_seconds[threads].
+ * Σ cpu / (threads x wall) well below 1 means the threads did not get the cores they were started on (a cgroup CPU quota, oversubscription) */
+void ago_cpu_baseline_ex(int rules, int rows, int cols, const AgoSearchConfig *cfg, int threads, int games_per_thread, double max_seconds, uint64_t *out_nodes,
+		uint64_t *out_games, uint64_t *out_moves, double *out_seconds, uint64_t *out_stats, double *out_thread_cpu_seconds)
+{
+	cpu_baseline_impl(rules, rows, cols, cfg, threads, games_per_thread, max_seconds, out_nodes, out_games, out_moves, out_seconds, out_stats, out_thread_cpu_seconds);
+}
+static void cpu_baseline_impl(int rules, int rows, int cols, const AgoSearchConfig *cfg, int threads, int games_per_thread, double max_seconds, uint64_t *out_nodes,
+		uint64_t *out_games, uint64_t *out_moves, double *out_seconds, uint64_t *out_stats, double *out_thread_cpu_seconds)
 {
 	const GameConfig gc = make_cfg(rules, rows, cols);
 	const SearchConfig sc = convert(cfg);
@@ -811,6 +826,8 @@ void ago_cpu_baseline(int rules, int rows, int cols, const AgoSearchConfig *cfg,
 		ready.fetch_add(1);
 		while (!go.load(std::memory_order_acquire))
 			std::this_thread::yield();
+		timespec cpu0;
+		clock_gettime(CLOCK_THREAD_CPUTIME_ID, &cpu0);
 		for (int gi = 0; gi < games_per_thread; gi++)
 		{
 			game.begin(prepare_opening(gc, 1000u * tid + gi));
@@ -829,6 +846,10 @@ void ago_cpu_baseline(int rules, int rows, int cols, const AgoSearchConfig *cfg,
 			if (el > max_seconds)
 				break;
 		}
+		timespec cpu1;
+		clock_gettime(CLOCK_THREAD_CPUTIME_ID, &cpu1);
+		if (out_thread_cpu_seconds != nullptr)
+			out_thread_cpu_seconds[tid] = static_cast<double>(cpu1.tv_sec - cpu0.tv_sec) + 1.0e-9 * static_cast<double>(cpu1.tv_nsec - cpu0.tv_nsec);
 		nodes[tid] = game.search.stats.nodes;
 		const Stats &s = game.search.stats;
 		const uint64_t vals[9] = { s.nodes, s.nn_evals, s.leaks, s.duplicates, s.proven, s.wasted, s.solver_nodes, game.tree.stats.select_levels, game.tree.stats.select_edges };

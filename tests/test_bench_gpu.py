@@ -49,3 +49,20 @@ def test_pool_rate_floor(agx_lib):
     assert line["slices"]["count"] == 4 and line["slices"]["cus_per_slice"] * 4 <= 256
     assert line["roofline"]["whole_chip_equivalent"] >= 800.0 and 0 < line["roofline"]["frac"] < 1, line["roofline"]
     assert line["peak_tree_per_game"]["arena_failures"] == 0
+
+
+def test_eight_ranks_on_one_gpu(agx_lib):
+    """BASELINE configs[2]'s launch shape — `bench.py --gpus 8 --config C3` = one rank per GPU, games sharded, no collective on the data path
+    (GeneratorManager.cpp:146-152) — on ONE GPU: all eight ranks on device 0 with small pools.  No scaling is measured here (there is one
+    GPU); what is checked is the whole-job line: eight ranks with disjoint openings, value = the ranks' simulations / the slowest rank's time,
+    a host-side launch loop per rank that needs less than one core."""
+    line = run_bench(["--gpus", "8", "--config", "C3", "--games", "128", "--steps", "40", "--warmup", "5", "--age-steps", "0", "--table-entries", "65536",
+                      "--no-cpu-baseline", "--slices", "1"], env={"AGX_FORCE_DEVICE": "0"})
+    assert line["n_gpus"] == 8 and line["scaling"] == "weak" and "standard" in json.dumps(line["config"]).lower()
+    ranks = line["ranks"]
+    assert [r["rank"] for r in ranks] == list(range(8)) and all(r["device"] == 0 for r in ranks)
+    assert len({r["opening_seed_base"] for r in ranks}) == 8
+    total = sum(r["simulations"] for r in ranks)
+    assert all(r["simulations"] > 0 for r in ranks)
+    assert abs(line["value"] * (line["ms_per_step"] * 1e-3 * line["steps"]) - total) <= 1e-6 * total
+    assert all(0.0 < r["host_cpu_utilisation"] < 1.5 for r in ranks)
