@@ -48,6 +48,7 @@ namespace agx
 #define AGX_OP_MAX(a, b) max(a, b)
 #define AGX_OP_ADD(a, b) ((a) + (b))
 #define AGX_OP_XOR(a, b) ((a) ^ (b))
+#define AGX_OP_OR(a, b) ((a) | (b))
 #define AGX_WAVE_REDUCE(V, OP) do { AGX_DPP_STEP(V, OP, 0x111, 0xf); AGX_DPP_STEP(V, OP, 0x112, 0xf); AGX_DPP_STEP(V, OP, 0x114, 0xf); \
 		AGX_DPP_STEP(V, OP, 0x118, 0xf); AGX_DPP_STEP(V, OP, 0x142, 0xa); AGX_DPP_STEP(V, OP, 0x143, 0xc); } while (0)
 		__device__ __forceinline__ uint32_t wave_reduce_umax(uint32_t v)
@@ -226,14 +227,16 @@ namespace agx
 				unsigned long long prof[8];
 				unsigned long long dprof[24];
 #endif
-				u64 hash_lo, hash_hi;
+				// the frame machine's scalars: written together when it yields, read together when it resumes — three 16-byte words
+				alignas(16) u64 hash_lo;
+				u64 hash_hi;
+				int phase, level, node_counter, stack_offset;
+				int stack_max, error, pending_value, cmd_move;
 				u64 time_deadline;       // time-limited solves (E.solve_time_ticks != 0): the wall-clock tick at which this task's share of the time is over
 				uint16_t *spill_lists;   // [2][10][hw] tails of the threat lists (HBM, per game)
 				Frame *spill_frames;     // [MAX_FRAMES] frames beyond LDS_FRAMES (HBM, per game)
 				int sign_to_move, depth;
-				int node_counter, stack_offset, stack_max, level;
-				int cmd, cmd_move, pending_value, error;
-				int result_score, phase;
+				int cmd, result_score;
 		};
 		typedef SolverSharedT<MAXN> SolverShared; // any board size
 
@@ -503,9 +506,10 @@ namespace agx
 				{ // every operand is requested before the first is looked at: one LDS round trip ahead of the table access, not two
 					const int at = rr * n + cc;
 					const int stone = sh.board[at];
-					const int t0 = sh.threat[at][0], t1 = sh.threat[at][1];
-					uint32_t w0 = *reinterpret_cast<const uint32_t*>(&sh.ptype[at][0]); // cross, one byte per direction
-					uint32_t w1 = *reinterpret_cast<const uint32_t*>(&sh.ptype[at][4]); // circle
+					const uint32_t t01 = *reinterpret_cast<const uint16_t*>(&sh.threat[at][0]); // both sides' threat types: one read
+					const int t0 = t01 & 255u, t1 = t01 >> 8;
+					const u64 w01 = *reinterpret_cast<const u64*>(&sh.ptype[at][0]);            // the eight pattern types of the cell: one read
+					uint32_t w0 = static_cast<uint32_t>(w01), w1 = static_cast<uint32_t>(w01 >> 32); // cross / circle, one byte per direction
 					uint32_t raw = 0;
 					if (!prefetched)
 						raw = narrow(normal_pattern(sh, n, rr, cc, d));
@@ -517,12 +521,12 @@ namespace agx
 						const uint32_t e = prefetched ? pf_e : E.t_pattern[raw]; // (the byte is widened HERE, not where it was requested)
 						w0 = (w0 & ~(255u << (8 * d))) | ((e & 15u) << (8 * d));
 						w1 = (w1 & ~(255u << (8 * d))) | ((e >> 4) << (8 * d));
-						sh.ptype[cell][d] = static_cast<uint8_t>(e & 15u);
-						sh.ptype[cell][4 + d] = static_cast<uint8_t>(e >> 4);
+						// (every lane of the gather owns a different cell — the four lines through the centre meet nowhere else — so the cell's whole pattern
+						//  words and both threat types go back in one store each)
+						*reinterpret_cast<u64*>(&sh.ptype[cell][0]) = static_cast<u64>(w0) | (static_cast<u64>(w1) << 32);
 						new0 = threat_lookup(sh, E, (w0 & 7u) | (((w0 >> 8) & 7u) << 3) | (((w0 >> 16) & 7u) << 6) | (((w0 >> 24) & 7u) << 9)) & 15;
 						new1 = threat_lookup(sh, E, (w1 & 7u) | (((w1 >> 8) & 7u) << 3) | (((w1 >> 16) & 7u) << 6) | (((w1 >> 24) & 7u) << 9)) >> 4;
-						sh.threat[cell][0] = static_cast<uint8_t>(new0);
-						sh.threat[cell][1] = static_cast<uint8_t>(new1);
+						*reinterpret_cast<uint16_t*>(&sh.threat[cell][0]) = static_cast<uint16_t>(new0 | (new1 << 8));
 					}
 				}
 			}
@@ -642,20 +646,17 @@ namespace agx
 				else
 					sh.lines[index] &= ~(3ull << (12 + shift));
 			}
-			if (lane == 0)
-			{
+			{ // wave-uniform values: every lane stores the same word to the same address (no exec masking around the stores)
 				sh.board[r * n + c] = add ? static_cast<uint8_t>(s) : 0;
-				if (add)
-					sh.legal[r] &= ~(1u << c);
-				else
-					sh.legal[r] |= (1u << c);
+				const uint32_t row_bits = sh.legal[r];
+				sh.legal[r] = add ? (row_bits & ~(1u << c)) : (row_bits | (1u << c));
 			}
 			wave_sync();
 			solver_update_around(sh, E, r, c, add, lane, prefetched, pf_e);
-			if (lane == 0)
 			{
-				sh.sign_to_move = 3 - sh.sign_to_move;
-				sh.depth += add ? 1 : -1;
+				const int to_move = sh.sign_to_move, stones = sh.depth;
+				sh.sign_to_move = 3 - to_move;
+				sh.depth = stones + (add ? 1 : -1);
 			}
 			wave_sync();
 		}
@@ -897,87 +898,72 @@ namespace agx
 		}
 
 		/* ---------------- defensive-move lookup (DefensiveMoveTable.cpp:380-461) ---------------- */
-		// line shapes of the attacker (cross stones; circle = 2x), read through the scalar cache
-		__constant__ const uint32_t FIVE[5] = { 85u, 277u, 325u, 337u, 340u };
-		__constant__ const uint32_t OPEN4[4] = { 84u, 276u, 324u, 336u };
-		__constant__ const uint32_t DOUBLE4[6] = { 4177u, 4369u, 4417u, 20549u, 20741u, 86037u };
-		__constant__ const int DOUBLE4_LEN[6] = { 7, 7, 7, 8, 8, 9 };
-		__constant__ const int DOUBLE4_OFF[6] = { 2, 3, 4, 2, 3, 2 };
-		__constant__ const uint32_t HALF4[20] = { 21u, 69u, 81u, 84u, 21u, 261u, 273u, 276u, 69u, 261u, 321u, 324u, 81u, 273u, 321u, 336u, 84u, 276u, 324u, 336u };
-		__constant__ const int HALF4_OFF[20] = { 3, 4, 5, 6, 2, 4, 5, 6, 2, 3, 5, 6, 2, 3, 4, 6, 2, 3, 4, 5 };
-		__constant__ const uint32_t OPEN3[12] = { 20u, 68u, 80u, 20u, 260u, 272u, 68u, 260u, 320u, 80u, 272u, 320u };
-		__constant__ const int OPEN3_OFF[12] = { 3, 4, 5, 2, 4, 5, 2, 3, 5, 2, 3, 4 };
 		__constant__ const uint32_t STENCIL_BOX[7] = { 73u, 62u, 62u, 119u, 62u, 62u, 73u };   // MoveGenerator.cpp:1014-1023
 		__constant__ const uint32_t STENCIL_STAR[7] = { 73u, 42u, 28u, 119u, 28u, 42u, 73u };  // MoveGenerator.cpp:1075-1084
 		__constant__ const int EVAL_OWN[10] = { 0, 0, 19, 49, 76, 170, 33, 159, 252, 0 };      // AlphaBetaSearch.cpp:356-357
 		__constant__ const int EVAL_OPP[10] = { 0, 0, -1, -50, -45, -135, -14, -154, -496, 0 };
 
+		/* The 47 line shapes of getDefensiveMoves (DefensiveMoveTable.cpp:380-461), one per LANE: the shape as cross stones, where it starts in the
+		 * 13-cell window and how long it is, its row in the defence table, the threat it answers (pattern type of the attacker's line: 6 FIVE,
+		 * 4 OPEN_4, 5 DOUBLE_4, 3 HALF_OPEN_4, 2 OPEN_3) and the window position its table entry is stored for.  Lanes 47-63 answer nothing. */
+		struct DefShape
+		{
+				uint32_t shape;
+				uint8_t start, len, row, kind, ref, pad[3];
+		};
+		__constant__ const DefShape DEF_SHAPES[64] = {
+			{ 85u, 2, 5, 0, 6, 2 }, { 277u, 3, 5, 1, 6, 3 }, { 325u, 4, 5, 2, 6, 4 }, { 337u, 5, 5, 3, 6, 5 }, { 340u, 6, 5, 4, 6, 6 },
+			{ 84u, 2, 6, 5, 4, 2 }, { 276u, 3, 6, 6, 4, 3 }, { 324u, 4, 6, 7, 4, 4 }, { 336u, 5, 6, 8, 4, 5 },
+			{ 4177u, 2, 7, 9, 5, 2 }, { 4369u, 3, 7, 10, 5, 3 }, { 4417u, 4, 7, 11, 5, 4 }, { 20549u, 2, 8, 12, 5, 2 }, { 20741u, 3, 8, 13, 5, 3 }, { 86037u, 2, 9, 14, 5, 2 },
+			{ 21u, 3, 5, 0, 3, 2 }, { 69u, 4, 5, 0, 3, 2 }, { 81u, 5, 5, 0, 3, 2 }, { 84u, 6, 5, 0, 3, 2 },
+			{ 21u, 2, 5, 1, 3, 3 }, { 261u, 4, 5, 1, 3, 3 }, { 273u, 5, 5, 1, 3, 3 }, { 276u, 6, 5, 1, 3, 3 },
+			{ 69u, 2, 5, 2, 3, 4 }, { 261u, 3, 5, 2, 3, 4 }, { 321u, 5, 5, 2, 3, 4 }, { 324u, 6, 5, 2, 3, 4 },
+			{ 81u, 2, 5, 3, 3, 5 }, { 273u, 3, 5, 3, 3, 5 }, { 321u, 4, 5, 3, 3, 5 }, { 336u, 6, 5, 3, 3, 5 },
+			{ 84u, 2, 5, 4, 3, 6 }, { 276u, 3, 5, 4, 3, 6 }, { 324u, 4, 5, 4, 3, 6 }, { 336u, 5, 5, 4, 3, 6 },
+			{ 20u, 3, 6, 5, 2, 2 }, { 68u, 4, 6, 5, 2, 2 }, { 80u, 5, 6, 5, 2, 2 },
+			{ 20u, 2, 6, 6, 2, 3 }, { 260u, 4, 6, 6, 2, 3 }, { 272u, 5, 6, 6, 2, 3 },
+			{ 68u, 2, 6, 7, 2, 4 }, { 260u, 3, 6, 7, 2, 4 }, { 320u, 5, 6, 7, 2, 4 },
+			{ 80u, 2, 6, 8, 2, 5 }, { 272u, 3, 6, 8, 2, 5 }, { 320u, 4, 6, 8, 2, 5 } };
+		/* All lanes hold the same arguments; lane i tests shape i against the window (one compare instead of a loop over up to 20 shapes run by
+		 * every lane), a ballot finds the first match in table order, and the matching lane's defence-table entry is broadcast.  Same results as
+		 * the loops of DefensiveMoveTable.cpp: first matching shape per threat kind; HALF_OPEN_4 under the caro rules ORs every match. */
 		__device__ __forceinline__ uint32_t defensive_mask(const EngineDev &E, uint32_t pattern, int defender, int threat_to_defend)
 		{
+			if (threat_to_defend < 2 || threat_to_defend > 6)
+				return 0u;
+			const int lane = static_cast<int>(threadIdx.x);
 			const int attacker = 3 - defender;
-			const int d = defender - 1;
 			const uint32_t mul = (attacker == 1) ? 1u : 2u;
-#define AGX_SUB(start, len) ((pattern >> (2 * (start))) & ((1u << (2 * (len))) - 1u))
-#define AGX_SIDES(left, right) (((pattern >> (2 * ((left) - 2))) & 15u) | (((pattern >> (2 * (right))) & 15u) << 4))
-			switch (threat_to_defend)
+			const DefShape c = DEF_SHAPES[lane];
+			const int start = c.start, len = c.len;
+			const uint32_t sub = (pattern >> (2 * start)) & ((1u << (2 * len)) - 1u);
+			bool match = (static_cast<int>(c.kind) == threat_to_defend) && (sub == c.shape * mul);
+			if (threat_to_defend == 3)
 			{
-				case 6: // FIVE
-					for (int i = 0; i < 5; i++)
-						if (AGX_SUB(2 + i, 5) == FIVE[i] * mul)
-							return E.t_defense[((0 + i) * 256 + AGX_SIDES(2 + i, 2 + i + 5)) * 2 + d];
-					return 0;
-				case 4: // OPEN_4
-					for (int i = 0; i < 4; i++)
-						if (AGX_SUB(2 + i, 6) == OPEN4[i] * mul)
-							return E.t_defense[((5 + i) * 256 + AGX_SIDES(2 + i, 2 + i + 6)) * 2 + d];
-					return 0;
-				case 5: // DOUBLE_4
-					for (int i = 0; i < 6; i++)
-						if (AGX_SUB(DOUBLE4_OFF[i], DOUBLE4_LEN[i]) == DOUBLE4[i] * mul)
-							return E.t_defense[((9 + i) * 256 + AGX_SIDES(DOUBLE4_OFF[i], DOUBLE4_OFF[i] + DOUBLE4_LEN[i])) * 2 + d];
-					return 0;
-				case 3: // HALF_OPEN_4
-				{
-					const bool allow_overline = (E.rules == AGX_FREESTYLE) || (E.rules == AGX_RENJU && attacker == 2) || (E.rules == AGX_CARO6);
-					const bool allow_blocked = (E.rules != AGX_CARO5 && E.rules != AGX_CARO6);
-					uint32_t result = 1u << 6;
-					for (int i = 0; i < 20; i++)
-					{
-						const int begin = HALF4_OFF[i];
-						if (AGX_SUB(begin, 5) != HALF4[i] * mul)
-							continue;
-						const int first = (pattern >> (2 * (begin - 1))) & 3, last = (pattern >> (2 * (begin + 5))) & 3;
-						if (!allow_overline && (first == attacker || last == attacker))
-							continue;
-						if (!allow_blocked && (first == defender && last == defender))
-							continue;
-						uint32_t tmp = E.t_defense[((i / 4) * 256 + AGX_SIDES(begin, begin + 5)) * 2 + d];
-						const int sh = begin - (2 + i / 4);
-						tmp = (sh >= 0) ? ((tmp << sh) & 0xFFFFu) : (tmp >> (-sh));
-						result |= tmp;
-						if (E.rules != AGX_CARO5 && E.rules != AGX_CARO6)
-							return result;
-					}
-					return result;
-				}
-				case 2: // OPEN_3
-					for (int i = 0; i < 12; i++)
-					{
-						const int begin = OPEN3_OFF[i];
-						if (AGX_SUB(begin, 6) == OPEN3[i] * mul)
-						{
-							uint32_t result = E.t_defense[((5 + i / 3) * 256 + AGX_SIDES(begin, begin + 6)) * 2 + d];
-							const int sh = begin - (2 + i / 3);
-							result = (sh >= 0) ? ((result << sh) & 0xFFFFu) : (result >> (-sh));
-							return result | (1u << 6);
-						}
-					}
-					return 0;
-				default:
-					return 0;
+				const bool allow_overline = (E.rules == AGX_FREESTYLE) || (E.rules == AGX_RENJU && attacker == 2) || (E.rules == AGX_CARO6);
+				const bool allow_blocked = (E.rules != AGX_CARO5 && E.rules != AGX_CARO6);
+				const int first = (pattern >> (2 * (start - 1))) & 3, last = (pattern >> (2 * (start + 5))) & 3;
+				if (!allow_overline && (first == attacker || last == attacker))
+					match = false;
+				if (!allow_blocked && (first == defender && last == defender))
+					match = false;
 			}
-#undef AGX_SUB
-#undef AGX_SIDES
+			const uint32_t sides = ((pattern >> (2 * (start - 2))) & 15u) | (((pattern >> (2 * (start + len))) & 15u) << 4);
+			uint32_t entry = E.t_defense[(static_cast<uint32_t>(c.row) * 256u + sides) * 2u + static_cast<uint32_t>(defender - 1)];
+			const int sh = start - static_cast<int>(c.ref);
+			entry = (sh >= 0) ? ((entry << sh) & 0xFFFFu) : (entry >> (-sh));
+			const u64 m = __ballot(match);
+			const uint32_t always = (threat_to_defend == 3) ? (1u << 6) : 0u; // HALF_OPEN_4: the answer starts from the centre cell
+			if (m == 0ull)
+				return always;
+			if (threat_to_defend == 3 && (E.rules == AGX_CARO5 || E.rules == AGX_CARO6))
+			{ // every matching shape contributes
+				uint32_t acc = match ? entry : 0u;
+				AGX_WAVE_REDUCE(acc, AGX_OP_OR);
+				return always | static_cast<uint32_t>(__builtin_amdgcn_readlane(acc, 63));
+			}
+			const uint32_t found = static_cast<uint32_t>(__builtin_amdgcn_readlane(entry, __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(m)) - 1)));
+			return found | ((threat_to_defend == 3 || threat_to_defend == 2) ? (1u << 6) : 0u);
 		}
 
 		/* ---------------- staged move generator, lane 0 only (MoveGenerator.cpp:159-1207, non-renju) ---------------- */
@@ -1199,9 +1185,11 @@ for (int k = 0; k < 5; k++)
 					const int to_defend = patterns(3 - defender, cell)[dir];
 					const uint32_t mask = defensive_mask(E, ext, defender, to_defend);
 					out.n = 0;
-					for (int i = -6; i <= 6; i++)
-						if ((mask >> (6 + i)) & 1)
-							out.add((r + i * row_step(dir)) * n + (c + i * col_step(dir)));
+					for (uint32_t m = mask & 0x1FFFu; m != 0u; m &= m - 1u)
+					{ // the set bits in ascending order = the cells i = -6 .. 6 along the line
+						const int i = __ffs(static_cast<int>(m)) - 1 - 6;
+						out.add((r + i * row_step(dir)) * n + (c + i * col_step(dir)));
+					}
 				}
 				__device__ __forceinline__ void get_defensive_moves(int cell, int dir, SmallSet &out)
 				{ // MoveGenerator::get_defensive_moves (:263-308): defender is the side to move
@@ -1804,8 +1792,8 @@ for (int k = 0; k < 5; k++)
 					const int distance_to_draw = E.draw_after - board_depth;
 					if (distance_to_draw <= 0)
 						return s_make(1, 0);
-					for (int r = 0; r < n; r++)
-						sh.added[r] = 0;
+					if (lane < n)
+						sh.added[lane] = 0; // one row per lane (LDS runs a wave's accesses in issue order: the generator's later reads see it)
 					sh.foul_count = 0;
 					uint32_t result = s_unknown(0);
 					bool go = true;
@@ -1940,11 +1928,18 @@ for (int k = 0; k < 5; k++)
 		/* AlphaBetaSearch::evaluate (AlphaBetaSearch.cpp:345-365) */
 		template<class SH>
 		__device__ __forceinline__ uint32_t solver_evaluate(const SH &sh)
-		{
-			const int own = sh.sign_to_move - 1, opp = 1 - own;
-			int result = 12;
-			for (int t = 2; t <= 8; t++)
-				result += EVAL_OWN[t] * sh.count[own][t] + EVAL_OPP[t] * sh.count[opp][t];
+		{ // one (side, threat type) per lane: lane 10 s + t weighs count[s][t] (types 0, 1 and 9 weigh nothing), a wave sum adds the 20 products — two's
+		  // complement, so the unsigned reduction IS the signed sum — instead of 14 LDS reads and 14 constant loads run by every lane
+			const int lane = static_cast<int>(threadIdx.x);
+			const int own = sh.sign_to_move - 1;
+			int product = 0;
+			if (lane < 20)
+			{
+				const int side = (lane >= 10) ? 1 : 0, t = lane - 10 * side;
+				const int weight = (side == own) ? EVAL_OWN[t] : EVAL_OPP[t];
+				product = weight * static_cast<int>(sh.count[side][t]);
+			}
+			const int result = 12 + static_cast<int>(wave_reduce_add(static_cast<uint32_t>(product)));
 			return s_unknown(max(-1000, min(1000, result)));
 		}
 

@@ -168,6 +168,9 @@ def main():
                     help="> 0: the chip as two partitions shared by all slices — this many compute units run every slice's network launches, the rest "
                          "every slice's search launches (streams ordered by events); 0: every slice owns 1 / slices of the chip for all its stages")
     ap.add_argument("--tree-cus", type=int, default=0, help="with --network-cus: compute units set aside for the expand / advance launches")
+    ap.add_argument("--stagger", type=int, default=1,
+                    help="1: the slices enter the timed region a stage apart in their cycles, as a pool that has run for a while has them (the synchronisation in "
+                         "front of the timed region would otherwise start all of them on the same stage); 0: all slices start with the search launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=24.0)
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline, 0 = every host CPU")
@@ -264,7 +267,33 @@ def main():
             print("bench.py: chip slices unavailable (%s), running one pool" % exc, file=sys.stderr)
             slices, streams = 1, [None]
 
-    def step_slice(g, nn_timer=None):
+    # Where in its cycle (0 search launch, 1 network, 2 expand / advance) a slice's step BEGINS.  A pool that has run for a while has its slices out
+    # of phase by itself (nothing couples them), but the device-wide synchronisation in front of the timed region lines all of them up at the
+    # search launch — four towers then run at once for the first cycles, which is exactly what the slicing is there to avoid, and a 20-step
+    # window is over before they have drifted apart again.  With --stagger (default) slice g enters the timed region `phase[g]` stages into
+    # its cycle (the stages before that are enqueued ahead of the synchronisation, untimed); inside the timed region every slice still runs
+    # EXACTLY `--steps` full cycles — select + solve, network, expand + backup + advance — only rotated.
+    phase = [(0, 1, 2, 1)[g % 4] if (args.stagger and slices > 1 and net_streams is None) else 0 for g in range(slices)]
+
+    def step_slice(g, nn_timer=None, first_stage=0):
+        for stage in ((0, 1, 2), (1, 2, 0), (2, 0, 1))[first_stage]:
+            run_stage(g, stage, nn_timer)
+
+    def run_stage(g, stage, nn_timer):
+        if net_streams is None:   # (the default: a slice's three stages on its one stream)
+            if stage == 0:
+                pool.select_solve_group(g, slices, streams[g])
+            elif stage == 1:
+                if nn_timer is not None:
+                    check(lib.agx_timer_start(nn_timer, streams[g]))
+                pool.evaluate_group(net, g, slices, streams[g])
+                if nn_timer is not None:
+                    check(lib.agx_timer_stop(nn_timer, streams[g]))
+            else:
+                pool.expand_backup_group(g, slices, streams[g])
+            return
+        if stage != 0:
+            return   # (chip partitions: the three stages are enqueued together, with their events, by stage 0)
         pool.select_solve_group(g, slices, streams[g])
         ns = streams[g]
         if net_streams is not None:   # the tower runs on the network partition: its stream waits for the search launch, and the search stream for it
@@ -303,6 +332,9 @@ def main():
         for g in range(slices):
             step_slice(g)
         keep_going(i)
+    for g in range(slices):   # the slices' phase offsets: the stages a rotated step does not begin with (see `phase`)
+        for stage in range(phase[g]):
+            run_stage(g, stage, None)
     check(lib.agx_device_synchronize())
     s0 = pool.stats()
     pool.kernel_timing(True)   # HIP events around every engine kernel, on the launch stream
@@ -315,7 +347,7 @@ def main():
     cpu0 = time.process_time()
     for i in range(args.steps):
         for g in range(slices):
-            step_slice(g, t_nn[g][i])
+            step_slice(g, t_nn[g][i], phase[g])
         keep_going(i)
     check(lib.agx_device_synchronize())
     if dist is not None:
@@ -385,7 +417,7 @@ def main():
         mfma_busy = None
         solver_issue = None
         nn_clock = None
-        pmc_path = os.path.join(ROOT, "profiles", "r03_pmc_summary.json")
+        pmc_path = os.path.join(ROOT, "profiles", "r04_pmc_summary.json")
         src_hash = source_hash()
         pmc_build = None
         if os.path.exists(pmc_path):
@@ -427,7 +459,7 @@ def main():
             "nn_positions_per_sec": evals / elapsed,
             # how the pool is stepped: `count` slices of games_per_gpu / count games, each on a stream that owns cus_per_slice compute units;
             # the slices' launches overlap in time, so the per-launch durations below add up to more than ms_per_step
-            "slices": {"count": slices, "cus_per_slice": cus_per_slice, "games_per_slice": args.games // slices,
+            "slices": {"count": slices, "cus_per_slice": cus_per_slice, "games_per_slice": args.games // slices, "first_stage_of_a_step": phase,
                        "partitions": ({"network_cus": cus_per_slice, "search_cus": total_cus - cus_per_slice - args.tree_cus, "tree_cus": args.tree_cus}
                                       if net_streams is not None else None)},
             "stage_ms_per_step": {"select_solve": ms_sel / launches, "network": ms_nn / launches, "expand_backup_advance": ms_exp / launches,
