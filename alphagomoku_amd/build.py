@@ -122,7 +122,9 @@ def build(force=False, verbose=True):
     # mtimes cannot be trusted (they do not survive every way of copying a tree): everything is compiled again
     current = source_hash()
     stale = list(SOURCES) if force else _stale_objects()
-    if not stale and _recorded_hash() is not None and _recorded_hash() != current:
+    if not stale and _recorded_hash() != current:
+        # (also when NO hash is recorded although objects exist — a tree copied with its .o files but without build_id.inc: the objects' origin is
+        #  unknown, stamping them with the current hash would defeat require_current_build)
         stale = list(SOURCES)
     procs = []
     for src in stale:   # in parallel: engine.hip alone takes minutes

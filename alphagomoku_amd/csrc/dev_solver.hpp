@@ -662,38 +662,41 @@ namespace agx
 		}
 
 		/* getOpenThreePromotionMoves (DefensiveMoveTable.cpp:329-377): first matching shape wins */
-		__constant__ const uint32_t PROMO_PATTERNS[12] = { 320u, 4352u, 20480u, 80u, 16640u, 69632u, 272u, 4160u, 81920u, 320u, 4352u, 20480u };
-		__constant__ const uint32_t PROMO_MASKS[12] = { 65520u, 262080u, 1048320u, 16380u, 262080u, 1048320u, 16380u, 65520u, 1048320u, 16380u, 65520u, 262080u };
+		__constant__ const uint32_t PROMO_PATTERNS[16] = { 320u, 4352u, 20480u, 80u, 16640u, 69632u, 272u, 4160u, 81920u, 320u, 4352u, 20480u, 0u, 0u, 0u, 0u };
+		__constant__ const uint32_t PROMO_MASKS[16] = { 65520u, 262080u, 1048320u, 16380u, 262080u, 1048320u, 16380u, 65520u, 1048320u, 16380u, 65520u, 262080u, 0u, 0u, 0u, 0u };
 		__constant__ const uint32_t PROMO_RESULTS[12] = { 196u, 392u, 784u, 82u, 328u, 656u, 74u, 148u, 592u, 70u, 140u, 280u };
 		__device__ __forceinline__ uint32_t promotion_moves(uint32_t pattern)
 		{
-			for (int i = 0; i < 12; i++)
-				if ((pattern & PROMO_MASKS[i]) == PROMO_PATTERNS[i])
-					return PROMO_RESULTS[i];
-			return 0;
+			// one shape per lane, the first match in table order (all lanes hold the same pattern)
+			const int l = static_cast<int>(threadIdx.x);
+			const bool hit = (l < 12) && ((pattern & PROMO_MASKS[l & 15]) == PROMO_PATTERNS[l & 15]);
+			const u64 m = __ballot(hit);
+			if (m == 0ull)
+				return 0;
+			return PROMO_RESULTS[__builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(m)) - 1)];
 		}
+		/* RawPatternCalculator::isStraightFourAt on the line bit-boards: the 11-cell window around (r, c) in direction d (2 bits per cell, off-board 3),
+		 * a cross stone assumed at the centre and, optionally, at window position `extra` (a stone that is on the reference's raw board but not in
+		 * the pattern state: is_3x3_forbidden puts the fork stone there while it tries the promotion moves, PatternCalculator.cpp:222-231) */
 		template<class SH>
-		__device__ __forceinline__ bool straight_four_at(const SH &sh, int n, int r, int c, int d)
-		{ // RawPatternCalculator::isStraightFourAt (RawPatternCalculator.hpp:142-178) on the byte board, cross stone assumed at (r, c)
-			uint32_t line = 0;
-			for (int k = -5, shf = 0; k <= 5; k++, shf += 2)
-			{
-				const int rr = r + k * row_step(d), cc = c + k * col_step(d);
-				uint32_t v = (rr >= 0 && rr < n && cc >= 0 && cc < n) ? sh.board[rr * n + cc] : 3u;
-				if (k == 0)
-					v |= 1u;
-				line |= v << shf;
-			}
+		__device__ __forceinline__ bool straight_four_with(const SH &sh, int n, int r, int c, int d, int extra)
+		{
+			uint32_t line = normal_pattern(sh, n, r, c, d) | (1u << 10);
+			if (extra >= 0)
+				line |= 1u << (2 * extra);
+			bool found = false;
+#pragma unroll
 			for (int k = 0; k < 7; k++, line >>= 2)
-				if ((line & 255u) == 85u)
-					return true;
-			return false;
+				found = found || ((line & 255u) == 85u);
+			return found;
 		}
 		/*
-		 * PatternCalculator::isForbidden + is_3x3_forbidden (PatternCalculator.hpp:161-177, PatternCalculator.cpp:213-244) for the
-		 * cross player under renju.  The reference recurses through addMove / isForbidden / undoMove; here the recursion is an
-		 * explicit stack, and the stone placement is the same wave-wide incremental update as everywhere else (so the threat lists are
-		 * permuted exactly as in the reference).  Called by ALL lanes.
+		 * PatternCalculator::isForbidden + is_3x3_forbidden (PatternCalculator.hpp:161-177, PatternCalculator.cpp:213-244) for the cross player under
+		 * renju.  The reference recurses through addMove / isForbidden / undoMove; here the recursion is an explicit machine whose CURRENT frame
+		 * (cell, direction, promotion-move cursor, count of legal threes, promotion mask) lives in registers — wave-uniform values — and only a real
+		 * recursion (a promotion cell that is itself a 3x3 fork: rare) goes through the LDS stack; a child that is decided by its threat type alone
+		 * returns on the spot.  Stones are placed with the same wave-wide incremental update as everywhere else, so the threat lists are permuted
+		 * exactly as in the reference.  Called by ALL lanes.
 		 */
 		template<class SH>
 		__device__ __forceinline__ bool renju_is_forbidden(SH &sh, const EngineDev &E, int cell0, int lane)
@@ -708,83 +711,43 @@ namespace agx
 				if (t != 3)
 					return false;
 			}
-			int sp = 0;
+			int sp = 0, cell = cell0, dir = 0, count = 0, i = -5, phase = 1; // phase 1: next direction, 2: next promotion move, 3: a child returned `ret`
+			uint32_t promo = 0;
 			bool ret = false;
-			int phase = 0; // 0 start of frame, 1 scan directions, 2 scan promotion moves, 3 child returned
-			if (lane == 0)
-				sh.fstack[0][0] = cell0;
-			wave_sync();
 			while (true)
 			{
-				const int cell = sh.fstack[sp][0];
 				const int r = cell / n, c = cell % n;
-				if (phase == 0)
-				{
-					bool decided = true;
-					if (sh.board[cell] != 0)
-						ret = false;
-					else
-					{
-						const int t = sh.threat[cell][0];
-						if (t == 9 || t == 6)
-							ret = true;
-						else if (t != 3)
-							ret = false;
-						else
-							decided = false;
-					}
-					if (decided)
-					{
-						if (sp == 0)
-							return ret;
-						sp--;
-						phase = 3;
-						continue;
-					}
-					if (lane == 0)
-					{
-						sh.fstack[sp][1] = 0; // dir
-						sh.fstack[sp][3] = 0; // count
-					}
-					wave_sync();
-					phase = 1;
-				}
 				if (phase == 1)
 				{
-					int dir = sh.fstack[sp][1];
-					while (dir < 4 && sh.ptype[cell][dir] != 2)
+					const uint32_t cross = *reinterpret_cast<const uint32_t*>(&sh.ptype[cell][0]); // the cell's four cross pattern types
+					while (dir < 4 && ((cross >> (8 * dir)) & 255u) != 2u)
 						dir++;
 					if (dir >= 4)
-					{
-						ret = sh.fstack[sp][3] >= 2;
+					{ // every direction tried: forbidden iff two or more threes can become legal straight fours
+						ret = count >= 2;
 						if (sp == 0)
 							return ret;
 						sp--;
+						cell = sh.fstack[sp][0];
+						dir = sh.fstack[sp][1];
+						i = sh.fstack[sp][2];
+						count = sh.fstack[sp][3];
+						promo = static_cast<uint32_t>(sh.fstack[sp][4]);
 						phase = 3;
 						continue;
 					}
-					const uint32_t promo = promotion_moves(normal_pattern(sh, n, r, c, dir));
-					if (lane == 0)
-					{
-						sh.fstack[sp][1] = dir;
-						sh.fstack[sp][2] = -5;
-						sh.fstack[sp][4] = static_cast<int>(promo);
-						sh.board[cell] = 1; // Board::putMove on the raw board only
-					}
-					wave_sync();
+					promo = promotion_moves(normal_pattern(sh, n, r, c, dir));
+					i = -5;
 					phase = 2;
 				}
 				if (phase == 2)
 				{
-					const int dir = sh.fstack[sp][1];
-					const uint32_t promo = static_cast<uint32_t>(sh.fstack[sp][4]);
-					int i = sh.fstack[sp][2];
 					int found = -1;
 					for (; i <= 5; i++)
 						if ((promo >> (5 + i)) & 1)
 						{
 							const int rr = r + i * row_step(dir), cc = c + i * col_step(dir);
-							if (sh.board[rr * n + cc] == 0 && straight_four_at(sh, n, rr, cc, dir))
+							if (sh.board[rr * n + cc] == 0 && straight_four_with(sh, n, rr, cc, dir, 5 - i))
 							{
 								found = rr * n + cc;
 								break;
@@ -792,63 +755,52 @@ namespace agx
 						}
 					if (found < 0)
 					{
-						if (lane == 0)
-						{
-							sh.board[cell] = 0;
-							sh.fstack[sp][1] = dir + 1;
-						}
-						wave_sync();
+						dir++;
 						phase = 1;
 						continue;
 					}
 					if (sp + 1 >= 16)
 					{
 						sh.error = ERR_FRAMES;
-						if (lane == 0)
-							sh.board[cell] = 0;
-						wave_sync();
 						return true;
 					}
-					if (lane == 0)
-					{
-						sh.fstack[sp][2] = i;
-						sh.board[cell] = 0;
-						sh.fstack[sp + 1][0] = found;
-					}
-					wave_sync();
 					solver_place(sh, E, 1u | (static_cast<uint32_t>(r) << 2) | (static_cast<uint32_t>(c) << 9), true, lane);
+					// isForbidden(found) with the fork stone on the board: decided by the threat type unless it is a 3x3 fork itself
+					const int ct = sh.threat[found][0];
+					if (ct != 3)
+					{
+						ret = (ct == 9 || ct == 6);
+						phase = 3;
+						continue;
+					}
+					sh.fstack[sp][0] = cell;
+					sh.fstack[sp][1] = dir;
+					sh.fstack[sp][2] = i;
+					sh.fstack[sp][3] = count;
+					sh.fstack[sp][4] = static_cast<int>(promo);
+					wave_sync();
 					sp++;
-					phase = 0;
+					cell = found;
+					dir = 0;
+					count = 0;
+					phase = 1;
 					continue;
 				}
-				if (phase == 3)
-				{ // the child (at sp + 1) returned `ret`
-					solver_place(sh, E, 1u | (static_cast<uint32_t>(r) << 2) | (static_cast<uint32_t>(c) << 9), false, lane);
-					if (!ret)
-					{
-						if (lane == 0)
-						{
-							sh.fstack[sp][3] += 1;
-							sh.board[cell] = 0;
-							sh.fstack[sp][1] += 1; // leave this direction ("break")
-						}
-						wave_sync();
-						phase = 1;
-					}
-					else
-					{
-						if (lane == 0)
-						{
-							sh.board[cell] = 1;
-							sh.fstack[sp][2] += 1;
-						}
-						wave_sync();
-						phase = 2;
-					}
+				// phase 3: the promotion move's cell returned `ret`; the fork stone comes off again
+				solver_place(sh, E, 1u | (static_cast<uint32_t>(r) << 2) | (static_cast<uint32_t>(c) << 9), false, lane);
+				if (!ret)
+				{ // a legal straight four: this three counts, on to the next direction ("break")
+					count++;
+					dir++;
+					phase = 1;
+				}
+				else
+				{
+					i++;
+					phase = 2;
 				}
 			}
 		}
-
 		/* NNInputFeatures::encode (NNInputFeatures.cpp:15-32,59-113) */
 		template<class SH>
 		__device__ __forceinline__ void solver_encode_features(const SH &sh, const EngineDev &E, uint32_t *out, int lane)

@@ -2534,6 +2534,10 @@ namespace
 	__global__ __launch_bounds__(256) void k_restore_game(EngineDev E, int g, const uint16_t *moves, int count, int opening_id, int nn_queued)
 	{
 		__shared__ u64 scratch[4];
+		if (threadIdx.x == 0)
+			E.games[g].generation = 0; // a loaded GameGenerator owns a new AlphaBetaSearch: its table's generation counts from 0 again (SharedHashTable.hpp:126,
+			                           // :155 — prepare_search makes it 1), and the ageing of entries (depth - (generation - entry's), modulo 64) follows that count
+		__syncthreads();
 		begin_game(E, g, opening_id, threadIdx.x, scratch, false, moves, count);
 		if (threadIdx.x == 0)
 			E.games[g].nn_queued = nn_queued;
@@ -3124,7 +3128,10 @@ static int group_range(const AgxEngine *e, int group, int n_groups, EngineDev &d
 static constexpr int CLEAR_PARTS = 16; // workgroups per restarting game in k_clear_tables
 
 #ifdef AGX_QUICK /* developer builds: only the 15x15 non-renju solver is instantiated (a fifth of the compile time) */
-#define AGX_LAUNCH_SOLVE(FUSED) hipLaunchKernelGGL((k_solve<false, 15, FUSED>), grid, block, 0, s, d)
+#ifndef AGX_QUICK_RENJU
+#define AGX_QUICK_RENJU false /* -DAGX_QUICK_RENJU=true: the developer build instantiates the renju solver instead */
+#endif
+#define AGX_LAUNCH_SOLVE(FUSED) hipLaunchKernelGGL((k_solve<AGX_QUICK_RENJU, 15, FUSED>), grid, block, 0, s, d)
 #else
 #define AGX_LAUNCH_SOLVE(FUSED) \
 	do { \
@@ -3159,7 +3166,7 @@ static void launch_search_spec(EngineDev d, int count, int group, int waves, hip
 	d.spec_waves = waves;
 	const dim3 grid(waves), block(64);
 #ifdef AGX_QUICK
-	hipLaunchKernelGGL((k_search_spec<false, 15>), grid, block, 0, s, d, count);
+	hipLaunchKernelGGL((k_search_spec<AGX_QUICK_RENJU, 15>), grid, block, 0, s, d, count);
 #else
 	if (d.rules == AGX_RENJU)
 	{
