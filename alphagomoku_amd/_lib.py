@@ -224,6 +224,7 @@ def _declare(c):  # noqa: F811
     c.agx_sample_v201_unpack.argtypes = [vp, sz, ci, ci, vp, vp, vp, vp, vp, vp, ctypes.POINTER(sz)]
     c.agx_debug_solve.argtypes = [vp, vp, vp, ci, vp, vp, vp, vp, vp, vp]
     c.agx_debug_new_generation.argtypes = [vp]
+    c.agx_debug_solve_nodes.argtypes = [vp, ci, vp]
     c.agx_debug_pattern_state.argtypes = [vp, vp, vp, vp, ci, ci, vp, vp, vp, ci]
     c.agx_host_tables.argtypes = [ci, vp, vp, vp, vp]
     c.agx_make_opening.argtypes = [ci, ci, ctypes.c_uint32, vp]

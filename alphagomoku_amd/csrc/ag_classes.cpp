@@ -1067,6 +1067,143 @@ namespace ag
 	{
 		return ab_search;
 	}
+
+	/* ---------------------------------------------------------------------------------------------------------------------------------- */
+	void SearchTask::set(const matrix<Sign> &base, Sign signToMove)
+	{ // SearchTask.cpp:32-50
+		if (base.rows() != rows || base.cols() != cols)
+			throw std::logic_error("SearchTask::set : the board is " + std::to_string(base.rows()) + "x" + std::to_string(base.cols()) + ", the task " + std::to_string(rows)
+					+ "x" + std::to_string(cols));
+		board = base;
+		sign_to_move = signToMove;
+		edges.clear();
+		action_scores.fill(Score());
+		std::fill(policy.begin(), policy.end(), 0.0f);
+		std::fill(action_values.begin(), action_values.end(), Value());
+		value = Value();
+		score = Score();
+		processed_by_network = processed_by_solver = must_defend = statically_solved = recursively_solved = false;
+	}
+	void SearchTask::addEdge(Move move)
+	{ // SearchTask.cpp:62-71
+		AgxEdgeView view { };
+		view.move = Move(move.row, move.col, sign_to_move).toShort();
+		view.score = Score::to_short(action_scores.at(move.row, move.col));
+		edges.push_back(Edge(view));
+	}
+
+	AlphaBetaSearch::AlphaBetaSearch(const GameConfig &gameConfig) :
+			standalone(true), game_config(gameConfig)
+	{
+		if (gameConfig.rows != gameConfig.cols)
+			throw std::logic_error("AlphaBetaSearch : only square boards are supported");
+	}
+	AlphaBetaSearch::~AlphaBetaSearch()
+	{
+		if (engine != nullptr)
+			agx_engine_destroy(engine);
+	}
+	void AlphaBetaSearch::require_engine()
+	{
+		if (!standalone)
+			throw std::logic_error("AlphaBetaSearch : the solver of a Search runs inside Search::solve (construct AlphaBetaSearch(GameConfig) for one of its own)");
+		if (engine != nullptr)
+			return;
+		AgxEngineConfig c;
+		check(agx_engine_default_config(&c));
+		c.rules = static_cast<int>(game_config.rules);
+		c.board_size = game_config.rows;
+		c.draw_after = game_config.draw_after;
+		c.n_games = 1;
+		c.max_batch_size = 1;
+		c.max_simulations = 1;
+		c.node_capacity = 64;
+		c.edge_capacity = 1024;
+		c.tss_max_positions = max_nodes;
+		c.tss_table_entries = static_cast<uint64_t>(table_entries);
+		check(agx_engine_create(&c, &engine));
+	}
+	void AlphaBetaSearch::clear() noexcept
+	{ // AlphaBetaSearch.cpp:67-71: an empty table
+		clear_requested = true; // (inside a Search: applied by its next cleanup; stand-alone: by the next solve)
+	}
+	void AlphaBetaSearch::increaseGeneration()
+	{ // AlphaBetaSearch.cpp:63-66
+		if (!standalone)
+			return; // (inside a Search the set-board launch ages the table: Search::setBoard)
+		require_engine();
+		check(agx_debug_new_generation(engine));
+	}
+	void AlphaBetaSearch::setNodeLimit(int nodes)
+	{ // the budget is a property of the engine: a new limit makes a new one (with an empty table)
+		if (nodes < 1)
+			throw std::logic_error("AlphaBetaSearch::setNodeLimit : " + std::to_string(nodes));
+		if (nodes != max_nodes && engine != nullptr)
+		{
+			agx_engine_destroy(engine);
+			engine = nullptr;
+		}
+		max_nodes = nodes;
+	}
+	int AlphaBetaSearch::solve(SearchTask &task)
+	{ // AlphaBetaSearch.cpp:77-156
+		require_engine();
+		const int n = game_config.rows, hw = n * n;
+		if (task.getRows() != n || task.getCols() != n)
+			throw std::logic_error("AlphaBetaSearch::solve : the task is not of this game's board size");
+		if (clear_requested)
+		{ // an empty opening list: begin() clears every table of the pool and leaves it idle
+			check(agx_engine_destroy(engine));
+			engine = nullptr;
+			require_engine();
+			clear_requested = false;
+		}
+		std::vector<uint8_t> cells(hw);
+		for (int i = 0; i < hw; i++)
+			cells[i] = static_cast<uint8_t>(task.getBoard()[i]);
+		const int sign = static_cast<int>(task.getSignToMove());
+		std::vector<uint16_t> moves(hw), scores(hw);
+		int count = 0;
+		uint32_t flags = 0;
+		uint16_t result = 0;
+		check(agx_debug_solve(engine, cells.data(), &sign, 1, task.getFeatures().data(), moves.data(), scores.data(), &count, &flags, &result));
+		unsigned long long nodes = 0;
+		check(agx_debug_solve_nodes(engine, 1, &nodes));
+		for (int i = 0; i < count; i++)
+		{
+			const Move m(moves[i]);
+			const Score sc = Score::from_short(scores[i]);
+			task.getActionScores().at(m.row, m.col) = sc;
+			if (sc.isProven())
+				task.getActionValues()[m.row * n + m.col] = sc.convertToValue();
+			task.addEdge(m);
+		}
+		task.setScore(Score::from_short(result));
+		if (task.getScore().isProven())
+		{
+			task.setValue(task.getScore().convertToValue());
+			task.setMovesLeft(static_cast<float>(task.getScore().getDistance()));
+		}
+		if (flags & 1u)  // TF_MUST_DEFEND
+			task.markAsDefensive();
+		if (flags & 32u) // TF_RECURSIVELY_SOLVED
+			task.maskAsRecursivelySolved();
+		if (flags & 16u) // TF_STATICALLY_SOLVED
+			task.markAsStaticallySolved();
+		task.markAsProcessedBySolver();
+		total_positions += static_cast<size_t>(nodes);
+		total_calls++;
+		return static_cast<int>(nodes);
+	}
+	void AlphaBetaSearch::print_stats() const
+	{
+		std::cout << "AlphaBetaSearch : " << total_calls << " calls, " << total_positions << " positions ("
+				<< (total_calls > 0 ? static_cast<double>(total_positions) / total_calls : 0.0) << " per call)\n";
+	}
+	int64_t AlphaBetaSearch::getMemory() const noexcept
+	{ // AlphaBetaSearch.cpp:157-160: the table (16 bytes per entry)
+		return standalone ? table_entries * 16 : 0;
+	}
 	void Search::setBoard(const matrix<Sign>&, Sign)
 	{ // Search.cpp:112-115: ab_search.increaseGeneration() — the set-board launch Tree::setBoard enqueued ages the solver table (k_set_board)
 	}

@@ -2590,8 +2590,7 @@ namespace
 			gs.active = 1;
 			gs.outcome = 0;
 			gs.error = 0;
-			gs.generation = 0;
-			gs.solve_pos = 0;
+			gs.solve_pos = 0; // (gs.generation: the idle template's — 0 until agx_debug_new_generation)
 			gs.solve_pending = 0;
 			gs.nn_queued = 0;
 		}
@@ -2677,6 +2676,7 @@ struct AgxEngine
 		EngineDev dev;
 		std::vector<void*> allocations;
 		std::vector<GameState> idle_games; // the pool before agx_engine_begin: every game idle, in its class-0 arena bundle
+		std::vector<unsigned long long> debug_solve_nodes; // solver nodes per position of the last agx_debug_solve
 		ArenaHeap idle_heap;
 		std::vector<uint64_t> zobrist; // [2*hw][2]
 		bool begun = false;
@@ -4154,10 +4154,27 @@ int agx_debug_solve(AgxEngine *e, const uint8_t *h_boards, const int *h_signs, i
 			AGX_HIP_CHECK(hipMemcpy(h_features + static_cast<size_t>(g) * d.hw, d.nn_features + static_cast<size_t>(g) * d.batch * d.hw, d.hw * sizeof(uint32_t),
 					hipMemcpyDeviceToHost));
 	}
+	{ // solver nodes of every position (GameState::stats[5]) for agx_debug_solve_nodes
+		std::vector<GameState> after(count);
+		AGX_HIP_CHECK(hipMemcpy(after.data(), d.games, static_cast<size_t>(count) * sizeof(GameState), hipMemcpyDeviceToHost));
+		e->debug_solve_nodes.resize(count);
+		for (int g = 0; g < count; g++)
+			e->debug_solve_nodes[g] = after[g].stats[5];
+	}
 	// leave the pool idle again
 	AGX_HIP_CHECK(hipMemcpy(d.games, e->idle_games.data(), e->idle_games.size() * sizeof(GameState), hipMemcpyHostToDevice)); // idle pool, arena descriptors intact
 	(void) hipFree(d_boards);
 	(void) hipFree(d_signs);
+	return AGX_OK;
+}
+
+int agx_debug_solve_nodes(AgxEngine *e, int count, unsigned long long *h_nodes)
+{
+	AGX_REQUIRE(e != nullptr && h_nodes != nullptr, AGX_ERR_INVALID, "agx_debug_solve_nodes: null argument");
+	AGX_REQUIRE(count >= 0 && static_cast<size_t>(count) <= e->debug_solve_nodes.size(), AGX_ERR_INVALID, "agx_debug_solve_nodes: the last agx_debug_solve solved %zu positions",
+			e->debug_solve_nodes.size());
+	for (int g = 0; g < count; g++)
+		h_nodes[g] = e->debug_solve_nodes[g];
 	return AGX_OK;
 }
 
@@ -4286,8 +4303,12 @@ int agx_engine_generate_openings(AgxEngine *e, AgxNet *net, int count, uint32_t 
 }
 
 int agx_debug_new_generation(AgxEngine *e)
-{ // not needed by the tests that keep generation 0; kept for symmetry with AlphaBetaSearch::increaseGeneration
+{ // AlphaBetaSearch::increaseGeneration (AlphaBetaSearch.cpp:63-66) for the positions agx_debug_solve solves: every game's solver table ages by one
 	AGX_REQUIRE(e != nullptr, AGX_ERR_INVALID, "agx_debug_new_generation: null engine");
+	// (agx_debug_solve leaves the pool idle after every call: the generation lives in the idle template it restores)
+	for (GameState &g : e->idle_games)
+		g.generation = (g.generation + 1) % 64;
+	AGX_HIP_CHECK(hipMemcpy(e->dev.games, e->idle_games.data(), e->idle_games.size() * sizeof(GameState), hipMemcpyHostToDevice));
 	return AGX_OK;
 }
 

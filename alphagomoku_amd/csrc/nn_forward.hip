@@ -52,10 +52,19 @@
 #define AGX_NN_COLS_INTERLEAVE 0
 #endif
 #ifndef AGX_NN_PAIR_BALANCE
-#define AGX_NN_PAIR_BALANCE 0 // 1: the two waves of a SIMD steer their priorities by each other's progress (measured: balances them, gains nothing)
+#define AGX_NN_PAIR_BALANCE 1 // 1: the two waves of a SIMD steer their priorities by each other's progress in the row-stationary k-loop (+0.8 %)
+#endif
+#ifndef AGX_NN_PAIR_BALANCE_COLS
+#define AGX_NN_PAIR_BALANCE_COLS 0 // the same in the column-tile k-loop (20x20)
 #endif
 #ifndef AGX_NN_WEIGHT_RING
 #define AGX_NN_WEIGHT_RING 2 // stages of weight fragments a wave holds in the row / column loops: 2 = fetched one stage ahead, 3 = two
+#endif
+#ifndef AGX_NN_LAYER_PREFETCH
+#define AGX_NN_LAYER_PREFETCH 1 // 1: the row-stationary k-loop's last turn requests the NEXT layer's first weight fragments (two-plane 15-column kernels)
+#endif
+#ifndef AGX_NN_CONV5_SPLIT
+#define AGX_NN_CONV5_SPLIT 1 // 1: 128-filter nets on 15-column boards run the input conv5x5 row-stationary in two passes per column shift
 #endif
 #ifndef AGX_NN_COLS_SWIZZLE
 #define AGX_NN_COLS_SWIZZLE 0 // 1: the conflict-free even swizzle on column-tile boards (measured 2 % slower: Geometry::swizzle)
@@ -240,7 +249,7 @@ namespace
 			}
 			__device__ __forceinline__ void turn()
 			{
-#if AGX_NN_PAIR_BALANCE
+#if AGX_NN_PAIR_BALANCE || AGX_NN_PAIR_BALANCE_COLS
 				const int ahead = __builtin_amdgcn_readfirstlane(tick - seen); // wave-uniform: a scalar compare and branch
 				if (ahead > 0)
 					__builtin_amdgcn_s_setprio(1);
@@ -252,7 +261,7 @@ namespace
 			}
 			__device__ __forceinline__ void done()
 			{
-#if AGX_NN_PAIR_BALANCE
+#if AGX_NN_PAIR_BALANCE || AGX_NN_PAIR_BALANCE_COLS
 				tick++;
 				*const_cast<volatile int*>(mine) = tick;
 				seen = *const_cast<const volatile int*>(partner);
@@ -263,6 +272,27 @@ namespace
 	__device__ __forceinline__ int plane_offset(int index, int chunk)
 	{ // byte offset of a 16-byte chunk of stored position `index` (= position + 1)
 		return (index * G::CH + (chunk ^ G::swizzle(index))) * 16;
+	}
+
+	/* The weight fragments of a layer's first stage, requested by the layer in front of it: a layer that fetches them itself starts with an
+	 * L2 / MALL round trip that nothing hides (every wave of the workgroup has just left the layer barrier).  `next` = the packed weights of
+	 * the layer that follows. */
+	template<int MT>
+	struct WeightCarry
+	{
+			half8 a[3][MT];
+			const half8 *next;
+	};
+	template<int F, int ROWS, int COLS>
+	__device__ __forceinline__ void request_first_stage(const half8 *__restrict__ wpk, int wave, int lane, WeightCarry<Geometry<F, ROWS, COLS>::MT> &carry)
+	{
+		typedef Geometry<F, ROWS, COLS> G;
+		const half8 *wl = wpk + __builtin_amdgcn_readfirstlane(G::channel_group(wave) * 3 * G::MT * 64);
+#pragma unroll
+		for (int dyi = 0; dyi < 3; dyi++)
+#pragma unroll
+			for (int i = 0; i < G::MT; i++)
+				carry.a[dyi][i] = wl[(dyi * G::MT + i) * 64 + lane];
 	}
 
 	/*
@@ -327,7 +357,7 @@ namespace
 	 */
 	template<int F, int ROWS, int COLS, bool ZERO = true>
 	__device__ __forceinline__ void conv3x3_mac_rows(const char *src, const half8 *__restrict__ wpk, int wave, int lane,
-			floatx4 (&acc)[Geometry<F, ROWS, COLS>::MT][Geometry<F, ROWS, COLS>::NTW])
+			floatx4 (&acc)[Geometry<F, ROWS, COLS>::MT][Geometry<F, ROWS, COLS>::NTW], WeightCarry<Geometry<F, ROWS, COLS>::MT> *carry = nullptr)
 	{
 		typedef Geometry<F, ROWS, COLS> G;
 		static_assert(G::S == 16, "a position tile must be a board row");
@@ -352,11 +382,13 @@ namespace
 		static_assert(STAGES % 2 == 0, "two stages per loop turn (static ring index)");
 		const half8 *wl = wpk + __builtin_amdgcn_readfirstlane(mg * 3 * G::MT * 64); // wave-uniform: scalar base + lane offset
 		half8 a0[3][G::MT], a1[3][G::MT];
+		// (the layer's last turn has to request SOMETHING, see below: the next layer's first stage when there is a carry, its own otherwise)
+		const half8 *wrap = (carry != nullptr) ? carry->next + __builtin_amdgcn_readfirstlane(mg * 3 * G::MT * 64) : wl;
 #pragma unroll
 		for (int dyi = 0; dyi < 3; dyi++)
 #pragma unroll
 			for (int i = 0; i < G::MT; i++)
-				a0[dyi][i] = wl[(dyi * G::MT + i) * 64 + lane];
+				a0[dyi][i] = (carry != nullptr) ? carry->a[dyi][i] : wl[(dyi * G::MT + i) * 64 + lane];
 		const int index_base = 1 + G::S + n0 * 16 + r; // stored index of this lane's position in the wave's first output row
 #if AGX_NN_PAIR_BALANCE
 		PairBalance balance(pair_progress(), wave);
@@ -408,13 +440,21 @@ namespace
 			conv3x3_rows_stage<F, ROWS, COLS>(src, wl + (s + 1) * STAGE_FRAGS, s / 3, s % 3, index_base, q4, my_tiles, lane, a0, a1, acc);
 			// the last turn fetches stage 0 again instead of branching around the fetch: with a conditional fetch the wait for THIS stage's
 			// fragments has to assume the newer loads were never issued (vmcnt(0)), which serialises fetch and MFMAs in every turn
-			conv3x3_rows_stage<F, ROWS, COLS>(src, wl + ((s + 2 < STAGES) ? (s + 2) : 0) * STAGE_FRAGS, (s + 1) / 3, (s + 1) % 3, index_base, q4, my_tiles, lane, a1,
+			conv3x3_rows_stage<F, ROWS, COLS>(src, (s + 2 < STAGES) ? wl + (s + 2) * STAGE_FRAGS : wrap, (s + 1) / 3, (s + 1) % 3, index_base, q4, my_tiles, lane, a1,
 					a0, acc);
 #if AGX_NN_PAIR_BALANCE
 			balance.done();
 #endif
 		}
 		__builtin_amdgcn_s_setprio(0);
+		if (carry != nullptr)
+		{
+#pragma unroll
+			for (int dyi = 0; dyi < 3; dyi++)
+#pragma unroll
+				for (int i = 0; i < G::MT; i++)
+					carry->a[dyi][i] = a0[dyi][i];
+		}
 	}
 
 	template<int F, int ROWS, int COLS, bool ZERO = true>
@@ -627,7 +667,7 @@ namespace
 				a0[dxi][i] = wl[(dxi * G::MT + i) * 64 + lane];
 		const int col_base = 1 + G::S + r * G::S + pg * G::COL_TILES - 1;                    // stored index of (row r, column x0 - 1)
 		const int tail_base = 1 + G::S + (G::TAIL_FIRST + pg * G::TAIL_TILES) * 16 + r;      // ... of this lane's cell in the wave's first tail tile
-#if AGX_NN_PAIR_BALANCE
+#if AGX_NN_PAIR_BALANCE_COLS
 		PairBalance balance(pair_progress(), wave);
 #endif
 #if AGX_NN_WEIGHT_RING == 3
@@ -657,7 +697,7 @@ namespace
 #pragma unroll 1
 		for (int s = 0; s < STAGES; s += 2)
 		{
-#if AGX_NN_PAIR_BALANCE
+#if AGX_NN_PAIR_BALANCE_COLS
 			balance.turn();
 #else
 			if (3 * s < STAGES) // (priority by remaining work)
@@ -669,7 +709,7 @@ namespace
 #endif
 			conv3x3_cols_stage<F, ROWS, COLS>(src, wl + (s + 1) * STAGE_FRAGS, s / 3, s % 3, col_base, tail_base, q4, lane, a0, a1, acc);
 			conv3x3_cols_stage<F, ROWS, COLS>(src, wl + ((s + 2 < STAGES) ? (s + 2) : 0) * STAGE_FRAGS, (s + 1) / 3, (s + 1) % 3, col_base, tail_base, q4, lane, a1, a0, acc);
-#if AGX_NN_PAIR_BALANCE
+#if AGX_NN_PAIR_BALANCE_COLS
 			balance.done();
 #endif
 		}
@@ -678,10 +718,10 @@ namespace
 
 	template<int F, int ROWS, int COLS, bool ZERO = true>
 	__device__ __forceinline__ void conv3x3_mac(const char *src, const half8 *__restrict__ wpk, int wave, int lane,
-			floatx4 (&acc)[Geometry<F, ROWS, COLS>::MT][Geometry<F, ROWS, COLS>::NTW])
+			floatx4 (&acc)[Geometry<F, ROWS, COLS>::MT][Geometry<F, ROWS, COLS>::NTW], WeightCarry<Geometry<F, ROWS, COLS>::MT> *carry = nullptr)
 	{
 		if constexpr (Geometry<F, ROWS, COLS>::S == 16 && AGX_NN_ROW_STATIONARY)
-			conv3x3_mac_rows<F, ROWS, COLS, ZERO>(src, wpk, wave, lane, acc);
+			conv3x3_mac_rows<F, ROWS, COLS, ZERO>(src, wpk, wave, lane, acc, carry);
 		else if constexpr (Geometry<F, ROWS, COLS>::COLT)
 			conv3x3_mac_cols<F, ROWS, COLS, ZERO>(src, wpk, wave, lane, acc);
 		else
@@ -696,7 +736,7 @@ namespace
 
 	template<int F, int ROWS, int COLS, bool SKIP, bool TANH = false>
 	__device__ __forceinline__ void conv3x3(const char *src, char *dst, const half8 *__restrict__ wpk, const float *__restrict__ bias, int wave,
-			int lane AGX_NN_STAMP_PARAM)
+			int lane AGX_NN_STAMP_PARAM, WeightCarry<Geometry<F, ROWS, COLS>::MT> *carry = nullptr)
 	{
 		typedef Geometry<F, ROWS, COLS> G;
 		const int r = lane & 15;
@@ -730,7 +770,7 @@ namespace
 			}
 		}
 		AGX_NN_MARK(2);
-		conv3x3_mac<F, ROWS, COLS, false>(src, wpk, wave, lane, acc);
+		conv3x3_mac<F, ROWS, COLS, false>(src, wpk, wave, lane, acc, carry);
 		AGX_NN_MARK(3);
 
 		// epilogue: lane holds out-channels 4*q4 .. 4*q4+3 of tile i for position r of tile n
@@ -1098,6 +1138,92 @@ namespace
 						a_cur[dyi][i] = a_next[dyi][i];
 			}
 		}
+		else if constexpr (G::S == 16 && AGX_NN_ROW_STATIONARY && F == 128 && AGX_NN_CONV5_SPLIT)
+		{
+			// 128 filters: the row-stationary loop above with the five vertical taps of a column shift taken in two passes — dy = -2, -1, 0
+			// (input rows -2 .. NTW - 1 of the wave) and dy = +1, +2 (rows 1 .. NTW + 1) — so that only 3 * MT + 2 * MT weight fragments are
+			// held at a time (the 2 x 5 * MT of the single pass spill): 5 x (2 NTW + 3) fragment reads instead of 25 x NTW, the tap-major
+			// loop's LDS traffic halved (it is bound by it: one ds_read_b128 per MT = 2 MFMAs).
+			const half8 *wl = wpk + __builtin_amdgcn_readfirstlane(mg * G::MT * 64); // + lane; tap (dy, dx), tile i at ((dy * 5 + dx) * MTILES + i) * 64
+			half8 a_up[3][G::MT], a_down[2][G::MT];
+#pragma unroll
+			for (int dyi = 0; dyi < 3; dyi++)
+#pragma unroll
+				for (int i = 0; i < G::MT; i++)
+					a_up[dyi][i] = wl[((dyi * 5 + 0) * G::MTILES + i) * 64 + lane];
+#pragma unroll 1
+			for (int dxi = 0; dxi < 5; dxi++)
+			{
+				const int dxn = (dxi + 1 < 5) ? (dxi + 1) : 0; // (the last turn requests the first shift's fragments again instead of branching)
+				auto fragment = [&](int j) -> half8
+				{ // stored cell of this lane in padded row (n0 + j + 2): column r + (dxi - 2) + 2
+					const int jj = (j <= my_tiles + 1) ? j : 0; // rows past the wave's last output row + 2 are not needed (and would leave the plane)
+					const int q = (n0 + jj + 2) * G::S5 + (r + dxi);
+					return *reinterpret_cast<const half8*>(in5 + (q * 4 + (q4 ^ ((q >> 2) & 3))) * 16);
+				};
+				constexpr int AHEAD = AGX_NN_AHEAD;
+				{ // pass 1: dy = -2, -1, 0 (dyi 0 .. 2) — while it runs the two lower taps' fragments of this shift arrive
+#pragma unroll
+					for (int dyi = 0; dyi < 2; dyi++)
+#pragma unroll
+						for (int i = 0; i < G::MT; i++)
+							a_down[dyi][i] = wl[(((3 + dyi) * 5 + dxi) * G::MTILES + i) * 64 + lane];
+					half8 b[AHEAD];
+#pragma unroll
+					for (int u = 0; u < AHEAD - 1; u++)
+						b[u] = fragment(u - 2);
+#pragma unroll
+					for (int j = -2; j <= G::NTW - 1; j++)
+					{
+						const int jn = j + AHEAD - 1;
+						if (jn <= G::NTW - 1)
+							b[(jn + 2) % AHEAD] = fragment(jn);
+#pragma unroll
+						for (int dyi = 0; dyi < 3; dyi++)
+						{
+							const int o = j - (dyi - 2);
+							if (o >= 0 && o < G::NTW && o < my_tiles)
+							{
+#pragma unroll
+								for (int i = 0; i < G::MT; i++)
+									acc[i][o] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_up[dyi][i], b[(j + 2) % AHEAD], acc[i][o], 0, 0, 0);
+							}
+						}
+						__builtin_amdgcn_sched_barrier(0);
+					}
+				}
+				{ // pass 2: dy = +1, +2 (dyi 3, 4) — and the next shift's upper taps are requested
+#pragma unroll
+					for (int dyi = 0; dyi < 3; dyi++)
+#pragma unroll
+						for (int i = 0; i < G::MT; i++)
+							a_up[dyi][i] = wl[((dyi * 5 + dxn) * G::MTILES + i) * 64 + lane];
+					half8 b[AHEAD];
+#pragma unroll
+					for (int u = 0; u < AHEAD - 1; u++)
+						b[u] = fragment(u + 1);
+#pragma unroll
+					for (int j = 1; j <= G::NTW + 1; j++)
+					{
+						const int jn = j + AHEAD - 1;
+						if (jn <= G::NTW + 1)
+							b[(jn - 1) % AHEAD] = fragment(jn);
+#pragma unroll
+						for (int dyi = 3; dyi < 5; dyi++)
+						{
+							const int o = j - (dyi - 2);
+							if (o >= 0 && o < G::NTW && o < my_tiles)
+							{
+#pragma unroll
+								for (int i = 0; i < G::MT; i++)
+									acc[i][o] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_down[dyi - 3][i], b[(j - 1) % AHEAD], acc[i][o], 0, 0, 0);
+							}
+						}
+						__builtin_amdgcn_sched_barrier(0);
+					}
+				}
+			}
+		}
 		else
 		{
 			// padded-plane index of the (dy = 0, dx = 0) input cell of this lane's position in every tile
@@ -1246,7 +1372,7 @@ namespace
 			for (int i = tid; i < F * 4; i += G::THREADS)
 				s_wq2[i] = p.wq2[i];
 
-#if AGX_NN_PAIR_BALANCE
+#if AGX_NN_PAIR_BALANCE || AGX_NN_PAIR_BALANCE_COLS
 		if (tid < 8)
 			pair_progress()[tid] = 0;
 #endif
@@ -1295,6 +1421,11 @@ namespace
 
 			AGX_NN_MARK(9);
 			// ---- residual tower ----
+			constexpr bool CARRY = !INPLACE && G::S == 16 && AGX_NN_ROW_STATIONARY && AGX_NN_LAYER_PREFETCH && AGX_NN_WEIGHT_RING == 2;
+			WeightCarry<G::MT> carry_store;
+			WeightCarry<G::MT> *carry = CARRY ? &carry_store : nullptr;
+			if constexpr (CARRY)
+				request_first_stage<F, ROWS, COLS>(p.w_tower, wave, lane, carry_store);
 			for (int blk = 0; blk < p.blocks; blk++)
 			{
 				if (INPLACE)
@@ -1307,10 +1438,14 @@ namespace
 				}
 				else
 				{
-					conv3x3<F, ROWS, COLS, false>(plane_x, plane_t, p.w_tower + (2 * blk) * layer_halves8, p.bias + (1 + 2 * blk) * F, wave, lane AGX_NN_STAMP_ARG);
+					if constexpr (CARRY)
+						carry_store.next = p.w_tower + (2 * blk + 1) * layer_halves8;
+					conv3x3<F, ROWS, COLS, false>(plane_x, plane_t, p.w_tower + (2 * blk) * layer_halves8, p.bias + (1 + 2 * blk) * F, wave, lane AGX_NN_STAMP_ARG, carry);
 					__syncthreads();
 					AGX_NN_MARK(5);
-					conv3x3<F, ROWS, COLS, true>(plane_t, plane_x, p.w_tower + (2 * blk + 1) * layer_halves8, p.bias + (2 + 2 * blk) * F, wave, lane AGX_NN_STAMP_ARG);
+					if constexpr (CARRY)
+						carry_store.next = p.w_tower + (2 * blk + 2) * layer_halves8; // (behind the last block: the policy conv)
+					conv3x3<F, ROWS, COLS, true>(plane_t, plane_x, p.w_tower + (2 * blk + 1) * layer_halves8, p.bias + (2 + 2 * blk) * F, wave, lane AGX_NN_STAMP_ARG, carry);
 					__syncthreads();
 					AGX_NN_MARK(5);
 				}
@@ -1355,7 +1490,11 @@ namespace
 				conv3x3_inplace<F, ROWS, COLS, 2>(plane_x, p.w_tower + (2 * p.blocks) * layer_halves8, p.bias + (1 + 2 * p.blocks) * F, nullptr, s_wp2, ppart,
 						wave, lane AGX_NN_STAMP_ARG);
 			else
-				conv3x3<F, ROWS, COLS, false>(plane_x, plane_t, p.w_tower + (2 * p.blocks) * layer_halves8, p.bias + (1 + 2 * p.blocks) * F, wave, lane AGX_NN_STAMP_ARG);
+			{
+				if constexpr (CARRY)
+					carry_store.next = p.w_tower + (2 * p.blocks) * layer_halves8; // nothing follows: its last turn requests its own first stage again
+				conv3x3<F, ROWS, COLS, false>(plane_x, plane_t, p.w_tower + (2 * p.blocks) * layer_halves8, p.bias + (1 + 2 * p.blocks) * F, wave, lane AGX_NN_STAMP_ARG, carry);
+			}
 			__syncthreads();
 			AGX_NN_MARK(7);
 

@@ -319,7 +319,9 @@ class GeneratorPool:
         results = np.zeros(n, np.uint16)
         p = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
         check(lib.agx_debug_solve(self._h, p(boards), p(signs), n, p(feats), p(moves), p(scores), p(counts), p(flags), p(results)))
-        return dict(features=feats, moves=moves, scores=scores, counts=counts, flags=flags, results=results)
+        nodes = np.zeros(n, np.uint64)
+        check(lib.agx_debug_solve_nodes(self._h, n, p(nodes)))
+        return dict(features=feats, moves=moves, scores=scores, counts=counts, flags=flags, results=results, nodes=nodes)
 
     def debug_pattern_state(self, boards, signs, moves):
         boards = np.ascontiguousarray(boards, dtype=np.uint8).reshape(-1, self.cells)

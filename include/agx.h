@@ -196,8 +196,9 @@ typedef struct AgxEngineConfig
 	                                     before the batch (every touched bucket copied into a per-task overlay), and committed in batch order; a task
 	                                     that saw a bucket an earlier task of the batch changed is solved again serially — results are bit-identical
 	                                     to the serial order of Search::solve (Search.cpp:159-183), the solver runs with 3 waves per SIMD instead of
-	                                     one wave per game.  0 (default): one wave per game, tasks in order.  Ignored by tournament-search pools and for
-	                                     solver budgets above 250 positions (the overlay holds 256 buckets). */
+	                                     one wave per game.  0 (default): one wave per game, tasks in order.  Tournament-search pools (search_threads > 1)
+	                                     take the speculative launch too; ignored for solver budgets above 250 positions (the overlay
+	                                     holds 256 buckets) and batches above 16. */
 	int speculative_waves;            /* waves of that launch over the whole pool, 0 = 12 per compute unit of the device */
 	int force_expand_root;            /* UnifiedGenerator's forceExpandRoot (EdgeGenerator.cpp:283-285): 1 (default, self-play: GameGenerator.cpp:183-184)
 	                                     never prunes the root's edges; 0 prunes the root like any node (evaluation Player, Player.cpp:109; match_mode
@@ -452,7 +453,8 @@ int agx_engine_zobrist(AgxEngine* engine, uint64_t* h_keys, size_t n_words);
 /* Test hooks: run single stages on caller-supplied positions (boards uint8[count][cells], 0 empty 1 cross 2 circle). */
 int agx_debug_solve(AgxEngine* engine, const uint8_t* h_boards, const int* h_signs, int count, uint32_t* h_features, uint16_t* h_moves,
 		uint16_t* h_scores, int* h_counts, uint32_t* h_flags, uint16_t* h_result_scores);
-int agx_debug_new_generation(AgxEngine* engine);
+int agx_debug_solve_nodes(AgxEngine* engine, int count, unsigned long long* h_nodes);   /* solver nodes visited per position by the last agx_debug_solve (AlphaBetaSearch::solve's return value) */
+int agx_debug_new_generation(AgxEngine* engine);                                       /* AlphaBetaSearch::increaseGeneration for the positions agx_debug_solve solves */
 int agx_debug_pattern_state(AgxEngine* engine, const uint8_t* h_boards, const int* h_signs, const uint16_t* h_moves, int count, int n_moves,
 		uint8_t* h_ptypes, uint8_t* h_threats, int16_t* h_lists, int lists_stride);
 /* Host-only: the lookup tables the engine uploads (pattern uint8[1<<20], half-open-three uint8[1<<20], threat uint8[4096][2],

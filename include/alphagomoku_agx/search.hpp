@@ -107,6 +107,20 @@ namespace ag
 			{
 				return getProvenValue() == ProvenValue::UNKNOWN;
 			}
+			Value convertToValue() const noexcept
+			{ // Score.hpp:266-281
+				switch (getProvenValue())
+				{
+					case ProvenValue::LOSS:
+						return Value(0.0f, 0.0f);
+					case ProvenValue::DRAW:
+						return Value(0.0f, 1.0f);
+					case ProvenValue::UNKNOWN:
+						return Value((1000 + getEval()) / 2000.0f, 0.0f);
+					default:
+						return isFinite() ? Value(1.0f, 0.0f) : Value();
+				}
+			}
 			int getDistance() const noexcept
 			{
 				switch (getProvenValue())
@@ -211,12 +225,38 @@ namespace ag
 			float moves_left = 0.0f;
 			Score score;
 			bool processed_by_network = false;
+			// the solver's side of a task (SearchTask.hpp:72, 111-117, 155-177, 187-217, 229-273): the position, and what AlphaBetaSearch::solve leaves
+			matrix<Sign> board;
+			Sign sign_to_move = Sign::NONE;
+			std::vector<Edge> edges;
+			matrix<Score> action_scores;
+			bool processed_by_solver = false, must_defend = false, statically_solved = false, recursively_solved = false;
 		public:
 			SearchTask() = default;
 			SearchTask(int rows, int cols) :
-					rows(rows), cols(cols), features(rows * cols), policy(rows * cols), action_values(rows * cols)
+					rows(rows), cols(cols), features(rows * cols), policy(rows * cols), action_values(rows * cols), board(rows, cols), action_scores(rows, cols)
 			{
 			}
+			explicit SearchTask(const GameConfig &config) :
+					SearchTask(config.rows, config.cols)
+			{
+			}
+			void set(const matrix<Sign> &base, Sign signToMove); // SearchTask.cpp:32-50
+			const matrix<Sign>& getBoard() const noexcept { return board; }
+			Sign getSignToMove() const noexcept { return sign_to_move; }
+			const std::vector<Edge>& getEdges() const noexcept { return edges; }
+			const matrix<Score>& getActionScores() const noexcept { return action_scores; }
+			matrix<Score>& getActionScores() noexcept { return action_scores; }
+			void addEdge(Move move);                               // SearchTask.cpp:62-71: the edge takes the cell's action score
+			bool wasProcessedBySolver() const noexcept { return processed_by_solver; }
+			bool mustDefend() const noexcept { return must_defend; }
+			bool wasStaticallySolved() const noexcept { return statically_solved; }
+			bool wasRecursivelySolved() const noexcept { return recursively_solved; }
+			bool isReady() const noexcept { return score.isProven() || processed_by_network; }
+			void markAsProcessedBySolver() noexcept { processed_by_solver = true; }
+			void markAsDefensive() noexcept { must_defend = true; }
+			void markAsStaticallySolved() noexcept { statically_solved = true; }
+			void maskAsRecursivelySolved() noexcept { recursively_solved = true; }
 			int getRows() const noexcept { return rows; }
 			int getCols() const noexcept { return cols; }
 			std::vector<uint32_t>& getFeatures() noexcept { return features; }
@@ -527,15 +567,38 @@ namespace ag
 			NodeCacheStats stats_baseline;
 			};
 
-	/* stand-in for the solver handle Search::getSolver returns (Search.hpp:74): the alpha-beta solver lives inside the device's solve stage; what
-	 * callers do with the handle is clear() it at the start of a game (EvaluationGame.cpp:81-82) */
+	/* AlphaBetaSearch (search/alpha_beta/AlphaBetaSearch.hpp:28-72).  Two ways to get one:
+	 *  - Search::getSolver() — the handle of the solver that lives inside a Search's solve stage; what callers do with it is clear() it at
+	 *    the start of a game (EvaluationGame.cpp:81-82);
+	 *  - AlphaBetaSearch(const GameConfig&) — the reference's constructor: a solver of its own (a one-position engine with the reference's
+	 *    4 Mi-entry table, created on first use), whose solve(SearchTask&) runs the device solver on the task's position and leaves what
+	 *    AlphaBetaSearch.cpp:77-156 leaves: the feature words, the generated actions as edges with their scores, the position's score (and
+	 *    value / moves left when it is proven) and the defensive / statically / recursively-solved marks.  Returns the nodes visited. */
 	class AlphaBetaSearch
 	{
 			friend class Search;
 			bool clear_requested = false;
+			bool standalone = false;
+			GameConfig game_config;
+			int max_nodes = 1000;          // AlphaBetaSearch.hpp:36
+			int64_t table_entries = 4 * 1024 * 1024;
+			AgxEngine *engine = nullptr;   // standalone only
+			size_t total_positions = 0, total_calls = 0;
+			void require_engine();
 		public:
-			void clear() noexcept { clear_requested = true; }
-			void increaseGeneration() noexcept { }
+			AlphaBetaSearch() = default;   // (the handle inside a Search)
+			explicit AlphaBetaSearch(const GameConfig &gameConfig);
+			AlphaBetaSearch(const AlphaBetaSearch&) = delete;
+			AlphaBetaSearch& operator=(const AlphaBetaSearch&) = delete;
+			~AlphaBetaSearch();
+			void clear() noexcept;
+			void increaseGeneration();
+			int solve(SearchTask &task);
+			void print_stats() const;
+			int64_t getMemory() const noexcept;
+			void setDepthLimit(int depth) noexcept { (void) depth; } // (the iterative deepening's depth cap is the reference's default 100 on the device)
+			void setNodeLimit(int nodes);
+			void setTimeLimit(double time) noexcept { (void) time; }   // (time shares are Search::solve(endTime)'s business)
 	};
 
 	/* Search (Search.hpp:56-101): Search(const GameConfig&, const SearchConfig&) is the reference's constructor — it owns a one-game engine

@@ -7,7 +7,10 @@ Three sources, none of them a guess:
     VMEM instructions every source function CONTRIBUTES to the kernel (static; everything is inlined, the line table keeps the callee's lines);
   * rocprofv3 --pmc totals of the same kernel in the bench run (scripts/profile_bench.sh) -> instructions per launch and per solver node (dynamic,
     whole kernel).
-usage: python scripts/search_phases.py OUT.json PROFILE_STDERR [PMC_SUMMARY.json BENCH_LINE.json]"""
+  * optionally scripts/place_pmc.py's counts of ONE place / undo (the debug kernel on 2048 positions, by difference of two launches).
+The bench line should be an un-profiled run of the PMC passes' own command (bench.py --steps 40 --warmup 30 --age-steps 0): its solver nodes per
+launch turn the per-launch counters into per-node ones.
+usage: python scripts/search_phases.py OUT.json PROFILE_STDERR [PMC_SUMMARY.json BENCH_LINE.json [PLACE_PMC.json]]"""
 import collections
 import json
 import os
@@ -132,6 +135,7 @@ def main():
     out_path, profile = sys.argv[1], sys.argv[2]
     pmc = json.load(open(sys.argv[3])) if len(sys.argv) > 3 else None
     bench = json.load(open(sys.argv[4])) if len(sys.argv) > 4 else None
+    place = json.load(open(sys.argv[5])) if len(sys.argv) > 5 else None
     if os.environ.get("AGX_PHASES_NO_ISA"):   # (stamps only: e.g. the renju kernel, which an AGX_QUICK build does not instantiate)
         per = {}
     else:
@@ -172,6 +176,14 @@ def main():
             if nodes_per_launch:
                 result["solver_nodes_per_launch"] = nodes_per_launch
                 result["wave_instructions_per_solver_node"] = {c: v / nodes_per_launch for c, v in dyn.items() if c.startswith("SQ_INSTS")}
+    if place:
+        result["one_place_or_undo_dynamic"] = {k: v for k, v in place.items() if k != "_comment"}
+        if "wave_instructions_per_solver_node" in result and stamps.get("places_per_solve") and stamps.get("generate_calls_per_solve"):
+            per_node = stamps["places_per_solve"] / stamps["generate_calls_per_solve"]   # (one generate() call per visited node)
+            result["place_undo_share_of_a_node's_instructions"] = {
+                c: place["per_place_or_undo"][c] * per_node / result["wave_instructions_per_solver_node"][c]
+                for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS") if c in place["per_place_or_undo"]}
+            result["places_and_undos_per_solver_node"] = per_node
     json.dump(result, open(out_path, "w"), indent=1)
     print(json.dumps({k: v for k, v in result.items() if k not in ("_comment",)}, indent=1)[:6000])
 

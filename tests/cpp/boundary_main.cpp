@@ -641,6 +641,47 @@ static int mode_generator(const std::map<std::string, std::string> &a)
 	return 0;
 }
 
+static int mode_solver(const std::map<std::string, std::string> &a)
+{ // AlphaBetaSearch(const GameConfig&) used the way OpeningGenerator.cpp:58-66 and the solver tools use it: one solver object, one table, a
+  // sequence of positions (file: one line per position, "<sign to move> <cells as digits 0/1/2>"), the table aged every fourth position
+	const int n = geti(a, "--board", 15);
+	GameConfig game_config(static_cast<GameRules>(geti(a, "--rules", 0)), n);
+	AlphaBetaSearch solver(game_config);
+	solver.setNodeLimit(geti(a, "--nodes", 1000));
+	std::ifstream in(a.at("--positions"));
+	if (!in)
+		throw std::runtime_error("cannot open " + a.at("--positions"));
+	SearchTask task(game_config);
+	std::string cells;
+	int sign = 0, index = 0;
+	while (in >> sign >> cells)
+	{
+		if (static_cast<int>(cells.size()) != n * n)
+			throw std::runtime_error("a position must have rows x cols cells");
+		matrix<Sign> board(n, n);
+		for (int i = 0; i < n * n; i++)
+			board[i] = static_cast<Sign>(cells[i] - '0');
+		if (index % 4 == 3)
+			solver.increaseGeneration();
+		task.set(board, static_cast<Sign>(sign));
+		const int nodes = solver.solve(task);
+		unsigned long long feature_sum = 0;
+		for (size_t i = 0; i < task.getFeatures().size(); i++)
+			feature_sum += static_cast<unsigned long long>(task.getFeatures()[i]) * (i + 1);
+		std::printf("{\"index\": %d, \"nodes\": %d, \"score\": %d, \"must_defend\": %d, \"statically_solved\": %d, \"recursively_solved\": %d, \"processed\": %d, "
+				"\"value\": [%.6f, %.6f], \"moves_left\": %.1f, \"feature_sum\": %llu, \"edges\": [", index, nodes, static_cast<int>(Score::to_short(task.getScore())),
+				task.mustDefend() ? 1 : 0, task.wasStaticallySolved() ? 1 : 0, task.wasRecursivelySolved() ? 1 : 0, task.wasProcessedBySolver() ? 1 : 0,
+				task.getValue().win_rate, task.getValue().draw_rate, task.getMovesLeft(), feature_sum);
+		for (size_t i = 0; i < task.getEdges().size(); i++)
+			std::printf("%s[%d, %d]", i ? ", " : "", static_cast<int>(task.getEdges()[i].getMove().toShort()), static_cast<int>(Score::to_short(task.getEdges()[i].getScore())));
+		std::printf("]}\n");
+		index++;
+	}
+	std::fprintf(stderr, "solver memory %lld bytes\n", static_cast<long long>(solver.getMemory()));
+	solver.print_stats();
+	return 0;
+}
+
 static int mode_errors(const std::map<std::string, std::string> &a)
 {
 	int caught = 0;
@@ -712,7 +753,7 @@ int main(int argc, char **argv)
 {
 	if (argc < 2)
 	{
-		std::fprintf(stderr, "usage: agx_boundary_test generate|evaluator|player|thread|generator|errors [--key value ...]\n");
+		std::fprintf(stderr, "usage: agx_boundary_test generate|evaluator|player|thread|tree|generator|solver|errors [--key value ...]\n");
 		return 2;
 	}
 	try
@@ -731,6 +772,8 @@ int main(int argc, char **argv)
 			return mode_tree(args);
 		if (mode == "generator")
 			return mode_generator(args);
+		if (mode == "solver")
+			return mode_solver(args);
 		if (mode == "errors")
 			return mode_errors(args);
 		std::fprintf(stderr, "unknown mode %s\n", mode.c_str());

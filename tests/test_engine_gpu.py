@@ -138,6 +138,7 @@ def test_solver_matches_oracle_per_position(agx_lib, olib, rules, max_nodes):
         assert np.array_equal(mv[:n], out["moves"][g, :n]), g          # same actions in the same ORDER
         assert np.array_equal(sc[:n], out["scores"][g, :n]), g
         assert rs.value == out["results"][g], g
+        assert nodes.value == int(out["nodes"][g]), g                 # AlphaBetaSearch::solve's return value
         assert bool(fl.value & 1) == bool(out["flags"][g] & 1), g     # must_defend
         assert np.array_equal(feat, out["features"][g]), g
         proven += int(((rs.value >> 13) & 3) != 2)
@@ -1049,10 +1050,11 @@ def test_pool_step_with_device_network_is_deterministic_and_consistent(agx_lib):
 
 FULL_SIZE = {
     # BASELINE.json configs at bench.py's sizes: rules, board, network, playouts, steps of the big pool, steps of the small pool
-    "C2-freestyle-15x15-6x128-400": dict(rules=0, n=15, blocks=6, sims=400, big_steps=160, small_steps=260),
-    "C3-standard-15x15-10x128-800": dict(rules=1, n=15, blocks=10, sims=800, big_steps=260, small_steps=420),
-    "C4-caro5-20x20-10x128-400": dict(rules=3, n=20, blocks=10, sims=400, big_steps=160, small_steps=260),
-    "C5-renju-15x15-10x128-1600": dict(rules=2, n=15, blocks=10, sims=1600, big_steps=460, small_steps=760),
+    # (+ the least number of move records that must have been compared over the 128 games looked at: 3 to 5 moves per game)
+    "C2-freestyle-15x15-6x128-400": dict(rules=0, n=15, blocks=6, sims=400, big_steps=420, small_steps=680, compared=450),
+    "C3-standard-15x15-10x128-800": dict(rules=1, n=15, blocks=10, sims=800, big_steps=460, small_steps=740, compared=300),
+    "C4-caro5-20x20-10x128-400": dict(rules=3, n=20, blocks=10, sims=400, big_steps=320, small_steps=520, compared=400),
+    "C5-renju-15x15-10x128-1600": dict(rules=2, n=15, blocks=10, sims=1600, big_steps=660, small_steps=1080, compared=250),
 }
 
 
@@ -1060,7 +1062,7 @@ FULL_SIZE = {
 def test_full_size_pool_matches_a_small_pool_game_by_game(agx_lib, name):
     """BASELINE configs[1..4] at FULL size — 1024 games, the config's network in the loop, its playout budget, batch 8, yielding on, the
     reference's 4 Mi-entry solver table per game and bench.py's arena sizes: games are independent, so every game of the big pool must play
-    exactly what the same opening plays in a 64-game pool stepped in one piece, serial solver, no yielding (whose behaviour the other tests pin
+    exactly what the same opening plays in a 128-game pool stepped in one piece, serial solver, no yielding (whose behaviour the other tests pin
     to the oracle step by step) — a size-independent property checked at full size, on the path bench.py times; the arenas must hold."""
     from alphagomoku_amd import selfplay, lib, check
     from alphagomoku_amd.networks import AGNetwork
@@ -1106,18 +1108,18 @@ def test_full_size_pool_matches_a_small_pool_game_by_game(agx_lib, name):
         pool.close()
         return st, {g: sorted(v) for g, v in per_game.items()}
     big_stats, big = run(1024, c["big_steps"], True)
-    small_stats, small = run(64, c["small_steps"], False)
+    small_stats, small = run(128, c["small_steps"], False)
     check(lib.agx_net_set_launch_width(net._net, 0))
     assert big_stats["first_error"] == 0 and small_stats["first_error"] == 0 and big_stats["arena_failures"] == 0
     assert big_stats["moves_played"] > 1024 and big_stats["evaluated_nodes"] > 1024 * sims and big_stats["speculative_solves"] > 0
     compared = 0
-    for g in range(64):
+    for g in range(128):
         a, b = big.get(g, []), small.get(g, [])
         k = min(len(a), len(b))
         assert k >= 1, g
         assert a[:k] == b[:k], g           # same moves, same root visit counts, same edge visits and scores
         compared += k
-    assert compared >= 128
+    assert compared >= c["compared"], compared
     net.close()
 
 
