@@ -3,7 +3,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libagx.so")
+LIB_PATH = os.environ.get("AGX_LIB_PATH") or os.path.join(_HERE, "libagx.so")   # (AGX_LIB_PATH: developer builds, e.g. scripts/sanitize_cpu.sh)
 
 
 class AgxError(RuntimeError):

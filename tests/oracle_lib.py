@@ -35,8 +35,8 @@ _lib = None
 def load():
     global _lib
     if _lib is None:
-        path = os.path.join(ROOT, "oracle", "libagoracle.so")
-        if os.path.exists(os.path.join(ROOT, "oracle", "Makefile")):
+        path = os.environ.get("AGO_LIB_PATH") or os.path.join(ROOT, "oracle", "libagoracle.so")   # (AGO_LIB_PATH: scripts/sanitize_cpu.sh)
+        if "AGO_LIB_PATH" not in os.environ and os.path.exists(os.path.join(ROOT, "oracle", "Makefile")):
             subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "libagoracle.so"])
         lib = ctypes.CDLL(path)
         for name in ["ago_defensive_moves", "ago_open_three_promotion_moves", "ago_score_op", "ago_score_make", "ago_move_to_short"]:
