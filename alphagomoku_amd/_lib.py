@@ -180,6 +180,8 @@ def _declare(c):  # noqa: F811
     c.agx_stream_create_with_cu_mask.argtypes = [ctypes.POINTER(vp), vp, ci]
     c.agx_stream_create_with_cu_mask_instance.argtypes = [ctypes.POINTER(vp), vp, ci, ci]
     c.agx_event_create.argtypes = [ctypes.POINTER(vp)]
+    c.agx_event_create_blocking.argtypes = [ctypes.POINTER(vp)]
+    c.agx_event_synchronize.argtypes = [vp]
     c.agx_event_record.argtypes = [vp, vp]
     c.agx_stream_wait_event.argtypes = [vp, vp]
     c.agx_event_destroy.argtypes = [vp]

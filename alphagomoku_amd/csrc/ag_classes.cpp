@@ -1568,6 +1568,11 @@ namespace ag
 	{
 		return (search != nullptr) ? search->getStats() : SearchStats();
 	}
+	GameGenerator::~GameGenerator()
+	{
+		for (void *e : pace_events)
+			agx_event_destroy(e);
+	}
 	GameGenerator::Status GameGenerator::generate()
 	{ // GameGenerator.cpp:46-121 for every game of the slice at once
 		if (pool == nullptr)
@@ -1597,6 +1602,19 @@ namespace ag
 			// decided per game on the device; finished games reach manager.addToBuffer through GeneratorThread::collectGames
 			make_move();
 			state = GAMEPLAY_SELECT_SOLVE_EVALUATE;
+			{ // host pacing: nothing here waits for the device, so the thread would enqueue until the launch queue is full and spin there (a CPU
+			  // per generator thread); it stays two steps ahead of its stream and sleeps on a blocking event instead
+				constexpr uint64_t AHEAD = 2;
+				if (pace_events.empty())
+				{
+					pace_events.assign(AHEAD + 1, nullptr);
+					for (void *&e : pace_events)
+						check(agx_event_create_blocking(&e));
+				}
+				check(agx_event_record(pace_events[steps % pace_events.size()], stream));
+				if (steps >= AHEAD)
+					check(agx_event_synchronize(pace_events[(steps - AHEAD) % pace_events.size()]));
+			}
 			steps++;
 			if (own_pool != nullptr && steps % 64 == 0)
 				serve_own_pool();

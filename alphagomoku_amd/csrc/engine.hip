@@ -29,6 +29,8 @@
 #include "sample_v201.hpp"
 
 #include <vector>
+#include <thread>
+#include <chrono>
 #include <mutex>
 #include <cstring>
 
@@ -4062,6 +4064,28 @@ int agx_event_create(void **out)
 	AGX_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
 	*out = ev;
 	return AGX_OK;
+}
+int agx_event_create_blocking(void **out)
+{ // for agx_event_synchronize: the waiting host thread sleeps (hipEventBlockingSync) instead of spinning
+	AGX_REQUIRE(out != nullptr, AGX_ERR_INVALID, "agx_event_create_blocking: null argument");
+	hipEvent_t ev = nullptr;
+	AGX_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventBlockingSync | hipEventDisableTiming));
+	*out = ev;
+	return AGX_OK;
+}
+int agx_event_synchronize(void *event)
+{ // a SLEEPING wait: hipEventSynchronize spins in user space on this runtime even for a hipEventBlockingSync event (measured: the waiting
+  // thread stays at 100 %), so the event is polled between 100 us naps — the callers wait for work that was queued steps ago
+	AGX_REQUIRE(event != nullptr, AGX_ERR_INVALID, "agx_event_synchronize: null event");
+	while (true)
+	{
+		const hipError_t st = hipEventQuery(static_cast<hipEvent_t>(event));
+		if (st == hipSuccess)
+			return AGX_OK;
+		if (st != hipErrorNotReady)
+			AGX_HIP_CHECK(st);
+		std::this_thread::sleep_for(std::chrono::microseconds(100));
+	}
 }
 int agx_event_record(void *event, void *stream)
 {

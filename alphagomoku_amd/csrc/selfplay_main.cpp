@@ -31,6 +31,7 @@ struct Options
 {
 		int games = 1024, steps = 200, warmup = 20, sims = 400, batch = 8, blocks = 6, filters = 128, rules = 0;
 		int balanced = 0, drain_every = 0, pvq = 0, symmetries = 0, match = 0, slices = 4;
+		int host_steps_ahead = 2; // agx::HostPacer: steps the launch loop may run ahead of a slice's stream (0 = unbounded: it then spins on a full launch queue)
 };
 struct DeviceResult
 {
@@ -73,6 +74,7 @@ static void run_device(int device, int thread_index, const Options &o, AgxGameBu
 		selfplay.network_outputs = network.getOutputConfig();
 		selfplay.record_format = (buffer != nullptr) ? 2 : 1; // format-201 samples when the games go to a buffer
 		agx::GeneratorPool pool(game, selfplay, o.match != 0);
+		pool.setHostStepsAhead(o.host_steps_ahead);
 		result.slices = o.match ? 1 : pool.useChipSlices(network, o.slices, thread_index); // the pool as slices of the chip (agx.hpp); masked streams of its own per device thread
 		auto one_step = [&]() { if (o.match) pool.generate(network, second_network); else pool.generate(network); };
 		uint32_t next_seed = static_cast<uint32_t>(thread_index) * 1000003u; // disjoint openings per device thread
@@ -178,6 +180,7 @@ int main(int argc, char **argv)
 		else if (k == "--balanced-openings") o.balanced = v;
 		else if (k == "--drain-every") o.drain_every = v;
 		else if (k == "--slices") o.slices = v;
+		else if (k == "--host-steps-ahead") o.host_steps_ahead = v;
 		else if (k == "--pvq") o.pvq = v;
 		else if (k == "--symmetries") o.symmetries = v;
 		else if (k == "--match") o.match = v;

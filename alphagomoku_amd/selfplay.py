@@ -23,6 +23,30 @@ def default_config(**overrides):
     return cfg
 
 
+class HostPacer:
+    """Keeps a launch loop at most `ahead` steps in front of a stream: call step(stream) behind every step's launches.  Without it the host
+    enqueues until the launch queue is full and spins there — a whole CPU per device thread; with it the thread sleeps on a blocking event
+    (agx.h: agx_event_create_blocking; agx.hpp: HostPacer).  Pacing only."""
+
+    def __init__(self, ahead=2):
+        self.ahead = ahead
+        self.count = 0
+        self.events = []
+        for _ in range(ahead + 1 if ahead > 0 else 0):
+            ev = ctypes.c_void_p()
+            check(lib.agx_event_create_blocking(ctypes.byref(ev)))
+            self.events.append(ev)
+
+    def step(self, stream=None):
+        if self.ahead <= 0:
+            return
+        ring = len(self.events)
+        check(lib.agx_event_record(self.events[self.count % ring], stream))
+        if self.count >= self.ahead:
+            check(lib.agx_event_synchronize(self.events[(self.count - self.ahead) % ring]))
+        self.count += 1
+
+
 def chip_slices(n_slices):
     """n_slices streams that own disjoint, equal blocks of the device's compute units (agx_stream_create_with_cu_mask), for stepping a pool as
     n_slices groups: returns (streams, compute units per slice).  The streams are never destroyed (agx.h)."""

@@ -46,6 +46,24 @@ def source_hash():
     return build.source_hash()
 
 
+def thread_cpu_seconds():
+    """{thread id: (name, user + system CPU seconds)} of this process, from /proc/self/task"""
+    out = {}
+    ticks = os.sysconf("SC_CLK_TCK")
+    try:
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                stat = open("/proc/self/task/%s/stat" % tid).read()
+            except OSError:
+                continue
+            name = stat[stat.index("(") + 1:stat.rindex(")")]
+            fields = stat[stat.rindex(")") + 2:].split()
+            out[int(tid)] = ("main thread" if int(tid) == os.getpid() else name + " (runtime thread)", (int(fields[11]) + int(fields[12])) / float(ticks))
+    except OSError:
+        pass
+    return out
+
+
 def host_cpu_limits():
     """what bounds a CPU leg on this box: the CPUs this process may run on (affinity), the cgroup CPU quota (cpu.max, cgroup v2; cfs quota, v1)
     and the CPU model"""
@@ -171,6 +189,9 @@ def main():
     ap.add_argument("--stagger", type=int, default=1,
                     help="1: the slices enter the timed region a stage apart in their cycles, as a pool that has run for a while has them (the synchronisation in "
                          "front of the timed region would otherwise start all of them on the same stage); 0: all slices start with the search launch")
+    ap.add_argument("--host-pacing", type=int, default=2,
+                    help="N > 0: the host stays at most N steps ahead of every slice's stream and SLEEPS on a blocking event; 0: it enqueues until the "
+                         "launch queue is full and spins there (a whole CPU more per rank: the line's ranks[].host_cpu_utilisation)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=24.0)
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline, 0 = every host CPU")
@@ -278,6 +299,8 @@ def main():
     def step_slice(g, nn_timer=None, first_stage=0):
         for stage in ((0, 1, 2), (1, 2, 0), (2, 0, 1))[first_stage]:
             run_stage(g, stage, nn_timer)
+        if pacing is not None:
+            pacing(g)
 
     def run_stage(g, stage, nn_timer):
         if net_streams is None:   # (the default: a slice's three stages on its one stream)
@@ -326,6 +349,26 @@ def main():
                 pool.add_openings(selfplay.pack_openings(extra))
                 n_openings += args.games
 
+    pacing = None
+    if args.host_pacing > 0:   # (agx.h: agx_event_create_blocking; the same pacing as agx.hpp's HostPacer and ag::GameGenerator::generate)
+        ring = args.host_pacing + 1
+        pace_events = []
+        for g in range(slices):
+            row = []
+            for _ in range(ring):
+                ev = ctypes.c_void_p()
+                check(lib.agx_event_create_blocking(ctypes.byref(ev)))
+                row.append(ev)
+            pace_events.append(row)
+        pace_count = [0] * slices
+
+        def pacing(g):
+            k = pace_count[g]
+            check(lib.agx_event_record(pace_events[g][k % ring], streams[g]))
+            pace_count[g] = k + 1
+            if k >= args.host_pacing:
+                check(lib.agx_event_synchronize(pace_events[g][(k - args.host_pacing) % ring]))
+
     # untimed: warm-up launches, then the pool is AGED so that a short timed region sees what a long run sees — games in every phase, trees of a
     # couple of thousand nodes, arenas that have grown, slices out of phase (fresh games alone are the opening phase: small trees, no game ends)
     for i in range(args.warmup + args.age_steps):
@@ -345,6 +388,7 @@ def main():
     check(lib.agx_device_synchronize())
     t0 = time.perf_counter()
     cpu0 = time.process_time()
+    threads0 = thread_cpu_seconds()
     for i in range(args.steps):
         for g in range(slices):
             step_slice(g, t_nn[g][i], phase[g])
@@ -354,6 +398,9 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     host_cpu_seconds = time.process_time() - cpu0   # user + system time of this rank's process inside the timed region (all its threads)
+    threads1 = thread_cpu_seconds()
+    # which threads that was: (name, CPU seconds) of the busiest ones — the launch loop is this process's main thread, the rest belong to the HIP / HSA runtime
+    host_threads = sorted(((name, round(sec - threads0.get(tid, (name, 0.0))[1], 2)) for tid, (name, sec) in threads1.items()), key=lambda x: -x[1])[:4]
     s1 = pool.stats()
     kernel_ms, kernel_launches = pool.kernel_timing(False)
 
@@ -459,7 +506,7 @@ def main():
             "nn_positions_per_sec": evals / elapsed,
             # how the pool is stepped: `count` slices of games_per_gpu / count games, each on a stream that owns cus_per_slice compute units;
             # the slices' launches overlap in time, so the per-launch durations below add up to more than ms_per_step
-            "slices": {"count": slices, "cus_per_slice": cus_per_slice, "games_per_slice": args.games // slices, "first_stage_of_a_step": phase,
+            "slices": {"count": slices, "cus_per_slice": cus_per_slice, "games_per_slice": args.games // slices, "first_stage_of_a_step": phase, "host_steps_ahead": args.host_pacing if args.host_pacing > 0 else None,
                        "partitions": ({"network_cus": cus_per_slice, "search_cus": total_cus - cus_per_slice - args.tree_cus, "tree_cus": args.tree_cus}
                                       if net_streams is not None else None)},
             "stage_ms_per_step": {"select_solve": ms_sel / launches, "network": ms_nn / launches, "expand_backup_advance": ms_exp / launches,
@@ -482,7 +529,8 @@ def main():
             # per rank: its own work and wall time, the host CPU it needed (CPU seconds of the rank's process / its wall seconds — one
             # launch loop per GPU must stay well below one core) and where it was pinned
             "ranks": [{"rank": i, "device": int(r[3]), "simulations": int(r[0]), "seconds": r[1], "opening_seed_base": int(r[2]),
-                       "host_cpu_seconds": r[5], "host_cpu_utilisation": r[5] / max(r[1], 1e-9), "numa_node": int(r[6]), "pinned_cpus": int(r[7])}
+                       "host_cpu_seconds": r[5], "host_cpu_utilisation": r[5] / max(r[1], 1e-9), "numa_node": int(r[6]), "pinned_cpus": int(r[7]),
+                       **({"host_threads_cpu_seconds": host_threads} if i == 0 else {})}
                       for i, r in enumerate(per_rank)],
             "longest_kernel": {"name": longest, "share_of_kernel_time": per_kernel[longest] / gpu_ms if gpu_ms > 0 else None},
             "source_hash": src_hash, "library_build_hash": build_hash,

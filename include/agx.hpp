@@ -34,6 +34,45 @@ namespace agx
 		throw std::runtime_error(msg);
 	}
 
+	/* Keeps a launch loop at most `ahead` steps in front of a stream: call step(stream) behind every step's launches.  Without it the host
+	 * enqueues until the launch queue is full and spins there — a whole CPU per device thread; with it the thread sleeps on a blocking event
+	 * (agx.h: agx_event_create_blocking).  Pacing only: the device never waits for the host while `ahead` >= 1 step is queued. */
+	class HostPacer
+	{
+			std::vector<void*> m_events;
+			uint64_t m_count = 0;
+			int m_ahead;
+		public:
+			explicit HostPacer(int ahead = 2) :
+					m_events(static_cast<size_t>(ahead > 0 ? ahead + 1 : 0), nullptr), m_ahead(ahead)
+			{
+				for (void *&e : m_events)
+					check(agx_event_create_blocking(&e));
+			}
+			HostPacer(const HostPacer&) = delete;
+			HostPacer& operator=(const HostPacer&) = delete;
+			HostPacer(HostPacer &&other) noexcept :
+					m_events(std::move(other.m_events)), m_count(other.m_count), m_ahead(other.m_ahead)
+			{
+				other.m_events.clear();
+			}
+			~HostPacer()
+			{
+				for (void *e : m_events)
+					agx_event_destroy(e);
+			}
+			void step(void *stream)
+			{
+				if (m_ahead <= 0)
+					return;
+				const size_t ring = m_events.size();
+				check(agx_event_record(m_events[m_count % ring], stream));
+				if (m_count >= static_cast<uint64_t>(m_ahead))
+					check(agx_event_synchronize(m_events[(m_count - m_ahead) % ring]));
+				m_count++;
+			}
+	};
+
 	struct GameConfig
 	{ // ag::GameConfig (utils/configs.hpp:23-44)
 			int rules = AGX_FREESTYLE;
@@ -140,6 +179,9 @@ namespace agx
 			AgxEngine *m_engine = nullptr;
 			AgxEngineBuffers m_buffers { };
 			std::vector<void*> m_slice_streams; // useChipSlices: one CU-masked stream per slice of the pool
+			std::vector<HostPacer> m_pacers;    // one per slice (or one for the un-sliced pool)
+			int m_steps_ahead = 2;
+			bool m_phase_started = false;
 			int m_games = 0;
 			bool m_match = false;
 		public:
@@ -241,11 +283,46 @@ namespace agx
 			void generate(AGNetwork &network, void *stream = nullptr)
 			{
 				if (m_slice_streams.empty())
+				{
 					check(agx_engine_step(m_engine, network.handle(), stream));
+					if (m_pacers.empty())
+						m_pacers.emplace_back(m_steps_ahead);
+					m_pacers[0].step(stream);
+				}
 				else
-					for (size_t g = 0; g < m_slice_streams.size(); g++)
-						check(agx_engine_step_group(m_engine, network.handle(), static_cast<int>(g), static_cast<int>(m_slice_streams.size()), m_slice_streams[g]));
+				{ // The slices run a stage apart: slice g's cycle starts `phase` stages early (once, at the first call), after that every call runs one
+				  // whole cycle per slice, rotated.  Slices that start together stay together while the host feeds them in step — four towers at
+				  // once, the power-limited case the slicing exists to avoid (bench.py --stagger: 780 k -> 827 k simulations/s in a short window).
+					const int n = static_cast<int>(m_slice_streams.size());
+					auto stage = [&](int g, int which)
+					{
+						if (which == 0)
+							check(agx_engine_select_solve_group(m_engine, g, n, m_slice_streams[g]));
+						else if (which == 1)
+							check(agx_engine_evaluate_group(m_engine, network.handle(), g, n, m_slice_streams[g]));
+						else
+							check(agx_engine_expand_backup_group(m_engine, g, n, m_slice_streams[g]));
+					};
+					static const int PHASES[4] = { 0, 1, 2, 1 };
+					if (!m_phase_started)
+					{
+						m_phase_started = true;
+						for (int g = 0; g < n; g++)
+							for (int k = 0; k < PHASES[g % 4]; k++)
+								stage(g, k);
+					}
+					for (int g = 0; g < n; g++)
+					{
+						for (int k = 0; k < 3; k++)
+							stage(g, (PHASES[g % 4] + k) % 3);
+						while (static_cast<int>(m_pacers.size()) <= g)
+							m_pacers.emplace_back(m_steps_ahead);
+						m_pacers[g].step(m_slice_streams[g]); // the host stays two steps ahead of every slice and sleeps otherwise (HostPacer)
+					}
+				}
 			}
+			/* steps the host may run ahead of the device (0: unbounded — the launch loop then spins on a full queue); before the first generate() */
+			void setHostStepsAhead(int steps) { m_steps_ahead = steps; }
 			/* EvaluationGame::generate for every pair: the first players' trees with their network, then the second players' */
 			void generate(AGNetwork &first, AGNetwork &second, void *stream = nullptr)
 			{

@@ -83,6 +83,7 @@ namespace ag
 			int group = 0, n_groups = 1;
 			void *stream = nullptr;
 			uint64_t steps = 0;
+			std::vector<void*> pace_events;     // host pacing: blocking events behind the last steps (agx.h: agx_event_create_blocking)
 			int own_openings = 0;
 			uint32_t opening_seed = 0;
 			void start_own_pool();
@@ -99,6 +100,7 @@ namespace ag
 			GameGenerator(const GameConfig &gameOptions, const SelfplayConfig &selfplayOptions, GeneratorManager &manager, NNEvaluator &evaluator, GamePool &pool,
 					int group, int n_groups, void *stream);
 
+			~GameGenerator();
 			void clearStats();
 			NodeCacheStats getCacheStats() const noexcept;
 			SearchStats getSearchStats() const noexcept;

@@ -65,5 +65,7 @@ def test_eight_ranks_on_one_gpu(agx_lib):
     total = sum(r["simulations"] for r in ranks)
     assert all(r["simulations"] > 0 for r in ranks)
     assert abs(line["value"] * (line["ms_per_step"] * 1e-3 * line["steps"]) - total) <= 1e-6 * total
-    # (the HIP runtime's helper threads spin while they wait for the device: informational, not a bound on one core)
-    assert all(r["host_cpu_seconds"] > 0.0 and r["host_cpu_utilisation"] < 16.0 for r in ranks)
+    # host pacing (bench.py --host-pacing 2, the default): the launch loop naps on an event two steps behind instead of spinning on a full
+    # launch queue — a rank needs a fraction of a CPU (0.12 measured for one rank per GPU), two whole ones without the pacing
+    assert line["slices"]["host_steps_ahead"] == 2
+    assert all(r["host_cpu_seconds"] > 0.0 and r["host_cpu_utilisation"] < 0.8 for r in ranks), [r["host_cpu_utilisation"] for r in ranks]
