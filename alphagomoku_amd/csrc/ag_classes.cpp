@@ -1892,11 +1892,22 @@ namespace ag
 		}
 
 		uint64_t iterations = 0;
+		// The slices' streams run their queues independently, so left alone every slice starts its first search launch at the same moment and
+		// the slices stay in step: all their network launches at once — the power-limited case the slicing exists to avoid.  The odd slices
+		// therefore begin when slice 0's first search launch is over (an event on its stream): two network launches at a time, not all.
+		void *first_search_done = nullptr;
 		while (is_running.load() and not manager.hasEnoughGames())
 		{
 			for (size_t i = 0; i < generators.size(); i++)
 			{
+				if (iterations == 0 && i % 2 == 1 && first_search_done != nullptr)
+					check(agx_stream_wait_event(streams[i], first_search_done));
 				const GameGenerator::Status status = generators[i]->generate();
+				if (iterations == 0 && i == 0 && generators.size() > 1)
+				{
+					check(agx_event_create(&first_search_done));
+					check(agx_event_record(first_search_done, streams[0]));
+				}
 				if (nn_evaluator.isQueueFull() or status == GameGenerator::TASKS_NOT_READY)
 				{
 					nn_evaluator.asyncEvaluateGraphJoin();
@@ -1918,6 +1929,8 @@ namespace ag
 		}
 		nn_evaluator.asyncEvaluateGraphJoin();
 		check(agx_device_synchronize());
+		if (first_search_done != nullptr)
+			check(agx_event_destroy(first_search_done));
 		collectGames();
 		{ // what saveGames will write: the games still in flight, slice by slice (their samples leave the manager's buffer with them)
 			saved_games.assign({ 'A', 'G', 'X', 'S', 1, 0, 0, 0 });

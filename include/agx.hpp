@@ -181,7 +181,7 @@ namespace agx
 			std::vector<void*> m_slice_streams; // useChipSlices: one CU-masked stream per slice of the pool
 			std::vector<HostPacer> m_pacers;    // one per slice (or one for the un-sliced pool)
 			int m_steps_ahead = 2;
-			bool m_phase_started = false;
+			bool m_phase_started = false, m_skip_first_search_of_slice0 = false;
 			int m_games = 0;
 			bool m_match = false;
 		public:
@@ -307,14 +307,38 @@ namespace agx
 					if (!m_phase_started)
 					{
 						m_phase_started = true;
+						// ... and on the DEVICE the odd slices begin when slice 0's first search launch is over (streams run their queues
+						// independently: without this every slice starts its first search at the same moment, whatever the host's order)
+						void *first_search_done = nullptr;
 						for (int g = 0; g < n; g++)
+						{
+							if (g % 2 == 1 && first_search_done != nullptr)
+								check(agx_stream_wait_event(m_slice_streams[g], first_search_done));
 							for (int k = 0; k < PHASES[g % 4]; k++)
 								stage(g, k);
+							if (g == 0 && n > 1)
+							{
+								check(agx_engine_select_solve_group(m_engine, 0, n, m_slice_streams[0])); // (slice 0's first cycle starts here; the loop below skips that stage once)
+								check(agx_event_create(&first_search_done));
+								check(agx_event_record(first_search_done, m_slice_streams[0]));
+								m_skip_first_search_of_slice0 = true;
+							}
+						}
+						if (first_search_done != nullptr)
+							check(agx_event_destroy(first_search_done));
 					}
 					for (int g = 0; g < n; g++)
 					{
 						for (int k = 0; k < 3; k++)
-							stage(g, (PHASES[g % 4] + k) % 3);
+						{
+							const int which = (PHASES[g % 4] + k) % 3;
+							if (g == 0 && which == 0 && m_skip_first_search_of_slice0)
+							{
+								m_skip_first_search_of_slice0 = false;
+								continue;
+							}
+							stage(g, which);
+						}
 						while (static_cast<int>(m_pacers.size()) <= g)
 							m_pacers.emplace_back(m_steps_ahead);
 						m_pacers[g].step(m_slice_streams[g]); // the host stays two steps ahead of every slice and sleeps otherwise (HostPacer)
