@@ -240,6 +240,7 @@ namespace agx
 				if (openings.empty() || openings.size() % AGX_OPENING_CAP != 0)
 					throw std::logic_error("GeneratorPool::begin: openings must hold a positive multiple of AGX_OPENING_CAP words");
 				check(agx_engine_begin(m_engine, openings.data(), static_cast<int>(openings.size() / AGX_OPENING_CAP), stream));
+				m_phase_started = m_skip_first_search_of_slice0 = false; // new games: every slice's cycle starts at its select stage again (generate())
 			}
 			/* OpeningGenerator::generate (OpeningGenerator.cpp:21-78): solver-unproven, network-balanced openings; before begin() */
 			std::vector<uint16_t> generateOpenings(AGNetwork &network, int count, uint32_t seed = 0)
