@@ -63,6 +63,12 @@
 #ifndef AGX_NN_LAYER_PREFETCH
 #define AGX_NN_LAYER_PREFETCH 1 // 1: the row-stationary k-loop's last turn requests the NEXT layer's first weight fragments (two-plane 15-column kernels)
 #endif
+#ifndef AGX_NN_FMA_MIX
+#define AGX_NN_FMA_MIX 1 // 1: the residual add of a layer's accumulator initialisation as v_fma_mix_f32 (fp16 operand widened by the instruction)
+#endif
+#ifndef AGX_NN_INPUT_PREFETCH
+#define AGX_NN_INPUT_PREFETCH 1 // 1: the next board's feature words are requested while the current board's heads run
+#endif
 #ifndef AGX_NN_CONV5_SPLIT
 #define AGX_NN_CONV5_SPLIT 1 // 1: 128-filter nets on 15-column boards run the input conv5x5 row-stationary in two passes per column shift
 #endif
@@ -728,6 +734,18 @@ namespace
 			conv3x3_mac_taps<F, ROWS, COLS, ZERO>(src, wpk, wave, lane, acc);
 	}
 
+	__device__ __forceinline__ float half_plus_float_lo(uint32_t packed_halves, float addend)
+	{
+		float d;
+		asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(packed_halves), "v"(addend));
+		return d;
+	}
+	__device__ __forceinline__ float half_plus_float_hi(uint32_t packed_halves, float addend)
+	{
+		float d;
+		asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(packed_halves), "v"(addend));
+		return d;
+	}
 	template<bool TANH>
 	__device__ __forceinline__ float activation(float x)
 	{ // ReLU of the tower / policy head, tanh of the action-values head (blocks.cpp:119-127)
@@ -760,11 +778,21 @@ namespace
 				if (SKIP && n < my_tiles)
 				{
 					const int pos = G::S + G::tile_position(wave, n, r);
+#if AGX_NN_FMA_MIX
+					// bias + (float) residual as ONE instruction per value: v_fma_mix_f32 widens the fp16 operand itself (h * 1.0 + b rounds once,
+					// exactly like the conversion followed by the add)
+					const uint2 sk = *reinterpret_cast<const uint2*>(dst + plane_offset<G>(pos + 1, ch / 8) + (ch % 8) * 2);
+					v[0] = half_plus_float_lo(sk.x, bv[0]);
+					v[1] = half_plus_float_hi(sk.x, bv[1]);
+					v[2] = half_plus_float_lo(sk.y, bv[2]);
+					v[3] = half_plus_float_hi(sk.y, bv[3]);
+#else
 					const half4 sk = *reinterpret_cast<const half4*>(dst + plane_offset<G>(pos + 1, ch / 8) + (ch % 8) * 2);
 					v[0] += static_cast<float>(sk[0]);
 					v[1] += static_cast<float>(sk[1]);
 					v[2] += static_cast<float>(sk[2]);
 					v[3] += static_cast<float>(sk[3]);
+#endif
 				}
 				acc[i][n] = v;
 			}
@@ -1380,6 +1408,12 @@ namespace
 #ifdef AGX_NN_PROFILE
 		NnStamp stamp(wave, lane);
 #endif
+#if AGX_NN_INPUT_PREFETCH
+		static_assert(G::HW <= G::THREADS, "one feature word per thread");
+		uint32_t next_word = 0; // this thread's feature word of the board about to be staged
+		if (static_cast<int>(blockIdx.x) < batch && tid < G::HW)
+			next_word = features[static_cast<size_t>((p.slot_list != nullptr) ? p.slot_list[blockIdx.x] : static_cast<int>(blockIdx.x)) * G::HW + tid];
+#endif
 		for (int bi = blockIdx.x; bi < batch; bi += gridDim.x)
 		{
 			const int b = (p.slot_list != nullptr) ? p.slot_list[bi] : bi;
@@ -1390,7 +1424,11 @@ namespace
 			__syncthreads();
 			for (int c = tid; c < G::HW; c += G::THREADS)
 			{
+#if AGX_NN_INPUT_PREFETCH
+				const uint32_t word = next_word;
+#else
 				const uint32_t word = features[static_cast<size_t>(b) * G::HW + c];
+#endif
 				const int q = (c / COLS + 2) * G::S5 + (c % COLS + 2);
 #pragma unroll
 				for (int k = 0; k < (RAW ? 1 : 4); k++)
@@ -1497,6 +1535,14 @@ namespace
 			}
 			__syncthreads();
 			AGX_NN_MARK(7);
+#if AGX_NN_INPUT_PREFETCH
+			// the next board's input: requested here, consumed by the staging loop at the top — the round trip rides under the heads
+			if (bi + static_cast<int>(gridDim.x) < batch && tid < G::HW)
+			{
+				const int nb = bi + static_cast<int>(gridDim.x);
+				next_word = features[static_cast<size_t>((p.slot_list != nullptr) ? p.slot_list[nb] : nb) * G::HW + tid];
+			}
+#endif
 
 			// ---- policy head: conv1x1 F->1 + bias, softmax over the board ----
 			{

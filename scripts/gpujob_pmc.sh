@@ -10,4 +10,5 @@ cp gpurun_out/r04_pmc_summary.json profiles/r04_pmc_summary.json
 python bench.py > gpurun_out/r04_bench_line.json 2> gpurun_out/r04_bench_line.err
 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r04_bench_line_driver_window_20_steps.json 2>/dev/null
 python bench.py --steps 40 --warmup 30 --age-steps 0 --no-cpu-baseline > gpurun_out/r04_pmc_workload_line.json 2>/dev/null
+timeout 900 python -m pytest tests/test_nn_gpu.py tests/test_engine_gpu.py -x -q -k 'nn or network or raw or whole_games_bit_exact or full_size_pool' 2>&1 | tail -3
 for f in gpurun_out/r04_bench_line.json gpurun_out/r04_bench_line_driver_window_20_steps.json; do python -c "import json; d=json.load(open('$f')); print('$f', round(d['value']), d['roofline']['frac'], d['roofline']['mfma_busy_fraction_pmc'], d['source_hash'])"; done
