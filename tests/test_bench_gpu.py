@@ -69,3 +69,37 @@ def test_eight_ranks_on_one_gpu(agx_lib):
     # launch queue — a rank needs a fraction of a CPU (0.12 measured for one rank per GPU), two whole ones without the pacing
     assert line["slices"]["host_steps_ahead"] == 2
     assert all(r["host_cpu_seconds"] > 0.0 and r["host_cpu_utilisation"] < 0.8 for r in ranks), [r["host_cpu_utilisation"] for r in ranks]
+
+
+def test_host_pacer_sleeps_behind_the_stream(agx_lib):
+    """agx_event_create_blocking / agx_event_synchronize and selfplay.HostPacer (agx.hpp: HostPacer, ag::GameGenerator::generate): a loop paced two
+    steps behind its stream completes, waits on never-recorded events return at once, and the waiting thread does not spin"""
+    import ctypes
+    import time
+    from alphagomoku_amd import selfplay, synthetic, lib, check
+    from alphagomoku_amd.networks import AGNetwork
+    ev = ctypes.c_void_p()
+    check(lib.agx_event_create_blocking(ctypes.byref(ev)))
+    check(lib.agx_event_synchronize(ev))          # never recorded: complete
+    check(lib.agx_event_record(ev, None))
+    check(lib.agx_event_synchronize(ev))
+    check(lib.agx_event_destroy(ev))
+    d = synthetic.net_desc(blocks=2, filters=64)
+    blob, _ = synthetic.make_weights(d)
+    net = AGNetwork(d)
+    net.loadWeights(blob)
+    pool = selfplay.GeneratorPool(selfplay.default_config(n_games=256, max_batch_size=8, max_simulations=200, tss_table_entries=1 << 16))
+    pool.begin(selfplay.pack_openings(synthetic.make_openings(15, 512, seed0=77)))
+    pacer = selfplay.HostPacer(2)
+    wall0, cpu0 = time.perf_counter(), time.thread_time()
+    for _ in range(300):
+        pool.step(net)
+        pacer.step(None)
+    check(lib.agx_device_synchronize())
+    wall, cpu = time.perf_counter() - wall0, time.thread_time() - cpu0
+    st = pool.stats()
+    assert st["first_error"] == 0 and st["evaluated_nodes"] > 300 * 256
+    assert pacer.count == 300
+    assert cpu < 0.6 * wall, (cpu, wall)          # the loop's thread naps while the device works (a spinning wait would be ~1.0)
+    pool.close()
+    net.close()
