@@ -69,30 +69,76 @@ def rank_seed_base(rank):
     return rank * 1000003
 
 
-def pin_to_gpu_numa_node(local_device):
+def _kfd_gpu_pci_addresses(sysfs_root):
+    """PCI addresses ("dddd:bb:dd.f") of the GPUs in KFD topology order — the order in which the HIP runtime numbers its devices (every
+    /sys/class/kfd/kfd/topology/nodes/<n>/properties with simd_count > 0 is a GPU; `domain` and `location_id` = bus << 8 | device << 3 | function
+    give its PCI function).  None when the topology cannot be read."""
+    base = os.path.join(sysfs_root, "sys/class/kfd/kfd/topology/nodes")
+    try:
+        nodes = sorted((int(n) for n in os.listdir(base) if n.isdigit()))
+    except OSError:
+        return None
+    out = []
+    for n in nodes:
+        try:
+            props = dict(line.split()[:2] for line in open(os.path.join(base, str(n), "properties")) if len(line.split()) >= 2)
+        except OSError:
+            continue   # (a node this user may not read: not one of its devices)
+        if int(props.get("simd_count", "0")) <= 0:
+            continue   # a CPU node
+        loc, dom = int(props.get("location_id", "0")), int(props.get("domain", "0"))
+        out.append("%04x:%02x:%02x.%x" % (dom, (loc >> 8) & 0xFF, (loc >> 3) & 0x1F, loc & 0x7))
+    return out or None
+
+
+def _visible_index(local_device):
+    """the runtime numbers only the VISIBLE devices: HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES = "2,3" makes device 0 the topology's GPU 2"""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        spec = os.environ.get(var, "").strip()
+        if spec:
+            try:
+                ids = [int(x) for x in spec.split(",") if x.strip() != ""]
+            except ValueError:
+                return None   # (UUID form: not resolved here)
+            return ids[local_device] if local_device < len(ids) else None
+    return local_device
+
+
+def pin_to_gpu_numa_node(local_device, sysfs_root="/"):
     """Binds this process's host threads to the CPUs of the NUMA node its GPU hangs off (one generator thread per device in the reference,
     GeneratorManager.cpp:146-152; SURVEY 8e: the host side of a rank is a launch loop, it must not wander to the other socket).  Best effort
-    from sysfs — the local_device-th AMD display / processing-accelerator PCI function in address order, its numa_node, that node's cpulist
-    intersected with the current affinity; returns (numa_node, cpus pinned to) or (None, 0) when the topology cannot be read."""
+    from sysfs: the GPU is the local_device-th VISIBLE one in KFD topology order (the HIP runtime's numbering; fallback: the AMD display /
+    processing-accelerator PCI functions in address order), its PCI function's numa_node, that node's cpulist intersected with the current
+    affinity.  Returns (numa_node, cpus pinned to) or (None, 0) when the topology cannot be read."""
     import glob
     try:
-        gpus = []
-        for dev in glob.glob("/sys/bus/pci/devices/*"):
-            try:
-                vendor = open(os.path.join(dev, "vendor")).read().strip()
-                cls = open(os.path.join(dev, "class")).read().strip()
-            except OSError:
-                continue
-            if vendor == "0x1002" and (cls.startswith("0x03") or cls.startswith("0x12")):
-                gpus.append(dev)
-        gpus.sort()
-        if local_device >= len(gpus):
+        index = _visible_index(local_device)
+        if index is None:
             return None, 0
-        node = int(open(os.path.join(gpus[local_device], "numa_node")).read().strip())
+        addresses = _kfd_gpu_pci_addresses(sysfs_root)
+        if addresses is not None:
+            if index >= len(addresses):
+                return None, 0
+            device_dir = os.path.join(sysfs_root, "sys/bus/pci/devices", addresses[index])
+        else:
+            gpus = []
+            for dev in glob.glob(os.path.join(sysfs_root, "sys/bus/pci/devices/*")):
+                try:
+                    vendor = open(os.path.join(dev, "vendor")).read().strip()
+                    cls = open(os.path.join(dev, "class")).read().strip()
+                except OSError:
+                    continue
+                if vendor == "0x1002" and (cls.startswith("0x03") or cls.startswith("0x12")):
+                    gpus.append(dev)
+            gpus.sort()
+            if index >= len(gpus):
+                return None, 0
+            device_dir = gpus[index]
+        node = int(open(os.path.join(device_dir, "numa_node")).read().strip())
         if node < 0:
             return None, 0
         cpus = set()
-        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+        for part in open(os.path.join(sysfs_root, "sys/devices/system/node/node%d/cpulist" % node)).read().strip().split(","):
             lo, _, hi = part.partition("-")
             cpus.update(range(int(lo), int(hi or lo) + 1))
         allowed = cpus & set(os.sched_getaffinity(0))

@@ -82,3 +82,45 @@ def test_bench_spawns_its_ranks(tmp_path):
                        text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-2000:]
     assert sorted(f for f in os.listdir(tmp_path) if f.startswith("rank")) == ["rank0_of_2", "rank1_of_2"]
+
+
+def _fake_sysfs(root, gpus, cpulists):
+    """gpus: [(kfd node, domain, bus, device, function, numa node)] in any order; cpulists: {numa node: "a-b,c"}; KFD node 0 is a CPU node"""
+    nodes = root / "sys/class/kfd/kfd/topology/nodes"
+    (nodes / "0").mkdir(parents=True)
+    (nodes / "0" / "properties").write_text("cpu_cores_count 64\nsimd_count 0\nlocation_id 0\ndomain 0\n")
+    for kfd, dom, bus, dev, fn, numa in gpus:
+        (nodes / str(kfd)).mkdir(parents=True)
+        (nodes / str(kfd) / "properties").write_text("cpu_cores_count 0\nsimd_count 1024\ndomain %d\nlocation_id %d\n" % (dom, (bus << 8) | (dev << 3) | fn))
+        pci = root / "sys/bus/pci/devices" / ("%04x:%02x:%02x.%x" % (dom, bus, dev, fn))
+        pci.mkdir(parents=True)
+        (pci / "numa_node").write_text("%d\n" % numa)
+        (pci / "vendor").write_text("0x1002\n")
+        (pci / "class").write_text("0x120000\n")
+    for numa, cpus in cpulists.items():
+        d = root / ("sys/devices/system/node/node%d" % numa)
+        d.mkdir(parents=True)
+        (d / "cpulist").write_text(cpus + "\n")
+
+
+def test_numa_pinning_follows_the_runtime_device_order(tmp_path, monkeypatch):
+    """distributed.pin_to_gpu_numa_node: device k is the k-th GPU in KFD topology order (NOT in PCI address order), HIP_VISIBLE_DEVICES renumbers,
+    the CPUs are the node's cpulist within the current affinity; an unreadable topology pins nothing"""
+    import os
+    from alphagomoku_amd import distributed
+    mine = sorted(os.sched_getaffinity(0))
+    lo, hi = mine[0], mine[-1]
+    # KFD order: node 1 = bus 0xc1 on NUMA 1, node 2 = bus 0x05 on NUMA 0 — the opposite of the PCI address order
+    _fake_sysfs(tmp_path, [(1, 0, 0xC1, 0, 0, 1), (2, 0, 0x05, 0, 0, 0)], {0: "%d" % lo, 1: "%d" % hi})
+    pinned = []
+    monkeypatch.setattr(os, "sched_setaffinity", lambda pid, cpus: pinned.append(set(cpus)))
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES", raising=False)
+    monkeypatch.delenv("ROCR_VISIBLE_DEVICES", raising=False)
+    assert distributed.pin_to_gpu_numa_node(0, str(tmp_path)) == (1, 1) and pinned[-1] == {hi}
+    assert distributed.pin_to_gpu_numa_node(1, str(tmp_path)) == (0, 1) and pinned[-1] == {lo}
+    assert distributed.pin_to_gpu_numa_node(2, str(tmp_path)) == (None, 0)            # no such device
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "1")                                     # device 0 is now the topology's second GPU
+    assert distributed.pin_to_gpu_numa_node(0, str(tmp_path)) == (0, 1) and pinned[-1] == {lo}
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    assert distributed.pin_to_gpu_numa_node(0, str(tmp_path / "nothing-here")) == (None, 0)
+    assert len(pinned) == 3
