@@ -68,6 +68,7 @@ def _declare(c):
     c.agx_timer_start.argtypes = [vp, vp]
     c.agx_timer_stop.argtypes = [vp, vp]
     c.agx_timer_elapsed_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
+    c.agx_timer_poll_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)]
     c.agx_timer_destroy.argtypes = [vp]
 
 
@@ -200,6 +201,7 @@ def _declare(c):  # noqa: F811
     c.agx_engine_root_summary.argtypes = [vp, ci, vp, ctypes.POINTER(ctypes.c_int)]
     c.agx_engine_buffers.argtypes = [vp, ctypes.POINTER(AgxEngineBuffers)]
     c.agx_engine_stats.argtypes = [vp, ctypes.POINTER(AgxEngineStats)]
+    c.agx_engine_device_bytes.argtypes = [vp, ctypes.POINTER(ctypes.c_ulonglong)]
     c.agx_engine_kernel_timing.argtypes = [vp, ci, vp, vp]
     c.agx_engine_add_openings.argtypes = [vp, vp, ci]
     c.agx_engine_match_results.argtypes = [vp, vp, ci]

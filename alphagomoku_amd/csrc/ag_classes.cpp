@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <csignal>
 #include <cstring>
 #include <filesystem>
 #include <fstream>
@@ -526,7 +527,8 @@ namespace ag
 				else if (network_timer_used[s.event])
 				{
 					float ms = 0.0f;
-					if (agx_timer_elapsed_ms(network_timer[s.event], &ms) == AGX_OK && ms > 0.0f)
+					int ready = 0; // (polled, never waited for: a launch that is still running keeps the previous estimate)
+					if (agx_timer_poll_ms(network_timer[s.event], &ms, &ready) == AGX_OK && ready != 0 && ms > 0.0f)
 						network_seconds = (network_seconds > 0.0) ? 0.75 * network_seconds + 0.25 * ms * 1.0e-3 : ms * 1.0e-3;
 				}
 				check(agx_timer_start(network_timer[s.event], own_stream));
@@ -1656,7 +1658,7 @@ namespace ag
 	{ // GameGenerator.cpp:131-141: the Game and its samples come back, the search starts again on an empty tree (prepare_search)
 		auto need = [&](size_t n)
 		{
-			if (offset + n > binary_data.size())
+			if (offset > binary_data.size() || n > binary_data.size() - offset) // (subtraction form: a length read from the file must not wrap the test)
 				throw std::runtime_error("GameGenerator::load() : the saved state is truncated");
 		};
 		need(sizeof(uint32_t));
@@ -1770,14 +1772,24 @@ namespace ag
 		last_search_stats = s;
 		last_cache_stats = c;
 	}
+	static std::vector<uint8_t> saved_games_header(uint32_t generators)
+	{ // "AGXS", u32 version, u32 number of generators
+		std::vector<uint8_t> out({ 'A', 'G', 'X', 'S', 1, 0, 0, 0 });
+		out.insert(out.end(), reinterpret_cast<const uint8_t*>(&generators), reinterpret_cast<const uint8_t*>(&generators) + 4);
+		return out;
+	}
 	void GeneratorThread::saveGames(const std::string &path) const
-	{ // GeneratorManager.cpp:98-110.  File: "AGXS", u32 version, u32 generators, then every generator's GameGenerator::save bytes
+	{ // GeneratorManager.cpp:98-110.  File: "AGXS", u32 version, u32 generators, then every generator's GameGenerator::save bytes.  A thread that
+	  // has no games in flight — never started, or its run() ended early — writes a valid state of zero generators (the reference writes an
+	  // empty Json then), which loadGames accepts: a 0-byte file would make the next start's loadState() throw until saved_state/ is removed by hand
 		if (!isFinished())
 			throw std::logic_error("GeneratorThread::saveGames() : cannot save while the generator is running");
 		std::ofstream out(path, std::ofstream::out | std::ofstream::binary);
 		if (!out.good())
 			throw std::runtime_error("GeneratorThread::saveGames() : cannot open '" + path + "'");
-		out.write(reinterpret_cast<const char*>(saved_games.data()), static_cast<std::streamsize>(saved_games.size()));
+		const std::vector<uint8_t> empty = saved_games_header(0);
+		const std::vector<uint8_t> &bytes = saved_games.empty() ? empty : saved_games;
+		out.write(reinterpret_cast<const char*>(bytes.data()), static_cast<std::streamsize>(bytes.size()));
 	}
 	void GeneratorThread::loadGames(const std::string &path)
 	{ // GeneratorManager.cpp:111-122; the games continue when the thread is started next (run() hands them to its generators)
@@ -1895,18 +1907,26 @@ namespace ag
 		// The slices' streams run their queues independently, so left alone every slice starts its first search launch at the same moment and
 		// the slices stay in step: all their network launches at once — the power-limited case the slicing exists to avoid.  The odd slices
 		// therefore begin when slice 0's first search launch is over (an event on its stream): two network launches at a time, not all.
-		void *first_search_done = nullptr;
+		struct EventGuard
+		{ // (destroyed on every way out of run(), a stage that throws included: the exception ends the process, GeneratorThread::start)
+				void *event = nullptr;
+				~EventGuard()
+				{
+					if (event != nullptr)
+						agx_event_destroy(event);
+				}
+		} first_search_done;
 		while (is_running.load() and not manager.hasEnoughGames())
 		{
 			for (size_t i = 0; i < generators.size(); i++)
 			{
-				if (iterations == 0 && i % 2 == 1 && first_search_done != nullptr)
-					check(agx_stream_wait_event(streams[i], first_search_done));
+				if (iterations == 0 && i % 2 == 1 && first_search_done.event != nullptr)
+					check(agx_stream_wait_event(streams[i], first_search_done.event));
 				const GameGenerator::Status status = generators[i]->generate();
 				if (iterations == 0 && i == 0 && generators.size() > 1)
 				{
-					check(agx_event_create(&first_search_done));
-					check(agx_event_record(first_search_done, streams[0]));
+					check(agx_event_create(&first_search_done.event));
+					check(agx_event_record(first_search_done.event, streams[0]));
 				}
 				if (nn_evaluator.isQueueFull() or status == GameGenerator::TASKS_NOT_READY)
 				{
@@ -1929,19 +1949,61 @@ namespace ag
 		}
 		nn_evaluator.asyncEvaluateGraphJoin();
 		check(agx_device_synchronize());
-		if (first_search_done != nullptr)
-			check(agx_event_destroy(first_search_done));
 		collectGames();
-		{ // what saveGames will write: the games still in flight, slice by slice (their samples leave the manager's buffer with them)
-			saved_games.assign({ 'A', 'G', 'X', 'S', 1, 0, 0, 0 });
-			const uint32_t count = static_cast<uint32_t>(generators.size());
-			saved_games.insert(saved_games.end(), reinterpret_cast<const uint8_t*>(&count), reinterpret_cast<const uint8_t*>(&count) + 4);
-			for (size_t i = 0; i < generators.size(); i++)
-				generators[i]->save(saved_games);
-			agx_game_buffer_forget_engine(manager.getGameBuffer().handle(), pool->handle());
-		}
+		park_games_in_flight();
 		nn_evaluator.unloadGraph();
 		teardown();
+	}
+	void GeneratorThread::park_games_in_flight()
+	{ // what saveGames will write: the games still in flight, slice by slice (their samples leave the manager's buffer with them)
+		saved_games = saved_games_header(static_cast<uint32_t>(generators.size()));
+		for (size_t i = 0; i < generators.size(); i++)
+			generators[i]->save(saved_games);
+		agx_game_buffer_forget_engine(manager.getGameBuffer().handle(), pool->handle());
+	}
+
+	/* ------------------------------------------------ signals (utils/os_utils.cpp:20-205) ------------------------------------------------ */
+	namespace
+	{
+		volatile std::sig_atomic_t captured_signals[6] = { 0, 0, 0, 0, 0, 0 };
+		int signal_number(SignalType type) noexcept
+		{
+			switch (type)
+			{
+				case SignalType::INT: return SIGINT;
+				case SignalType::ILL: return SIGILL;
+				case SignalType::ABRT: return SIGABRT;
+				case SignalType::FPE: return SIGFPE;
+				case SignalType::SEGV: return SIGSEGV;
+				default: return SIGTERM;
+			}
+		}
+		template<int K>
+		void capture(int)
+		{
+			captured_signals[K] = 1;
+		}
+	}
+	void setupSignalHandler(SignalType type, SignalHandlerMode mode)
+	{
+		typedef void (*Handler)(int);
+		static const Handler custom[6] = { capture<0>, capture<1>, capture<2>, capture<3>, capture<4>, capture<5> };
+		switch (mode)
+		{
+			case SignalHandlerMode::DEFAULT_HANDLER:
+				std::signal(signal_number(type), SIG_DFL);
+				break;
+			case SignalHandlerMode::IGNORE_SIGNAL:
+				std::signal(signal_number(type), SIG_IGN);
+				break;
+			case SignalHandlerMode::CUSTOM_HANDLER:
+				std::signal(signal_number(type), custom[static_cast<int>(type)]);
+				break;
+		}
+	}
+	bool hasCapturedSignal(SignalType type) noexcept
+	{
+		return captured_signals[static_cast<int>(type)] != 0;
 	}
 
 	/* ------------------------------------------------ GeneratorManager ------------------------------------------------ */
@@ -1982,8 +2044,9 @@ namespace ag
 		return game_buffer.numberOfGames() >= games_to_generate;
 	}
 	void GeneratorManager::generate(const NetworkLoader &loader, int numberOfGames)
-	{ // GeneratorManager.cpp:182-218: start every device's thread, wait until all of them have seen hasEnoughGames() (SIGINT handling stays with
-	  // the caller; the polling interval is 20 ms instead of 1 s — a pool finishes games by the hundred per second)
+	{ // GeneratorManager.cpp:182-218: start every device's thread, wait until all of them have seen hasEnoughGames(); the statistics every 60 s
+	  // (and once at the end of a shorter call); a captured SIGINT stops the threads and returns, so that the caller gets to saveState
+	  // (TrainingManager.cpp:202-209).  The polling interval is 20 ms instead of 1 s — a pool finishes games by the hundred per second.
 		games_to_generate = numberOfGames;
 		network_loader = loader;
 		for (auto &thread : generators)
@@ -1995,8 +2058,28 @@ namespace ag
 		{
 			return std::all_of(generators.begin(), generators.end(), [](const std::unique_ptr<GeneratorThread> &t) { return t->isFinished(); });
 		};
+		const auto begun = std::chrono::steady_clock::now();
+		long long minutes_reported = 0;
 		while (!all_finished())
+		{
 			std::this_thread::sleep_for(std::chrono::milliseconds(20));
+			const long long minutes = std::chrono::duration_cast<std::chrono::seconds>(std::chrono::steady_clock::now() - begun).count() / stats_period_seconds;
+			if (minutes > minutes_reported)
+			{
+				minutes_reported = minutes;
+				printStats();
+			}
+			if (hasCapturedSignal(SignalType::INT))
+			{
+				std::cout << "Caught interruption signal" << std::endl;
+				for (auto &thread : generators)
+					thread->stop(); // (joins: the thread parks its games in flight on the way out, GeneratorThread::run)
+				std::cout << "Generators stopped" << std::endl;
+				return;
+			}
+		}
+		if (minutes_reported == 0)
+			printStats();
 	}
 	void GeneratorManager::printStats()
 	{ // GeneratorManager.cpp:219-240: progress, the buffer's summary, then the per-thread statistics averaged over the threads

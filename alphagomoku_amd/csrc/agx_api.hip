@@ -123,6 +123,20 @@ int agx_timer_elapsed_ms(AgxTimer *t, float *ms)
 	AGX_HIP_CHECK(hipEventElapsedTime(ms, t->start, t->stop));
 	return AGX_OK;
 }
+int agx_timer_poll_ms(AgxTimer *t, float *ms, int *ready)
+{
+	AGX_REQUIRE(t != nullptr && ms != nullptr && ready != nullptr, AGX_ERR_INVALID, "agx_timer_poll_ms: null argument");
+	const hipError_t st = hipEventQuery(t->stop);
+	if (st == hipErrorNotReady)
+	{
+		*ready = 0;
+		return AGX_OK;
+	}
+	AGX_HIP_CHECK(st);
+	AGX_HIP_CHECK(hipEventElapsedTime(ms, t->start, t->stop));
+	*ready = 1;
+	return AGX_OK;
+}
 int agx_timer_destroy(AgxTimer *t)
 {
 	if (t == nullptr)

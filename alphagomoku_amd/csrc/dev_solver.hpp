@@ -68,6 +68,21 @@ namespace agx
 			AGX_WAVE_REDUCE(hi, AGX_OP_XOR);
 			return static_cast<u64>(static_cast<uint32_t>(__builtin_amdgcn_readlane(lo, 63))) | (static_cast<u64>(static_cast<uint32_t>(__builtin_amdgcn_readlane(hi, 63))) << 32); // readlane yields int: no sign extension
 		}
+		/* how many of the lanes BELOW this one are set in a ballot: v_mbcnt_lo / _hi, two instructions and no per-lane mask constant (the mask
+		 * ~0 >> (64 - lane) is a 64-bit lane-derived value that hipcc hoists to the top of the kernel and, at 168 registers, reloads from scratch
+		 * at every inlined use) */
+#ifndef AGX_MBCNT
+#define AGX_MBCNT 1
+#endif
+		__device__ __forceinline__ int lanes_below(u64 ballot, int lane)
+		{
+#if AGX_MBCNT
+			(void) lane;
+			return static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(ballot >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(ballot), 0u)));
+#else
+			return __popcll((lane == 0) ? 0ull : (ballot & (~0ull >> (64 - lane))));
+#endif
+		}
 		/* inclusive prefix sum over lanes 0..31 (the rows of a board): 16-lane scans, then row 0's total into row 1 */
 		__device__ __forceinline__ uint32_t wave_scan32_add(uint32_t v)
 		{
@@ -164,6 +179,9 @@ namespace agx
 #define AGX_LUT_LDS 0 /* 1: a private 4 KB copy of the packed ThreatTable in every solver wave's LDS (-1.4 % solver time at one wave per SIMD); 0: read
                          through the vector L1 / L2 — 4 KB less LDS per wave buys a third wave per SIMD, which hides far more than that latency */
 #endif
+#ifndef AGX_PLACE_OPAQUE_LANE
+#define AGX_PLACE_OPAQUE_LANE 0 /* 1: solver_update_around / pattern_prefetch recompute their lane-derived values instead of taking hoisted copies out of scratch */
+#endif
 		constexpr int NODE_TIME_OVER = 0x40000000; // set in the node counter when a time-limited solve runs out of time: every "nodes left" test then fails
 		constexpr int NODE_COUNT_MASK = NODE_TIME_OVER - 1;
 		constexpr int LDS_FRAMES = 42;
@@ -234,8 +252,10 @@ namespace agx
 				int stack_max, error, pending_value, cmd_move;
 				u64 time_deadline;       // time-limited solves (E.solve_time_ticks != 0): the wall-clock tick at which this task's share of the time is over
 				uint16_t *spill_lists;   // [2][10][hw] tails of the threat lists (HBM, per game)
-				Frame *spill_frames;     // [MAX_FRAMES] frames beyond LDS_FRAMES (HBM, per game)
+				// solver_place reads the next three together (one 16-byte access)
+				alignas(16) u64 *snap;   // [hw + 2][64] undo snapshots of this solve's area (HBM): what addMove overwrote, one level per stone on the board
 				int sign_to_move, depth;
+				Frame *spill_frames;     // [MAX_FRAMES] frames beyond LDS_FRAMES (HBM, per game)
 				int cmd, result_score;
 		};
 		typedef SolverSharedT<MAXN> SolverShared; // any board size
@@ -413,7 +433,6 @@ namespace agx
 					sh.threat[cell][1] = static_cast<uint8_t>(t1);
 				}
 				// ordered (row-major) append to the threat lists
-				const u64 lower = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 				for (int t = 1; t < 10; t++)
 				{
 					const u64 m0 = __ballot(t0 == t);
@@ -422,8 +441,8 @@ namespace agx
 						const int cnt = sh.count[0][t];
 						if (t0 == t && t != 1)
 						{
-							list_set(sh, 0, t, cnt + __popcll(m0 & lower), cell);
-							sh.pos[0][cell] = static_cast<uint16_t>(cnt + __popcll(m0 & lower));
+							list_set(sh, 0, t, cnt + lanes_below(m0, lane), cell);
+							sh.pos[0][cell] = static_cast<uint16_t>(cnt + lanes_below(m0, lane));
 						}
 						wave_sync();
 						if (lane == 0)
@@ -436,8 +455,8 @@ namespace agx
 						const int cnt = sh.count[1][t];
 						if (t1 == t && t != 1)
 						{
-							list_set(sh, 1, t, cnt + __popcll(m1 & lower), cell);
-							sh.pos[1][cell] = static_cast<uint16_t>(cnt + __popcll(m1 & lower));
+							list_set(sh, 1, t, cnt + lanes_below(m1, lane), cell);
+							sh.pos[1][cell] = static_cast<uint16_t>(cnt + lanes_below(m1, lane));
 						}
 						wave_sync();
 						if (lane == 0)
@@ -466,6 +485,9 @@ namespace agx
 		__device__ __forceinline__ uint8_t pattern_prefetch(const SH &sh, const EngineDev &E, int n, uint32_t mv, bool add, int lane)
 		{ // branch-free on purpose: ONE load instruction for the whole wave (idle lanes read entry 0), so that nothing has to wait for
 		  // it before solver_update_around consumes it
+#if AGX_PLACE_OPAQUE_LANE
+			asm volatile("" : "+v"(lane)); // (as in solver_update_around: no lane-derived value of this function comes out of scratch)
+#endif
 			const int s = mv & 3, r = (mv >> 2) & 127, c = (mv >> 9) & 127;
 			const bool around = lane < 40;
 			const int ki = lane >> 2, d = around ? (lane & 3) : ((lane - 40) & 3);
@@ -485,18 +507,74 @@ namespace agx
 		 * directions in the order k = -5..5 (k != 0), direction 0..3 — one lane per (k, direction); lanes 40-43 re-classify the four
 		 * directions of the centre when a stone is removed.
 		 * The threat lists must end up in the reference's order (push-back add, swap-with-last remove, applied cell by cell): see the
-		 * list-edit steps below. */
+		 * list-edit steps below.
+		 *
+		 * Undo by snapshot (AGX_SNAPSHOT_UNDO, round 5).  undoMove re-derives what addMove overwrote: the pattern types of the <= 40 cells around
+		 * the stone and of the centre, and from them the threat types — two dependent table round trips per cell.  Stones come off in the reverse
+		 * order they went on (alpha-beta recursion, renju foul probes), and between a stone's add and its undo every cell's pattern / threat
+		 * TYPES return to what they were right after the add (only the lists' order does not), so the add parks what it overwrites — per lane one
+		 * 64-bit word: the cell's eight pattern types (4 bits used per byte) with both old threat types and a valid bit in the free nibbles; lane
+		 * 40 the centre's — in a per-solve HBM area indexed by the number of stones on the board, and the undo gets its `new` values from one
+		 * coalesced 512-byte read (requested by the frame machine when it decides to return) instead of 40 pattern-table + 80 threat-table
+		 * gathers.  The ordered list edits are unchanged: their order is observable. */
+#ifndef AGX_SNAPSHOT_UNDO
+#define AGX_SNAPSHOT_UNDO 1
+#endif
+#ifndef AGX_SNAPSHOT_PREFETCH
+#define AGX_SNAPSHOT_PREFETCH 1 /* the snapshot word is requested by the frame machine when a node returns (0: by solver_place itself) */
+#endif
 		template<class SH>
-		__device__ __forceinline__ void solver_update_around(SH &sh, const EngineDev &E, int r, int c, bool added, int lane, bool prefetched = false,
-				uint8_t pf_e = 0)
-		{ // prefetched: pf_e holds this lane's pattern_prefetch() result for exactly this stone
+		__device__ __forceinline__ void solver_update_around(SH &sh, const EngineDev &E, int r, int c, bool added, int lane, bool prefetched, uint8_t pf_e,
+				u64 *snap_slot, u64 snap_word)
+		{ // prefetched: pf_e holds this lane's pattern_prefetch() result for exactly this stone; snap_slot: this lane's word of the stone's snapshot
+		  // level (written when a stone is added); snap_word: that word as the add wrote it (when a stone is removed)
+#if AGX_PLACE_OPAQUE_LANE
+			// What a lane owns here (which neighbour, which direction, its steps) is a function of the lane index alone, so hipcc computes all of it
+			// once at the top of the kernel and — at 168 registers — parks it in scratch: every call then began with two scratch reloads and an
+			// s_waitcnt vmcnt(0), which also waits for the transposition-table bucket that was requested to travel DURING this call (an HBM miss).
+			// With the lane index opaque the handful of values are recomputed here (~10 VALU instructions) and nothing waits.
+			asm volatile("" : "+v"(lane));
+#endif
 			const int n = E.n;
 			const int center = r * n + c;
 			AGX_PROF_BEGIN();
 			int cnt = (lane < 20) ? sh.count[lane / 10][lane % 10] : 0; // lane 10 s + t holds the size of list (s, t)
 
 			int cell = -1, old0 = 0, old1 = 0, new0 = 0, new1 = 0;
+			int c0 = 0, c1 = 0; // the centre's threat types: its old ones leave the lists (stone added), its new ones join them (stone removed)
+#if AGX_SNAPSHOT_UNDO
+			if (!added)
+			{ // ---- undo: everything the add overwrote comes out of the snapshot ----
+				const uint32_t lo = static_cast<uint32_t>(snap_word), hi = static_cast<uint32_t>(snap_word >> 32);
+				const bool valid = ((lo >> 20) & 1u) != 0u;
+				new0 = static_cast<int>((lo >> 4) & 15u);
+				new1 = static_cast<int>((lo >> 12) & 15u);
+				const u64 types = static_cast<u64>(lo & 0x0F0F0F0Fu) | (static_cast<u64>(hi) << 32);
+				if (lane <= 40 && valid)
+				{
+					const int ki = lane >> 2, d = lane & 3;
+					const int k = (ki < 5) ? ki - 5 : ki - 4;
+					const int at = (lane == 40) ? center : (r + k * row_step(d)) * n + (c + k * col_step(d));
+					const uint32_t t01 = *reinterpret_cast<const uint16_t*>(&sh.threat[at][0]);
+					*reinterpret_cast<u64*>(&sh.ptype[at][0]) = types;
+					*reinterpret_cast<uint16_t*>(&sh.threat[at][0]) = static_cast<uint16_t>(new0 | (new1 << 8));
+					if (lane < 40)
+					{
+						cell = at;
+						old0 = t01 & 255u;
+						old1 = t01 >> 8;
+					}
+				}
+				c0 = __builtin_amdgcn_readlane(new0, 40);
+				c1 = __builtin_amdgcn_readlane(new1, 40);
+			}
+			else
+#endif
+			{
 			uint32_t centre_bits = 0; // lanes 40-43: pattern types of the centre in direction lane - 40, as 3-bit fields of the two threat indices
+#if AGX_SNAPSHOT_UNDO
+			u64 park = 0; // what this lane's cell held before the stone (valid bit 20 clear: nothing to restore)
+#endif
 			if (lane < 40)
 			{
 				const int ki = lane >> 2, d = lane & 3;
@@ -518,6 +596,9 @@ namespace agx
 						cell = at;
 						old0 = t0;
 						old1 = t1;
+#if AGX_SNAPSHOT_UNDO
+						park = static_cast<u64>(w0 | (t01 << 4 & 0xF0u) | ((t01 >> 8) << 12) | (1u << 20)) | (static_cast<u64>(w1) << 32);
+#endif
 						const uint32_t e = prefetched ? pf_e : E.t_pattern[raw]; // (the byte is widened HERE, not where it was requested)
 						w0 = (w0 & ~(255u << (8 * d))) | ((e & 15u) << (8 * d));
 						w1 = (w1 & ~(255u << (8 * d))) | ((e >> 4) << (8 * d));
@@ -538,12 +619,17 @@ namespace agx
 				sh.ptype[center][4 + d] = static_cast<uint8_t>(e >> 4);
 				centre_bits = ((e & 15u) << (3 * d)) | ((e >> 4) << (16 + 3 * d));
 			}
-			// the centre: its old threats leave the lists (stone added) or its new ones join them (stone removed)
-			int c0 = 0, c1 = 0;
 			if (added)
 			{
 				c0 = sh.threat[center][0];
 				c1 = sh.threat[center][1];
+#if AGX_SNAPSHOT_UNDO
+				{ // lane 40 parks the centre; every lane stores its word (one coalesced 512-byte store, nothing waits for it)
+					const u64 cw = *reinterpret_cast<const u64*>(&sh.ptype[center][0]);
+					const u64 centre_park = (cw & 0xFFFFFFFF0F0F0F0Full) | static_cast<u64>((static_cast<uint32_t>(c0) << 4) | (static_cast<uint32_t>(c1) << 12) | (1u << 20));
+					*snap_slot = (lane == 40) ? centre_park : park;
+				}
+#endif
 				if (lane < 8)
 					sh.ptype[center][lane] = 0;
 				if (lane < 2)
@@ -560,6 +646,7 @@ namespace agx
 					sh.threat[center][0] = static_cast<uint8_t>(c0);
 					sh.threat[center][1] = static_cast<uint8_t>(c1);
 				}
+			}
 			}
 			u64 changed0 = __ballot(cell >= 0 && old0 != new0);
 			u64 changed1 = __ballot(cell >= 0 && old1 != new1);
@@ -631,12 +718,29 @@ namespace agx
 			wave_sync();
 			AGX_PROF_MARK(sh, 12);
 		}
+		/* this lane's word of snapshot level `level` (wave-uniform base and level: a scalar base + the lane's offset) */
+		template<class SH>
+		__device__ __forceinline__ u64* snap_address(u64 *base, int level, int lane)
+		{
+			const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(reinterpret_cast<uintptr_t>(base)));
+			const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(reinterpret_cast<uintptr_t>(base) >> 32));
+			u64 *uniform = reinterpret_cast<u64*>((static_cast<uintptr_t>(hi) << 32) | lo);
+			return uniform + (static_cast<size_t>(__builtin_amdgcn_readfirstlane(level)) * 64 + lane);
+		}
 		template<class SH>
 		__device__ __forceinline__ void solver_place(SH &sh, const EngineDev &E, uint32_t move, bool add, int lane, bool prefetched = false,
-				uint8_t pf_e = 0)
-		{ // PatternCalculator::addMove / undoMove (PatternCalculator.cpp:68-105)
+				uint8_t pf_e = 0, bool have_snap = false, u64 pf_snap = 0)
+		{ // PatternCalculator::addMove / undoMove (PatternCalculator.cpp:68-105); have_snap: pf_snap is snap_address(..)'s word for exactly this undo
 			const int n = E.n;
 			const int s = move & 3, r = (move >> 2) & 127, c = (move >> 9) & 127;
+			u64 *const snap_base = sh.snap;
+			const int to_move = sh.sign_to_move, stones = sh.depth;
+			u64 *snap_slot = nullptr;
+#if AGX_SNAPSHOT_UNDO
+			snap_slot = snap_address<SH>(snap_base, add ? stones : stones - 1, lane);
+			if (!add && !have_snap)
+				pf_snap = *snap_slot;
+#endif
 			if (lane < 4)
 			{
 				int index, shift;
@@ -652,9 +756,8 @@ namespace agx
 				sh.legal[r] = add ? (row_bits & ~(1u << c)) : (row_bits | (1u << c));
 			}
 			wave_sync();
-			solver_update_around(sh, E, r, c, add, lane, prefetched, pf_e);
+			solver_update_around(sh, E, r, c, add, lane, prefetched, pf_e, snap_slot, pf_snap);
 			{
-				const int to_move = sh.sign_to_move, stones = sh.depth;
 				sh.sign_to_move = 3 - to_move;
 				sh.depth = stones + (add ? 1 : -1);
 			}
@@ -1120,8 +1223,7 @@ for (int k = 0; k < 5; k++)
 						}
 						if (fresh)
 						{
-							const u64 below = (lane == 0) ? 0ull : (m & (~0ull >> (64 - lane)));
-							act_set(sh, act, f.base + f.size + __popcll(below), move_of(cell) | (score << 16));
+							act_set(sh, act, f.base + f.size + lanes_below(m, lane), move_of(cell) | (score << 16));
 							atomicOr(&sh.added[r], 1u << c);
 						}
 						f.size += n_new;
@@ -1902,7 +2004,7 @@ for (int k = 0; k < 5; k++)
 		 */
 		template<bool RENJU, class SH>
 		__device__ __forceinline__ int solver_run(SH &sh, const EngineDev &E, uint32_t *act, u64 *tt, int generation, int lane, u64 &pf_word,
-				uint8_t &pf_pattern, int &pf_pattern_tag)
+				uint8_t &pf_pattern, int &pf_pattern_tag, u64 &pf_snap)
 		{ // executed by ALL lanes with identical (wave-uniform) state: stores are same-address / same-value, scans are lane-parallel.
 		  // The scalars of the machine and the current frame are held in registers and written back to LDS only when the machine yields.
 			AGX_PROF_BEGIN();
@@ -2201,8 +2303,13 @@ for (int k = 0; k < 5; k++)
 					if (level > 0)
 					{ // the stone of the parent's move comes off next: its pattern entries travel while the table is updated
 						const uint32_t umv = frame_get(sh, level - 1).move;
+#if AGX_SNAPSHOT_UNDO && AGX_SNAPSHOT_PREFETCH
+						pf_snap = *snap_address<SH>(sh.snap, sh.depth - 1, lane); // what this node's stone overwrote (solver_update_around)
+						pf_pattern_tag = static_cast<int>(umv);
+#elif !AGX_SNAPSHOT_UNDO
 						pf_pattern = pattern_prefetch(sh, E, n, umv, false, lane);
 						pf_pattern_tag = static_cast<int>(umv);
+#endif
 					}
 					int bound;
 					if (best <= f.original_alpha)

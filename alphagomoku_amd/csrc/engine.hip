@@ -246,6 +246,7 @@ namespace
 		{ // HBM tails of the LDS-resident threat lists and frames (dev_solver.hpp: list_get / frame_get)
 			sh.spill_lists = E.list_spill + static_cast<size_t>(area) * 20 * MAXHW; // (stride of list_get / list_set: SolverSharedT::HW <= MAXHW whatever the kernel instantiation)
 			sh.spill_frames = reinterpret_cast<Frame*>(E.frame_spill) + static_cast<size_t>(area) * MAX_FRAMES;
+			sh.snap = E.snap_spill + static_cast<size_t>(area) * (E.hw + 2) * 64; // undo snapshots, one level per stone on the board (dev_solver.hpp)
 			sh.ov_on = (overlay != nullptr) ? 1 : 0;
 			sh.ov_data = overlay;
 			sh.ov_count = 0;
@@ -307,6 +308,7 @@ namespace
 		u64 pf_word = 0; // lanes 0-7: the transposition-table bucket prefetched for the frame about to be entered
 		uint8_t pf_pattern = 0; // pattern-table entries prefetched for the stone about to be placed / removed (dev_solver.hpp:pattern_prefetch)
 		int pf_pattern_tag = -1; // move | add << 16 they belong to
+		u64 pf_snap = 0; // an undo's snapshot word, requested by the frame machine when the node returns (tag: the move, add bit clear)
 		for (int depth = 0; depth <= E.tss_max_depth; depth += 4)
 		{
 			int stack_before = 0;
@@ -329,7 +331,7 @@ namespace
 				const unsigned long long r0 = wall_clock64();
 #endif
 				pf_pattern_tag = -1;
-				const int cmd_now = solver_run<RENJU>(sh, E, act, tt, generation, lane, pf_word, pf_pattern, pf_pattern_tag);
+				const int cmd_now = solver_run<RENJU>(sh, E, act, tt, generation, lane, pf_word, pf_pattern, pf_pattern_tag, pf_snap);
 				if (lane == 0)
 					sh.cmd = cmd_now;
 				wave_sync();
@@ -341,7 +343,7 @@ namespace
 				if (cmd == CMD_ADD)
 					solver_place(sh, E, static_cast<uint32_t>(sh.cmd_move), true, lane, pf_pattern_tag == (sh.cmd_move | 0x10000), pf_pattern);
 				else if (cmd == CMD_UNDO)
-					solver_place(sh, E, static_cast<uint32_t>(sh.cmd_move), false, lane, pf_pattern_tag == sh.cmd_move, pf_pattern);
+					solver_place(sh, E, static_cast<uint32_t>(sh.cmd_move), false, lane, pf_pattern_tag == sh.cmd_move, pf_pattern, pf_pattern_tag == sh.cmd_move, pf_snap);
 				else
 					break;
 #ifdef AGX_SOLVER_PROFILE
@@ -536,7 +538,7 @@ namespace
 				if (E.solve_time_ticks != 0ull && lane == 0)
 				{ // ab_search.setTimeLimit((endTime - getTime()) / (getBatchSize() - i)) (Search.cpp:175-180): this task's share of what is left
 					const unsigned long long now = wall_clock64(), end = t_launch + E.solve_time_ticks;
-					sh.time_deadline = now + ((end > now) ? (end - now) / static_cast<unsigned long long>(max(1, n_tasks - k)) : 0ull);
+					sh.time_deadline = now + ((end > now) ? (end - now) / static_cast<unsigned long long>(max(1, E.batch_limit - k)) : 0ull); // (the buffer's SIZE, not its fill: a partly filled batch gets the reference's smaller shares)
 				}
 				if (threshold != 0x7FFFFFFF && k > gs.solve_pos)
 				{ // at least one task per launch is always solved, so every game makes progress
@@ -754,10 +756,14 @@ namespace
 #define SPEC_T(var) unsigned long long var = wall_clock64()
 #define SPEC_ADD(k, v) do { if (lane == 0) atomicAdd(&E.spec_prof[k], static_cast<unsigned long long>(v)); } while (0)
 #define SPEC_MAX(k, v) do { if (lane == 0) atomicMax(&E.spec_prof[k], static_cast<unsigned long long>(v)); } while (0)
+/* per wave of the LAST launch: launch-relative ticks of its select phase's end and of its exit, leaves it solved, ticks it waited for items */
+#define SPEC_WAVE_EXIT() do { if (lane == 0) { unsigned long long *w_ = E.spec_trace + 4 * (static_cast<size_t>(E.n_games) + E.spec_group * E.spec_waves + blockIdx.x); \
+		w_[0] = t_selected; w_[1] = wall_clock64(); w_[2] = wave_solves; w_[3] = wave_waited; } } while (0)
 #else
 #define SPEC_T(var) do { } while (0)
 #define SPEC_ADD(k, v) do { } while (0)
 #define SPEC_MAX(k, v) do { } while (0)
+#define SPEC_WAVE_EXIT() do { } while (0)
 #endif
 #ifndef AGX_SPEC_WAVES
 #define AGX_SPEC_WAVES 3 /* waves per SIMD the register allocation of k_search_spec leaves room for (LDS: 12 waves per compute unit at 15x15) */
@@ -878,6 +884,9 @@ namespace
 		SpecCommit commit;
 		commit.game = -1;
 		SPEC_T(t_commit0);
+#ifdef AGX_SPEC_PROFILE
+		unsigned long long wave_solves = 0, wave_waited = 0;
+#endif
 		while (true)
 		{
 			int g, k;
@@ -915,7 +924,10 @@ namespace
 					i = atomicAdd(c_head, 1);
 				i = __builtin_amdgcn_readfirstlane(i);
 				if (i >= item_cap)
+				{
+					SPEC_WAVE_EXIT();
 					return;
+				}
 				int v = 0;
 				if (lane == 0)
 				{ // wait for queue slot i to be filled.  The waiting waves must not disturb the ones that still select (they are the critical path):
@@ -955,9 +967,13 @@ namespace
 				v = __builtin_amdgcn_readfirstlane(v);
 				SPEC_T(t_got);
 				SPEC_ADD(2, t_got - t_pop); // waiting for an item
+#ifdef AGX_SPEC_PROFILE
+				wave_waited += t_got - t_pop;
+#endif
 				if (v < 0)
 				{
 					SPEC_MAX(7, t_got - t_begin); // the last wave's exit = the launch
+					SPEC_WAVE_EXIT();
 					return;
 				}
 				__threadfence(); // (acquire: the task as its selecting wave wrote it)
@@ -981,6 +997,9 @@ namespace
 			SPEC_T(t_solved);
 			SPEC_ADD(3, t_solved - t_s0); // speculative solves
 			SPEC_ADD(6, 1);
+#ifdef AGX_SPEC_PROFILE
+			wave_solves++;
+#endif
 			__threadfence(); // release: task results, features, overlay and its header
 			int left = 0;
 			if (lane == 0)
@@ -2606,6 +2625,7 @@ namespace
 		{
 			sh.spill_lists = E.list_spill + static_cast<size_t>(g) * 20 * MAXHW;
 			sh.spill_frames = reinterpret_cast<Frame*>(E.frame_spill) + static_cast<size_t>(g) * MAX_FRAMES;
+			sh.snap = E.snap_spill + static_cast<size_t>(g) * (E.hw + 2) * 64;
 		}
 		solver_load_threat_table(sh, E, lane);
 		solver_set_board(sh, E, boards + static_cast<size_t>(g) * E.hw, signs[g], lane);
@@ -2677,6 +2697,7 @@ struct AgxEngine
 		AgxEngineConfig cfg;
 		EngineDev dev;
 		std::vector<void*> allocations;
+		unsigned long long device_bytes = 0; // sum of the allocations' sizes (agx_engine_device_bytes)
 		std::vector<GameState> idle_games; // the pool before agx_engine_begin: every game idle, in its class-0 arena bundle
 		std::vector<unsigned long long> debug_solve_nodes; // solver nodes per position of the last agx_debug_solve
 		ArenaHeap idle_heap;
@@ -2751,6 +2772,7 @@ namespace
 			return AGX_ERR_HIP;
 		}
 		e->allocations.push_back(p);
+		e->device_bytes += std::max<size_t>(count * sizeof(T), 16);
 		*ptr = static_cast<T*>(p);
 		return AGX_OK;
 	}
@@ -2940,13 +2962,14 @@ int agx_engine_create(const AgxEngineConfig *cfg, AgxEngine **out)
 	// per area 20 lists x MAXHW entries: list_get / list_set stride by the kernel's compile-time board (SolverSharedT::HW, = MAXHW in the any-size kernels)
 	AGX_TRY(dev_alloc(e, &d.list_spill, areas * 20 * static_cast<size_t>(MAXHW)));
 	AGX_TRY(dev_alloc(e, &d.frame_spill, areas * MAX_FRAMES));
+	AGX_TRY(dev_alloc(e, &d.snap_spill, areas * static_cast<size_t>(d.hw + 2) * 64)); // undo snapshots: 512 bytes per stone on the board and area
 	d.spec_group = 0;
 	d.spec_waves = e->spec_waves;
 	AGX_TRY(dev_alloc(e, &d.spec_watchdog, 16));
 	(void) hipMemset(d.spec_watchdog, 0, 16 * sizeof(int));
 	AGX_TRY(dev_alloc(e, &d.spec_prof, 16));
-	AGX_TRY(dev_alloc(e, &d.spec_trace, 4 * G));
-	(void) hipMemset(d.spec_trace, 0, 4 * G * sizeof(unsigned long long));
+	AGX_TRY(dev_alloc(e, &d.spec_trace, 4 * (G + static_cast<size_t>(std::max(e->spec_waves, 16))))); // per game, then per wave (profile builds)
+	(void) hipMemset(d.spec_trace, 0, 4 * (G + static_cast<size_t>(std::max(e->spec_waves, 16))) * sizeof(unsigned long long));
 	(void) hipMemset(d.spec_prof, 0, 16 * sizeof(unsigned long long));
 	AGX_TRY(dev_alloc(e, &d.spec_items, e->speculative ? G * d.batch + 16 * static_cast<size_t>(SPEC_QUEUE_SLACK) : 1));
 	AGX_TRY(dev_alloc(e, &d.spec_left, e->speculative ? G : 1));
@@ -3696,6 +3719,12 @@ int agx_engine_set_max_simulations(AgxEngine *e, int max_simulations)
 	e->cfg.max_simulations = max_simulations;
 	return AGX_OK;
 }
+int agx_engine_device_bytes(AgxEngine *e, unsigned long long *bytes)
+{
+	AGX_REQUIRE(e != nullptr && bytes != nullptr, AGX_ERR_INVALID, "agx_engine_device_bytes: null argument");
+	*bytes = e->device_bytes;
+	return AGX_OK;
+}
 int agx_engine_stats(AgxEngine *e, AgxEngineStats *out)
 {
 	AGX_REQUIRE(e != nullptr && out != nullptr, AGX_ERR_INVALID, "agx_engine_stats: null argument");
@@ -3743,6 +3772,16 @@ int agx_engine_stats(AgxEngine *e, AgxEngineStats *out)
 		{
 			for (size_t g = 0; g < games.size(); g++)
 				fprintf(f, "%llu %llu %llu %llu\n", tr[4 * g], tr[4 * g + 1], tr[4 * g + 2], tr[4 * g + 3]);
+			fclose(f);
+		}
+		// per wave of the last launches (one per group): select phase over, exit, leaves solved, ticks waited for items
+		std::vector<unsigned long long> wv(4 * static_cast<size_t>(std::max(e->spec_waves, 16)));
+		AGX_HIP_CHECK(hipMemcpy(wv.data(), e->dev.spec_trace + 4 * games.size(), wv.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+		f = fopen((std::string(getenv("AGX_SPEC_TRACE")) + ".waves").c_str(), "w");
+		if (f != nullptr)
+		{
+			for (size_t w = 0; 4 * w < wv.size(); w++)
+				fprintf(f, "%llu %llu %llu %llu\n", wv[4 * w], wv[4 * w + 1], wv[4 * w + 2], wv[4 * w + 3]);
 			fclose(f);
 		}
 	}
@@ -4340,6 +4379,7 @@ int agx_debug_pattern_state(AgxEngine *e, const uint8_t *h_boards, const int *h_
 		uint8_t *h_threats, int16_t *h_lists, int lists_stride)
 {
 	AGX_REQUIRE(e != nullptr, AGX_ERR_INVALID, "agx_debug_pattern_state: null engine");
+	AGX_REQUIRE(count > 0 && count <= e->dev.n_games, AGX_ERR_INVALID, "agx_debug_pattern_state: count must be in [1, n_games] (a position uses its game's spill areas)");
 	const EngineDev &d = e->dev;
 	uint8_t *d_boards = nullptr, *d_pt = nullptr, *d_th = nullptr;
 	int *d_signs = nullptr;

@@ -240,6 +240,7 @@ namespace agx
 			uint32_t *act;  // [game][act_cap] alpha-beta action stack: move | score << 16
 			uint16_t *list_spill;       // [game][2][10][hw] tails of the solver's threat lists beyond their LDS capacity (dev_solver.hpp)
 			FrameBytes *frame_spill;    // [game][MAX_FRAMES] alpha-beta frames (dev::Frame, 32 bytes) beyond the LDS-resident ones
+			uint64_t *snap_spill;       // [game][hw + 2][64] undo snapshots of the solver's pattern update (dev_solver.hpp: solver_update_around)
 			uint64_t *tt;   // [game][buckets][4][2]
 			// read-only tables
 			const uint8_t *t_pattern;

@@ -312,24 +312,28 @@ int agx_game_buffer_load(AgxGameBuffer *b, const char *path)
 	for (size_t i = 0; i < offsets.size(); i++)
 	{
 		const size_t begin = offsets[i], end = (i + 1 < offsets.size()) ? offsets[i + 1] : blob_size;
-		AGX_REQUIRE(begin + 20 <= end && end <= blob_size, AGX_ERR_INVALID, "agx_game_buffer_load: game %zu lies outside the file", i);
+		// (subtraction forms: an offset near SIZE_MAX must not wrap the test; offsets must ascend)
+		AGX_REQUIRE(begin <= blob_size && end <= blob_size && begin <= end && end - begin >= 20, AGX_ERR_INVALID, "agx_game_buffer_load: game %zu lies outside the file", i);
 		const uint8_t *g = blob + begin;
 		uint32_t n_samples = 0, n_moves = 0;
 		std::memcpy(&n_samples, g, 4);
 		size_t at = 4;
 		for (uint32_t k = 0; k < n_samples; k++)
 		{
-			AGX_REQUIRE(begin + at + agx::v201::HEADER_BYTES <= end, AGX_ERR_INVALID, "agx_game_buffer_load: game %zu is truncated", i);
+			AGX_REQUIRE(at <= end - begin && end - begin - at >= static_cast<size_t>(agx::v201::HEADER_BYTES), AGX_ERR_INVALID, "agx_game_buffer_load: game %zu is truncated", i);
 			uint32_t count = 0;
 			std::memcpy(&count, g + at + 12, 4);
 			at += agx::v201::HEADER_BYTES + static_cast<size_t>(agx::v201::ENTRY_BYTES) * count;
 		}
-		AGX_REQUIRE(begin + at + 4 <= end, AGX_ERR_INVALID, "agx_game_buffer_load: game %zu is truncated", i);
+		AGX_REQUIRE(at <= end - begin && end - begin - at >= 4, AGX_ERR_INVALID, "agx_game_buffer_load: game %zu is truncated", i);
 		std::memcpy(&n_moves, g + at, 4);
 		at += 4 + 2 * static_cast<size_t>(n_moves);
-		AGX_REQUIRE(begin + at + 12 == end, AGX_ERR_INVALID, "agx_game_buffer_load: game %zu has %zu bytes where its layout needs %zu", i, end - begin, at + 12);
-		int outcome = 0;
+		AGX_REQUIRE(at <= end - begin && end - begin - at == 12, AGX_ERR_INVALID, "agx_game_buffer_load: game %zu has %zu bytes where its layout needs %zu", i, end - begin, at + 12);
+		int outcome = 0, g_rows = 0, g_cols = 0;
 		std::memcpy(&outcome, g + at, 4);
+		std::memcpy(&g_rows, g + at + 4, 4);
+		std::memcpy(&g_cols, g + at + 8, 4);
+		AGX_REQUIRE(g_rows == b->rows && g_cols == b->cols, AGX_ERR_INVALID, "agx_game_buffer_load: game %zu is %dx%d, the buffer %dx%d", i, g_rows, g_cols, b->rows, b->cols);
 		games.emplace_back(g, g + (end - begin));
 		outcomes.push_back(outcome);
 		lengths.push_back(static_cast<int>(n_moves));

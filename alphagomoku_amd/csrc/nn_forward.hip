@@ -1355,7 +1355,14 @@ namespace
 	}
 
 	template<int F, int ROWS, int COLS, bool INPLACE, bool QHEAD, bool RAW = false>
-	__global__ __launch_bounds__(512, 2) void nn_tower_kernel(NetParams p, const uint32_t *__restrict__ features, float *__restrict__ policy,
+#ifndef AGX_NN_WAVES_PER_EU
+#define AGX_NN_WAVES_PER_EU 2 /* register budget of the tower: 2 = 256 registers per wave (its 8 waves fill a compute unit's register file); 3 = 168, which
+                                 leaves room for one 168-register solver wave per SIMD next to a tower workgroup (the co-resident pairing experiment:
+                                 profiles/r05_coresident_ab.txt, together with AGX_NN_SINGLE_PLANE=1 for the LDS) */
+#endif
+	// (a waves-per-EU request above what the kernel's LDS allows is ignored by hipcc; declaring a larger maximum block — 12 waves = 3 per SIMD — is what
+	//  caps the allocation at 168 registers.  The kernel is always launched with 512 threads.)
+	__global__ __launch_bounds__(256 * AGX_NN_WAVES_PER_EU) void nn_tower_kernel(NetParams p, const uint32_t *__restrict__ features, float *__restrict__ policy,
 			float *__restrict__ value)
 	{
 		typedef Geometry<F, ROWS, COLS> G;

@@ -91,17 +91,38 @@ def _kfd_gpu_pci_addresses(sysfs_root):
     return out or None
 
 
+def _id_list(var):
+    """the integer list of a *_VISIBLE_DEVICES variable: None when unset, False when it cannot be resolved here (UUID form, garbage)"""
+    spec = os.environ.get(var, "").strip()
+    if not spec:
+        return None
+    try:
+        return [int(x) for x in spec.split(",") if x.strip() != ""]
+    except ValueError:
+        return False
+
+
 def _visible_index(local_device):
-    """the runtime numbers only the VISIBLE devices: HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES = "2,3" makes device 0 the topology's GPU 2"""
-    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
-        spec = os.environ.get(var, "").strip()
-        if spec:
-            try:
-                ids = [int(x) for x in spec.split(",") if x.strip() != ""]
-            except ValueError:
-                return None   # (UUID form: not resolved here)
-            return ids[local_device] if local_device < len(ids) else None
-    return local_device
+    """The runtime numbers only the VISIBLE devices, and the filters COMPOSE: ROCR_VISIBLE_DEVICES selects from the topology's GPUs, then
+    HIP_VISIBLE_DEVICES (or CUDA_VISIBLE_DEVICES, which HIP honours as well) selects from what ROCR left — ROCR "2,3" + HIP "1" makes device 0
+    the topology's GPU 3.  None whenever a case cannot be resolved (UUID forms, both HIP_ and CUDA_ set to different lists, an index out of
+    range): the rank then stays unpinned instead of being pinned to another GPU's NUMA node."""
+    rocr, hip, cuda = _id_list("ROCR_VISIBLE_DEVICES"), _id_list("HIP_VISIBLE_DEVICES"), _id_list("CUDA_VISIBLE_DEVICES")
+    if rocr is False or hip is False or cuda is False:
+        return None
+    if hip is not None and cuda is not None and hip != cuda:
+        return None
+    inner = hip if hip is not None else cuda
+    index = local_device
+    if inner is not None:
+        if index >= len(inner):
+            return None
+        index = inner[index]
+    if rocr is not None:
+        if index < 0 or index >= len(rocr):
+            return None
+        index = rocr[index]
+    return index if index >= 0 else None
 
 
 def pin_to_gpu_numa_node(local_device, sysfs_root="/"):

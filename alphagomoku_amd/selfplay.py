@@ -67,6 +67,19 @@ def chip_slices(n_slices):
     return streams, per
 
 
+def shared_chip_slices(n_slices, sharing):
+    """n_slices streams in groups of `sharing`: the streams of a group own the SAME block of compute units (n_slices / sharing disjoint blocks),
+    so the kernels of a group's slices may be co-resident on those units — the co-resident pairing experiment (bench.py --share-cus).  Returns
+    (streams, compute units per block)."""
+    if sharing < 1 or n_slices % sharing != 0:
+        raise ValueError("%d slices cannot share compute-unit blocks %d by %d" % (n_slices, sharing, sharing))
+    cus = ctypes.c_int()
+    check(lib.agx_device_cu_count(ctypes.byref(cus)))
+    blocks = n_slices // sharing
+    per = cus.value // blocks
+    return [cu_mask_stream((k // sharing) * per, per, instance=k % sharing) for k in range(n_slices)], per
+
+
 def cu_mask_stream(first_cu, n_cus, instance=0):
     """a stream whose kernels run on compute units [first_cu, first_cu + n_cus); `instance` distinguishes several streams on one mask"""
     total = ctypes.c_int()
@@ -255,6 +268,12 @@ class GeneratorPool:
         n = (ctypes.c_longlong * 4)()
         check(lib.agx_engine_kernel_timing(self._h, 1 if enable else 0, ms, n))
         return list(ms), list(n)
+
+    def device_bytes(self):
+        """device memory the pool's engine holds (agx_engine_device_bytes)"""
+        n = ctypes.c_ulonglong()
+        check(lib.agx_engine_device_bytes(self._h, ctypes.byref(n)))
+        return int(n.value)
 
     def stats(self):
         check(lib.agx_device_synchronize())

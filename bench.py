@@ -186,6 +186,10 @@ def main():
                     help="> 0: the chip as two partitions shared by all slices — this many compute units run every slice's network launches, the rest "
                          "every slice's search launches (streams ordered by events); 0: every slice owns 1 / slices of the chip for all its stages")
     ap.add_argument("--tree-cus", type=int, default=0, help="with --network-cus: compute units set aside for the expand / advance launches")
+    ap.add_argument("--share-cus", type=int, default=1,
+                    help="the co-resident pairing experiment: this many slices share one block of compute units (e.g. --slices 8 --share-cus 2 = four "
+                         "blocks of 64 CUs with two half-slices each, whose search and network launches may overlap on the same units; needs a tower "
+                         "that leaves room: a library built with -DAGX_NN_WAVES_PER_EU=3 and AGX_NN_SINGLE_PLANE=1)")
     ap.add_argument("--stagger", type=int, default=1,
                     help="1: the slices enter the timed region a stage apart in their cycles, as a pool that has run for a while has them (the synchronisation in "
                          "front of the timed region would otherwise start all of them on the same stage); 0: all slices start with the search launch")
@@ -281,8 +285,12 @@ def main():
             events.append(ev)
     elif slices > 1:
         try:
-            streams, cus_per_slice = selfplay.chip_slices(slices)
-            total_cus = cus_per_slice * slices
+            if args.share_cus > 1:
+                streams, cus_per_slice = selfplay.shared_chip_slices(slices, args.share_cus)
+                total_cus = cus_per_slice * slices // args.share_cus
+            else:
+                streams, cus_per_slice = selfplay.chip_slices(slices)
+                total_cus = cus_per_slice * slices
             check(lib.agx_net_set_launch_width(net._net, cus_per_slice))
         except Exception as exc:   # no CU-mask support: one lock-step pool
             print("bench.py: chip slices unavailable (%s), running one pool" % exc, file=sys.stderr)
@@ -425,7 +433,8 @@ def main():
     leaks = s1["information_leaks"] - s0["information_leaks"]
     local_elapsed = elapsed
     per_rank = distributed.gather(dist, [sims, local_elapsed, distributed.rank_seed_base(rank), int(os.environ.get("AGX_FORCE_DEVICE", local_rank)),
-                                         s1["first_error"], host_cpu_seconds, -1 if numa_node is None else numa_node, pinned_cpus])
+                                         s1["first_error"], host_cpu_seconds, -1 if numa_node is None else numa_node, pinned_cpus,
+                                         pool.device_bytes(), len(threads1)])
     elapsed, (sims, evals, moves, games_done) = distributed.combine(dist, elapsed, [sims, evals, moves, games_done])
     # an engine error on ANY rank fails every rank, after the collectives (a rank that raised before them would leave the others waiting)
     failed = [(i, int(r[4])) for i, r in enumerate(per_rank) if int(r[4]) != 0]
@@ -506,7 +515,7 @@ def main():
             "nn_positions_per_sec": evals / elapsed,
             # how the pool is stepped: `count` slices of games_per_gpu / count games, each on a stream that owns cus_per_slice compute units;
             # the slices' launches overlap in time, so the per-launch durations below add up to more than ms_per_step
-            "slices": {"count": slices, "cus_per_slice": cus_per_slice, "games_per_slice": args.games // slices, "first_stage_of_a_step": phase, "host_steps_ahead": args.host_pacing if args.host_pacing > 0 else None,
+            "slices": {"count": slices, "cus_per_slice": cus_per_slice, "slices_per_cu_block": args.share_cus, "games_per_slice": args.games // slices, "first_stage_of_a_step": phase, "host_steps_ahead": args.host_pacing if args.host_pacing > 0 else None,
                        "partitions": ({"network_cus": cus_per_slice, "search_cus": total_cus - cus_per_slice - args.tree_cus, "tree_cus": args.tree_cus}
                                       if net_streams is not None else None)},
             "stage_ms_per_step": {"select_solve": ms_sel / launches, "network": ms_nn / launches, "expand_backup_advance": ms_exp / launches,
@@ -530,6 +539,10 @@ def main():
             # launch loop per GPU must stay well below one core) and where it was pinned
             "ranks": [{"rank": i, "device": int(r[3]), "simulations": int(r[0]), "seconds": r[1], "opening_seed_base": int(r[2]),
                        "host_cpu_seconds": r[5], "host_cpu_utilisation": r[5] / max(r[1], 1e-9), "numa_node": int(r[6]), "pinned_cpus": int(r[7]),
+                       # what the rank takes of its GPU's 288 GB (trees + 16 B x table entries x games of solver tables + spill areas + exchange
+                       # buffers + record pools; the network's weights are a few MB on top) and how many host threads its process runs
+                       # (the launch loop + the HIP / HSA runtime's) — one such rank per GPU; NO multi-GPU scaling curve has been measured
+                       "device_bytes_allocated": int(r[8]), "host_threads": int(r[9]),
                        **({"host_threads_cpu_seconds": host_threads} if i == 0 else {})}
                       for i, r in enumerate(per_rank)],
             "longest_kernel": {"name": longest, "share_of_kernel_time": per_kernel[longest] / gpu_ms if gpu_ms > 0 else None},

@@ -424,6 +424,10 @@ int agx_engine_solve_timed_group(AgxEngine* engine, int group, int n_groups, int
 int agx_engine_set_force_expand_root(AgxEngine* engine, int force_expand_root); /* AgxEngineConfig.force_expand_root, for the launches that follow */
 int agx_engine_buffers(AgxEngine* engine, AgxEngineBuffers* out);
 int agx_engine_stats(AgxEngine* engine, AgxEngineStats* out);
+/* Device memory this engine holds (every hipMalloc of agx_engine_create: tree heaps, the solver tables — 16 bytes x tss_table_entries per
+ * game —, task / exchange buffers, the solver's spill areas and undo snapshots, record pools).  What one rank of a multi-GPU job needs of its
+ * GPU's HBM next to the network's weights (GeneratorManager.cpp:146-152: one generator thread, i.e. one such pool, per device). */
+int agx_engine_device_bytes(AgxEngine* engine, unsigned long long* bytes);
 /* Per-kernel timing of the engine's own launches, by HIP events recorded on the launch stream around every kernel (the role of
  * SearchStats' TimedStat members, search/monte_carlo/Search.hpp, for the device kernels).  Synchronises the device, returns the
  * time and launch count accumulated since the previous call in ms_out[4] / launches_out[4] (0 k_select, 1 k_solve, 2 k_expand,
@@ -524,6 +528,9 @@ int agx_timer_create(AgxTimer** out);
 int agx_timer_start(AgxTimer* t, void* stream);
 int agx_timer_stop(AgxTimer* t, void* stream);
 int agx_timer_elapsed_ms(AgxTimer* t, float* ms); /* synchronises on the stop event */
+/* the same without waiting: *ready = 0 (and *ms untouched) while the timed work has not finished.  What NNEvaluator::asyncEvaluateGraphLaunch's
+ * end-time estimate reads (NNEvaluator.cpp:197-206): a launch loop must not block on its previous network launch for a statistic. */
+int agx_timer_poll_ms(AgxTimer* t, float* ms, int* ready);
 int agx_timer_destroy(AgxTimer* t);
 
 #ifdef __cplusplus

@@ -280,7 +280,39 @@ namespace agx
 				check(agx_net_set_launch_width(network.handle(), per));
 				return slices;
 			}
-			/* GameGenerator::generate for every game of the pool: one select -> solve -> evaluate -> expand/backup -> move step */
+		private:
+			void run_stage(AGNetwork &network, int g, int which)
+			{
+				const int n = static_cast<int>(m_slice_streams.size());
+				if (which == 0)
+					check(agx_engine_select_solve_group(m_engine, g, n, m_slice_streams[g]));
+				else if (which == 1)
+					check(agx_engine_evaluate_group(m_engine, network.handle(), g, n, m_slice_streams[g]));
+				else
+					check(agx_engine_expand_backup_group(m_engine, g, n, m_slice_streams[g]));
+			}
+			static int slice_phase(int g) noexcept
+			{ // stages of its NEXT cycle a slice has queued between two generate() calls
+				static const int PHASES[4] = { 0, 1, 2, 1 };
+				return PHASES[g % 4];
+			}
+			struct EventGuard
+			{ // (an event must not outlive a stage that throws)
+					void *event = nullptr;
+					~EventGuard()
+					{
+						if (event != nullptr)
+							agx_event_destroy(event);
+					}
+			};
+		public:
+			/* GameGenerator::generate for every game of the pool: one select -> solve -> evaluate -> expand/backup -> move step.
+			 *
+			 * A SLICED pool (setSlices) is left ROTATED between calls: slice g has the first slice_phase(g) = 0 / 1 / 2 / 1 stages of its next cycle
+			 * queued already (slices 1 and 3 their search launch, slice 2 search + network), so a call that drains records, reads statistics or
+			 * game_info, saves the games, or passes ANOTHER network sees a step boundary for slice 0 only — the network given to this call is not
+			 * the one that evaluates slice 2's already-queued batch.  Callers that need step-aligned state (a network swap between training
+			 * iterations, save_games, comparisons against a lock-step pool) call align() first; the next generate() re-enters the rotation. */
 			void generate(AGNetwork &network, void *stream = nullptr)
 			{
 				if (m_slice_streams.empty())
@@ -295,56 +327,63 @@ namespace agx
 				  // whole cycle per slice, rotated.  Slices that start together stay together while the host feeds them in step — four towers at
 				  // once, the power-limited case the slicing exists to avoid (bench.py --stagger: 780 k -> 827 k simulations/s in a short window).
 					const int n = static_cast<int>(m_slice_streams.size());
-					auto stage = [&](int g, int which)
-					{
-						if (which == 0)
-							check(agx_engine_select_solve_group(m_engine, g, n, m_slice_streams[g]));
-						else if (which == 1)
-							check(agx_engine_evaluate_group(m_engine, network.handle(), g, n, m_slice_streams[g]));
-						else
-							check(agx_engine_expand_backup_group(m_engine, g, n, m_slice_streams[g]));
-					};
-					static const int PHASES[4] = { 0, 1, 2, 1 };
 					if (!m_phase_started)
 					{
 						m_phase_started = true;
 						// ... and on the DEVICE the odd slices begin when slice 0's first search launch is over (streams run their queues
 						// independently: without this every slice starts its first search at the same moment, whatever the host's order)
-						void *first_search_done = nullptr;
+						EventGuard first_search_done;
 						for (int g = 0; g < n; g++)
 						{
-							if (g % 2 == 1 && first_search_done != nullptr)
-								check(agx_stream_wait_event(m_slice_streams[g], first_search_done));
-							for (int k = 0; k < PHASES[g % 4]; k++)
-								stage(g, k);
+							if (g % 2 == 1 && first_search_done.event != nullptr)
+								check(agx_stream_wait_event(m_slice_streams[g], first_search_done.event));
+							for (int k = 0; k < slice_phase(g); k++)
+								run_stage(network, g, k);
 							if (g == 0 && n > 1)
 							{
 								check(agx_engine_select_solve_group(m_engine, 0, n, m_slice_streams[0])); // (slice 0's first cycle starts here; the loop below skips that stage once)
-								check(agx_event_create(&first_search_done));
-								check(agx_event_record(first_search_done, m_slice_streams[0]));
+								check(agx_event_create(&first_search_done.event));
+								check(agx_event_record(first_search_done.event, m_slice_streams[0]));
 								m_skip_first_search_of_slice0 = true;
 							}
 						}
-						if (first_search_done != nullptr)
-							check(agx_event_destroy(first_search_done));
 					}
 					for (int g = 0; g < n; g++)
 					{
 						for (int k = 0; k < 3; k++)
 						{
-							const int which = (PHASES[g % 4] + k) % 3;
+							const int which = (slice_phase(g) + k) % 3;
 							if (g == 0 && which == 0 && m_skip_first_search_of_slice0)
 							{
 								m_skip_first_search_of_slice0 = false;
 								continue;
 							}
-							stage(g, which);
+							run_stage(network, g, which);
 						}
 						while (static_cast<int>(m_pacers.size()) <= g)
 							m_pacers.emplace_back(m_steps_ahead);
 						m_pacers[g].step(m_slice_streams[g]); // the host stays two steps ahead of every slice and sleeps otherwise (HostPacer)
 					}
 				}
+			}
+			/* Brings every slice of a sliced pool to a step boundary: the stages of the cycles that generate() left begun are completed with
+			 * `network` (no new cycle is started), so that records, statistics, save_games and a network swap see whole steps of every slice.  The
+			 * next generate() starts the rotation again.  Nothing to do for an unsliced pool or before the first generate(). */
+			void align(AGNetwork &network)
+			{
+				if (m_slice_streams.empty() || !m_phase_started)
+					return;
+				const int n = static_cast<int>(m_slice_streams.size());
+				for (int g = 0; g < n; g++)
+				{
+					int begun = slice_phase(g);
+					if (g == 0 && m_skip_first_search_of_slice0)
+						begun = 1; // (only between the two halves of a first generate() that threw)
+					for (int k = begun; begun > 0 && k < 3; k++)
+						run_stage(network, g, k);
+				}
+				m_phase_started = false;
+				m_skip_first_search_of_slice0 = false;
 			}
 			/* steps the host may run ahead of the device (0: unbounded — the launch loop then spins on a full queue); before the first generate() */
 			void setHostStepsAhead(int steps) { m_steps_ahead = steps; }

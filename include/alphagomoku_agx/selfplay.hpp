@@ -64,6 +64,20 @@ namespace ag
 
 	class GeneratorManager;
 
+	/* utils/os_utils.hpp:46-63: the process-wide signal flags.  TrainingManager installs the custom SIGINT handler once and GeneratorManager::generate
+	 * polls hasCapturedSignal(SignalType::INT) to stop its threads and return, so that the caller reaches saveState (TrainingManager.cpp:88-113,
+	 * 205-209).  The handler only sets a flag (async-signal-safe); a captured signal stays captured, as in the reference. */
+	enum class SignalType
+	{
+		INT, ILL, ABRT, FPE, SEGV, TERM
+	};
+	enum class SignalHandlerMode
+	{
+		DEFAULT_HANDLER, IGNORE_SIGNAL, CUSTOM_HANDLER
+	};
+	void setupSignalHandler(SignalType type, SignalHandlerMode mode);
+	bool hasCapturedSignal(SignalType type) noexcept;
+
 	class GameGenerator
 	{ // selfplay/GameGenerator.hpp:25-66
 		private:
@@ -156,6 +170,7 @@ namespace ag
 			void run();
 			void setup();
 			void teardown();
+			void park_games_in_flight();
 	};
 
 	class GeneratorManager
@@ -168,8 +183,11 @@ namespace ag
 			int games_to_generate = 0;
 			std::string working_directory;
 			NetworkLoader network_loader;
+			int stats_period_seconds = 60; // GeneratorManager.cpp:198-199
 		public:
 			GeneratorManager(const GameConfig &gameOptions, const SelfplayConfig &selfplayOptions);
+			/* how often generate() prints the statistics (the reference: every 60 s, not configurable; tests shorten it) */
+			void setStatsPeriod(int seconds) noexcept { stats_period_seconds = (seconds > 0) ? seconds : 60; }
 
 			void setWorkingDirectory(const std::string &path);
 			/* the device-resident counterpart of addToBuffer(const GameDataStorage&): drains `engine`'s record pools into the buffer under

@@ -75,15 +75,29 @@ def forward(desc, blob, features, storage="fp32"):
     matrix cores are fp16, every activation plane is rounded to fp16 after bias (+ residual) + ReLU / tanh, accumulation and biases
     stay fp32, the 1x1 policy / action-value convolutions and the last dense layer keep fp32 weights, softmax in fp32.  Comparing the
     device against THIS mode separates kernel errors (order of fp32 additions only: ~1e-4) from the precision format's own rounding
-    (which the fp32 mode measures)."""
+    (which the fp32 mode measures).  DEVIATION from the reference, stated: the reference converts the WHOLE graph
+    (graph.convertTo(FLOAT16), AGNetwork.cpp:157); storage="fp16_all" below restates that, and the device test reports its distance to both."""
     rows, cols = desc["rows"], desc["cols"]
     parts = split_blob(desc, blob)
     it = iter(parts)
-    half = (storage == "fp16")
-    assert storage in ("fp32", "fp16")
+    half = storage in ("fp16", "fp16_all")
+    whole = (storage == "fp16_all")
+    assert storage in ("fp32", "fp16", "fp16_all")
 
     def q(a):  # round to fp16 storage
         return np.asarray(a, dtype=np.float32).astype(np.float16).astype(np.float32) if half else a
+
+    def qa(a):  # ... of the tensors only a WHOLE-graph conversion stores as fp16
+        return np.asarray(a, dtype=np.float32).astype(np.float16).astype(np.float32) if whole else a
+    if whole:
+        # storage="fp16_all": what graph.convertTo(FLOAT16) does to the WHOLE graph (AGNetwork::convertToHalfFloats, AGNetwork.cpp:157): every
+        # parameter tensor — the 1x1 policy / action-value convolutions, the last dense layer and all biases included — and every layer's
+        # output tensor (the hidden dense layer, the logits) is an fp16 tensor; accumulation inside a layer stays fp32.  The device kernel
+        # keeps those few small tensors in fp32 (the "fp16" mode above is ITS format); this mode measures how far that deviation is from a
+        # literal whole-graph conversion.  Unpinned like the rest (MinML absent): which accumulations MinML's fp16 kernels carry in fp32 is
+        # not recoverable from the reference.
+        parts = [qa(p) for p in parts]
+        it = iter(parts)
     x = unpack_input(features, rows, cols, desc["in_channels"])
     x = q(relu(conv2d_same(x, q(next(it)), next(it))))
     for _ in range(desc["blocks"]):
@@ -93,18 +107,18 @@ def forward(desc, blob, features, storage="fp32"):
         x = q(relu(x + y))
     wp1, bp1, wp2, bp2 = q(next(it)), next(it), next(it), next(it)
     p = q(relu(conv2d_same(x, wp1, bp1)))
-    logits = np.tensordot(p, wp2, axes=([3], [0])) + bp2[0]
+    logits = qa(np.tensordot(p, wp2, axes=([3], [0])) + bp2[0])
     policy = softmax(logits.reshape(logits.shape[0], -1), axis=1)
     wv1, bv1, wv2, bv2, wv3, bv3 = q(next(it)), next(it), q(next(it)), next(it), next(it), next(it)
     v = q(relu(np.tensordot(x, wv1, axes=([3], [0])) + bv1.reshape(1, 1, 1, 4)))
     v = v.reshape(v.shape[0], -1)
-    h = relu(v @ wv2 + bv2)
-    value = softmax(h @ wv3 + bv3, axis=1)
+    h = qa(relu(v @ wv2 + bv2))
+    value = softmax(qa(h @ wv3 + bv3), axis=1)
     if desc.get("action_values", 0):
         # createActionValuesHead (blocks.cpp:119-127): conv3x3 + BN(tanh), conv1x1 F->3 with bias, softmax over the last axis;
         # the search keeps (win, draw) of every cell (NetworkDataPack::unpackActionValues, NetworkDataPack.cpp:214-224)
         wq1, bq1, wq2, bq2 = q(next(it)), next(it), next(it), next(it)
         t = q(np.tanh(conv2d_same(x, wq1, bq1)))
-        qv = softmax(np.tensordot(t, wq2, axes=([3], [0])) + bq2.reshape(1, 1, 1, 3), axis=3)
+        qv = softmax(qa(np.tensordot(t, wq2, axes=([3], [0])) + bq2.reshape(1, 1, 1, 3)), axis=3)
         return policy.astype(np.float32), value.astype(np.float32), qv.reshape(qv.shape[0], -1, 3)[:, :, :2].astype(np.float32)
     return policy.astype(np.float32), value.astype(np.float32)

@@ -26,6 +26,7 @@
 #include <mutex>
 #include <sstream>
 #include <thread>
+#include <filesystem>
 
 using namespace ag;
 
@@ -68,15 +69,24 @@ static int mode_generate(const std::map<std::string, std::string> &a)
 	}
 	const std::string out = a.count("--out") ? a.at("--out") : std::string(".");
 
+	// TrainingManager installs the custom SIGINT handler before anything runs (TrainingManager.cpp: setupSignalHandler(SignalType::INT, ...));
+	// generate() then stops its threads on a captured signal and the caller saves the state
+	const bool interruptible = geti(a, "--interruptible", 0) != 0;
+	if (interruptible)
+		setupSignalHandler(SignalType::INT, SignalHandlerMode::CUSTOM_HANDLER);
 	GeneratorManager manager(game_config, selfplay_config);
+	manager.setStatsPeriod(geti(a, "--stats-period", 60));
 	manager.setWorkingDirectory(out);
 	manager.loadState();
+	if (interruptible)
+		std::cout << "generating" << std::endl; // (the test sends its SIGINT some seconds after this line)
 	// one generate() per training iteration in the reference (TrainingManager::runIterationRL): every call sets its generator threads up again,
 	// and must get the SAME CU-masked streams back (they cannot be destroyed: agx.h)
 	const int iterations = geti(a, "--iterations", 1);
 	for (int it = 0; it < iterations; it++)
 		manager.generate(NetworkLoader(a.at("--network")), geti(a, "--games", 32) * (it + 1) / iterations);
-	manager.saveState(true);
+	const bool was_interrupted = hasCapturedSignal(SignalType::INT);
+	manager.saveState(interruptible ? was_interrupted : true); // TrainingManager.cpp:205-207: saveState(was_interrupted)
 	manager.getGameBuffer().save(out + "/buffer_0.bin");
 	manager.printStats();
 
@@ -91,8 +101,9 @@ static int mode_generate(const std::map<std::string, std::string> &a)
 		raw.write(reinterpret_cast<const char*>(g.data()), g.size());
 	}
 	std::printf("{\"mode\": \"generate\", \"threads\": %zu, \"games\": %d, \"samples\": %d, \"cross_win\": %d, \"draws\": %d, \"circle_win\": %d, \"game_length\": %d, "
-			"\"iterations\": %d, \"masked_streams\": %d}\n",
-			selfplay_config.device_config.size(), st.games, st.samples, st.cross_win, st.draws, st.circle_win, st.game_length, iterations, agx_stream_masked_count());
+			"\"iterations\": %d, \"masked_streams\": %d, \"interrupted\": %s}\n",
+			selfplay_config.device_config.size(), st.games, st.samples, st.cross_win, st.draws, st.circle_win, st.game_length, iterations, agx_stream_masked_count(),
+			was_interrupted ? "true" : "false");
 	return 0;
 }
 
@@ -744,7 +755,24 @@ static int mode_errors(const std::map<std::string, std::string> &a)
 	{
 		caught |= 16;
 	}
-	(void) a;
+	{ // a checkpoint taken before any generator thread ever ran (saveState ahead of the first generate): valid files of zero generators, which the
+	  // next loadState reads back — not 0-byte files that make it throw until saved_state/ is removed by hand
+		const std::string dir = a.count("--out") ? a.at("--out") : std::string("/tmp/agx_boundary_empty_state");
+		std::filesystem::remove_all(dir + "/saved_state");
+		GameConfig g(GameRules::FREESTYLE, 15);
+		SelfplayConfig sp;
+		sp.device_config.assign(2, DeviceConfig());
+		sp.device_config[0].device = sp.device_config[1].device = Device::hip(0);
+		GeneratorManager manager(g, sp);
+		manager.setWorkingDirectory(dir);
+		manager.saveState(false);
+		const auto size = std::filesystem::file_size(dir + "/saved_state/thread_1.bin");
+		GeneratorManager again(g, sp);
+		again.setWorkingDirectory(dir);
+		again.loadState(); // (would throw "is not a saved generator state")
+		if (size >= 12)
+			caught |= 32;
+	}
 	std::printf("{\"mode\": \"errors\", \"caught\": %d}\n", caught);
 	return 0;
 }

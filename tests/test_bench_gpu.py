@@ -69,6 +69,17 @@ def test_eight_ranks_on_one_gpu(agx_lib):
     # launch queue — a rank needs a fraction of a CPU (0.12 measured for one rank per GPU), two whole ones without the pacing
     assert line["slices"]["host_steps_ahead"] == 2
     assert all(r["host_cpu_seconds"] > 0.0 and r["host_cpu_utilisation"] < 0.8 for r in ranks), [r["host_cpu_utilisation"] for r in ranks]
+    # every rank reports what it holds of its GPU and how many host threads it runs
+    assert all(r["device_bytes_allocated"] > (64 << 20) and 1 <= r["host_threads"] <= 64 for r in ranks), [(r["device_bytes_allocated"], r["host_threads"]) for r in ranks]
+    # configs[2] at full size is 1024 games per GPU with the reference's 4 Mi-entry solver tables: ONE such rank's engine is created here (the
+    # eight of a node sit on eight GPUs) — its footprint must fit a GPU's 288 GB with room for the network and the runtime
+    from alphagomoku_amd import selfplay
+    full = selfplay.GeneratorPool(selfplay.default_config(n_games=1024, rules=1, max_batch_size=8, max_simulations=800, tss_table_entries=4 * 1024 * 1024,
+                                                          node_capacity=4096, edge_capacity=76800, speculative_solver=1))
+    footprint = full.device_bytes()
+    full.close()
+    print("C3 per-rank device footprint at 1024 games: %.1f GB" % (footprint / 1e9))
+    assert 64e9 < footprint < 0.6 * 288e9, footprint     # 64 GB of solver tables alone; well inside one GPU's HBM (8 ranks = 8 GPUs x 288 GB)
 
 
 def test_host_pacer_sleeps_behind_the_stream(agx_lib):

@@ -144,6 +144,47 @@ def read_games(out, n):
     return games
 
 
+def test_generate_stops_on_sigint_and_the_next_start_resumes(network_file, tmp_path):
+    """GeneratorManager::generate (GeneratorManager.cpp:196-208) with the process's SIGINT handler installed the way TrainingManager does
+    (utils/os_utils.hpp:62-63): a captured SIGINT stops the generator threads, generate() returns, the caller's saveState(was_interrupted)
+    writes the buffer AND the games in flight, the process ends normally — and the next start loads both and goes on.  The statistics are
+    printed periodically while it runs (every 60 s in the reference; 2 s here)."""
+    import signal
+    import time
+    path, d, _ = network_file
+    out = tmp_path / "work"
+    out.mkdir()
+    common = ["--network", path, "--games-per-thread", 16, "--devices", "0,0", "--sims", 50, "--batch", 4, "--out", out, "--nn-batch", 32]
+    cmd = [BINARY, "generate", "--games", 1000000, "--interruptible", 1, "--stats-period", 2] + [str(a) for a in common]
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    try:
+        deadline = time.time() + 600
+        while time.time() < deadline:
+            line = p.stdout.readline()
+            if line.startswith("generating") or line == "":
+                break
+        assert p.poll() is None, p.stderr.read()[-2000:]
+        time.sleep(12.0)                     # set-up (networks, openings) + a few seconds of play
+        p.send_signal(signal.SIGINT)
+        stdout, stderr = p.communicate(timeout=300)
+    finally:
+        if p.poll() is None:
+            p.kill()
+    assert p.returncode == 0, stderr[-3000:] + stdout[-2000:]
+    assert "Caught interruption signal" in stdout and "Generators stopped" in stdout and "Saving buffer" in stdout
+    assert stdout.count("Played games = ") >= 2          # the periodic statistics + the caller's printStats
+    first = json.loads([x for x in stdout.splitlines() if x.startswith('{"mode"')][0])
+    assert first["interrupted"] is True and 0 < first["games"] < 1000000
+    state = out / "saved_state"
+    assert (state / "buffer.bin").exists() and (state / "thread_0.bin").exists() and (state / "thread_1.bin").exists()
+    in_flight = sum(len(parse_saved_games(state / ("thread_%d.bin" % t))) for t in range(2))
+    assert in_flight >= 16
+    second, stdout2 = run("generate", "--games", first["games"] + 8, "--interruptible", 1, *common)
+    assert second["interrupted"] is False and "Loaded buffer" in stdout2 and "thread_1.bin" in stdout2 and second["games"] >= first["games"] + 8
+    # an uninterrupted run's saveState(false) leaves no buffer behind (TrainingManager.cpp:207), only the games in flight
+    assert not (state / "buffer.bin").exists() and (state / "thread_0.bin").exists()
+
+
 def test_generator_manager_restart_continues_the_games_in_flight(network_file, tmp_path):
     """GeneratorManager::saveState / loadState (GeneratorManager.cpp:241-290) and GameGenerator::save / load (GameGenerator.cpp:122-141) across
     two PROCESSES: the first plays 12 games and stops — its buffer goes to saved_state/buffer.bin, the games still in flight (their moves and
@@ -449,6 +490,6 @@ def test_game_generators_with_the_reference_constructor(network_file, agx_lib):
     assert line["generators"] == 3 and line["games"] >= 2 and line["samples"] > line["games"]
 
 
-def test_boundary_error_behaviour(agx_lib):
-    line, _ = run("errors")
-    assert line["caught"] == 31
+def test_boundary_error_behaviour(agx_lib, tmp_path):
+    line, _ = run("errors", "--out", tmp_path)
+    assert line["caught"] == 63     # five of the reference's exceptions + (32) a checkpoint written before the first generate() loads again

@@ -124,3 +124,18 @@ def test_numa_pinning_follows_the_runtime_device_order(tmp_path, monkeypatch):
     monkeypatch.delenv("HIP_VISIBLE_DEVICES")
     assert distributed.pin_to_gpu_numa_node(0, str(tmp_path / "nothing-here")) == (None, 0)
     assert len(pinned) == 3
+    # the filters compose: ROCR selects from the topology, HIP / CUDA from what ROCR left
+    monkeypatch.delenv("CUDA_VISIBLE_DEVICES", raising=False)
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "1,0")
+    assert distributed._visible_index(0) == 1 and distributed._visible_index(1) == 0 and distributed._visible_index(2) is None
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "1")
+    assert distributed._visible_index(0) == 0                                          # ROCR's second entry = the topology's first GPU
+    assert distributed.pin_to_gpu_numa_node(0, str(tmp_path)) == (1, 1) and pinned[-1] == {hi}
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    monkeypatch.setenv("CUDA_VISIBLE_DEVICES", "1")                                    # HIP honours it as well
+    assert distributed._visible_index(0) == 0
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0")                                     # two different inner lists: not resolved, the rank stays unpinned
+    assert distributed._visible_index(0) is None and distributed.pin_to_gpu_numa_node(0, str(tmp_path)) == (None, 0)
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "GPU-abcdef")                            # UUID form
+    monkeypatch.delenv("CUDA_VISIBLE_DEVICES")
+    assert distributed._visible_index(0) is None

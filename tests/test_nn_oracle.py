@@ -76,3 +76,19 @@ def test_fp16_storage_mode_rounds_where_the_kernel_does():
     parts = nn_ref.split_blob(d, blob)
     # (policy 1x1 / last dense weights and biases stay fp32 in the kernel, so the two blobs may differ there)
     assert np.abs(pa - pb).max() < 1e-3 and np.abs(va - vb).max() < 1e-3 and len(parts) > 0
+
+
+def test_whole_graph_fp16_mode():
+    """storage="fp16_all" restates graph.convertTo(FLOAT16) over the WHOLE graph (AGNetwork.cpp:157): with it a blob and its fp16-rounded copy
+    give IDENTICAL results (every parameter is rounded on entry, the kernel-format mode keeps the 1x1 head / last dense weights and the biases
+    in fp32), and it stays within the format's tolerance of the kernel-format mode."""
+    d = synthetic.net_desc(blocks=2, filters=64, action_values=1)
+    blob, _ = synthetic.make_weights(d, seed=9)
+    f = synthetic.random_features(3, 15, 15, seed=21)
+    blob16 = blob.astype(np.float16).astype(np.float32)
+    a = nn_ref.forward(d, blob, f, storage="fp16_all")
+    b = nn_ref.forward(d, blob16, f, storage="fp16_all")
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    k = nn_ref.forward(d, blob, f, storage="fp16")
+    assert not np.array_equal(a[0], k[0])
+    assert all(np.abs(x - y).max() < 4e-3 for x, y in zip(a, k))
