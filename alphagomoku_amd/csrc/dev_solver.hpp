@@ -72,7 +72,7 @@ namespace agx
 		 * ~0 >> (64 - lane) is a 64-bit lane-derived value that hipcc hoists to the top of the kernel and, at 168 registers, reloads from scratch
 		 * at every inlined use) */
 #ifndef AGX_MBCNT
-#define AGX_MBCNT 1
+#define AGX_MBCNT 0 /* (measured flat to slightly slower than the mask form: 3.975 against 3.944 ms) */
 #endif
 		__device__ __forceinline__ int lanes_below(u64 ballot, int lane)
 		{
@@ -180,7 +180,8 @@ namespace agx
                          through the vector L1 / L2 — 4 KB less LDS per wave buys a third wave per SIMD, which hides far more than that latency */
 #endif
 #ifndef AGX_PLACE_OPAQUE_LANE
-#define AGX_PLACE_OPAQUE_LANE 0 /* 1: solver_update_around / pattern_prefetch recompute their lane-derived values instead of taking hoisted copies out of scratch */
+#define AGX_PLACE_OPAQUE_LANE 1 /* 1: solver_update_around / pattern_prefetch recompute their lane-derived values instead of taking hoisted copies out of scratch
+                                   (search launch 4.08 -> 3.94 ms, profiles/r05_search_variants_ab.txt) */
 #endif
 		constexpr int NODE_TIME_OVER = 0x40000000; // set in the node counter when a time-limited solve runs out of time: every "nodes left" test then fails
 		constexpr int NODE_COUNT_MASK = NODE_TIME_OVER - 1;
@@ -1979,6 +1980,62 @@ for (int k = 0; k < 5; k++)
 			bucket[2 * idx + 1] = value;
 		}
 
+		/* The same two operations with the bucket spread over lanes (AGX_TT_LANES): lane i < 8 holds word i of the bucket — the way the prefetch
+		 * delivers it.  The forms above are run by all 64 lanes redundantly and walk the four entries one after the other: up to eight DEPENDENT
+		 * round trips (LDS for the prefetched bucket, L2 / HBM for an insert) for what is one key compare per lane and a ballot. */
+#ifndef AGX_TT_LANES
+#define AGX_TT_LANES 1 /* (search launch 3.95 -> 3.92 ms; ScratchSize 396 -> 340 B/lane) */
+#endif
+		__device__ __forceinline__ u64 wave_read64(u64 v, int src_lane)
+		{
+			const int l = __builtin_amdgcn_readfirstlane(src_lane);
+			const uint32_t lo = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(static_cast<uint32_t>(v)), l));
+			const uint32_t hi = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(static_cast<uint32_t>(v >> 32)), l));
+			return static_cast<u64>(lo) | (static_cast<u64>(hi) << 32);
+		}
+		/* index (0..3) of the FIRST entry whose key matches (SharedHashTable.hpp:150-165: hi word equal, top 16 bits of the data word equal to
+		 * the top 16 bits of lo), or -1 */
+		__device__ __forceinline__ int tt_match_lanes(u64 word, u64 lo, u64 hi, int lane)
+		{
+			const u64 KEY = 0xFFFF000000000000ull;
+			const bool mine = (lane < 8) && (((lane & 1) == 0) ? (word == hi) : ((word & KEY) == (lo & KEY)));
+			const uint32_t m = static_cast<uint32_t>(__ballot(mine));
+			const uint32_t both = m & (m >> 1) & 0x55u; // bit 2k: entry k's key word (lane 2k) and tag (lane 2k + 1) both match
+			return (both != 0u) ? ((__ffs(static_cast<int>(both)) - 1) >> 1) : -1;
+		}
+		__device__ __forceinline__ u64 tt_seek_lanes(u64 word, u64 lo, u64 hi, int lane)
+		{
+			const int k = tt_match_lanes(word, lo, hi, lane);
+			return (k >= 0) ? wave_read64(word, 2 * k + 1) : tt_pack(0, 0, s_unknown(0), 0);
+		}
+		__device__ __forceinline__ void tt_insert_lanes(u64 *bucket, u64 lo, u64 hi, u64 value, int generation, int lane)
+		{ // `bucket`: the eight words (wave-uniform pointer)
+			const u64 KEY = 0xFFFF000000000000ull;
+			value &= ~(KEY | 0xFCull);
+			value |= static_cast<u64>(generation) << 2;
+			value |= (lo & KEY);
+			u64 word = 0;
+			if (lane < 8)
+				word = bucket[lane];
+			const uint32_t score = static_cast<uint32_t>((value >> 16) & 65535u);
+			int idx = -1;
+			if (s_proven(score) || (value & 3ull) == 3ull)
+				idx = tt_match_lanes(word, lo, hi, lane);
+			if (idx < 0)
+			{ // the first minimum of depth - age over the four entries (their data words sit in the odd lanes)
+				const int worth = static_cast<int>((word >> 8) & 255) - (generation - static_cast<int>((word >> 2) & 63));
+				const int w0 = __builtin_amdgcn_readlane(worth, 1), w1 = __builtin_amdgcn_readlane(worth, 3), w2 = __builtin_amdgcn_readlane(worth, 5),
+						w3 = __builtin_amdgcn_readlane(worth, 7);
+				idx = 0;
+				int best = w0;
+				if (w1 < best) { best = w1; idx = 1; }
+				if (w2 < best) { best = w2; idx = 2; }
+				if (w3 < best) { best = w3; idx = 3; }
+			}
+			if (lane < 2)
+				bucket[2 * idx + lane] = (lane == 0) ? hi : value;
+		}
+
 		/* AlphaBetaSearch::evaluate (AlphaBetaSearch.cpp:345-365) */
 		template<class SH>
 		__device__ __forceinline__ uint32_t solver_evaluate(const SH &sh)
@@ -2057,6 +2114,17 @@ for (int k = 0; k < 5; k++)
 								slot = ov_create(sh, bucket, pf_word, lane);
 							f.ov_slot = static_cast<uint32_t>(slot);
 						}
+#if AGX_TT_LANES
+						entry = tt_seek_lanes(pf_word, hash_lo, hash_hi, lane);
+					}
+					else
+					{
+						u64 word = 0;
+						if (lane < 8)
+							word = tt[8 * (hash_lo & E.tt_bucket_mask) + lane];
+						entry = tt_seek_lanes(word, hash_lo, hash_hi, lane);
+					}
+#else
 						if (lane < 8)
 							sh.pf_bucket[lane] = pf_word;
 						wave_sync();
@@ -2068,6 +2136,7 @@ for (int k = 0; k < 5; k++)
 					}
 					else
 						entry = tt_seek(tt, E.tt_bucket_mask, hash_lo, hash_hi);
+#endif
 					sh.pf_valid = 0;
 					bool early = false;
 					if (sh.ov_on && sh.ov_overflow)
@@ -2321,13 +2390,21 @@ for (int k = 0; k < 5; k++)
 						if (error != ERR_OVERLAY)
 						{
 							const int slot = static_cast<int>(f.ov_slot);
+#if AGX_TT_LANES
+							tt_insert_lanes(sh.ov_data + slot * 16 + 8, hash_lo, hash_hi, tt_pack(bound, f.depth_remaining, best, f.best_move), generation, lane);
+#else
 							tt_insert(sh.ov_data + slot * 16 + 8, 0ull, hash_lo, hash_hi, tt_pack(bound, f.depth_remaining, best, f.best_move), generation);
+#endif
 							if (lane == 0)
 								sh.ov_dirty[slot >> 5] |= 1u << (slot & 31);
 						}
 					}
 					else
+#if AGX_TT_LANES
+						tt_insert_lanes(tt + 8 * (hash_lo & E.tt_bucket_mask), hash_lo, hash_hi, tt_pack(bound, f.depth_remaining, best, f.best_move), generation, lane);
+#else
 						tt_insert(tt, E.tt_bucket_mask, hash_lo, hash_hi, tt_pack(bound, f.depth_remaining, best, f.best_move), generation);
+#endif
 					value = best;
 					returning = true;
 #ifdef AGX_SOLVER_PROFILE

@@ -627,6 +627,9 @@ namespace
 	 * all but a few games of the launch are done (the yield rule of k_solve, AgxEngineConfig.solver_yield_fraction) — the leaves before it
 	 * stay committed, the game sits out this step's network / expand stages and the next launch queues its remaining leaves again: the
 	 * same operations one step later. */
+#ifndef AGX_DEFER_ON_EMPTY_QUEUE
+#define AGX_DEFER_ON_EMPTY_QUEUE 0 /* 1: a batch whose commit needs a serial re-run is also deferred once the launch's queue has run dry (spec_commit_game) */
+#endif
 	struct SpecCommit
 	{
 		int game, k, first; // first: where the game's batch began in THIS launch (0, or the solve_pos a deferred game came back with)
@@ -634,8 +637,8 @@ namespace
 			unsigned long long nodes, solved, reruns;
 	};
 	template<class SH>
-	__device__ __forceinline__ int spec_commit_game(SH &sh, const EngineDev &E, SpecCommit &c, int lane, const int *c_done, int defer_threshold)
-	{
+	__device__ __forceinline__ int spec_commit_game(SH &sh, const EngineDev &E, SpecCommit &c, int lane, const int *c_done, int defer_threshold, const int *c_queue, int count)
+	{ // c_queue: the launch's counters (select cursor, queue head, queue tail, games selected)
 		const int g = c.game;
 		GameState &gs = E.games[g];
 		const int n_tasks = gs.n_tasks;
@@ -683,7 +686,18 @@ namespace
 					done = __hip_atomic_load(c_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				// (like k_solve's rule: the first leaf of the launch is always finished — a game whose first pending leaf needs the re-run every time,
 				//  e.g. one whose overlay overflows, would otherwise be deferred launch after launch with its speculative work thrown away)
+#if AGX_DEFER_ON_EMPTY_QUEUE
+				// ... or the launch has nothing left to hide a serial re-run behind: every game has queued its leaves and every leaf has been taken, so
+				// the waves are leaving and a 1.1 ms re-run now only lengthens the launch (in-kernel trace, profiles/r05_search_launch_timeline.txt: the
+				// games that end a launch are the ones whose commit began when the queue ran dry and needed one re-run)
+				int dry = 0;
+				if (lane == 0 && defer_threshold != 0x7FFFFFFF)
+					dry = (__hip_atomic_load(c_queue + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= count
+							&& __hip_atomic_load(c_queue + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= __hip_atomic_load(c_queue + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) ? 1 : 0;
+				const bool defer = (__builtin_amdgcn_readfirstlane(done) >= defer_threshold || __builtin_amdgcn_readfirstlane(dry) != 0) && k > c.first;
+#else
 				const bool defer = __builtin_amdgcn_readfirstlane(done) >= defer_threshold && k > c.first;
+#endif
 				// forget the speculative result: of this leaf (it is solved again), or of this leaf and the ones behind it (deferred)
 				for (int j = k; j < (defer ? n_tasks : k + 1); j++)
 				{
@@ -894,7 +908,7 @@ namespace
 			SPEC_T(t_pop);
 			if (commit.game >= 0)
 			{ // this wave is committing a game: go on until a leaf needs its serial re-run
-				const int r = spec_commit_game(sh, E, commit, lane, c_done, defer_threshold);
+				const int r = spec_commit_game(sh, E, commit, lane, c_done, defer_threshold, c_select, count);
 				if (r < 0)
 				{
 					if (r == -1 && lane == 0)
@@ -1022,6 +1036,9 @@ namespace
 	}
 
 	/* ------------------------------------------------------------------------------------------------------------ */
+#ifndef AGX_WIDE_BACKUP
+#define AGX_WIDE_BACKUP 1 /* Tree::backup with all levels of a path in flight at once (k_expand); 0: level by level */
+#endif
 	__global__ __launch_bounds__(64) void k_expand(EngineDev E)
 	{
 		__shared__ float e_prior[MAXHW], e_win[MAXHW], e_draw[MAXHW];
@@ -1379,6 +1396,105 @@ namespace
 			float ml = t.moves_left;
 			bool have_child = final_node >= 0;
 			uint32_t child_score = have_child ? nodes[final_node].score : 0u;
+#if AGX_WIDE_BACKUP
+			if (path_len <= 64)
+			{ /* All levels of the path at once.  Level by level (below) a leaf costs two DEPENDENT round trips to HBM per level — the node head + edge,
+			   * then the scan of the node's edge scores — and a path is ~8 levels deep: the expand stage was that chain (75 % of its wave cycles parked
+			   * at s_waitcnt).  Nothing in a level's running means depends on another level (a position occurs once on a path), only the proven SCORE
+			   * travels upwards: lane i takes level i — head, edge and value update —, the score scans of up to eight levels are requested together,
+			   * and the score chain then runs over registers.  The arithmetic of every level is the serial loop's, operation for operation. */
+				const bool mine = lane < path_len;
+				const int node = mine ? t.path_node[lane] : 0, e = mine ? t.path_edge[lane] : 0;
+				DNode nd;
+				node_head(nd, nodes[node]);
+				DEdge ed = edges[e];
+				float ml_i = ml; // the serial loop adds 1.0f per level on its way up: the same additions, not one multiple
+				for (int k = path_len - 1; k > lane; k--)
+					ml_i += 1.0f;
+				float vw = win, vd = draw;
+				if (nd.sign_to_move != sign)
+				{
+					vw = 1.0f - (win + draw);
+					vd = draw;
+				}
+				nd.visits++;
+				const float tn = static_cast<float>(1.0 / nd.visits);
+				nd.win = fmaxf(0.0f, fminf(1.0f, nd.win + (vw - nd.win) * tn));
+				nd.draw = fmaxf(0.0f, fminf(1.0f, nd.draw + (vd - nd.draw) * tn));
+				ed.visits++;
+				const float te = 1.0f / ed.visits;
+				ed.win = fmaxf(0.0f, fminf(1.0f, ed.win + (vw - ed.win) * te));
+				ed.draw = fmaxf(0.0f, fminf(1.0f, ed.draw + (vd - ed.draw) * te));
+				nd.moves_left += (ml_i - nd.moves_left) / nd.visits;
+				nd.vl--;
+				ed.flag_vl = static_cast<uint16_t>(((ed.flag_vl & 0x7FFF) - 1) & 0x7FFF);
+				// the largest score among the OTHER edges of every level's node
+				uint32_t others = 0;
+				constexpr int LEVELS = 8, LOADS = (MAXHW + 63) / 64;
+				for (int base = 0; base < path_len; base += LEVELS)
+				{
+					uint32_t sc[LEVELS][LOADS];
+#pragma unroll
+					for (int u = 0; u < LEVELS; u++)
+					{
+						const int lv = min(base + u, path_len - 1);
+						const int eb = __builtin_amdgcn_readlane(nd.edge_begin, __builtin_amdgcn_readfirstlane(lv));
+						const int ne = __builtin_amdgcn_readlane(static_cast<int>(nd.n_edges), __builtin_amdgcn_readfirstlane(lv));
+						const int ee = __builtin_amdgcn_readlane(e, __builtin_amdgcn_readfirstlane(lv));
+#pragma unroll
+						for (int jj = 0; jj < LOADS; jj++)
+						{
+							const int j = lane + 64 * jj;
+							sc[u][jj] = (base + u < path_len && j < ne && eb + j != ee) ? static_cast<uint32_t>(edges[eb + j].score) : 0u;
+						}
+					}
+#pragma unroll
+					for (int u = 0; u < LEVELS; u++)
+					{
+						uint32_t m = 0;
+#pragma unroll
+						for (int jj = 0; jj < LOADS; jj++)
+							m = max(m, sc[u][jj]);
+						m = wave_max_u32(m);
+						if (lane == base + u)
+							others = m;
+					}
+				}
+				// the score chain, leaf to root, on registers
+				for (int i = path_len - 1; i >= 0; i--)
+				{
+					const int li = __builtin_amdgcn_readfirstlane(i);
+					uint32_t new_score = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(ed.score), li));
+					if (have_child)
+						new_score = s_invert_up(child_score);
+					const uint32_t result = max(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(others), li)), new_score);
+					const uint32_t level_flags = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(nd.flags), li));
+					uint32_t node_score = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(nd.score), li));
+					if (((level_flags & 4u) != 0u) || s_win(result) || s_unproven(result))
+						node_score = result;
+					if (lane == i)
+					{
+						ed.score = static_cast<uint16_t>(new_score);
+						nd.score = static_cast<uint16_t>(node_score);
+					}
+					child_score = node_score;
+					have_child = true;
+				}
+				if (mine)
+				{
+					DNode &dn = nodes[node];
+					dn.visits = nd.visits;
+					dn.win = nd.win;
+					dn.draw = nd.draw;
+					dn.moves_left = nd.moves_left;
+					dn.vl = nd.vl;
+					dn.score = nd.score;
+					edges[e] = ed;
+				}
+				__syncthreads();
+				continue;
+			}
+#endif
 			for (int i = path_len - 1; i >= 0; i--)
 			{
 				const int node = t.path_node[i], e = t.path_edge[i];

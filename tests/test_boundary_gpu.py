@@ -155,7 +155,7 @@ def test_generate_stops_on_sigint_and_the_next_start_resumes(network_file, tmp_p
     out = tmp_path / "work"
     out.mkdir()
     common = ["--network", path, "--games-per-thread", 16, "--devices", "0,0", "--sims", 50, "--batch", 4, "--out", out, "--nn-batch", 32]
-    cmd = [BINARY, "generate", "--games", 1000000, "--interruptible", 1, "--stats-period", 2] + [str(a) for a in common]
+    cmd = [str(a) for a in [BINARY, "generate", "--games", 1000000, "--interruptible", 1, "--stats-period", 2] + common]
     p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     try:
         deadline = time.time() + 600

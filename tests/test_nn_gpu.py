@@ -50,7 +50,11 @@ def test_deep_network_tolerance(agx_lib, rows):
 
 
 FP16_ORACLE_TOL = 1.0e-3
-WHOLE_GRAPH_TOL = 1.0e-2   # device (fp32 head weights / biases / logits) against the literal whole-graph fp16 conversion, on softmax outputs
+# device (fp32 head weights / biases / logits) against the literal whole-graph fp16 conversion, on softmax outputs.  Measured on MI355X: 1.1e-5 / 1.8e-4
+# (2x64), 5.9e-4 / 4.6e-4 (6x128), 4.7e-5 / 5.0e-4 (10x128, order-one activations) — the same 1e-3 as against the kernel-format oracle; the plain
+# He-init 10x128 tower 1.45e-2 / 3.2e-3 (the two ORACLE modes differ by 1.57e-2 there: near one-hot policies amplify the logits' fp16 rounding), bounded
+# by DEEP_TOL like the fp32 comparison
+WHOLE_GRAPH_TOL = 1.0e-3
 
 
 @pytest.mark.parametrize("rows,blocks,filters,gain", [(15, 2, 64, 1.0), (15, 6, 128, 1.0), (15, 10, 128, 0.5), (15, 10, 128, 1.0), (20, 2, 64, 1.0), (20, 10, 128, 0.5),
@@ -83,12 +87,13 @@ def test_forward_matches_the_fp16_storage_oracle(agx_lib, rows, blocks, filters,
     assert (p.argmax(1) == pr.argmax(1)).all()
     # the literal whole-graph conversion (graph.convertTo(FLOAT16), AGNetwork.cpp:157: also the 1x1 head weights, the last dense layer, the biases,
     # the hidden dense layer and the logits as fp16 tensors) — the device keeps those small tensors in fp32; reported next to the mode above and
-    # bounded: the fp16 rounding of a logit is <= 2^-11 of its magnitude, i.e. <= 1e-2 on a softmax output for logits below ~20
+    # bounded like the kernel-format comparison (1e-3; the plain He-init 10x128 tower by DEEP_TOL)
     pa, va = nn_ref.forward(d, blob, f, storage="fp16_all")
     all_p, all_v = float(np.abs(p - pa).max()), float(np.abs(v - va).max())
     print("whole-graph fp16 oracle %dx%d %dx%d gain %.1f: policy %.2e value %.2e (oracle fp16 vs fp16_all: policy %.2e value %.2e)"
           % (rows, rows, blocks, filters, gain, all_p, all_v, float(np.abs(pr - pa).max()), float(np.abs(vr - va).max())))
-    assert all_p <= WHOLE_GRAPH_TOL and all_v <= WHOLE_GRAPH_TOL
+    whole_tol = DEEP_TOL if deep_he_init else WHOLE_GRAPH_TOL
+    assert all_p <= whole_tol and all_v <= whole_tol
     assert (p.argmax(1) == pa.argmax(1)).all()
     net.close()
 
