@@ -68,6 +68,37 @@ namespace agx
 			AGX_WAVE_REDUCE(hi, AGX_OP_XOR);
 			return static_cast<u64>(static_cast<uint32_t>(__builtin_amdgcn_readlane(lo, 63))) | (static_cast<u64>(static_cast<uint32_t>(__builtin_amdgcn_readlane(hi, 63))) << 32); // readlane yields int: no sign extension
 		}
+		/* A pointer that went through LDS (sh.snap, sh.ov_data, sh.spill_*) has lost its address space: hipcc accesses what it points to with FLAT
+		 * instructions, and a FLAT access counts on BOTH wait counters — every later s_waitcnt lgkmcnt(0), i.e. every LDS round trip, then also waits for
+		 * it.  The solver's prefetches (the child's table bucket, the undo snapshot) are requested exactly so that they travel during LDS-heavy work:
+		 * as FLAT loads they were waited for at the first LDS access behind them.  These accesses go through a global-address-space view of the
+		 * pointer (global_load / global_store: vmcnt only).  All of these pointers are hipMalloc'ed device memory.  (AGX_GLOBAL_VIEW = 0: plain.) */
+#ifndef AGX_GLOBAL_VIEW
+#define AGX_GLOBAL_VIEW 1
+#endif
+#if AGX_GLOBAL_VIEW
+		typedef __attribute__((address_space(1))) u64 global_u64;
+		__device__ __forceinline__ global_u64* global_view(u64 *p) { return (global_u64*) p; }
+		__device__ __forceinline__ const global_u64* global_view(const u64 *p) { return (const global_u64*) p; }
+#else
+		__device__ __forceinline__ u64* global_view(u64 *p) { return p; }
+		__device__ __forceinline__ const u64* global_view(const u64 *p) { return p; }
+#endif
+		/* The lane index as a value hipcc cannot see through.  Everything a function derives from the lane index (LDS addresses of per-lane
+		 * elements, masks, move encodings) is loop-invariant for the whole kernel, so the compiler computes all of it ONCE at the top — and at
+		 * 168 registers parks it in scratch: a one-instruction value then costs a scratch reload plus an s_waitcnt vmcnt(0) at its use (which also
+		 * waits for whatever prefetch is in flight), because LLVM does not rematerialise VALU results.  Used locally, right in front of the use,
+		 * the value is recomputed there and dies there.  (AGX_FRESH_LANE = 0: the plain lane index.) */
+#ifndef AGX_FRESH_LANE
+#define AGX_FRESH_LANE 1 /* (no scratch access left inside the solver's loop: ScratchSize 340 -> 224 B/lane, renju 672 -> 208; search launch 3.91 -> 3.87 ms) */
+#endif
+		__device__ __forceinline__ int fresh_lane(int lane)
+		{
+#if AGX_FRESH_LANE
+			asm volatile("" : "+v"(lane));
+#endif
+			return lane;
+		}
 		/* how many of the lanes BELOW this one are set in a ballot: v_mbcnt_lo / _hi, two instructions and no per-lane mask constant (the mask
 		 * ~0 >> (64 - lane) is a 64-bit lane-derived value that hipcc hoists to the top of the kernel and, at 168 registers, reloads from scratch
 		 * at every inlined use) */
@@ -628,7 +659,7 @@ namespace agx
 				{ // lane 40 parks the centre; every lane stores its word (one coalesced 512-byte store, nothing waits for it)
 					const u64 cw = *reinterpret_cast<const u64*>(&sh.ptype[center][0]);
 					const u64 centre_park = (cw & 0xFFFFFFFF0F0F0F0Full) | static_cast<u64>((static_cast<uint32_t>(c0) << 4) | (static_cast<uint32_t>(c1) << 12) | (1u << 20));
-					*snap_slot = (lane == 40) ? centre_park : park;
+					*global_view(snap_slot) = (lane == 40) ? centre_park : park;
 				}
 #endif
 				if (lane < 8)
@@ -740,7 +771,7 @@ namespace agx
 #if AGX_SNAPSHOT_UNDO
 			snap_slot = snap_address<SH>(snap_base, add ? stones : stones - 1, lane);
 			if (!add && !have_snap)
-				pf_snap = *snap_slot;
+				pf_snap = *global_view(snap_slot);
 #endif
 			if (lane < 4)
 			{
@@ -1077,6 +1108,7 @@ namespace agx
 		template<class SH>
 		__device__ __forceinline__ int act_find_move(const SH &sh, const uint32_t *spill, int begin, int end, uint32_t move, int lane)
 		{
+			lane = fresh_lane(lane);
 			for (int base = begin; base < end; base += 64)
 			{
 				const int j = base + lane;
@@ -1159,7 +1191,7 @@ for (int k = 0; k < 5; k++)
 				__device__ __forceinline__ int copy_list(int sign, int t)
 				{ // MoveGenerator::get_copy_of (:1174-1178)
 					const int cnt = count(sign, t);
-					for (int i = lane; i < cnt; i += 64)
+					for (int i = fresh_lane(lane); i < cnt; i += 64)
 						sh.tmp_list[i] = item(sign, t, i);
 					wave_sync();
 					return cnt;
@@ -1207,6 +1239,7 @@ for (int k = 0; k < 5; k++)
 						return;
 					}
 					// the cells of one threat list are distinct, so the not-yet-added ones can be appended in list order by all lanes at once
+					const int lane = fresh_lane(this->lane);
 					for (int base = 0; base < cnt; base += 64)
 					{
 						const int k = base + lane;
@@ -1375,6 +1408,7 @@ for (int k = 0; k < 5; k++)
 				__device__ __forceinline__ uint32_t stencil_row(const uint32_t *stencil, int which_sign) const
 				{
 					uint32_t m = 0;
+					const int lane = fresh_lane(this->lane);
 					if (lane < n)
 						for (int dr = -3; dr <= 3; dr++)
 						{
@@ -1397,6 +1431,7 @@ for (int k = 0; k < 5; k++)
 				}
 				__device__ __forceinline__ void create_remaining_moves(const uint32_t *mask, uint32_t score)
 				{ // :1127-1137 — row-major append; one row per lane, offsets by a wave prefix sum
+					const int lane = fresh_lane(this->lane);
 					uint32_t bits = (lane < n) ? (mask[lane] & (~sh.added[lane])) : 0u;
 					const int mine = __popc(bits);
 					int offset = static_cast<int>(wave_scan32_add(static_cast<uint32_t>(mine)));
@@ -1759,6 +1794,7 @@ for (int k = 0; k < 5; k++)
 							const int hr = half4.at(i) / n, hc = half4.at(i) % n;
 							int l = -1;
 							bool wanted = false;
+							const int lane = fresh_lane(this->lane);
 							if (lane < 36)
 							{
 								const int d = lane / 9, j = lane % 9 - 4;
@@ -1792,12 +1828,12 @@ for (int k = 0; k < 5; k++)
 							}
 						add_list(own, 3, s_unknown(13), false);
 						add_list(own, 2, s_unknown(1), false);
-						if (lane < n)
-							sh.row_mask[lane] = stencil_row(STENCIL_STAR, own);
+						if (fresh_lane(lane) < n)
+							sh.row_mask[fresh_lane(lane)] = stencil_row(STENCIL_STAR, own);
 						wave_sync();
 						for (int base = 0; base < n * n; base += 64)
 						{ // one cell per lane: inside the star mask, legal, not yet added, and a half-open three in some direction
-							const int cell = base + lane;
+							const int cell = base + fresh_lane(lane);
 							bool wanted = false;
 							if (cell < n * n)
 							{
@@ -1826,6 +1862,7 @@ for (int k = 0; k < 5; k++)
 				__device__ __forceinline__ void mark_neighborhood() const
 				{ // :1011-1071 -> sh.row_mask
 					uint32_t m = stencil_row(STENCIL_BOX, 0);
+					const int lane = fresh_lane(this->lane);
 					if (board_depth == 0 && lane == n / 2)
 						m |= (1u << (n / 2));
 					if (lane < n)
@@ -1847,8 +1884,8 @@ for (int k = 0; k < 5; k++)
 					const int distance_to_draw = E.draw_after - board_depth;
 					if (distance_to_draw <= 0)
 						return s_make(1, 0);
-					if (lane < n)
-						sh.added[lane] = 0; // one row per lane (LDS runs a wave's accesses in issue order: the generator's later reads see it)
+					if (fresh_lane(lane) < n)
+						sh.added[fresh_lane(lane)] = 0; // one row per lane (LDS runs a wave's accesses in issue order: the generator's later reads see it)
 					sh.foul_count = 0;
 					uint32_t result = s_unknown(0);
 					bool go = true;
@@ -1906,6 +1943,7 @@ for (int k = 0; k < 5; k++)
 		__device__ __forceinline__ int ov_find(const SH &sh, uint32_t bucket, int lane)
 		{ // slot of `bucket` or -1: the keys are searched 64 per step, one per lane
 			const int cnt = sh.ov_count;
+			lane = fresh_lane(lane);
 			for (int base = 0; base < cnt; base += 64)
 			{
 				const u64 m = __ballot(base + lane < cnt && sh.ov_keys[base + lane] == bucket);
@@ -1925,7 +1963,7 @@ for (int k = 0; k < 5; k++)
 				return -1;
 			}
 			if (lane < 16)
-				sh.ov_data[p * 16 + lane] = word; // lanes 0-7: first-touch copy, lanes 8-15 (same words): working copy
+				global_view(sh.ov_data)[p * 16 + lane] = word; // lanes 0-7: first-touch copy, lanes 8-15 (same words): working copy
 			if (lane == 0)
 			{
 				sh.ov_keys[p] = bucket;
@@ -2016,7 +2054,7 @@ for (int k = 0; k < 5; k++)
 			value |= (lo & KEY);
 			u64 word = 0;
 			if (lane < 8)
-				word = bucket[lane];
+				word = global_view(bucket)[lane];
 			const uint32_t score = static_cast<uint32_t>((value >> 16) & 65535u);
 			int idx = -1;
 			if (s_proven(score) || (value & 3ull) == 3ull)
@@ -2033,7 +2071,7 @@ for (int k = 0; k < 5; k++)
 				if (w3 < best) { best = w3; idx = 3; }
 			}
 			if (lane < 2)
-				bucket[2 * idx + lane] = (lane == 0) ? hi : value;
+				global_view(bucket)[2 * idx + lane] = (lane == 0) ? hi : value;
 		}
 
 		/* AlphaBetaSearch::evaluate (AlphaBetaSearch.cpp:345-365) */
@@ -2109,7 +2147,7 @@ for (int k = 0; k < 5; k++)
 							const uint32_t bucket = static_cast<uint32_t>(hash_lo & E.tt_bucket_mask);
 							int slot = have_pf ? sh.pf_slot : ov_find(sh, bucket, lane);
 							if (!have_pf && lane < 16)
-								pf_word = (slot >= 0) ? sh.ov_data[slot * 16 + 8 + (lane & 7)] : tt[8 * static_cast<u64>(bucket) + (lane & 7)];
+								pf_word = (slot >= 0) ? global_view(sh.ov_data)[slot * 16 + 8 + (lane & 7)] : global_view(tt)[8 * static_cast<u64>(bucket) + (lane & 7)];
 							if (slot < 0)
 								slot = ov_create(sh, bucket, pf_word, lane);
 							f.ov_slot = static_cast<uint32_t>(slot);
@@ -2248,7 +2286,7 @@ for (int k = 0; k < 5; k++)
 						else if (f.size - f.i <= 64)
 						{ // first maximum of the remaining actions, one per lane: the key is (score, lowest index), one DPP reduction picks the
 						  // winner, and the two entries that trade places come out of the lanes' registers (one LDS round trip, not four)
-							const int j = f.i + lane;
+							const int j = f.i + fresh_lane(lane);
 							const uint32_t mine = (j < f.size) ? act_get(sh, act, f.base + j) : 0u;
 							uint32_t key = (j < f.size) ? (((mine >> 16) << 16) | static_cast<uint32_t>(0xFFFF - j)) : 0u;
 							key = wave_reduce_umax(key);
@@ -2320,7 +2358,7 @@ for (int k = 0; k < 5; k++)
 									const uint32_t bucket = static_cast<uint32_t>(hash_lo & E.tt_bucket_mask);
 									const int slot = ov_find(sh, bucket, lane);
 									if (lane < 16)
-										pf_word = (slot >= 0) ? sh.ov_data[slot * 16 + 8 + (lane & 7)] : tt[8 * static_cast<u64>(bucket) + (lane & 7)];
+										pf_word = (slot >= 0) ? global_view(sh.ov_data)[slot * 16 + 8 + (lane & 7)] : global_view(tt)[8 * static_cast<u64>(bucket) + (lane & 7)];
 									sh.pf_slot = slot;
 								}
 								else if (lane < 8)
@@ -2373,7 +2411,7 @@ for (int k = 0; k < 5; k++)
 					{ // the stone of the parent's move comes off next: its pattern entries travel while the table is updated
 						const uint32_t umv = frame_get(sh, level - 1).move;
 #if AGX_SNAPSHOT_UNDO && AGX_SNAPSHOT_PREFETCH
-						pf_snap = *snap_address<SH>(sh.snap, sh.depth - 1, lane); // what this node's stone overwrote (solver_update_around)
+						pf_snap = *global_view(snap_address<SH>(sh.snap, sh.depth - 1, lane)); // what this node's stone overwrote (solver_update_around)
 						pf_pattern_tag = static_cast<int>(umv);
 #elif !AGX_SNAPSHOT_UNDO
 						pf_pattern = pattern_prefetch(sh, E, n, umv, false, lane);

@@ -5,7 +5,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 ROWS = [("", "C2 default, 6000 steps"), ("_driver_window_20_steps", "driver window"), ("_driver_window_slices_in_phase", "window, --stagger 0"),
         ("_serial_solver", "serial solver"), ("_trained_like_policy", "trained-like"), ("_c3_standard_10x128_800", "C3"), ("_c4_caro5_20x20", "C4"),
         ("_c5_renju_1600", "C5"), ("_soak_30000_steps", "soak"), ("_2_ranks_on_one_gpu", "2 ranks / 1 GPU"), ("_8_ranks_on_one_gpu", "8 ranks / 1 GPU"),

@@ -1,6 +1,6 @@
 #!/bin/bash
 # the round's bench lines and profiles (run through gpurun from the repo root); copies go to profiles/<tag>_*
-tag=${1:-r04}
+tag=${1:-r05}
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 python bench.py > gpurun_out/${tag}_bench_line.json 2> gpurun_out/${tag}_bench_line.err

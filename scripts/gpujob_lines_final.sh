@@ -3,7 +3,7 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-tag=r04
+tag=r05
 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --stagger 0 > gpurun_out/${tag}_bench_line_driver_window_slices_in_phase.json 2>/dev/null
 python bench.py --config C3 --steps 3000 --no-cpu-baseline > gpurun_out/${tag}_bench_line_c3_standard_10x128_800.json 2>/dev/null
 python bench.py --config C4 --steps 3000 --no-cpu-baseline > gpurun_out/${tag}_bench_line_c4_caro5_20x20.json 2>/dev/null

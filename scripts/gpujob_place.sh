@@ -8,8 +8,8 @@ timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VM
 echo "place_pmc run: $?"
 find gpurun_out/place_pmc -name "*.db" | head
 db=$(find gpurun_out/place_pmc -name "*_results.db" | head -1)
-python3 scripts/place_pmc.py summary "$db" gpurun_out/r04_place_pmc.json
+python3 scripts/place_pmc.py summary "$db" gpurun_out/r05_place_pmc.json
 rm -rf gpurun_out/place_pmc
-timeout 600 python3 bench.py --steps 40 --warmup 30 --age-steps 0 --no-cpu-baseline > gpurun_out/r04_pmc_workload_line.json 2> gpurun_out/r04_pmc_workload_line.err
+timeout 600 python3 bench.py --steps 40 --warmup 30 --age-steps 0 --no-cpu-baseline > gpurun_out/r05_pmc_workload_line.json 2> gpurun_out/r05_pmc_workload_line.err
 echo "workload line: $?"
-head -c 600 gpurun_out/r04_pmc_workload_line.json
+head -c 600 gpurun_out/r05_pmc_workload_line.json

@@ -3,7 +3,7 @@
 #   gpurun_out/<tag>_trace   rocprofv3 --kernel-trace --stats          -> profiles/<tag>_bench_kernel_stats.csv (scripts/prof_summary.py)
 #   gpurun_out/<tag>_pmc_*   rocprofv3 --pmc, one pass per counter set -> profiles/<tag>_pmc_summary.json       (scripts/pmc_bench_summary.py)
 # Counters are collected in their own runs (no tracing flags besides the kernel trace the tool adds itself).
-tag=${1:-r04}
+tag=${1:-r05}
 steps=${2:-300}
 extra="${4:-}"   # e.g. "--config C4": the same passes for another BASELINE configuration (tag r03_c4)
 cd /tmp && export TMPDIR=/tmp

@@ -3,7 +3,7 @@
 # -DAGX_SOLVER_PROFILE -DAGX_SPEC_PROFILE (scripts/build_engine_variant.sh P "..."); the profile lines go to stderr at agx_engine_stats.
 # usage: scripts/solver_profile.sh TAG [bench args]
 cd "$(dirname "$0")/.."
-tag=${1:-r04}; shift
+tag=${1:-r05}; shift
 mkdir -p gpurun_out
 cp alphagomoku_amd/libagx.so /tmp/libagx_keep.so
 cp alphagomoku_amd/libagx_P.so alphagomoku_amd/libagx.so
