@@ -750,7 +750,7 @@ namespace ag
 		// pacing only, per-game results do not depend on either: the leaves of a batch solved in parallel (k_search_spec), stragglers of a
 		// launch put off to the next one
 		c.speculative_solver = 1;
-		c.solver_yield_fraction = (games >= 64) ? 0.6f : 0.0f;   // (swept 0.3 .. 0.9 on the 1024-game pool: 0.5-0.6 is the flat optimum)
+		c.solver_yield_fraction = (games >= 64) ? 0.5f : 0.0f;   // (swept 0.3 .. 0.8 on the 1024-game pool, round 5 with 16 solver waves per unit: 0.4-0.5 best)
 		if (searchBuffers == 2)
 		{ // records 0 and 1 are the two task buffers of the one tree (stepped as group 0 / 1 of 2)
 			c.n_games = 2;

@@ -239,8 +239,11 @@ namespace agx
 				static constexpr int SELECT_KEY_BYTES = 3 * (1 + HW) * 8;
 				// (round 3, late: 20x20 had 2112 entries + 42 frames only to give the select stage's keys room in act + frames — 20.5 KB per wave,
 				// 7 waves per compute unit; the keys now run on over ptype / threat / items, which a select does not use either: 16.4 KB, 10 waves)
-				static constexpr int ACT_LDS = 1024;
-				static constexpr int FRAMES = (N <= 15) ? 42 : 34; // alpha-beta frames kept in LDS (LDS_FRAMES at most); deeper ones live in HBM
+				// (round 5, late: 15x15 boards keep 448 action-stack entries and 30 frames in LDS instead of 1024 and 42 — 12 928 -> 10 240 bytes per wave,
+				// SIXTEEN waves per compute unit instead of twelve: a slice's ~1 900 leaves are then two rounds of solves on its 1 024 waves, not 2.47 -> three
+				// on 768; a 100-node solve's stack stays below 448 entries and 30 levels nearly always, the tails go to HBM as before)
+				static constexpr int ACT_LDS = (N <= 15) ? 448 : 1024;
+				static constexpr int FRAMES = (N <= 15) ? 30 : 34; // alpha-beta frames kept in LDS (LDS_FRAMES at most); deeper ones live in HBM
 				__device__ static constexpr int list_cap(int t) { return (t == 2) ? CAP2 : CAP; }
 				__device__ static constexpr int list_off(int t) { return (t == 2) ? 0 : CAP2 + (t - 3) * CAP; }
 
@@ -291,6 +294,9 @@ namespace agx
 				int cmd, result_score;
 		};
 		typedef SolverSharedT<MAXN> SolverShared; // any board size
+#if !defined(AGX_SOLVER_PROFILE)
+		static_assert(sizeof(SolverSharedT<15>) <= 10240, "15x15 solver state: sixteen waves per compute unit (160 KB of LDS)");
+#endif
 
 		/* Threat-list entries: LDS below the list's capacity, the game's HBM spill area above it.  As with the action stack the two paths
 		 * stay two different instructions (inline assembly), or hipcc merges them into FLAT accesses. */

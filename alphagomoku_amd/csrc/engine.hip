@@ -780,10 +780,16 @@ namespace
 #define SPEC_WAVE_EXIT() do { } while (0)
 #endif
 #ifndef AGX_SPEC_WAVES
-#define AGX_SPEC_WAVES 3 /* waves per SIMD the register allocation of k_search_spec leaves room for (LDS: 12 waves per compute unit at 15x15) */
+#define AGX_SPEC_WAVES 3 /* waves per SIMD the register allocation of k_search_spec leaves room for on boards whose LDS state allows 9-12 waves per compute unit */
 #endif
+#ifndef AGX_SPEC_WAVES_15
+#define AGX_SPEC_WAVES_15 4 /* ... and on 15x15 boards (10 240 bytes of LDS state: 16 waves per compute unit): 128 registers.  Measured (profiles/r05_search_variants_ab.txt,
+                               boxes 11-12): the spills of the tighter allocation sit outside the solver's loops (69 scratch instructions in the whole kernel) and cost
+                               nothing — at 12 waves per unit the 128-register kernel is as fast as the 168-register one —, and with 16 the launch is 8.6 % shorter */
+#endif
+	constexpr int spec_waves_per_simd(int nfix) { return (nfix == 15) ? AGX_SPEC_WAVES_15 : AGX_SPEC_WAVES; }
 	template<bool RENJU, int NFIX>
-	__global__ __launch_bounds__(64, AGX_SPEC_WAVES) void k_search_spec(EngineDev E, int count)
+	__global__ __launch_bounds__(64, spec_waves_per_simd(NFIX)) void k_search_spec(EngineDev E, int count)
 	{
 		if (NFIX != 0)
 		{
@@ -2966,6 +2972,36 @@ int agx_engine_default_config(AgxEngineConfig *cfg)
 	return AGX_OK;
 }
 
+#if defined(AGX_QUICK) && !defined(AGX_QUICK_RENJU)
+#define AGX_QUICK_RENJU false /* developer builds (AGX_QUICK: only the 15x15 solver is instantiated); -DAGX_QUICK_RENJU=true: the renju solver instead of the other rules' */
+#endif
+/* the instantiation of k_search_spec a pool of these rules and board size launches */
+typedef void (*SpecKernel)(EngineDev, int);
+static SpecKernel spec_kernel(int rules, int n)
+{
+#ifdef AGX_QUICK
+	(void) rules;
+	(void) n;
+	return k_search_spec<AGX_QUICK_RENJU, 15>;
+#else
+	if (rules == AGX_RENJU)
+		return (n == 15) ? k_search_spec<true, 15> : k_search_spec<true, 0>;
+	if (n == 15)
+		return k_search_spec<false, 15>;
+	return (n == 20) ? k_search_spec<false, 20> : k_search_spec<false, 0>;
+#endif
+}
+/* how many of its one-wave workgroups a compute unit keeps resident (LDS state and registers of that instantiation; asked of the runtime, 12 if it will not say) */
+static int spec_resident_waves_per_cu(int rules, int n)
+{
+	int blocks = 0;
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, reinterpret_cast<const void*>(spec_kernel(rules, n)), 64, 0) != hipSuccess || blocks <= 0)
+	{
+		(void) hipGetLastError();
+		return 12;
+	}
+	return blocks;
+}
 int agx_engine_create(const AgxEngineConfig *cfg, AgxEngine **out)
 {
 	AGX_REQUIRE(cfg != nullptr && out != nullptr, AGX_ERR_INVALID, "agx_engine_create: null argument");
@@ -3068,8 +3104,10 @@ int agx_engine_create(const AgxEngineConfig *cfg, AgxEngine **out)
 		int cus = 0, device_of_engine = 0;
 		(void) hipGetDevice(&device_of_engine);
 		(void) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_of_engine);
-		// default: 12 waves per compute unit, but no more than one per leaf of a full batch (a one-tree engine has a few dozen leaves per launch)
-		e->spec_waves = (cfg->speculative_waves > 0) ? cfg->speculative_waves : std::min<long long>(12 * std::max(1, cus), std::max<long long>(64, static_cast<long long>(G) * cfg->max_batch_size));
+		// default: as many waves as the launch's kernel keeps resident (16 per compute unit on 15x15 boards, 10 on 20x20: its LDS state and registers), but
+		// no more than one per leaf of a full batch (a one-tree engine has a few dozen leaves per launch)
+		const int per_cu = spec_resident_waves_per_cu(cfg->rules, cfg->board_size);
+		e->spec_waves = (cfg->speculative_waves > 0) ? cfg->speculative_waves : std::min<long long>(static_cast<long long>(per_cu) * std::max(1, cus), std::max<long long>(64, static_cast<long long>(G) * cfg->max_batch_size));
 		e->spec_waves = std::min(e->spec_waves, SPEC_QUEUE_SLACK);
 	}
 	// (a group's waves take the areas n_games + group * waves + wave with waves = max(1, spec_waves / n_groups): at least one area per possible group)
@@ -3269,9 +3307,6 @@ static int group_range(const AgxEngine *e, int group, int n_groups, EngineDev &d
 static constexpr int CLEAR_PARTS = 16; // workgroups per restarting game in k_clear_tables
 
 #ifdef AGX_QUICK /* developer builds: only the 15x15 non-renju solver is instantiated (a fifth of the compile time) */
-#ifndef AGX_QUICK_RENJU
-#define AGX_QUICK_RENJU false /* -DAGX_QUICK_RENJU=true: the developer build instantiates the renju solver instead */
-#endif
 #define AGX_LAUNCH_SOLVE(FUSED) hipLaunchKernelGGL((k_solve<AGX_QUICK_RENJU, 15, FUSED>), grid, block, 0, s, d)
 #else
 #define AGX_LAUNCH_SOLVE(FUSED) \
@@ -3306,23 +3341,7 @@ static void launch_search_spec(EngineDev d, int count, int group, int waves, hip
 	d.spec_group = group;
 	d.spec_waves = waves;
 	const dim3 grid(waves), block(64);
-#ifdef AGX_QUICK
-	hipLaunchKernelGGL((k_search_spec<AGX_QUICK_RENJU, 15>), grid, block, 0, s, d, count);
-#else
-	if (d.rules == AGX_RENJU)
-	{
-		if (d.n == 15)
-			hipLaunchKernelGGL((k_search_spec<true, 15>), grid, block, 0, s, d, count);
-		else
-			hipLaunchKernelGGL((k_search_spec<true, 0>), grid, block, 0, s, d, count);
-	}
-	else if (d.n == 15)
-		hipLaunchKernelGGL((k_search_spec<false, 15>), grid, block, 0, s, d, count);
-	else if (d.n == 20)
-		hipLaunchKernelGGL((k_search_spec<false, 20>), grid, block, 0, s, d, count);
-	else
-		hipLaunchKernelGGL((k_search_spec<false, 0>), grid, block, 0, s, d, count);
-#endif
+	hipLaunchKernelGGL(spec_kernel(d.rules, d.n), grid, block, 0, s, d, count);
 }
 static void launch_solve(const EngineDev &d, int count, hipStream_t s, bool with_select = false)
 {
@@ -3833,6 +3852,12 @@ int agx_engine_set_max_simulations(AgxEngine *e, int max_simulations)
 	AGX_REQUIRE(e != nullptr && max_simulations > 0, AGX_ERR_INVALID, "agx_engine_set_max_simulations: invalid argument");
 	e->dev.max_sims = max_simulations;
 	e->cfg.max_simulations = max_simulations;
+	return AGX_OK;
+}
+int agx_engine_speculative_waves(AgxEngine *e, int *waves)
+{
+	AGX_REQUIRE(e != nullptr && waves != nullptr, AGX_ERR_INVALID, "agx_engine_speculative_waves: null argument");
+	*waves = e->speculative ? e->spec_waves : 0;
 	return AGX_OK;
 }
 int agx_engine_device_bytes(AgxEngine *e, unsigned long long *bytes)

@@ -275,6 +275,12 @@ class GeneratorPool:
         check(lib.agx_engine_device_bytes(self._h, ctypes.byref(n)))
         return int(n.value)
 
+    def speculative_waves(self):
+        """waves of the speculative search launch over the whole pool (agx_engine_speculative_waves); 0 = serial solver"""
+        n = ctypes.c_int()
+        check(lib.agx_engine_speculative_waves(self._h, ctypes.byref(n)))
+        return int(n.value)
+
     def stats(self):
         check(lib.agx_device_synchronize())
         s = AgxEngineStats()

@@ -165,15 +165,15 @@ def main():
     ap.add_argument("--rules", type=int, default=0)
     ap.add_argument("--action-values", type=int, default=0, help="1: ResnetPVQ network (extra action-values head feeding the edge Q)")
     ap.add_argument("--table-entries", type=int, default=4 * 1024 * 1024)
-    ap.add_argument("--yield-fraction", type=float, default=0.6,
+    ap.add_argument("--yield-fraction", type=float, default=0.5,
                     help="straggler cut-off of the search launch: once this fraction of its games is done, a game whose batch still needs a serial re-run\n"
                          "(speculative solver) or another serial solve sits this step out (0 = never).  Pacing only, the games are the same; measured on\n"
-                         "one box (profiles/r03_sweep_yield_fraction.txt): 0.3 785 k, 0.5 796 k, 0.6 796 k, 0.7 790 k, 0.8 765 k, 0.85 752 k, 0.9 744 k")
+                         "one box (profiles/r05_sweep_yield_fraction.txt, 16 solver waves per compute unit): 0.3 956 k, 0.4 964 k, 0.5 964 k, 0.6 935 k, 0.7 906 k, 0.8 902 k")
     ap.add_argument("--slices", type=int, default=4,
                     help="the pool stepped as this many slices on streams that own disjoint blocks of the chip's compute units (1 = one lock-step pool)")
     ap.add_argument("--speculative", type=int, default=1,
                     help="1: select + threat solver as one persistent launch with the leaves of a batch solved in parallel (AgxEngineConfig.speculative_solver)")
-    ap.add_argument("--speculative-waves", type=int, default=0, help="waves of that launch over the whole pool, 0 = 12 per compute unit")
+    ap.add_argument("--speculative-waves", type=int, default=0, help="waves of that launch over the whole pool, 0 = as many as stay resident (16 per compute unit on 15x15 boards, 10 on 20x20)")
     ap.add_argument("--config", default="", help="BASELINE.json preset: C2 (the default), C3 (standard, 10x128, 800 playouts: with --gpus 8 = configs[2]), "
                                                  "C4 (caro5 20x20, 10x128), C5 (renju, 10x128, 1600 playouts)")
     ap.add_argument("--age-steps", type=int, default=-1,
@@ -186,6 +186,9 @@ def main():
                     help="> 0: the chip as two partitions shared by all slices — this many compute units run every slice's network launches, the rest "
                          "every slice's search launches (streams ordered by events); 0: every slice owns 1 / slices of the chip for all its stages")
     ap.add_argument("--tree-cus", type=int, default=0, help="with --network-cus: compute units set aside for the expand / advance launches")
+    ap.add_argument("--tree-on-network", type=int, default=0,
+                    help="with --network-cus: 1 = the expand / advance launches follow the tower on the network partition's stream (the search partition then "
+                         "holds nothing but persistent search launches: the next slice's waves move in as the previous launch's leave)")
     ap.add_argument("--share-cus", type=int, default=1,
                     help="the co-resident pairing experiment: this many slices share one block of compute units (e.g. --slices 8 --share-cus 2 = four "
                          "blocks of 64 CUs with two half-slices each, whose search and network launches may overlap on the same units; needs a tower "
@@ -337,12 +340,14 @@ def main():
         if nn_timer is not None:
             check(lib.agx_timer_stop(nn_timer, ns))
         ts = streams[g]
-        if net_streams is not None:
+        if net_streams is not None and args.tree_on_network:
+            ts = ns   # (behind the tower on its own stream: no event in between)
+        elif net_streams is not None:
             ts = tree_streams[g] if tree_streams is not None else streams[g]
             check(lib.agx_event_record(events[3 * g + 1], ns))
             check(lib.agx_stream_wait_event(ts, events[3 * g + 1]))
         pool.expand_backup_group(g, slices, ts)
-        if tree_streams is not None:   # the slice's next search launch waits for its tree launches
+        if ts is not streams[g]:   # the slice's next search launch waits for its tree launches
             check(lib.agx_event_record(events[3 * g + 2], ts))
             check(lib.agx_stream_wait_event(streams[g], events[3 * g + 2]))
 
@@ -487,7 +492,7 @@ def main():
                 nn_clock = pmc.get("nn_tower_shader_clock_mhz")
         cu_total = ctypes.c_int()
         check(lib.agx_device_cu_count(ctypes.byref(cu_total)))
-        spec_waves_per_launch = max(1, (args.speculative_waves if args.speculative_waves > 0 else 12 * cu_total.value) // slices)
+        spec_waves_per_launch = max(1, pool.speculative_waves() // slices)
         gpu_ms = kernel_ms[0] + kernel_ms[1] + kernel_ms[2] + kernel_ms[3] + ms_nn
         search_kernel = "k_search_spec" if args.speculative else "k_solve"   # the launch timed as the solve stage
         per_kernel = {"k_select": kernel_ms[0], search_kernel: kernel_ms[1], "nn_tower": ms_nn, "k_expand": kernel_ms[2], "k_advance": kernel_ms[3]}
@@ -569,7 +574,7 @@ def main():
                          # only runs part of each slice's cycle; the search kernels use no MFMA)
                          "time_averaged_whole_chip_frac": (evals / elapsed) * flops / 2.5e15 / world,
                          "pmc_summary_build": pmc_build},
-            "roofline_solver": {"bound": ("none (instruction issue of the solver waves: 3 per SIMD, the leaves of a batch in parallel)" if args.speculative
+            "roofline_solver": {"bound": ("none (instruction issue of the solver waves: %d per SIMD, the leaves of a batch in parallel)" % (4 if args.board <= 15 else 3) if args.speculative
                                           else "none (instruction issue / dependent-chain latency: one wave per game, tasks of a game strictly ordered)"),
                                 "kernel": ("k_search_spec (select + speculative threat solver + commit, one persistent launch)" if args.speculative else
                                            ("k_solve (select + threat solver of a game in one wave)" if os.environ.get("AGX_FUSE_SELECT", "1") != "0" else "k_solve")),

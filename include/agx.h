@@ -195,11 +195,12 @@ typedef struct AgxEngineConfig
 	                                     leaves of a game's batch are solved in PARALLEL, each wave against the game's transposition table as it was
 	                                     before the batch (every touched bucket copied into a per-task overlay), and committed in batch order; a task
 	                                     that saw a bucket an earlier task of the batch changed is solved again serially — results are bit-identical
-	                                     to the serial order of Search::solve (Search.cpp:159-183), the solver runs with 3 waves per SIMD instead of
+	                                     to the serial order of Search::solve (Search.cpp:159-183), the solver runs with 3-4 waves per SIMD instead of
 	                                     one wave per game.  0 (default): one wave per game, tasks in order.  Tournament-search pools (search_threads > 1)
 	                                     take the speculative launch too; ignored for solver budgets above 250 positions (the overlay
 	                                     holds 256 buckets) and batches above 16. */
-	int speculative_waves;            /* waves of that launch over the whole pool, 0 = 12 per compute unit of the device */
+	int speculative_waves;            /* waves of that launch over the whole pool, 0 = as many as stay resident: 16 per compute unit of the device on 15x15
+	                                     boards, 10 on 20x20 (agx_engine_speculative_waves reports the number in use) */
 	int force_expand_root;            /* UnifiedGenerator's forceExpandRoot (EdgeGenerator.cpp:283-285): 1 (default, self-play: GameGenerator.cpp:183-184)
 	                                     never prunes the root's edges; 0 prunes the root like any node (evaluation Player, Player.cpp:109; match_mode
 	                                     engines always do) */
@@ -428,6 +429,9 @@ int agx_engine_stats(AgxEngine* engine, AgxEngineStats* out);
  * game —, task / exchange buffers, the solver's spill areas and undo snapshots, record pools).  What one rank of a multi-GPU job needs of its
  * GPU's HBM next to the network's weights (GeneratorManager.cpp:146-152: one generator thread, i.e. one such pool, per device). */
 int agx_engine_device_bytes(AgxEngine* engine, unsigned long long* bytes);
+/* Waves of the speculative search launch over the whole pool (AgxEngineConfig.speculative_waves, or the default resolved for this device, rules and
+ * board); 0 when the pool runs the serial solver.  A group's launch takes waves / n_groups of them. */
+int agx_engine_speculative_waves(AgxEngine* engine, int* waves);
 /* Per-kernel timing of the engine's own launches, by HIP events recorded on the launch stream around every kernel (the role of
  * SearchStats' TimedStat members, search/monte_carlo/Search.hpp, for the device kernels).  Synchronises the device, returns the
  * time and launch count accumulated since the previous call in ms_out[4] / launches_out[4] (0 k_select, 1 k_solve, 2 k_expand,

@@ -220,7 +220,7 @@ namespace agx
 				// pacing only, per-game results do not depend on either (agx.h): the leaves of a batch solved in parallel, a launch's stragglers
 				// put off to the next launch
 				c.speculative_solver = 1;
-				c.solver_yield_fraction = (c.n_games >= 64) ? 0.6f : 0.0f;
+				c.solver_yield_fraction = (c.n_games >= 64) ? 0.5f : 0.0f;
 				if (game.rows != game.cols)
 					throw std::logic_error("GeneratorPool: only square boards are supported");
 				check(agx_engine_create(&c, &m_engine));
