@@ -116,7 +116,7 @@ class AgxEngineStats(ctypes.Structure):
                  "peak_edges"]] + [(n, ctypes.c_int) for n in
                                    ["games_finished", "openings_taken", "active_games", "records_used", "record_edges_used",
                                     "first_error", "arena_grows", "arena_releases", "arena_failures", "arena_max_class"]] + \
-               [("arena_heap_used", ctypes.c_float), ("reserved0", ctypes.c_int), ("speculative_solves", ctypes.c_ulonglong),
+               [("arena_heap_used", ctypes.c_float), ("speculative_parks", ctypes.c_int), ("speculative_solves", ctypes.c_ulonglong),
                 ("speculative_reruns", ctypes.c_ulonglong), ("speculative_deferrals", ctypes.c_ulonglong)]
 
 

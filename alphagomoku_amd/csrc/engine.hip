@@ -237,16 +237,145 @@ namespace
 	/* Where a solve keeps what does not fit into LDS: `area` indexes the per-game spill areas (the game itself, or for speculative solves —
 	 * several tasks of one game at once — the wave's own area behind the games'); `overlay` != nullptr makes the solve speculative
 	 * (dev_solver.hpp: the table is only read, every touched bucket lives in the overlay). */
+	/*
+	 * Parking (round 5).  A launch of k_search_spec ends when its last solve does, and a few solves per launch run several times the
+	 * average (renju: positions whose move generation tests dozens of cells for fouls — 0.5 % of the leaves take 5-9 ms against 1.7 on average,
+	 * profiles/r05_c5_search_launch_timeline.txt): the compute units of the slice idle for half the launch behind a handful of waves.  Once
+	 * SPEC_PARK_FRACTION of the launch's games are done and the queue has run dry, a speculative solve that is still running is PARKED at its
+	 * next command boundary: the solver's LDS state (everything the frame machine needs: it already yields to the caller for every stone) goes
+	 * into a park buffer, the in-use parts of the wave's HBM tails (undo snapshots, action stack / frame / list tails) into the buffer's own
+	 * spill area, the game sits this step out like a game whose commit was deferred (solve_pending), and the next launch — which queues the
+	 * game's unsolved leaves as it does for a deferred game — finds the task's park buffer and takes the solve up where it stopped, in any
+	 * wave.  The solve's result cannot depend on it: the machine continues from the same state against the same table (the game's table is not
+	 * written while its batch is in flight).  A solve is parked at most once (it then has a whole launch in front of it), and only when a
+	 * buffer is free.  Pacing only, like the yield rule.
+	 */
+	constexpr float SPEC_PARK_FRACTION = 0.90f; // (C5 on one box: 0.80 484 k, 0.86 511 k, 0.90 520 k, 0.94 469 k, 0.97 406 k simulations/s; without parking 408 k)
+	struct ParkCtl
+	{
+			int count;     // games of the launch
+			int threshold; // games done from which running solves are parked (0x7FFFFFFF: never)
+	};
+	/* what a solve keeps in spill area `from`, copied to area `to`: the parts in use (or a superset of them) */
+	template<class SH>
+	__device__ __forceinline__ void park_copy_tails(const SH &sh, const EngineDev &E, int from, int to, int lane)
+	{
+		lane = fresh_lane(lane); // (cold code: none of its per-lane addresses is to be computed at the top of the kernel and kept in registers or scratch)
+		{ // undo snapshots: one 512-byte level per stone on the board
+			const u64 *a = E.snap_spill + static_cast<size_t>(from) * (E.hw + 2) * 64;
+			u64 *b = E.snap_spill + static_cast<size_t>(to) * (E.hw + 2) * 64;
+			const int words = min(sh.depth, E.hw + 2) * 64;
+			for (int i = lane; i < words; i += 64)
+				b[i] = a[i];
+		}
+		{ // action stack beyond its LDS part
+			const uint32_t *a = E.act + static_cast<size_t>(from) * E.act_cap;
+			uint32_t *b = E.act + static_cast<size_t>(to) * E.act_cap;
+			const int top = min(sh.stack_max, E.act_cap);
+			for (int i = SH::ACT_LDS + lane; i < top; i += 64)
+				b[i] = a[i];
+		}
+		{ // frames beyond the LDS-resident ones (32 bytes each)
+			const u64 *a = reinterpret_cast<const u64*>(E.frame_spill) + static_cast<size_t>(from) * MAX_FRAMES * 4;
+			u64 *b = reinterpret_cast<u64*>(E.frame_spill) + static_cast<size_t>(to) * MAX_FRAMES * 4;
+			const int top = min(sh.level + 2, MAX_FRAMES) * 4;
+			for (int i = SH::FRAMES * 4 + lane; i < top; i += 64)
+				b[i] = a[i];
+		}
+		{ // threat-list entries beyond a list's LDS capacity
+			const uint16_t *a = E.list_spill + static_cast<size_t>(from) * 20 * MAXHW;
+			uint16_t *b = E.list_spill + static_cast<size_t>(to) * 20 * MAXHW;
+			for (int st = 0; st < 20; st++)
+			{
+				const int side = st / 10, type = st % 10;
+				if (type < 2)
+					continue;
+				const int cnt = sh.count[side][type];
+				for (int i = SH::list_cap(type) + lane; i < cnt; i += 64)
+					b[st * SH::HW + i] = a[st * SH::HW + i];
+			}
+		}
+	}
+	template<class SH>
+	__device__ __forceinline__ void park_point_tails_at(SH &sh, const EngineDev &E, int area)
+	{ // HBM tails of the LDS-resident threat lists and frames (dev_solver.hpp: list_get / frame_get), undo snapshots (lane 0)
+		sh.spill_lists = E.list_spill + static_cast<size_t>(area) * 20 * MAXHW; // (stride of list_get / list_set: SolverSharedT::HW <= MAXHW whatever the kernel instantiation)
+		sh.spill_frames = reinterpret_cast<Frame*>(E.frame_spill) + static_cast<size_t>(area) * MAX_FRAMES;
+		sh.snap = E.snap_spill + static_cast<size_t>(area) * (E.hw + 2) * 64; // undo snapshots, one level per stone on the board (dev_solver.hpp)
+	}
+	/* every lane: is it time to park (wave-uniform result)?  One counter read while the launch is busy, three more once the threshold is reached. */
+	__device__ __forceinline__ bool park_wanted(const EngineDev &E, const ParkCtl &p, int lane)
+	{
+		const int *c_done = E.counters + E.yield_counter;                 // games of the launch that are done with their batch
+		const int *c_queue = E.counters + SPEC_COUNTER0 + 4 * E.spec_group; // [0] select cursor, [1] queue head, [2] queue tail, [3] games selected
+		int yes = 0;
+		if (lane == 0 && __hip_atomic_load(c_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= p.threshold)
+			yes = (__hip_atomic_load(c_queue + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= p.count
+					&& __hip_atomic_load(c_queue + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= __hip_atomic_load(c_queue + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) ? 1 : 0;
+		return __builtin_amdgcn_readfirstlane(yes) != 0;
+	}
+	/* claims a free park buffer for task `slot` (every lane gets the same answer: the buffer's index, or -1) */
+	__device__ __forceinline__ int park_claim(const EngineDev &E, int slot, int lane)
+	{
+		int b = -1;
+		if (lane == 0)
+			for (int probe = 0; probe < 8 && b < 0; probe++)
+			{
+				const int i = (slot * 7 + probe * 13) & (SPEC_PARK_POOL - 1);
+				if (atomicCAS(&E.park_owner[i], 0, slot + 1) == 0)
+					b = i;
+			}
+		return __builtin_amdgcn_readfirstlane(b);
+	}
+	/* forgets what game g has parked (the game is restarted, its board set from outside, its pending batch cancelled): lane 0 / one thread */
+	__device__ __forceinline__ void park_forget_game(const EngineDev &E, int g)
+	{
+		for (int k = 0; k < E.batch; k++)
+		{
+			const int b = E.park_slot[g * E.batch + k];
+			if (b != 0)
+			{
+				E.park_slot[g * E.batch + k] = 0;
+				__hip_atomic_store(&E.park_owner[b - 1], 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+			}
+		}
+	}
+	/* returns true when the solve was parked (nothing of `t` has been written then), false when it is finished */
 	template<bool RENJU, class SH>
-	__device__ __forceinline__ void solve_task(SH &sh, const EngineDev &E, int g, DTask &t, int slot, int generation, int lane, unsigned long long &solver_nodes,
-			int area, u64 *overlay = nullptr)
+	__device__ __forceinline__ bool solve_task(SH &sh, const EngineDev &E, int g, DTask &t, int slot, int generation, int lane, unsigned long long &solver_nodes,
+			int area, u64 *overlay = nullptr, const ParkCtl *park = nullptr)
 	{ // AlphaBetaSearch::solve (AlphaBetaSearch.cpp:77-156)
 		uint32_t *act = E.act + static_cast<size_t>(area) * E.act_cap;
+		u64 *tt = E.tt + static_cast<size_t>(g % E.tt_mod) * (E.tt_bucket_mask + 1ull) * 8ull; // (double-buffered search: both buffers of a thread use its one solver)
+		const int parked_in = (park != nullptr) ? __builtin_amdgcn_readfirstlane(E.park_slot[slot]) : 0; // park buffer + 1 this task's solve waits in
+		int depth_first = 0, stack_before_first = 0;
+		if (parked_in != 0)
+		{ // ---- take a parked solve up again: LDS state and loop variables out of the buffer, the HBM tails into this wave's area ----
+			static_assert(sizeof(SH) % 8 == 0 && sizeof(SH) / 8 <= SPEC_PARK_WORDS - 8, "park buffer holds the solver's LDS state");
+			const u64 *src = E.park_lds + static_cast<size_t>(parked_in - 1) * SPEC_PARK_WORDS;
+			u64 *lds = reinterpret_cast<u64*>(&sh);
+			for (int i = fresh_lane(lane); i < static_cast<int>(sizeof(SH) / 8); i += 64)
+				lds[i] = global_view(src)[i];
+			depth_first = static_cast<int>(src[SPEC_PARK_WORDS - 8]);
+			stack_before_first = static_cast<int>(src[SPEC_PARK_WORDS - 7]);
+			wave_sync();
+			park_copy_tails(sh, E, E.park_area0 + parked_in - 1, area, lane);
+			if (lane == 0)
+			{
+				park_point_tails_at(sh, E, area);
+				sh.pf_valid = 0; // (the bucket prefetched for the next frame was in registers)
+				E.park_slot[slot] = 0;
+			}
+			__threadfence(); // the copies are done before the buffer can be claimed again
+			wave_sync();
+			if (lane == 0)
+				__hip_atomic_store(&E.park_owner[parked_in - 1], 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		else
+		{
 		if (lane == 0)
-		{ // HBM tails of the LDS-resident threat lists and frames (dev_solver.hpp: list_get / frame_get)
-			sh.spill_lists = E.list_spill + static_cast<size_t>(area) * 20 * MAXHW; // (stride of list_get / list_set: SolverSharedT::HW <= MAXHW whatever the kernel instantiation)
-			sh.spill_frames = reinterpret_cast<Frame*>(E.frame_spill) + static_cast<size_t>(area) * MAX_FRAMES;
-			sh.snap = E.snap_spill + static_cast<size_t>(area) * (E.hw + 2) * 64; // undo snapshots, one level per stone on the board (dev_solver.hpp)
+		{
+			park_point_tails_at(sh, E, area);
 			sh.ov_on = (overlay != nullptr) ? 1 : 0;
 			sh.ov_data = overlay;
 			sh.ov_count = 0;
@@ -255,10 +384,13 @@ namespace
 		}
 		if (lane < OV_CAP / 32)
 			sh.ov_dirty[lane] = 0;
-		u64 *tt = E.tt + static_cast<size_t>(g % E.tt_mod) * (E.tt_bucket_mask + 1ull) * 8ull; // (double-buffered search: both buffers of a thread use its one solver)
+		}
 #ifdef AGX_SOLVER_PROFILE
 		unsigned long long c0 = wall_clock64(), c_run = 0, c_place = 0, n_place = 0;
+		unsigned long long c1 = c0, t_forbidden = 0;
 #endif
+		if (parked_in == 0)
+		{
 		solver_set_board(sh, E, t.board, t.sign_to_move, lane);
 		solver_encode_features(sh, E, E.nn_features + static_cast<size_t>(slot) * E.hw, lane);
 		#ifdef AGX_SOLVER_PROFILE
@@ -267,8 +399,8 @@ namespace
 		if (RENJU)
 			solver_encode_forbidden(sh, E, E.nn_features + static_cast<size_t>(slot) * E.hw, lane);
 		#ifdef AGX_SOLVER_PROFILE
-		unsigned long long c1 = wall_clock64();
-		const unsigned long long t_forbidden = c1 - c_enc; // renju: the forbidden-move bits of the network input (probes place and remove stones)
+		c1 = wall_clock64();
+		t_forbidden = c1 - c_enc; // renju: the forbidden-move bits of the network input (probes place and remove stones)
 		#endif
 		u64 lo = 0, hi = 0;
 		for (int i = lane; i < E.hw; i += 64)
@@ -304,15 +436,21 @@ namespace
 			f.must_defend = f.has_initiative = f.fully_expanded = 0;
 		}
 		wave_sync();
+		}
 		uint32_t result = s_unknown(0);
 		u64 pf_word = 0; // lanes 0-7: the transposition-table bucket prefetched for the frame about to be entered
 		uint8_t pf_pattern = 0; // pattern-table entries prefetched for the stone about to be placed / removed (dev_solver.hpp:pattern_prefetch)
 		int pf_pattern_tag = -1; // move | add << 16 they belong to
 		u64 pf_snap = 0; // an undo's snapshot word, requested by the frame machine when the node returns (tag: the move, add bit clear)
-		for (int depth = 0; depth <= E.tss_max_depth; depth += 4)
+		// a solve may be parked once, and not in a launch in which nothing can be gained by it
+		const bool may_park = (park != nullptr) && (parked_in == 0) && (park->threshold != 0x7FFFFFFF) && (overlay != nullptr);
+		int turns = 0;
+		for (int depth = depth_first; depth <= E.tss_max_depth; depth += 4)
 		{
 			int stack_before = 0;
-			if (lane == 0)
+			if (parked_in != 0 && depth == depth_first)
+				stack_before = stack_before_first; // (the iteration the solve was parked in goes on)
+			else if (lane == 0)
 			{
 				stack_before = sh.stack_max;
 				Frame &f = sh.frames[0];
@@ -327,6 +465,35 @@ namespace
 			wave_sync();
 			while (true)
 			{
+				if (may_park && ((++turns) & 15) == 0 && park_wanted(E, *park, lane))
+				{ // ---- park: between two commands everything the machine needs is in LDS ----
+					const int b = park_claim(E, slot, lane);
+					if (b >= 0)
+					{
+						u64 *dst = E.park_lds + static_cast<size_t>(b) * SPEC_PARK_WORDS;
+						const u64 *lds = reinterpret_cast<const u64*>(&sh);
+						for (int i = fresh_lane(lane); i < static_cast<int>(sizeof(SH) / 8); i += 64)
+							global_view(dst)[i] = lds[i];
+						const int sb = __builtin_amdgcn_readfirstlane(stack_before); // (lane 0's)
+						if (lane == 0)
+						{
+							dst[SPEC_PARK_WORDS - 8] = static_cast<u64>(depth);
+							dst[SPEC_PARK_WORDS - 7] = static_cast<u64>(sb);
+						}
+						park_copy_tails(sh, E, area, E.park_area0 + b, lane);
+						__threadfence();
+						if (lane == 0)
+						{
+							GameState &pg = E.games[g];
+							E.park_slot[slot] = b + 1;
+							pg.solve_pending = 1; // (solve_pos stays: 0, or where a deferred game's batch went on)
+							atomicAdd(&pg.spec_stats[3], 1ull);
+						}
+						__threadfence();
+						wave_sync();
+						return true;
+					}
+				}
 #ifdef AGX_SOLVER_PROFILE
 				const unsigned long long r0 = wall_clock64();
 #endif
@@ -412,6 +579,7 @@ namespace
 		}
 #endif
 		wave_sync();
+		return false;
 	}
 
 	/* Search::scheduleToNN (Search.cpp:184-199) for one game whose whole batch has been solved: input symmetries, the device-side queue of
@@ -803,6 +971,11 @@ namespace
 		int *const c_done = E.counters + E.yield_counter; // games of this launch whose batch is on the network queue (or that had nothing to do)
 		const float fraction = E.match_mode ? 0.5f + 0.5f * E.yield_fraction : E.yield_fraction; // (match mode: half of the trees wait for their opponents)
 		const int defer_threshold = (E.yield_fraction > 0.0f) ? static_cast<int>(fraction * count) : 0x7FFFFFFF;
+		// Only the renju kernels park: their launches end with a few solves of several times the average length; on the other rules a launch ends with
+		// commits and their re-runs (the yield rule's business), nothing was ever parked at this threshold (C2: 0-1 solves in 300 steps), and the code's
+		// registers cost the launch 4 % (3.25 -> 3.40 ms).  For them the pointer below is a compile-time null and all of it folds away.
+		constexpr bool SPEC_PARKS = RENJU;
+		const ParkCtl park_ctl = { count, (E.park_fraction > 0.0f && count >= 4) ? static_cast<int>(E.park_fraction * count) : 0x7FFFFFFF };
 		int *const items = E.spec_items + static_cast<size_t>(E.g0) * E.batch + static_cast<size_t>(E.spec_group) * SPEC_QUEUE_SLACK;
 		const int item_cap = count * E.batch + SPEC_QUEUE_SLACK;
 		const int area = E.n_games + E.spec_group * E.spec_waves + blockIdx.x; // this wave's spill areas (action stack, list / frame tails)
@@ -1007,10 +1180,17 @@ namespace
 			const float moves_left0 = t.moves_left;
 			unsigned long long n1 = 0;
 			SPEC_T(t_s0);
-			solve_task<RENJU>(sh, E, g, t, slot, E.games[g].generation, lane, n1, area, speculative ? E.spec_overlay + static_cast<size_t>(slot) * (SPEC_OV_CAP * 16) : nullptr);
+			const bool parked = solve_task<RENJU>(sh, E, g, t, slot, E.games[g].generation, lane, n1, area,
+					speculative ? E.spec_overlay + static_cast<size_t>(slot) * (SPEC_OV_CAP * 16) : nullptr, (SPEC_PARKS && speculative) ? &park_ctl : nullptr);
 			if (!speculative)
 			{ // a re-run inside a commit: its result stands
 				commit.nodes += n1;
+				continue;
+			}
+			if (parked)
+			{ // the solve goes on in the next launch (the queue is dry: this wave's next turn finds nothing and leaves)
+				SPEC_T(t_parked);
+				SPEC_ADD(3, t_parked - t_s0);
 				continue;
 			}
 			spec_flush(sh, E.spec_tasks[slot], static_cast<int>(n1), flags0, moves_left0, lane);
@@ -1642,6 +1822,7 @@ namespace
 			gs.need_move = 0;
 			gs.solve_pos = 0;
 			gs.solve_pending = 0;
+			park_forget_game(E, g);
 			gs.max_depth = 0;
 			gs.nn_queued = 0;
 			gs.restart_id = 0;
@@ -1813,6 +1994,7 @@ namespace
 				gs.need_move = 0;
 				gs.solve_pos = 0;
 				gs.solve_pending = 0;
+				park_forget_game(E, g);
 				gs.outcome = 0;
 				gs.n_moves = 0;
 				gs.restart_id = (g < E.n_games / 2) ? -1 : 0;
@@ -2357,6 +2539,7 @@ namespace
 				gs.need_move = 0;
 				gs.solve_pos = 0;
 				gs.solve_pending = 0;
+				park_forget_game(E, t);
 				gs.nn_queued = 0;
 				gs.restart_id = 0;
 				gs.noise_ready = 0;
@@ -2620,6 +2803,7 @@ namespace
 				os.n_tasks = 0;
 				os.solve_pos = 0;
 				os.solve_pending = 0;
+				park_forget_game(E, r);
 			}
 		}
 	}
@@ -2650,6 +2834,7 @@ namespace
 			gs.need_move = 0;
 			gs.solve_pos = 0;
 			gs.solve_pending = 0;
+			park_forget_game(E, g);
 			gs.grow_pending = 0;
 			gs.noise_ready = 0;
 			gs.restart_id = 0;
@@ -2735,6 +2920,7 @@ namespace
 			gs.error = 0;
 			gs.solve_pos = 0; // (gs.generation: the idle template's — 0 until agx_debug_new_generation)
 			gs.solve_pending = 0;
+			park_forget_game(E, g);
 			gs.nn_queued = 0;
 		}
 	}
@@ -3111,7 +3297,19 @@ int agx_engine_create(const AgxEngineConfig *cfg, AgxEngine **out)
 		e->spec_waves = std::min(e->spec_waves, SPEC_QUEUE_SLACK);
 	}
 	// (a group's waves take the areas n_games + group * waves + wave with waves = max(1, spec_waves / n_groups): at least one area per possible group)
-	const size_t areas = G + static_cast<size_t>(std::max(e->spec_waves, 16));
+	// ... and behind the waves' areas one per park buffer (a parked solve keeps its tails there until the next launch takes it up)
+	const bool parking = e->speculative && cfg->rules == AGX_RENJU && cfg->solver_yield_fraction > 0.0f && !cfg->match_mode && std::max(1, cfg->search_threads) == 1;
+	const size_t areas = G + static_cast<size_t>(std::max(e->spec_waves, 16)) + (parking ? SPEC_PARK_POOL : 0);
+	d.park_area0 = static_cast<int>(G) + std::max(e->spec_waves, 16);
+	d.park_fraction = parking ? SPEC_PARK_FRACTION : 0.0f;
+	if (const char *pf = std::getenv("AGX_PARK_FRACTION")) // (developer knob: the sweep behind SPEC_PARK_FRACTION, profiles/r05_search_variants_ab.txt)
+		if (parking && std::atof(pf) > 0.0)
+			d.park_fraction = static_cast<float>(std::atof(pf));
+	AGX_TRY(dev_alloc(e, &d.park_slot, G * d.batch));
+	AGX_TRY(dev_alloc(e, &d.park_owner, SPEC_PARK_POOL));
+	AGX_TRY(dev_alloc(e, &d.park_lds, parking ? static_cast<size_t>(SPEC_PARK_POOL) * SPEC_PARK_WORDS : 1));
+	(void) hipMemset(d.park_slot, 0, G * d.batch * sizeof(int));
+	(void) hipMemset(d.park_owner, 0, SPEC_PARK_POOL * sizeof(int));
 	AGX_TRY(dev_alloc(e, &d.act, areas * d.act_cap));
 	// per area 20 lists x MAXHW entries: list_get / list_set stride by the kernel's compile-time board (SolverSharedT::HW, = MAXHW in the any-size kernels)
 	AGX_TRY(dev_alloc(e, &d.list_spill, areas * 20 * static_cast<size_t>(MAXHW)));
@@ -3889,6 +4087,7 @@ int agx_engine_stats(AgxEngine *e, AgxEngineStats *out)
 		out->speculative_solves += g.spec_stats[0];
 		out->speculative_reruns += g.spec_stats[1];
 		out->speculative_deferrals += g.spec_stats[2];
+		out->speculative_parks += static_cast<int>(g.spec_stats[3]);
 		out->peak_nodes = std::max<unsigned long long>(out->peak_nodes, g.stats[10]);
 		out->peak_edges = std::max<unsigned long long>(out->peak_edges, g.stats[11]);
 		out->active_games += g.active ? 1 : 0;

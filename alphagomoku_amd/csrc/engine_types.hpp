@@ -20,6 +20,8 @@ namespace agx
 	constexpr int MAXHW = MAXN * MAXN;
 	constexpr int BWORDS = 13;      // 2 bits per cell, 32 cells per 64-bit word (NodeCache.hpp:56)
 	constexpr int PATH_CAP = 256;
+	constexpr int SPEC_PARK_POOL = 128;   // park buffers of a pool (a launch parks a handful of solves; none free = the solve simply runs on)
+	constexpr int SPEC_PARK_WORDS = 2048 + 8; // 64-bit words per park buffer: the largest solver state (16 064 bytes at 20x20) + the solve's loop variables
 	constexpr int MAX_FRAMES = 104; // alpha-beta recursion depth is bounded by the iterative-deepening limit (100 plies) + root
 	constexpr int OPENING_CAP = 32;
 
@@ -122,7 +124,7 @@ namespace agx
 			uint64_t cboard[BWORDS];
 			unsigned long long prof[8];   // optional cycle counters (AGX_SOLVER_PROFILE builds only)
 			unsigned long long dprof[24]; // finer stage stamps of the same builds (shader cycles)
-			unsigned long long spec_stats[4]; // speculative solver: leaves solved against the pre-batch table, of which re-run serially, batches deferred, pad
+			unsigned long long spec_stats[4]; // speculative solver: leaves solved against the pre-batch table, of which re-run serially, batches deferred, solves parked
 			unsigned long long stats[12]; // nodes, nn, leaks, proven, wasted, solver nodes, select levels, select edges, moves, duplicates, max nodes, max edges
 			uint8_t board[MAXHW];
 			uint16_t moves[MAXHW];
@@ -275,6 +277,13 @@ namespace agx
 			int *spec_left;        // [game] tasks of the batch still being solved
 			SpecTask *spec_tasks;  // [game * batch]
 			uint64_t *spec_overlay; // [game * batch][SPEC_OV_CAP][16]
+			// parked solves (engine.hip: "Parking"): a speculative solve that is still running when all but a few games of the launch are done is set
+			// aside — its LDS state in park_lds, its HBM tails in a spill area of its own — and taken up again by the next launch
+			int *park_slot;        // [game * batch] park buffer + 1 of a task whose solve is parked, 0 = none
+			int *park_owner;       // [SPEC_PARK_POOL] task slot + 1 that holds the buffer, 0 = free
+			uint64_t *park_lds;    // [SPEC_PARK_POOL][SPEC_PARK_WORDS] the solver's LDS state, then 8 words of the solve's loop variables
+			int park_area0;        // spill area of park buffer 0 (behind the games' and the waves' areas)
+			float park_fraction;   // solves are parked once this fraction of the launch's games is done (0 = never)
 			int *nn_list;          // compacted slots to evaluate
 			int *counters;         // [0] (unused), [1] next opening, [2] finished games, [3] records used, [4] record edges used, [5] total moves, [6] sample bytes used, [7] game-end records used, [16 + group] positions scheduled for the network by that group, [32 + group] games of that group done with their solver batch
 			// output records

@@ -532,7 +532,8 @@ def main():
             "select_fused_into_solve": os.environ.get("AGX_FUSE_SELECT", "1") != "0",
             "speculative_solver": {"enabled": bool(args.speculative), "leaves_solved": int(s1["speculative_solves"] - s0["speculative_solves"]),
                                    "rerun_serially": int(s1["speculative_reruns"] - s0["speculative_reruns"]),
-                                   "batches_deferred": int(s1["speculative_deferrals"] - s0["speculative_deferrals"])},
+                                   "batches_deferred": int(s1["speculative_deferrals"] - s0["speculative_deferrals"]),
+                                   "solves_parked": int(s1["speculative_parks"] - s0["speculative_parks"])},
             "peak_tree_per_game": {"nodes": int(s1["peak_nodes"]), "edges": int(s1["peak_edges"]), "class0_node_capacity": node_capacity,
                                    "class0_edge_capacity": edge_capacity, "arena_grows": int(s1["arena_grows"]), "arena_releases": int(s1["arena_releases"]),
                                    "arena_failures": int(s1["arena_failures"]), "arena_max_class": int(s1["arena_max_class"]),

@@ -255,7 +255,7 @@ typedef struct AgxEngineStats
 	int arena_failures;                       /* growth requests the heap could not serve (reserve exhausted) */
 	int arena_max_class;                      /* largest size class in use: capacities = class-0 capacities << class */
 	float arena_heap_used;                    /* high-water mark of the edge heap, fraction of its size */
-	int reserved0;
+	int speculative_parks;                    /* speculative solves set aside at the end of a launch and taken up again by the next one (engine: "Parking") */
 	unsigned long long speculative_solves;    /* speculative_solver: leaves solved against the pre-batch table ... */
 	unsigned long long speculative_reruns;    /* ... and how many of them had to be solved again serially (conflict or full overlay) */
 	unsigned long long speculative_deferrals; /* batches whose commit was put off to the next launch (solver_yield_fraction) */

@@ -674,14 +674,17 @@ def test_double_buffered_tournament_search(agx_lib, olib, rules, threads, batch,
     olib.ago_game_destroy(h)
 
 
-@pytest.mark.parametrize("fraction,speculative,table_bits", [(0.5, 0, 16), (0.5, 1, 16), (0.25, 1, 10), (0.9, 1, 22)])
-def test_yielding_pool_gives_the_same_games(agx_lib, olib, fraction, speculative, table_bits):
+@pytest.mark.parametrize("fraction,speculative,table_bits,rules", [(0.5, 0, 16, 0), (0.5, 1, 16, 0), (0.25, 1, 10, 0), (0.9, 1, 22, 0), (0.5, 1, 16, 2), (0.9, 1, 22, 2),
+                                                                   (0.5, 1, 16, 1)])
+def test_yielding_pool_gives_the_same_games(agx_lib, olib, fraction, speculative, table_bits, rules):
     """solver_yield_fraction only changes the pacing (stragglers sit out a step): every game must still produce exactly the
     oracle's moves and root visit counts.  Compared through the output records, game by game.  With the speculative solver the rule
-    defers a batch whose commit needs a serial re-run while the rest of the launch is done (small tables provoke those)."""
+    defers a batch whose commit needs a serial re-run while the rest of the launch is done (small tables provoke those), and a solve that is
+    still running when all but the last game of the launch are done is PARKED and taken up again by the next launch (engine.hip "Parking":
+    renju pools; with 12 games from 11 done on — nearly every launch here)."""
     from alphagomoku_amd import selfplay
     games, batch, sims = 12, 8, 60
-    cfg = selfplay.default_config(n_games=games, max_batch_size=batch, max_simulations=sims, tss_table_entries=1 << table_bits, node_capacity=4096,
+    cfg = selfplay.default_config(rules=rules, n_games=games, max_batch_size=batch, max_simulations=sims, tss_table_entries=1 << table_bits, node_capacity=4096,
                                   edge_capacity=65536, solver_yield_fraction=fraction, speculative_solver=speculative, speculative_waves=48)
     pool = selfplay.GeneratorPool(cfg)
     ocfg = ol.default_search_config(max_batch_size=batch, max_simulations=sims, table_entries=1 << table_bits)
@@ -689,7 +692,7 @@ def test_yielding_pool_gives_the_same_games(agx_lib, olib, fraction, speculative
     openings = []
     for g in range(games):
         op = np.zeros(64, np.uint16)
-        k = olib.ago_prepare_opening(0, N, N, 300 + g, ol.ptr(op))
+        k = olib.ago_prepare_opening(rules, N, N, 300 + g, ol.ptr(op))
         openings.append([int(x) for x in op[:k]])
     pool.begin(selfplay.pack_openings(openings))
     for _ in range(6000):
@@ -705,9 +708,11 @@ def test_yielding_pool_gives_the_same_games(agx_lib, olib, fraction, speculative
     assert st["first_error"] == 0 and st["games_finished"] == games
     if speculative:
         assert st["speculative_solves"] > 0 and (st["speculative_deferrals"] > 0 or table_bits > 16)   # the deferral path ran
+        print("solves %d, re-runs %d, deferrals %d, parked %d" % (st["speculative_solves"], st["speculative_reruns"], st["speculative_deferrals"], st["speculative_parks"]))
+        assert (st["speculative_parks"] > 0) == (rules == 2)   # ... and so did parking (renju pools only)
     recs, edges = pool.records()
     for g in range(games):
-        h = olib.ago_game_create(0, N, N, ctypes.byref(ocfg))
+        h = olib.ago_game_create(rules, N, N, ctypes.byref(ocfg))
         op = np.array(openings[g] + [0] * (64 - len(openings[g])), np.uint16)
         olib.ago_game_begin(h, ol.ptr(op), len(openings[g]))
         f = np.zeros((batch, HW), np.uint32)
