@@ -364,6 +364,26 @@ def test_whole_games_bit_exact_with_stand_in_evaluator(agx_lib, olib, rules, bat
     assert stats["games_finished"] == 6 and stats["information_leaks"] > 0 and stats["proven_edge_visits"] > 0
 
 
+@pytest.mark.parametrize("rules,n,per_cu", [(0, 15, 16), (2, 15, 16), (3, 20, 10), (0, 12, 10)])
+def test_default_search_waves_are_what_stays_resident(agx_lib, rules, n, per_cu):
+    """AgxEngineConfig.speculative_waves = 0: the search launch gets as many one-wave workgroups as its kernel instantiation keeps resident — sixteen per
+    compute unit on 15x15 boards (10 240 B of LDS state, 128 registers), ten for the 20x20 and the any-size kernels (16 064 B) — and
+    agx_engine_speculative_waves reports the number; an explicit count is taken as given, the serial solver reports 0."""
+    from alphagomoku_amd import selfplay, lib, check
+    cus = ctypes.c_int()
+    check(lib.agx_device_cu_count(ctypes.byref(cus)))
+    common = dict(rules=rules, board_size=n, n_games=1024, max_batch_size=8, max_simulations=50, tss_table_entries=1 << 12, node_capacity=256, edge_capacity=8192)
+    pool = selfplay.GeneratorPool(selfplay.default_config(speculative_solver=1, **common))
+    assert pool.speculative_waves() == per_cu * cus.value
+    pool.close()
+    pool = selfplay.GeneratorPool(selfplay.default_config(speculative_solver=1, speculative_waves=96, **common))
+    assert pool.speculative_waves() == 96
+    pool.close()
+    pool = selfplay.GeneratorPool(selfplay.default_config(speculative_solver=0, **common))
+    assert pool.speculative_waves() == 0
+    pool.close()
+
+
 @pytest.mark.parametrize("rules,n,batch,sims,symmetries,table_entries", [(0, 15, 8, 100, 0, 1 << 16), (1, 15, 8, 100, 1, 1 << 10), (2, 15, 8, 60, 0, 1 << 16),
                                                                          (3, 20, 8, 60, 0, 1 << 12), (4, 15, 4, 60, 1, 1 << 16), (0, 12, 8, 60, 0, 1 << 8)])
 def test_speculative_solver_plays_the_same_games(agx_lib, olib, rules, n, batch, sims, symmetries, table_entries):
