@@ -1100,11 +1100,11 @@ def test_full_size_pool_matches_a_small_pool_game_by_game(agx_lib, name):
     openings = synthetic.make_openings(n, 1024, seed0=900, rules=c["rules"])
 
     def run(games, steps, as_bench):
-        # as_bench: exactly bench.py's way of running the pool — 4 chip slices on CU-masked streams, the speculative solver, yielding at 0.6,
+        # as_bench: exactly bench.py's way of running the pool — 4 chip slices on CU-masked streams, the speculative solver, yielding at 0.5 (renju: parking),
         # format-201 samples on (record_format 3 = samples + the raw root edges this test compares), records drained as it goes
         pool = selfplay.GeneratorPool(selfplay.default_config(rules=c["rules"], board_size=n, draw_after=n * n, n_games=games, max_batch_size=8, max_simulations=sims,
                                                               tss_table_entries=4 * 1024 * 1024, node_capacity=max(4096, 8 * sims),
-                                                              edge_capacity=max(65536, 192 * sims), arena_reserve=3.0, solver_yield_fraction=0.6 if as_bench else 0.0,
+                                                              edge_capacity=max(65536, 192 * sims), arena_reserve=3.0, solver_yield_fraction=0.5 if as_bench else 0.0,
                                                               speculative_solver=1 if as_bench else 0, record_format=3 if as_bench else 1,
                                                               record_capacity=games * 64, record_edge_capacity=games * 64 * n * n))
         pool.begin(selfplay.pack_openings(openings[:games]))   # no spare openings: a finished game stays finished
@@ -1137,6 +1137,7 @@ def test_full_size_pool_matches_a_small_pool_game_by_game(agx_lib, name):
     check(lib.agx_net_set_launch_width(net._net, 0))
     assert big_stats["first_error"] == 0 and small_stats["first_error"] == 0 and big_stats["arena_failures"] == 0
     assert big_stats["moves_played"] > 1024 and big_stats["evaluated_nodes"] > 1024 * sims and big_stats["speculative_solves"] > 0
+    assert (big_stats["speculative_parks"] > 0) == (c["rules"] == 2)   # renju launches park the solves that outlast them (a dozen per slice launch), the others never
     compared = 0
     for g in range(128):
         a, b = big.get(g, []), small.get(g, [])
