@@ -53,13 +53,17 @@ def parse_game(data, n):
     return samples, moves, outcome
 
 
-def test_generator_manager_call_chain(network_file, tmp_path):
+@pytest.mark.parametrize("rules,games_per_thread", [(0, 32), (2, 64)])
+def test_generator_manager_call_chain(network_file, tmp_path, rules, games_per_thread):
+    """training_launcher's call chain on the reference-named classes; (2, 64): renju with pools large enough for GeneratorThread's pacing rules
+    (64 games: yield fraction 0.5, and the renju search launches park the solves that outlast them) — the games must still be legal games whose
+    recorded outcome is what replaying their moves gives"""
     path, d, _ = network_file
     olib = ol.load()
     out = tmp_path / "work"
     out.mkdir()
-    line, stdout = run("generate", "--network", path, "--games", 24, "--games-per-thread", 32, "--devices", "0,0", "--sims", 60, "--batch", 4,
-                       "--out", out, "--nn-batch", 64)   # 32 games x 4 = 128 slots, 64 per launch -> 2 slices per thread, pipelined on 2 streams
+    line, stdout = run("generate", "--network", path, "--rules", rules, "--games", 24, "--games-per-thread", games_per_thread, "--devices", "0,0", "--sims", 60, "--batch", 4,
+                       "--out", out, "--nn-batch", 2 * games_per_thread)   # 32 games x 4 = 128 slots, 64 per launch -> 2 slices per thread, pipelined on 2 streams
     assert line["threads"] == 2 and line["games"] >= 24 and line["samples"] > line["games"]
     assert line["cross_win"] + line["draws"] + line["circle_win"] == line["games"]
     assert "Played games" in stdout and "----SearchStats----" in stdout and "----NNEvaluator----" in stdout       # printStats
@@ -67,7 +71,7 @@ def test_generator_manager_call_chain(network_file, tmp_path):
     blob = zlib.decompress((out / "buffer_0.bin").read_bytes())
     header, _, body = blob.partition(b"\n")
     meta = json.loads(header)
-    assert meta["format"] == 201 and meta["config"] == {"rules": "FREESTYLE", "rows": 15, "cols": 15, "draw_after": 225}
+    assert meta["format"] == 201 and meta["config"] == {"rules": "RENJU" if rules == 2 else "FREESTYLE", "rows": 15, "cols": 15, "draw_after": 225}
     assert len(meta["offsets"]) == line["games"] and (out / "saved_state" / "buffer.bin").exists()
     raw = np.frombuffer((out / "games.raw").read_bytes(), np.uint8)
     pos, total_samples = 0, 0
@@ -86,7 +90,7 @@ def test_generator_manager_call_chain(network_file, tmp_path):
             s, r, c = int(m) & 3, (int(m) >> 2) & 127, (int(m) >> 9) & 127
             assert board[r * 15 + c] == 0 and s == 1 + (k % 2)
             board[r * 15 + c] = s
-            res = olib.ago_outcome(0, 15, 15, ol.ptr(board), s, r, c, 225)
+            res = olib.ago_outcome(rules, 15, 15, ol.ptr(board), s, r, c, 225)
             assert (res != 0) == (k == len(moves) - 1) and (res == 0 or res == outcome)
         # every sample decodes (storeTo) on the position it was taken from: move_number stones, entries on empty cells only
         first = len(moves) - len(samples)
