@@ -327,7 +327,10 @@ namespace
 			}
 		return __builtin_amdgcn_readfirstlane(b);
 	}
-	/* forgets what game g has parked (the game is restarted, its board set from outside, its pending batch cancelled): lane 0 / one thread */
+	/* forgets what game g has parked (the game is restarted, its board set from outside, its pending batch cancelled): lane 0 / one thread.
+	 * With a parked solve the game's OTHER leaves of that launch stay "solved speculatively" (SpecTask::solved, overlay uncommitted) across
+	 * launches; whoever discards the batch discards those too, or a later batch's proven-edge task in the same slot — which the solver never
+	 * sees — would be taken for one by spec_commit_game and have a stale overlay written into the table. */
 	__device__ __forceinline__ void park_forget_game(const EngineDev &E, int g)
 	{
 		for (int k = 0; k < E.batch; k++)
@@ -338,7 +341,31 @@ namespace
 				E.park_slot[g * E.batch + k] = 0;
 				__hip_atomic_store(&E.park_owner[b - 1], 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 			}
+			if (E.spec_on)
+				E.spec_tasks[g * E.batch + k].solved = 0;
 		}
+	}
+	/* A serial solve launch (k_solve: Search::solve with a time limit, or solve() behind flush_select()) on a pool whose last speculative launch
+	 * left game g waiting (a deferred commit or a parked solve): the leaves of the batch that were solved speculatively but never committed go
+	 * back to what the select stage made of them — as spec_commit_game's defer path does — and the parked solve is dropped, so that the serial
+	 * loop solves every pending leaf on the table itself, in batch order.  lane 0 / one thread. */
+	__device__ __forceinline__ void spec_discard_pending(const EngineDev &E, int g)
+	{
+		if (!E.spec_on)
+			return;
+		for (int k = 0; k < E.batch; k++)
+		{
+			SpecTask &h = E.spec_tasks[g * E.batch + k];
+			if (h.solved != 0)
+			{
+				DTask &t = E.tasks[static_cast<size_t>(g) * E.batch + k];
+				t.flags = h.flags0;
+				t.win = 0.0f;
+				t.draw = 0.0f;
+				t.moves_left = h.moves_left0;
+			}
+		}
+		park_forget_game(E, g); // (also clears SpecTask::solved)
 	}
 	/* returns true when the solve was parked (nothing of `t` has been written then), false when it is finished */
 	template<bool RENJU, class SH>
@@ -682,6 +709,13 @@ namespace
 		GameState &gs = E.games[g];
 		const bool idle = (!gs.active || gs.error != 0 || gs.outcome != 0 || E.games[E.shared_tree ? 0 : g].grow_pending != 0);
 		const int n_tasks = idle ? 0 : gs.n_tasks;
+		if (E.spec_on && !idle && gs.solve_pending)
+		{ // (a speculative pool stepped with a serial launch: nothing of the last speculative launch may outlive this one)
+			if (lane == 0)
+				spec_discard_pending(E, g);
+			__threadfence();
+			__syncthreads();
+		}
 		if (n_tasks > 0)
 			solver_load_threat_table(sh, E, lane);
 		unsigned long long solver_nodes = 0;
@@ -1049,7 +1083,14 @@ namespace
 				}
 			}
 			if (idle && lane == 0)
+			{
+				if (gs.error != 0 && gs.solve_pending)
+				{ // a game stopped for good with a batch in flight: its park buffers go back to the pool
+					gs.solve_pending = 0;
+					park_forget_game(E, g);
+				}
 				atomicAdd(c_done, 1);
+			}
 #ifdef AGX_SPEC_PROFILE
 			if (lane == 0)
 			{
@@ -3301,10 +3342,11 @@ int agx_engine_create(const AgxEngineConfig *cfg, AgxEngine **out)
 	const bool parking = e->speculative && cfg->rules == AGX_RENJU && cfg->solver_yield_fraction > 0.0f && !cfg->match_mode && std::max(1, cfg->search_threads) == 1;
 	const size_t areas = G + static_cast<size_t>(std::max(e->spec_waves, 16)) + (parking ? SPEC_PARK_POOL : 0);
 	d.park_area0 = static_cast<int>(G) + std::max(e->spec_waves, 16);
+	d.spec_on = e->speculative ? 1 : 0;
 	d.park_fraction = parking ? SPEC_PARK_FRACTION : 0.0f;
 	if (const char *pf = std::getenv("AGX_PARK_FRACTION")) // (developer knob: the sweep behind SPEC_PARK_FRACTION, profiles/r05_search_variants_ab.txt)
 		if (parking && std::atof(pf) > 0.0)
-			d.park_fraction = static_cast<float>(std::atof(pf));
+			d.park_fraction = std::min(1.0f, static_cast<float>(std::atof(pf))); // (a fraction of the launch's games: (0, 1])
 	AGX_TRY(dev_alloc(e, &d.park_slot, G * d.batch));
 	AGX_TRY(dev_alloc(e, &d.park_owner, SPEC_PARK_POOL));
 	AGX_TRY(dev_alloc(e, &d.park_lds, parking ? static_cast<size_t>(SPEC_PARK_POOL) * SPEC_PARK_WORDS : 1));

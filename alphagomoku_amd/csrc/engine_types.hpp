@@ -268,6 +268,7 @@ namespace agx
 			int tt_mod;      // solver table of record g = table g % tt_mod (n_games, or the thread count when a thread has two buffers)
 			int grp_first, grp_count; // the records of this launch's group (kept when g0 is redirected to the tree's record)
 			// speculative solver
+			int spec_on;           // the pool has speculative state (spec_tasks / spec_overlay per task, park buffers): AgxEngineConfig.speculative_solver took effect
 			int spec_group;        // index of this launch's group (its queue segment and counters)
 			int *spec_watchdog;            // [16] what a wave that gave up waiting for a queue slot saw
 			unsigned long long *spec_trace; // AGX_SPEC_PROFILE builds: [game][4] time stamps of the last launch

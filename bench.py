@@ -575,7 +575,7 @@ def main():
                          # only runs part of each slice's cycle; the search kernels use no MFMA)
                          "time_averaged_whole_chip_frac": (evals / elapsed) * flops / 2.5e15 / world,
                          "pmc_summary_build": pmc_build},
-            "roofline_solver": {"bound": ("none (instruction issue of the solver waves: %d per SIMD, the leaves of a batch in parallel)" % (4 if args.board <= 15 else 3) if args.speculative
+            "roofline_solver": {"bound": ("none (instruction issue of the solver waves: %.1f per SIMD, the leaves of a batch in parallel)" % (pool.speculative_waves() / (4.0 * max(1, cu_total.value))) if args.speculative
                                           else "none (instruction issue / dependent-chain latency: one wave per game, tasks of a game strictly ordered)"),
                                 "kernel": ("k_search_spec (select + speculative threat solver + commit, one persistent launch)" if args.speculative else
                                            ("k_solve (select + threat solver of a game in one wave)" if os.environ.get("AGX_FUSE_SELECT", "1") != "0" else "k_solve")),

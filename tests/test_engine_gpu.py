@@ -694,6 +694,33 @@ def test_double_buffered_tournament_search(agx_lib, olib, rules, threads, batch,
     olib.ago_game_destroy(h)
 
 
+def _compare_records_with_fresh_oracle_games(olib, pool, rules, openings, batch, ocfg, ev):
+    """every game of `openings` played by the pool to its end: moves, root visits and root edge visits of every record against an oracle game
+    played from the same opening (the pacing of the pool — yields, deferrals, parked solves — must not show)"""
+    games = len(openings)
+    recs, edges = pool.records()
+    for g in range(games):
+        h = olib.ago_game_create(rules, N, N, ctypes.byref(ocfg))
+        op = np.array(openings[g] + [0] * (64 - len(openings[g])), np.uint16)
+        olib.ago_game_begin(h, ol.ptr(op), len(openings[g]))
+        f = np.zeros((batch, HW), np.uint32)
+        while olib.ago_game_outcome(h) == 0:
+            c = olib.ago_game_step_select(h, ol.ptr(f), batch)
+            p, v = ev(f[:c]) if c else (np.zeros((0, HW), np.float32), np.zeros((0, 2), np.float32))
+            olib.ago_game_step_expand(h, ol.ptr(np.ascontiguousarray(p)), ol.ptr(np.ascontiguousarray(v)))
+        mine = sorted((r.move_number, r) for r in recs if r.game_serial == g)
+        assert len(mine) == olib.ago_game_num_records(h), g
+        for i, (_, r) in enumerate(mine):
+            mv, rv, rs = ctypes.c_uint16(), ctypes.c_int(), ctypes.c_uint16()
+            rval = (ctypes.c_float * 2)()
+            em, ev_ = np.zeros(512, np.uint16), np.zeros(512, np.int32)
+            ep, evl, es = np.zeros(512, np.float32), np.zeros(1024, np.float32), np.zeros(512, np.uint16)
+            ne = olib.ago_game_record(h, i, ctypes.byref(mv), ctypes.byref(rv), rval, ctypes.byref(rs), ol.ptr(em), ol.ptr(ev_), ol.ptr(ep), ol.ptr(evl), ol.ptr(es), 512)
+            assert (r.move, r.root_visits, r.n_edges) == (mv.value, rv.value, ne), (g, i)
+            assert [e.visits for e in edges[r.edge_offset:r.edge_offset + r.n_edges]] == [int(x) for x in ev_[:ne]], (g, i)
+        olib.ago_game_destroy(h)
+
+
 @pytest.mark.parametrize("fraction,speculative,table_bits,rules", [(0.5, 0, 16, 0), (0.5, 1, 16, 0), (0.25, 1, 10, 0), (0.9, 1, 22, 0), (0.5, 1, 16, 2), (0.9, 1, 22, 2),
                                                                    (0.5, 1, 16, 1)])
 def test_yielding_pool_gives_the_same_games(agx_lib, olib, fraction, speculative, table_bits, rules):
@@ -730,27 +757,66 @@ def test_yielding_pool_gives_the_same_games(agx_lib, olib, fraction, speculative
         assert st["speculative_solves"] > 0 and (st["speculative_deferrals"] > 0 or table_bits > 16)   # the deferral path ran
         print("solves %d, re-runs %d, deferrals %d, parked %d" % (st["speculative_solves"], st["speculative_reruns"], st["speculative_deferrals"], st["speculative_parks"]))
         assert (st["speculative_parks"] > 0) == (rules == 2)   # ... and so did parking (renju pools only)
-    recs, edges = pool.records()
-    for g in range(games):
-        h = olib.ago_game_create(rules, N, N, ctypes.byref(ocfg))
-        op = np.array(openings[g] + [0] * (64 - len(openings[g])), np.uint16)
-        olib.ago_game_begin(h, ol.ptr(op), len(openings[g]))
-        f = np.zeros((batch, HW), np.uint32)
-        while olib.ago_game_outcome(h) == 0:
-            c = olib.ago_game_step_select(h, ol.ptr(f), batch)
-            p, v = ev(f[:c]) if c else (np.zeros((0, HW), np.float32), np.zeros((0, 2), np.float32))
-            olib.ago_game_step_expand(h, ol.ptr(np.ascontiguousarray(p)), ol.ptr(np.ascontiguousarray(v)))
-        mine = sorted((r.move_number, r) for r in recs if r.game_serial == g)
-        assert len(mine) == olib.ago_game_num_records(h), g
-        for i, (_, r) in enumerate(mine):
-            mv, rv, rs = ctypes.c_uint16(), ctypes.c_int(), ctypes.c_uint16()
-            rval = (ctypes.c_float * 2)()
-            em, ev_ = np.zeros(512, np.uint16), np.zeros(512, np.int32)
-            ep, evl, es = np.zeros(512, np.float32), np.zeros(1024, np.float32), np.zeros(512, np.uint16)
-            ne = olib.ago_game_record(h, i, ctypes.byref(mv), ctypes.byref(rv), rval, ctypes.byref(rs), ol.ptr(em), ol.ptr(ev_), ol.ptr(ep), ol.ptr(evl), ol.ptr(es), 512)
-            assert (r.move, r.root_visits, r.n_edges) == (mv.value, rv.value, ne), (g, i)
-            assert [e.visits for e in edges[r.edge_offset:r.edge_offset + r.n_edges]] == [int(x) for x in ev_[:ne]], (g, i)
-        olib.ago_game_destroy(h)
+    _compare_records_with_fresh_oracle_games(olib, pool, rules, openings, batch, ocfg, ev)
+    pool.close()
+
+
+@pytest.mark.parametrize("how", ["begin", "serial"])
+def test_interrupted_speculative_launches_leave_nothing_behind(agx_lib, olib, how):
+    """A parked solve leaves its game's OTHER leaves of that launch "solved speculatively, not committed" across launches.  Whoever ends such a
+    batch from outside must end that state too: (begin) the pool is restarted with new openings right behind a launch that parked solves;
+    (serial) a speculative pool is stepped with the serial launches (Search::solve with a deadline: agx_engine_select_group +
+    agx_engine_solve_timed_group at the configured node limit) whenever the previous launch has left parked solves.  Either way the games
+    are the oracle's, record by record."""
+    from alphagomoku_amd import selfplay
+    rules, games, batch, sims, table_bits = 2, 12, 8, 60, 16
+    cfg = selfplay.default_config(rules=rules, n_games=games, max_batch_size=batch, max_simulations=sims, tss_table_entries=1 << table_bits, node_capacity=4096,
+                                  edge_capacity=65536, solver_yield_fraction=0.5, speculative_solver=1, speculative_waves=48)
+    pool = selfplay.GeneratorPool(cfg)
+    ocfg = ol.default_search_config(max_batch_size=batch, max_simulations=sims, table_entries=1 << table_bits)
+    ev = _stand_in_evaluator(olib)
+
+    def make(seed0):
+        out = []
+        for g in range(games):
+            op = np.zeros(64, np.uint16)
+            k = olib.ago_prepare_opening(rules, N, N, seed0 + g, ol.ptr(op))
+            out.append([int(x) for x in op[:k]])
+        return out
+
+    def finish_step():
+        slots, feats = pool.scheduled()
+        if len(slots):
+            p, v = ev(feats)
+            pool.provide(slots, p, np.concatenate([v, 1 - v.sum(1, keepdims=True)], 1).astype(np.float32))
+        pool.expand_backup()
+
+    openings = make(300)
+    pool.begin(selfplay.pack_openings(openings))
+    parks, interrupted, serial_steps = 0, 0, 0
+    for _ in range(6000):
+        if how == "serial" and pool.stats()["speculative_parks"] > parks:
+            # the last launch parked solves: this step is the serial pair of launches
+            parks = pool.stats()["speculative_parks"]
+            pool.select_group(0, 1)
+            pool.solve_timed_group(0, 1, 100, 60.0)
+            serial_steps += 1
+        else:
+            pool.select_solve()
+        if how == "begin" and interrupted < 3 and pool.stats()["speculative_parks"] > parks + 2:
+            # parked solves and their solved siblings are in flight: start over with other games (three times, then play to the end)
+            interrupted += 1
+            openings = make(300 + 40 * interrupted)
+            pool.begin(selfplay.pack_openings(openings))
+            parks = pool.stats()["speculative_parks"]
+            continue
+        finish_step()
+        if pool.stats()["active_games"] == 0:
+            break
+    st = pool.stats()
+    assert st["first_error"] == 0 and st["games_finished"] == games
+    assert (interrupted == 3) if how == "begin" else (serial_steps > 5)
+    _compare_records_with_fresh_oracle_games(olib, pool, rules, openings, batch, ocfg, ev)
     pool.close()
 
 
