@@ -39,54 +39,23 @@
 #include <cmath>
 #include <cstdlib>
 
-#ifndef AGX_NN_ROW_STATIONARY
-#define AGX_NN_ROW_STATIONARY 1 // 0: the tap-major k-loop for every board (A/B builds)
-#endif
-#ifndef AGX_NN_COLUMN_TILES
-#define AGX_NN_COLUMN_TILES 1 // 0: the tap-major k-loop on 20x20 boards (A/B builds)
-#endif
 #ifndef AGX_NN_COLS_AHEAD
 #define AGX_NN_COLS_AHEAD 4 // activation fragments in flight per wave in the column-tile k-loop
 #endif
-#ifndef AGX_NN_COLS_INTERLEAVE
-#define AGX_NN_COLS_INTERLEAVE 0
+#ifndef AGX_NN_COLS_PAD
+#define AGX_NN_COLS_PAD 1 // 16-byte units of padding per stored position on column-tile boards (Geometry::PAD): 1 or 2
 #endif
 #ifndef AGX_NN_PAIR_BALANCE
 #define AGX_NN_PAIR_BALANCE 1 // 1: the two waves of a SIMD steer their priorities by each other's progress in the row-stationary k-loop (+0.8 %)
 #endif
-#ifndef AGX_NN_PAIR_BALANCE_COLS
-#define AGX_NN_PAIR_BALANCE_COLS 0 // the same in the column-tile k-loop (20x20)
-#endif
-#ifndef AGX_NN_WEIGHT_RING
-#define AGX_NN_WEIGHT_RING 2 // stages of weight fragments a wave holds in the row / column loops: 2 = fetched one stage ahead, 3 = two
-#endif
-#ifndef AGX_NN_LAYER_PREFETCH
-#define AGX_NN_LAYER_PREFETCH 1 // 1: the row-stationary k-loop's last turn requests the NEXT layer's first weight fragments (two-plane 15-column kernels)
-#endif
-#ifndef AGX_NN_FMA_MIX
-#define AGX_NN_FMA_MIX 1 // 1: the residual add of a layer's accumulator initialisation as v_fma_mix_f32 (fp16 operand widened by the instruction)
-#endif
-#ifndef AGX_NN_INPUT_PREFETCH
-#define AGX_NN_INPUT_PREFETCH 1 // 1: the next board's feature words are requested while the current board's heads run
-#endif
-#ifndef AGX_NN_CONV5_SPLIT
-#define AGX_NN_CONV5_SPLIT 1 // 1: 128-filter nets on 15-column boards run the input conv5x5 row-stationary in two passes per column shift
-#endif
-#ifndef AGX_NN_COLS_SWIZZLE
-#define AGX_NN_COLS_SWIZZLE 0 // 1: the conflict-free even swizzle on column-tile boards (measured 2 % slower: Geometry::swizzle)
-#endif
-#ifndef AGX_NN_COLS_BARRIER
-#define AGX_NN_COLS_BARRIER 1
-#endif
-#ifndef AGX_NN_PAIR_LDS
-#define AGX_NN_PAIR_LDS 1
-#endif
-#ifndef AGX_NN_OPAQUE_SKIP
-#define AGX_NN_OPAQUE_SKIP 1
-#endif
 #ifndef AGX_NN_AHEAD
 #define AGX_NN_AHEAD 4 // activation fragments in flight per wave in the row-stationary k-loop
 #endif
+/* (Variants measured flat or negative and removed from the source — the records are in profiles/: a ring of three weight stages
+ *  (r04_nn_ab*.txt: spills), the pair-balance ticks in the column-tile loop (-0.6 %), the interleaved read order of the column loop, the
+ *  conditional layer prefetch / input prefetch / fused residual add / two-pass conv5x5 switches (all on since round 4), the
+ *  operand-traffic timing experiments AGX_NN_DBG_NOLDS / _NOW (r03), the 12-wave tile and the accumulator initialisation inside the first
+ *  stage (r05_nn_ab.txt).) */
 
 namespace
 {
@@ -157,7 +126,6 @@ namespace
 			static constexpr int NPOS = 1 + S + NT * 16 + S + 2;                  // stored positions (index = position + 1)
 			static constexpr int CH = F / 8;                                     // 16-byte chunks per position
 			static constexpr int PPR = (16 / CH) > 0 ? (16 / CH) : 1;            // positions per 256-byte bank row
-			static constexpr int PLANE_BYTES = NPOS * F * 2;
 			// The 8 waves of a workgroup are CG channel groups x PG position groups: 4 x 2, except for 64-filter nets on boards whose tiles are
 			// not rows (20x20: the tap-major k-loop, one activation fragment read per (tap, tile)), where 4 groups would leave a wave a single
 			// 16-channel tile (MT = 1) per fragment read: 2 x 4 there (+12 % measured).  128-filter nets keep 4 x 2 on every board: with
@@ -169,8 +137,20 @@ namespace
 			// neighbouring column is the same tile shifted by one position, so one activation fragment feeds the three taps dx = -1, 0, +1 like
 			// a row's fragment feeds dy on 15x15 boards (conv3x3_mac_cols) — and rows 16..19 stay six ordinary tiles of consecutive positions
 			// (16 rows x 21 = 336 positions = 21 whole tiles lie in front of them).  A position group owns 10 columns + 3 of those.
-			static constexpr bool COLT = (ROWS == 20 && COLS == 20 && F == 128 && AGX_NN_COLUMN_TILES != 0);
+			static constexpr bool COLT = (ROWS == 20 && COLS == 20 && F == 128);
 			static constexpr int COL_TILES = COLS / 2, TAIL_TILES = 3, TAIL_FIRST = 21;
+			/* Bytes of a stored position.  Row tiles (S = 16: a tile's 16 positions are whole 256-byte bank rows) keep F halves per position and the
+			 * XOR chunk swizzle below — every LDS address of the k-loop is one base + immediates anyway.  On column tiles the lanes of a fragment
+			 * are 21 positions apart and the XOR term differs from fragment to fragment: 4.2 vector instructions of address arithmetic per
+			 * ds_read_b128 (176 beside the 156 MFMAs of two stages, round 5), and as many per epilogue store.  There a position is PADDED by
+			 * PAD x 16 bytes instead: chunk c of position i sits at i * POS_BYTES + 16 c — bank group (PAD * i + c) mod 16, the additive
+			 * counterpart of the swizzle — so every fragment of a stage is ONE per-lane base + an immediate offset, and so is every epilogue
+			 * store.  Bank model (MI355X_MICROARCH.md, LDS; scripts/nn_lds_banks.py): PAD 1 = the XOR swizzle's conflicts (column and tail
+			 * reads 2-way, 8-byte stores 2-way), PAD 2 = every read conflict-free, stores 4-way.  (The one-position pad also keeps planes
+			 * 16-byte aligned; 8-byte pads would give conflict-free stores but misalign ds_read_b128.) */
+			static constexpr int PAD = COLT ? AGX_NN_COLS_PAD : 0;
+			static constexpr int POS_BYTES = F * 2 + 16 * PAD;
+			static constexpr int PLANE_BYTES = NPOS * POS_BYTES;
 			static constexpr int NTW = COLT ? (COL_TILES + TAIL_TILES) : (NT + PG - 1) / PG; // position tiles per wave
 			static constexpr int THREADS = 512;                                  // 8 waves, 2 per SIMD
 			// (shifts and masks on purpose: written with / and % the 15x15 kernels came out 12 % (6x128) and 60 x (2x64) slower)
@@ -178,18 +158,13 @@ namespace
 			__device__ static __forceinline__ int first_tile(int wave) { return (wave >> (CG == 4 ? 2 : 1)) * NTW; }
 			/* Which 16-byte slot of its bank row a position's chunk c lives in: c ^ swizzle(stored index).  A ds_read_b128 is served in four
 			 * groups of 16 lanes — {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32 (MI355X_MICROARCH.md, LDS): a group is 8 lanes
-			 * of one 8-channel chunk and 8 of the next, and is conflict-free when its 16 slots differ.  Default: index mod CH — consecutive
-			 * positions take consecutive slots (unshifted tiles conflict-free, tiles shifted by an odd dx 2-way in two of the four groups).
-			 * Column tiles: 2 * index mod 16 — only even values, so the two chunks of a group keep to even / odd slots, and the 8 lanes of a
-			 * chunk, whose positions differ mod 8 in every tile kind (consecutive, or 21 apart: 42 r = 10 r mod 16), get 8 different ones:
-			 * every fragment read of the column loop is conflict-free (model: 8.0 -> 4.0 LDS cycles per column read, 5.8 -> 4.0 per tail
-			 * read), at the price of 4-way instead of 2-way conflicts on the epilogue's 8-byte stores (26 per layer against 252 reads).
-			 * Measured on the 10x128 tower: 1172-1183 against 1197-1201 TFLOP/s — the k-loop is not waiting for the LDS array, the exposed
-			 * stores of the epilogue are; off by default (AGX_NN_COLS_SWIZZLE). */
+			 * of one 8-channel chunk and 8 of the next, and is conflict-free when its 16 slots differ.  index mod CH: consecutive positions
+			 * take consecutive slots (unshifted tiles conflict-free, tiles shifted by an odd dx 2-way in two of the four groups).  Padded
+			 * positions (PAD > 0) are not swizzled. */
 			__device__ static __forceinline__ int swizzle(int index)
 			{
-				if constexpr (COLT && AGX_NN_COLS_SWIZZLE)
-					return (index << 1) & 15;
+				if constexpr (PAD > 0)
+					return 0;
 				else
 					return (index / PPR) % CH;
 			}
@@ -254,11 +229,7 @@ namespace
 	{
 			// (LDS address space spelled out: through plain `volatile int*` the two accesses of done() were FLAT instructions — to LDS by way of the
 			//  vector-memory path, counted on both wait counters — in the middle of the k-loop's counted lgkmcnt / vmcnt waits)
-#if AGX_NN_PAIR_LDS
 			typedef __attribute__((address_space(3))) int lds_int;
-#else
-			typedef int lds_int;
-#endif
 			volatile lds_int *mine;
 			const volatile lds_int *partner;
 			int tick, seen;
@@ -268,7 +239,7 @@ namespace
 			}
 			__device__ __forceinline__ void turn()
 			{
-#if AGX_NN_PAIR_BALANCE || AGX_NN_PAIR_BALANCE_COLS
+#if AGX_NN_PAIR_BALANCE
 				const int ahead = __builtin_amdgcn_readfirstlane(tick - seen); // wave-uniform: a scalar compare and branch
 				if (ahead > 0)
 					__builtin_amdgcn_s_setprio(1);
@@ -280,7 +251,7 @@ namespace
 			}
 			__device__ __forceinline__ void done()
 			{
-#if AGX_NN_PAIR_BALANCE || AGX_NN_PAIR_BALANCE_COLS
+#if AGX_NN_PAIR_BALANCE
 				tick++;
 				*mine = tick;
 				seen = *partner;
@@ -290,7 +261,7 @@ namespace
 	template<typename G>
 	__device__ __forceinline__ int plane_offset(int index, int chunk)
 	{ // byte offset of a 16-byte chunk of stored position `index` (= position + 1)
-		return (index * G::CH + (chunk ^ G::swizzle(index))) * 16;
+		return index * G::POS_BYTES + (chunk ^ G::swizzle(index)) * 16;
 	}
 
 	/* The weight fragments of a layer's first stage, requested by the layer in front of it: a layer that fetches them itself starts with an
@@ -302,6 +273,21 @@ namespace
 			half8 a[3][MT];
 			const half8 *next;
 	};
+	/* A layer's bias values, requested by the layer in front of it behind its k-loop: requested at the layer's own top — straight behind the
+	 * layer barrier — every wave of the workgroup waits out an L2 round trip there, per channel tile, with nothing to hide it (the
+	 * accumulators start from the bias).  Carried across the epilogue and the barrier only, where the k-loop's weight registers are free. */
+	template<int MT>
+	struct BiasCarry
+	{
+			floatx4 b[MT];
+	};
+	template<typename G>
+	__device__ __forceinline__ void request_bias(const float *__restrict__ bias, int wave, int lane, BiasCarry<G::MT> &carry)
+	{
+#pragma unroll
+		for (int i = 0; i < G::MT; i++)
+			carry.b[i] = *reinterpret_cast<const floatx4*>(bias + (G::channel_group(wave) * G::MT + i) * 16 + 4 * (lane >> 4));
+	}
 	template<int F, int ROWS, int COLS>
 	__device__ __forceinline__ void request_first_stage(const half8 *__restrict__ wpk, int wave, int lane, WeightCarry<Geometry<F, ROWS, COLS>::MT> &carry)
 	{
@@ -379,7 +365,7 @@ namespace
 			floatx4 (&acc)[Geometry<F, ROWS, COLS>::MT][Geometry<F, ROWS, COLS>::NTW], WeightCarry<Geometry<F, ROWS, COLS>::MT> *carry = nullptr)
 	{
 		typedef Geometry<F, ROWS, COLS> G;
-		static_assert(G::S == 16, "a position tile must be a board row");
+		static_assert(G::S == 16 && G::PAD == 0, "a position tile must be a board row (whole 256-byte bank rows, XOR chunk swizzle)");
 		const int r = lane & 15;
 		const int q4 = lane >> 4;
 		const int mg = G::channel_group(wave);   // output channels [mg * 16 * MT, (mg + 1) * 16 * MT)
@@ -411,33 +397,6 @@ namespace
 		const int index_base = 1 + G::S + n0 * 16 + r; // stored index of this lane's position in the wave's first output row
 #if AGX_NN_PAIR_BALANCE
 		PairBalance balance(pair_progress(), wave);
-#endif
-#if AGX_NN_WEIGHT_RING == 3
-		// Three sets of weight fragments: a stage's fragments are requested TWO stages before their use.  One stage of MFMAs (~0.7 us for the
-		// two waves of a SIMD) is about an L2 round trip under load — fetched one stage ahead every stage began by waiting for its weights.
-		static_assert(STAGES % 3 == 0, "three stages per loop turn (static ring index)");
-		half8 a2[3][G::MT];
-#pragma unroll
-		for (int dyi = 0; dyi < 3; dyi++)
-#pragma unroll
-			for (int i = 0; i < G::MT; i++)
-				a1[dyi][i] = wl[STAGE_FRAGS + (dyi * G::MT + i) * 64 + lane];
-#pragma unroll 1
-		for (int s = 0; s < STAGES; s += 3)
-		{
-			if (3 * s < STAGES)
-				__builtin_amdgcn_s_setprio(3);
-			else if (3 * s < 2 * STAGES)
-				__builtin_amdgcn_s_setprio(2);
-			else
-				__builtin_amdgcn_s_setprio(1);
-			// (past the layer's last stage the requests wrap around to its first ones instead of branching: see below)
-			conv3x3_rows_stage<F, ROWS, COLS>(src, wl + ((s + 2) % STAGES) * STAGE_FRAGS, s / 3, s % 3, index_base, q4, my_tiles, lane, a0, a2, acc);
-			conv3x3_rows_stage<F, ROWS, COLS>(src, wl + ((s + 3) % STAGES) * STAGE_FRAGS, (s + 1) / 3, (s + 1) % 3, index_base, q4, my_tiles, lane, a1, a0, acc);
-			conv3x3_rows_stage<F, ROWS, COLS>(src, wl + ((s + 4) % STAGES) * STAGE_FRAGS, (s + 2) / 3, (s + 2) % 3, index_base, q4, my_tiles, lane, a2, a1, acc);
-		}
-		__builtin_amdgcn_s_setprio(0);
-		return;
 #endif
 #pragma unroll 1
 		for (int s = 0; s < STAGES; s += 2)
@@ -481,6 +440,7 @@ namespace
 			floatx4 (&acc)[Geometry<F, ROWS, COLS>::MT][Geometry<F, ROWS, COLS>::NTW])
 	{
 		typedef Geometry<F, ROWS, COLS> G;
+		static_assert(G::PAD == 0, "tiles of consecutive positions in unpadded planes (the XOR chunk swizzle is invariant over a wave's tiles)");
 		const int r = lane & 15;
 		const int q4 = lane >> 4;
 		const int mg = G::channel_group(wave);   // output channels [mg * 16 * MT, (mg + 1) * 16 * MT)
@@ -567,7 +527,7 @@ namespace
 	 * shift, accumulating into OUTPUT columns c + 1, c, c - 1.  A wave owns 10 output columns (12 input fragments per stage instead of
 	 * 30) and three ordinary tiles of rows 16..19, which take their three shifted fragments from the same stage's weights: 21 fragment
 	 * reads per stage of 78 MFMAs, against 42 per 84 before.  Lanes of a fragment are 21 positions apart: 21 r mod 16 = 5 r mod 16 is a
-	 * permutation, so the chunk swizzle (position mod 16) still spreads the 16 lanes of a read over all banks.
+	 * permutation, so the padded positions (Geometry::PAD: bank group (PAD * position + chunk) mod 16) spread the 16 lanes of a read over all banks.
 	 * Weight fragments in consumption order (pack_conv_rows with the roles of dx and dy exchanged): stage = (chunk, dy), then channel
 	 * group, dx, tile.
 	 */
@@ -577,46 +537,23 @@ namespace
 			floatx4 (&acc)[Geometry<F, ROWS, COLS>::MT][Geometry<F, ROWS, COLS>::NTW])
 	{
 		typedef Geometry<F, ROWS, COLS> G;
-		static_assert(G::PPR == 1 && G::CH == 16, "one position per 256-byte bank row");
+		static_assert(G::PAD > 0, "padded positions: every fragment of a stage is a per-lane base + an immediate offset");
 #pragma unroll
 		for (int dxi = 0; dxi < 3; dxi++)
 #pragma unroll
 			for (int i = 0; i < G::MT; i++)
-#ifdef AGX_NN_DBG_NOW /* timing experiment only (wrong results): no weight fetch */
-				a_next[dxi][i] = a_cur[dxi][i];
-#else
 				a_next[dxi][i] = wnext[(dxi * G::MT + i) * 64 + lane];
-#endif
-		const int shift = (dyi - 1) * G::S;
-		const int chunk = kc * 4 + q4;
 		constexpr int NCOL = G::COL_TILES + 2;             // input columns x0 - 1 .. x0 + COL_TILES
 		constexpr int NFRAG = NCOL + 3 * G::TAIL_TILES;     // then (tail tile, dx) pairs
-		// the order of the reads: the (tail tile, dx) fragments feed MT MFMAs each, a column's 3 * MT — dealt between the columns, every
-		// stretch of the loop has the same MFMAs per read.  slot(f) < NCOL: input column slot(f); else the pair slot(f) - NCOL
-#ifdef AGX_NN_DBG_NOLDS
-		const half8 b0_dbg = *reinterpret_cast<const half8*>(src + (col_base + shift) * (G::CH * 16) + ((chunk ^ ((col_base + shift) & 15)) * 16));
-#endif
-		auto slot = [](int f) -> int
-		{
-#if AGX_NN_COLS_INTERLEAVE
-			if (f < 2)
-				return f;
-			if (f >= 2 + 2 * 3 * G::TAIL_TILES)
-				return f - 3 * G::TAIL_TILES;
-			return ((f & 1) == 0) ? (NCOL + (f - 2) / 2) : ((f + 1) / 2);
-#else
-			return f;
-#endif
-		};
-		auto fragment = [&](int f) -> half8
-		{
-			const int k = slot(f);
-#ifdef AGX_NN_DBG_NOLDS /* timing experiment only (wrong results): one fragment read per stage */
-			if (f > 0)
-				return b0_dbg;
-#endif
-			const int index = (k < NCOL) ? (col_base + shift + k) : (tail_base + shift + ((k - NCOL) / 3) * 16 + ((k - NCOL) % 3 - 1));
-			return *reinterpret_cast<const half8*>(src + index * (G::CH * 16) + ((chunk ^ G::swizzle(index)) * 16));
+		// the stage's two bases: this lane's cell in input column x0 - 1 and in the wave's first tail tile, both shifted by dy rows, chunk kc * 4 + q4
+		const int stage_off = (dyi - 1) * G::S * G::POS_BYTES + kc * 64; // wave-uniform
+		const char *col_ptr = src + col_base + stage_off;
+		const char *tail_ptr = src + tail_base + stage_off;
+		auto fragment = [&](int k) -> half8
+		{ // k < NCOL: input column k; else the pair (tail tile, dx) = ((k - NCOL) / 3, (k - NCOL) % 3)
+			if (k < NCOL)
+				return *reinterpret_cast<const half8*>(col_ptr + k * G::POS_BYTES);
+			return *reinterpret_cast<const half8*>(tail_ptr + (((k - NCOL) / 3) * 16 + ((k - NCOL) % 3 - 1)) * G::POS_BYTES);
 		};
 		constexpr int AHEAD = AGX_NN_COLS_AHEAD;
 		half8 b[AHEAD];
@@ -629,7 +566,7 @@ namespace
 			const int fn = f + AHEAD - 1;
 			if (fn < NFRAG)
 				b[fn % AHEAD] = fragment(fn);
-			const int k = slot(f);
+			const int k = f;
 			if (k < NCOL)
 			{
 #pragma unroll
@@ -651,9 +588,7 @@ namespace
 				for (int i = 0; i < G::MT; i++)
 					acc[i][G::COL_TILES + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_cur[dxi][i], b[f % AHEAD], acc[i][G::COL_TILES + t], 0, 0, 0);
 			}
-#if AGX_NN_COLS_BARRIER
 			__builtin_amdgcn_sched_barrier(0); // (as in conv3x3_rows_stage: keep AHEAD - 1 requests in flight behind every turn's MFMAs)
-#endif
 		}
 	}
 	template<int F, int ROWS, int COLS, bool ZERO = true>
@@ -684,53 +619,20 @@ namespace
 #pragma unroll
 			for (int i = 0; i < G::MT; i++)
 				a0[dxi][i] = wl[(dxi * G::MT + i) * 64 + lane];
-		const int col_base = 1 + G::S + r * G::S + pg * G::COL_TILES - 1;                    // stored index of (row r, column x0 - 1)
-		const int tail_base = 1 + G::S + (G::TAIL_FIRST + pg * G::TAIL_TILES) * 16 + r;      // ... of this lane's cell in the wave's first tail tile
-#if AGX_NN_PAIR_BALANCE_COLS
-		PairBalance balance(pair_progress(), wave);
-#endif
-#if AGX_NN_WEIGHT_RING == 3
-		static_assert(STAGES % 3 == 0, "three stages per loop turn (static ring index)");
-		half8 a2[3][G::MT]; // (weights requested two stages ahead: conv3x3_mac_rows)
-#pragma unroll
-		for (int dxi = 0; dxi < 3; dxi++)
-#pragma unroll
-			for (int i = 0; i < G::MT; i++)
-				a1[dxi][i] = wl[STAGE_FRAGS + (dxi * G::MT + i) * 64 + lane];
-#pragma unroll 1
-		for (int s = 0; s < STAGES; s += 3)
-		{
-			if (3 * s < STAGES)
-				__builtin_amdgcn_s_setprio(3);
-			else if (3 * s < 2 * STAGES)
-				__builtin_amdgcn_s_setprio(2);
-			else
-				__builtin_amdgcn_s_setprio(1);
-			conv3x3_cols_stage<F, ROWS, COLS>(src, wl + ((s + 2) % STAGES) * STAGE_FRAGS, s / 3, s % 3, col_base, tail_base, q4, lane, a0, a2, acc);
-			conv3x3_cols_stage<F, ROWS, COLS>(src, wl + ((s + 3) % STAGES) * STAGE_FRAGS, (s + 1) / 3, (s + 1) % 3, col_base, tail_base, q4, lane, a1, a0, acc);
-			conv3x3_cols_stage<F, ROWS, COLS>(src, wl + ((s + 4) % STAGES) * STAGE_FRAGS, (s + 2) / 3, (s + 2) % 3, col_base, tail_base, q4, lane, a2, a1, acc);
-		}
-		__builtin_amdgcn_s_setprio(0);
-		return;
-#endif
+		// byte offsets (chunk q4) of this lane's cell (row r, column x0 - 1) and of its cell in the wave's first tail tile
+		const int col_base = plane_offset<G>(1 + G::S + r * G::S + pg * G::COL_TILES - 1, q4);
+		const int tail_base = plane_offset<G>(1 + G::S + (G::TAIL_FIRST + pg * G::TAIL_TILES) * 16 + r, q4);
 #pragma unroll 1
 		for (int s = 0; s < STAGES; s += 2)
 		{
-#if AGX_NN_PAIR_BALANCE_COLS
-			balance.turn();
-#else
 			if (3 * s < STAGES) // (priority by remaining work)
 				__builtin_amdgcn_s_setprio(3);
 			else if (3 * s < 2 * STAGES)
 				__builtin_amdgcn_s_setprio(2);
 			else
 				__builtin_amdgcn_s_setprio(1);
-#endif
 			conv3x3_cols_stage<F, ROWS, COLS>(src, wl + (s + 1) * STAGE_FRAGS, s / 3, s % 3, col_base, tail_base, q4, lane, a0, a1, acc);
 			conv3x3_cols_stage<F, ROWS, COLS>(src, wl + ((s + 2 < STAGES) ? (s + 2) : 0) * STAGE_FRAGS, (s + 1) / 3, (s + 1) % 3, col_base, tail_base, q4, lane, a1, a0, acc);
-#if AGX_NN_PAIR_BALANCE_COLS
-			balance.done();
-#endif
 		}
 		__builtin_amdgcn_s_setprio(0);
 	}
@@ -739,7 +641,7 @@ namespace
 	__device__ __forceinline__ void conv3x3_mac(const char *src, const half8 *__restrict__ wpk, int wave, int lane,
 			floatx4 (&acc)[Geometry<F, ROWS, COLS>::MT][Geometry<F, ROWS, COLS>::NTW], WeightCarry<Geometry<F, ROWS, COLS>::MT> *carry = nullptr)
 	{
-		if constexpr (Geometry<F, ROWS, COLS>::S == 16 && AGX_NN_ROW_STATIONARY)
+		if constexpr (Geometry<F, ROWS, COLS>::S == 16)
 			conv3x3_mac_rows<F, ROWS, COLS, ZERO>(src, wpk, wave, lane, acc, carry);
 		else if constexpr (Geometry<F, ROWS, COLS>::COLT)
 			conv3x3_mac_cols<F, ROWS, COLS, ZERO>(src, wpk, wave, lane, acc);
@@ -767,8 +669,9 @@ namespace
 
 	template<int F, int ROWS, int COLS, bool SKIP, bool TANH = false>
 	__device__ __forceinline__ void conv3x3(const char *src, char *dst, const half8 *__restrict__ wpk, const float *__restrict__ bias, int wave,
-			int lane AGX_NN_STAMP_PARAM, WeightCarry<Geometry<F, ROWS, COLS>::MT> *carry = nullptr)
-	{
+			int lane AGX_NN_STAMP_PARAM, WeightCarry<Geometry<F, ROWS, COLS>::MT> *carry = nullptr, BiasCarry<Geometry<F, ROWS, COLS>::MT> *bias_carry = nullptr,
+			const float *__restrict__ next_bias = nullptr)
+	{ // bias_carry: holds this layer's bias values on entry and the next layer's (next_bias) on return
 		typedef Geometry<F, ROWS, COLS> G;
 		const int r = lane & 15;
 		const int q4 = lane >> 4;
@@ -779,11 +682,17 @@ namespace
 		// the shadow of the first weight fetch, and the epilogue — which both waves of a SIMD reach with no MFMAs left to hide behind —
 		// shrinks to ReLU, convert, mask, store.
 		floatx4 acc[G::MT][G::NTW];
+		// Row tiles (S = 16): tile n of the wave is 16 whole bank rows behind tile 0 and the chunk swizzle does not depend on the tile, so a lane's
+		// accesses to its cells are ONE address per channel tile + immediates (n * 4096 bytes) — written out here: left to plane_offset() of each
+		// tile's position the compiler kept MT * NTW per-lane offsets in registers for the whole kernel and added one to the plane per access.
+		constexpr bool ROW_TILES = (G::S == 16);
+		const int index0 = 1 + G::S + n0 * 16 + r; // stored index of this lane's cell in the wave's first tile (row tiles)
 #pragma unroll
 		for (int i = 0; i < G::MT; i++)
 		{
 			const int ch = (mg * G::MT + i) * 16 + 4 * q4;
-			const floatx4 bv = *reinterpret_cast<const floatx4*>(bias + ch);
+			const floatx4 bv = (bias_carry != nullptr) ? bias_carry->b[i] : *reinterpret_cast<const floatx4*>(bias + ch);
+			const char *skip0 = dst + plane_offset<G>(index0, ch / 8) + (ch % 8) * 2;
 #pragma unroll
 			for (int n = 0; n < G::NTW; n++)
 			{
@@ -791,21 +700,14 @@ namespace
 				if (SKIP && n < my_tiles)
 				{
 					const int pos = G::S + G::tile_position(wave, n, r);
-#if AGX_NN_FMA_MIX
 					// bias + (float) residual as ONE instruction per value: v_fma_mix_f32 widens the fp16 operand itself (h * 1.0 + b rounds once,
 					// exactly like the conversion followed by the add)
-					const uint2 sk = *reinterpret_cast<const uint2*>(dst + plane_offset<G>(pos + 1, ch / 8) + (ch % 8) * 2);
+					const uint2 sk = ROW_TILES ? *reinterpret_cast<const uint2*>(skip0 + n * 16 * G::POS_BYTES)
+							: *reinterpret_cast<const uint2*>(dst + plane_offset<G>(pos + 1, ch / 8) + (ch % 8) * 2);
 					v[0] = half_plus_float_lo(sk.x, bv[0]);
 					v[1] = half_plus_float_hi(sk.x, bv[1]);
 					v[2] = half_plus_float_lo(sk.y, bv[2]);
 					v[3] = half_plus_float_hi(sk.y, bv[3]);
-#else
-					const half4 sk = *reinterpret_cast<const half4*>(dst + plane_offset<G>(pos + 1, ch / 8) + (ch % 8) * 2);
-					v[0] += static_cast<float>(sk[0]);
-					v[1] += static_cast<float>(sk[1]);
-					v[2] += static_cast<float>(sk[2]);
-					v[3] += static_cast<float>(sk[3]);
-#endif
 				}
 				acc[i][n] = v;
 			}
@@ -813,8 +715,41 @@ namespace
 		AGX_NN_MARK(2);
 		conv3x3_mac<F, ROWS, COLS, false>(src, wpk, wave, lane, acc, carry);
 		AGX_NN_MARK(3);
+		if (bias_carry != nullptr)
+			request_bias<G>(next_bias, wave, lane, *bias_carry);
 
 		// epilogue: lane holds out-channels 4*q4 .. 4*q4+3 of tile i for position r of tile n
+		if constexpr (ROW_TILES && !TANH)
+		{
+			// Every tile of a wave is a board row (NT == ROWS): the only cell of a tile that is not on the board is the spare column's, lane
+			// r == COLS of every tile.  Those lanes sit the stores out (one exec mask around all of them) instead of every tile masking its
+			// values: the spare column stays zero from the plane's clearing.  ReLU after the conversion (rounding is monotonic, so
+			// max(cvt(x), 0) == cvt(max(x, 0))) on packed halves: 4 vector instructions per tile (2 conversions, 2 packed max) + one
+			// ds_write_b64 at an immediate offset.
+			static_assert(G::NT == ROWS && G::S == COLS + 1, "a tile is a board row + the spare column");
+			if (r < COLS)
+			{
+#pragma unroll
+				for (int i = 0; i < G::MT; i++)
+				{
+					const int ch = (mg * G::MT + i) * 16 + 4 * q4;
+					char *out0 = dst + plane_offset<G>(index0, ch / 8) + (ch % 8) * 2;
+#pragma unroll
+					for (int n = 0; n < G::NTW; n++)
+						if (n < my_tiles)
+						{
+							const floatx4 v = acc[i][n];
+							half2 lo { static_cast<half_t>(v[0]), static_cast<half_t>(v[1]) }, hi { static_cast<half_t>(v[2]), static_cast<half_t>(v[3]) };
+							const half2 zero2 { static_cast<half_t>(0.0f), static_cast<half_t>(0.0f) };
+							lo = __builtin_elementwise_max(lo, zero2);
+							hi = __builtin_elementwise_max(hi, zero2);
+							*reinterpret_cast<uint2*>(out0 + n * 16 * G::POS_BYTES) = uint2 { __builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi) };
+						}
+				}
+			}
+			AGX_NN_MARK(4);
+			return;
+		}
 #pragma unroll
 		for (int i = 0; i < G::MT; i++)
 		{
@@ -839,8 +774,7 @@ namespace
 						*reinterpret_cast<half4*>(ptr) = o;
 					}
 					else
-					{ // ReLU after the conversion (rounding is monotonic, so max(cvt(x), 0) == cvt(max(x, 0))) on packed halves, the spare
-					  // column / overhang cells masked to zero by an AND: 6 vector instructions per tile instead of 10
+					{ // (boards whose tiles are not rows: the spare column / overhang cells masked to zero by an AND)
 						half2 lo { static_cast<half_t>(v[0]), static_cast<half_t>(v[1]) }, hi { static_cast<half_t>(v[2]), static_cast<half_t>(v[3]) };
 						const half2 zero2 { static_cast<half_t>(0.0f), static_cast<half_t>(0.0f) };
 						lo = __builtin_elementwise_max(lo, zero2);
@@ -868,9 +802,9 @@ namespace
 	 *         add their partial sums one after the other (fixed order, so results do not depend on wave timing).
 	 */
 	template<int F, int ROWS, int COLS, int MODE>
-	__device__ __forceinline__ void conv3x3_inplace(char *plane, const half8 *__restrict__ wpk, const float *__restrict__ bias, half4 *skip,
-			const float *__restrict__ wp2, float *ppart, int wave, int lane AGX_NN_STAMP_PARAM)
-	{
+	__device__ __forceinline__ void conv3x3_inplace(char *plane, const half8 *__restrict__ wpk, BiasCarry<Geometry<F, ROWS, COLS>::MT> &bias_carry,
+			const float *__restrict__ next_bias, half4 *skip, const float *__restrict__ wp2, float *ppart, int wave, int lane AGX_NN_STAMP_PARAM)
+	{ // bias_carry: this layer's bias values on entry, the next layer's (next_bias, may be null: nothing follows) on return
 		typedef Geometry<F, ROWS, COLS> G;
 		const int r = lane & 15;
 		const int q4 = lane >> 4;
@@ -878,16 +812,15 @@ namespace
 		const int n0 = G::first_tile(wave);
 		const int my_tiles = G::tile_count(wave);
 		floatx4 acc[G::MT][G::NTW];
-		half4 *my_skip_generic = skip + (wave * G::MT * G::NTW) * 64 + lane;
-#if AGX_NN_OPAQUE_SKIP
-		// (the 2 * MT * NTW addresses behind this pointer do not depend on the layer: hipcc computed all of them — 26 register pairs on 20x20 — once per
-		//  kernel, kept what fitted and reloaded the rest from scratch one by one, each reload followed by s_waitcnt vmcnt(0), in front of every
-		//  layer's residual loads and stores; with the pointer opaque they are this layer's own base + immediate offsets.  The opaque pointer has lost
-		//  its address space — accesses through it would be FLAT and count on the LDS wait counter as well — so it is viewed as global memory again.)
-		asm volatile("" : "+v"(my_skip_generic));
-#endif
+		// (the 2 * MT * NTW addresses of a lane's residual values do not depend on the layer: hipcc computed all of them — 26 register pairs on 20x20 —
+		//  once per kernel, kept what fitted and reloaded the rest from scratch one by one, each reload followed by s_waitcnt vmcnt(0), in front of
+		//  every layer's residual loads and stores.  With the LANE's part of the address opaque they are this layer's own: a wave-uniform base in
+		//  scalar registers + one 32-bit lane offset + immediates (the scalar-base form of global_load / global_store), no 64-bit vector address
+		//  arithmetic per access.)
 		typedef __attribute__((address_space(1))) half4 global_half4;
-		global_half4 *my_skip = (global_half4*) my_skip_generic;
+		int skip_lane = lane;
+		asm volatile("" : "+v"(skip_lane));
+		global_half4 *my_skip = (global_half4*) (skip + __builtin_amdgcn_readfirstlane(wave * G::MT * G::NTW * 64)) + skip_lane;
 		if (MODE == 0 || MODE == 1)
 		{ // The accumulators START from bias (+ the residual input, fetched from the workgroup's scratch): requested here, the 2 * NTW loads of a
 		  // lane are in flight together behind the layer's first weight fetch.  In the epilogue — where nothing is left to hide a global
@@ -895,19 +828,18 @@ namespace
 #pragma unroll
 			for (int i = 0; i < G::MT; i++)
 			{
-				const int ch = (mg * G::MT + i) * 16 + 4 * q4;
-				const floatx4 bv = *reinterpret_cast<const floatx4*>(bias + ch);
+				const floatx4 bv = bias_carry.b[i];
 #pragma unroll
 				for (int n = 0; n < G::NTW; n++)
 				{
 					floatx4 v = bv;
 					if (MODE == 1)
-					{
-						const half4 sk = my_skip[(i * G::NTW + n) * 64];
-						v[0] += static_cast<float>(sk[0]);
-						v[1] += static_cast<float>(sk[1]);
-						v[2] += static_cast<float>(sk[2]);
-						v[3] += static_cast<float>(sk[3]);
+					{ // bias + (float) residual as one v_fma_mix_f32 per value (conv3x3: h * 1.0 + b rounds once, like the conversion followed by the add)
+						const uint2 sk = __builtin_bit_cast(uint2, my_skip[(i * G::NTW + n) * 64]);
+						v[0] = half_plus_float_lo(sk.x, bv[0]);
+						v[1] = half_plus_float_hi(sk.x, bv[1]);
+						v[2] = half_plus_float_lo(sk.y, bv[2]);
+						v[3] = half_plus_float_hi(sk.y, bv[3]);
 					}
 					acc[i][n] = v;
 				}
@@ -921,6 +853,9 @@ namespace
 			conv3x3_mac<F, ROWS, COLS>(plane, wpk, wave, lane, acc);
 		}
 		AGX_NN_MARK(3);
+		const BiasCarry<G::MT> bias_now = bias_carry; // (modes 2 and 3 add the bias behind the k-loop)
+		if (next_bias != nullptr)
+			request_bias<G>(next_bias, wave, lane, bias_carry);
 
 		if (MODE == 3)
 		{
@@ -934,7 +869,7 @@ namespace
 			for (int i = 0; i < G::MT; i++)
 			{
 				const int ch = (mg * G::MT + i) * 16 + 4 * q4;
-				const floatx4 bv = *reinterpret_cast<const floatx4*>(bias + ch);
+				const floatx4 bv = bias_now.b[i];
 #pragma unroll
 				for (int n = 0; n < G::NTW; n++)
 				{
@@ -986,7 +921,7 @@ namespace
 			for (int i = 0; i < G::MT; i++)
 			{
 				const int ch = (mg * G::MT + i) * 16 + 4 * q4;
-				const floatx4 bv = *reinterpret_cast<const floatx4*>(bias + ch);
+				const floatx4 bv = bias_now.b[i];
 				const floatx4 wv = *reinterpret_cast<const floatx4*>(wp2 + ch);
 #pragma unroll
 				for (int n = 0; n < G::NTW; n++)
@@ -1000,9 +935,7 @@ namespace
 				}
 			}
 			int r_part = r;
-#if AGX_NN_OPAQUE_SKIP
 			asm volatile("" : "+v"(r_part)); // (the NTW partial-sum addresses are this call's own, not kernel-wide constants reloaded from scratch one by one)
-#endif
 #pragma unroll
 			for (int n = 0; n < G::NTW; n++)
 			{
@@ -1020,30 +953,43 @@ namespace
 		// front of every LDS write of every layer.  An opaque copy of the lane's row makes them this layer's own few VALU instructions.
 		int r_mask = r;
 		asm volatile("" : "+v"(r_mask));
-		half4 out[G::MT][G::NTW];
+		// ReLU after the conversion on packed halves (rounding is monotonic: max(cvt(x), 0) == cvt(max(x, 0))): 4 vector instructions per tile
+		// instead of 6.  Cells that are not on the board (spare column, overhang of the last tile: tail tiles only) are masked to zero by an AND.
+		uint2 out[G::MT][G::NTW];
+		bool valid[G::NTW];
+#pragma unroll
+		for (int n = 0; n < G::NTW; n++)
+		{
+			valid[n] = (n < my_tiles);
+			if (!(G::COLT && n < G::COL_TILES))
+			{ // (a column tile holds 16 cells of the board: nothing to mask)
+				const int pos = G::S + G::tile_position(wave, n, r_mask);
+				const int x = pos % G::S;
+				const int y = pos / G::S - 1;
+				valid[n] = valid[n] && (x < COLS) && (y < ROWS);
+			}
+		}
 #pragma unroll
 		for (int i = 0; i < G::MT; i++)
 		{
 #pragma unroll
 			for (int n = 0; n < G::NTW; n++)
 			{
-				bool valid = (n < my_tiles);
-				if (!(G::COLT && n < G::COL_TILES))
-				{ // (a column tile holds 16 cells of the board: nothing to mask)
-					const int pos = G::S + G::tile_position(wave, n, r_mask);
-					const int x = pos % G::S;
-					const int y = pos / G::S - 1;
-					valid = valid && (x < COLS) && (y < ROWS);
-				}
 				const floatx4 v = acc[i][n];
-				half4 o;
-				o[0] = static_cast<half_t>(valid ? fmaxf(v[0], 0.0f) : 0.0f);
-				o[1] = static_cast<half_t>(valid ? fmaxf(v[1], 0.0f) : 0.0f);
-				o[2] = static_cast<half_t>(valid ? fmaxf(v[2], 0.0f) : 0.0f);
-				o[3] = static_cast<half_t>(valid ? fmaxf(v[3], 0.0f) : 0.0f);
-				out[i][n] = o;
+				half2 lo { static_cast<half_t>(v[0]), static_cast<half_t>(v[1]) }, hi { static_cast<half_t>(v[2]), static_cast<half_t>(v[3]) };
+				const half2 zero2 { static_cast<half_t>(0.0f), static_cast<half_t>(0.0f) };
+				lo = __builtin_elementwise_max(lo, zero2);
+				hi = __builtin_elementwise_max(hi, zero2);
+				uint2 packed { __builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi) };
+				if (!(G::COLT && n < G::COL_TILES))
+				{
+					const uint32_t keep = valid[n] ? 0xFFFFFFFFu : 0u;
+					packed.x &= keep;
+					packed.y &= keep;
+				}
+				out[i][n] = packed;
 				if (MODE == 1)
-					my_skip[(i * G::NTW + n) * 64] = o;
+					my_skip[(i * G::NTW + n) * 64] = __builtin_bit_cast(half4, packed);
 			}
 		}
 		AGX_NN_MARK(4);
@@ -1051,6 +997,7 @@ namespace
 		AGX_NN_MARK(5);
 		int r_write = r;
 		asm volatile("" : "+v"(r_write));
+		// (padded positions: the stores of a lane are two bases — its cell in the wave's first column tile and in its first tail tile — + immediates)
 #pragma unroll
 		for (int i = 0; i < G::MT; i++)
 		{
@@ -1060,7 +1007,7 @@ namespace
 				if (n < my_tiles)
 				{
 					const int pos = G::S + G::tile_position(wave, n, r_write);
-					*reinterpret_cast<half4*>(plane + plane_offset<G>(pos + 1, ch / 8) + (ch % 8) * 2) = out[i][n];
+					*reinterpret_cast<uint2*>(plane + plane_offset<G>(pos + 1, ch / 8) + (ch % 8) * 2) = out[i][n];
 				}
 		}
 		AGX_NN_MARK(4);
@@ -1133,7 +1080,7 @@ namespace
 					}
 			}
 		}
-		else if constexpr (G::S == 16 && AGX_NN_ROW_STATIONARY && F == 64) // (128-filter nets keep the tap-major loop: measured 1 % faster, the 2 x 10 weight fragments in flight spill)
+		else if constexpr (G::S == 16 && F == 64) // (128-filter nets keep the tap-major loop: measured 1 % faster, the 2 x 10 weight fragments in flight spill)
 		{
 			// Input-row stationary like conv3x3_mac_rows: for a column shift dx the fragment of padded input row j is read once and feeds the
 			// five taps dy = -2 .. 2 (output rows j + 2 .. j - 2): 5 x (NTW + 4) fragment reads instead of 25 x NTW, and — the padded plane being
@@ -1192,7 +1139,7 @@ namespace
 						a_cur[dyi][i] = a_next[dyi][i];
 			}
 		}
-		else if constexpr (G::S == 16 && AGX_NN_ROW_STATIONARY && F == 128 && AGX_NN_CONV5_SPLIT)
+		else if constexpr (G::S == 16 && F == 128)
 		{
 			// 128 filters: the row-stationary loop above with the five vertical taps of a column shift taken in two passes — dy = -2, -1, 0
 			// (input rows -2 .. NTW - 1 of the wave) and dy = +1, +2 (rows 1 .. NTW + 1) — so that only 3 * MT + 2 * MT weight fragments are
@@ -1329,16 +1276,10 @@ namespace
 				reinterpret_cast<uint4*>(dst)[i] = zero4;
 			__syncthreads();
 		}
-		half4 *my_skip_generic = skip + (wave * G::MT * G::NTW) * 64 + lane;
-#if AGX_NN_OPAQUE_SKIP
-		// (the 2 * MT * NTW addresses behind this pointer do not depend on the layer: hipcc computed all of them — 26 register pairs on 20x20 — once per
-		//  kernel, kept what fitted and reloaded the rest from scratch one by one, each reload followed by s_waitcnt vmcnt(0), in front of every
-		//  layer's residual loads and stores; with the pointer opaque they are this layer's own base + immediate offsets.  The opaque pointer has lost
-		//  its address space — accesses through it would be FLAT and count on the LDS wait counter as well — so it is viewed as global memory again.)
-		asm volatile("" : "+v"(my_skip_generic));
-#endif
-		typedef __attribute__((address_space(1))) half4 global_half4;
-		global_half4 *my_skip = (global_half4*) my_skip_generic;
+		typedef __attribute__((address_space(1))) half4 global_half4; // (scalar base + opaque lane offset: conv3x3_inplace)
+		int skip_lane = lane;
+		asm volatile("" : "+v"(skip_lane));
+		global_half4 *my_skip = (global_half4*) (skip + __builtin_amdgcn_readfirstlane(wave * G::MT * G::NTW * 64)) + skip_lane;
 #pragma unroll
 		for (int i = 0; i < G::MT; i++)
 		{
@@ -1442,7 +1383,7 @@ namespace
 			for (int i = tid; i < F * 4; i += G::THREADS)
 				s_wq2[i] = p.wq2[i];
 
-#if AGX_NN_PAIR_BALANCE || AGX_NN_PAIR_BALANCE_COLS
+#if AGX_NN_PAIR_BALANCE
 		if (tid < 8)
 			pair_progress()[tid] = 0;
 #endif
@@ -1450,12 +1391,10 @@ namespace
 #ifdef AGX_NN_PROFILE
 		NnStamp stamp(wave, lane);
 #endif
-#if AGX_NN_INPUT_PREFETCH
 		static_assert(G::HW <= G::THREADS, "one feature word per thread");
 		uint32_t next_word = 0; // this thread's feature word of the board about to be staged
 		if (static_cast<int>(blockIdx.x) < batch && tid < G::HW)
 			next_word = features[static_cast<size_t>((p.slot_list != nullptr) ? p.slot_list[blockIdx.x] : static_cast<int>(blockIdx.x)) * G::HW + tid];
-#endif
 		for (int bi = blockIdx.x; bi < batch; bi += gridDim.x)
 		{
 			const int b = (p.slot_list != nullptr) ? p.slot_list[bi] : bi;
@@ -1466,11 +1405,7 @@ namespace
 			__syncthreads();
 			for (int c = tid; c < G::HW; c += G::THREADS)
 			{
-#if AGX_NN_INPUT_PREFETCH
 				const uint32_t word = next_word;
-#else
-				const uint32_t word = features[static_cast<size_t>(b) * G::HW + c];
-#endif
 				const int q = (c / COLS + 2) * G::S5 + (c % COLS + 2);
 #pragma unroll
 				for (int k = 0; k < (RAW ? 1 : 4); k++)
@@ -1490,6 +1425,8 @@ namespace
 			__syncthreads();
 			AGX_NN_MARK(0);
 			conv5x5_input<F, ROWS, COLS, INPLACE, RAW>(plane_t, plane_x, p.w_in, p.bias, skip, wave, lane);
+			BiasCarry<G::MT> bias_carry; // the first tower layer's bias values (with no block: the policy conv's), then each layer's successor's
+			request_bias<G>(p.bias + F, wave, lane, bias_carry);
 			__syncthreads();
 			AGX_NN_MARK(1);
 			if (!INPLACE)
@@ -1501,18 +1438,20 @@ namespace
 
 			AGX_NN_MARK(9);
 			// ---- residual tower ----
-			constexpr bool CARRY = !INPLACE && G::S == 16 && AGX_NN_ROW_STATIONARY && AGX_NN_LAYER_PREFETCH && AGX_NN_WEIGHT_RING == 2;
+			constexpr bool CARRY = !INPLACE && G::S == 16;
 			WeightCarry<G::MT> carry_store;
 			WeightCarry<G::MT> *carry = CARRY ? &carry_store : nullptr;
 			if constexpr (CARRY)
 				request_first_stage<F, ROWS, COLS>(p.w_tower, wave, lane, carry_store);
 			for (int blk = 0; blk < p.blocks; blk++)
 			{
+				// (bias_carry: every layer requests the next layer's bias values behind its k-loop; behind the last block follows the policy conv)
 				if (INPLACE)
 				{
-					conv3x3_inplace<F, ROWS, COLS, 0>(plane_x, p.w_tower + (2 * blk) * layer_halves8, p.bias + (1 + 2 * blk) * F, skip, nullptr, nullptr, wave, lane AGX_NN_STAMP_ARG);
+					conv3x3_inplace<F, ROWS, COLS, 0>(plane_x, p.w_tower + (2 * blk) * layer_halves8, bias_carry, p.bias + (2 + 2 * blk) * F, skip, nullptr, nullptr, wave,
+							lane AGX_NN_STAMP_ARG);
 					lds_barrier();
-					conv3x3_inplace<F, ROWS, COLS, 1>(plane_x, p.w_tower + (2 * blk + 1) * layer_halves8, p.bias + (2 + 2 * blk) * F, skip, nullptr, nullptr, wave,
+					conv3x3_inplace<F, ROWS, COLS, 1>(plane_x, p.w_tower + (2 * blk + 1) * layer_halves8, bias_carry, p.bias + (3 + 2 * blk) * F, skip, nullptr, nullptr, wave,
 							lane AGX_NN_STAMP_ARG);
 					lds_barrier();
 				}
@@ -1520,12 +1459,14 @@ namespace
 				{
 					if constexpr (CARRY)
 						carry_store.next = p.w_tower + (2 * blk + 1) * layer_halves8;
-					conv3x3<F, ROWS, COLS, false>(plane_x, plane_t, p.w_tower + (2 * blk) * layer_halves8, p.bias + (1 + 2 * blk) * F, wave, lane AGX_NN_STAMP_ARG, carry);
+					conv3x3<F, ROWS, COLS, false>(plane_x, plane_t, p.w_tower + (2 * blk) * layer_halves8, p.bias + (1 + 2 * blk) * F, wave, lane AGX_NN_STAMP_ARG, carry, &bias_carry,
+							p.bias + (2 + 2 * blk) * F);
 					__syncthreads();
 					AGX_NN_MARK(5);
 					if constexpr (CARRY)
 						carry_store.next = p.w_tower + (2 * blk + 2) * layer_halves8; // (behind the last block: the policy conv)
-					conv3x3<F, ROWS, COLS, true>(plane_t, plane_x, p.w_tower + (2 * blk + 1) * layer_halves8, p.bias + (2 + 2 * blk) * F, wave, lane AGX_NN_STAMP_ARG, carry);
+					conv3x3<F, ROWS, COLS, true>(plane_t, plane_x, p.w_tower + (2 * blk + 1) * layer_halves8, p.bias + (2 + 2 * blk) * F, wave, lane AGX_NN_STAMP_ARG, carry, &bias_carry,
+							p.bias + (3 + 2 * blk) * F);
 					__syncthreads();
 					AGX_NN_MARK(5);
 				}
@@ -1543,7 +1484,7 @@ namespace
 					floatx4 v { p.bv1[0], p.bv1[1], p.bv1[2], p.bv1[3] };
 					const int index0 = 1 + G::S + n * 16 + r;
 					const int swz0 = G::swizzle(index0);
-					const char *src0 = plane_x + index0 * G::CH * 16;
+					const char *src0 = plane_x + index0 * G::POS_BYTES;
 #pragma unroll
 					for (int kc = 0; kc < G::KC; kc++)
 					{
@@ -1567,24 +1508,23 @@ namespace
 			AGX_NN_MARK(6);
 			// ---- policy head: conv3x3 + ReLU into plane_t ----
 			if (INPLACE)
-				conv3x3_inplace<F, ROWS, COLS, 2>(plane_x, p.w_tower + (2 * p.blocks) * layer_halves8, p.bias + (1 + 2 * p.blocks) * F, nullptr, s_wp2, ppart,
-						wave, lane AGX_NN_STAMP_ARG);
+				conv3x3_inplace<F, ROWS, COLS, 2>(plane_x, p.w_tower + (2 * p.blocks) * layer_halves8, bias_carry, QHEAD ? p.bias + (2 + 2 * p.blocks) * F : nullptr, nullptr, s_wp2,
+						ppart, wave, lane AGX_NN_STAMP_ARG);
 			else
 			{
 				if constexpr (CARRY)
 					carry_store.next = p.w_tower + (2 * p.blocks) * layer_halves8; // nothing follows: its last turn requests its own first stage again
-				conv3x3<F, ROWS, COLS, false>(plane_x, plane_t, p.w_tower + (2 * p.blocks) * layer_halves8, p.bias + (1 + 2 * p.blocks) * F, wave, lane AGX_NN_STAMP_ARG, carry);
+				conv3x3<F, ROWS, COLS, false>(plane_x, plane_t, p.w_tower + (2 * p.blocks) * layer_halves8, p.bias + (1 + 2 * p.blocks) * F, wave, lane AGX_NN_STAMP_ARG, carry,
+						&bias_carry, p.bias + (1 + 2 * p.blocks) * F); // (nothing follows: its own values again)
 			}
 			__syncthreads();
 			AGX_NN_MARK(7);
-#if AGX_NN_INPUT_PREFETCH
 			// the next board's input: requested here, consumed by the staging loop at the top — the round trip rides under the heads
 			if (bi + static_cast<int>(gridDim.x) < batch && tid < G::HW)
 			{
 				const int nb = bi + static_cast<int>(gridDim.x);
 				next_word = features[static_cast<size_t>((p.slot_list != nullptr) ? p.slot_list[nb] : nb) * G::HW + tid];
 			}
-#endif
 
 			// ---- policy head: conv1x1 F->1 + bias, softmax over the board ----
 			{
@@ -1629,7 +1569,7 @@ namespace
 				const float *bq1 = p.bias + (2 + 2 * p.blocks) * F;
 				__syncthreads(); // the policy head is done with plane_t / the partial-sum buffers
 				if (INPLACE)
-					conv3x3_inplace<F, ROWS, COLS, 3>(plane_x, wq1, bq1, nullptr, s_wq2, qpart, wave, lane AGX_NN_STAMP_ARG);
+					conv3x3_inplace<F, ROWS, COLS, 3>(plane_x, wq1, bias_carry, nullptr, nullptr, s_wq2, qpart, wave, lane AGX_NN_STAMP_ARG);
 				else
 				{
 					conv3x3<F, ROWS, COLS, false, true>(plane_x, plane_t, wq1, bq1, wave, lane AGX_NN_STAMP_ARG);
@@ -1944,9 +1884,9 @@ int agx_net_load_weights(AgxNet *net, const float *h_blob, size_t n_floats)
 	bias.insert(bias.end(), ptr, ptr + F);
 	ptr += F;
 	// 15-column boards (row stride 16 = one MFMA tile) run the row-stationary k-loop, which reads the fragments in its own order
-	const bool row_order = (net->desc.cols + 1 == 16) && (AGX_NN_ROW_STATIONARY != 0);
+	const bool row_order = (net->desc.cols + 1 == 16);
 	// 20x20 boards with 128 filters run the column-tile k-loop (Geometry::COLT)
-	const bool column_order = (net->desc.rows == 20 && net->desc.cols == 20 && F == 128) && (AGX_NN_COLUMN_TILES != 0);
+	const bool column_order = (net->desc.rows == 20 && net->desc.cols == 20 && F == 128);
 	auto pack3x3 = [&](const float *w)
 	{
 		if (row_order)
