@@ -45,6 +45,9 @@
 #ifndef AGX_NN_COLS_PAD
 #define AGX_NN_COLS_PAD 1 // 16-byte units of padding per stored position on column-tile boards (Geometry::PAD): 1 or 2
 #endif
+#ifndef AGX_NN_ROW_GROUPS
+#define AGX_NN_ROW_GROUPS 8 // channel groups of a workgroup's 8 waves on 15-column boards with 128 filters (Geometry::CG): 8 (x 1 position group) or 4 (x 2)
+#endif
 #ifndef AGX_NN_PAIR_BALANCE
 #define AGX_NN_PAIR_BALANCE 1 // 1: the two waves of a SIMD steer their priorities by each other's progress in the row-stationary k-loop (+0.8 %)
 #endif
@@ -130,9 +133,19 @@ namespace
 			// not rows (20x20: the tap-major k-loop, one activation fragment read per (tap, tile)), where 4 groups would leave a wave a single
 			// 16-channel tile (MT = 1) per fragment read: 2 x 4 there (+12 % measured).  128-filter nets keep 4 x 2 on every board: with
 			// 2 x 4 (MT = 4) each weight fragment is fetched by four waves instead of two and the kernel lost 8 %.
-			static constexpr int CG = (S == 16 || F >= 128) ? 4 : 2;
+			// Row tiles with 128 filters (the 15x15 towers of BASELINE configs 1, 2, 4): 8 x 1 — a wave owns ONE 16-channel tile of ALL rows.  Each
+			// weight fragment is then fetched by one wave instead of two (4 x 2: the two position groups; fetched by four, 2 x 4 lost 8 %), 3 per
+			// stage and wave instead of 6: half the vector-memory instructions and L2 -> CU bytes, which ran at half the CU's L2 bandwidth at full
+			// MFMA rate; the price is LDS reads — an activation fragment feeds 3 MFMAs instead of 6 (17 reads per 45 MFMAs instead of 10 per 48,
+			// the LDS array 22 % -> 38 % busy at full MFMA rate) — and the gain besides: all eight waves carry the same 15 rows (no 8 / 7 split,
+			// no runtime tile counts), 60 accumulator registers instead of 64.
+			static constexpr int CG = (S == 16 && F >= 128) ? AGX_NN_ROW_GROUPS : ((S == 16 || F >= 128) ? 4 : 2);
 			static constexpr int PG = 8 / CG;
 			static constexpr int MT = F / (16 * CG);                             // 16-channel output tiles per wave
+			// stages of weight fragments a wave holds in the row-stationary k-loop: 2 = a stage's fragments are requested one stage ahead.  (With one
+			// channel tile per wave a set is 12 registers and deeper rings fit: 3 measured equal to 2, 4 is 18 % slower — profiles/r06_nn_ab4_weight_ring.txt;
+			// with two tiles per wave a third set spilled, profiles/r04_nn_ab*.txt.  An L2 round trip is covered by one stage of MFMAs.)
+			static constexpr int WRING = 2;
 			// 20x20 boards with 128 filters: the tiles of rows 0..15 are COLUMNS (16 cells of one board column: lane r = row r) — the
 			// neighbouring column is the same tile shifted by one position, so one activation fragment feeds the three taps dx = -1, 0, +1 like
 			// a row's fragment feeds dy on 15x15 boards (conv3x3_mac_cols) — and rows 16..19 stay six ordinary tiles of consecutive positions
@@ -155,7 +168,7 @@ namespace
 			static constexpr int THREADS = 512;                                  // 8 waves, 2 per SIMD
 			// (shifts and masks on purpose: written with / and % the 15x15 kernels came out 12 % (6x128) and 60 x (2x64) slower)
 			__device__ static __forceinline__ int channel_group(int wave) { return wave & (CG - 1); }
-			__device__ static __forceinline__ int first_tile(int wave) { return (wave >> (CG == 4 ? 2 : 1)) * NTW; }
+			__device__ static __forceinline__ int first_tile(int wave) { return (wave >> (CG == 8 ? 3 : (CG == 4 ? 2 : 1))) * NTW; }
 			/* Which 16-byte slot of its bank row a position's chunk c lives in: c ^ swizzle(stored index).  A ds_read_b128 is served in four
 			 * groups of 16 lanes — {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32 (MI355X_MICROARCH.md, LDS): a group is 8 lanes
 			 * of one 8-channel chunk and 8 of the next, and is conflict-free when its 16 slots differ.  index mod CH: consecutive positions
@@ -183,6 +196,8 @@ namespace
 			{
 				if constexpr (COLT)
 					return NTW;
+				else if constexpr (PG == 1)
+					return NT;
 				else if constexpr (PG == 2)
 					return (wave >> 2) ? (NT - NTW) : NTW;
 				else
@@ -197,8 +212,8 @@ namespace
 			static constexpr int KPAD = (HW * 4 + 31) / 32 * 32;                 // value-head dense input length, padded to whole MFMA k-steps
 			static constexpr int SCRATCH_FLOATS = HW * 4 + D + 8 + 256 + 8 + F * 4 + F + F * 4;
 			static constexpr int LDS_BYTES = 2 * PLANE_BYTES + SCRATCH_FLOATS * 4;
-			// single-plane variant (boards whose two planes do not fit): one plane + scratch + policy partial sums [4][NT*16]
-			static constexpr int LDS_BYTES_INPLACE = PLANE_BYTES + SCRATCH_FLOATS * 4 + 4 * NT * 16 * 4 + 3 * NT * 16 * 4;
+			// single-plane variant (boards whose two planes do not fit): one plane + scratch + policy partial sums [CG][NT*16] + action-value sums [3][NT*16]
+			static constexpr int LDS_BYTES_INPLACE = PLANE_BYTES + SCRATCH_FLOATS * 4 + CG * NT * 16 * 4 + 3 * NT * 16 * 4;
 			static constexpr int SKIP_PER_WG = 8 * MT * NTW * 64;               // half4 elements of residual scratch per workgroup
 	};
 
@@ -264,13 +279,13 @@ namespace
 		return index * G::POS_BYTES + (chunk ^ G::swizzle(index)) * 16;
 	}
 
-	/* The weight fragments of a layer's first stage, requested by the layer in front of it: a layer that fetches them itself starts with an
+	/* The weight fragments of a layer's first stage(s), requested by the layer in front of it: a layer that fetches them itself starts with an
 	 * L2 / MALL round trip that nothing hides (every wave of the workgroup has just left the layer barrier).  `next` = the packed weights of
 	 * the layer that follows. */
-	template<int MT>
+	template<typename G>
 	struct WeightCarry
 	{
-			half8 a[3][MT];
+			half8 a[G::WRING - 1][3][G::MT]; // the first WRING - 1 stages of the layer
 			const half8 *next;
 	};
 	/* A layer's bias values, requested by the layer in front of it behind its k-loop: requested at the layer's own top — straight behind the
@@ -289,15 +304,17 @@ namespace
 			carry.b[i] = *reinterpret_cast<const floatx4*>(bias + (G::channel_group(wave) * G::MT + i) * 16 + 4 * (lane >> 4));
 	}
 	template<int F, int ROWS, int COLS>
-	__device__ __forceinline__ void request_first_stage(const half8 *__restrict__ wpk, int wave, int lane, WeightCarry<Geometry<F, ROWS, COLS>::MT> &carry)
+	__device__ __forceinline__ void request_first_stage(const half8 *__restrict__ wpk, int wave, int lane, WeightCarry<Geometry<F, ROWS, COLS>> &carry)
 	{
 		typedef Geometry<F, ROWS, COLS> G;
 		const half8 *wl = wpk + __builtin_amdgcn_readfirstlane(G::channel_group(wave) * 3 * G::MT * 64);
 #pragma unroll
-		for (int dyi = 0; dyi < 3; dyi++)
+		for (int u = 0; u < G::WRING - 1; u++)
 #pragma unroll
-			for (int i = 0; i < G::MT; i++)
-				carry.a[dyi][i] = wl[(dyi * G::MT + i) * 64 + lane];
+			for (int dyi = 0; dyi < 3; dyi++)
+#pragma unroll
+				for (int i = 0; i < G::MT; i++)
+					carry.a[u][dyi][i] = wl[u * (G::CG * 3 * G::MT * 64) + (dyi * G::MT + i) * 64 + lane];
 	}
 
 	/*
@@ -362,7 +379,7 @@ namespace
 	 */
 	template<int F, int ROWS, int COLS, bool ZERO = true>
 	__device__ __forceinline__ void conv3x3_mac_rows(const char *src, const half8 *__restrict__ wpk, int wave, int lane,
-			floatx4 (&acc)[Geometry<F, ROWS, COLS>::MT][Geometry<F, ROWS, COLS>::NTW], WeightCarry<Geometry<F, ROWS, COLS>::MT> *carry = nullptr)
+			floatx4 (&acc)[Geometry<F, ROWS, COLS>::MT][Geometry<F, ROWS, COLS>::NTW], WeightCarry<Geometry<F, ROWS, COLS>> *carry = nullptr)
 	{
 		typedef Geometry<F, ROWS, COLS> G;
 		static_assert(G::S == 16 && G::PAD == 0, "a position tile must be a board row (whole 256-byte bank rows, XOR chunk swizzle)");
@@ -382,24 +399,26 @@ namespace
 		}
 
 		constexpr int STAGES = 3 * G::KC;               // stage = (32-channel chunk kc, column shift dx)
-		static_assert(G::CG == 4, "pack_conv_rows lays a stage out for four channel groups");
 		constexpr int STAGE_FRAGS = G::CG * 3 * G::MT * 64; // half8 elements of one stage: channel groups x 3 taps x MT tiles x 64 lanes
-		static_assert(STAGES % 2 == 0, "two stages per loop turn (static ring index)");
+		constexpr int RING = G::WRING;                  // sets of weight fragments: a stage's are requested RING - 1 stages ahead
+		static_assert(STAGES % RING == 0, "RING stages per loop turn (static ring index)");
 		const half8 *wl = wpk + __builtin_amdgcn_readfirstlane(mg * 3 * G::MT * 64); // wave-uniform: scalar base + lane offset
-		half8 a0[3][G::MT], a1[3][G::MT];
-		// (the layer's last turn has to request SOMETHING, see below: the next layer's first stage when there is a carry, its own otherwise)
+		half8 a[RING][3][G::MT];
+		// (the layer's last requests have to ask for SOMETHING, see below: the next layer's first stages when there is a carry, its own otherwise)
 		const half8 *wrap = (carry != nullptr) ? carry->next + __builtin_amdgcn_readfirstlane(mg * 3 * G::MT * 64) : wl;
 #pragma unroll
-		for (int dyi = 0; dyi < 3; dyi++)
+		for (int u = 0; u < RING - 1; u++)
 #pragma unroll
-			for (int i = 0; i < G::MT; i++)
-				a0[dyi][i] = (carry != nullptr) ? carry->a[dyi][i] : wl[(dyi * G::MT + i) * 64 + lane];
+			for (int dyi = 0; dyi < 3; dyi++)
+#pragma unroll
+				for (int i = 0; i < G::MT; i++)
+					a[u][dyi][i] = (carry != nullptr) ? carry->a[u][dyi][i] : wl[u * STAGE_FRAGS + (dyi * G::MT + i) * 64 + lane];
 		const int index_base = 1 + G::S + n0 * 16 + r; // stored index of this lane's position in the wave's first output row
 #if AGX_NN_PAIR_BALANCE
 		PairBalance balance(pair_progress(), wave);
 #endif
 #pragma unroll 1
-		for (int s = 0; s < STAGES; s += 2)
+		for (int s = 0; s < STAGES; s += RING)
 		{
 			// The two waves of a SIMD are issued oldest-first: left alone, the older one runs ahead, finishes its k-loop early and waits at
 			// the layer barrier while the younger one finishes ALONE (a lone wave hides none of its LDS / L2 latencies: measured 2.1 x its
@@ -415,23 +434,31 @@ namespace
 			else
 				__builtin_amdgcn_s_setprio(1);
 #endif
-			conv3x3_rows_stage<F, ROWS, COLS>(src, wl + (s + 1) * STAGE_FRAGS, s / 3, s % 3, index_base, q4, my_tiles, lane, a0, a1, acc);
-			// the last turn fetches stage 0 again instead of branching around the fetch: with a conditional fetch the wait for THIS stage's
-			// fragments has to assume the newer loads were never issued (vmcnt(0)), which serialises fetch and MFMAs in every turn
-			conv3x3_rows_stage<F, ROWS, COLS>(src, (s + 2 < STAGES) ? wl + (s + 2) * STAGE_FRAGS : wrap, (s + 1) / 3, (s + 1) % 3, index_base, q4, my_tiles, lane, a1,
-					a0, acc);
+#pragma unroll
+			for (int u = 0; u < RING; u++)
+			{
+				// stage s + u computes with set u and requests stage s + u + RING - 1 into the set that stage s + u - 1 has just finished with.
+				// Past the layer's end the requests go on with the NEXT layer's first stages (its own again without a carry) instead of
+				// branching around the fetch: with a conditional fetch the wait for THIS stage's fragments has to assume the newer loads were
+				// never issued (vmcnt(0)), which serialises fetch and MFMAs in every turn
+				const int ahead = s + u + RING - 1;
+				const half8 *wnext = (ahead < STAGES) ? wl + ahead * STAGE_FRAGS : wrap + (ahead - STAGES) * STAGE_FRAGS;
+				conv3x3_rows_stage<F, ROWS, COLS>(src, wnext, (s + u) / 3, (s + u) % 3, index_base, q4, my_tiles, lane, a[u], a[(u + RING - 1) % RING], acc);
+			}
 #if AGX_NN_PAIR_BALANCE
 			balance.done();
 #endif
 		}
 		__builtin_amdgcn_s_setprio(0);
 		if (carry != nullptr)
-		{
+		{ // (behind the last turn sets 0 .. RING - 2 hold the next layer's stages 0 .. RING - 2)
 #pragma unroll
-			for (int dyi = 0; dyi < 3; dyi++)
+			for (int u = 0; u < RING - 1; u++)
 #pragma unroll
-				for (int i = 0; i < G::MT; i++)
-					carry->a[dyi][i] = a0[dyi][i];
+				for (int dyi = 0; dyi < 3; dyi++)
+#pragma unroll
+					for (int i = 0; i < G::MT; i++)
+						carry->a[u][dyi][i] = a[u][dyi][i];
 		}
 	}
 
@@ -639,7 +666,7 @@ namespace
 
 	template<int F, int ROWS, int COLS, bool ZERO = true>
 	__device__ __forceinline__ void conv3x3_mac(const char *src, const half8 *__restrict__ wpk, int wave, int lane,
-			floatx4 (&acc)[Geometry<F, ROWS, COLS>::MT][Geometry<F, ROWS, COLS>::NTW], WeightCarry<Geometry<F, ROWS, COLS>::MT> *carry = nullptr)
+			floatx4 (&acc)[Geometry<F, ROWS, COLS>::MT][Geometry<F, ROWS, COLS>::NTW], WeightCarry<Geometry<F, ROWS, COLS>> *carry = nullptr)
 	{
 		if constexpr (Geometry<F, ROWS, COLS>::S == 16)
 			conv3x3_mac_rows<F, ROWS, COLS, ZERO>(src, wpk, wave, lane, acc, carry);
@@ -669,7 +696,7 @@ namespace
 
 	template<int F, int ROWS, int COLS, bool SKIP, bool TANH = false>
 	__device__ __forceinline__ void conv3x3(const char *src, char *dst, const half8 *__restrict__ wpk, const float *__restrict__ bias, int wave,
-			int lane AGX_NN_STAMP_PARAM, WeightCarry<Geometry<F, ROWS, COLS>::MT> *carry = nullptr, BiasCarry<Geometry<F, ROWS, COLS>::MT> *bias_carry = nullptr,
+			int lane AGX_NN_STAMP_PARAM, WeightCarry<Geometry<F, ROWS, COLS>> *carry = nullptr, BiasCarry<Geometry<F, ROWS, COLS>::MT> *bias_carry = nullptr,
 			const float *__restrict__ next_bias = nullptr)
 	{ // bias_carry: holds this layer's bias values on entry and the next layer's (next_bias) on return
 		typedef Geometry<F, ROWS, COLS> G;
@@ -1356,8 +1383,8 @@ namespace
 		float *s_wv1 = red + 8 + 256 + 8;                                      // [F][4] value-head 1x1 weights (kept in LDS, not in registers)
 		float *s_wp2 = s_wv1 + F * 4;                                      // [F] policy-head 1x1 weights
 		float *s_wq2 = s_wp2 + F;                                          // [F][4] action-values head 1x1 weights
-		float *ppart = s_wq2 + F * 4;                                      // [4][NT*16] policy partial logits (single-plane variant only)
-		float *qpart = ppart + 4 * G::NT * 16;                             // [3][NT*16] action-value logits (single-plane variant only)
+		float *ppart = s_wq2 + F * 4;                                      // [CG][NT*16] policy partial logits (single-plane variant only)
+		float *qpart = ppart + G::CG * G::NT * 16;                         // [3][NT*16] action-value logits (single-plane variant only)
 		half4 *skip = INPLACE ? (p.skip + static_cast<size_t>(blockIdx.x) * G::SKIP_PER_WG) : nullptr;
 
 		const int tid = threadIdx.x;
@@ -1439,8 +1466,8 @@ namespace
 			AGX_NN_MARK(9);
 			// ---- residual tower ----
 			constexpr bool CARRY = !INPLACE && G::S == 16;
-			WeightCarry<G::MT> carry_store;
-			WeightCarry<G::MT> *carry = CARRY ? &carry_store : nullptr;
+			WeightCarry<G> carry_store;
+			WeightCarry<G> *carry = CARRY ? &carry_store : nullptr;
 			if constexpr (CARRY)
 				request_first_stage<F, ROWS, COLS>(p.w_tower, wave, lane, carry_store);
 			for (int blk = 0; blk < p.blocks; blk++)
@@ -1536,10 +1563,14 @@ namespace
 					if (INPLACE)
 					{
 						const int idx = (c / COLS) * G::S + (c % COLS);
-						if constexpr (G::CG == 4)
-							s += (ppart[idx] + ppart[G::NT * 16 + idx]) + (ppart[2 * G::NT * 16 + idx] + ppart[3 * G::NT * 16 + idx]);
+						constexpr int PS = G::NT * 16; // the channel groups' partial sums, added in a fixed order
+						if constexpr (G::CG == 8)
+							s += ((ppart[idx] + ppart[PS + idx]) + (ppart[2 * PS + idx] + ppart[3 * PS + idx]))
+									+ ((ppart[4 * PS + idx] + ppart[5 * PS + idx]) + (ppart[6 * PS + idx] + ppart[7 * PS + idx]));
+						else if constexpr (G::CG == 4)
+							s += (ppart[idx] + ppart[PS + idx]) + (ppart[2 * PS + idx] + ppart[3 * PS + idx]);
 						else
-							s += ppart[idx] + ppart[G::NT * 16 + idx];
+							s += ppart[idx] + ppart[PS + idx];
 					}
 					else
 					{
@@ -1712,18 +1743,19 @@ namespace
 {
 	/*
 	 * The same fragments in the order the row-stationary k-loop consumes them (conv3x3_mac_rows): [kc][dx][channel group][dy][tile][lane][8],
-	 * so the 3 * MT fragments a wave needs for one stage are consecutive.  3x3 kernels only; MT = cout / 64 tiles per channel group.
+	 * so the 3 * MT fragments a wave needs for one stage are consecutive.  3x3 kernels only; MT = cout / (16 * groups) tiles per channel group.
 	 */
-	void pack_conv_rows(const float *w, int cin, int cout, std::vector<half_t> &dst, bool by_row_shift = false)
+	void pack_conv_rows(const float *w, int cin, int cout, std::vector<half_t> &dst, bool by_row_shift = false, int groups = 4)
 	{ // by_row_shift: the column-tile loop (conv3x3_mac_cols) — stage = (chunk, dy), inside it dx: the same order with the roles exchanged
-		const int kcs = cin / 32, mt_per_group = cout / 64;
+	  // groups: channel groups of the kernel's geometry (Geometry::CG)
+		const int kcs = cin / 32, mt_per_group = cout / (16 * groups);
 		const size_t base = dst.size();
 		dst.resize(base + static_cast<size_t>(9) * kcs * (cout / 16) * 512);
 		half_t *out = dst.data() + base;
 		size_t frag = 0;
 		for (int kc = 0; kc < kcs; kc++)
 			for (int dx = 0; dx < 3; dx++)
-				for (int mg = 0; mg < 4; mg++)
+				for (int mg = 0; mg < groups; mg++)
 					for (int dy = 0; dy < 3; dy++)
 						for (int i = 0; i < mt_per_group; i++, frag++)
 							for (int lane = 0; lane < 64; lane++)
@@ -1890,7 +1922,7 @@ int agx_net_load_weights(AgxNet *net, const float *h_blob, size_t n_floats)
 	auto pack3x3 = [&](const float *w)
 	{
 		if (row_order)
-			pack_conv_rows(w, F, F, w_tower);
+			pack_conv_rows(w, F, F, w_tower, false, (F == 128) ? Geometry<128, 15, 15>::CG : Geometry<64, 15, 15>::CG);
 		else if (column_order)
 			pack_conv_rows(w, F, F, w_tower, true);
 		else
