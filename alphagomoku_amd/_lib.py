@@ -202,6 +202,7 @@ def _declare(c):  # noqa: F811
     c.agx_engine_buffers.argtypes = [vp, ctypes.POINTER(AgxEngineBuffers)]
     c.agx_engine_stats.argtypes = [vp, ctypes.POINTER(AgxEngineStats)]
     c.agx_engine_device_bytes.argtypes = [vp, ctypes.POINTER(ctypes.c_ulonglong)]
+    c.agx_engine_estimate_device_bytes.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_ulonglong)]
     c.agx_engine_speculative_waves.argtypes = [vp, ctypes.POINTER(ctypes.c_int)]
     c.agx_engine_kernel_timing.argtypes = [vp, ci, vp, vp]
     c.agx_engine_add_openings.argtypes = [vp, vp, ci]

@@ -3058,6 +3058,8 @@ struct AgxEngine
 		// AgxEngineConfig.speculative_solver: select + solver as one persistent launch with the leaves of a batch solved in parallel (k_search_spec)
 		uint8_t *board_staging = nullptr; // agx_engine_set_board: the caller's board on its way to the device
 		uint16_t *moves_staging = nullptr; // agx_engine_restore_game: the saved move list on its way to the device
+		bool sizing_only = false; // agx_engine_estimate_device_bytes: dev_alloc only adds up, nothing touches a device
+		int sizing_cus = 0;
 		int *summary_dev = nullptr, *summary_host = nullptr; // agx_engine_root_summary: four words on their way back (device, pinned host)
 		bool speculative = false;
 		bool external_moves = false; // agx_engine_set_board has been called: the caller makes the moves, no advance stage services the arenas
@@ -3112,6 +3114,12 @@ namespace
 	template<typename T>
 	int dev_alloc(AgxEngine *e, T **ptr, size_t count)
 	{
+		if (e->sizing_only)
+		{
+			e->device_bytes += std::max<size_t>(count * sizeof(T), 16);
+			*ptr = nullptr;
+			return AGX_OK;
+		}
 		void *p = nullptr;
 		const hipError_t err = hipMalloc(&p, std::max<size_t>(count * sizeof(T), 16));
 		if (err != hipSuccess)
@@ -3132,7 +3140,8 @@ namespace
 		const int st = dev_alloc(e, &p, src.size());
 		if (st != AGX_OK)
 			return st;
-		AGX_HIP_CHECK(hipMemcpy(p, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+		if (!e->sizing_only)
+			AGX_HIP_CHECK(hipMemcpy(p, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
 		*ptr = p;
 		return AGX_OK;
 	}
@@ -3229,7 +3238,9 @@ static int spec_resident_waves_per_cu(int rules, int n)
 	}
 	return blocks;
 }
-int agx_engine_create(const AgxEngineConfig *cfg, AgxEngine **out)
+/* sizing_cus > 0: nothing is allocated and no device is touched — the engine only adds up what it WOULD allocate on a device with that many
+ * compute units (agx_engine_estimate_device_bytes); *out then is a host-only object for the caller to read device_bytes from and delete */
+static int engine_create(const AgxEngineConfig *cfg, AgxEngine **out, int sizing_cus)
 {
 	AGX_REQUIRE(cfg != nullptr && out != nullptr, AGX_ERR_INVALID, "agx_engine_create: null argument");
 	AGX_REQUIRE(cfg->rules >= 0 && cfg->rules <= AGX_CARO6, AGX_ERR_INVALID, "agx_engine_create: unknown rules %d", cfg->rules);
@@ -3254,6 +3265,8 @@ int agx_engine_create(const AgxEngineConfig *cfg, AgxEngine **out)
 
 	AgxEngine *e = new AgxEngine();
 	e->cfg = *cfg;
+	e->sizing_only = sizing_cus > 0;
+	e->sizing_cus = sizing_cus;
 	if (const char *fuse = std::getenv("AGX_FUSE_SELECT"))
 		e->fuse_select = std::atoi(fuse) != 0;
 	EngineDev &d = e->dev;
@@ -3328,9 +3341,12 @@ int agx_engine_create(const AgxEngineConfig *cfg, AgxEngine **out)
 	e->speculative = cfg->speculative_solver != 0 && cfg->tss_max_positions <= 250 && cfg->max_batch_size <= 16;
 	if (e->speculative)
 	{
-		int cus = 0, device_of_engine = 0;
-		(void) hipGetDevice(&device_of_engine);
-		(void) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_of_engine);
+		int cus = e->sizing_cus, device_of_engine = 0;
+		if (!e->sizing_only)
+		{
+			(void) hipGetDevice(&device_of_engine);
+			(void) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_of_engine);
+		}
 		// default: as many waves as the launch's kernel keeps resident (16 per compute unit on 15x15 boards, 10 on 20x20: its LDS state and registers), but
 		// no more than one per leaf of a full batch (a one-tree engine has a few dozen leaves per launch)
 		const int per_cu = spec_resident_waves_per_cu(cfg->rules, cfg->board_size);
@@ -3350,8 +3366,10 @@ int agx_engine_create(const AgxEngineConfig *cfg, AgxEngine **out)
 	AGX_TRY(dev_alloc(e, &d.park_slot, G * d.batch));
 	AGX_TRY(dev_alloc(e, &d.park_owner, SPEC_PARK_POOL));
 	AGX_TRY(dev_alloc(e, &d.park_lds, parking ? static_cast<size_t>(SPEC_PARK_POOL) * SPEC_PARK_WORDS : 1));
-	(void) hipMemset(d.park_slot, 0, G * d.batch * sizeof(int));
-	(void) hipMemset(d.park_owner, 0, SPEC_PARK_POOL * sizeof(int));
+	if (!e->sizing_only)
+		(void) hipMemset(d.park_slot, 0, G * d.batch * sizeof(int));
+	if (!e->sizing_only)
+		(void) hipMemset(d.park_owner, 0, SPEC_PARK_POOL * sizeof(int));
 	AGX_TRY(dev_alloc(e, &d.act, areas * d.act_cap));
 	// per area 20 lists x MAXHW entries: list_get / list_set stride by the kernel's compile-time board (SolverSharedT::HW, = MAXHW in the any-size kernels)
 	AGX_TRY(dev_alloc(e, &d.list_spill, areas * 20 * static_cast<size_t>(MAXHW)));
@@ -3360,11 +3378,14 @@ int agx_engine_create(const AgxEngineConfig *cfg, AgxEngine **out)
 	d.spec_group = 0;
 	d.spec_waves = e->spec_waves;
 	AGX_TRY(dev_alloc(e, &d.spec_watchdog, 16));
-	(void) hipMemset(d.spec_watchdog, 0, 16 * sizeof(int));
+	if (!e->sizing_only)
+		(void) hipMemset(d.spec_watchdog, 0, 16 * sizeof(int));
 	AGX_TRY(dev_alloc(e, &d.spec_prof, 16));
 	AGX_TRY(dev_alloc(e, &d.spec_trace, 4 * (G + static_cast<size_t>(std::max(e->spec_waves, 16))))); // per game, then per wave (profile builds)
-	(void) hipMemset(d.spec_trace, 0, 4 * (G + static_cast<size_t>(std::max(e->spec_waves, 16))) * sizeof(unsigned long long));
-	(void) hipMemset(d.spec_prof, 0, 16 * sizeof(unsigned long long));
+	if (!e->sizing_only)
+		(void) hipMemset(d.spec_trace, 0, 4 * (G + static_cast<size_t>(std::max(e->spec_waves, 16))) * sizeof(unsigned long long));
+	if (!e->sizing_only)
+		(void) hipMemset(d.spec_prof, 0, 16 * sizeof(unsigned long long));
 	AGX_TRY(dev_alloc(e, &d.spec_items, e->speculative ? G * d.batch + 16 * static_cast<size_t>(SPEC_QUEUE_SLACK) : 1));
 	AGX_TRY(dev_alloc(e, &d.spec_left, e->speculative ? G : 1));
 	AGX_TRY(dev_alloc(e, &d.spec_tasks, e->speculative ? G * d.batch : 1));
@@ -3429,7 +3450,9 @@ int agx_engine_create(const AgxEngineConfig *cfg, AgxEngine **out)
 		heap.free_capacity = static_cast<int32_t>(G);
 		e->idle_games = games;
 		e->idle_heap = heap;
-		hipError_t err = hipMemcpy(d.games, games.data(), G * sizeof(GameState), hipMemcpyHostToDevice);
+		hipError_t err = e->sizing_only ? hipSuccess : hipMemcpy(d.games, games.data(), G * sizeof(GameState), hipMemcpyHostToDevice);
+		if (e->sizing_only)
+			err = hipErrorUnknown; // (skips the chain below; reset behind it)
 		if (err == hipSuccess)
 			err = hipMemcpy(d.heap, &heap, sizeof(heap), hipMemcpyHostToDevice);
 		if (err == hipSuccess)
@@ -3442,7 +3465,7 @@ int agx_engine_create(const AgxEngineConfig *cfg, AgxEngine **out)
 			err = hipMemset(d.spec_tasks, 0, G * d.batch * sizeof(SpecTask));
 		if (err == hipSuccess && e->speculative)
 			err = hipMemset(d.spec_left, 0, G * sizeof(int));
-		if (err != hipSuccess)
+		if (err != hipSuccess && !e->sizing_only)
 		{
 			agx::set_error("hipMemset failed: %s", hipGetErrorString(err));
 			status = AGX_ERR_HIP;
@@ -3456,6 +3479,25 @@ int agx_engine_create(const AgxEngineConfig *cfg, AgxEngine **out)
 		return status;
 	}
 	*out = e;
+	return AGX_OK;
+}
+
+int agx_engine_create(const AgxEngineConfig *cfg, AgxEngine **out)
+{
+	return engine_create(cfg, out, 0);
+}
+
+/* What agx_engine_create(cfg) allocates on a device with `compute_units` compute units, without touching one (a launcher sizing its ranks:
+ * GeneratorManager.cpp:146-152 starts one generator thread per device; tests of the multi-GPU plan on a box without a GPU) */
+int agx_engine_estimate_device_bytes(const AgxEngineConfig *cfg, int compute_units, unsigned long long *bytes)
+{
+	AGX_REQUIRE(bytes != nullptr && compute_units > 0, AGX_ERR_INVALID, "agx_engine_estimate_device_bytes: invalid argument");
+	AgxEngine *e = nullptr;
+	const int st = engine_create(cfg, &e, compute_units);
+	if (st != AGX_OK)
+		return st;
+	*bytes = e->device_bytes;
+	delete e;
 	return AGX_OK;
 }
 

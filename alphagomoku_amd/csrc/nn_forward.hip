@@ -58,7 +58,9 @@
  *  (r04_nn_ab*.txt: spills), the pair-balance ticks in the column-tile loop (-0.6 %), the interleaved read order of the column loop, the
  *  conditional layer prefetch / input prefetch / fused residual add / two-pass conv5x5 switches (all on since round 4), the
  *  operand-traffic timing experiments AGX_NN_DBG_NOLDS / _NOW (r03), the 12-wave tile and the accumulator initialisation inside the first
- *  stage (r05_nn_ab.txt).) */
+ *  stage (r05_nn_ab.txt); round 6: a row's fragment read once per channel chunk and SHIFTED BY LANES (DPP row_shr / row_shl) for the taps
+ *  dx = -1, +1 — a third of the LDS reads for 8 vector moves per row, one between every two MFMAs: 20-23 % slower, vector instructions in
+ *  the MFMA stream cost far more than the LDS reads they replace (r06_nn_ab6_lane_shifted_rows_negative.txt).) */
 
 namespace
 {
@@ -139,6 +141,10 @@ namespace
 			// MFMA rate; the price is LDS reads — an activation fragment feeds 3 MFMAs instead of 6 (17 reads per 45 MFMAs instead of 10 per 48,
 			// the LDS array 22 % -> 38 % busy at full MFMA rate) — and the gain besides: all eight waves carry the same 15 rows (no 8 / 7 split,
 			// no runtime tile counts), 60 accumulator registers instead of 64.
+			// Column tiles (below) keep 4 x 2: with eight groups the tail tiles' fragments feed ONE MFMA each and the LDS array carries 40 reads per 78
+			// MFMAs only with the conflict-free PAD 2 plane (whose epilogue stores are 4-way): measured 2.7 % (whole chip) to 7 % (64 CUs) slower,
+			// profiles/r06_nn_ab8_column_tiles_eight_groups_negative.txt.
+			static constexpr bool COLT = (ROWS == 20 && COLS == 20 && F == 128);
 			static constexpr int CG = (S == 16 && F >= 128) ? AGX_NN_ROW_GROUPS : ((S == 16 || F >= 128) ? 4 : 2);
 			static constexpr int PG = 8 / CG;
 			static constexpr int MT = F / (16 * CG);                             // 16-channel output tiles per wave
@@ -146,12 +152,12 @@ namespace
 			// channel tile per wave a set is 12 registers and deeper rings fit: 3 measured equal to 2, 4 is 18 % slower — profiles/r06_nn_ab4_weight_ring.txt;
 			// with two tiles per wave a third set spilled, profiles/r04_nn_ab*.txt.  An L2 round trip is covered by one stage of MFMAs.)
 			static constexpr int WRING = 2;
+			static constexpr int STAGE_TAPS = 3;                                 // weight fragments per stage and channel tile (the row / column loops)
 			// 20x20 boards with 128 filters: the tiles of rows 0..15 are COLUMNS (16 cells of one board column: lane r = row r) — the
 			// neighbouring column is the same tile shifted by one position, so one activation fragment feeds the three taps dx = -1, 0, +1 like
 			// a row's fragment feeds dy on 15x15 boards (conv3x3_mac_cols) — and rows 16..19 stay six ordinary tiles of consecutive positions
-			// (16 rows x 21 = 336 positions = 21 whole tiles lie in front of them).  A position group owns 10 columns + 3 of those.
-			static constexpr bool COLT = (ROWS == 20 && COLS == 20 && F == 128);
-			static constexpr int COL_TILES = COLS / 2, TAIL_TILES = 3, TAIL_FIRST = 21;
+			// (16 rows x 21 = 336 positions = 21 whole tiles lie in front of them).  A position group owns COLS / PG columns + 6 / PG of those.
+			static constexpr int COL_TILES = COLS / PG, TAIL_TILES = 6 / PG, TAIL_FIRST = 21;
 			/* Bytes of a stored position.  Row tiles (S = 16: a tile's 16 positions are whole 256-byte bank rows) keep F halves per position and the
 			 * XOR chunk swizzle below — every LDS address of the k-loop is one base + immediates anyway.  On column tiles the lanes of a fragment
 			 * are 21 positions apart and the XOR term differs from fragment to fragment: 4.2 vector instructions of address arithmetic per
@@ -186,7 +192,7 @@ namespace
 			{
 				if constexpr (COLT)
 				{
-					const int pg = wave >> 2;
+					const int pg = wave >> (CG == 8 ? 3 : 2);
 					return (n < COL_TILES) ? (r * S + pg * COL_TILES + n) : ((TAIL_FIRST + pg * TAIL_TILES + (n - COL_TILES)) * 16 + r);
 				}
 				else
@@ -285,7 +291,7 @@ namespace
 	template<typename G>
 	struct WeightCarry
 	{
-			half8 a[G::WRING - 1][3][G::MT]; // the first WRING - 1 stages of the layer
+			half8 a[G::WRING - 1][G::STAGE_TAPS][G::MT]; // the first WRING - 1 stages of the layer
 			const half8 *next;
 	};
 	/* A layer's bias values, requested by the layer in front of it behind its k-loop: requested at the layer's own top — straight behind the
@@ -307,14 +313,14 @@ namespace
 	__device__ __forceinline__ void request_first_stage(const half8 *__restrict__ wpk, int wave, int lane, WeightCarry<Geometry<F, ROWS, COLS>> &carry)
 	{
 		typedef Geometry<F, ROWS, COLS> G;
-		const half8 *wl = wpk + __builtin_amdgcn_readfirstlane(G::channel_group(wave) * 3 * G::MT * 64);
+		const half8 *wl = wpk + __builtin_amdgcn_readfirstlane(G::channel_group(wave) * G::STAGE_TAPS * G::MT * 64);
 #pragma unroll
 		for (int u = 0; u < G::WRING - 1; u++)
 #pragma unroll
-			for (int dyi = 0; dyi < 3; dyi++)
+			for (int t = 0; t < G::STAGE_TAPS; t++)
 #pragma unroll
 				for (int i = 0; i < G::MT; i++)
-					carry.a[u][dyi][i] = wl[u * (G::CG * 3 * G::MT * 64) + (dyi * G::MT + i) * 64 + lane];
+					carry.a[u][t][i] = wl[u * (G::CG * G::STAGE_TAPS * G::MT * 64) + (t * G::MT + i) * 64 + lane];
 	}
 
 	/*
@@ -325,8 +331,9 @@ namespace
 	__device__ __forceinline__ void conv3x3_rows_stage(const char *src, const half8 *__restrict__ wnext, int kc, int dxi, int index_base, int q4,
 			int my_tiles, int lane, const half8 (&a_cur)[3][Geometry<F, ROWS, COLS>::MT], half8 (&a_next)[3][Geometry<F, ROWS, COLS>::MT],
 			floatx4 (&acc)[Geometry<F, ROWS, COLS>::MT][Geometry<F, ROWS, COLS>::NTW])
-	{
+	{ // dxi is a compile-time constant at every call (conv3x3_mac_rows unrolls the three shifts of a chunk)
 		typedef Geometry<F, ROWS, COLS> G;
+		static_assert(((G::KC - 1) << 6) < G::CH * 16, "a stage's chunk kc * 4 lies inside the chunk field of a position's bytes");
 		// the next stage's 3 * MT weight fragments: contiguous for this wave (pack_conv_rows), one scalar base + small offsets
 #pragma unroll
 		for (int dyi = 0; dyi < 3; dyi++)
@@ -335,7 +342,10 @@ namespace
 				a_next[dyi][i] = wnext[(dyi * G::MT + i) * 64 + lane];
 		const int index0 = index_base + (dxi - 1);
 		const int swz0 = (index0 / G::PPR) % G::CH; // invariant over rows: 16 positions == whole bank rows
-		const char *src0 = src + index0 * G::CH * 16 + (((kc * 4 + q4) ^ swz0) * 16);
+		// (kc * 4 + q4) ^ swz0 == (kc * 4) ^ (q4 ^ swz0): the lane's part does not depend on the stage — one register per shift for the whole
+		// kernel — and the stage's chunk is ONE exclusive-or with a scalar
+		const int lane_part = index0 * G::CH * 16 + ((q4 ^ swz0) * 16);
+		const char *src0 = src + (lane_part ^ (kc << 6));
 		// input rows j = -1 .. NTW, each fragment used by its own three taps only: a window of AHEAD fragments in flight
 		constexpr int AHEAD = AGX_NN_AHEAD;
 		half8 b[AHEAD];
@@ -401,6 +411,7 @@ namespace
 		constexpr int STAGES = 3 * G::KC;               // stage = (32-channel chunk kc, column shift dx)
 		constexpr int STAGE_FRAGS = G::CG * 3 * G::MT * 64; // half8 elements of one stage: channel groups x 3 taps x MT tiles x 64 lanes
 		constexpr int RING = G::WRING;                  // sets of weight fragments: a stage's are requested RING - 1 stages ahead
+		static_assert(G::STAGE_TAPS == 3, "stage = (chunk, column shift): three taps");
 		static_assert(STAGES % RING == 0, "RING stages per loop turn (static ring index)");
 		const half8 *wl = wpk + __builtin_amdgcn_readfirstlane(mg * 3 * G::MT * 64); // wave-uniform: scalar base + lane offset
 		half8 a[RING][3][G::MT];
@@ -417,37 +428,46 @@ namespace
 #if AGX_NN_PAIR_BALANCE
 		PairBalance balance(pair_progress(), wave);
 #endif
+		// A loop turn is TURN = 6 stages — two channel chunks x the three column shifts — so that a stage's shift and its set of weight fragments
+		// are compile-time constants: no scalar divisions by three, the LDS address of a stage is one exclusive-or, the weight requests are scalar
+		// base + immediate.  (Vector instructions in the MFMA stream are expensive: profiles/r06_nn_ab6_lane_shifted_rows_negative.txt.)
+		constexpr int TURN = 6;
+		static_assert(STAGES % TURN == 0 && TURN % RING == 0, "whole turns, static ring index");
 #pragma unroll 1
-		for (int s = 0; s < STAGES; s += RING)
+		for (int s = 0; s < STAGES; s += TURN)
 		{
-			// The two waves of a SIMD are issued oldest-first: left alone, the older one runs ahead, finishes its k-loop early and waits at
-			// the layer barrier while the younger one finishes ALONE (a lone wave hides none of its LDS / L2 latencies: measured 2.1 x its
-			// MFMA time).  Priority by remaining work — the wave that is behind goes first — keeps the pair together to the end.
-			// (a static bias towards the younger wave of a pair was measured worse)
-#if AGX_NN_PAIR_BALANCE
-			balance.turn();
-#else
-			if (3 * s < STAGES)
-				__builtin_amdgcn_s_setprio(3);
-			else if (3 * s < 2 * STAGES)
-				__builtin_amdgcn_s_setprio(2);
-			else
-				__builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
-			for (int u = 0; u < RING; u++)
+			for (int u = 0; u < TURN; u++)
 			{
-				// stage s + u computes with set u and requests stage s + u + RING - 1 into the set that stage s + u - 1 has just finished with.
-				// Past the layer's end the requests go on with the NEXT layer's first stages (its own again without a carry) instead of
+				// The two waves of a SIMD are issued oldest-first: left alone, the older one runs ahead, finishes its k-loop early and waits at
+				// the layer barrier while the younger one finishes ALONE (a lone wave hides none of its LDS / L2 latencies: measured 2.1 x its
+				// MFMA time).  Priority by remaining work — the wave that is behind goes first — keeps the pair together to the end.
+				// (a static bias towards the younger wave of a pair was measured worse)
+				if (u % 2 == 0)
+				{
+#if AGX_NN_PAIR_BALANCE
+					balance.turn();
+#else
+					if (3 * (s + u) < STAGES)
+						__builtin_amdgcn_s_setprio(3);
+					else if (3 * (s + u) < 2 * STAGES)
+						__builtin_amdgcn_s_setprio(2);
+					else
+						__builtin_amdgcn_s_setprio(1);
+#endif
+				}
+				// stage s + u computes with set u % RING and requests stage s + u + RING - 1 into the set that stage s + u - 1 has just finished
+				// with.  Past the layer's end the requests go on with the NEXT layer's first stages (its own again without a carry) instead of
 				// branching around the fetch: with a conditional fetch the wait for THIS stage's fragments has to assume the newer loads were
 				// never issued (vmcnt(0)), which serialises fetch and MFMAs in every turn
 				const int ahead = s + u + RING - 1;
-				const half8 *wnext = (ahead < STAGES) ? wl + ahead * STAGE_FRAGS : wrap + (ahead - STAGES) * STAGE_FRAGS;
-				conv3x3_rows_stage<F, ROWS, COLS>(src, wnext, (s + u) / 3, (s + u) % 3, index_base, q4, my_tiles, lane, a[u], a[(u + RING - 1) % RING], acc);
-			}
+				const half8 *wnext = (u + RING - 1 < TURN || ahead < STAGES) ? wl + ahead * STAGE_FRAGS : wrap + (ahead - STAGES) * STAGE_FRAGS;
+				conv3x3_rows_stage<F, ROWS, COLS>(src, wnext, s / 3 + u / 3, u % 3, index_base, q4, my_tiles, lane, a[u % RING], a[(u + RING - 1) % RING], acc);
 #if AGX_NN_PAIR_BALANCE
-			balance.done();
+				if (u % 2 == 1)
+					balance.done();
 #endif
+			}
 		}
 		__builtin_amdgcn_s_setprio(0);
 		if (carry != nullptr)
@@ -623,11 +643,11 @@ namespace
 			floatx4 (&acc)[Geometry<F, ROWS, COLS>::MT][Geometry<F, ROWS, COLS>::NTW])
 	{
 		typedef Geometry<F, ROWS, COLS> G;
-		static_assert(G::COLT && G::CG == 4 && G::PG == 2, "column tiles: four channel groups x two position groups");
+		static_assert(G::COLT && (G::CG == 4 || G::CG == 8), "column tiles: four channel groups x two position groups, or eight x one");
 		const int r = lane & 15;
 		const int q4 = lane >> 4;
 		const int mg = G::channel_group(wave);
-		const int pg = wave >> 2;
+		const int pg = wave >> (G::CG == 8 ? 3 : 2);
 		if (ZERO)
 		{
 #pragma unroll
@@ -1924,7 +1944,7 @@ int agx_net_load_weights(AgxNet *net, const float *h_blob, size_t n_floats)
 		if (row_order)
 			pack_conv_rows(w, F, F, w_tower, false, (F == 128) ? Geometry<128, 15, 15>::CG : Geometry<64, 15, 15>::CG);
 		else if (column_order)
-			pack_conv_rows(w, F, F, w_tower, true);
+			pack_conv_rows(w, F, F, w_tower, true, Geometry<128, 20, 20>::CG);
 		else
 			pack_conv(w, 9, F, F, w_tower);
 	};

@@ -199,6 +199,8 @@ def main():
     ap.add_argument("--host-pacing", type=int, default=2,
                     help="N > 0: the host stays at most N steps ahead of every slice's stream and SLEEPS on a blocking event; 0: it enqueues until the "
                          "launch queue is full and spins there (a whole CPU more per rank: the line's ranks[].host_cpu_utilisation)")
+    ap.add_argument("--plan-only", action="store_true",
+                    help="print every rank's plan (device index, opening seeds, device memory the pool would allocate) as one JSON line and exit: touches no GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=24.0)
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline, 0 = every host CPU")
@@ -239,13 +241,6 @@ def main():
     build_hash = _lib.require_current_build()   # refuses a stale prebuilt libagx.so (its compiled-in hash != the sources beside it)
 
     device_index = int(os.environ.get("AGX_FORCE_DEVICE", local_rank))  # AGX_FORCE_DEVICE: test the N > 1 flow on a 1-GPU box
-    # a rank's host side is one launch loop: keep it on the CPUs next to its GPU (only with several ranks: a single rank keeps the box's affinity)
-    numa_node, pinned_cpus = distributed.pin_to_gpu_numa_node(device_index) if world > 1 and not os.environ.get("AGX_NO_PIN") else (None, 0)
-    check(lib.agx_set_device(device_index))
-    desc = synthetic.net_desc(rows=args.board, cols=args.board, blocks=args.blocks, filters=args.filters, action_values=args.action_values)
-    blob, _ = synthetic.make_weights(desc, policy_gain=args.policy_gain)
-    net = AGNetwork(desc)
-    net.loadWeights(blob)
     # tree arenas: every game starts with class-0 regions (8 nodes / 192 edges per playout of the budget) in pool-wide heaps and moves into larger
     # ones on demand (AgxEngineConfig.arena_reserve: the heaps hold 4 x the class-0 total); the measured peaks are on the line
     node_capacity = max(4096, 8 * args.sims)
@@ -254,9 +249,32 @@ def main():
                                   max_simulations=args.sims, tss_table_entries=args.table_entries, solver_yield_fraction=args.yield_fraction,
                                   action_values=args.action_values, node_capacity=node_capacity, edge_capacity=edge_capacity, arena_reserve=3.0,
                                   record_format=2, speculative_solver=args.speculative, speculative_waves=args.speculative_waves)
+    n_openings = args.games * 3  # enough openings for every game that can finish during the run; seeds are disjoint across ranks
+    if args.plan_only:
+        # What each rank WOULD do, from its environment alone (no device call: the library's sizing pass adds up agx_engine_create's allocations):
+        # one pool per device like the reference's one generator thread per device (GeneratorManager.cpp:146-152).  No scaling curve is measured here.
+        need = ctypes.c_ulonglong()
+        check(lib.agx_engine_estimate_device_bytes(ctypes.byref(cfg), 256, ctypes.byref(need)))
+        seed0 = distributed.rank_seed_base(rank)
+        mine = [rank, local_rank, device_index, seed0, seed0 + n_openings - 1, need.value, len(os.sched_getaffinity(0))]
+        everyone = distributed.gather(dist, mine)
+        if rank == 0:
+            print(json.dumps({"plan": [dict(rank=int(r[0]), local_rank=int(r[1]), device_index=int(r[2]), opening_seeds=[int(r[3]), int(r[4])],
+                                            device_bytes=int(r[5]), host_cpus=int(r[6])) for r in everyone],
+                              "n_gpus": world, "hbm_bytes_per_device": 288 * 10 ** 9, "scaling": "weak",
+                              "note": "plan only: nothing was run, no scaling curve measured"}))
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+    # a rank's host side is one launch loop: keep it on the CPUs next to its GPU (only with several ranks: a single rank keeps the box's affinity)
+    numa_node, pinned_cpus = distributed.pin_to_gpu_numa_node(device_index) if world > 1 and not os.environ.get("AGX_NO_PIN") else (None, 0)
+    check(lib.agx_set_device(device_index))
+    desc = synthetic.net_desc(rows=args.board, cols=args.board, blocks=args.blocks, filters=args.filters, action_values=args.action_values)
+    blob, _ = synthetic.make_weights(desc, policy_gain=args.policy_gain)
+    net = AGNetwork(desc)
+    net.loadWeights(blob)
     pool = selfplay.GeneratorPool(cfg)
-    # enough openings for every game that can finish during the run; seeds are disjoint across ranks
-    n_openings = args.games * 3
     openings = synthetic.make_openings(args.board, n_openings, seed0=distributed.rank_seed_base(rank), rules=args.rules)
     pool.begin(selfplay.pack_openings(openings))
     check(lib.agx_device_synchronize())

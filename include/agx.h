@@ -429,6 +429,9 @@ int agx_engine_stats(AgxEngine* engine, AgxEngineStats* out);
  * game —, task / exchange buffers, the solver's spill areas and undo snapshots, record pools).  What one rank of a multi-GPU job needs of its
  * GPU's HBM next to the network's weights (GeneratorManager.cpp:146-152: one generator thread, i.e. one such pool, per device). */
 int agx_engine_device_bytes(AgxEngine* engine, unsigned long long* bytes);
+/* The same number for an engine that has not been created: what agx_engine_create(cfg) would allocate on a device with `compute_units` compute units
+ * (256 on MI355X).  Touches no device — a launcher can size its ranks (one pool per device, GeneratorManager.cpp:146-152) before it starts them. */
+int agx_engine_estimate_device_bytes(const AgxEngineConfig* cfg, int compute_units, unsigned long long* bytes);
 /* Waves of the speculative search launch over the whole pool (AgxEngineConfig.speculative_waves, or the default resolved for this device, rules and
  * board); 0 when the pool runs the serial solver.  A group's launch takes waves / n_groups of them. */
 int agx_engine_speculative_waves(AgxEngine* engine, int* waves);

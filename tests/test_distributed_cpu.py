@@ -139,3 +139,28 @@ def test_numa_pinning_follows_the_runtime_device_order(tmp_path, monkeypatch):
     monkeypatch.setenv("HIP_VISIBLE_DEVICES", "GPU-abcdef")                            # UUID form
     monkeypatch.delenv("CUDA_VISIBLE_DEVICES")
     assert distributed._visible_index(0) is None
+
+
+def test_eight_ranks_plan_disjoint_devices_and_seeds():
+    """`bench.py --gpus 8 --plan-only` (no GPU here, none touched): the launcher starts eight ranks, each derives its device index from LOCAL_RANK alone
+    (no AGX_FORCE_DEVICE), a seed range no other rank shares, and the device memory its pool would allocate (the library's sizing pass over
+    agx_engine_create's allocations).  One pool per device is the reference's split (GeneratorManager.cpp:146-152: one generator thread per
+    device); a C3 rank must fit a 288-GB device with room for the network.  NO scaling curve is measured by this: it checks the plan only."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "AGX_FORCE_DEVICE")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--plan-only", "--config", "C3"], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads([x for x in p.stdout.splitlines() if x.startswith("{")][-1])
+    plan = line["plan"]
+    assert line["n_gpus"] == 8 and len(plan) == 8 and sorted(r["rank"] for r in plan) == list(range(8))
+    assert sorted(r["device_index"] for r in plan) == list(range(8))          # eight distinct devices, local rank = device
+    assert all(r["device_index"] == r["local_rank"] for r in plan)
+    ranges = sorted(tuple(r["opening_seeds"]) for r in plan)
+    assert all(a[1] < b[0] for a, b in zip(ranges, ranges[1:]))                # disjoint opening seeds: the ranks play different games
+    # a C3 pool (1024 games: 4 Mi-entry solver tables = 64 GiB, tree heaps for 800 playouts per move, speculative overlays, spill areas) on one
+    # 288-GB device, the 10x128 network beside it; tests/test_bench_gpu.py checks the sizing pass against what an engine really allocates
+    assert all(64 * 2 ** 30 < r["device_bytes"] < 130e9 for r in plan), [r["device_bytes"] for r in plan]
+    assert len(set(r["device_bytes"] for r in plan)) == 1
+    assert all(r["device_bytes"] < 0.5 * line["hbm_bytes_per_device"] for r in plan)
+    assert "no scaling curve" in line["note"]

@@ -1679,3 +1679,21 @@ def test_configuration_errors_are_reported(agx_lib):
     assert pool.stats()["first_error"] == 0
     pool.close()
     net.close()
+
+
+@pytest.mark.parametrize("overrides", [dict(), dict(rules=2, solver_yield_fraction=0.5, speculative_solver=1), dict(board_size=20, rules=3, speculative_solver=1),
+                                       dict(speculative_solver=0, max_batch_size=4)])
+def test_sizing_pass_equals_what_an_engine_allocates(agx_lib, overrides):
+    """agx_engine_estimate_device_bytes (no device touched: bench.py --plan-only sizes the ranks of a multi-GPU job with it) adds up exactly the
+    allocations agx_engine_create makes on this device"""
+    from alphagomoku_amd import selfplay, lib, check
+    cus = ctypes.c_int()
+    check(lib.agx_device_cu_count(ctypes.byref(cus)))
+    base = dict(n_games=24, max_batch_size=8, max_simulations=100, tss_table_entries=1 << 14, node_capacity=4096, edge_capacity=131072)
+    base.update(overrides)
+    cfg = selfplay.default_config(**base)
+    need = ctypes.c_ulonglong()
+    check(lib.agx_engine_estimate_device_bytes(ctypes.byref(cfg), cus.value, ctypes.byref(need)))
+    pool = selfplay.GeneratorPool(cfg)
+    assert pool.device_bytes() == need.value and need.value > 0
+    pool.close()
