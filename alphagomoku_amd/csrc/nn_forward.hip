@@ -38,6 +38,7 @@
 #include <cstring>
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 
 #ifndef AGX_NN_COLS_AHEAD
 #define AGX_NN_COLS_AHEAD 4 // activation fragments in flight per wave in the column-tile k-loop
@@ -327,11 +328,21 @@ namespace
 	 * 3x3 convolution + bias (+ skip) + ReLU over one board held in LDS.
 	 * src, dst: activation planes; if SKIP the residual input is read from (and the result written to) dst.
 	 */
-	template<int F, int ROWS, int COLS>
+	/* the default row epilogue of the row-stationary loop: none (the caller finishes the layer behind the k-loop) */
+	struct NoRowEpilogue
+	{
+			static constexpr bool FUSED = false;
+			__device__ __forceinline__ void operator()(int) const
+			{
+			}
+	};
+	template<int F, int ROWS, int COLS, bool FINISH = false, typename Epi = NoRowEpilogue>
 	__device__ __forceinline__ void conv3x3_rows_stage(const char *src, const half8 *__restrict__ wnext, int kc, int dxi, int index_base, int q4,
 			int my_tiles, int lane, const half8 (&a_cur)[3][Geometry<F, ROWS, COLS>::MT], half8 (&a_next)[3][Geometry<F, ROWS, COLS>::MT],
-			floatx4 (&acc)[Geometry<F, ROWS, COLS>::MT][Geometry<F, ROWS, COLS>::NTW])
+			floatx4 (&acc)[Geometry<F, ROWS, COLS>::MT][Geometry<F, ROWS, COLS>::NTW], const Epi &epi = Epi())
 	{ // dxi is a compile-time constant at every call (conv3x3_mac_rows unrolls the three shifts of a chunk)
+	  // FINISH: the layer's last stage — output row o is complete behind input row o + 1; epi(o) converts and stores it one row later, beside the
+	  // MFMAs of the rows that follow (its vector instructions would otherwise wait for the matrix pipe to deliver the row)
 		typedef Geometry<F, ROWS, COLS> G;
 		static_assert(((G::KC - 1) << 6) < G::CH * 16, "a stage's chunk kc * 4 lies inside the chunk field of a position's bytes");
 		// the next stage's 3 * MT weight fragments: contiguous for this wave (pack_conv_rows), one scalar base + small offsets
@@ -369,10 +380,21 @@ namespace
 						acc[i][o] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_cur[dyi][i], b[(j + 1) % AHEAD], acc[i][o], 0, 0, 0);
 				}
 			}
+			if constexpr (FINISH)
+			{
+				const int done = j - 2;
+				if (done >= 0 && done < my_tiles)
+					epi(done);
+			}
 			// nothing crosses a row boundary: the fragment requested in this turn is the one used AHEAD - 1 turns later, so the wait in
 			// front of a turn's MFMAs leaves the younger requests in flight (left to itself the scheduler sinks every request to just
 			// before its use and a wave running alone on its SIMD stalls on each one)
 			__builtin_amdgcn_sched_barrier(0);
+		}
+		if constexpr (FINISH)
+		{
+			if (G::NTW - 1 < my_tiles)
+				epi(G::NTW - 1);
 		}
 	}
 
@@ -387,10 +409,10 @@ namespace
 	 * fragments are packed in consumption order (pack_conv_rows: stage = (chunk, dx), then channel group, dy, tile), so a stage's
 	 * fragments are 3 * MT consecutive KB behind one scalar base.
 	 */
-	template<int F, int ROWS, int COLS, bool ZERO = true>
+	template<int F, int ROWS, int COLS, bool ZERO = true, typename Epi = NoRowEpilogue>
 	__device__ __forceinline__ void conv3x3_mac_rows(const char *src, const half8 *__restrict__ wpk, int wave, int lane,
-			floatx4 (&acc)[Geometry<F, ROWS, COLS>::MT][Geometry<F, ROWS, COLS>::NTW], WeightCarry<Geometry<F, ROWS, COLS>> *carry = nullptr)
-	{
+			floatx4 (&acc)[Geometry<F, ROWS, COLS>::MT][Geometry<F, ROWS, COLS>::NTW], WeightCarry<Geometry<F, ROWS, COLS>> *carry = nullptr, const Epi &epi = Epi())
+	{ // epi (Epi::FUSED): the caller's epilogue of one output row, run inside the layer's last stage
 		typedef Geometry<F, ROWS, COLS> G;
 		static_assert(G::S == 16 && G::PAD == 0, "a position tile must be a board row (whole 256-byte bank rows, XOR chunk swizzle)");
 		const int r = lane & 15;
@@ -433,9 +455,9 @@ namespace
 		// base + immediate.  (Vector instructions in the MFMA stream are expensive: profiles/r06_nn_ab6_lane_shifted_rows_negative.txt.)
 		constexpr int TURN = 6;
 		static_assert(STAGES % TURN == 0 && TURN % RING == 0, "whole turns, static ring index");
-#pragma unroll 1
-		for (int s = 0; s < STAGES; s += TURN)
+		auto turn = [&](int s, auto last_turn)
 		{
+			constexpr bool LAST_TURN = decltype(last_turn)::value;
 #pragma unroll
 			for (int u = 0; u < TURN; u++)
 			{
@@ -462,13 +484,21 @@ namespace
 				// never issued (vmcnt(0)), which serialises fetch and MFMAs in every turn
 				const int ahead = s + u + RING - 1;
 				const half8 *wnext = (u + RING - 1 < TURN || ahead < STAGES) ? wl + ahead * STAGE_FRAGS : wrap + (ahead - STAGES) * STAGE_FRAGS;
-				conv3x3_rows_stage<F, ROWS, COLS>(src, wnext, s / 3 + u / 3, u % 3, index_base, q4, my_tiles, lane, a[u % RING], a[(u + RING - 1) % RING], acc);
+				if (LAST_TURN && Epi::FUSED && u == TURN - 1) // (a constant once the turn is unrolled)
+					conv3x3_rows_stage<F, ROWS, COLS, true, Epi>(src, wnext, s / 3 + u / 3, u % 3, index_base, q4, my_tiles, lane, a[u % RING], a[(u + RING - 1) % RING], acc, epi);
+				else
+					conv3x3_rows_stage<F, ROWS, COLS, false, Epi>(src, wnext, s / 3 + u / 3, u % 3, index_base, q4, my_tiles, lane, a[u % RING], a[(u + RING - 1) % RING], acc, epi);
 #if AGX_NN_PAIR_BALANCE
 				if (u % 2 == 1)
 					balance.done();
 #endif
 			}
-		}
+		};
+		// (the layer's last turn is its own copy of the code: its last stage carries the caller's row epilogue)
+#pragma unroll 1
+		for (int s = 0; s + TURN < STAGES; s += TURN)
+			turn(s, std::false_type());
+		turn(STAGES - TURN, std::true_type());
 		__builtin_amdgcn_s_setprio(0);
 		if (carry != nullptr)
 		{ // (behind the last turn sets 0 .. RING - 2 hold the next layer's stages 0 .. RING - 2)
@@ -684,12 +714,13 @@ namespace
 		__builtin_amdgcn_s_setprio(0);
 	}
 
-	template<int F, int ROWS, int COLS, bool ZERO = true>
+	template<int F, int ROWS, int COLS, bool ZERO = true, typename Epi = NoRowEpilogue>
 	__device__ __forceinline__ void conv3x3_mac(const char *src, const half8 *__restrict__ wpk, int wave, int lane,
-			floatx4 (&acc)[Geometry<F, ROWS, COLS>::MT][Geometry<F, ROWS, COLS>::NTW], WeightCarry<Geometry<F, ROWS, COLS>> *carry = nullptr)
+			floatx4 (&acc)[Geometry<F, ROWS, COLS>::MT][Geometry<F, ROWS, COLS>::NTW], WeightCarry<Geometry<F, ROWS, COLS>> *carry = nullptr, const Epi &epi = Epi())
 	{
+		static_assert(!Epi::FUSED || Geometry<F, ROWS, COLS>::S == 16, "only the row-stationary loop runs a row epilogue inside its last stage");
 		if constexpr (Geometry<F, ROWS, COLS>::S == 16)
-			conv3x3_mac_rows<F, ROWS, COLS, ZERO>(src, wpk, wave, lane, acc, carry);
+			conv3x3_mac_rows<F, ROWS, COLS, ZERO, Epi>(src, wpk, wave, lane, acc, carry, epi);
 		else if constexpr (Geometry<F, ROWS, COLS>::COLT)
 			conv3x3_mac_cols<F, ROWS, COLS, ZERO>(src, wpk, wave, lane, acc);
 		else
@@ -714,6 +745,32 @@ namespace
 		return TANH ? tanhf(x) : fmaxf(x, 0.0f);
 	}
 
+	/* The epilogue of ONE output row of a row-tile layer (conv3x3): convert, ReLU on packed halves, store — the spare column's lanes sit the
+	 * store out.  Run by the row-stationary loop inside the layer's last stage (conv3x3_rows_stage<.., FINISH>). */
+	template<typename G>
+	struct RowEpilogue
+	{
+			static constexpr bool FUSED = true;
+			floatx4 (&acc)[G::MT][G::NTW];
+			char *(&out0)[G::MT]; // this lane's cell in the wave's first row, per channel tile
+			int r;
+			__device__ __forceinline__ void operator()(int n) const
+			{
+				if (r < G::S - 1)
+				{
+#pragma unroll
+					for (int i = 0; i < G::MT; i++)
+					{
+						const floatx4 v = acc[i][n];
+						half2 lo { static_cast<half_t>(v[0]), static_cast<half_t>(v[1]) }, hi { static_cast<half_t>(v[2]), static_cast<half_t>(v[3]) };
+						const half2 zero2 { static_cast<half_t>(0.0f), static_cast<half_t>(0.0f) };
+						lo = __builtin_elementwise_max(lo, zero2);
+						hi = __builtin_elementwise_max(hi, zero2);
+						*reinterpret_cast<uint2*>(out0[i] + n * 16 * G::POS_BYTES) = uint2 { __builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi) };
+					}
+				}
+			}
+	};
 	template<int F, int ROWS, int COLS, bool SKIP, bool TANH = false>
 	__device__ __forceinline__ void conv3x3(const char *src, char *dst, const half8 *__restrict__ wpk, const float *__restrict__ bias, int wave,
 			int lane AGX_NN_STAMP_PARAM, WeightCarry<Geometry<F, ROWS, COLS>> *carry = nullptr, BiasCarry<Geometry<F, ROWS, COLS>::MT> *bias_carry = nullptr,
@@ -760,43 +817,44 @@ namespace
 			}
 		}
 		AGX_NN_MARK(2);
+		if constexpr (ROW_TILES && !TANH)
+		{
+			// Every tile of a wave is a board row (NT == ROWS): the only cell of a tile that is not on the board is the spare column's, lane
+			// r == COLS of every tile.  Those lanes sit the stores out (an exec mask) instead of every tile masking its values: the spare column
+			// stays zero from the plane's clearing.  ReLU after the conversion (rounding is monotonic, so max(cvt(x), 0) == cvt(max(x, 0))) on
+			// packed halves: 4 vector instructions per tile (2 conversions, 2 packed max) + one ds_write_b64 at an immediate offset.  The rows
+			// are finished INSIDE the layer's last stage, each beside the MFMAs of the rows behind it (conv3x3_rows_stage<.., FINISH>): nobody
+			// reads `dst` during this layer, and behind the k-loop both waves of a SIMD would convert and store with no MFMA left in flight.
+			static_assert(G::NT == ROWS && G::S == COLS + 1, "a tile is a board row + the spare column");
+			char *out0[G::MT];
+#pragma unroll
+			for (int i = 0; i < G::MT; i++)
+			{
+				const int ch = (mg * G::MT + i) * 16 + 4 * q4;
+				out0[i] = dst + plane_offset<G>(index0, ch / 8) + (ch % 8) * 2;
+			}
+			const RowEpilogue<G> epilogue { acc, out0, r };
+			if constexpr (G::MT == 1)
+			{ // (one channel tile: the next layer's bias values are four registers — requested here they have the whole k-loop to arrive)
+				if (bias_carry != nullptr)
+					request_bias<G>(next_bias, wave, lane, *bias_carry);
+			}
+			conv3x3_mac<F, ROWS, COLS, false, RowEpilogue<G>>(src, wpk, wave, lane, acc, carry, epilogue);
+			AGX_NN_MARK(3);
+			if constexpr (G::MT != 1)
+			{
+				if (bias_carry != nullptr)
+					request_bias<G>(next_bias, wave, lane, *bias_carry);
+			}
+			AGX_NN_MARK(4);
+			return;
+		}
 		conv3x3_mac<F, ROWS, COLS, false>(src, wpk, wave, lane, acc, carry);
 		AGX_NN_MARK(3);
 		if (bias_carry != nullptr)
 			request_bias<G>(next_bias, wave, lane, *bias_carry);
 
-		// epilogue: lane holds out-channels 4*q4 .. 4*q4+3 of tile i for position r of tile n
-		if constexpr (ROW_TILES && !TANH)
-		{
-			// Every tile of a wave is a board row (NT == ROWS): the only cell of a tile that is not on the board is the spare column's, lane
-			// r == COLS of every tile.  Those lanes sit the stores out (one exec mask around all of them) instead of every tile masking its
-			// values: the spare column stays zero from the plane's clearing.  ReLU after the conversion (rounding is monotonic, so
-			// max(cvt(x), 0) == cvt(max(x, 0))) on packed halves: 4 vector instructions per tile (2 conversions, 2 packed max) + one
-			// ds_write_b64 at an immediate offset.
-			static_assert(G::NT == ROWS && G::S == COLS + 1, "a tile is a board row + the spare column");
-			if (r < COLS)
-			{
-#pragma unroll
-				for (int i = 0; i < G::MT; i++)
-				{
-					const int ch = (mg * G::MT + i) * 16 + 4 * q4;
-					char *out0 = dst + plane_offset<G>(index0, ch / 8) + (ch % 8) * 2;
-#pragma unroll
-					for (int n = 0; n < G::NTW; n++)
-						if (n < my_tiles)
-						{
-							const floatx4 v = acc[i][n];
-							half2 lo { static_cast<half_t>(v[0]), static_cast<half_t>(v[1]) }, hi { static_cast<half_t>(v[2]), static_cast<half_t>(v[3]) };
-							const half2 zero2 { static_cast<half_t>(0.0f), static_cast<half_t>(0.0f) };
-							lo = __builtin_elementwise_max(lo, zero2);
-							hi = __builtin_elementwise_max(hi, zero2);
-							*reinterpret_cast<uint2*>(out0 + n * 16 * G::POS_BYTES) = uint2 { __builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi) };
-						}
-				}
-			}
-			AGX_NN_MARK(4);
-			return;
-		}
+		// epilogue: lane holds out-channels 4*q4 .. 4*q4+3 of tile i for position r of tile n (boards whose tiles are not rows, tanh layers)
 #pragma unroll
 		for (int i = 0; i < G::MT; i++)
 		{
@@ -1127,7 +1185,7 @@ namespace
 					}
 			}
 		}
-		else if constexpr (G::S == 16 && F == 64) // (128-filter nets keep the tap-major loop: measured 1 % faster, the 2 x 10 weight fragments in flight spill)
+		else if constexpr (G::S == 16 && G::MT == 1) // (one channel tile per wave: 2 x 5 weight fragments in flight; with two tiles they spill: the two-pass form below)
 		{
 			// Input-row stationary like conv3x3_mac_rows: for a column shift dx the fragment of padded input row j is read once and feeds the
 			// five taps dy = -2 .. 2 (output rows j + 2 .. j - 2): 5 x (NTW + 4) fragment reads instead of 25 x NTW, and — the padded plane being
@@ -1186,7 +1244,7 @@ namespace
 						a_cur[dyi][i] = a_next[dyi][i];
 			}
 		}
-		else if constexpr (G::S == 16 && F == 128)
+		else if constexpr (G::S == 16 && G::MT == 2)
 		{
 			// 128 filters: the row-stationary loop above with the five vertical taps of a column shift taken in two passes — dy = -2, -1, 0
 			// (input rows -2 .. NTW - 1 of the wave) and dy = +1, +2 (rows 1 .. NTW + 1) — so that only 3 * MT + 2 * MT weight fragments are
