@@ -40,11 +40,11 @@ def test_two_ranks_on_one_gpu_report_the_whole_job(agx_lib):
 
 
 def test_pool_rate_floor(agx_lib):
-    """the default workload for 150 steps of an aged pool (the pool's boxes reach 820-840 k simulations/s there): a tripwire for regressions
+    """the default workload for 150 steps of an aged pool (round 6: the boxes reach 950-1000 k simulations/s there): a tripwire for regressions
     that leave every parity test green, not a benchmark"""
-    line = run_bench(["--steps", "150", "--warmup", "20", "--no-cpu-baseline"])
-    assert line["config"]["games_per_gpu"] == 1024 and line["n_gpus"] == 1 and line["aged_steps"] == 3000
-    assert line["value"] >= 700e3, line["value"]
+    line = run_bench(["--steps", "150", "--warmup", "20", "--age-steps", "1500", "--no-cpu-baseline"])
+    assert line["config"]["games_per_gpu"] == 1024 and line["n_gpus"] == 1 and line["aged_steps"] == 1500
+    assert line["value"] >= 800e3, line["value"]
     assert line["speculative_solver"]["enabled"] and line["speculative_solver"]["leaves_solved"] > 0
     assert line["slices"]["count"] == 4 and line["slices"]["cus_per_slice"] * 4 <= 256
     assert line["roofline"]["whole_chip_equivalent"] >= 800.0 and 0 < line["roofline"]["frac"] < 1, line["roofline"]

@@ -1141,11 +1141,11 @@ def test_pool_step_with_device_network_is_deterministic_and_consistent(agx_lib):
 
 FULL_SIZE = {
     # BASELINE.json configs at bench.py's sizes: rules, board, network, playouts, steps of the big pool, steps of the small pool
-    # (+ the least number of move records that must have been compared over the 128 games looked at: 3 to 5 moves per game)
-    "C2-freestyle-15x15-6x128-400": dict(rules=0, n=15, blocks=6, sims=400, big_steps=420, small_steps=680, compared=450),
-    "C3-standard-15x15-10x128-800": dict(rules=1, n=15, blocks=10, sims=800, big_steps=460, small_steps=740, compared=300),
-    "C4-caro5-20x20-10x128-400": dict(rules=3, n=20, blocks=10, sims=400, big_steps=320, small_steps=520, compared=400),
-    "C5-renju-15x15-10x128-1600": dict(rules=2, n=15, blocks=10, sims=1600, big_steps=660, small_steps=1080, compared=250),
+    # (+ the least number of move records that must have been compared over the 128 games looked at: 2 to 3 moves per game)
+    "C2-freestyle-15x15-6x128-400": dict(rules=0, n=15, blocks=6, sims=400, big_steps=320, small_steps=510, compared=300),
+    "C3-standard-15x15-10x128-800": dict(rules=1, n=15, blocks=10, sims=800, big_steps=350, small_steps=560, compared=200),
+    "C4-caro5-20x20-10x128-400": dict(rules=3, n=20, blocks=10, sims=400, big_steps=240, small_steps=390, compared=270),
+    "C5-renju-15x15-10x128-1600": dict(rules=2, n=15, blocks=10, sims=1600, big_steps=500, small_steps=810, compared=170),
 }
 
 
@@ -1594,12 +1594,12 @@ def test_evaluation_matches_bit_exact(agx_lib, olib, rules, batch, sims, max_chi
     """match_mode: EvaluationGame + Player (evaluation/EvaluationGame.cpp:77-146, evaluation/Player.cpp:98-216): two players with
     their own trees, solvers and networks share a game; every opening is played twice with the colours swapped; a player's tree
     jumps two plies per setBoard and survives from game to game; the root is pruned like any node.  Device vs oracle after
-    every half-step (features of every scheduled leaf, root edges of the searching tree), for three pairs playing two matches;
+    every half-step (features of every scheduled leaf, root edges of the searching tree), for two pairs playing two matches each;
     stepped as two groups and as merged launches over both players' trees (agx_engine_step_match)."""
-    compared, stats, results = _play_matches_and_compare(olib, rules, pairs=3, n_openings=6, batch=batch, sims=sims, max_steps=6000, max_children=max_children,
+    compared, stats, results = _play_matches_and_compare(olib, rules, pairs=2, n_openings=4, batch=batch, sims=sims, max_steps=6000, max_children=max_children,
                                                          draw_after=80, merged=merged, use_symmetries=symmetries)
-    assert len(results) == 12 and compared > 300                     # 6 openings x 2 games
-    assert stats["games_finished"] == 12
+    assert len(results) == 8 and compared > 200                      # 4 openings x 2 games
+    assert stats["games_finished"] == 8
     by_opening = {}
     for m, oid, k, outcome in results:
         by_opening.setdefault(oid, []).append(k)
