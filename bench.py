@@ -496,7 +496,7 @@ def main():
         mfma_busy = None
         solver_issue = None
         nn_clock = None
-        pmc_path = os.path.join(ROOT, "profiles", "r05_pmc_summary.json")
+        pmc_path = os.path.join(ROOT, "profiles", "r06_pmc_summary.json")
         src_hash = source_hash()
         pmc_build = None
         if os.path.exists(pmc_path):
