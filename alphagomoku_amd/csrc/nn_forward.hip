@@ -188,6 +188,10 @@ namespace
 				else
 					return (index / PPR) % CH;
 			}
+			// (Row tiles: slot (chunk + 2 * index) mod 16 instead of the XOR makes every fragment read of the row-stationary loop conflict-free — the XOR
+			//  form reads one column shift in three 2-way — but the 8-byte epilogue stores 4-way: measured 3.6-3.9 % slower,
+			//  profiles/r06_nn_ab12_rotation_swizzle_negative.txt; no linear XOR swizzle does better than the identity, scripts/nn_lds_banks.py.)
+			__device__ static __forceinline__ int slot(int index, int chunk) { return chunk ^ swizzle(index); }
 			/* row-major position (stride S, 0 = cell (0, 0)) of lane r's cell in tile n of the wave */
 			__device__ static __forceinline__ int tile_position(int wave, int n, int r)
 			{
@@ -212,7 +216,10 @@ namespace
 			}
 			static constexpr int MTILES = F / 16;
 			static constexpr int KC = F / 32;                                    // k-steps per tap
-			static constexpr int S5 = S + 4;                                     // row stride of the padded input plane
+			// row stride of the padded input plane.  Row tiles with 128 filters: 32 positions, so that the plane's chunk swizzle ((index >> 2) & 3) does
+			// not depend on the ROW — a lane's fragments of one column shift are one address + immediates (with stride S + 4 every fragment read of the
+			// input conv cost ~15 vector instructions of address arithmetic: 380 beside the 75 MFMAs of a column shift)
+			static constexpr int S5 = (S == 16 && F >= 128) ? 32 : S + 4;
 			static constexpr int NPOS5 = (ROWS + 4) * S5 + 4;
 			static constexpr int HW = ROWS * COLS;
 			static constexpr int D = (2 * F < 256) ? 2 * F : 256;
@@ -283,7 +290,7 @@ namespace
 	template<typename G>
 	__device__ __forceinline__ int plane_offset(int index, int chunk)
 	{ // byte offset of a 16-byte chunk of stored position `index` (= position + 1)
-		return index * G::POS_BYTES + (chunk ^ G::swizzle(index)) * 16;
+		return index * G::POS_BYTES + G::slot(index, chunk) * 16;
 	}
 
 	/* The weight fragments of a layer's first stage(s), requested by the layer in front of it: a layer that fetches them itself starts with an
@@ -1207,9 +1214,13 @@ namespace
 					for (int i = 0; i < G::MT; i++)
 						a_next[dyi][i] = wl[((dyi * 5 + dxn) * G::MTILES + i) * 64 + lane];
 				// stored cell of this lane in padded row (n0 + j + 2): column r + (dxi - 2) + 2
+				const int column = r + dxi;
+				const char *column_ptr = in5 + (column * 4 + (q4 ^ ((column >> 2) & 3))) * 16; // (row stride a multiple of 16 positions: the swizzle is the column's)
 				auto fragment = [&](int j) -> half8
 				{
 					const int jj = (j <= my_tiles + 1) ? j : 0; // rows past the wave's last output row + 2 are not needed (and would leave the plane)
+					if constexpr (G::S5 % 16 == 0)
+						return *reinterpret_cast<const half8*>(column_ptr + (n0 + jj + 2) * (G::S5 * 64));
 					const int q = (n0 + jj + 2) * G::S5 + (r + dxi);
 					return *reinterpret_cast<const half8*>(in5 + (q * 4 + (q4 ^ ((q >> 2) & 3))) * 16);
 				};
@@ -1385,6 +1396,33 @@ namespace
 		int skip_lane = lane;
 		asm volatile("" : "+v"(skip_lane));
 		global_half4 *my_skip = (global_half4*) (skip + __builtin_amdgcn_readfirstlane(wave * G::MT * G::NTW * 64)) + skip_lane;
+		if constexpr (G::S == 16 && !INPLACE)
+		{ // row tiles, two planes: conv3x3's epilogue (RowEpilogue) with the bias added — one address per channel tile + n * 4096, the spare column's lanes
+		  // sit the stores out (the plane's border stays zero), ReLU on packed halves
+			static_assert(G::NT == ROWS, "a tile is a board row + the spare column");
+			if (r < COLS)
+			{
+#pragma unroll
+				for (int i = 0; i < G::MT; i++)
+				{
+					const int ch = (mg * G::MT + i) * 16 + 4 * q4;
+					const floatx4 bv = *reinterpret_cast<const floatx4*>(bias + ch);
+					char *out0 = dst + plane_offset<G>(1 + G::S + n0 * 16 + r, ch / 8) + (ch % 8) * 2;
+#pragma unroll
+					for (int n = 0; n < G::NTW; n++)
+						if (n < my_tiles)
+						{
+							const floatx4 v = acc[i][n];
+							half2 lo { static_cast<half_t>(v[0] + bv[0]), static_cast<half_t>(v[1] + bv[1]) }, hi { static_cast<half_t>(v[2] + bv[2]), static_cast<half_t>(v[3] + bv[3]) };
+							const half2 zero2 { static_cast<half_t>(0.0f), static_cast<half_t>(0.0f) };
+							lo = __builtin_elementwise_max(lo, zero2);
+							hi = __builtin_elementwise_max(hi, zero2);
+							*reinterpret_cast<uint2*>(out0 + n * 16 * G::POS_BYTES) = uint2 { __builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi) };
+						}
+				}
+			}
+			return;
+		}
 #pragma unroll
 		for (int i = 0; i < G::MT; i++)
 		{
@@ -1588,12 +1626,10 @@ namespace
 				{
 					floatx4 v { p.bv1[0], p.bv1[1], p.bv1[2], p.bv1[3] };
 					const int index0 = 1 + G::S + n * 16 + r;
-					const int swz0 = G::swizzle(index0);
-					const char *src0 = plane_x + index0 * G::POS_BYTES;
 #pragma unroll
 					for (int kc = 0; kc < G::KC; kc++)
 					{
-						const half8 bfrag = *reinterpret_cast<const half8*>(src0 + (((kc * 4 + q4) ^ swz0) * 16));
+						const half8 bfrag = *reinterpret_cast<const half8*>(plane_x + plane_offset<G>(index0, kc * 4 + q4));
 						v = __builtin_amdgcn_mfma_f32_16x16x32_f16(s_wv1f[kc * 64 + lane], bfrag, v, 0, 0, 0);
 					}
 					// lanes with q4 == 0 hold outputs 0 .. 3 of position r of tile n (the bias of the other, unused rows is irrelevant)
