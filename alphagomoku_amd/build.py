@@ -107,7 +107,7 @@ def _compile_cmd(hipcc, src, obj):
 def build(force=False, verbose=True):
     """Incremental: an object is recompiled when its source or any device header is newer, libagx.so is linked when an object is newer,
     the host-side binaries (driver, reference-named classes, boundary test) when their sources / headers are."""
-    if os.environ.get("AGX_NO_BUILD"):   # developer A/B runs that swap prebuilt variants of libagx.so in (scripts/ab_bench.sh)
+    if os.environ.get("AGX_NO_BUILD"):   # developer A/B runs with prebuilt variant libraries selected by AGX_LIB_PATH (scripts/nn_ab.py)
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cxx = os.environ.get("CXX", "g++")

@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage: scripts/build_engine_variant.sh NAME "<-D flags>" — a variant of engine.hip linked into alphagomoku_amd/libagx_NAME.so (the other objects as built);
-# run it with scripts/ab_engine_run.sh (AGX_NO_BUILD=1 skips the source-hash check for such developer variants)
+# run anything with it through AGX_NO_BUILD=1 AGX_LIB_PATH=alphagomoku_amd/libagx_NAME.so (AGX_NO_BUILD skips the source-hash check for such developer variants)
 cd "$(dirname "$0")/.."
 name="$1"; flags="$2"
 # RELINK=1: only link /tmp/engine_NAME.o again (the other objects have been rebuilt meanwhile)
