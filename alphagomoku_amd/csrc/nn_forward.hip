@@ -310,6 +310,14 @@ namespace
 	{
 			floatx4 b[MT];
 	};
+	/* The residual input of a block's second layer (single-plane kernels: parked in the workgroup's global scratch), requested by the block's FIRST
+	 * layer behind its k-loop — its accumulator registers are free there — so that the round trips ride through that layer's barrier and plane
+	 * write instead of standing in front of the second layer's k-loop, where every wave of the workgroup waited for them. */
+	template<typename G>
+	struct SkipCarry
+	{
+			uint2 v[G::MT][G::NTW];
+	};
 	template<typename G>
 	__device__ __forceinline__ void request_bias(const float *__restrict__ bias, int wave, int lane, BiasCarry<G::MT> &carry)
 	{
@@ -677,8 +685,8 @@ namespace
 	}
 	template<int F, int ROWS, int COLS, bool ZERO = true>
 	__device__ __forceinline__ void conv3x3_mac_cols(const char *src, const half8 *__restrict__ wpk, int wave, int lane,
-			floatx4 (&acc)[Geometry<F, ROWS, COLS>::MT][Geometry<F, ROWS, COLS>::NTW])
-	{
+			floatx4 (&acc)[Geometry<F, ROWS, COLS>::MT][Geometry<F, ROWS, COLS>::NTW], WeightCarry<Geometry<F, ROWS, COLS>> *carry = nullptr)
+	{ // carry: as in conv3x3_mac_rows — the first stage's fragments come from the layer in front, the last requests are the next layer's first stage
 		typedef Geometry<F, ROWS, COLS> G;
 		static_assert(G::COLT && (G::CG == 4 || G::CG == 8), "column tiles: four channel groups x two position groups, or eight x one");
 		const int r = lane & 15;
@@ -697,17 +705,19 @@ namespace
 		constexpr int STAGE_FRAGS = G::CG * 3 * G::MT * 64;
 		static_assert(STAGES % 2 == 0, "two stages per loop turn (static ring index)");
 		const half8 *wl = wpk + __builtin_amdgcn_readfirstlane(mg * 3 * G::MT * 64);
+		static_assert(G::WRING == 2, "two sets of weight fragments");
+		const half8 *wrap = (carry != nullptr) ? carry->next + __builtin_amdgcn_readfirstlane(mg * 3 * G::MT * 64) : wl;
 		half8 a0[3][G::MT], a1[3][G::MT];
 #pragma unroll
 		for (int dxi = 0; dxi < 3; dxi++)
 #pragma unroll
 			for (int i = 0; i < G::MT; i++)
-				a0[dxi][i] = wl[(dxi * G::MT + i) * 64 + lane];
+				a0[dxi][i] = (carry != nullptr) ? carry->a[0][dxi][i] : wl[(dxi * G::MT + i) * 64 + lane];
 		// byte offsets (chunk q4) of this lane's cell (row r, column x0 - 1) and of its cell in the wave's first tail tile
 		const int col_base = plane_offset<G>(1 + G::S + r * G::S + pg * G::COL_TILES - 1, q4);
 		const int tail_base = plane_offset<G>(1 + G::S + (G::TAIL_FIRST + pg * G::TAIL_TILES) * 16 + r, q4);
 #pragma unroll 1
-		for (int s = 0; s < STAGES; s += 2)
+		for (int s = 0; s + 2 < STAGES; s += 2)
 		{
 			if (3 * s < STAGES) // (priority by remaining work)
 				__builtin_amdgcn_s_setprio(3);
@@ -716,9 +726,20 @@ namespace
 			else
 				__builtin_amdgcn_s_setprio(1);
 			conv3x3_cols_stage<F, ROWS, COLS>(src, wl + (s + 1) * STAGE_FRAGS, s / 3, s % 3, col_base, tail_base, q4, lane, a0, a1, acc);
-			conv3x3_cols_stage<F, ROWS, COLS>(src, wl + ((s + 2 < STAGES) ? (s + 2) : 0) * STAGE_FRAGS, (s + 1) / 3, (s + 1) % 3, col_base, tail_base, q4, lane, a1, a0, acc);
+			conv3x3_cols_stage<F, ROWS, COLS>(src, wl + (s + 2) * STAGE_FRAGS, (s + 1) / 3, (s + 1) % 3, col_base, tail_base, q4, lane, a1, a0, acc);
 		}
+		// (the layer's last two stages: the very last requests the NEXT layer's first stage — its own again without a carry — see conv3x3_mac_rows)
+		conv3x3_cols_stage<F, ROWS, COLS>(src, wl + (STAGES - 1) * STAGE_FRAGS, (STAGES - 2) / 3, (STAGES - 2) % 3, col_base, tail_base, q4, lane, a0, a1, acc);
+		conv3x3_cols_stage<F, ROWS, COLS>(src, wrap, (STAGES - 1) / 3, (STAGES - 1) % 3, col_base, tail_base, q4, lane, a1, a0, acc);
 		__builtin_amdgcn_s_setprio(0);
+		if (carry != nullptr)
+		{ // (behind the last stage set 0 holds the next layer's first stage)
+#pragma unroll
+			for (int dxi = 0; dxi < 3; dxi++)
+#pragma unroll
+				for (int i = 0; i < G::MT; i++)
+					carry->a[0][dxi][i] = a0[dxi][i];
+		}
 	}
 
 	template<int F, int ROWS, int COLS, bool ZERO = true, typename Epi = NoRowEpilogue>
@@ -729,7 +750,7 @@ namespace
 		if constexpr (Geometry<F, ROWS, COLS>::S == 16)
 			conv3x3_mac_rows<F, ROWS, COLS, ZERO, Epi>(src, wpk, wave, lane, acc, carry, epi);
 		else if constexpr (Geometry<F, ROWS, COLS>::COLT)
-			conv3x3_mac_cols<F, ROWS, COLS, ZERO>(src, wpk, wave, lane, acc);
+			conv3x3_mac_cols<F, ROWS, COLS, ZERO>(src, wpk, wave, lane, acc, carry);
 		else
 			conv3x3_mac_taps<F, ROWS, COLS, ZERO>(src, wpk, wave, lane, acc);
 	}
@@ -915,8 +936,11 @@ namespace
 	 */
 	template<int F, int ROWS, int COLS, int MODE>
 	__device__ __forceinline__ void conv3x3_inplace(char *plane, const half8 *__restrict__ wpk, BiasCarry<Geometry<F, ROWS, COLS>::MT> &bias_carry,
-			const float *__restrict__ next_bias, half4 *skip, const float *__restrict__ wp2, float *ppart, int wave, int lane AGX_NN_STAMP_PARAM)
-	{ // bias_carry: this layer's bias values on entry, the next layer's (next_bias, may be null: nothing follows) on return
+			const float *__restrict__ next_bias, half4 *skip, const float *__restrict__ wp2, float *ppart, int wave, int lane AGX_NN_STAMP_PARAM,
+			SkipCarry<Geometry<F, ROWS, COLS>> *skip_carry = nullptr, WeightCarry<Geometry<F, ROWS, COLS>> *carry = nullptr)
+	{ // carry: the layer's first weight fragments on entry, the next layer's on return (conv3x3_mac_rows / _cols)
+	  // bias_carry: this layer's bias values on entry, the next layer's (next_bias, may be null: nothing follows) on return
+	  // skip_carry: mode 0 fills it behind its k-loop with the block's residual input, mode 1 starts its accumulators from it
 		typedef Geometry<F, ROWS, COLS> G;
 		const int r = lane & 15;
 		const int q4 = lane >> 4;
@@ -947,7 +971,7 @@ namespace
 					floatx4 v = bv;
 					if (MODE == 1)
 					{ // bias + (float) residual as one v_fma_mix_f32 per value (conv3x3: h * 1.0 + b rounds once, like the conversion followed by the add)
-						const uint2 sk = __builtin_bit_cast(uint2, my_skip[(i * G::NTW + n) * 64]);
+						const uint2 sk = (skip_carry != nullptr) ? skip_carry->v[i][n] : __builtin_bit_cast(uint2, my_skip[(i * G::NTW + n) * 64]);
 						v[0] = half_plus_float_lo(sk.x, bv[0]);
 						v[1] = half_plus_float_hi(sk.x, bv[1]);
 						v[2] = half_plus_float_lo(sk.y, bv[2]);
@@ -957,12 +981,12 @@ namespace
 				}
 			}
 			AGX_NN_MARK(2);
-			conv3x3_mac<F, ROWS, COLS, false>(plane, wpk, wave, lane, acc);
+			conv3x3_mac<F, ROWS, COLS, false>(plane, wpk, wave, lane, acc, carry);
 		}
 		else
 		{
 			AGX_NN_MARK(2);
-			conv3x3_mac<F, ROWS, COLS>(plane, wpk, wave, lane, acc);
+			conv3x3_mac<F, ROWS, COLS>(plane, wpk, wave, lane, acc, carry);
 		}
 		AGX_NN_MARK(3);
 		const BiasCarry<G::MT> bias_now = bias_carry; // (modes 2 and 3 add the bias behind the k-loop)
@@ -1103,6 +1127,14 @@ namespace
 				if (MODE == 1)
 					my_skip[(i * G::NTW + n) * 64] = __builtin_bit_cast(half4, packed);
 			}
+		}
+		if (MODE == 0 && skip_carry != nullptr)
+		{ // (the accumulators are dead, the packed outputs hold half their registers: room for the next layer's residual input)
+#pragma unroll
+			for (int i = 0; i < G::MT; i++)
+#pragma unroll
+				for (int n = 0; n < G::NTW; n++)
+					skip_carry->v[i][n] = __builtin_bit_cast(uint2, my_skip[(i * G::NTW + n) * 64]);
 		}
 		AGX_NN_MARK(4);
 		lds_barrier(); // every wave has consumed the plane: it can be overwritten now
@@ -1581,7 +1613,7 @@ namespace
 
 			AGX_NN_MARK(9);
 			// ---- residual tower ----
-			constexpr bool CARRY = !INPLACE && G::S == 16;
+			constexpr bool CARRY = INPLACE ? (G::COLT && !RAW) : G::S == 16;
 			WeightCarry<G> carry_store;
 			WeightCarry<G> *carry = CARRY ? &carry_store : nullptr;
 			if constexpr (CARRY)
@@ -1591,11 +1623,16 @@ namespace
 				// (bias_carry: every layer requests the next layer's bias values behind its k-loop; behind the last block follows the policy conv)
 				if (INPLACE)
 				{
+					SkipCarry<G> skip_carry; // the block's residual input: requested by its first layer, consumed by its second
+					if constexpr (CARRY)
+						carry_store.next = p.w_tower + (2 * blk + 1) * layer_halves8;
 					conv3x3_inplace<F, ROWS, COLS, 0>(plane_x, p.w_tower + (2 * blk) * layer_halves8, bias_carry, p.bias + (2 + 2 * blk) * F, skip, nullptr, nullptr, wave,
-							lane AGX_NN_STAMP_ARG);
+							lane AGX_NN_STAMP_ARG, &skip_carry, carry);
 					lds_barrier();
+					if constexpr (CARRY)
+						carry_store.next = p.w_tower + (2 * blk + 2) * layer_halves8; // (behind the last block: the policy conv)
 					conv3x3_inplace<F, ROWS, COLS, 1>(plane_x, p.w_tower + (2 * blk + 1) * layer_halves8, bias_carry, p.bias + (3 + 2 * blk) * F, skip, nullptr, nullptr, wave,
-							lane AGX_NN_STAMP_ARG);
+							lane AGX_NN_STAMP_ARG, &skip_carry, carry);
 					lds_barrier();
 				}
 				else
@@ -1649,8 +1686,12 @@ namespace
 			AGX_NN_MARK(6);
 			// ---- policy head: conv3x3 + ReLU into plane_t ----
 			if (INPLACE)
+			{
+				if constexpr (CARRY) // (nothing follows: its own first stage again)
+					carry_store.next = p.w_tower + (2 * p.blocks) * layer_halves8;
 				conv3x3_inplace<F, ROWS, COLS, 2>(plane_x, p.w_tower + (2 * p.blocks) * layer_halves8, bias_carry, QHEAD ? p.bias + (2 + 2 * p.blocks) * F : nullptr, nullptr, s_wp2,
-						ppart, wave, lane AGX_NN_STAMP_ARG);
+						ppart, wave, lane AGX_NN_STAMP_ARG, nullptr, carry);
+			}
 			else
 			{
 				if constexpr (CARRY)
