@@ -558,6 +558,9 @@ namespace agx
 #ifndef AGX_SNAPSHOT_UNDO
 #define AGX_SNAPSHOT_UNDO 1
 #endif
+#ifndef AGX_LEAN_LIST_EDITS
+#define AGX_LEAN_LIST_EDITS 1 /* the ordered list edits of a pattern update as one packed event word per step (see solver_update_around) */
+#endif
 #ifndef AGX_SNAPSHOT_PREFETCH
 #define AGX_SNAPSHOT_PREFETCH 1 /* the snapshot word is requested by the frame machine when a node returns (0: by solver_place itself) */
 #endif
@@ -700,6 +703,64 @@ namespace agx
 			 * reference's order per list.  LDS executes a wave's instructions in issue order, so a step sees the previous one.
 			 */
 			const int my_s = (lane >= 10) ? 1 : 0;
+#if AGX_LEAN_LIST_EDITS
+			/* The step, leaner (round 6; the serial form below stays for lists about to outgrow their LDS capacity).  An event — one cell changing
+			 * its threat type on one or both sides — travels as ONE word (cell | old0 << 9 | new0 << 13 | old1 << 17 | new1 << 21: one v_readlane per
+			 * side instead of three), a list lane pulls its side's fields out with its own shift amounts, lanes without a list hold type -1 and match
+			 * nothing, and the only exec region left is the one around the two stores.  ~50 instructions per step against ~95. */
+			const int t_raw = lane - 10 * my_s;
+			const int lean_t = (lane < 20 && t_raw != 0) ? t_raw : -1;
+			const int pending = 1 + max(__popcll(changed0), __popcll(changed1)); // no list grows by more than this
+			const bool roomy = __ballot(lean_t >= 2 && cnt + pending > SH::list_cap(lean_t)) == 0ull;
+			if (__builtin_expect(roomy, 1))
+			{
+				const uint32_t ev = static_cast<uint32_t>(cell) | (static_cast<uint32_t>(old0) << 9) | (static_cast<uint32_t>(new0) << 13)
+						| (static_cast<uint32_t>(old1) << 17) | (static_cast<uint32_t>(new1) << 21);
+				const uint32_t shift_old = 9u + 8u * my_s, shift_new = 13u + 8u * my_s;
+				uint16_t *const my_items = &sh.items[my_s][(lean_t >= 3) ? SH::list_off(lean_t) : 0];
+				uint16_t *const my_pos = &sh.pos[my_s][0];
+				const bool stored = (lean_t != 1); // the HALF_OPEN_3 list is only counted
+				const uint32_t centre_event = static_cast<uint32_t>(center)
+						| (added ? ((static_cast<uint32_t>(c0) << 9) | (static_cast<uint32_t>(c1) << 17)) : ((static_cast<uint32_t>(c0) << 13) | (static_cast<uint32_t>(c1) << 21)));
+				uint32_t e0 = centre_event, e1 = centre_event; // the centre is the first event of both sides
+				for (;;)
+				{
+					const uint32_t e = my_s ? e1 : e0;
+					const int o = static_cast<int>((e >> shift_old) & 15u), nw = static_cast<int>((e >> shift_new) & 15u);
+					const int cl = static_cast<int>(e & 511u);
+					const bool take = (lean_t == o), put = (lean_t == nw);
+					const int idx = my_pos[cl];
+					const int last = my_items[max(cnt - 1, 0)];
+					const int where = take ? idx : cnt, what = take ? last : cl;
+					if ((take || put) && stored)
+					{
+						my_items[where] = static_cast<uint16_t>(what);
+						if (put || last != cl)
+							my_pos[what] = static_cast<uint16_t>(where);
+					}
+					cnt += (put ? 1 : 0) - (take ? 1 : 0);
+					__builtin_amdgcn_wave_barrier();
+					if ((changed0 | changed1) == 0ull)
+						break;
+					e0 = 0u;
+					e1 = 0u;
+					if (changed0 != 0ull)
+					{
+						const int src = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(changed0)) - 1);
+						changed0 &= changed0 - 1;
+						e0 = __builtin_amdgcn_readlane(ev, src);
+					}
+					if (changed1 != 0ull)
+					{
+						const int src = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(changed1)) - 1);
+						changed1 &= changed1 - 1;
+						e1 = __builtin_amdgcn_readlane(ev, src);
+					}
+				}
+			}
+			else
+#endif
+			{
 			const int my_t = (lane < 20) ? lane - 10 * my_s : -1;
 			auto edit = [&](int cell0, int o0, int n0, int cell1, int o1, int n1)
 			{
@@ -750,6 +811,7 @@ namespace agx
 					n1 = __builtin_amdgcn_readlane(new1, src);
 				}
 				edit(cell0, o0, n0, cell1, o1, n1);
+			}
 			}
 			if (lane < 20)
 				sh.count[lane / 10][lane % 10] = static_cast<uint16_t>(cnt);
