@@ -242,7 +242,12 @@ namespace agx
 				// (round 5, late: 15x15 boards keep 448 action-stack entries and 30 frames in LDS instead of 1024 and 42 — 12 928 -> 10 240 bytes per wave,
 				// SIXTEEN waves per compute unit instead of twelve: a slice's ~1 900 leaves are then two rounds of solves on its 1 024 waves, not 2.47 -> three
 				// on 768; a 100-node solve's stack stays below 448 entries and 30 levels nearly always, the tails go to HBM as before)
-				static constexpr int ACT_LDS = (N <= 15) ? 448 : 1024;
+				// (round 6: 20x20 boards keep 336 entries instead of 1024 — 16 064 -> 13 312 bytes per wave, TWELVE waves per compute unit instead of ten; the select
+				// stage's keys run on over everything up to `board`)
+#ifndef AGX_ACT_LDS_20
+#define AGX_ACT_LDS_20 336
+#endif
+				static constexpr int ACT_LDS = (N <= 15) ? 448 : AGX_ACT_LDS_20;
 				static constexpr int FRAMES = (N <= 15) ? 30 : 34; // alpha-beta frames kept in LDS (LDS_FRAMES at most); deeper ones live in HBM
 				__device__ static constexpr int list_cap(int t) { return (t == 2) ? CAP2 : CAP; }
 				__device__ static constexpr int list_off(int t) { return (t == 2) ? 0 : CAP2 + (t - 3) * CAP; }

@@ -688,8 +688,8 @@ namespace
 		{
 			static_assert(offsetof(SH, act) % 8 == 0 && offsetof(SH, frames) == offsetof(SH, act) + sizeof(sh.act) && offsetof(SH, ptype) == offsetof(SH, frames) + sizeof(sh.frames)
 				&& offsetof(SH, threat) == offsetof(SH, ptype) + sizeof(sh.ptype) && offsetof(SH, items) == offsetof(SH, threat) + sizeof(sh.threat),
-				"select-stage keys: 64-bit words over act + frames + ptype + threat + items (contiguous)");
-			static_assert(sizeof(sh.act) + sizeof(sh.frames) + sizeof(sh.ptype) + sizeof(sh.threat) + sizeof(sh.items) >= SH::SELECT_KEY_BYTES && sizeof(sh.lines) >= BWORDS * sizeof(u64),
+				"select-stage keys: 64-bit words over act + frames + ptype + threat + items (contiguous) and on over the per-solve scratch up to board");
+			static_assert(offsetof(SH, board) - offsetof(SH, act) >= SH::SELECT_KEY_BYTES && offsetof(SH, board) > offsetof(SH, items) && sizeof(sh.lines) >= BWORDS * sizeof(u64),
 				"select-stage LDS must fit");
 			const GameState &sg = E.games[g];
 			if (sg.active && sg.error == 0 && sg.outcome == 0 && !sg.grow_pending)
@@ -1017,8 +1017,8 @@ namespace
 		/* ---- 1. select: games off a cursor ---- */
 		static_assert(offsetof(SH, act) % 8 == 0 && offsetof(SH, frames) == offsetof(SH, act) + sizeof(sh.act) && offsetof(SH, ptype) == offsetof(SH, frames) + sizeof(sh.frames)
 				&& offsetof(SH, threat) == offsetof(SH, ptype) + sizeof(sh.ptype) && offsetof(SH, items) == offsetof(SH, threat) + sizeof(sh.threat),
-				"select-stage keys: 64-bit words over act + frames + ptype + threat + items (contiguous)");
-		static_assert(sizeof(sh.act) + sizeof(sh.frames) + sizeof(sh.ptype) + sizeof(sh.threat) + sizeof(sh.items) >= SH::SELECT_KEY_BYTES && sizeof(sh.lines) >= BWORDS * sizeof(u64),
+				"select-stage keys: 64-bit words over act + frames + ptype + threat + items (contiguous) and on over the per-solve scratch up to board");
+		static_assert(offsetof(SH, board) - offsetof(SH, act) >= SH::SELECT_KEY_BYTES && offsetof(SH, board) > offsetof(SH, items) && sizeof(sh.lines) >= BWORDS * sizeof(u64),
 				"select-stage LDS must fit");
 		u64 *sel_keys = reinterpret_cast<u64*>(&sh.act[0]);
 		bool keys_loaded = false;
