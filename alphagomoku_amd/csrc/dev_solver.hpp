@@ -870,18 +870,18 @@ namespace agx
 		}
 
 		/* getOpenThreePromotionMoves (DefensiveMoveTable.cpp:329-377): first matching shape wins */
-		__constant__ const uint32_t PROMO_PATTERNS[16] = { 320u, 4352u, 20480u, 80u, 16640u, 69632u, 272u, 4160u, 81920u, 320u, 4352u, 20480u, 0u, 0u, 0u, 0u };
-		__constant__ const uint32_t PROMO_MASKS[16] = { 65520u, 262080u, 1048320u, 16380u, 262080u, 1048320u, 16380u, 65520u, 1048320u, 16380u, 65520u, 262080u, 0u, 0u, 0u, 0u };
-		__constant__ const uint32_t PROMO_RESULTS[12] = { 196u, 392u, 784u, 82u, 328u, 656u, 74u, 148u, 592u, 70u, 140u, 280u };
 		__device__ __forceinline__ uint32_t promotion_moves(uint32_t pattern)
-		{
-			// one shape per lane, the first match in table order (all lanes hold the same pattern)
-			const int l = static_cast<int>(threadIdx.x);
-			const bool hit = (l < 12) && ((pattern & PROMO_MASKS[l & 15]) == PROMO_PATTERNS[l & 15]);
-			const u64 m = __ballot(hit);
-			if (m == 0ull)
-				return 0;
-			return PROMO_RESULTS[__builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(m)) - 1)];
+		{ // The pattern is wave-uniform: twelve compare-and-select steps on the scalar unit with the shapes as immediates.  (As one shape per lane the
+		  // three tables were loads from memory — two vector round trips and a scalar one per direction of every 3x3-fork test, nothing to hide them.)
+			constexpr uint32_t PATTERNS[12] = { 320u, 4352u, 20480u, 80u, 16640u, 69632u, 272u, 4160u, 81920u, 320u, 4352u, 20480u };
+			constexpr uint32_t MASKS[12] = { 65520u, 262080u, 1048320u, 16380u, 262080u, 1048320u, 16380u, 65520u, 1048320u, 16380u, 65520u, 262080u };
+			constexpr uint32_t RESULTS[12] = { 196u, 392u, 784u, 82u, 328u, 656u, 74u, 148u, 592u, 70u, 140u, 280u };
+			const uint32_t p = __builtin_amdgcn_readfirstlane(pattern);
+			uint32_t result = 0u;
+#pragma unroll
+			for (int k = 11; k >= 0; k--) // (the last assignment is the first match in table order)
+				result = ((p & MASKS[k]) == PATTERNS[k]) ? RESULTS[k] : result;
+			return result;
 		}
 		/* RawPatternCalculator::isStraightFourAt on the line bit-boards: the 11-cell window around (r, c) in direction d (2 bits per cell, off-board 3),
 		 * a cross stone assumed at the centre and, optionally, at window position `extra` (a stone that is on the reference's raw board but not in
@@ -919,8 +919,8 @@ namespace agx
 				if (t != 3)
 					return false;
 			}
-			int sp = 0, cell = cell0, dir = 0, count = 0, i = -5, phase = 1; // phase 1: next direction, 2: next promotion move, 3: a child returned `ret`
-			uint32_t promo = 0;
+			int sp = 0, cell = cell0, dir = 0, count = 0, phase = 1; // phase 1: next direction, 2: next promotion move, 3: a child returned `ret`
+			uint32_t candidates = 0; // promotion moves of (cell, dir) still to try: bit k = the empty cell k - 5 steps along the direction that would make a straight four
 			bool ret = false;
 			while (true)
 			{
@@ -938,35 +938,36 @@ namespace agx
 						sp--;
 						cell = sh.fstack[sp][0];
 						dir = sh.fstack[sp][1];
-						i = sh.fstack[sp][2];
+						candidates = static_cast<uint32_t>(sh.fstack[sp][2]);
 						count = sh.fstack[sp][3];
-						promo = static_cast<uint32_t>(sh.fstack[sp][4]);
 						phase = 3;
 						continue;
 					}
-					promo = promotion_moves(normal_pattern(sh, n, r, c, dir));
-					i = -5;
+					const uint32_t promo = promotion_moves(normal_pattern(sh, n, r, c, dir));
+					{ // All promotion moves of the direction are looked at at once, one per lane (board cell, straight-four window: two LDS round trips for
+					  // the direction instead of two per move); the stones that come and go between two of them leave board and lines as they were.
+						const int k = fresh_lane(lane);
+						bool makes_four = false;
+						if (k < 11 && ((promo >> k) & 1u) != 0u)
+						{
+							const int rr = r + (k - 5) * row_step(dir), cc = c + (k - 5) * col_step(dir);
+							makes_four = sh.board[rr * n + cc] == 0 && straight_four_with(sh, n, rr, cc, dir, 10 - k);
+						}
+						candidates = static_cast<uint32_t>(__ballot(makes_four));
+					}
 					phase = 2;
 				}
 				if (phase == 2)
 				{
-					int found = -1;
-					for (; i <= 5; i++)
-						if ((promo >> (5 + i)) & 1)
-						{
-							const int rr = r + i * row_step(dir), cc = c + i * col_step(dir);
-							if (sh.board[rr * n + cc] == 0 && straight_four_with(sh, n, rr, cc, dir, 5 - i))
-							{
-								found = rr * n + cc;
-								break;
-							}
-						}
-					if (found < 0)
+					if (candidates == 0u)
 					{
 						dir++;
 						phase = 1;
 						continue;
 					}
+					const int i = __ffs(static_cast<int>(candidates)) - 1 - 5;
+					candidates &= candidates - 1u;
+					const int found = (r + i * row_step(dir)) * n + (c + i * col_step(dir));
 					if (sp + 1 >= 16)
 					{
 						sh.error = ERR_FRAMES;
@@ -983,9 +984,8 @@ namespace agx
 					}
 					sh.fstack[sp][0] = cell;
 					sh.fstack[sp][1] = dir;
-					sh.fstack[sp][2] = i;
+					sh.fstack[sp][2] = static_cast<int>(candidates);
 					sh.fstack[sp][3] = count;
-					sh.fstack[sp][4] = static_cast<int>(promo);
 					wave_sync();
 					sp++;
 					cell = found;
@@ -1003,10 +1003,7 @@ namespace agx
 					phase = 1;
 				}
 				else
-				{
-					i++;
-					phase = 2;
-				}
+					phase = 2; // the next promotion move of the same direction
 			}
 		}
 		/* NNInputFeatures::encode (NNInputFeatures.cpp:15-32,59-113) */
@@ -1060,9 +1057,6 @@ namespace agx
 		/* ---------------- defensive-move lookup (DefensiveMoveTable.cpp:380-461) ---------------- */
 		__constant__ const uint32_t STENCIL_BOX[7] = { 73u, 62u, 62u, 119u, 62u, 62u, 73u };   // MoveGenerator.cpp:1014-1023
 		__constant__ const uint32_t STENCIL_STAR[7] = { 73u, 42u, 28u, 119u, 28u, 42u, 73u };  // MoveGenerator.cpp:1075-1084
-		__constant__ const int EVAL_OWN[10] = { 0, 0, 19, 49, 76, 170, 33, 159, 252, 0 };      // AlphaBetaSearch.cpp:356-357
-		__constant__ const int EVAL_OPP[10] = { 0, 0, -1, -50, -45, -135, -14, -154, -496, 0 };
-
 		/* The 47 line shapes of getDefensiveMoves (DefensiveMoveTable.cpp:380-461), one per LANE: the shape as cross stones, where it starts in the
 		 * 13-cell window and how long it is, its row in the defence table, the threat it answers (pattern type of the attacker's line: 6 FIVE,
 		 * 4 OPEN_4, 5 DOUBLE_4, 3 HALF_OPEN_4, 2 OPEN_3) and the window position its table entry is stored for.  Lanes 47-63 answer nothing. */
@@ -1241,9 +1235,12 @@ for (int k = 0; k < 5; k++)
 					if (!fouls_possible_for(sign))
 						return false;
 					const int cached = sh.foul_count;
-					for (int k = 0; k < cached; k++)
-						if (sh.foul_cell[k] == cell)
-							return sh.foul_flag[k] != 0;
+					{ // the cache, one entry per lane (its first match, as the scan in list order would find it): one LDS round trip, not one per entry
+						const int k = fresh_lane(lane);
+						const u64 hits = __ballot(k < cached && sh.foul_cell[k] == cell);
+						if (hits != 0ull)
+							return sh.foul_flag[__ffsll(static_cast<long long>(hits)) - 1] != 0;
+					}
 					#ifdef AGX_SOLVER_PROFILE
 					const unsigned long long foul_t0 = clock64();
 					#endif
@@ -2158,7 +2155,14 @@ for (int k = 0; k < 5; k++)
 			if (lane < 20)
 			{
 				const int side = (lane >= 10) ? 1 : 0, t = lane - 10 * side;
-				const int weight = (side == own) ? EVAL_OWN[t] : EVAL_OPP[t];
+				// AlphaBetaSearch.cpp:356-357: own { 0, 0, 19, 49, 76, 170, 33, 159, 252, 0 }, opponent { 0, 0, -1, -50, -45, -135, -14, -154, -496, 0 } — types 2 .. 8
+				// as 8-bit fields / negated as 9-bit fields of one 64-bit constant each (no loads from memory in front of the wave sum)
+				constexpr u64 OWN_WEIGHTS = 19ull | (49ull << 8) | (76ull << 16) | (170ull << 24) | (33ull << 32) | (159ull << 40) | (252ull << 48);
+				constexpr u64 OPP_WEIGHTS = 1ull | (50ull << 9) | (45ull << 18) | (135ull << 27) | (14ull << 36) | (154ull << 45) | (496ull << 54);
+				const bool mine = (side == own), weighs = (t >= 2 && t <= 8);
+				const int field = weighs ? t - 2 : 0;
+				const int magnitude = static_cast<int>(((mine ? OWN_WEIGHTS : OPP_WEIGHTS) >> ((mine ? 8 : 9) * field)) & (mine ? 255ull : 511ull));
+				const int weight = weighs ? (mine ? magnitude : -magnitude) : 0;
 				product = weight * static_cast<int>(sh.count[side][t]);
 			}
 			const int result = 12 + static_cast<int>(wave_reduce_add(static_cast<uint32_t>(product)));
