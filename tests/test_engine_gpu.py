@@ -364,10 +364,10 @@ def test_whole_games_bit_exact_with_stand_in_evaluator(agx_lib, olib, rules, bat
     assert stats["games_finished"] == 6 and stats["information_leaks"] > 0 and stats["proven_edge_visits"] > 0
 
 
-@pytest.mark.parametrize("rules,n,per_cu", [(0, 15, 16), (2, 15, 16), (3, 20, 10), (0, 12, 10)])
+@pytest.mark.parametrize("rules,n,per_cu", [(0, 15, 16), (2, 15, 16), (3, 20, 12), (0, 12, 12)])
 def test_default_search_waves_are_what_stays_resident(agx_lib, rules, n, per_cu):
     """AgxEngineConfig.speculative_waves = 0: the search launch gets as many one-wave workgroups as its kernel instantiation keeps resident — sixteen per
-    compute unit on 15x15 boards (10 240 B of LDS state, 128 registers), ten for the 20x20 and the any-size kernels (16 064 B) — and
+    compute unit on 15x15 boards (10 240 B of LDS state, 128 registers), twelve for the 20x20 and the any-size kernels (13 312 B, 168 registers) — and
     agx_engine_speculative_waves reports the number; an explicit count is taken as given, the serial solver reports 0."""
     from alphagomoku_amd import selfplay, lib, check
     cus = ctypes.c_int()
