@@ -78,7 +78,7 @@ def main():
                 env["AGX_LIB_PATH"] = os.path.join(ROOT, "alphagomoku_amd", "libagx_%s.so" % v)
             try:
                 res = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", "--configs", a.configs, "--width", str(a.width), "--launches", str(a.launches)],
-                                     env=env, capture_output=True, text=True, timeout=600)
+                                     env=env, capture_output=True, text=True, timeout=int(os.environ.get("NN_AB_CHILD_TIMEOUT", "600")))
             except subprocess.TimeoutExpired:
                 print("%s round %d: TIMEOUT" % (v, r), flush=True)
                 continue
