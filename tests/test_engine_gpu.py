@@ -86,8 +86,14 @@ def test_pattern_state_after_move_sequences(agx_lib, olib, rules):
         boards.append(b)
         signs.append(sign)
         moves.append(seq)
+    _compare_pattern_state_with_the_oracle(pool, olib, rules, boards, signs, moves)
+    pool.close()
+
+
+def _compare_pattern_state_with_the_oracle(pool, olib, rules, boards, signs, moves):
     pt, th, lists = pool.debug_pattern_state(np.array(boards), signs, np.array(moves, np.uint16))
-    for g in range(G):
+    sizes = []
+    for g in range(len(boards)):
         opt = np.zeros((HW, 8), np.uint8)
         oth = np.zeros((HW, 2), np.uint8)
         olists = np.zeros(4096, np.int16)
@@ -102,6 +108,56 @@ def test_pattern_state_after_move_sequences(agx_lib, olib, rules):
                 assert sorted(dl[key]) == sorted(rl[key]), (g, key)
             else:            # every list the move generator / evaluation reads: same cells in the same ORDER
                 assert dl[key] == rl[key], (g, key)
+                sizes.append(len(rl[key]))
+    return sizes
+
+
+def _random_move_sequence(rng, board, sign, length):
+    seq, cur, s, done = [], board.copy(), sign, []
+    for _ in range(length):
+        if done and rng.random() < 0.35:
+            seq.append(0)
+            m = done.pop()
+            cur[(m >> 2 & 127) * N + (m >> 9 & 127)] = 0
+        else:
+            cell = int(rng.choice(np.flatnonzero(cur == 0)))
+            m = s | ((cell // N) << 2) | ((cell % N) << 9)
+            seq.append(m)
+            done.append(m)
+            cur[cell] = s
+        s = 3 - s
+    return seq
+
+
+@pytest.mark.parametrize("rules", [0, 2])
+def test_pattern_state_with_lists_beyond_their_lds_capacity(agx_lib, olib, rules):
+    """Threat lists keep 24 entries (OPEN_3: 64) in LDS and the tail in HBM; the ordered list edits of a place / undo take their lean loop only
+    while no list can outgrow its LDS part in the call (solver_update_around).  Boards of many parallel threes / twos hold lists of 30-56 cells:
+    stones going on and coming off around them cross that boundary in both directions, and every list must still equal the oracle's in ORDER."""
+    from alphagomoku_amd import selfplay
+    rng = np.random.default_rng(70 + rules)
+    pool = selfplay.GeneratorPool(selfplay.default_config(rules=rules, n_games=32, max_batch_size=2, tss_table_entries=1 << 12, node_capacity=256, edge_capacity=4096))
+    boards, signs, moves = [], [], []
+    for g in range(32):
+        b = np.zeros(HW, np.uint8)
+        side = 1 + g % 2
+        if (g >> 1) % 2 == 0:   # two threes in every other row: OPEN_4 / HALF_OPEN_4 / 4x4-fork cells by the dozen
+            for r in range(0, N, 2):
+                for c0 in (2, 9):
+                    b[r * N + c0:r * N + c0 + 3] = side
+        else:                   # three twos in every other row: ~56 OPEN_3 cells
+            for r in range(0, N, 2):
+                for c0 in (1, 6, 11):
+                    b[r * N + c0:r * N + c0 + 2] = side
+        empties = np.flatnonzero(b == 0)
+        for cell in rng.choice(empties, size=int(rng.integers(0, 6)), replace=False):   # a few stones of the other side in between
+            b[cell] = 3 - side
+        sign = 1 if int((b != 0).sum()) % 2 == 0 else 2
+        boards.append(b)
+        signs.append(sign)
+        moves.append(_random_move_sequence(rng, b, sign, 14))
+    sizes = _compare_pattern_state_with_the_oracle(pool, olib, rules, boards, signs, moves)
+    assert max(sizes) > 40 and sum(1 for x in sizes if x > 24) >= 32, (max(sizes), sum(1 for x in sizes if x > 24))
     pool.close()
 
 
