@@ -14,7 +14,7 @@
  *   k_advance  GameGenerator::make_move + prepare_search (:145-185): final selector, sample record, outcome test (incl. renju
  *              fouls), NodeCache::cleanup as a keep-test + prefix-sum compaction into the game's other arena
  *   k_assign_openings / k_restart   finished games take the next openings in game order (GAME_NOT_STARTED -> next game)
- *   k_arena_service / _copy / _commit   trees that outgrew their arenas move into larger ones (NodeCache::resize, ObjectPool growth)
+ *   k_arena_service / _copy   trees that outgrew their arenas move into larger ones (NodeCache::resize, ObjectPool growth)
  *
  * Everything stays in HBM between steps; the host only enqueues launches.  One wavefront per game for the sequential
  * tree work (games are independent, the batch inside a game is order-dependent through virtual loss); k_advance uses a
@@ -1492,16 +1492,25 @@ namespace
 					__syncthreads();
 					n_e = kept;
 				}
-				// renormalize_policy (:23-40): the sum runs in edge order in fp32, exactly like the reference
-				if (lane == 0)
+				// renormalize_policy (:23-40): the sum runs in edge order in fp32, exactly like the reference.  (As a loop of one lane over LDS every
+				// addend was a full LDS round trip; now 64 priors travel into registers at once and the additions take them lane by lane: the same
+				// additions in the same order, one v_readlane apiece, on every lane alike.)
+				float sum = 0.0f;
+				for (int base = 0; base < n_e; base += 64)
 				{
-					float sum = 0.0f;
-					for (int i = 0; i < n_e; i++)
-						sum += e_prior[i];
-					sh_sum = sum;
+					const int mine_i = __float_as_int((base + lane < n_e) ? e_prior[base + lane] : 0.0f);
+					const int m = min(64, n_e - base);
+					int j = 0;
+					for (; j + 4 <= m; j += 4)
+					{
+						sum += __int_as_float(__builtin_amdgcn_readlane(mine_i, j));
+						sum += __int_as_float(__builtin_amdgcn_readlane(mine_i, j + 1));
+						sum += __int_as_float(__builtin_amdgcn_readlane(mine_i, j + 2));
+						sum += __int_as_float(__builtin_amdgcn_readlane(mine_i, j + 3));
+					}
+					for (; j < m; j++)
+						sum += __int_as_float(__builtin_amdgcn_readlane(mine_i, j));
 				}
-				__syncthreads();
-				const float sum = sh_sum;
 				if (sum == 0.0f)
 				{
 					const float u = 1.0f / n_e;
@@ -2478,8 +2487,8 @@ namespace
 	 * played, NOT of which slot finished first, so a pool plays the same games however it is sliced into groups and however their launches
 	 * interleave on their streams.  A slot whose next opening is not in the list yet waits (agx_engine_add_openings).  counters[1] keeps the
 	 * high-water mark (openings_taken). */
-	__global__ __launch_bounds__(1024) void k_assign_openings(EngineDev E, int count)
-	{
+	__device__ __forceinline__ void assign_openings(const EngineDev &E, int count)
+	{ // (1024 threads of one workgroup)
 		const int slots = E.shared_tree ? 1 : (E.match_mode ? E.n_games / 2 : E.n_games);
 		for (int i = threadIdx.x; i < count; i += 1024)
 		{
@@ -2496,14 +2505,39 @@ namespace
 			}
 		}
 	}
+	__global__ __launch_bounds__(1024) void k_assign_openings(EngineDev E, int count)
+	{
+		assign_openings(E, count);
+	}
+	/* the workgroup that finishes a game's LAST part (of k_arena_copy, k_clear_tables) does what used to be the launch behind it: every part
+	 * makes its writes visible (agent-scope fence), takes a ticket, and the holder of the last ticket knows that all the others are through */
+	__device__ __forceinline__ bool last_part_of(int *counter, int parts)
+	{
+		__shared__ int sh_last;
+		__threadfence();
+		__syncthreads();
+		if (threadIdx.x == 0)
+		{
+			const int ticket = __hip_atomic_fetch_add(counter, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+			sh_last = (ticket == parts - 1) ? 1 : 0;
+			if (sh_last)
+				__hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (ready for the game's next time)
+		}
+		__syncthreads();
+		const bool last = sh_last != 0;
+		if (last)
+			__threadfence();
+		return last;
+	}
 	/*
 	 * Tree::clear + AlphaBetaSearch::clear for the games about to restart, spread over `parts` workgroups per game: a 4 Mi-entry
 	 * solver table is 64 MB, which one workgroup takes a millisecond to fill — longer than every other kernel of the step but two.
 	 * Match mode: both trees of a pair whose first player's tree carries the restart request; the node tables stay (Player keeps
 	 * its tree).
 	 */
-	__global__ __launch_bounds__(256) void k_clear_tables(EngineDev E, int parts)
-	{
+	__global__ __launch_bounds__(256) void k_clear_tables(EngineDev E, int parts, int restart)
+	{ // restart != 0 (self-play pools with a tree per game): the workgroup that finishes a game's last part starts its next game (k_restart's work)
+		__shared__ u64 scratch[4];
 		const int g = E.g0 + blockIdx.x / parts, part = blockIdx.x % parts, tid = threadIdx.x;
 		const int asks = E.shared_tree ? 0 : (E.match_mode ? g % (E.n_games / 2) : g);
 		if (E.games[asks].restart_id <= 0)
@@ -2523,6 +2557,8 @@ namespace
 			for (int i = part * 256 + tid; i < E.games[g].ht_cap; i += parts * 256)
 				ht[i] = 0;
 		}
+		if (restart != 0 && last_part_of(E.parts_done + E.n_games + g, parts))
+			begin_game(E, g, E.games[g].restart_id - 1, tid, scratch, true); // (every table of the game is empty and visible: last_part_of)
 	}
 	__global__ __launch_bounds__(256) void k_restart(EngineDev E)
 	{
@@ -2681,8 +2717,8 @@ namespace
 		}
 		heap_unlock(h);
 	}
-	__global__ __launch_bounds__(1024) void k_arena_service(EngineDev E, int count)
-	{
+	__global__ __launch_bounds__(1024) void k_arena_service(EngineDev E, int count, int assign_count)
+	{ // assign_count > 0: the finished games of the first assign_count take their next openings here as well (k_assign_openings' work, one launch less per cycle)
 		__shared__ int sh_list[1024];
 		__shared__ int sh_n;
 		const int tid = threadIdx.x;
@@ -2754,14 +2790,18 @@ namespace
 			}
 			__syncthreads();
 		}
+		if (assign_count > 0)
+			assign_openings(E, assign_count); // (behind the releases: a finished game gives its grown bundle back before it is handed its next opening)
 	}
 	/* moves a game's tree into the bundle k_arena_service reserved for it: nodes and edges of the active arena copied as they are (indices
 	 * stay valid), the node-cache table rebuilt at its new size.  `parts` workgroups per game: the edges (a few MB for a large tree) are
-	 * split among parts 1.., part 0 moves the nodes and rebuilds the table; k_arena_commit then switches the game over. */
+	 * split among parts 1.., part 0 moves the nodes and rebuilds the table; the workgroup that finishes the game's last part switches the game over (arena_commit). */
+	/* the old bundle goes onto the free list, the game continues in the new one (ONE acting thread: the heap lock must never be contended by lanes of one wave) */
+	__device__ void arena_commit(const EngineDev &E, GameState &gs);
 	__global__ __launch_bounds__(256) void k_arena_copy(EngineDev E, int parts)
 	{
 		const int g = E.g0 + blockIdx.x / parts, part = blockIdx.x % parts, tid = threadIdx.x;
-		const GameState &gs = E.games[g];
+		GameState &gs = E.games[g];
 		if (gs.grow_pending != 3)
 			return;
 		if (part != 0)
@@ -2773,33 +2813,33 @@ namespace
 				dst_edges[i] = src_edges[i];
 			if ((halves & 1) != 0 && part == 1 && tid == 0)
 				reinterpret_cast<u64*>(dst_edges)[halves - 1] = reinterpret_cast<const u64*>(src_edges)[halves - 1];
-			return;
 		}
-		const int new_ht_cap = E.ht_cap << (gs.arena_class + 1);
-		const DNode *src_nodes = nodes_of(E, g, gs.arena);
-		DNode *dst_nodes = E.nodes + gs.new_node_off[gs.arena];
-		int *ht = E.ht + gs.new_ht_off;
-		for (int i = tid; i < new_ht_cap; i += 256)
-			ht[i] = 0;
-		__syncthreads();
-		const int mask = new_ht_cap - 1;
-		for (int i = tid; i < gs.n_nodes; i += 256)
+		else
 		{
-			const DNode nd = src_nodes[i];
-			dst_nodes[i] = nd;
-			int slot = static_cast<int>(nd.hash & static_cast<u64>(mask));
-			while (atomicCAS(&ht[slot], 0, i + 1) != 0)
-				slot = (slot + 1) & mask;
+			const int new_ht_cap = E.ht_cap << (gs.arena_class + 1);
+			const DNode *src_nodes = nodes_of(E, g, gs.arena);
+			DNode *dst_nodes = E.nodes + gs.new_node_off[gs.arena];
+			int *ht = E.ht + gs.new_ht_off;
+			for (int i = tid; i < new_ht_cap; i += 256)
+				ht[i] = 0;
+			__syncthreads();
+			const int mask = new_ht_cap - 1;
+			for (int i = tid; i < gs.n_nodes; i += 256)
+			{
+				const DNode nd = src_nodes[i];
+				dst_nodes[i] = nd;
+				int slot = static_cast<int>(nd.hash & static_cast<u64>(mask));
+				while (atomicCAS(&ht[slot], 0, i + 1) != 0)
+					slot = (slot + 1) & mask;
+			}
 		}
+		// (once a launch of its own, k_arena_commit: the game is switched over by whichever workgroup finishes its last part — the others only READ the game's state,
+		//  and none of them is still running when it changes)
+		if (last_part_of(E.parts_done + g, parts) && tid == 0)
+			arena_commit(E, gs);
 	}
-	/* the old bundle goes onto the free list, the game continues in the new one */
-	__global__ __launch_bounds__(64) void k_arena_commit(EngineDev E)
-	{ // one workgroup per game and ONE acting thread in it: the heap lock must never be contended by lanes of one wave
-		if (threadIdx.x != 0)
-			return;
-		GameState &gs = E.games[E.g0 + blockIdx.x];
-		if (gs.grow_pending != 3)
-			return;
+	__device__ void arena_commit(const EngineDev &E, GameState &gs)
+	{
 		const int cls = gs.arena_class + 1;
 		arena_free(E, gs.arena_class, gs);
 		gs.node_off[0] = gs.new_node_off[0];
@@ -3365,6 +3405,9 @@ static int engine_create(const AgxEngineConfig *cfg, AgxEngine **out, int sizing
 			d.park_fraction = std::min(1.0f, static_cast<float>(std::atof(pf))); // (a fraction of the launch's games: (0, 1])
 	AGX_TRY(dev_alloc(e, &d.park_slot, G * d.batch));
 	AGX_TRY(dev_alloc(e, &d.park_owner, SPEC_PARK_POOL));
+	AGX_TRY(dev_alloc(e, &d.parts_done, 2 * G));
+	if (!e->sizing_only)
+		(void) hipMemset(d.parts_done, 0, 2 * G * sizeof(int));
 	AGX_TRY(dev_alloc(e, &d.park_lds, parking ? static_cast<size_t>(SPEC_PARK_POOL) * SPEC_PARK_WORDS : 1));
 	if (!e->sizing_only)
 		(void) hipMemset(d.park_slot, 0, G * d.batch * sizeof(int));
@@ -3803,11 +3846,10 @@ int agx_engine_expand_backup_match(AgxEngine *e, void *stream)
 		KernelTimer t(e, s, 3);
 		// a moving tree's workgroup also rebases its partner's tree; the partner's own workgroup has nothing to do (it is not searching)
 		hipLaunchKernelGGL(k_advance, dim3(d.n_games), dim3(ADV_THREADS), 0, s, d);
-		hipLaunchKernelGGL(k_arena_service, dim3(1), dim3(1024), 0, s, d, d.n_games);
-		hipLaunchKernelGGL(k_arena_copy, dim3(d.n_games * CLEAR_PARTS), dim3(256), 0, s, d, CLEAR_PARTS);
-		hipLaunchKernelGGL(k_arena_commit, dim3(d.n_games), dim3(64), 0, s, d);
+		hipLaunchKernelGGL(k_arena_service, dim3(1), dim3(1024), 0, s, d, d.n_games, 0);
+		hipLaunchKernelGGL(k_arena_copy, dim3(d.n_games * CLEAR_PARTS), dim3(256), 0, s, d, CLEAR_PARTS); // (its last part per game commits)
 		hipLaunchKernelGGL(k_assign_openings, dim3(1), dim3(1024), 0, s, d, d.n_games / 2);
-		hipLaunchKernelGGL(k_clear_tables, dim3(d.n_games * CLEAR_PARTS), dim3(256), 0, s, d, CLEAR_PARTS);
+		hipLaunchKernelGGL(k_clear_tables, dim3(d.n_games * CLEAR_PARTS), dim3(256), 0, s, d, CLEAR_PARTS, 0);
 		hipLaunchKernelGGL(k_match_restart, dim3(d.n_games / 2), dim3(256), 0, s, d);
 	}
 	AGX_HIP_CHECK(hipGetLastError());
@@ -3873,9 +3915,8 @@ static int expand_stage(AgxEngine *e, int group, int n_groups, void *stream, boo
 		const int trees = d.shared_tree ? 1 : count;
 		if (d.shared_tree)
 			d.g0 = 0;
-		hipLaunchKernelGGL(k_arena_service, dim3(1), dim3(1024), 0, s, d, trees);
-		hipLaunchKernelGGL(k_arena_copy, dim3(trees * CLEAR_PARTS), dim3(256), 0, s, d, CLEAR_PARTS);
-		hipLaunchKernelGGL(k_arena_commit, dim3(trees), dim3(64), 0, s, d);
+		hipLaunchKernelGGL(k_arena_service, dim3(1), dim3(1024), 0, s, d, trees, 0);
+		hipLaunchKernelGGL(k_arena_copy, dim3(trees * CLEAR_PARTS), dim3(256), 0, s, d, CLEAR_PARTS); // (its last part per game commits)
 	}
 	AGX_HIP_CHECK(hipGetLastError());
 	return AGX_OK;
@@ -3906,13 +3947,13 @@ int agx_engine_advance_group(AgxEngine *e, int group, int n_groups, void *stream
 			count = d.n_games;
 		}
 		hipLaunchKernelGGL(k_advance, dim3(trees), dim3(ADV_THREADS), 0, s, d);
-		hipLaunchKernelGGL(k_arena_service, dim3(1), dim3(1024), 0, s, d, trees);
+		// four launches behind k_advance instead of seven (round 6): the openings are assigned by the service workgroup, a game's last copy part
+		// commits its larger arenas, a game's last clear part restarts it
+		hipLaunchKernelGGL(k_arena_service, dim3(1), dim3(1024), 0, s, d, trees, d.match_mode ? 0 : trees);
 		hipLaunchKernelGGL(k_arena_copy, dim3(trees * CLEAR_PARTS), dim3(256), 0, s, d, CLEAR_PARTS);
-		hipLaunchKernelGGL(k_arena_commit, dim3(trees), dim3(64), 0, s, d);
 		if (!d.match_mode)
 		{
-			hipLaunchKernelGGL(k_assign_openings, dim3(1), dim3(1024), 0, s, d, trees);
-			hipLaunchKernelGGL(k_clear_tables, dim3(count * CLEAR_PARTS), dim3(256), 0, s, d, CLEAR_PARTS);
+			hipLaunchKernelGGL(k_clear_tables, dim3(count * CLEAR_PARTS), dim3(256), 0, s, d, CLEAR_PARTS, d.shared_tree ? 0 : 1);
 			if (d.shared_tree)
 			{ // the search threads restart on thread 0's opening: they first (they read its request), thread 0 last (it clears the request)
 				EngineDev others = d;
@@ -3921,8 +3962,7 @@ int agx_engine_advance_group(AgxEngine *e, int group, int n_groups, void *stream
 					hipLaunchKernelGGL(k_restart, dim3(count - 1), dim3(256), 0, s, others);
 				hipLaunchKernelGGL(k_restart, dim3(1), dim3(256), 0, s, d);
 			}
-			else
-				hipLaunchKernelGGL(k_restart, dim3(count), dim3(256), 0, s, d);
+
 		}
 		else if (group == 0)
 		{ // restarts go by pair, requested through the first players' trees (= group 0)
@@ -3930,7 +3970,7 @@ int agx_engine_advance_group(AgxEngine *e, int group, int n_groups, void *stream
 			{
 				EngineDev all = d; // both players' trees
 				all.g0 = 0;
-				hipLaunchKernelGGL(k_clear_tables, dim3(all.n_games * CLEAR_PARTS), dim3(256), 0, s, all, CLEAR_PARTS);
+				hipLaunchKernelGGL(k_clear_tables, dim3(all.n_games * CLEAR_PARTS), dim3(256), 0, s, all, CLEAR_PARTS, 0);
 			}
 			hipLaunchKernelGGL(k_match_restart, dim3(count), dim3(256), 0, s, d);
 		}

@@ -282,6 +282,7 @@ namespace agx
 			// aside — its LDS state in park_lds, its HBM tails in a spill area of its own — and taken up again by the next launch
 			int *park_slot;        // [game * batch] park buffer + 1 of a task whose solve is parked, 0 = none
 			int *park_owner;       // [SPEC_PARK_POOL] task slot + 1 that holds the buffer, 0 = free
+			int *parts_done;       // [2][n_games] workgroups of k_arena_copy / k_clear_tables that have finished their part of a game (the last one commits / restarts it)
 			uint64_t *park_lds;    // [SPEC_PARK_POOL][SPEC_PARK_WORDS] the solver's LDS state, then 8 words of the solve's loop variables
 			int park_area0;        // spill area of park buffer 0 (behind the games' and the waves' areas)
 			float park_fraction;   // solves are parked once this fraction of the launch's games is done (0 = never)
